@@ -1,0 +1,301 @@
+"""ctypes front-end of oracle/liboracle.so (the CPU restatement of the reference path).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg.  The product package (videovector_amd/) must never import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+_PIN = os.path.join(_HERE, "pin", "stdlib_pin")
+
+
+def build(force=False):
+    """Compile liboracle.so and pin/stdlib_pin with the Makefile in this directory."""
+    if force or not (os.path.exists(_LIB) and os.path.exists(_PIN)) or \
+            os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "vv_oracle.c")):
+        subprocess.run(["make", "-C", _HERE, "-s", "all"], check=True)
+    return _LIB
+
+
+class _Rng(C.Structure):
+    _fields_ = [("r", C.c_int32 * 31), ("f", C.c_int), ("b", C.c_int)]
+
+
+class _Dataset(C.Structure):
+    _fields_ = [("n_videos", C.c_int32), ("video_id", C.c_void_p), ("n_shots", C.c_void_p),
+                ("row_base", C.c_void_p), ("shot_ids", C.c_void_p), ("shot_off", C.c_void_p)]
+
+
+class _SamplerParam(C.Structure):
+    _fields_ = [("batch_size", C.c_int32), ("context_size", C.c_int32),
+                ("num_negative_samples", C.c_int32), ("max_buffer_size", C.c_int32),
+                ("negative_swap_percentage", C.c_int32), ("max_same_video_negs", C.c_int32),
+                ("max_tries_for_negs", C.c_int32)]
+
+
+class _StepCfg(C.Structure):
+    _fields_ = [("B", C.c_int32), ("C", C.c_int32), ("Nn", C.c_int32), ("F", C.c_int32),
+                ("D", C.c_int32), ("margin", C.c_float), ("norm", C.c_int32),
+                ("loss_weight", C.c_float), ("ctx_coeff", C.c_void_p),
+                ("dropout_ratio", C.c_float), ("dropout_mask", C.c_void_p),
+                ("relu_negative_slope", C.c_float), ("ip_regularization", C.c_float),
+                ("global_count", C.c_int64)]
+
+
+class _StepOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("Y", "H", "ctx", "posneg", "s_true", "s_bogus", "dY", "dW", "db")] + \
+               [("loss", C.c_float), ("violations", C.c_float)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB)
+        L.orc_rand.restype = C.c_int32
+        L.orc_sampler_create.restype = C.c_void_p
+        L.orc_sampler_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+        L.orc_sampler_destroy.argtypes = [C.c_void_p]
+        L.orc_sampler_next.argtypes = [C.c_void_p] * 4
+        L.orc_sampler_buffer_rows.restype = C.c_void_p
+        L.orc_sampler_buffer_rows.argtypes = [C.c_void_p]
+        L.orc_sampler_buffer_ids.restype = C.c_void_p
+        L.orc_sampler_buffer_ids.argtypes = [C.c_void_p]
+        L.orc_sampler_cursor.restype = C.c_int32
+        L.orc_sampler_cursor.argtypes = [C.c_void_p]
+        L.orc_sampler_rand_calls.restype = C.c_int64
+        L.orc_sampler_rand_calls.argtypes = [C.c_void_p]
+        L.orc_sgemm.argtypes = [C.c_int] * 5 + [C.c_float, C.c_void_p, C.c_void_p, C.c_float,
+                                                C.c_void_p]
+        L.orc_get_threads.restype = C.c_int
+        L.orc_learning_rate.restype = C.c_float
+        L.orc_learning_rate.argtypes = [C.c_char_p, C.c_float, C.c_float, C.c_float, C.c_int,
+                                        C.c_int]
+        L.orc_sgd_update.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                     C.c_float, C.c_float, C.c_float, C.c_float, C.c_int]
+        L.orc_normalize_fwd.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_normalize_bwd.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_max_margin_fwd.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                         C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_max_margin_bwd.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                         C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+        L.orc_sum_fwd.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_sum_bwd.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_forward_backward.argtypes = [C.c_void_p] * 7
+        L.orc_embed.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+# ------------------------------------------------------------------------------- RNG ---------
+class Rand:
+    """glibc rand() clone (seed 1 == never seeded)."""
+
+    def __init__(self, seed=1):
+        self.g = _Rng()
+        lib().orc_srand(C.byref(self.g), C.c_uint(seed))
+
+    def next(self):
+        return lib().orc_rand(C.byref(self.g))
+
+    def random_unique(self, a, n):
+        a = np.ascontiguousarray(a, dtype=np.int32)
+        lib().orc_random_unique(C.byref(self.g), _p(a), C.c_int(len(a)), C.c_int(n))
+        return a
+
+    def random_shuffle(self, a):
+        a = np.ascontiguousarray(a, dtype=np.int32)
+        lib().orc_random_shuffle(C.byref(self.g), _p(a), C.c_int(len(a)))
+        return a
+
+
+def stdlib_pin(*args):
+    """Run oracle/pin/stdlib_pin (real glibc / libstdc++) and return its stdout lines."""
+    build()
+    out = subprocess.run([_PIN] + [str(a) for a in args], check=True, capture_output=True,
+                         text=True).stdout
+    return out.strip().split("\n")
+
+
+# ------------------------------------------------------------------------------- sampler -----
+class Sampler:
+    """VideoSampledShotsDataLayer restated (WINDOW context)."""
+
+    def __init__(self, video_id, n_shots, row_base, *, batch_size, context_size,
+                 num_negative_samples, max_buffer_size, negative_swap_percentage,
+                 max_same_video_negs=0, max_tries_for_negs=100, shot_ids=None, seed=1):
+        self._vid = np.ascontiguousarray(video_id, dtype=np.int32)
+        self._ns = np.ascontiguousarray(n_shots, dtype=np.int32)
+        self._rb = np.ascontiguousarray(row_base, dtype=np.int64)
+        self._sid = None if shot_ids is None else np.ascontiguousarray(shot_ids, dtype=np.int32)
+        self._soff = None
+        if self._sid is not None:
+            self._soff = np.concatenate([[0], np.cumsum(self._ns[:-1])]).astype(np.int64)
+        self.ds = _Dataset(len(self._vid), _p(self._vid), _p(self._ns), _p(self._rb),
+                           _p(self._sid), _p(self._soff))
+        self.p = _SamplerParam(batch_size, context_size, num_negative_samples, max_buffer_size,
+                               negative_swap_percentage, max_same_video_negs, max_tries_for_negs)
+        self.h = lib().orc_sampler_create(C.byref(self.ds), C.byref(self.p), seed)
+        if not self.h:
+            raise ValueError("reference would CHECK-fail for these sampler parameters")
+        self.B, self.CN = batch_size, context_size + num_negative_samples
+        self.max_buffer = max_buffer_size if num_negative_samples > 0 else 0
+
+    def next(self):
+        idx = np.empty((self.B, self.CN), np.int32)
+        last = np.empty((self.B, self.CN), np.int32)
+        label = np.empty((self.B,), np.int32)
+        lib().orc_sampler_next(self.h, _p(idx), _p(last), _p(label))
+        return idx, last, label
+
+    def buffer_rows(self):
+        p = lib().orc_sampler_buffer_rows(self.h)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int32)), (self.max_buffer,)).copy()
+
+    def buffer_ids(self):
+        p = lib().orc_sampler_buffer_ids(self.h)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int32)), (self.max_buffer,)).copy()
+
+    def cursor(self):
+        return lib().orc_sampler_cursor(self.h)
+
+    def rand_calls(self):
+        return lib().orc_sampler_rand_calls(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_sampler_destroy(self.h)
+            self.h = None
+
+
+# ------------------------------------------------------------------------------- layers ------
+def sgemm(transA, transB, A, B, alpha=1.0, beta=0.0, Cmat=None):
+    A, B = _f32(A), _f32(B)
+    M = A.shape[1] if transA else A.shape[0]
+    K = A.shape[0] if transA else A.shape[1]
+    N = B.shape[0] if transB else B.shape[1]
+    out = np.zeros((M, N), np.float32) if Cmat is None else _f32(Cmat)
+    lib().orc_sgemm(int(transA), int(transB), M, N, K, alpha, _p(A), _p(B), beta, _p(out))
+    return out
+
+
+def set_threads(n):
+    lib().orc_set_threads(C.c_int(n))
+
+
+def get_threads():
+    return lib().orc_get_threads()
+
+
+def normalize_fwd(x):
+    x = _f32(x); n = x.shape[0]; y = np.empty_like(x)
+    lib().orc_normalize_fwd(n, x.size // n, _p(x), _p(y))
+    return y
+
+
+def normalize_bwd(x, dy):
+    x, dy = _f32(x), _f32(dy); n = x.shape[0]; dx = np.empty_like(x)
+    lib().orc_normalize_bwd(n, x.size // n, _p(x), _p(dy), _p(dx))
+    return dx
+
+
+def max_margin_fwd(s_true, s_bogus, margin, norm, weight=None):
+    s_true, s_bogus = _f32(s_true), _f32(s_bogus)
+    w = None if weight is None else _f32(weight)
+    loss, viol = C.c_float(), C.c_float()
+    lib().orc_max_margin_fwd(s_true.size, _p(s_true), _p(s_bogus), _p(w), margin, norm,
+                             C.byref(loss), C.byref(viol))
+    return loss.value, viol.value
+
+
+def max_margin_bwd(s_true, s_bogus, margin, norm, loss_weight=1.0, weight=None):
+    s_true, s_bogus = _f32(s_true), _f32(s_bogus)
+    w = None if weight is None else _f32(weight)
+    dt, db = np.empty_like(s_true), np.empty_like(s_bogus)
+    lib().orc_max_margin_bwd(s_true.size, _p(s_true), _p(s_bogus), _p(w), margin, norm,
+                             loss_weight, _p(dt), _p(db))
+    return dt, db
+
+
+def sum_fwd(x, num_output):
+    x = _f32(x); n = x.shape[0]; y = np.empty((n, num_output), np.float32)
+    lib().orc_sum_fwd(n, x.size // n, num_output, _p(x), _p(y))
+    return y
+
+
+def sum_bwd(dy, dim):
+    dy = _f32(dy); n, no = dy.shape; dx = np.empty((n, dim), np.float32)
+    lib().orc_sum_bwd(n, dim, no, _p(dy), _p(dx))
+    return dx
+
+
+def learning_rate(policy, base_lr, gamma, power, stepsize, it):
+    return lib().orc_learning_rate(policy.encode(), base_lr, gamma, power, stepsize, it)
+
+
+def sgd_update(w, grad, hist, rate, lr_mult, momentum, weight_decay, decay_mult, reg="L2"):
+    """In place on float32 contiguous arrays (as Blob::Update does)."""
+    for a in (w, grad, hist):
+        assert a.dtype == np.float32 and a.flags.c_contiguous
+    lib().orc_sgd_update(w.size, _p(w), _p(grad), _p(hist), rate, lr_mult, momentum, weight_decay,
+                         decay_mult, 2 if reg == "L2" else 1)
+
+
+def forward_backward(table, idx, W, b, *, C_, Nn, margin=2.0, norm=2, loss_weight=1.0,
+                     ctx_coeff=None, dropout_ratio=0.0, dropout_mask=None, last_src=None,
+                     global_count=0, ip_regularization=0.0, want=("dW", "db")):
+    """One Net::ForwardBackward.  Returns a dict with loss, violations and the requested arrays
+    (names of orc_step_out)."""
+    table, W = _f32(table), _f32(W)
+    b = None if b is None else _f32(b)
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    B, CN = idx.shape
+    assert CN == C_ + Nn
+    D, F = W.shape
+    assert table.shape[1] == F
+    coeff = _f32(np.full(C_ - 1, 1.0 / (C_ - 1)) if ctx_coeff is None else ctx_coeff)
+    mask = None if dropout_mask is None else np.ascontiguousarray(dropout_mask, dtype=np.uint8)
+    last = None if last_src is None else np.ascontiguousarray(last_src, dtype=np.int32)
+    cfg = _StepCfg(B, C_, Nn, F, D, margin, norm, loss_weight, _p(coeff), dropout_ratio, _p(mask),
+                   0.0, ip_regularization, global_count)
+    R, Q = CN * B, 1 + Nn
+    shapes = dict(Y=(R, D), H=(R, D), ctx=(B, D), posneg=(Q * B, D), s_true=(B, Nn),
+                  s_bogus=(B, Nn), dY=(R, D), dW=(D, F), db=(D,))
+    arrs = {k: np.zeros(shapes[k], np.float32) for k in want}
+    out = _StepOut()
+    for k, a in arrs.items():
+        setattr(out, k, a.ctypes.data)
+    lib().orc_forward_backward(C.byref(cfg), _p(table), _p(idx), _p(last), _p(W), _p(b),
+                               C.byref(out))
+    res = dict(arrs)
+    res["loss"], res["violations"] = out.loss, out.violations
+    return res
+
+
+def embed(table, rows, W, b, relu=True, l2norm=False):
+    table, W = _f32(table), _f32(W)
+    b = None if b is None else _f32(b)
+    rows = None if rows is None else np.ascontiguousarray(rows, dtype=np.int32)
+    n = table.shape[0] if rows is None else len(rows)
+    D, F = W.shape
+    out = np.empty((n, D), np.float32)
+    lib().orc_embed(n, F, D, _p(table), _p(rows), _p(W), _p(b), int(relu), int(l2norm), _p(out))
+    return out

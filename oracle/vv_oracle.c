@@ -1,0 +1,631 @@
+/*
+ * vv_oracle.c -- CPU restatement of the reference's videovec_embedding training path.
+ * TEST INFRASTRUCTURE ONLY (see vv_oracle.h).  Plain C11 + OpenMP; every function cites the
+ * reference file:line (relative to /root/reference) it restates.  Written from the reference's
+ * behaviour; no reference source text is reproduced here.
+ */
+#include "vv_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ============================================================ glibc random() TYPE_3 ========= */
+/* glibc 2.35 stdlib/random_r.c: __srandom_r / __random_r with rand_type TYPE_3 (deg 31, sep 3),
+ * which is what rand() uses (stdlib/rand.c -> __random()).  Third-party dependency of the
+ * reference, pinned in tests against the real libc of this image. */
+void orc_srand(orc_rng* g, unsigned seed) {
+  int32_t word = (int32_t)(seed ? seed : 1u);
+  g->r[0] = word;
+  for (int i = 1; i < 31; ++i) {
+    long hi = word / 127773, lo = word % 127773;
+    word = (int32_t)(16807 * lo - 2836 * hi);
+    if (word < 0) word += 2147483647;
+    g->r[i] = word;
+  }
+  g->f = 3;
+  g->b = 0;
+  for (int i = 0; i < 310; ++i) (void)orc_rand(g);
+}
+
+int32_t orc_rand(orc_rng* g) {
+  uint32_t val = (uint32_t)g->r[g->f] + (uint32_t)g->r[g->b];
+  g->r[g->f] = (int32_t)val;
+  if (++g->f >= 31) { g->f = 0; ++g->b; }
+  else if (++g->b >= 31) g->b = 0;
+  return (int32_t)(val >> 1);
+}
+
+/* include/caffe/util/rng.hpp:43-54 */
+void orc_random_unique(orc_rng* g, int32_t* a, int len, int n) {
+  int left = len, first = 0;
+  while (n--) {
+    int r = first + orc_rand(g) % left;
+    int32_t t = a[first]; a[first] = a[r]; a[r] = t;
+    ++first; --left;
+  }
+}
+
+/* libstdc++ std::random_shuffle(first, last): for i in [1, len): j = rand() % (i + 1); swap if
+ * different.  Call site: video_sampled_shots_data_layer.cpp:482 */
+void orc_random_shuffle(orc_rng* g, int32_t* a, int len) {
+  for (int i = 1; i < len; ++i) {
+    int j = orc_rand(g) % (i + 1);
+    if (i != j) { int32_t t = a[i]; a[i] = a[j]; a[j] = t; }
+  }
+}
+
+/* ============================================================ sampler ======================= */
+struct orc_sampler {
+  orc_dataset ds;
+  orc_sampler_param p;
+  orc_rng rng;
+  int64_t rand_calls;
+  int32_t cursor;
+  /* negative ring buffer (negatives_, negative_id_to_key_, negative_keys_set_, buffer_ids_) */
+  int32_t* buffer_ids;     /* persistent permutation, …data_layer.cpp:81-83 */
+  int32_t* buf_row;        /* slot -> table row (stands for the copied feature vector) */
+  uint64_t* buf_key;       /* slot -> "vid:shot" key */
+  int32_t* chain_next;     /* hash chain over slots */
+  int32_t* bucket;         /* bucket heads */
+  int32_t n_bucket;
+  /* persistent prefetch_data_ contents (needed for quirk Q1) */
+  int32_t* slot_row;       /* [B][C+Nn] */
+  int32_t* slot_last;      /* [B][C+Nn] */
+  int32_t* perm;           /* scratch, max n_shots */
+};
+
+static int32_t s_rand(orc_sampler* s) { ++s->rand_calls; return orc_rand(&s->rng); }
+
+static uint64_t make_key(int32_t vid, int32_t shot) {
+  return ((uint64_t)(uint32_t)vid << 32) | (uint32_t)shot;
+}
+static uint32_t hash_key(uint64_t k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
+  return (uint32_t)k;
+}
+static int key_find(const orc_sampler* s, uint64_t k) {
+  for (int32_t i = s->bucket[hash_key(k) & (s->n_bucket - 1)]; i >= 0; i = s->chain_next[i])
+    if (s->buf_key[i] == k) return 1;
+  return 0;
+}
+static void key_insert(orc_sampler* s, int32_t slot, uint64_t k) {
+  uint32_t h = hash_key(k) & (s->n_bucket - 1);
+  s->buf_key[slot] = k;
+  s->chain_next[slot] = s->bucket[h];
+  s->bucket[h] = slot;
+}
+static void key_erase(orc_sampler* s, int32_t slot) {
+  uint32_t h = hash_key(s->buf_key[slot]) & (s->n_bucket - 1);
+  int32_t* pp = &s->bucket[h];
+  while (*pp != slot) pp = &s->chain_next[*pp];
+  *pp = s->chain_next[slot];
+}
+static int32_t shot_id_of(const orc_dataset* ds, int v, int j) {
+  return ds->shot_ids ? ds->shot_ids[ds->shot_off[v] + j] : j;
+}
+
+static void s_random_unique(orc_sampler* s, int32_t* a, int len, int n) {
+  int left = len, first = 0;
+  while (n--) {
+    int r = first + s_rand(s) % left;
+    int32_t t = a[first]; a[first] = a[r]; a[r] = t;
+    ++first; --left;
+  }
+}
+static void s_random_shuffle(orc_sampler* s, int32_t* a, int len) {
+  for (int i = 1; i < len; ++i) {
+    int j = s_rand(s) % (i + 1);
+    if (i != j) { int32_t t = a[i]; a[i] = a[j]; a[j] = t; }
+  }
+}
+
+void orc_sampler_destroy(orc_sampler* s) {
+  if (!s) return;
+  free(s->buffer_ids); free(s->buf_row); free(s->buf_key); free(s->chain_next); free(s->bucket);
+  free(s->slot_row); free(s->slot_last); free(s->perm); free(s);
+}
+
+/* video_sampled_shots_data_layer.cpp:64-369 (DataLayerSetUp) */
+orc_sampler* orc_sampler_create(const orc_dataset* ds, const orc_sampler_param* p, unsigned seed) {
+  if (p->context_size < 2 || p->batch_size < 1 || ds->n_videos < 1) return NULL;   /* :207,:209 */
+  if (p->num_negative_samples > 0 &&
+      (p->negative_swap_percentage < 0 || p->negative_swap_percentage > 99)) return NULL; /* :79-80 */
+  orc_sampler* s = (orc_sampler*)calloc(1, sizeof(*s));
+  s->ds = *ds; s->p = *p;
+  orc_srand(&s->rng, seed);
+  const int CN = p->context_size + p->num_negative_samples;
+  const int mb = p->num_negative_samples > 0 ? p->max_buffer_size : 0;
+  int max_n = 1;
+  for (int v = 0; v < ds->n_videos; ++v) if (ds->n_shots[v] > max_n) max_n = ds->n_shots[v];
+  s->perm = (int32_t*)malloc(sizeof(int32_t) * (size_t)max_n);
+  s->slot_row = (int32_t*)malloc(sizeof(int32_t) * (size_t)p->batch_size * CN);
+  s->slot_last = (int32_t*)malloc(sizeof(int32_t) * (size_t)p->batch_size * CN);
+  for (int i = 0; i < p->batch_size * CN; ++i) s->slot_row[i] = s->slot_last[i] = -1;
+  s->n_bucket = 16;
+  while (s->n_bucket < 2 * mb) s->n_bucket <<= 1;
+  s->bucket = (int32_t*)malloc(sizeof(int32_t) * (size_t)s->n_bucket);
+  for (int i = 0; i < s->n_bucket; ++i) s->bucket[i] = -1;
+  s->buffer_ids = (int32_t*)malloc(sizeof(int32_t) * (size_t)(mb + 1));
+  s->buf_row = (int32_t*)malloc(sizeof(int32_t) * (size_t)(mb + 1));
+  s->buf_key = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)(mb + 1));
+  s->chain_next = (int32_t*)malloc(sizeof(int32_t) * (size_t)(mb + 1));
+  for (int i = 0; i < mb; ++i) s->buffer_ids[i] = i;                                   /* :81-83 */
+
+  /* :240-344 -- one rand()%num_shots per visited record until the buffer holds max_buffer_size
+   * unique keys; the cursor advances on every visit and is NOT rewound afterwards. */
+  if (mb > 0) {
+    int added = 0;
+    const int64_t tries = (int64_t)p->max_tries_for_negs * mb;
+    for (int64_t nid = 0; nid < tries; ++nid) {
+      const int v = s->cursor;
+      s->cursor = (s->cursor + 1) % ds->n_videos;
+      const int n = ds->n_shots[v];
+      const int j = s_rand(s) % n;                                                     /* :306 */
+      const uint64_t k = make_key(ds->video_id[v], shot_id_of(ds, v, j));
+      if (!key_find(s, k)) {
+        s->buf_row[added] = (int32_t)(ds->row_base[v] + j);
+        key_insert(s, added, k);
+        ++added;
+      }
+      if (added >= mb) break;                                                          /* :338 */
+    }
+    if (added != mb) { orc_sampler_destroy(s); return NULL; }                          /* :344 */
+  }
+  return s;
+}
+
+/* video_sampled_shots_data_layer.cpp:371-393,425-507 (AddSamplesToTop, CONTEXT_WINDOW) */
+static int add_samples_window(orc_sampler* s, int v, int item, int* added_negs) {
+  const orc_sampler_param* p = &s->p;
+  const int C = p->context_size, CN = C + p->num_negative_samples;
+  const int n = s->ds.n_shots[v];
+  const int64_t base = s->ds.row_base[v];
+  *added_negs = 0;
+  if (n < 2) return 0;                                                                 /* :387 */
+  if (n < C) return 0;                                                                 /* :427 */
+  int32_t* perm = s->perm;
+  for (int i = 0; i < n; ++i) perm[i] = i;                                             /* :391 */
+  s_random_unique(s, perm, n, C);                                                      /* :432 */
+  /* :437 std::sort of the first C ids (distinct ints) */
+  for (int i = 1; i < C; ++i) {
+    int32_t x = perm[i]; int j = i - 1;
+    while (j >= 0 && perm[j] > x) { perm[j + 1] = perm[j]; --j; }
+    perm[j + 1] = x;
+  }
+  const int half = C / 2;
+  int ctx = 0;
+  int32_t* row = s->slot_row + (size_t)item * CN;
+  int32_t* last = s->slot_last + (size_t)item * CN;
+  for (int i = 0; i < C; ++i) {                                                        /* :439-453 */
+    const int32_t r = (int32_t)(base + perm[i]);
+    if (i == half) { row[0] = r; last[0] = r; }
+    else { row[ctx + 1] = r; last[ctx + 1] = r; ++ctx; }
+  }
+  if (p->num_negative_samples > 0 && n > C) {                                          /* :479-503 */
+    s_random_shuffle(s, perm + C, n - C);                                              /* :482 */
+    for (int nid = C; nid < n && *added_negs < p->max_same_video_negs; ++nid) {
+      if (perm[nid] < perm[half - 1] || perm[nid] > perm[half + 1]) {                  /* :489-490 */
+        /* :492 copies only datum_height_-1 values: the last feature keeps the slot's old one */
+        row[C + *added_negs] = (int32_t)(base + perm[nid]);
+        ++*added_negs;
+      }
+    }
+  }
+  return 1;
+}
+
+/* video_sampled_shots_data_layer.cpp:768-909 (InternalThreadEntry) */
+void orc_sampler_next(orc_sampler* s, int32_t* idx, int32_t* last_src, int32_t* label) {
+  const orc_sampler_param* p = &s->p;
+  const int C = p->context_size, Nn = p->num_negative_samples, CN = C + Nn;
+  int item = 0;
+  while (item < p->batch_size) {
+    const int v = s->cursor;
+    int added = 0;
+    const int ok = add_samples_window(s, v, item, &added);                             /* :820 */
+    s->cursor = (s->cursor + 1) % s->ds.n_videos;                                      /* :826-846 */
+    if (!ok) continue;                                                                 /* :848 */
+    if (Nn > 0) {
+      s_random_unique(s, s->buffer_ids, p->max_buffer_size, Nn - added);               /* :855 */
+      for (int c = C + added; c < CN; ++c) {                                           /* :856-875 */
+        const int32_t neg = s->buffer_ids[c - C - added];
+        s->slot_row[(size_t)item * CN + c] = s->buf_row[neg];
+        s->slot_last[(size_t)item * CN + c] = s->buf_row[neg];
+      }
+    }
+    if (label) label[item] = s->ds.video_id[v];                                        /* :879 */
+    ++item;
+    if (Nn > 0 && p->negative_swap_percentage > 0) {                                   /* :888-906 */
+      const int n = s->ds.n_shots[v];
+      for (int j = 0; j < n; ++j) {
+        const uint64_t k = make_key(s->ds.video_id[v], shot_id_of(&s->ds, v, j));
+        if (key_find(s, k)) continue;
+        if (s_rand(s) % 100 < p->negative_swap_percentage) {                           /* :27 */
+          const int pos = s_rand(s) % p->max_buffer_size;                              /* :29 */
+          key_erase(s, pos);
+          s->buf_row[pos] = (int32_t)(s->ds.row_base[v] + j);
+          key_insert(s, pos, k);
+        }
+      }
+    }
+  }
+  const size_t nb = sizeof(int32_t) * (size_t)p->batch_size * CN;
+  if (idx) memcpy(idx, s->slot_row, nb);
+  if (last_src) memcpy(last_src, s->slot_last, nb);
+}
+
+const int32_t* orc_sampler_buffer_rows(const orc_sampler* s) { return s->buf_row; }
+const int32_t* orc_sampler_buffer_ids(const orc_sampler* s) { return s->buffer_ids; }
+int32_t orc_sampler_cursor(const orc_sampler* s) { return s->cursor; }
+int64_t orc_sampler_rand_calls(const orc_sampler* s) { return s->rand_calls; }
+
+/* ============================================================ sgemm ========================= */
+static int g_threads = 0;
+void orc_set_threads(int n) { g_threads = n; }
+int orc_get_threads(void) {
+#ifdef _OPENMP
+  return g_threads > 0 ? g_threads : omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+#define MR 4
+#define NR 32
+/* C[M][N] (+)= alpha * A[M][K] * Bp[K][N] with Bp packed row-major (k-major).  The inner body is
+ * an outer-product update over an MR x NR register block, vectorised by the compiler. */
+static void gemm_nn_packed(int M, int N, int K, float alpha, const float* A, int lda, int a_trans,
+                           const float* Bp, float beta, float* C) {
+  const int nt = orc_get_threads();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nt)
+  for (int i0 = 0; i0 < M; i0 += MR) {
+    const int mr = M - i0 < MR ? M - i0 : MR;
+    for (int j0 = 0; j0 < N; j0 += NR) {
+      const int nr = N - j0 < NR ? N - j0 : NR;
+      float acc[MR][NR];
+      for (int i = 0; i < MR; ++i) for (int j = 0; j < NR; ++j) acc[i][j] = 0.f;
+      if (mr == MR && nr == NR) {
+        for (int k = 0; k < K; ++k) {
+          const float* bp = Bp + (size_t)k * N + j0;
+          float a[MR];
+          for (int i = 0; i < MR; ++i)
+            a[i] = a_trans ? A[(size_t)k * lda + i0 + i] : A[(size_t)(i0 + i) * lda + k];
+          for (int i = 0; i < MR; ++i) {
+#pragma omp simd
+            for (int j = 0; j < NR; ++j) acc[i][j] += a[i] * bp[j];
+          }
+        }
+      } else {
+        for (int k = 0; k < K; ++k) {
+          const float* bp = Bp + (size_t)k * N + j0;
+          for (int i = 0; i < mr; ++i) {
+            const float a = a_trans ? A[(size_t)k * lda + i0 + i] : A[(size_t)(i0 + i) * lda + k];
+            for (int j = 0; j < nr; ++j) acc[i][j] += a * bp[j];
+          }
+        }
+      }
+      for (int i = 0; i < mr; ++i) {
+        float* c = C + (size_t)(i0 + i) * N + j0;
+        if (beta == 0.f) for (int j = 0; j < nr; ++j) c[j] = alpha * acc[i][j];
+        else for (int j = 0; j < nr; ++j) c[j] = alpha * acc[i][j] + beta * c[j];
+      }
+    }
+  }
+}
+
+/* caffe_cpu_gemm (math_functions.cpp:12-21): row-major, lda/ldb derived from the trans flags. */
+void orc_sgemm(int transA, int transB, int M, int N, int K, float alpha, const float* A,
+               const float* B, float beta, float* C) {
+  const float* Bp = B;
+  float* tmp = NULL;
+  if (transB) {   /* B given as [N][K]: pack to [K][N] */
+    tmp = (float*)malloc(sizeof(float) * (size_t)K * N);
+    const int nt = orc_get_threads();
+#pragma omp parallel for num_threads(nt)
+    for (int k0 = 0; k0 < K; k0 += 32)
+      for (int n = 0; n < N; ++n) {
+        const int k1 = k0 + 32 < K ? k0 + 32 : K;
+        for (int k = k0; k < k1; ++k) tmp[(size_t)k * N + n] = B[(size_t)n * K + k];
+      }
+    Bp = tmp;
+  }
+  gemm_nn_packed(M, N, K, alpha, A, transA ? M : K, transA, Bp, beta, C);
+  free(tmp);
+}
+
+/* ============================================================ layers ======================== */
+/* normalization_layer.cpp:29-61.  caffe_powx -> powf (mkl_alternate.hpp:55). */
+void orc_normalize_fwd(int num, int dim, const float* x, float* y) {
+  const float eps = 1e-10f;
+#pragma omp parallel for num_threads(orc_get_threads())
+  for (int i = 0; i < num; ++i) {
+    const float* xi = x + (size_t)i * dim;
+    float s = 0.f;
+    for (int j = 0; j < dim; ++j) s += powf(xi[j], 2.f);                              /* :39-44 */
+    const float nrm = powf(s, 0.5f) + eps;                                            /* :47-51 */
+    for (int j = 0; j < dim; ++j) y[(size_t)i * dim + j] = xi[j] / nrm;               /* :54-59 */
+  }
+}
+
+/* normalization_layer.cpp:63-112: dx = (s*dy - x*(x.dy)) / (s^1.5 + eps), s = sum x^2 */
+void orc_normalize_bwd(int num, int dim, const float* x, const float* dy, float* dx) {
+  const float eps = 1e-10f;
+#pragma omp parallel for num_threads(orc_get_threads())
+  for (int i = 0; i < num; ++i) {
+    const float* xi = x + (size_t)i * dim;
+    const float* gi = dy + (size_t)i * dim;
+    float dot = 0.f, s = 0.f;
+    for (int j = 0; j < dim; ++j) dot += xi[j] * gi[j];                               /* :77-79 */
+    for (int j = 0; j < dim; ++j) s += powf(xi[j], 2.f);                              /* :88-93 */
+    const float den = powf(s, 1.5f) + eps;                                            /* :103-107 */
+    for (int j = 0; j < dim; ++j)
+      dx[(size_t)i * dim + j] = (s * gi[j] - xi[j] * dot) / den;                      /* :85,97-110 */
+  }
+}
+
+/* max_margin_loss_layer.cpp:53-127 */
+void orc_max_margin_fwd(int count, const float* s_true, const float* s_bogus, const float* weight,
+                        float margin, int norm, float* loss, float* violations) {
+  float nv = 0.f;
+  double acc = 0.0;
+  for (int i = 0; i < count; ++i) {
+    const float d = s_true[i] - s_bogus[i];                                           /* :69 */
+    if (d < 0) nv += 1.f;                                                             /* :78-80 */
+    float h = fmaxf(0.f, margin - d);                                                 /* :99 */
+    if (weight) h *= (norm == 2) ? sqrtf(weight[i]) : weight[i];                      /* :84-90 */
+    acc += (norm == 2) ? (double)h * h : fabs((double)h);                             /* :112-118 */
+  }
+  if (loss) *loss = (float)(acc / count);
+  if (violations) *violations = nv;                                                   /* :123-126 */
+}
+
+/* max_margin_loss_layer.cpp:129-214 */
+void orc_max_margin_bwd(int count, const float* s_true, const float* s_bogus, const float* weight,
+                        float margin, int norm, float loss_weight, float* d_true, float* d_bogus) {
+  for (int i = 0; i < count; ++i) {
+    float h = fmaxf(0.f, margin - (s_true[i] - s_bogus[i]));                          /* :149-161 */
+    if (weight) h *= weight[i];                                                       /* :154 */
+    float g;
+    if (norm == 1) {                                                                  /* :173-189 */
+      g = h > 0.f ? (weight ? weight[i] : 1.f) : h;
+      g *= loss_weight / count;
+    } else {
+      g = h * (loss_weight * 2 / count);                                              /* :191 */
+    }
+    d_bogus[i] = g;
+    d_true[i] = -g;                                                                   /* :211 */
+  }
+}
+
+/* sum_layer.cpp:31-54 */
+void orc_sum_fwd(int num, int dim, int num_output, const float* x, float* y) {
+  for (int i = 0; i < num; ++i) {
+    float s = 0.f;
+    for (int j = 0; j < dim; ++j) s += x[(size_t)i * dim + j];
+    for (int o = 0; o < num_output; ++o) y[(size_t)i * num_output + o] = s;
+  }
+}
+/* sum_layer.cpp:56-82 */
+void orc_sum_bwd(int num, int dim, int num_output, const float* dy, float* dx) {
+  for (int i = 0; i < num; ++i) {
+    float s = 0.f;
+    for (int o = 0; o < num_output; ++o) s += dy[(size_t)i * num_output + o];
+    for (int j = 0; j < dim; ++j) dx[(size_t)i * dim + j] = s;
+  }
+}
+
+/* solver.cpp:440-460 */
+float orc_learning_rate(const char* policy, float base_lr, float gamma, float power, int stepsize,
+                        int iter) {
+  if (!strcmp(policy, "fixed")) return base_lr;
+  if (!strcmp(policy, "step")) return base_lr * powf(gamma, (float)(iter / stepsize));
+  if (!strcmp(policy, "exp")) return base_lr * powf(gamma, (float)iter);
+  if (!strcmp(policy, "inv")) return base_lr * powf(1.f + gamma * iter, -power);
+  return NAN;
+}
+
+/* solver.cpp:502-531 (ComputeUpdateValue, CPU branch) then blob.cpp:112-136 (Blob::Update) */
+void orc_sgd_update(int64_t n, float* w, float* grad, float* hist, float rate, float lr_mult,
+                    float momentum, float weight_decay, float decay_mult, int reg) {
+  const float local_rate = rate * lr_mult, local_decay = weight_decay * decay_mult;
+  if (local_decay != 0.f) {
+    if (reg == 2) for (int64_t i = 0; i < n; ++i) grad[i] += local_decay * w[i];
+    else for (int64_t i = 0; i < n; ++i)
+      grad[i] += local_decay * (float)((w[i] > 0.f) - (w[i] < 0.f));
+  }
+  for (int64_t i = 0; i < n; ++i) hist[i] = local_rate * grad[i] + momentum * hist[i];
+  for (int64_t i = 0; i < n; ++i) grad[i] = hist[i];
+  for (int64_t i = 0; i < n; ++i) w[i] -= grad[i];
+}
+
+/* ============================================================ whole step ==================== */
+static float* falloc(size_t n) {
+  float* p = (float*)calloc(n ? n : 1, sizeof(float));
+  if (!p) { fprintf(stderr, "vv_oracle: out of memory (%zu floats)\n", n); abort(); }
+  return p;
+}
+
+/* Net::ForwardBackward over mednet_embedding_train.prototxt (TRAIN phase), layer by layer. */
+void orc_forward_backward(const orc_step_cfg* cfg, const float* table, const int32_t* idx,
+                          const int32_t* last_src, const float* W, const float* b,
+                          orc_step_out* out) {
+  const int B = cfg->B, C = cfg->C, Nn = cfg->Nn, F = cfg->F, D = cfg->D;
+  const int CN = C + Nn, R = CN * B, Q = 1 + Nn;
+  const int nt = orc_get_threads();
+  const float drop_scale = cfg->dropout_ratio > 0.f ? 1.f / (1.f - cfg->dropout_ratio) : 1.f;
+
+  /* --- data layer copy (…data_layer.cpp:439-452,856-875) then SLICE dim 1 + CONCAT dim 0
+   * (prototxt :48-131; slice_layer.cpp:75-105, concat_layer.cpp:56-67) + FLATTEN: X row = ch*B+b */
+  float* data = falloc((size_t)B * CN * F);
+#pragma omp parallel for num_threads(nt)
+  for (int i = 0; i < B * CN; ++i) {
+    float* dst = data + (size_t)i * F;
+    if (idx[i] >= 0) memcpy(dst, table + (size_t)idx[i] * F, sizeof(float) * F);
+    if (last_src && last_src[i] != idx[i])
+      dst[F - 1] = last_src[i] >= 0 ? table[(size_t)last_src[i] * F + F - 1] : 0.f;
+  }
+  float* X = falloc((size_t)R * F);
+#pragma omp parallel for num_threads(nt)
+  for (int r = 0; r < R; ++r) {
+    const int ch = r / B, bb = r % B;
+    memcpy(X + (size_t)r * F, data + ((size_t)bb * CN + ch) * F, sizeof(float) * F);
+  }
+  free(data);
+
+  /* --- fc7 INNER_PRODUCT (inner_product_layer.cpp:60-74): Y = X W^T + 1 b^T */
+  float* Y = falloc((size_t)R * D);
+  orc_sgemm(0, 1, R, D, F, 1.f, X, W, 0.f, Y);
+  if (b) {
+#pragma omp parallel for num_threads(nt)
+    for (int r = 0; r < R; ++r) for (int d = 0; d < D; ++d) Y[(size_t)r * D + d] += b[d];
+  }
+  /* --- RELU (relu_layer.cpp:9-20), DROPOUT in place on ip2 (dropout_layer.cpp:35-50) */
+  float* H = falloc((size_t)R * D);
+  const float slope = cfg->relu_negative_slope;
+#pragma omp parallel for num_threads(nt)
+  for (size_t i = 0; i < (size_t)R * D; ++i) {
+    float h = fmaxf(Y[i], 0.f) + slope * fminf(Y[i], 0.f);
+    if (cfg->dropout_ratio > 0.f) h = h * (float)cfg->dropout_mask[i] * drop_scale;
+    H[i] = h;
+  }
+  /* --- SLICE dim 0 (prototxt :232-257): E_ch = H[ch*B .. (ch+1)*B) */
+  /* --- ELTWISE SUM with coeffs (eltwise_layer.cpp:65-71): A = sum_j c_j E_cj */
+  float* A = falloc((size_t)B * D);
+  for (int j = 1; j < C; ++j) {
+    const float c = cfg->ctx_coeff ? cfg->ctx_coeff[j - 1] : 1.f;
+    const float* E = H + (size_t)j * B * D;
+#pragma omp parallel for num_threads(nt)
+    for (size_t i = 0; i < (size_t)B * D; ++i) A[i] += c * E[i];
+  }
+  /* --- NORMALIZATION of the context mean (prototxt :281-288) */
+  float* Ahat = falloc((size_t)B * D);
+  orc_normalize_fwd(B, D, A, Ahat);
+  /* --- CONCAT dim 0 of target + negatives, NORMALIZATION, SLICE (prototxt :290-342) */
+  float* PN = falloc((size_t)Q * B * D);
+  memcpy(PN, H, sizeof(float) * (size_t)B * D);
+  if (Nn > 0) memcpy(PN + (size_t)B * D, H + (size_t)C * B * D, sizeof(float) * (size_t)Nn * B * D);
+  float* Phat = falloc((size_t)Q * B * D);
+  orc_normalize_fwd(Q * B, D, PN, Phat);
+  /* --- ELTWISE PROD + SUM (prototxt :354-629): s+ replicated Nn times, s-[b][k] */
+  float* s_true = falloc((size_t)B * (Nn > 0 ? Nn : 1));
+  float* s_bogus = falloc((size_t)B * (Nn > 0 ? Nn : 1));
+  float* prod = falloc((size_t)B * D);
+  float* col = falloc((size_t)B);
+  for (int q = 0; q < Q; ++q) {
+    const float* P = Phat + (size_t)q * B * D;
+#pragma omp parallel for num_threads(nt)
+    for (size_t i = 0; i < (size_t)B * D; ++i) prod[i] = Ahat[i] * P[i];             /* eltwise :62 */
+    if (q == 0) orc_sum_fwd(B, D, Nn, prod, s_true);                                  /* sum :43-47 */
+    else {
+      orc_sum_fwd(B, D, 1, prod, col);
+      for (int bb = 0; bb < B; ++bb) s_bogus[(size_t)bb * Nn + (q - 1)] = col[bb];    /* concat dim 1 */
+    }
+  }
+  /* --- MAX_MARGIN_LOSS (prototxt :655-671) */
+  const int count = B * Nn;
+  orc_max_margin_fwd(count, s_true, s_bogus, NULL, cfg->margin, cfg->norm, &out->loss,
+                     &out->violations);
+  out->loss *= cfg->loss_weight;                                                      /* layer.hpp:416-422 */
+
+  /* ================= backward (Net::BackwardFromTo, net.cpp:567-578) ================= */
+  float* d_true = falloc((size_t)count + 1);
+  float* d_bogus = falloc((size_t)count + 1);
+  orc_max_margin_bwd(count, s_true, s_bogus, NULL, cfg->margin, cfg->norm, cfg->loss_weight,
+                     d_true, d_bogus);
+  if (cfg->global_count > 0 && cfg->global_count != count) {
+    /* data-parallel shard: the loss normaliser is the GLOBAL B*Nn */
+    const float f = (float)count / (float)cfg->global_count;
+    for (int i = 0; i < count; ++i) { d_true[i] *= f; d_bogus[i] *= f; }
+  }
+  /* SUM / PROD backward per q, SPLIT of context_feature accumulates (split_layer.cpp:38-51) */
+  float* dAhat = falloc((size_t)B * D);
+  float* dPhat = falloc((size_t)Q * B * D);
+  float* dprod = falloc((size_t)B * D);
+  for (int q = 0; q < Q; ++q) {
+    if (q == 0) orc_sum_bwd(B, D, Nn, d_true, dprod);                                 /* sum :70-76 */
+    else {
+      for (int bb = 0; bb < B; ++bb) col[bb] = d_bogus[(size_t)bb * Nn + (q - 1)];
+      orc_sum_bwd(B, D, 1, col, dprod);
+    }
+    const float* P = Phat + (size_t)q * B * D;
+    float* dP = dPhat + (size_t)q * B * D;
+#pragma omp parallel for num_threads(nt)
+    for (size_t i = 0; i < (size_t)B * D; ++i) {                                      /* eltwise :116-131 */
+      dP[i] = Ahat[i] * dprod[i];
+      dAhat[i] += P[i] * dprod[i];
+    }
+  }
+  float* dPN = falloc((size_t)Q * B * D);
+  orc_normalize_bwd(Q * B, D, PN, dPhat, dPN);
+  float* dA = falloc((size_t)B * D);
+  orc_normalize_bwd(B, D, A, dAhat, dA);
+  /* gather diffs back to dH rows (slice/concat backward), eltwise SUM backward (:132-138) */
+  float* dH = falloc((size_t)R * D);
+  memcpy(dH, dPN, sizeof(float) * (size_t)B * D);
+  if (Nn > 0) memcpy(dH + (size_t)C * B * D, dPN + (size_t)B * D, sizeof(float) * (size_t)Nn * B * D);
+  for (int j = 1; j < C; ++j) {
+    const float c = cfg->ctx_coeff ? cfg->ctx_coeff[j - 1] : 1.f;
+    float* dE = dH + (size_t)j * B * D;
+#pragma omp parallel for num_threads(nt)
+    for (size_t i = 0; i < (size_t)B * D; ++i) dE[i] = c * dA[i];
+  }
+  /* DROPOUT backward (dropout_layer.cpp:53-68), RELU backward (relu_layer.cpp:23-37) */
+  float* dY = falloc((size_t)R * D);
+#pragma omp parallel for num_threads(nt)
+  for (size_t i = 0; i < (size_t)R * D; ++i) {
+    float g = dH[i];
+    if (cfg->dropout_ratio > 0.f) g = g * (float)cfg->dropout_mask[i] * drop_scale;
+    dY[i] = g * ((Y[i] > 0.f) + slope * (Y[i] <= 0.f));
+  }
+  /* INNER_PRODUCT backward (inner_product_layer.cpp:76-106): dW = dY^T X, db = dY^T 1 */
+  if (out->dW) {
+    orc_sgemm(1, 0, D, F, R, 1.f, dY, X, 0.f, out->dW);
+    if (cfg->ip_regularization > 0.f) {
+      const float f = (float)(1.0 + cfg->ip_regularization / 2);
+      for (size_t i = 0; i < (size_t)D * F; ++i) out->dW[i] *= f;
+    }
+  }
+  if (out->db) {
+    for (int d = 0; d < D; ++d) out->db[d] = 0.f;
+    for (int r = 0; r < R; ++r) for (int d = 0; d < D; ++d) out->db[d] += dY[(size_t)r * D + d];
+  }
+
+  if (out->Y) memcpy(out->Y, Y, sizeof(float) * (size_t)R * D);
+  if (out->H) memcpy(out->H, H, sizeof(float) * (size_t)R * D);
+  if (out->ctx) memcpy(out->ctx, Ahat, sizeof(float) * (size_t)B * D);
+  if (out->posneg) memcpy(out->posneg, Phat, sizeof(float) * (size_t)Q * B * D);
+  if (out->s_true) memcpy(out->s_true, s_true, sizeof(float) * (size_t)B * Nn);
+  if (out->s_bogus) memcpy(out->s_bogus, s_bogus, sizeof(float) * (size_t)B * Nn);
+  if (out->dY) memcpy(out->dY, dY, sizeof(float) * (size_t)R * D);
+
+  free(X); free(Y); free(H); free(A); free(Ahat); free(PN); free(Phat); free(s_true);
+  free(s_bogus); free(prod); free(col); free(d_true); free(d_bogus); free(dAhat); free(dPhat);
+  free(dprod); free(dPN); free(dA); free(dH); free(dY);
+}
+
+/* videovec_extraction.prototxt:179-205 (fc7 INNER_PRODUCT + RELU), optional NORMALIZATION as in
+ * the TEST branch of mednet_embedding_train.prototxt:344-352 */
+void orc_embed(int n, int F, int D, const float* table, const int32_t* rows, const float* W,
+               const float* b, int relu, int l2norm, float* out) {
+  float* X = falloc((size_t)n * F);
+  for (int i = 0; i < n; ++i)
+    memcpy(X + (size_t)i * F, table + (size_t)(rows ? rows[i] : i) * F, sizeof(float) * F);
+  orc_sgemm(0, 1, n, D, F, 1.f, X, W, 0.f, out);
+  for (int i = 0; i < n; ++i)
+    for (int d = 0; d < D; ++d) {
+      float y = out[(size_t)i * D + d] + (b ? b[d] : 0.f);
+      out[(size_t)i * D + d] = relu ? fmaxf(y, 0.f) : y;
+    }
+  if (l2norm) {
+    float* t = falloc((size_t)n * D);
+    orc_normalize_fwd(n, D, out, t);
+    memcpy(out, t, sizeof(float) * (size_t)n * D);
+    free(t);
+  }
+  free(X);
+}

@@ -1,0 +1,101 @@
+"""Sampler restatement: C oracle (glibc clone) vs an independent pure-Python restatement driven by
+the REAL glibc rand() -- bit-exact indices -- plus structural invariants of the reference layer
+(src/caffe/layers/video_sampled_shots_data_layer.cpp).  The reference has no test for this layer
+(SURVEY.md section 4): these checks are all that pins it."""
+import numpy as np
+import pytest
+
+from tests.pyref import PySampler
+from videovector_amd.synth import SyntheticVideos
+
+
+def _mk(oracle, ds, **kw):
+    return oracle.Sampler(ds.video_id, ds.n_shots, ds.row_base, **kw)
+
+
+@pytest.mark.parametrize("B,C,Nn,mb,swap,max_same", [
+    (32, 5, 2, 100, 50, 0),      # BASELINE config 1 shape
+    (16, 5, 10, 200, 50, 6),     # shipped prototxt values (quirk Q1 active)
+    (8, 3, 4, 64, 99, 2),
+    (8, 7, 3, 50, 0, 0),         # swap 0: buffer never changes
+    (4, 5, 0, 0, 0, 0),          # no negatives at all
+])
+def test_c_oracle_equals_python_restatement_on_real_glibc(oracle, B, C, Nn, mb, swap, max_same):
+    ds = SyntheticVideos(seed=7, n_videos=60, lo=2, span=20)      # includes videos shorter than C
+    s = _mk(oracle, ds, batch_size=B, context_size=C, num_negative_samples=Nn,
+            max_buffer_size=mb, negative_swap_percentage=swap, max_same_video_negs=max_same)
+    p = PySampler(ds.video_id, ds.n_shots, ds.row_base, B, C, Nn, mb, swap, max_same)
+    if Nn > 0:
+        assert s.buffer_rows().tolist() == p.buf_row
+    for _ in range(6):
+        i1, l1, y1 = s.next()
+        i2, l2, y2 = p.next()
+        assert np.array_equal(i1, i2) and np.array_equal(l1, l2) and np.array_equal(y1, y2)
+        assert s.rand_calls() == p.calls and s.cursor() == p.cursor
+    if Nn > 0:
+        assert s.buffer_rows().tolist() == p.buf_row
+        assert s.buffer_ids().tolist() == p.buffer_ids
+
+
+def test_window_structure(oracle):
+    ds = SyntheticVideos(seed=3, n_videos=80)
+    C, Nn, B = 5, 6, 64
+    s = _mk(oracle, ds, batch_size=B, context_size=C, num_negative_samples=Nn,
+            max_buffer_size=300, negative_swap_percentage=50)
+    row2vid = np.repeat(ds.video_id, ds.n_shots)
+    for _ in range(4):
+        buf_before = set(s.buffer_rows().tolist())
+        idx, last, label = s.next()
+        assert np.array_equal(idx, last)                       # max_same_video_negs == 0
+        # target + context come from the labelled video, distinct frames, and the target is the
+        # temporal middle: context channels are sorted and split evenly around it (:437-453)
+        for b in range(B):
+            assert np.all(row2vid[idx[b, :C]] == label[b])
+            t, ctx = idx[b, 0], idx[b, 1:C]
+            assert np.all(np.diff(ctx) > 0)
+            assert (ctx < t).sum() == C // 2 and (ctx > t).sum() == C // 2
+            assert len(set(idx[b, C:].tolist())) == Nn          # partial Fisher-Yates: distinct slots
+        # item 0's negatives were drawn before any swap of this batch
+        assert set(idx[0, C:].tolist()) <= buf_before
+
+
+def test_short_videos_are_skipped_but_advance_cursor(oracle):
+    # :387,:427,:848 -- records with fewer than C shots add nothing and draw nothing
+    vid = np.arange(6, dtype=np.int32)
+    ns = np.array([1, 4, 9, 2, 12, 3], np.int32)
+    rb = np.concatenate([[0], np.cumsum(ns[:-1])]).astype(np.int64)
+    s = oracle.Sampler(vid, ns, rb, batch_size=6, context_size=5, num_negative_samples=0,
+                       max_buffer_size=0, negative_swap_percentage=0)
+    _, _, label = s.next()
+    assert label.tolist() == [2, 4, 2, 4, 2, 4]
+
+
+def test_q1_same_video_negatives_keep_previous_last_feature(oracle):
+    ds = SyntheticVideos(seed=11, n_videos=40)
+    C, Nn, B = 5, 8, 8
+    s = _mk(oracle, ds, batch_size=B, context_size=C, num_negative_samples=Nn,
+            max_buffer_size=100, negative_swap_percentage=50, max_same_video_negs=6)
+    idx0, last0, _ = s.next()
+    row2vid = np.repeat(ds.video_id, ds.n_shots)
+    # first batch: same-video negative slots were never written before -> last feature is zero (-1)
+    same = row2vid[idx0[:, C:]] == row2vid[idx0[:, :1]]
+    assert same[:, :6].all() and np.all(last0[:, C:C + 6] == -1)
+    assert np.array_equal(idx0[:, C + 6:], last0[:, C + 6:])
+    idx1, last1, _ = s.next()
+    # second batch: those slots still hold nothing for the last feature (only Q1 copies hit them)
+    assert np.all(last1[:, C:C + 6] == -1) and not np.array_equal(idx0, idx1)
+    # the same-video negatives lie outside the target's immediate sampled neighbours (:489-490)
+    for b in range(B):
+        lo, hi = idx1[b, C // 2], idx1[b, C // 2 + 1]
+        assert np.all((idx1[b, C:C + 6] < lo) | (idx1[b, C:C + 6] > hi))
+
+
+def test_setup_check_fails_like_reference(oracle):
+    # :344 CHECK_EQ(num_negatives_added, max_buffer_size): more slots than unique shots
+    ds = SyntheticVideos(seed=1, n_videos=3, lo=2, span=1)     # 6 shots in total
+    with pytest.raises(ValueError):
+        _mk(oracle, ds, batch_size=2, context_size=3, num_negative_samples=2, max_buffer_size=7,
+            negative_swap_percentage=10)
+    with pytest.raises(ValueError):                             # :79-80 swap percentage range
+        _mk(oracle, ds, batch_size=2, context_size=3, num_negative_samples=2, max_buffer_size=4,
+            negative_swap_percentage=100)
