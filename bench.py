@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py -- triplets/sec of the videovec_embedding training step on N MI355X (one process per GPU).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[1] per GPU: synthetic fc7 features 4096-d -> 512-d embedding, batch
+1024 per GPU (global batch N*1024, weak scaling), context window +-2 (context_size 5), 50 negatives.
+A step = one full training iteration on one batch: gather-GEMM forward, fused score/loss
+forward+backward, gather-GEMM^T weight gradient, (RCCL all-reduce for N>1), fused SGD update.
+Triplet index batches are sampled beforehand by the product sampler and are resident in HBM when
+the timed region starts (the sampler is integer host work that does not depend on the model).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+
+B_PER_GPU, C, NN, F, D = 1024, 5, 50, 4096, 512
+N_VIDEOS, SEED = 2048, 1701
+MFMA_PEAK_TFLOPS = 2500.0     # dense bf16/f16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(ds, idx, W, b, items=256, iters=3):
+    """The oracle (CPU restatement of the reference path, layer by layer with an sgemm for fc7)
+    timed on a bounded sample of the same workload: `items` batch items of the first batch."""
+    from oracle import oracle as orc
+    sh = idx[:items]
+    uniq, inv = np.unique(sh.reshape(-1), return_inverse=True)
+    table = ds.table(F, uniq)
+    idx_local = inv.reshape(sh.shape).astype(np.int32)
+    Wo, bo = W.copy(), b.copy()
+    hW, hb = np.zeros_like(W), np.zeros_like(b)
+    ts = []
+    for _ in range(iters + 1):
+        t0 = time.perf_counter()
+        r = orc.forward_backward(table, idx_local, Wo, bo, C_=C, Nn=NN, want=("dW", "db"))
+        orc.sgd_update(Wo, r["dW"], hW, 1e-3, 1.0, 0.9, 5e-4, 1.0)
+        orc.sgd_update(bo, r["db"], hb, 1e-3, 2.0, 0.9, 5e-4, 0.0)
+        ts.append(time.perf_counter() - t0)
+    t = float(np.mean(ts[1:]))
+    return {"value": items * NN / t, "unit": "triplets/s", "cores": orc.get_threads(), "kind": "port",
+            "sample": "%d of 1024 batch items (%d rows) of the same 4096->512, C5, Nn50 step, "
+                      "%d timed iterations after 1 warm-up, %.2f s each" % (items, items * (C + NN), iters, t)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--prec", default=os.environ.get("VV_PREC", "f16"), choices=["f16", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import videovector_amd as vv
+    from videovector_amd.synth import SyntheticVideos, init_weights
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    K, Wm = args.steps, args.warmup
+    Bg = B_PER_GPU * world
+    ds = SyntheticVideos(seed=SEED, n_videos=N_VIDEOS)
+    # one logical sampler for the global batch on every rank; each rank keeps its slice
+    smp = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, batch_size=Bg, context_size=C,
+                     num_negative_samples=NN, max_buffer_size=5000, negative_swap_percentage=50)
+    t0 = time.perf_counter()
+    batches = np.stack([smp.next()[rank * B_PER_GPU:(rank + 1) * B_PER_GPU] for _ in range(Wm + K)])
+    sampler_s = (time.perf_counter() - t0) / (Wm + K)
+    idx_dev = torch.from_numpy(batches).to(dev)
+
+    W0, b0 = init_weights(SEED, D, F)
+    eng = vv.Engine(local_rank, args.prec)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.table_synth(ds.seed, ds.n_rows, F)
+    eng.params_set(W0, b0)
+    grads = None
+    if world > 1:
+        grads = torch.zeros(D * F + D, dtype=torch.float32, device=dev)
+        eng.grads_bind(grads.data_ptr())
+    cfg = vv.StepConfig(B_PER_GPU, C, NN, global_count=Bg * NN)
+    stride = B_PER_GPU * (C + NN) * 4
+
+    def lr_at(it):     # shipped solver: inv policy, base 1e-3, gamma 1e-3, power .75
+        return 1e-3 * (1.0 + 1e-3 * it) ** -0.75
+
+    def step(i):
+        cfg.set("lr", lr_at(i))
+        ptr = idx_dev.data_ptr() + i * stride
+        if world > 1:
+            eng.forward_backward(cfg, idx_dev_ptr=ptr)
+            dist.all_reduce(grads)
+            eng.apply_update(cfg)
+        else:
+            eng.step(cfg, idx_dev_ptr=ptr)
+
+    for i in range(Wm):
+        step(i)
+    if dist: dist.barrier()
+    torch.cuda.synchronize()
+    eng.profile_enable(True)
+    t0 = time.perf_counter()
+    for i in range(Wm, Wm + K):
+        step(i)
+    torch.cuda.synchronize()
+    if dist: dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss, viol = eng.loss()
+    kern = {k: eng.profile_get(k) for k in ("fwd_gemm", "score_loss", "wgrad_gemm", "reduce", "sgd")}
+    eng.profile_enable(False)
+
+    if rank == 0:
+        ms = elapsed / K * 1e3
+        value = Bg * NN * K / elapsed
+        R = B_PER_GPU * (C + NN)
+        gemm_flop = 2.0 * R * F * D          # per launch of either GEMM kernel
+        dom = max(("fwd_gemm", "wgrad_gemm"), key=lambda k: kern[k][0])
+        dom_ms = kern[dom][0]
+        ach = gemm_flop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        pmc = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc_path):
+            try:
+                pmc = json.load(open(pmc_path)).get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                pmc = None
+        out = {
+            "metric": "triplets/sec (whole node), 4096->512-d embed, batch 1024/GPU, C5, Nn50",
+            "value": value, "unit": "triplets/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.prec + " MFMA operands, fp32 accumulate / fp32 everything else",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1] per GPU: synthetic fc7 4096-d -> 512-d, batch "
+                                   "%d/GPU (global %d), context_size 5 (window +-2), 50 negatives, "
+                                   "max_buffer 5000, swap 50%%, margin 2 L2, SGD momentum .9 wd 5e-4 inv lr"
+                                   % (B_PER_GPU, Bg),
+                       "global_batch": Bg, "triplets_per_step": Bg * NN,
+                       "parallelism": "dp%d" % world, "items_per_s": value / NN},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": pmc,
+                         "algorithmic_flop_per_launch": gemm_flop, "avg_launch_ms": dom_ms},
+            "kernels_ms": {k: round(v[0], 4) for k, v in kern.items()},
+            "step_tflops": 2 * gemm_flop / (ms * 1e-3) / 1e12,
+            "gather_GBs": 2.0 * R * F * 2 / (ms * 1e-3) / 1e9,
+            "sampler_ms_per_global_batch": sampler_s * 1e3,
+            "final_loss": loss, "final_violations": viol,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ds, batches[0], W0, b0)
+        print(json.dumps(out))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,175 @@
+/*
+ * videovec.h -- C ABI of the MI355X-native videovec_embedding training path.
+ *
+ * The reference (eevignesh/videovector, a Caffe fork) has no FFI: its boundary for this path is the
+ * C++ Layer / Solver class hierarchy.  This ABI is what a drop-in replacement of that path binds
+ * to; every entry point names the reference interface it replaces (paths relative to the
+ * reference root).  INTEGRATION.md shows the reference-side stubs (a Layer subclass, ctypes).
+ *
+ * Conventions: plain pointers and sizes, no C++ or torch types.  Every function returns VV_OK (0)
+ * or a VV_ERR_* code; vv_last_error() gives the thread's last message.  Nothing throws across the
+ * boundary.  "host" pointers are ordinary CPU memory; the context owns all device memory.
+ * Errors the reference reports with CHECK/LOG(FATAL) (abort) are reported here as VV_ERR_ARG.
+ */
+#ifndef VIDEOVEC_H_
+#define VIDEOVEC_H_
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vv_ctx vv_ctx;
+
+enum { VV_OK = 0, VV_ERR_ARG = 1, VV_ERR_HIP = 2, VV_ERR_STATE = 3, VV_ERR_NOGPU = 4 };
+
+/* MFMA operand type of the two GEMMs (accumulation is always fp32). */
+enum { VV_PREC_F16 = 0, VV_PREC_BF16 = 1 };
+
+/* Loss norm: MaxMarginLossParameter.Norm (src/caffe/proto/caffe.proto:858-863). */
+enum { VV_NORM_L1 = 1, VV_NORM_L2 = 2 };
+/* SolverParameter.regularization_type (caffe.proto:130-132). */
+enum { VV_REG_L1 = 1, VV_REG_L2 = 2 };
+
+/* One context per process / GPU.  Replaces Caffe::SetDevice + Caffe::set_mode(GPU)
+ * (src/caffe/common.cpp:127-145, tools/caffe.cpp:92-104). */
+int vv_create(int device, int prec, vv_ctx** out);
+int vv_destroy(vv_ctx* ctx);
+const char* vv_last_error(void);
+const char* vv_version(void);
+/* Run all kernels of this context on an existing hipStream_t (NULL = the context's own stream).
+ * The reference has only the default CUDA stream. */
+int vv_set_stream(vv_ctx* ctx, void* hip_stream);
+int vv_synchronize(vv_ctx* ctx);
+
+/* ---- feature table: stands for the rows the data layer copies out of the VideoShots DB
+ * (VideoSampledShotsDataLayer::AddSamplesToTop, src/caffe/layers/video_sampled_shots_data_layer.cpp:
+ * 439-452, and BasePrefetchingDataLayer::Forward_gpu's H2D copy, base_data_layer.cu:7-21).  The
+ * table stays resident in HBM; a batch is then just row indices.  rows: host fp32 [n_rows][F]. */
+int vv_table_set(vv_ctx* ctx, const float* rows, int64_t n_rows, int32_t F);
+/* Fill the table with the synthetic features of videovector_amd/synth.py (integer hashing only,
+ * bit-identical to the host generator). */
+int vv_table_synth(vv_ctx* ctx, uint64_t seed, int64_t n_rows, int32_t F);
+/* Read rows back as fp32 (host [n][F]); rows == NULL means 0..n-1. */
+int vv_table_get(vv_ctx* ctx, const int32_t* rows, int64_t n, float* out);
+
+/* ---- fc7 parameters and SGD history.  InnerProductLayer blobs_[0] (1,1,D,F) row-major D x F and
+ * blobs_[1] (1,1,1,D) (src/caffe/layers/inner_product_layer.cpp:29,36); SGDSolver::history_
+ * (include/caffe/solver.hpp:79,91).  NULL history = zeros.  All host fp32. */
+int vv_params_set(vv_ctx* ctx, int32_t D, const float* W, const float* b, const float* hW,
+                  const float* hb);
+int vv_params_get(vv_ctx* ctx, float* W, float* b, float* hW, float* hb);
+
+/* ---- one training iteration */
+typedef struct {
+  /* shapes: VideoSampledShotsDataParameter batch_size / context_size / num_negative_samples
+   * (caffe.proto:562-620); F and D come from the table and the parameters. */
+  int32_t B, C, Nn;
+  /* MAX_MARGIN_LOSS (src/caffe/layers/max_margin_loss_layer.cpp:39-40, caffe.proto:858-868) and
+   * the loss weight of its first top (include/caffe/layer.hpp:416-422). */
+  float margin;
+  int32_t norm;
+  float loss_weight;
+  /* ELTWISE SUM coefficients of context_average (eltwise_layer.cpp:22-32); host [C-1], NULL =
+   * 1/(C-1) each (the shipped prototxt's 0.25 x 4). */
+  const float* ctx_coeff;
+  /* DROPOUT on ip2 (dropout_layer.cpp:13-22): ratio 0 = layer absent.  mask: host uint8
+   * [(C+Nn)*B][D] in the reference's row order (row = ch*B + b), 1 = keep; NULL = a counter-based
+   * mask from dropout_seed and the iteration counter. */
+  float dropout_ratio;
+  const uint8_t* dropout_mask;
+  uint64_t dropout_seed;
+  /* Loss normaliser for data-parallel shards: the GLOBAL B*Nn; 0 = this batch's B*Nn
+   * (max_margin_loss_layer.cpp:67 uses the local count; there is no multi-GPU in the reference). */
+  int64_t global_count;
+  /* SGDSolver::ComputeUpdateValue (src/caffe/solver.cpp:485-531): rate from the lr policy,
+   * momentum, weight_decay, per-blob blobs_lr / weight_decay multipliers {W, b}, regulariser. */
+  float lr, momentum, weight_decay;
+  float lr_mult[2], decay_mult[2];
+  int32_t reg;
+} vv_step_cfg;
+
+/* Defaults of the shipped project files (mednet_embedding_train.prototxt:195-198,655-671,
+ * mednet_embedding_train_solver.prototxt:12-14): margin 2, L2, loss_weight 1, no dropout,
+ * momentum .9, weight_decay 5e-4, lr_mult {1,2}, decay_mult {1,0}, L2 regulariser. */
+void vv_step_cfg_default(vv_step_cfg* cfg);
+
+/* Net::ForwardBackward (include/caffe/net.hpp:78-83) over the videovec TRAIN graph
+ * (projects/videovec_embedding/mednet_embedding_train.prototxt:1-671):
+ * gather -> fc7 -> ReLU(-> dropout) -> context mean -> L2 normalise -> dot-product scores ->
+ * max-margin loss, and its backward down to the fc7 parameter gradients.
+ * idx: int32 [B][C+Nn] table rows exactly as the data layer lays out its top blob
+ * (video_sampled_shots_data_layer.cpp:214-220: channel 0 target, 1..C-1 context, C.. negatives),
+ * -1 = all-zero row; idx_on_device != 0 means idx is a device pointer. */
+int vv_forward_backward(vv_ctx* ctx, const vv_step_cfg* cfg, const int32_t* idx, int idx_on_device);
+/* SGDSolver::ComputeUpdateValue + Net::Update (solver.cpp:485-531, net.cpp:803-839,
+ * blob.cpp:112-136) on the gradients currently in the gradient buffer. */
+int vv_apply_update(vv_ctx* ctx, const vv_step_cfg* cfg);
+/* Both of the above: one iteration of Solver::Solve's loop body (solver.cpp:194,219-220). */
+int vv_step(vv_ctx* ctx, const vv_step_cfg* cfg, const int32_t* idx, int idx_on_device);
+
+/* Loss (already multiplied by loss_weight) and train_violations of the last forward; synchronises.
+ * (the two tops of MAX_MARGIN_LOSS, max_margin_loss_layer.cpp:111-126.) */
+int vv_loss_get(vv_ctx* ctx, float* loss, float* violations);
+
+/* ---- gradients.  The flat fp32 device buffer [dW (D*F) | db (D)] that a data-parallel host
+ * all-reduces (RCCL) between vv_forward_backward and vv_apply_update; there is no counterpart in
+ * the reference (single GPU). */
+int vv_grads_device(vv_ctx* ctx, void** dev_ptr, int64_t* n_floats);
+/* Make the context write its gradients into caller-owned device memory of D*F + D floats (e.g. a
+ * tensor of the collective library); NULL returns to the context's own buffer. */
+int vv_grads_bind(vv_ctx* ctx, void* dev_ptr);
+/* InnerProductLayer blobs_[0]/[1] cpu_diff() after Backward (inner_product_layer.cpp:76-98). */
+int vv_grads_get(vv_ctx* ctx, float* dW, float* db);
+
+/* ---- inspection of named blobs of the last forward (Net::blob_by_name, net.cpp:846-857);
+ * every output optional (NULL).  Host fp32, in the reference's layouts:
+ *   ip2          [(C+Nn)*B][D]  row = ch*B + b   (after ReLU / dropout)
+ *   target_score [B][Nn], negative_scores [B][Nn]
+ *   ip2_diff     [(C+Nn)*B][D]  the diff of ip1_nonorm */
+int vv_blobs_get(vv_ctx* ctx, float* ip2, float* target_score, float* negative_scores,
+                 float* ip1_diff);
+
+/* ---- inference: fc7 (+ReLU) (+L2 normalise) of arbitrary table rows -- the extract_features path
+ * (tools/extract_features.cpp:99-198 over videovec_extraction.prototxt:179-205) and the TEST
+ * branch's embedding (mednet_embedding_train.prototxt:344-352).  rows host int32 [n] (NULL = 0..n-1),
+ * out host fp32 [n][D]. */
+int vv_embed(vv_ctx* ctx, const int32_t* rows, int64_t n, int relu, int l2norm, float* out);
+
+/* ---- triplet sampler (host side, integer only).  Replaces VideoSampledShotsDataLayer's
+ * DataLayerSetUp / AddSamplesToTop / InternalThreadEntry / AddToBuffer / RandomShuffleTopids
+ * (src/caffe/layers/video_sampled_shots_data_layer.cpp:24-44,64-369,371-507,768-909) with the
+ * feature copies replaced by table-row indices.  The draw order of the reference's libc rand()
+ * stream (never seeded => glibc seed 1), include/caffe/util/rng.hpp:43-54's random_unique and
+ * libstdc++'s std::random_shuffle are reproduced exactly, so indices are bit-identical.
+ * One DB record = one video: record v has video_id[v], n_shots[v] frames whose features are table
+ * rows row_base[v] .. row_base[v]+n_shots[v]-1, and shot ids shot_ids[shot_off..] (NULL = 0..n-1).
+ * Only context_type WINDOW (caffe.proto VideoSampledShotsDataParameter.ContextType) is built. */
+typedef struct vv_sampler vv_sampler;
+typedef struct {
+  int32_t batch_size, context_size, num_negative_samples;
+  int32_t max_buffer_size, negative_swap_percentage, max_same_video_negs;
+  int32_t max_tries_for_negs;      /* gflag --max_tries_for_negs, default 100 (...data_layer.cpp:20) */
+} vv_sampler_param;
+void vv_sampler_param_default(vv_sampler_param* p);
+int vv_sampler_create(const vv_sampler_param* p, int32_t n_videos, const int32_t* video_id,
+                      const int32_t* n_shots, const int64_t* row_base, const int32_t* shot_ids,
+                      vv_sampler** out);
+/* One prefetch batch.  idx / last_src: int32 [batch_size][context_size + num_negative_samples]
+ * (last_src: the row whose LAST feature the slot holds -- differs from idx only for same-video
+ * negatives, which the reference copies without their last element, ...data_layer.cpp:492; -1 =
+ * zero); label: int32 [batch_size] video ids (...:879).  Any output may be NULL. */
+int vv_sampler_next(vv_sampler* s, int32_t* idx, int32_t* last_src, int32_t* label);
+int vv_sampler_destroy(vv_sampler* s);
+
+/* Timing hook for the benchmark: average device time in ms of one named kernel ("fwd_gemm",
+ * "score_loss", "wgrad_gemm", "reduce", "sgd") over the launches since the last reset, measured
+ * with hipEvents on the context's stream (only while enabled; enabling adds two event records
+ * per launch). */
+int vv_profile_enable(vv_ctx* ctx, int on);
+int vv_profile_get(vv_ctx* ctx, const char* kernel, double* avg_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

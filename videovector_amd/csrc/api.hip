@@ -1,0 +1,585 @@
+// api.hip -- implementation of the C ABI in include/videovec.h (gfx950 / HIP only; there is no CPU
+// fallback: every entry point fails with VV_ERR_NOGPU / VV_ERR_HIP when no device is usable).
+#include "../../include/videovec.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "vv_internal.h"
+
+namespace vv { void set_wgrad_tr(bool on); void set_gemm_variant(int v); int wgrad_max_ksteps_per_split(); }
+using namespace vv;
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIPCHK(x)                                                                              \
+  do {                                                                                         \
+    hipError_t e_ = (x);                                                                       \
+    if (e_ != hipSuccess)                                                                      \
+      return fail(VV_ERR_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__,    \
+                  __LINE__);                                                                   \
+  } while (0)
+
+struct ProfEntry { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; };
+
+struct vv_ctx {
+  int device = 0, prec = 0;
+  hipStream_t stream = nullptr, own_stream = nullptr;
+  // feature table
+  uint16_t* table = nullptr; int64_t n_rows = 0; int F = 0, Fp = 0; float sx = 1.f;
+  // parameters
+  int D = 0, Dp = 0;
+  float *W = nullptr, *b = nullptr, *hW = nullptr, *hb = nullptr;
+  uint16_t* Wh = nullptr; Scales* scales = nullptr; float* wmax_blocks = nullptr;
+  float* grads = nullptr;           // [D*F + D] (own buffer, or the bound external one)
+  float* grads_own = nullptr;
+  // per-batch buffers
+  int B = 0, C = 0, Nn = 0, R = 0, Rp = 0;
+  int32_t *idx_dev = nullptr, *rows = nullptr;
+  float* H = nullptr; uint16_t* dYh = nullptr; float* dbp = nullptr;
+  float *loss_part = nullptr, *viol_part = nullptr, *s_true = nullptr, *s_bogus = nullptr;
+  float* coeff = nullptr; std::vector<float> coeff_host;
+  uint8_t* mask = nullptr; size_t mask_bytes = 0;
+  float* slabs = nullptr; size_t slab_bytes = 0; int S = 1, kps = 0;
+  float* loss2 = nullptr;           // {loss, violations}
+  float sg = 1.f; float last_loss_weight = 1.f;
+  uint64_t iter = 0;
+  bool have_fwd = false;
+  // profiling
+  bool prof = false;
+  std::map<std::string, ProfEntry> prof_map;
+};
+
+static void dfree(void* p) { if (p) (void)hipFree(p); }
+
+static void prof_begin(vv_ctx* c, const char* name, hipEvent_t* e0, hipEvent_t* e1) {
+  *e0 = *e1 = nullptr;
+  if (!c->prof) return;
+  auto& pe = c->prof_map[name];
+  if (pe.ev.size() >= 8192) return;
+  if (hipEventCreate(e0) != hipSuccess || hipEventCreate(e1) != hipSuccess) { *e0 = *e1 = nullptr; return; }
+  (void)hipEventRecord(*e0, c->stream);
+}
+static void prof_end(vv_ctx* c, const char* name, hipEvent_t e0, hipEvent_t e1) {
+  if (!e0) return;
+  (void)hipEventRecord(e1, c->stream);
+  c->prof_map[name].ev.emplace_back(e0, e1);
+}
+#define PROFILED(c, name, call)                 \
+  do {                                          \
+    hipEvent_t e0_, e1_;                        \
+    prof_begin(c, name, &e0_, &e1_);            \
+    call;                                       \
+    prof_end(c, name, e0_, e1_);                \
+  } while (0)
+
+extern "C" {
+
+const char* vv_last_error(void) { return g_err; }
+const char* vv_version(void) { return "videovec-mi355x 0.1 (gfx950)"; }
+
+void vv_step_cfg_default(vv_step_cfg* cfg) {
+  memset(cfg, 0, sizeof(*cfg));
+  cfg->margin = 2.0f; cfg->norm = VV_NORM_L2; cfg->loss_weight = 1.0f;
+  cfg->momentum = 0.9f; cfg->weight_decay = 5e-4f; cfg->lr = 1e-3f;
+  cfg->lr_mult[0] = 1.f; cfg->lr_mult[1] = 2.f;
+  cfg->decay_mult[0] = 1.f; cfg->decay_mult[1] = 0.f;
+  cfg->reg = VV_REG_L2;
+}
+
+int vv_create(int device, int prec, vv_ctx** out) {
+  if (!out) return fail(VV_ERR_ARG, "vv_create: out is NULL");
+  if (prec != VV_PREC_F16 && prec != VV_PREC_BF16) return fail(VV_ERR_ARG, "vv_create: bad prec %d", prec);
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(VV_ERR_NOGPU, "vv_create: no HIP device visible (this library has no CPU path)");
+  if (device < 0 || device >= n) return fail(VV_ERR_ARG, "vv_create: device %d out of range (%d)", device, n);
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(VV_ERR_NOGPU, "vv_create: device %d is %s; this build targets gfx950 only", device,
+                prop.gcnArchName);
+  vv_ctx* c = new vv_ctx();
+  c->device = device; c->prec = prec;
+  HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  c->stream = c->own_stream;
+  HIPCHK(hipMalloc(&c->scales, sizeof(Scales)));
+  Scales h = {1.f, 1.f, 1.f, 0u};
+  HIPCHK(hipMemcpy(c->scales, &h, sizeof(h), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc(&c->wmax_blocks, SGD_BLOCKS * sizeof(float)));
+  HIPCHK(hipMemset(c->wmax_blocks, 0, SGD_BLOCKS * sizeof(float)));
+  HIPCHK(hipMalloc(&c->loss2, 2 * sizeof(float)));
+  HIPCHK(hipMemset(c->loss2, 0, 2 * sizeof(float)));
+  const char* tr = getenv("VV_WGRAD_TR");
+  if (tr) set_wgrad_tr(atoi(tr) != 0);
+  const char* gv = getenv("VV_GEMM_VARIANT");
+  if (gv) set_gemm_variant(atoi(gv));
+  *out = c;
+  return VV_OK;
+}
+
+static void free_batch(vv_ctx* c) {
+  dfree(c->idx_dev); dfree(c->rows); dfree(c->H); dfree(c->dYh); dfree(c->dbp);
+  dfree(c->loss_part); dfree(c->viol_part); dfree(c->s_true); dfree(c->s_bogus);
+  dfree(c->coeff); dfree(c->slabs);
+  c->idx_dev = c->rows = nullptr; c->H = nullptr; c->dYh = nullptr; c->dbp = nullptr;
+  c->loss_part = c->viol_part = c->s_true = c->s_bogus = c->coeff = nullptr; c->slabs = nullptr;
+  c->slab_bytes = 0; c->B = c->C = c->Nn = c->R = c->Rp = 0; c->coeff_host.clear();
+  c->have_fwd = false;
+}
+
+int vv_destroy(vv_ctx* c) {
+  if (!c) return VV_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  free_batch(c);
+  dfree(c->table); dfree(c->W); dfree(c->b); dfree(c->hW); dfree(c->hb); dfree(c->Wh);
+  dfree(c->scales); dfree(c->wmax_blocks); dfree(c->grads_own); dfree(c->mask); dfree(c->loss2);
+  for (auto& kv : c->prof_map)
+    for (auto& e : kv.second.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+  return VV_OK;
+}
+
+int vv_set_stream(vv_ctx* c, void* s) {
+  if (!c) return fail(VV_ERR_ARG, "vv_set_stream: ctx is NULL");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return VV_OK;
+}
+
+int vv_synchronize(vv_ctx* c) {
+  if (!c) return fail(VV_ERR_ARG, "vv_synchronize: ctx is NULL");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return VV_OK;
+}
+
+// ------------------------------------------------------------------------------- table --------
+static int table_alloc(vv_ctx* c, int64_t n_rows, int F) {
+  if (n_rows <= 0 || F <= 0) return fail(VV_ERR_ARG, "table: n_rows=%lld F=%d", (long long)n_rows, F);
+  if (n_rows >= (1ll << 31) - 1) return fail(VV_ERR_ARG, "table: too many rows for int32 indices");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->D && F != c->F) return fail(VV_ERR_STATE, "table: F=%d differs from the parameters' F=%d", F, c->F);
+  dfree(c->table); c->table = nullptr;
+  c->n_rows = n_rows; c->F = F; c->Fp = (int)round_up(F, F_ALIGN);
+  const size_t bytes = (size_t)(n_rows + 1) * c->Fp * sizeof(uint16_t);   // +1: the all-zero row
+  HIPCHK(hipMalloc(&c->table, bytes));
+  HIPCHK(hipMemsetAsync(c->table, 0, bytes, c->stream));
+  return VV_OK;
+}
+
+static int set_sx(vv_ctx* c, float sx) {
+  c->sx = sx;
+  HIPCHK(hipMemcpyAsync(&c->scales->sx, &c->sx, sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return VV_OK;
+}
+
+int vv_table_set(vv_ctx* c, const float* rows, int64_t n_rows, int32_t F) {
+  if (!c || !rows) return fail(VV_ERR_ARG, "vv_table_set: NULL argument");
+  int rc = table_alloc(c, n_rows, F);
+  if (rc) return rc;
+  // range guard for f16: keep max|x|*sx inside [2^-8, 2^14]; otherwise move it to ~2^8
+  float mx = 0.f;
+  for (int64_t i = 0; i < n_rows * F; ++i) {
+    const float v = fabsf(rows[i]);
+    if (!(v <= 3.0e38f)) return fail(VV_ERR_ARG, "vv_table_set: non-finite feature at %lld", (long long)i);
+    if (v > mx) mx = v;
+  }
+  float sx = 1.f;
+  if (c->prec == VV_PREC_F16 && mx > 0.f && (mx > 16384.f || mx < 1.f / 256.f)) {
+    int e; frexpf(mx, &e); sx = ldexpf(1.f, 8 - e);
+  }
+  if ((rc = set_sx(c, sx))) return rc;
+  const int64_t chunk_rows = std::max<int64_t>(1, (64ll << 20) / ((int64_t)F * 4));
+  float* stage = nullptr;
+  HIPCHK(hipMalloc(&stage, (size_t)chunk_rows * F * sizeof(float)));
+  for (int64_t r0 = 0; r0 < n_rows; r0 += chunk_rows) {
+    const int64_t nr = std::min(chunk_rows, n_rows - r0);
+    hipError_t e = hipMemcpyAsync(stage, rows + r0 * F, (size_t)nr * F * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) { dfree(stage); return fail(VV_ERR_HIP, "table upload: %s", hipGetErrorString(e)); }
+    launch_table_convert(c->prec, stage, c->table + r0 * c->Fp, nr, F, c->Fp, sx, c->stream);
+    (void)hipStreamSynchronize(c->stream);
+  }
+  dfree(stage);
+  HIPCHK(hipGetLastError());
+  return VV_OK;
+}
+
+int vv_table_synth(vv_ctx* c, uint64_t seed, int64_t n_rows, int32_t F) {
+  if (!c) return fail(VV_ERR_ARG, "vv_table_synth: ctx is NULL");
+  int rc = table_alloc(c, n_rows, F);
+  if (rc) return rc;
+  if ((rc = set_sx(c, 1.f))) return rc;
+  launch_table_synth(c->prec, c->table, seed, n_rows, F, c->Fp, 1.f, c->stream);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return VV_OK;
+}
+
+int vv_table_get(vv_ctx* c, const int32_t* rows, int64_t n, float* out) {
+  if (!c || !out || n <= 0) return fail(VV_ERR_ARG, "vv_table_get: bad argument");
+  if (!c->table) return fail(VV_ERR_STATE, "vv_table_get: no table");
+  HIPCHK(hipSetDevice(c->device));
+  int32_t* drows = nullptr; float* dout = nullptr;
+  if (rows) {
+    for (int64_t i = 0; i < n; ++i)
+      if (rows[i] < 0 || rows[i] >= c->n_rows) return fail(VV_ERR_ARG, "vv_table_get: row %d out of range", rows[i]);
+    HIPCHK(hipMalloc(&drows, n * sizeof(int32_t)));
+    HIPCHK(hipMemcpy(drows, rows, n * sizeof(int32_t), hipMemcpyHostToDevice));
+  } else if (n > c->n_rows) return fail(VV_ERR_ARG, "vv_table_get: n > n_rows");
+  HIPCHK(hipMalloc(&dout, (size_t)n * c->F * sizeof(float)));
+  launch_table_read(c->prec, c->table, drows, n, c->F, c->Fp, 1.f / c->sx, dout, c->stream);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(out, dout, (size_t)n * c->F * sizeof(float), hipMemcpyDeviceToHost));
+  dfree(drows); dfree(dout);
+  return VV_OK;
+}
+
+// ------------------------------------------------------------------------------- params -------
+int vv_params_set(vv_ctx* c, int32_t D, const float* W, const float* b, const float* hW,
+                  const float* hb) {
+  if (!c || !W || D <= 0) return fail(VV_ERR_ARG, "vv_params_set: bad argument");
+  if (!c->table) return fail(VV_ERR_STATE, "vv_params_set: set the feature table first (defines F)");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const int F = c->F;
+  const size_t nW = (size_t)D * F;
+  if (D != c->D) {
+    dfree(c->W); dfree(c->b); dfree(c->hW); dfree(c->hb); dfree(c->Wh); dfree(c->grads_own);
+    c->W = c->b = c->hW = c->hb = nullptr; c->Wh = nullptr; c->grads = c->grads_own = nullptr;
+    c->D = D; c->Dp = (int)round_up(D, D_ALIGN);
+    HIPCHK(hipMalloc(&c->W, nW * 4)); HIPCHK(hipMalloc(&c->hW, nW * 4));
+    HIPCHK(hipMalloc(&c->b, D * 4)); HIPCHK(hipMalloc(&c->hb, D * 4));
+    HIPCHK(hipMalloc(&c->Wh, (size_t)c->Dp * c->Fp * 2));
+    HIPCHK(hipMemset(c->Wh, 0, (size_t)c->Dp * c->Fp * 2));
+    HIPCHK(hipMalloc(&c->grads_own, (nW + D) * 4));
+    HIPCHK(hipMemset(c->grads_own, 0, (nW + D) * 4));
+    c->grads = c->grads_own;
+    free_batch(c);
+  }
+  HIPCHK(hipMemcpy(c->W, W, nW * 4, hipMemcpyHostToDevice));
+  if (b) HIPCHK(hipMemcpy(c->b, b, D * 4, hipMemcpyHostToDevice)); else HIPCHK(hipMemset(c->b, 0, D * 4));
+  if (hW) HIPCHK(hipMemcpy(c->hW, hW, nW * 4, hipMemcpyHostToDevice)); else HIPCHK(hipMemset(c->hW, 0, nW * 4));
+  if (hb) HIPCHK(hipMemcpy(c->hb, hb, D * 4, hipMemcpyHostToDevice)); else HIPCHK(hipMemset(c->hb, 0, D * 4));
+  // scale for the half copy from max|W|, then convert
+  HIPCHK(hipMemsetAsync(&c->scales->wmax_bits, 0, sizeof(unsigned), c->stream));
+  launch_absmax(c->W, (int64_t)nW, &c->scales->wmax_bits, c->stream);
+  launch_scale_update(c->prec, c->scales, nullptr, c->stream);
+  launch_w_convert(c->prec, c->W, c->Wh, D, F, c->Dp, c->Fp, c->scales, c->stream);
+  // seed the running max for the first SGD step's scale update
+  launch_absmax(c->W, (int64_t)nW, &c->scales->wmax_bits, c->stream);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->have_fwd = false;
+  return VV_OK;
+}
+
+int vv_params_get(vv_ctx* c, float* W, float* b, float* hW, float* hb) {
+  if (!c) return fail(VV_ERR_ARG, "vv_params_get: ctx is NULL");
+  if (!c->W) return fail(VV_ERR_STATE, "vv_params_get: no parameters");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const size_t nW = (size_t)c->D * c->F;
+  if (W) HIPCHK(hipMemcpy(W, c->W, nW * 4, hipMemcpyDeviceToHost));
+  if (b) HIPCHK(hipMemcpy(b, c->b, c->D * 4, hipMemcpyDeviceToHost));
+  if (hW) HIPCHK(hipMemcpy(hW, c->hW, nW * 4, hipMemcpyDeviceToHost));
+  if (hb) HIPCHK(hipMemcpy(hb, c->hb, c->D * 4, hipMemcpyDeviceToHost));
+  return VV_OK;
+}
+
+// ------------------------------------------------------------------------------- step ---------
+static int ensure_batch(vv_ctx* c, int B, int C, int Nn) {
+  if (B == c->B && C == c->C && Nn == c->Nn && c->H) return VV_OK;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  free_batch(c);
+  const int CN = C + Nn;
+  const int64_t R64 = (int64_t)B * CN;
+  if (R64 > (1ll << 30)) return fail(VV_ERR_ARG, "batch too large");
+  c->B = B; c->C = C; c->Nn = Nn; c->R = (int)R64; c->Rp = (int)round_up(R64, R_ALIGN);
+  const int D = c->D;
+  HIPCHK(hipMalloc(&c->idx_dev, (size_t)c->R * 4));
+  HIPCHK(hipMalloc(&c->rows, (size_t)c->Rp * 4));
+  HIPCHK(hipMalloc(&c->H, (size_t)c->R * D * 4));
+  HIPCHK(hipMalloc(&c->dYh, (size_t)c->Rp * c->Dp * 2));
+  HIPCHK(hipMemset(c->dYh, 0, (size_t)c->Rp * c->Dp * 2));     // padding rows / columns stay zero
+  HIPCHK(hipMalloc(&c->dbp, (size_t)B * D * 4));
+  HIPCHK(hipMalloc(&c->loss_part, (size_t)B * 4));
+  HIPCHK(hipMalloc(&c->viol_part, (size_t)B * 4));
+  HIPCHK(hipMalloc(&c->s_true, (size_t)B * 4));
+  HIPCHK(hipMalloc(&c->s_bogus, (size_t)B * std::max(Nn, 1) * 4));
+  HIPCHK(hipMalloc(&c->coeff, (size_t)std::max(C - 1, 1) * 4));
+  // split-K so that tiles * S is about one wave of workgroups over the 256 CUs
+  const int tiles = (c->Dp / BM) * (c->Fp / BN);
+  const int total_steps = c->Rp / BK;
+  int S = (256 + tiles - 1) / tiles;
+  if (S > total_steps) S = total_steps;
+  if (S < 1) S = 1;
+  // the ring kernel keeps the split's row ids in LDS: bound the K range of one split
+  while ((total_steps + S - 1) / S > wgrad_max_ksteps_per_split() && S < total_steps) ++S;
+  c->S = S; c->kps = (total_steps + S - 1) / S;
+  c->slab_bytes = (size_t)S * c->Dp * c->Fp * 4;
+  HIPCHK(hipMalloc(&c->slabs, c->slab_bytes));
+  return VV_OK;
+}
+
+static int check_cfg(vv_ctx* c, const vv_step_cfg* cfg) {
+  if (!c || !cfg) return fail(VV_ERR_ARG, "NULL ctx / cfg");
+  if (!c->table || !c->W) return fail(VV_ERR_STATE, "table and parameters must be set first");
+  if (cfg->B < 1) return fail(VV_ERR_ARG, "batch_size must be >= 1 (video_sampled_shots_data_layer.cpp:209)");
+  if (cfg->C < 2) return fail(VV_ERR_ARG, "context_size must be >= 2 (video_sampled_shots_data_layer.cpp:207)");
+  if (cfg->Nn < 1) return fail(VV_ERR_ARG, "num_negative_samples must be >= 1 for the ranking loss");
+  if (cfg->norm != VV_NORM_L1 && cfg->norm != VV_NORM_L2) return fail(VV_ERR_ARG, "Unknown Norm (max_margin_loss_layer.cpp:120)");
+  if (cfg->dropout_ratio < 0.f || cfg->dropout_ratio >= 1.f) return fail(VV_ERR_ARG, "dropout_ratio must be in [0,1)");
+  if (cfg->reg != VV_REG_L1 && cfg->reg != VV_REG_L2) return fail(VV_ERR_ARG, "Unknown regularization type (solver.cpp:523)");
+  return VV_OK;
+}
+
+int vv_forward_backward(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int idx_on_device) {
+  int rc = check_cfg(c, cfg);
+  if (rc) return rc;
+  if (!idx) return fail(VV_ERR_ARG, "vv_forward_backward: idx is NULL");
+  HIPCHK(hipSetDevice(c->device));
+  if ((rc = ensure_batch(c, cfg->B, cfg->C, cfg->Nn))) return rc;
+  const int B = c->B, C = c->C, Nn = c->Nn, CN = C + Nn, D = c->D;
+  hipStream_t s = c->stream;
+
+  const int32_t* didx = idx;
+  if (!idx_on_device) {
+    for (int i = 0; i < c->R; ++i)
+      if (idx[i] < -1 || idx[i] >= c->n_rows) return fail(VV_ERR_ARG, "idx[%d] = %d out of range [-1, %lld)", i, idx[i], (long long)c->n_rows);
+    HIPCHK(hipMemcpyAsync(c->idx_dev, idx, (size_t)c->R * 4, hipMemcpyHostToDevice, s));
+    didx = c->idx_dev;
+  }
+  launch_map_rows(didx, c->rows, c->R, c->Rp, (int32_t)c->n_rows, s);
+
+  // eltwise coefficients (cached on the device until they change)
+  std::vector<float> coeff(C - 1);
+  for (int j = 0; j < C - 1; ++j) coeff[j] = cfg->ctx_coeff ? cfg->ctx_coeff[j] : 1.0f / (C - 1);
+  if (coeff != c->coeff_host) {
+    HIPCHK(hipMemcpyAsync(c->coeff, coeff.data(), coeff.size() * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    c->coeff_host = coeff;
+  }
+  if (cfg->dropout_ratio > 0.f && cfg->dropout_mask) {
+    const size_t nb = (size_t)c->R * D;
+    if (nb > c->mask_bytes) { dfree(c->mask); c->mask = nullptr; HIPCHK(hipMalloc(&c->mask, nb)); c->mask_bytes = nb; }
+    HIPCHK(hipMemcpyAsync(c->mask, cfg->dropout_mask, nb, hipMemcpyHostToDevice, s));
+  }
+
+  FwdArgs fa;
+  fa.table = c->table; fa.rows = c->rows; fa.Wh = c->Wh; fa.bias = c->b; fa.scales = c->scales;
+  fa.H = c->H; fa.R = c->R; fa.D = D; fa.Fp = c->Fp; fa.relu = 1;
+  fa.drop_ratio = cfg->dropout_ratio;
+  fa.mask = (cfg->dropout_ratio > 0.f && cfg->dropout_mask) ? c->mask : nullptr;
+  fa.drop_seed = cfg->dropout_seed * 0x9E3779B97F4A7C15ull + c->iter;
+  fa.B = B; fa.CN = CN;
+  PROFILED(c, "fwd_gemm", launch_fwd_gemm(c->prec, fa, s));
+
+  const int64_t count = (int64_t)B * Nn;
+  const int64_t gcount = cfg->global_count > 0 ? cfg->global_count : count;
+  // half-precision gradient scale: a power of two near the loss count keeps dY*sg around 1
+  int e; frexpf((float)gcount, &e);
+  c->sg = c->prec == VV_PREC_F16 ? ldexpf(1.f, e) : 1.f;
+  c->last_loss_weight = cfg->loss_weight;
+
+  ScoreArgs sa;
+  sa.H = c->H; sa.dYh = c->dYh; sa.dbp = c->dbp; sa.loss_part = c->loss_part; sa.viol_part = c->viol_part;
+  sa.s_true = c->s_true; sa.s_bogus = c->s_bogus; sa.coeff = c->coeff;
+  sa.B = B; sa.C = C; sa.Nn = Nn; sa.D = D; sa.Dp = c->Dp;
+  sa.margin = cfg->margin; sa.norm = cfg->norm;
+  sa.grad_scale = cfg->loss_weight / (float)gcount;
+  sa.drop_scale = cfg->dropout_ratio > 0.f ? 1.f / (1.f - cfg->dropout_ratio) : 1.f;
+  sa.sg = c->sg;
+  PROFILED(c, "score_loss", launch_score_loss(c->prec, sa, s));
+  launch_final_loss(c->loss_part, c->viol_part, B, cfg->loss_weight / (float)count, c->loss2, s);
+
+  WgradArgs wa;
+  wa.dYh = c->dYh; wa.table = c->table; wa.rows = c->rows; wa.slabs = c->slabs;
+  wa.Rp = c->Rp; wa.Dp = c->Dp; wa.Fp = c->Fp; wa.S = c->S; wa.ksteps_per_split = c->kps;
+  PROFILED(c, "wgrad_gemm", launch_wgrad_gemm(c->prec, wa, s));
+
+  ReduceArgs ra;
+  ra.slabs = c->slabs; ra.S = c->S; ra.Dp = c->Dp; ra.Fp = c->Fp; ra.dbp = c->dbp; ra.B = B;
+  ra.scales = c->scales; ra.sg = c->sg; ra.grads = c->grads; ra.D = D; ra.F = c->F; ra.ip_scale = 1.f;
+  PROFILED(c, "reduce", launch_reduce(ra, s));
+
+  HIPCHK(hipGetLastError());
+  c->have_fwd = true;
+  return VV_OK;
+}
+
+int vv_apply_update(vv_ctx* c, const vv_step_cfg* cfg) {
+  int rc = check_cfg(c, cfg);
+  if (rc) return rc;
+  if (!c->have_fwd) return fail(VV_ERR_STATE, "vv_apply_update: no gradients (call vv_forward_backward)");
+  HIPCHK(hipSetDevice(c->device));
+  SgdArgs a;
+  a.W = c->W; a.b = c->b; a.hW = c->hW; a.hb = c->hb; a.grads = c->grads; a.Wh = c->Wh; a.scales = c->scales; a.wmax_blocks = c->wmax_blocks;
+  a.D = c->D; a.F = c->F; a.Dp = c->Dp; a.Fp = c->Fp;
+  a.rate = cfg->lr; a.momentum = cfg->momentum; a.weight_decay = cfg->weight_decay;
+  a.lr_mult_w = cfg->lr_mult[0]; a.lr_mult_b = cfg->lr_mult[1];
+  a.decay_mult_w = cfg->decay_mult[0]; a.decay_mult_b = cfg->decay_mult[1];
+  a.reg = cfg->reg;
+  PROFILED(c, "sgd", launch_sgd(c->prec, a, c->stream));
+  launch_scale_update(c->prec, c->scales, c->wmax_blocks, c->stream);
+  HIPCHK(hipGetLastError());
+  c->iter++;
+  return VV_OK;
+}
+
+int vv_step(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int idx_on_device) {
+  int rc = vv_forward_backward(c, cfg, idx, idx_on_device);
+  if (rc) return rc;
+  return vv_apply_update(c, cfg);
+}
+
+int vv_loss_get(vv_ctx* c, float* loss, float* violations) {
+  if (!c) return fail(VV_ERR_ARG, "vv_loss_get: ctx is NULL");
+  if (!c->have_fwd) return fail(VV_ERR_STATE, "vv_loss_get: no forward pass yet");
+  HIPCHK(hipSetDevice(c->device));
+  float h[2];
+  HIPCHK(hipMemcpyAsync(h, c->loss2, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (loss) *loss = h[0];
+  if (violations) *violations = h[1];
+  return VV_OK;
+}
+
+int vv_grads_device(vv_ctx* c, void** dev_ptr, int64_t* n_floats) {
+  if (!c || !dev_ptr || !n_floats) return fail(VV_ERR_ARG, "vv_grads_device: NULL argument");
+  if (!c->grads) return fail(VV_ERR_STATE, "vv_grads_device: no parameters");
+  *dev_ptr = c->grads;
+  *n_floats = (int64_t)c->D * c->F + c->D;
+  return VV_OK;
+}
+
+int vv_grads_bind(vv_ctx* c, void* dev_ptr) {
+  if (!c) return fail(VV_ERR_ARG, "vv_grads_bind: ctx is NULL");
+  if (!c->grads_own) return fail(VV_ERR_STATE, "vv_grads_bind: no parameters");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->grads = dev_ptr ? (float*)dev_ptr : c->grads_own;
+  c->have_fwd = false;
+  return VV_OK;
+}
+
+int vv_grads_get(vv_ctx* c, float* dW, float* db) {
+  if (!c) return fail(VV_ERR_ARG, "vv_grads_get: ctx is NULL");
+  if (!c->have_fwd) return fail(VV_ERR_STATE, "vv_grads_get: no backward pass yet");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const size_t nW = (size_t)c->D * c->F;
+  if (dW) HIPCHK(hipMemcpy(dW, c->grads, nW * 4, hipMemcpyDeviceToHost));
+  if (db) HIPCHK(hipMemcpy(db, c->grads + nW, c->D * 4, hipMemcpyDeviceToHost));
+  return VV_OK;
+}
+
+int vv_blobs_get(vv_ctx* c, float* ip2, float* target_score, float* negative_scores, float* ip1_diff) {
+  if (!c) return fail(VV_ERR_ARG, "vv_blobs_get: ctx is NULL");
+  if (!c->have_fwd) return fail(VV_ERR_STATE, "vv_blobs_get: no forward pass yet");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const int B = c->B, CN = c->C + c->Nn, D = c->D, Nn = c->Nn;
+  const size_t n = (size_t)c->R * D;
+  auto reorder = [&](const std::vector<float>& src, float* dst) {   // (b*CN+ch) -> (ch*B+b)
+    for (int bb = 0; bb < B; ++bb)
+      for (int ch = 0; ch < CN; ++ch)
+        memcpy(dst + ((size_t)ch * B + bb) * D, src.data() + ((size_t)bb * CN + ch) * D, (size_t)D * 4);
+  };
+  if (ip2) {
+    std::vector<float> tmp(n);
+    HIPCHK(hipMemcpy(tmp.data(), c->H, n * 4, hipMemcpyDeviceToHost));
+    reorder(tmp, ip2);
+  }
+  if (target_score) {
+    std::vector<float> st(B);
+    HIPCHK(hipMemcpy(st.data(), c->s_true, (size_t)B * 4, hipMemcpyDeviceToHost));
+    for (int bb = 0; bb < B; ++bb) for (int k = 0; k < Nn; ++k) target_score[(size_t)bb * Nn + k] = st[bb];
+  }
+  if (negative_scores) HIPCHK(hipMemcpy(negative_scores, c->s_bogus, (size_t)B * Nn * 4, hipMemcpyDeviceToHost));
+  if (ip1_diff) {
+    float* d = nullptr;
+    HIPCHK(hipMalloc(&d, n * 4));
+    launch_dyh_to_float(c->prec, c->dYh, c->R, D, c->Dp, 1.f / c->sg, d, c->stream);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::vector<float> tmp(n);
+    HIPCHK(hipMemcpy(tmp.data(), d, n * 4, hipMemcpyDeviceToHost));
+    dfree(d);
+    reorder(tmp, ip1_diff);
+  }
+  return VV_OK;
+}
+
+// ------------------------------------------------------------------------------- embed --------
+int vv_embed(vv_ctx* c, const int32_t* rows, int64_t n, int relu, int l2norm, float* out) {
+  if (!c || !out || n <= 0) return fail(VV_ERR_ARG, "vv_embed: bad argument");
+  if (!c->table || !c->W) return fail(VV_ERR_STATE, "vv_embed: table and parameters must be set first");
+  if (n > (1ll << 30)) return fail(VV_ERR_ARG, "vv_embed: n too large");
+  HIPCHK(hipSetDevice(c->device));
+  const int D = c->D;
+  const int Rp = (int)round_up(n, R_ALIGN);
+  std::vector<int32_t> h(Rp, (int32_t)c->n_rows);
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t r = rows ? rows[i] : i;
+    if (r < 0 || r >= c->n_rows) return fail(VV_ERR_ARG, "vv_embed: row %lld out of range", (long long)r);
+    h[i] = (int32_t)r;
+  }
+  int32_t* drows = nullptr; float* dout = nullptr;
+  HIPCHK(hipMalloc(&drows, (size_t)Rp * 4));
+  HIPCHK(hipMalloc(&dout, (size_t)n * D * 4));
+  HIPCHK(hipMemcpyAsync(drows, h.data(), (size_t)Rp * 4, hipMemcpyHostToDevice, c->stream));
+  FwdArgs fa;
+  fa.table = c->table; fa.rows = drows; fa.Wh = c->Wh; fa.bias = c->b; fa.scales = c->scales;
+  fa.H = dout; fa.R = (int)n; fa.D = D; fa.Fp = c->Fp; fa.relu = relu ? 1 : 0;
+  fa.drop_ratio = 0.f; fa.mask = nullptr; fa.drop_seed = 0; fa.B = 1; fa.CN = 1;
+  launch_fwd_gemm(c->prec, fa, c->stream);
+  if (l2norm) launch_row_normalize(dout, (int)n, D, c->stream);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(out, dout, (size_t)n * D * 4, hipMemcpyDeviceToHost));
+  dfree(drows); dfree(dout);
+  return VV_OK;
+}
+
+// ------------------------------------------------------------------------------- profiling ----
+int vv_profile_enable(vv_ctx* c, int on) {
+  if (!c) return fail(VV_ERR_ARG, "vv_profile_enable: ctx is NULL");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (auto& kv : c->prof_map)
+    for (auto& e : kv.second.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  c->prof_map.clear();
+  c->prof = on != 0;
+  return VV_OK;
+}
+
+int vv_profile_get(vv_ctx* c, const char* kernel, double* avg_ms, int64_t* launches) {
+  if (!c || !kernel) return fail(VV_ERR_ARG, "vv_profile_get: NULL argument");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  auto it = c->prof_map.find(kernel);
+  double tot = 0; int64_t n = 0;
+  if (it != c->prof_map.end())
+    for (auto& e : it->second.ev) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { tot += ms; ++n; }
+    }
+  if (avg_ms) *avg_ms = n ? tot / n : 0.0;
+  if (launches) *launches = n;
+  return VV_OK;
+}
+
+}  // extern "C"

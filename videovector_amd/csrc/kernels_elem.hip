@@ -1,0 +1,514 @@
+// kernels_elem.hip -- the HBM-bound kernels of the videovec training step (gfx950 only).
+//
+//   k_score_loss : everything between ip2 and the loss, forward AND backward, one workgroup per
+//                  batch item: context mean, the two L2 normalisations, the (1+Nn) dot-product
+//                  scores, max-margin loss + violations, and the gradient w.r.t. ip1_nonorm.
+//                  Replaces SLICE dim 0, ELTWISE SUM, NORMALIZATION x2, CONCAT, ELTWISE PROD x(1+Nn),
+//                  SUM x(1+Nn), CONCAT dim 1, MAX_MARGIN_LOSS (CPU-only in the reference), SPLIT,
+//                  and all their backward passes + ReLU/Dropout backward
+//                  (reference: eltwise_layer.cu:34-119, normalization_layer.cu:10-97,
+//                  sum_layer.cu:10-55, max_margin_loss_layer.cpp:53-214, split_layer.cu:18-33,
+//                  relu_layer.cu:36-59, dropout_layer.cu:44-73).
+//   k_reduce     : split-K slabs -> dW, per-item partials -> db (flat gradient buffer).
+//   k_sgd        : SGDSolver::ComputeUpdateValue + Blob::Update in one pass
+//                  (solver.cpp:502-531, blob.cpp:112-136), also refreshes the half copy of W.
+//   table / conversion helpers.
+#include "vv_internal.h"
+
+namespace vv {
+
+constexpr int SL_THREADS = 256;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-wide sum for 256 threads; red must hold >= 4 floats; result broadcast to all threads
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// ------------------------------------------------------------------------------- score/loss ---
+// Rows of item b: r = b*CN + ch, ch 0 = target, 1..C-1 = context, C.. = negatives.
+// Math:
+//   A = sum_j c_j H[j],  Ah = A/(|A|+eps)
+//   per q in {0, C..}: n_q = |H[q]|, t_q = Ah.H[q], score_q = t_q/(n_q+eps)
+//   d_k = s+ - s-_k, h = max(0, margin - d), loss += h^2 (L2) or |h| (L1), viol += d < 0
+//   g_k = grad_scale * (2h | [h>0]);  c_0 = -sum_k g_k, c_{C+k} = g_k
+//   dAh = sum_q c_q H[q]/(n_q+eps);   dH[q] = c_q (n_q^2 Ah - H[q] t_q)/(n_q^3 + eps)
+//   dA  = (sA dAh - A (A.dAh))/(sA^1.5 + eps), dH[j] = c_j dA
+//   dY  = dH * drop_scale * [H > 0]
+template <typename T, bool VEC>
+__global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int D = a.D, C = a.C, Nn = a.Nn, CN = C + Nn;
+  float* A = sm;               // [D] context mean
+  float* Ah = A + D;           // [D] normalised context mean
+  const int PD = D > 1024 ? D : 1024;
+  float* acc0 = Ah + D;        // [G][D] row-group partial dAh (G*D <= PD)
+  float* acc1 = acc0 + PD;     // [G][D] row-group partial db
+  float* n2 = acc1 + PD;       // [CN] squared norms
+  float* tq = n2 + CN;         // [CN] dots with Ah
+  float* cq = tq + CN;         // [CN] upstream coefficients
+  float* red = cq + CN;        // [8]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* Hb = a.H + (int64_t)b * CN * D;
+  const float eps = 1e-10f;
+
+  // ---- phase 1: context mean (column-parallel) and its norm
+  float ssq = 0.f;
+  for (int d = tid; d < D; d += SL_THREADS) {
+    float s = 0.f;
+    for (int j = 1; j < C; ++j) s += a.coeff[j - 1] * Hb[(int64_t)j * D + d];
+    A[d] = s;
+    ssq += s * s;
+  }
+  const float sA = block_sum(ssq, red);
+  const float nA = sqrtf(sA) + eps;
+  for (int d = tid; d < D; d += SL_THREADS) Ah[d] = A[d] / nA;
+  __syncthreads();
+
+  // ---- phase 2: norms and dots of target / negative rows (one row per wave at a time)
+  for (int qi = wave; qi < 1 + Nn; qi += 4) {
+    const int ch = qi == 0 ? 0 : C + qi - 1;
+    const float* h = Hb + (int64_t)ch * D;
+    float s = 0.f, t = 0.f;
+    if (VEC) {
+      for (int d = lane * 4; d < D; d += 256) {
+        const float4 x = *(const float4*)(h + d);
+        const float4 y = *(const float4*)(Ah + d);
+        s += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+        t += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+      }
+    } else {
+      for (int d = lane; d < D; d += 64) { const float x = h[d]; s += x * x; t += x * Ah[d]; }
+    }
+    s = wave_sum(s); t = wave_sum(t);
+    if (lane == 0) { n2[ch] = s; tq[ch] = t; }
+  }
+  __syncthreads();
+
+  // ---- phase 3: scores, hinge, loss, coefficients
+  const float sp = tq[0] / (sqrtf(n2[0]) + eps);
+  float lsum = 0.f, vsum = 0.f, gsum = 0.f;
+  for (int k = tid; k < Nn; k += SL_THREADS) {
+    const int ch = C + k;
+    const float sn = tq[ch] / (sqrtf(n2[ch]) + eps);
+    const float d = sp - sn;
+    const float h = fmaxf(0.f, a.margin - d);
+    float g;
+    if (a.norm == 2) { lsum += h * h; g = 2.f * h * a.grad_scale; }
+    else { lsum += fabsf(h); g = h > 0.f ? a.grad_scale : 0.f; }
+    vsum += d < 0.f ? 1.f : 0.f;
+    gsum += g;
+    cq[ch] = g;
+    if (a.s_bogus) a.s_bogus[(int64_t)b * Nn + k] = sn;
+  }
+  lsum = block_sum(lsum, red);
+  vsum = block_sum(vsum, red);
+  gsum = block_sum(gsum, red);
+  if (tid == 0) {
+    cq[0] = -gsum;
+    a.loss_part[b] = lsum;
+    a.viol_part[b] = vsum;
+    if (a.s_true) a.s_true[b] = sp;
+  }
+  __syncthreads();
+
+  // ---- phase 4: backward of the normalised target / negative rows, column-parallel: a thread
+  // owns one group of W consecutive columns (16-B loads) and walks the rows of its row group,
+  // keeping its dAh / db partial sums in registers (deterministic order, no atomics).
+  const int64_t rbase = (int64_t)b * CN;
+  constexpr int W = VEC ? 4 : 1;
+  const int Dv = D / W;                       // column groups
+  const int Dvp = Dv < SL_THREADS ? Dv : SL_THREADS;
+  const int G = SL_THREADS / Dvp;             // row groups running side by side
+  if (tid < G * Dvp) {
+    const int rg = tid / Dvp;
+    for (int cg = tid % Dvp; cg < Dv; cg += Dvp) {
+      const int d = cg * W;
+      float ya[W], pa[W], pb[W];
+#pragma unroll
+      for (int e = 0; e < W; ++e) { ya[e] = Ah[d + e]; pa[e] = 0.f; pb[e] = 0.f; }
+      for (int qi = rg; qi < 1 + Nn; qi += G) {
+        const int ch = qi == 0 ? 0 : C + qi - 1;
+        const float c = cq[ch], s = n2[ch], t = tq[ch];
+        const float inv_n = 1.f / (sqrtf(s) + eps);
+        const float inv_den = 1.f / (s * sqrtf(s) + eps);
+        const float* h = Hb + (int64_t)ch * D + d;
+        uint16_t* dy = a.dYh + (rbase + ch) * a.Dp + d;
+        float xv[W];
+        if (VEC) { const float4 x = *(const float4*)h; xv[0] = x.x; xv[1 % W] = x.y; xv[2 % W] = x.z; xv[3 % W] = x.w; }
+        else xv[0] = h[0];
+        uint16_t o[W];
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+          pa[e] += c * xv[e] * inv_n;
+          float g = c * (s * ya[e] - xv[e] * t) * inv_den * a.drop_scale;
+          g = xv[e] > 0.f ? g : 0.f;
+          pb[e] += g;
+          o[e] = T::from_float(g * a.sg);
+        }
+        if (VEC) *(uint2*)dy = make_uint2(o[0] | ((uint32_t)o[1 % W] << 16), o[2 % W] | ((uint32_t)o[3 % W] << 16));
+        else dy[0] = o[0];
+      }
+#pragma unroll
+      for (int e = 0; e < W; ++e) { acc0[rg * D + d + e] = pa[e]; acc1[rg * D + d + e] = pb[e]; }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 5: backward of the context normalisation and mean (column-parallel)
+  float dot = 0.f;
+  for (int d = tid; d < D; d += SL_THREADS) {
+    float u = 0.f;
+    for (int gI = 0; gI < G; ++gI) u += acc0[gI * D + d];
+    acc0[d] = u;                 // each column is owned by one thread from here on
+    dot += A[d] * u;
+  }
+  dot = block_sum(dot, red);
+  const float inv_denA = 1.f / (sA * sqrtf(sA) + eps);
+  for (int d = tid; d < D; d += SL_THREADS) {
+    const float dA = (sA * acc0[d] - A[d] * dot) * inv_denA;
+    float dbv = 0.f;
+    for (int gI = 0; gI < G; ++gI) dbv += acc1[gI * D + d];
+    for (int j = 1; j < C; ++j) {
+      const float x = Hb[(int64_t)j * D + d];
+      float g = a.coeff[j - 1] * dA * a.drop_scale;
+      g = x > 0.f ? g : 0.f;
+      dbv += g;
+      a.dYh[(rbase + j) * a.Dp + d] = T::from_float(g * a.sg);
+    }
+    a.dbp[(int64_t)b * D + d] = dbv;
+  }
+}
+
+void launch_score_loss(int prec, const ScoreArgs& a, hipStream_t s) {
+  const size_t lds = sizeof(float) * ((size_t)2 * a.D + 2 * (a.D > 1024 ? a.D : 1024) + 3 * (a.C + a.Nn) + 8);
+  const bool vec = a.D % 4 == 0;
+  const dim3 grid(a.B), block(SL_THREADS);
+#define VV_SL(T, V)                                                                              \
+  do {                                                                                           \
+    (void)hipFuncSetAttribute((const void*)k_score_loss<T, V>,                                   \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
+    hipLaunchKernelGGL((k_score_loss<T, V>), grid, block, lds, s, a);                            \
+  } while (0)
+  if (prec == 0) { if (vec) VV_SL(F16, true); else VV_SL(F16, false); }
+  else { if (vec) VV_SL(BF16, true); else VV_SL(BF16, false); }
+#undef VV_SL
+}
+
+// loss = scale * sum(loss_part), violations = sum(viol_part); fixed-order (deterministic)
+__global__ void k_final_loss(const float* lp, const float* vp, int B, float scale, float* out2) {
+  __shared__ float red[8];
+  float l = 0.f, v = 0.f;
+  for (int i = threadIdx.x; i < B; i += 256) { l += lp[i]; v += vp[i]; }
+  l = block_sum(l, red);
+  v = block_sum(v, red + 4);
+  if (threadIdx.x == 0) { out2[0] = l * scale; out2[1] = v; }
+}
+void launch_final_loss(const float* lp, const float* vp, int B, float scale, float* out2,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(k_final_loss, dim3(1), dim3(256), 0, s, lp, vp, B, scale, out2);
+}
+
+// ------------------------------------------------------------------------------- reduce -------
+// Blocks [0, nblk_dw) sum the split-K slabs into dW (grid-stride, 16-B accesses); the remaining
+// blocks each own 64 bias columns and sum the per-item partials in a fixed order.
+constexpr int RED_DW_BLOCKS = 2048;
+
+// 16 bias columns per block, 16 row groups, 8 independent loads in flight per thread; the
+// partial sums are combined in a fixed order (bit-reproducible, no atomics)
+__device__ __forceinline__ void reduce_db(const ReduceArgs& a, int blk) {
+  __shared__ float part[16][16];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int d = blk * 16 + tx;
+  float s = 0.f;
+  if (d < a.D) {
+    const float* p = a.dbp + d;
+    int b = ty;
+    for (; b + 112 < a.B; b += 128) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(b + 16 * u) * a.D];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; b < a.B; b += 16) s += p[(int64_t)b * a.D];
+  }
+  part[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && d < a.D) {
+    float t = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t += part[u][tx];
+    a.grads[(int64_t)a.D * a.F + d] = t;
+  }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
+  if (blockIdx.x >= RED_DW_BLOCKS) { reduce_db(a, blockIdx.x - RED_DW_BLOCKS); return; }
+  const float inv = a.ip_scale / (a.sg * a.scales->sx);
+  const int64_t slab_sz = (int64_t)a.Dp * a.Fp;
+  if (VEC) {
+    const int f4 = a.F / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)a.D * f4;
+         i += (int64_t)RED_DW_BLOCKS * 256) {
+      const int d = (int)(i / f4), f = (int)(i % f4) * 4;
+      const float* p = a.slabs + (int64_t)d * a.Fp + f;
+      float4 s = *(const float4*)p;
+      int k = 1;
+      for (; k + 3 < a.S; k += 4) {
+        const float4 t0 = *(const float4*)(p + (k + 0) * slab_sz), t1 = *(const float4*)(p + (k + 1) * slab_sz);
+        const float4 t2 = *(const float4*)(p + (k + 2) * slab_sz), t3 = *(const float4*)(p + (k + 3) * slab_sz);
+        s.x += t0.x; s.y += t0.y; s.z += t0.z; s.w += t0.w;
+        s.x += t1.x; s.y += t1.y; s.z += t1.z; s.w += t1.w;
+        s.x += t2.x; s.y += t2.y; s.z += t2.z; s.w += t2.w;
+        s.x += t3.x; s.y += t3.y; s.z += t3.z; s.w += t3.w;
+      }
+      for (; k < a.S; ++k) {
+        const float4 t = *(const float4*)(p + k * slab_sz);
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+      }
+      *(float4*)(a.grads + (int64_t)d * a.F + f) =
+          make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+    }
+  } else {
+    const int64_t nW = (int64_t)a.D * a.F;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nW; i += (int64_t)RED_DW_BLOCKS * 256) {
+      const int d = (int)(i / a.F), f = (int)(i % a.F);
+      float s = 0.f;
+      for (int k = 0; k < a.S; ++k) s += a.slabs[k * slab_sz + (int64_t)d * a.Fp + f];
+      a.grads[i] = s * inv;
+    }
+  }
+}
+void launch_reduce(const ReduceArgs& a, hipStream_t s) {
+  const dim3 grid(RED_DW_BLOCKS + (a.D + 15) / 16);
+  if (a.F % 4 == 0) hipLaunchKernelGGL(k_reduce<true>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(k_reduce<false>, grid, dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------- SGD ----------
+// solver.cpp:502-531: g += local_decay * w (L2) | sign(w) (L1); h = local_rate * g + momentum * h;
+// blob.cpp:118-120: w -= h.  Also writes the scaled half copy used by the next forward and tracks
+// max |w| for the f16 range guard.
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void k_sgd(SgdArgs a) {
+  const float sw = a.scales->sw_next;
+  const int64_t nW = (int64_t)a.D * a.F;
+  const float lr_w = a.rate * a.lr_mult_w, dc_w = a.weight_decay * a.decay_mult_w;
+  float wmax = 0.f;
+  auto upd = [&](float w, float g, float& h) {
+    if (dc_w != 0.f) g += dc_w * (a.reg == 2 ? w : (float)((w > 0.f) - (w < 0.f)));
+    h = lr_w * g + a.momentum * h;
+    w -= h;
+    wmax = fmaxf(wmax, fabsf(w));
+    return w;
+  };
+  if (VEC) {       // F % 4 == 0: 16-B accesses, one row segment per thread
+    const int f4 = a.F / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)a.D * f4;
+         i += (int64_t)gridDim.x * 256) {
+      const int d = (int)(i / f4), f = (int)(i % f4) * 4;
+      const int64_t o = (int64_t)d * a.F + f;
+      float4 w = *(const float4*)(a.W + o), h = *(const float4*)(a.hW + o);
+      const float4 g = *(const float4*)(a.grads + o);
+      w.x = upd(w.x, g.x, h.x); w.y = upd(w.y, g.y, h.y); w.z = upd(w.z, g.z, h.z); w.w = upd(w.w, g.w, h.w);
+      *(float4*)(a.W + o) = w;
+      *(float4*)(a.hW + o) = h;
+      const uint32_t lo = T::from_float(w.x * sw) | ((uint32_t)T::from_float(w.y * sw) << 16);
+      const uint32_t hi = T::from_float(w.z * sw) | ((uint32_t)T::from_float(w.w * sw) << 16);
+      *(uint2*)(a.Wh + (int64_t)d * a.Fp + f) = make_uint2(lo, hi);
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nW; i += (int64_t)gridDim.x * 256) {
+      float h = a.hW[i];
+      const float w = upd(a.W[i], a.grads[i], h);
+      a.hW[i] = h;
+      a.W[i] = w;
+      const int d = (int)(i / a.F), f = (int)(i % a.F);
+      a.Wh[(int64_t)d * a.Fp + f] = T::from_float(w * sw);
+    }
+  }
+  const float lr_b = a.rate * a.lr_mult_b, dc_b = a.weight_decay * a.decay_mult_b;
+  for (int d = blockIdx.x * 256 + threadIdx.x; d < a.D; d += gridDim.x * 256) {
+    float w = a.b[d], g = a.grads[nW + d];
+    if (dc_b != 0.f) g += dc_b * (a.reg == 2 ? w : (float)((w > 0.f) - (w < 0.f)));
+    const float h = lr_b * g + a.momentum * a.hb[d];
+    a.hb[d] = h;
+    a.b[d] = w - h;
+  }
+  // per-block max |w| -> one slot per block (no atomics: thousands of adds on one address
+  // serialise at ~12 ns each); k_scale_update folds the slots
+  __shared__ float wm[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = wmax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a.wmax_blocks[blockIdx.x] = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    if (blockIdx.x == 0) a.scales->sw_cur = sw;
+  }
+}
+void launch_sgd(int prec, const SgdArgs& a, hipStream_t s) {
+  const bool vec = a.F % 4 == 0;
+  const dim3 grid(SGD_BLOCKS), block(256);
+  if (prec == 0) { if (vec) hipLaunchKernelGGL((k_sgd<F16, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_sgd<F16, false>), grid, block, 0, s, a); }
+  else { if (vec) hipLaunchKernelGGL((k_sgd<BF16, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_sgd<BF16, false>), grid, block, 0, s, a); }
+}
+
+// next W->half scale from the running max: f16 keeps max|W|*sw in [2^11, 2^12); bf16 needs none.
+__global__ void k_scale_update(Scales* sc, const float* wmax_blocks, int nblocks, int prec) {
+  __shared__ float red[8];
+  float mm = 0.f;
+  if (wmax_blocks)
+    for (int i = threadIdx.x; i < nblocks; i += 256) mm = fmaxf(mm, wmax_blocks[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mm;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  mm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float m = fmaxf(mm, __uint_as_float(sc->wmax_bits));
+  float sw = 1.f;
+  if (prec == 0 && m > 0.f && isfinite(m)) {
+    int e;
+    frexpf(m, &e);                 // m = f * 2^e, f in [0.5, 1)
+    sw = ldexpf(1.f, 12 - e);      // m * sw in [2^11, 2^12)
+  }
+  sc->sw_next = sw;
+  sc->wmax_bits = 0u;
+}
+void launch_scale_update(int prec, Scales* sc, const float* wmax_blocks, hipStream_t s) {
+  hipLaunchKernelGGL(k_scale_update, dim3(1), dim3(256), 0, s, sc, wmax_blocks, SGD_BLOCKS, prec);
+}
+
+__global__ __launch_bounds__(256) void k_absmax(const float* x, int64_t n, unsigned* out_bits) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));
+}
+void launch_absmax(const float* x, int64_t n, unsigned* out_bits, hipStream_t s) {
+  hipLaunchKernelGGL(k_absmax, dim3(512), dim3(256), 0, s, x, n, out_bits);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_w_convert(const float* W, uint16_t* Wh, int D, int F,
+                                                   int Fp, Scales* sc) {
+  const float sw = sc->sw_next;
+  const int64_t nW = (int64_t)D * F;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nW; i += (int64_t)gridDim.x * 256) {
+    const int d = (int)(i / F), f = (int)(i % F);
+    Wh[(int64_t)d * Fp + f] = T::from_float(W[i] * sw);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) sc->sw_cur = sw;
+}
+void launch_w_convert(int prec, const float* W, uint16_t* Wh, int D, int F, int Dp, int Fp,
+                      Scales* sc, hipStream_t s) {
+  (void)Dp;
+  if (prec == 0) hipLaunchKernelGGL(k_w_convert<F16>, dim3(1024), dim3(256), 0, s, W, Wh, D, F, Fp, sc);
+  else hipLaunchKernelGGL(k_w_convert<BF16>, dim3(1024), dim3(256), 0, s, W, Wh, D, F, Fp, sc);
+}
+
+// ------------------------------------------------------------------------------- table --------
+template <typename T>
+__global__ __launch_bounds__(256) void k_table_convert(const float* src, uint16_t* dst,
+                                                       int64_t n_rows, int F, int Fp, float sx) {
+  const int64_t n = n_rows * F;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / F; const int f = (int)(i % F);
+    dst[r * Fp + f] = T::from_float(src[i] * sx);
+  }
+}
+void launch_table_convert(int prec, const float* src, uint16_t* dst, int64_t n_rows, int F, int Fp,
+                          float sx, hipStream_t s) {
+  if (prec == 0) hipLaunchKernelGGL(k_table_convert<F16>, dim3(2048), dim3(256), 0, s, src, dst, n_rows, F, Fp, sx);
+  else hipLaunchKernelGGL(k_table_convert<BF16>, dim3(2048), dim3(256), 0, s, src, dst, n_rows, F, Fp, sx);
+}
+
+// synthetic features, bit-identical to videovector_amd/synth.py:feature_rows
+template <typename T>
+__global__ __launch_bounds__(256) void k_table_synth(uint16_t* dst, uint64_t seed, int64_t n_rows,
+                                                     int F, int Fp, float sx) {
+  const int64_t n = n_rows * F;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / F; const int f = (int)(i % F);
+    const uint64_t h = mix64(seed, (1ull << 40) + (uint64_t)i);
+    const int s = (int)(h & 15) + (int)((h >> 4) & 15) + (int)((h >> 8) & 15) + (int)((h >> 12) & 15);
+    const float x = (float)(s > 30 ? s - 30 : 0) * 0.125f;
+    dst[r * Fp + f] = T::from_float(x * sx);
+  }
+}
+void launch_table_synth(int prec, uint16_t* dst, uint64_t seed, int64_t n_rows, int F, int Fp,
+                        float sx, hipStream_t s) {
+  if (prec == 0) hipLaunchKernelGGL(k_table_synth<F16>, dim3(4096), dim3(256), 0, s, dst, seed, n_rows, F, Fp, sx);
+  else hipLaunchKernelGGL(k_table_synth<BF16>, dim3(4096), dim3(256), 0, s, dst, seed, n_rows, F, Fp, sx);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_table_read(const uint16_t* table, const int32_t* rows,
+                                                    int64_t n, int F, int Fp, float inv_sx,
+                                                    float* out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n * F; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / F; const int f = (int)(i % F);
+    const int64_t src = rows ? rows[r] : r;
+    out[i] = T::to_float(table[src * Fp + f]) * inv_sx;
+  }
+}
+void launch_table_read(int prec, const uint16_t* table, const int32_t* rows, int64_t n, int F,
+                       int Fp, float inv_sx, float* out, hipStream_t s) {
+  if (prec == 0) hipLaunchKernelGGL(k_table_read<F16>, dim3(1024), dim3(256), 0, s, table, rows, n, F, Fp, inv_sx, out);
+  else hipLaunchKernelGGL(k_table_read<BF16>, dim3(1024), dim3(256), 0, s, table, rows, n, F, Fp, inv_sx, out);
+}
+
+// idx (data-layer layout, -1 = empty slot) -> table rows, padded to Rp with the all-zero row
+__global__ void k_map_rows(const int32_t* idx, int32_t* rows, int R, int Rp, int32_t zero_row) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < Rp) rows[i] = (i < R && idx[i] >= 0) ? idx[i] : zero_row;
+}
+void launch_map_rows(const int32_t* idx, int32_t* rows, int R, int Rp, int32_t zero_row,
+                     hipStream_t s) {
+  hipLaunchKernelGGL(k_map_rows, dim3((Rp + 255) / 256), dim3(256), 0, s, idx, rows, R, Rp, zero_row);
+}
+
+template <typename T>
+__global__ void k_dyh_to_float(const uint16_t* dYh, int R, int D, int Dp, float inv_sg, float* out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)R * D; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / D; const int d = (int)(i % D);
+    out[i] = T::to_float(dYh[r * Dp + d]) * inv_sg;
+  }
+}
+void launch_dyh_to_float(int prec, const uint16_t* dYh, int R, int D, int Dp, float inv_sg,
+                         float* out, hipStream_t s) {
+  if (prec == 0) hipLaunchKernelGGL(k_dyh_to_float<F16>, dim3(1024), dim3(256), 0, s, dYh, R, D, Dp, inv_sg, out);
+  else hipLaunchKernelGGL(k_dyh_to_float<BF16>, dim3(1024), dim3(256), 0, s, dYh, R, D, Dp, inv_sg, out);
+}
+
+// NORMALIZATION forward on rows of x in place (normalization_layer.cu:10-45): y = x/(|x|+1e-10)
+__global__ __launch_bounds__(256) void k_row_normalize(float* x, int n, int D) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= n) return;
+  float* p = x + (int64_t)r * D;
+  float s = 0.f;
+  for (int d = lane; d < D; d += 64) s += p[d] * p[d];
+  s = wave_sum(s);
+  const float inv = 1.f / (sqrtf(s) + 1e-10f);
+  for (int d = lane; d < D; d += 64) p[d] *= inv;
+}
+void launch_row_normalize(float* x, int n, int D, hipStream_t s) {
+  hipLaunchKernelGGL(k_row_normalize, dim3((n + 3) / 4), dim3(256), 0, s, x, n, D);
+}
+
+}  // namespace vv

@@ -1,0 +1,594 @@
+// kernels_gemm.hip -- the two MFMA kernels of the videovec training step (gfx950 only).
+//
+//   k_fwd_gemm   : ip2 = ReLU(X W^T + b) with X gathered row-by-row from the HBM-resident feature
+//                  table through the triplet index.  Replaces the data layer's batch copy +
+//                  SLICE/CONCAT transpose + InnerProductLayer::Forward + ReLU (+Dropout)
+//                  (reference: video_sampled_shots_data_layer.cpp:439-452,856-875,
+//                  slice_layer.cu:22-33, concat_layer.cu:21-32, inner_product_layer.cu:12-27,
+//                  relu_layer.cu:10-27, dropout_layer.cu:15-41).
+//   k_wgrad_gemm : dW = dY^T X (split-K partial slabs), X gathered again through the same index.
+//                  Replaces InnerProductLayer::Backward's weight gradient
+//                  (inner_product_layer.cu:36-42).
+//
+// Both: 256x256 output tile per 512-thread workgroup, K advanced 64 at a time, operand tiles
+// brought HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, 16 B per lane; the gather is simply the
+// per-lane source address), double buffered; 8 waves x (8x4) MFMA 16x16x32 accumulators.
+#include "vv_internal.h"
+
+namespace vv {
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  // LDS destination = wave-uniform base + lane * 16 (hardware rule); source is per lane.
+  __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc), LDS_PTR(lds_wave_base), 16, 0, 0);
+}
+
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  // Blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous run of
+  // logical tiles so tiles that share operand rows also share an L2.  Speed only.
+  return (nblk % 8 == 0) ? (bid % 8) * (nblk / 8) + bid / 8 : bid;
+}
+
+// ------------------------------------------------------------------------------- forward ------
+// LDS operand image: [256 rows][64 halves] = 128-B rows of 8 16-B chunks, chunk' = chunk ^ (row&7)
+// (conflict-free for the ds_read_b128 fragment reads: tools/lds_banks.py).
+template <typename T, bool DROP, bool VEC>
+__global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm(FwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int Dp = (int)round_up(a.D, D_ALIGN);
+  const int tilesN = Dp / BN;
+  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (L / tilesN) * BM, n0 = (L % tilesN) * BN;
+  const int Fp = a.Fp;
+
+  const uint16_t* a_src[4];
+  const uint16_t* b_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = (i * 8 + wave) * 64 + lane;
+    const int row = c >> 3, lc = (c & 7) ^ (row & 7);
+    a_src[i] = a.table + (int64_t)a.rows[m0 + row] * Fp + lc * 8;
+    b_src[i] = a.Wh + (int64_t)(n0 + row) * Fp + lc * 8;
+  }
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto stage = [&](int p, int kt) {
+    unsigned char* As = smem + p * 2 * LDS_TILE_BYTES;
+    unsigned char* Bs = As + LDS_TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(a_src[i] + kt * BK, As + (i * 8 + wave) * 1024);
+      glds16(b_src[i] + kt * BK, Bs + (i * 8 + wave) * 1024);
+    }
+  };
+
+  const int nk = Fp / BK;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int frow = lane & 15, fq = lane >> 4;
+  for (int t = 0; t < nk; ++t) {
+    const int p = t & 1;
+    if (t + 1 < nk) stage(p ^ 1, t + 1);
+    const unsigned char* As = smem + p * 2 * LDS_TILE_BYTES;
+    const unsigned char* Bs = As + LDS_TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int coff = ((kk * 4 + fq) ^ (frow & 7)) << 4;
+      i16x8 af[8], bf[4];
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi)
+        af[mi] = *(const i16x8*)(As + (wm * 128 + mi * 16 + frow) * 128 + coff);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        bf[ni] = *(const i16x8*)(Bs + (wn * 64 + ni * 16 + frow) * 128 + coff);
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = T::mfma(bf[ni], af[mi], acc[mi][ni]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // Epilogue: descale, bias, ReLU, dropout.  The MFMA was issued with the operands swapped
+  // (D' = W_tile X_tile^T), so in the 16x16 C/D map (col = lane&15, row = 4*(lane>>4)+j) the lane's
+  // column is the batch row m and its 4 registers are 4 CONSECUTIVE outputs n: one 16-B store.
+  const float descale = 1.0f / (a.scales->sx * a.scales->sw_cur);
+  const float dscale = DROP ? 1.0f / (1.0f - a.drop_ratio) : 1.0f;
+  const float lo = a.relu ? 0.f : -INFINITY;
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+    const int m = m0 + wm * 128 + mi * 16 + frow;
+    if (m >= a.R) continue;
+    int64_t ref_row = 0;
+    if (DROP) {
+      const int bb = m / a.CN, ch = m - bb * a.CN;
+      ref_row = (int64_t)ch * a.B + bb;
+    }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = n0 + wn * 64 + ni * 16 + fq * 4;
+      if (n >= a.D) continue;
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float bj = (n + j < a.D) ? a.bias[n + j] : 0.f;
+        v[j] = fmaxf(acc[mi][ni][j] * descale + bj, lo);
+        if (DROP) {
+          const uint64_t e = (uint64_t)(ref_row * a.D + n + j);
+          bool keep;
+          if (a.mask) keep = (n + j < a.D) && a.mask[e] != 0;
+          else keep = (float)(mix64(a.drop_seed, e) >> 40) * (1.0f / 16777216.0f) >= a.drop_ratio;
+          v[j] = keep ? v[j] * dscale : 0.f;
+        }
+      }
+      float* dst = a.H + (int64_t)m * a.D + n;
+      if (VEC) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+      else
+        for (int j = 0; j < 4; ++j) if (n + j < a.D) dst[j] = v[j];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------- wgrad --------
+// LDS operand image: [64 k-rows][256 halves] = 512-B rows of 32 16-B chunks, both operands
+// k-major exactly as they sit in HBM (dY rows / gathered feature rows).  MFMA fragments need 8
+// consecutive k for one m (or n): read with ds_read_b64_tr_b16 (4 k-rows x 16 columns per 16-lane
+// group, delivered column-major).  chunk' = chunk ^ (h(row) << 1), h = (row&3) | ((row>>3)&1)<<2,
+// puts the 8 row segments of one 32-lane half on disjoint banks (tools/lds_banks.py).
+__device__ __forceinline__ int wg_h(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+template <typename T, bool TR>
+__global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int tilesM = a.Dp / BM, tilesN = a.Fp / BN;
+  // logical order: tm fastest (the two M tiles of one (split, tn) read the same feature bytes)
+  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int tm = L % tilesM, tn = (L / tilesM) % tilesN, sp = L / (tilesM * tilesN);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int total_steps = a.Rp / BK;
+  const int k_begin = sp * a.ksteps_per_split;
+  int k_end = k_begin + a.ksteps_per_split;
+  if (k_end > total_steps) k_end = total_steps;
+  const int nk = k_end > k_begin ? k_end - k_begin : 0;
+
+  int srow[4], slc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = (i * 8 + wave) * 64 + lane;
+    srow[i] = c >> 5;
+    slc[i] = (c & 31) ^ (wg_h(srow[i]) << 1);
+  }
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int32_t rid[4];   // table rows of the NEXT k-step to stage
+  auto load_ids = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rid[i] = a.rows[(int64_t)(k_begin + kt) * BK + srow[i]];
+  };
+  auto stage = [&](int p, int kt) {
+    unsigned char* As = smem + p * 2 * LDS_TILE_BYTES;
+    unsigned char* Bs = As + LDS_TILE_BYTES;
+    const int64_t kg = (int64_t)(k_begin + kt) * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(a.dYh + (kg + srow[i]) * a.Dp + m0 + slc[i] * 8, As + (i * 8 + wave) * 1024);
+      glds16(a.table + (int64_t)rid[i] * a.Fp + n0 + slc[i] * 8, Bs + (i * 8 + wave) * 1024);
+    }
+  };
+
+  if (nk > 0) {
+    load_ids(0);
+    stage(0, 0);
+    if (nk > 1) load_ids(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+  for (int t = 0; t < nk; ++t) {
+    const int p = t & 1;
+    if (t + 1 < nk) {
+      stage(p ^ 1, t + 1);
+      if (t + 2 < nk) load_ids(t + 2);
+    }
+    const unsigned char* As = smem + p * 2 * LDS_TILE_BYTES;
+    const unsigned char* Bs = As + LDS_TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      i16x8 af[8], bf[4];
+      if constexpr (TR) {
+        const int row1 = kk * 32 + 8 * g + q;
+        const int hx = wg_h(row1) << 1;       // identical for row1 + 4
+        const int rbase = row1 * 512 + (pp & 1) * 8;
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+          const int off = rbase + (((wm * 16 + mi * 2 + (pp >> 1)) ^ hx) << 4);
+          const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) i16x4*)(As + off));
+          const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) i16x4*)(As + off + 4 * 512));
+          af[mi] = i16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const int off = rbase + (((wn * 8 + ni * 2 + (pp >> 1)) ^ hx) << 4);
+          const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) i16x4*)(Bs + off));
+          const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) i16x4*)(Bs + off + 4 * 512));
+          bf[ni] = i16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+      } else {
+        // reference fragment loader: eight 16-bit LDS reads per fragment (slow, layout-obvious)
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+          const int col = wm * 128 + mi * 16 + li;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int row = kk * 32 + 8 * g + j;
+            af[mi][j] = *(const short*)(As + row * 512 + (((col >> 3) ^ (wg_h(row) << 1)) << 4) +
+                                        (col & 7) * 2);
+          }
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const int col = wn * 64 + ni * 16 + li;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int row = kk * 32 + 8 * g + j;
+            bf[ni][j] = *(const short*)(Bs + row * 512 + (((col >> 3) ^ (wg_h(row) << 1)) << 4) +
+                                        (col & 7) * 2);
+          }
+        }
+      }
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = T::mfma(bf[ni], af[mi], acc[mi][ni]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // swapped operands (D' = X_tile^T dY_tile): lane column = m (output row d), registers = 4
+  // consecutive n (feature columns) -> 16-B stores into the split's fp32 slab.
+  float* slab = a.slabs + (int64_t)sp * a.Dp * a.Fp;
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+    const int m = m0 + wm * 128 + mi * 16 + li;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = n0 + wn * 64 + ni * 16 + g * 4;
+      *(float4*)(slab + (int64_t)m * a.Fp + n) =
+          make_float4(acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]);
+    }
+  }
+}
+
+// =============================================================================================
+// Ring variants: the same tiles with K advanced 32 at a time through a 4-slot LDS ring and counted
+// waits, so that 2-3 units (64-96 KiB per CU) of LDS-DMA stay in flight ACROSS the barriers instead
+// of draining to zero every K-step.  (The 2-buffer kernels above are latency-bound: at most 64 KiB
+// in flight per CU against ~2 us of loaded HBM latency.)
+//   iteration u:  issue unit u+3 -> slot (u+3)&3   (last read in iteration u-1, released by its barrier)
+//                 ds_read + 32 MFMA on slot u&3
+//                 s_waitcnt vmcnt(8)   (own loads of unit u+1 landed; units u+2, u+3 stay in flight)
+//                 s_barrier            (everyone's unit u+1 landed, everyone done reading slot u&3)
+// =============================================================================================
+constexpr int RING = 4;
+constexpr int UNIT_K = 32;
+constexpr int UNIT_OP_BYTES = 256 * UNIT_K * 2;        // one operand, one unit: 16 KiB
+constexpr int UNIT_BYTES = 2 * UNIT_OP_BYTES;          // A + B: 32 KiB
+constexpr int RING_LDS_BYTES = RING * UNIT_BYTES;      // 128 KiB
+
+#define VV_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+__device__ __forceinline__ void ring_wait_and_barrier(int u, int nu) {
+  // loads still allowed in flight: 4 per unit issued after unit u+1
+  if (u + 3 < nu) VV_WAIT_VMCNT(8);
+  else if (u + 2 < nu) VV_WAIT_VMCNT(4);
+  else VV_WAIT_VMCNT(0);
+  __builtin_amdgcn_s_barrier();
+}
+
+// forward: LDS unit image per operand [256 rows][32 halves] = 64-B rows of 4 chunks,
+// chunk' = chunk ^ ((-(row>>2)) & 3)  (conflict-free ds_read_b128: tools/lds_banks.py)
+__device__ __forceinline__ int fw_f(int row) { return (-(row >> 2)) & 3; }
+
+template <typename T, bool DROP, bool VEC>
+__global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ring(FwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int Dp = (int)round_up(a.D, D_ALIGN);
+  const int tilesN = Dp / BN;
+  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (L / tilesN) * BM, n0 = (L % tilesN) * BN;
+  const int Fp = a.Fp;
+
+  const uint16_t* a_src[2];
+  const uint16_t* b_src[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = (i * 8 + wave) * 64 + lane;
+    const int row = c >> 2, lc = (c & 3) ^ fw_f(row);
+    a_src[i] = a.table + (int64_t)a.rows[m0 + row] * Fp + lc * 8;
+    b_src[i] = a.Wh + (int64_t)(n0 + row) * Fp + lc * 8;
+  }
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto stage = [&](int u) {
+    unsigned char* As = smem + (u & (RING - 1)) * UNIT_BYTES;
+    unsigned char* Bs = As + UNIT_OP_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      glds16(a_src[i] + u * UNIT_K, As + (i * 8 + wave) * 1024);
+      glds16(b_src[i] + u * UNIT_K, Bs + (i * 8 + wave) * 1024);
+    }
+  };
+
+  const int nu = Fp / UNIT_K;
+  stage(0);
+  if (nu > 1) stage(1);
+  if (nu > 2) stage(2);
+  if (nu > 2) VV_WAIT_VMCNT(8); else if (nu > 1) VV_WAIT_VMCNT(4); else VV_WAIT_VMCNT(0);
+  __builtin_amdgcn_s_barrier();
+
+  const int frow = lane & 15, fq = lane >> 4;
+  const int aoff = (wm * 128 + frow) * 64 + ((fq ^ fw_f(frow)) << 4);   // fw_f(row) depends on row&15 only
+  const int boff = (wn * 64 + frow) * 64 + ((fq ^ fw_f(frow)) << 4);
+  for (int u = 0; u < nu; ++u) {
+    if (u + 3 < nu) stage(u + 3);
+    const unsigned char* As = smem + (u & (RING - 1)) * UNIT_BYTES;
+    const unsigned char* Bs = As + UNIT_OP_BYTES;
+    i16x8 af[8], bf[4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) af[mi] = *(const i16x8*)(As + aoff + mi * 16 * 64);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) bf[ni] = *(const i16x8*)(Bs + boff + ni * 16 * 64);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = T::mfma(bf[ni], af[mi], acc[mi][ni]);
+    __builtin_amdgcn_s_setprio(0);
+    ring_wait_and_barrier(u, nu);
+  }
+
+  const float descale = 1.0f / (a.scales->sx * a.scales->sw_cur);
+  const float dscale = DROP ? 1.0f / (1.0f - a.drop_ratio) : 1.0f;
+  const float lo = a.relu ? 0.f : -INFINITY;
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+    const int m = m0 + wm * 128 + mi * 16 + frow;
+    if (m >= a.R) continue;
+    int64_t ref_row = 0;
+    if (DROP) {
+      const int bb = m / a.CN, ch = m - bb * a.CN;
+      ref_row = (int64_t)ch * a.B + bb;
+    }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = n0 + wn * 64 + ni * 16 + fq * 4;
+      if (n >= a.D) continue;
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float bj = (n + j < a.D) ? a.bias[n + j] : 0.f;
+        v[j] = fmaxf(acc[mi][ni][j] * descale + bj, lo);
+        if (DROP) {
+          const uint64_t e = (uint64_t)(ref_row * a.D + n + j);
+          bool keep;
+          if (a.mask) keep = (n + j < a.D) && a.mask[e] != 0;
+          else keep = (float)(mix64(a.drop_seed, e) >> 40) * (1.0f / 16777216.0f) >= a.drop_ratio;
+          v[j] = keep ? v[j] * dscale : 0.f;
+        }
+      }
+      float* dst = a.H + (int64_t)m * a.D + n;
+      if (VEC) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+      else
+        for (int j = 0; j < 4; ++j) if (n + j < a.D) dst[j] = v[j];
+    }
+  }
+}
+
+// weight gradient: unit image per operand [32 k-rows][256 halves] (512-B rows), same swizzle and
+// transposed reads as k_wgrad_gemm.  The table-row ids of the split's whole K range are copied to
+// LDS once (the last 32 KiB of the 160 KiB), so the loop issues no ordinary global loads: hipcc
+// would otherwise wait vmcnt(0) on them and drain the ring.
+constexpr int WG_IDS_MAX = 8192;
+constexpr int WG_RING_LDS_BYTES = RING_LDS_BYTES + WG_IDS_MAX * 4;   // 160 KiB
+
+template <typename T>
+__global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ring(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int32_t* ids = (int32_t*)(smem + RING_LDS_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int tilesM = a.Dp / BM, tilesN = a.Fp / BN;
+  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int tm = L % tilesM, tn = (L / tilesM) % tilesN, sp = L / (tilesM * tilesN);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int total_units = a.Rp / UNIT_K;
+  const int u_begin = sp * a.ksteps_per_split * (BK / UNIT_K);
+  int u_end = u_begin + a.ksteps_per_split * (BK / UNIT_K);
+  if (u_end > total_units) u_end = total_units;
+  const int nu = u_end > u_begin ? u_end - u_begin : 0;
+
+  for (int i = tid; i < nu * UNIT_K; i += GEMM_THREADS) ids[i] = a.rows[(int64_t)u_begin * UNIT_K + i];
+  __syncthreads();
+
+  int srow[2], slc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = (i * 8 + wave) * 64 + lane;
+    srow[i] = c >> 5;
+    slc[i] = (c & 31) ^ (wg_h(srow[i]) << 1);
+  }
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto stage = [&](int u) {
+    unsigned char* As = smem + (u & (RING - 1)) * UNIT_BYTES;
+    unsigned char* Bs = As + UNIT_OP_BYTES;
+    const int64_t kg = (int64_t)(u_begin + u) * UNIT_K;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int32_t rid = ids[u * UNIT_K + srow[i]];
+      glds16(a.dYh + (kg + srow[i]) * a.Dp + m0 + slc[i] * 8, As + (i * 8 + wave) * 1024);
+      glds16(a.table + (int64_t)rid * a.Fp + n0 + slc[i] * 8, Bs + (i * 8 + wave) * 1024);
+    }
+  };
+
+  if (nu > 0) {
+    stage(0);
+    if (nu > 1) stage(1);
+    if (nu > 2) stage(2);
+    if (nu > 2) VV_WAIT_VMCNT(8); else if (nu > 1) VV_WAIT_VMCNT(4); else VV_WAIT_VMCNT(0);
+    __builtin_amdgcn_s_barrier();
+  }
+
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+  const int row1 = 8 * g + q;
+  const int hx = wg_h(row1) << 1;
+  const int rbase = row1 * 512 + (pp & 1) * 8;
+  for (int u = 0; u < nu; ++u) {
+    if (u + 3 < nu) stage(u + 3);
+    const unsigned char* As = smem + (u & (RING - 1)) * UNIT_BYTES;
+    const unsigned char* Bs = As + UNIT_OP_BYTES;
+    i16x8 af[8], bf[4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+      const int off = rbase + (((wm * 16 + mi * 2 + (pp >> 1)) ^ hx) << 4);
+      const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) i16x4*)(As + off));
+      const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) i16x4*)(As + off + 4 * 512));
+      af[mi] = i16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int off = rbase + (((wn * 8 + ni * 2 + (pp >> 1)) ^ hx) << 4);
+      const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) i16x4*)(Bs + off));
+      const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) i16x4*)(Bs + off + 4 * 512));
+      bf[ni] = i16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = T::mfma(bf[ni], af[mi], acc[mi][ni]);
+    __builtin_amdgcn_s_setprio(0);
+    ring_wait_and_barrier(u, nu);
+  }
+
+  float* slab = a.slabs + (int64_t)sp * a.Dp * a.Fp;
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+    const int m = m0 + wm * 128 + mi * 16 + li;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = n0 + wn * 64 + ni * 16 + g * 4;
+      *(float4*)(slab + (int64_t)m * a.Fp + n) =
+          make_float4(acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------- launchers ----
+static bool g_wgrad_tr = true;
+static int g_gemm_variant = 1;     // 0 = two-buffer K=64 kernels, 1 = 4-slot ring K=32 kernels
+void set_wgrad_tr(bool on) { g_wgrad_tr = on; }
+void set_gemm_variant(int v) { g_gemm_variant = v; }
+int wgrad_max_ksteps_per_split() { return g_gemm_variant == 1 ? WG_IDS_MAX / BK : (1 << 30); }
+
+template <typename T, bool DROP, bool VEC>
+static void launch_fwd_t(const FwdArgs& a, hipStream_t s) {
+  static bool once = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm<T, DROP, VEC>,
+                      hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES), true);
+  (void)once;
+  const int Rp = (int)round_up(a.R, R_ALIGN), Dp = (int)round_up(a.D, D_ALIGN);
+  const dim3 grid((Rp / BM) * (Dp / BN)), block(GEMM_THREADS);
+  if (g_gemm_variant == 1) {
+    static bool once2 = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ring<T, DROP, VEC>,
+                         hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES), true);
+    (void)once2;
+    hipLaunchKernelGGL((k_fwd_gemm_ring<T, DROP, VEC>), grid, block, RING_LDS_BYTES, s, a);
+    return;
+  }
+  hipLaunchKernelGGL((k_fwd_gemm<T, DROP, VEC>), grid, block, GEMM_LDS_BYTES, s, a);
+}
+
+template <typename T>
+static void launch_fwd_p(const FwdArgs& a, hipStream_t s) {
+  const bool drop = a.drop_ratio > 0.f, vec = a.D % 4 == 0;
+  if (drop) { if (vec) launch_fwd_t<T, true, true>(a, s); else launch_fwd_t<T, true, false>(a, s); }
+  else { if (vec) launch_fwd_t<T, false, true>(a, s); else launch_fwd_t<T, false, false>(a, s); }
+}
+
+void launch_fwd_gemm(int prec, const FwdArgs& a, hipStream_t s) {
+  if (prec == 0) launch_fwd_p<F16>(a, s); else launch_fwd_p<BF16>(a, s);
+}
+
+template <typename T, bool TR>
+static void launch_wgrad_t(const WgradArgs& a, hipStream_t s) {
+  static bool once = ((void)hipFuncSetAttribute((const void*)k_wgrad_gemm<T, TR>,
+                      hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES), true);
+  (void)once;
+  const dim3 grid((a.Dp / BM) * (a.Fp / BN) * a.S), block(GEMM_THREADS);
+  hipLaunchKernelGGL((k_wgrad_gemm<T, TR>), grid, block, GEMM_LDS_BYTES, s, a);
+}
+
+template <typename T>
+static void launch_wgrad_ring_t(const WgradArgs& a, hipStream_t s) {
+  static bool once = ((void)hipFuncSetAttribute((const void*)k_wgrad_gemm_ring<T>,
+                      hipFuncAttributeMaxDynamicSharedMemorySize, WG_RING_LDS_BYTES), true);
+  (void)once;
+  const dim3 grid((a.Dp / BM) * (a.Fp / BN) * a.S), block(GEMM_THREADS);
+  hipLaunchKernelGGL((k_wgrad_gemm_ring<T>), grid, block, WG_RING_LDS_BYTES, s, a);
+}
+
+void launch_wgrad_gemm(int prec, const WgradArgs& a, hipStream_t s) {
+  if (g_gemm_variant == 1 && g_wgrad_tr && a.ksteps_per_split * BK <= WG_IDS_MAX) {
+    if (prec == 0) launch_wgrad_ring_t<F16>(a, s); else launch_wgrad_ring_t<BF16>(a, s);
+    return;
+  }
+  if (prec == 0) { if (g_wgrad_tr) launch_wgrad_t<F16, true>(a, s); else launch_wgrad_t<F16, false>(a, s); }
+  else { if (g_wgrad_tr) launch_wgrad_t<BF16, true>(a, s); else launch_wgrad_t<BF16, false>(a, s); }
+}
+
+}  // namespace vv

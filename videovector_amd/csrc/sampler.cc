@@ -1,0 +1,198 @@
+// sampler.cc -- host-side triplet sampler of the MI355X videovec path (product code; the test
+// oracle under oracle/ is a separate, independent restatement and is never linked here).
+//
+// Reproduces, with table-row indices in place of feature copies, the reference's
+// VideoSampledShotsDataLayer in CONTEXT_WINDOW mode:
+//   setup   src/caffe/layers/video_sampled_shots_data_layer.cpp:64-369
+//   batch   ...:768-909 (InternalThreadEntry), :371-393,425-507 (AddSamplesToTop), :24-44
+// including the exact consumption order of the C library's rand() stream.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <new>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/videovec.h"
+
+namespace {
+
+// glibc rand() == random() with the default TYPE_3 state: 31 words seeded from seed 1 by the
+// 16807 Lehmer recurrence, then state[f] += state[f-3] walking f cyclically; output is the new
+// word >> 1; the first 310 outputs are discarded by srandom.  (glibc 2.35 stdlib/random_r.c)
+class LibcRand {
+ public:
+  LibcRand() {
+    int64_t w = 1;
+    st_[0] = 1;
+    for (int i = 1; i < 31; ++i) {
+      w = (16807 * w) % 2147483647;     // exact in 64 bits; equals glibc's overflow-free form
+      st_[i] = (uint32_t)w;
+    }
+    f_ = 3; r_ = 0;
+    for (int i = 0; i < 310; ++i) (void)step();
+  }
+  int32_t next() { return (int32_t)(step() >> 1); }
+
+ private:
+  uint32_t step() {
+    const uint32_t v = (st_[f_] += st_[r_]);
+    f_ = f_ == 30 ? 0 : f_ + 1;
+    r_ = r_ == 30 ? 0 : r_ + 1;
+    return v;
+  }
+  uint32_t st_[31];
+  int f_, r_;
+};
+
+struct Slot { int32_t row = -1, last = -1; };
+
+}  // namespace
+
+struct vv_sampler {
+  vv_sampler_param p;
+  std::vector<int32_t> video_id, n_shots, shot_ids;
+  std::vector<int64_t> row_base, shot_off;
+  bool has_ids = false;
+  LibcRand rng;
+  int32_t cursor = 0;
+  std::vector<int32_t> buffer_ids;            // persistent permutation (…data_layer.cpp:81-83)
+  std::vector<int32_t> buf_row;               // slot -> table row
+  std::vector<uint64_t> buf_key;              // slot -> (video_id, shot_id)
+  std::unordered_set<uint64_t> keys;          // negative_keys_set_
+  std::vector<Slot> slots;                    // persistent prefetch_data_ contents [B][C+Nn]
+  std::vector<int32_t> perm;
+
+  static uint64_t key(int32_t vid, int32_t shot) { return ((uint64_t)(uint32_t)vid << 32) | (uint32_t)shot; }
+  int32_t shot_id(int v, int j) const { return has_ids ? shot_ids[shot_off[v] + j] : j; }
+
+  // include/caffe/util/rng.hpp:43-54
+  void random_unique(std::vector<int32_t>& a, int n) {
+    int left = (int)a.size();
+    for (int first = 0; first < n; ++first, --left) std::swap(a[first], a[first + rng.next() % left]);
+  }
+};
+
+extern "C" {
+
+void vv_sampler_param_default(vv_sampler_param* p) {
+  memset(p, 0, sizeof(*p));
+  p->batch_size = 128; p->context_size = 5; p->num_negative_samples = 10;   // shipped prototxt :13-23
+  p->max_buffer_size = 5000; p->negative_swap_percentage = 50; p->max_same_video_negs = 0;
+  p->max_tries_for_negs = 100;
+}
+
+int vv_sampler_create(const vv_sampler_param* p, int32_t n_videos, const int32_t* video_id,
+                      const int32_t* n_shots, const int64_t* row_base, const int32_t* shot_ids,
+                      vv_sampler** out) {
+  if (!p || !video_id || !n_shots || !row_base || !out || n_videos < 1) return VV_ERR_ARG;
+  if (p->batch_size < 1 || p->context_size < 2) return VV_ERR_ARG;                // :207,:209
+  if (p->context_size % 2 != 1) return VV_ERR_ARG;                                // :434 (WINDOW)
+  const int Nn = p->num_negative_samples;
+  if (Nn < 0) return VV_ERR_ARG;
+  if (Nn > 0 && (p->negative_swap_percentage < 0 || p->negative_swap_percentage > 99 ||
+                 p->max_buffer_size < Nn)) return VV_ERR_ARG;                     // :79-80
+  vv_sampler* s = new (std::nothrow) vv_sampler();
+  if (!s) return VV_ERR_STATE;
+  s->p = *p;
+  s->video_id.assign(video_id, video_id + n_videos);
+  s->n_shots.assign(n_shots, n_shots + n_videos);
+  s->row_base.assign(row_base, row_base + n_videos);
+  int max_n = 1; int64_t total = 0;
+  s->shot_off.resize(n_videos);
+  for (int v = 0; v < n_videos; ++v) {
+    if (n_shots[v] < 1) { delete s; return VV_ERR_ARG; }                         // :808
+    s->shot_off[v] = total; total += n_shots[v]; max_n = std::max(max_n, n_shots[v]);
+  }
+  if (shot_ids) { s->has_ids = true; s->shot_ids.assign(shot_ids, shot_ids + total); }
+  s->perm.reserve(max_n);
+  const int CN = p->context_size + Nn;
+  s->slots.assign((size_t)p->batch_size * CN, Slot());
+  const int mb = Nn > 0 ? p->max_buffer_size : 0;
+  s->buffer_ids.resize(mb);
+  for (int i = 0; i < mb; ++i) s->buffer_ids[i] = i;
+  s->buf_row.reserve(mb); s->buf_key.reserve(mb);
+  // fill the negative buffer: one random shot of each visited record until full (:240-344)
+  if (mb > 0) {
+    const int64_t tries = (int64_t)p->max_tries_for_negs * mb;
+    for (int64_t t = 0; t < tries && (int)s->buf_row.size() < mb; ++t) {
+      const int v = s->cursor;
+      s->cursor = (s->cursor + 1) % n_videos;
+      const int j = s->rng.next() % s->n_shots[v];
+      const uint64_t k = vv_sampler::key(s->video_id[v], s->shot_id(v, j));
+      if (s->keys.insert(k).second) {
+        s->buf_row.push_back((int32_t)(s->row_base[v] + j));
+        s->buf_key.push_back(k);
+      }
+    }
+    if ((int)s->buf_row.size() != mb) { delete s; return VV_ERR_ARG; }           // :344
+  }
+  *out = s;
+  return VV_OK;
+}
+
+int vv_sampler_next(vv_sampler* s, int32_t* idx, int32_t* last_src, int32_t* label) {
+  if (!s) return VV_ERR_ARG;
+  const vv_sampler_param& p = s->p;
+  const int C = p.context_size, Nn = p.num_negative_samples, CN = C + Nn, half = C / 2;
+  const int V = (int)s->video_id.size();
+  for (int item = 0; item < p.batch_size;) {
+    const int v = s->cursor;
+    const int n = s->n_shots[v];
+    const int64_t base = s->row_base[v];
+    Slot* sl = &s->slots[(size_t)item * CN];
+    int added = 0;
+    const bool ok = n >= 2 && n >= C;                                              // :387,:427
+    if (ok) {
+      std::vector<int32_t>& perm = s->perm;
+      perm.resize(n);
+      for (int i = 0; i < n; ++i) perm[i] = i;
+      s->random_unique(perm, C);                                                   // :432
+      std::sort(perm.begin(), perm.begin() + C);                                   // :437
+      for (int i = 0, ctx = 0; i < C; ++i) {                                       // :439-453
+        const int32_t r = (int32_t)(base + perm[i]);
+        Slot& d = (i == half) ? sl[0] : sl[++ctx];
+        d.row = d.last = r;
+      }
+      if (Nn > 0 && n > C) {                                                       // :479-503
+        for (int i = C + 1; i < n; ++i) {         // std::random_shuffle(perm + C, perm + n)
+          const int j = C + s->rng.next() % (i - C + 1);
+          if (i != j) std::swap(perm[i], perm[j]);
+        }
+        for (int nid = C; nid < n && added < p.max_same_video_negs; ++nid)
+          if (perm[nid] < perm[half - 1] || perm[nid] > perm[half + 1])
+            sl[C + added++].row = (int32_t)(base + perm[nid]);   // F-1 values copied: .last stays
+      }
+    }
+    s->cursor = (s->cursor + 1) % V;                                               // :826-846
+    if (!ok) continue;                                                             // :848
+    if (Nn > 0) {
+      s->random_unique(s->buffer_ids, Nn - added);                                 // :855
+      for (int c = C + added; c < CN; ++c)
+        sl[c].row = sl[c].last = s->buf_row[s->buffer_ids[c - C - added]];         // :856-875
+    }
+    if (label) label[item] = s->video_id[v];                                       // :879
+    ++item;
+    if (Nn > 0 && p.negative_swap_percentage > 0) {                                // :888-906
+      for (int j = 0; j < n; ++j) {
+        const uint64_t k = vv_sampler::key(s->video_id[v], s->shot_id(v, j));
+        if (s->keys.count(k)) continue;
+        if (s->rng.next() % 100 < p.negative_swap_percentage) {                    // :27
+          const int pos = s->rng.next() % p.max_buffer_size;                       // :29
+          s->keys.erase(s->buf_key[pos]);
+          s->keys.insert(k);
+          s->buf_key[pos] = k;
+          s->buf_row[pos] = (int32_t)(base + j);
+        }
+      }
+    }
+  }
+  const size_t n = s->slots.size();
+  if (idx) for (size_t i = 0; i < n; ++i) idx[i] = s->slots[i].row;
+  if (last_src) for (size_t i = 0; i < n; ++i) last_src[i] = s->slots[i].last;
+  return VV_OK;
+}
+
+int vv_sampler_destroy(vv_sampler* s) { delete s; return VV_OK; }
+
+}  // extern "C"

@@ -1,0 +1,173 @@
+// vv_internal.h -- shared declarations of the HIP implementation behind include/videovec.h.
+// gfx950 (MI355X, CDNA4) only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vv {
+
+// ---------------------------------------------------------------------------------------------
+// GEMM tiling shared by the forward (gather-GEMM) and weight-gradient (gather-GEMM^T) kernels.
+// One workgroup = 512 threads = 8 waves (2 along M x 4 along N), one 256x256 output tile,
+// K advanced 64 at a time through a double-buffered LDS image filled by LDS-DMA
+// (global_load_lds_dwordx4).  Each wave owns a 128x64 sub-tile = 8x4 MFMA 16x16x32 accumulators.
+// ---------------------------------------------------------------------------------------------
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int GEMM_THREADS = 512;
+constexpr int LDS_TILE_BYTES = 256 * 64 * 2;          // one operand tile: 32 KiB
+constexpr int GEMM_LDS_BYTES = 4 * LDS_TILE_BYTES;    // {A,B} x 2 buffers = 128 KiB
+
+// Row padding rules of the half-precision operand copies kept in HBM.
+constexpr int F_ALIGN = 256;   // table / W row length (K of fwd, N of wgrad)
+constexpr int D_ALIGN = 256;   // W rows (N of fwd), dY row length (M of wgrad)
+constexpr int R_ALIGN = 256;   // batch rows (M of fwd, K of wgrad)
+constexpr int SGD_BLOCKS = 1024;
+
+inline __host__ __device__ int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+// Device-resident scale block: power-of-two factors that keep f16 operands in range.
+//   table_h = x * sx          (fixed at table load)
+//   W_h     = W * sw_cur      (refreshed by the SGD kernel each step)
+//   dY_h    = dY * sg         (sg chosen per step from the loss count)
+struct Scales {
+  float sx;            // table scale
+  float sw_cur;        // scale the current W_h copy carries
+  float sw_next;       // scale the next W -> W_h conversion will use
+  unsigned wmax_bits;  // running max |W| (float bits) collected by the SGD kernel
+};
+
+struct FwdArgs {
+  const uint16_t* table;   // [n_rows + 1][Fp], last row all zero
+  const int32_t* rows;     // [Rp] table row per batch row (already mapped, padding -> zero row)
+  const uint16_t* Wh;      // [Dp][Fp]
+  const float* bias;       // [D] or null
+  const Scales* scales;
+  float* H;                // [R][D] fp32 output (ip2)
+  int R, D, Fp;
+  int relu;
+  // dropout
+  float drop_ratio;        // 0 = off
+  const uint8_t* mask;     // explicit mask [(C+Nn)*B][D] in reference row order, or null
+  uint64_t drop_seed;
+  int B, CN;               // to map an internal row (b*CN+ch) to the reference row (ch*B+b)
+};
+
+struct ScoreArgs {
+  const float* H;          // [R][D] item-major rows (b*CN + ch)
+  uint16_t* dYh;           // [Rp][Dp] scaled half gradient of ip1_nonorm
+  float* dbp;              // [B][D] per-item column sums of dY (fp32, unscaled)
+  float* loss_part;        // [B]
+  float* viol_part;        // [B]
+  float* s_true;           // [B] (replicated Nn times by the reference's SUM layer)
+  float* s_bogus;          // [B][Nn]
+  const float* coeff;      // [C-1] device
+  int B, C, Nn, D, Dp;
+  float margin; int norm;
+  float grad_scale;        // loss_weight / global_count
+  float drop_scale;        // 1/(1-ratio) or 1
+  float sg;                // half-precision gradient scale
+};
+
+struct WgradArgs {
+  const uint16_t* dYh;     // [Rp][Dp]
+  const uint16_t* table;   // [n_rows+1][Fp]
+  const int32_t* rows;     // [Rp]
+  float* slabs;            // [S][Dp][Fp] fp32 partial products
+  int Rp, Dp, Fp;
+  int S;                   // split-K factor
+  int ksteps_per_split;    // BK-steps per split
+};
+
+struct ReduceArgs {
+  const float* slabs; int S, Dp, Fp;
+  const float* dbp; int B;
+  const Scales* scales;
+  float sg;
+  float* grads;            // [D*F + D]
+  int D, F;
+  float ip_scale;          // 1 + regularization/2 (inner_product_layer.cpp:80-90), normally 1
+};
+
+struct SgdArgs {
+  float* W; float* b; float* hW; float* hb;
+  const float* grads;      // [D*F + D]
+  uint16_t* Wh; Scales* scales;
+  float* wmax_blocks;      // [SGD_BLOCKS] per-block max |w| of this update
+  int D, F, Dp, Fp;
+  float rate, momentum, weight_decay;
+  float lr_mult_w, lr_mult_b, decay_mult_w, decay_mult_b;
+  int reg;
+};
+
+// kernel launchers (defined in the .hip files); prec: 0 = f16, 1 = bf16
+void launch_fwd_gemm(int prec, const FwdArgs& a, hipStream_t s);
+void launch_wgrad_gemm(int prec, const WgradArgs& a, hipStream_t s);
+void launch_score_loss(int prec, const ScoreArgs& a, hipStream_t s);
+void launch_reduce(const ReduceArgs& a, hipStream_t s);
+void launch_sgd(int prec, const SgdArgs& a, hipStream_t s);
+void launch_scale_update(int prec, Scales* sc, const float* wmax_blocks, hipStream_t s);
+void launch_table_convert(int prec, const float* src, uint16_t* dst, int64_t n_rows, int F, int Fp,
+                          float sx, hipStream_t s);
+void launch_table_synth(int prec, uint16_t* dst, uint64_t seed, int64_t n_rows, int F, int Fp,
+                        float sx, hipStream_t s);
+void launch_table_read(int prec, const uint16_t* table, const int32_t* rows, int64_t n, int F,
+                       int Fp, float inv_sx, float* out, hipStream_t s);
+void launch_w_convert(int prec, const float* W, uint16_t* Wh, int D, int F, int Dp, int Fp,
+                      Scales* sc, hipStream_t s);
+void launch_map_rows(const int32_t* idx, int32_t* rows, int R, int Rp, int32_t zero_row,
+                     hipStream_t s);
+void launch_final_loss(const float* loss_part, const float* viol_part, int B, float scale,
+                       float* out2, hipStream_t s);
+void launch_dyh_to_float(int prec, const uint16_t* dYh, int R, int D, int Dp, float inv_sg,
+                         float* out, hipStream_t s);
+void launch_row_normalize(float* x, int n, int D, hipStream_t s);
+void launch_absmax(const float* x, int64_t n, unsigned* out_bits, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// 16-bit operand types
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+typedef short i16x8 __attribute__((ext_vector_type(8)));
+
+struct F16 {
+  static constexpr int id = 0;
+  static __device__ __forceinline__ f32x4 mfma(i16x8 a, i16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a),
+                                                  __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ uint16_t from_float(float x) {
+    x = fminf(fmaxf(x, -65504.f), 65504.f);   // saturate instead of producing inf
+    return __builtin_bit_cast(uint16_t, (_Float16)x);
+  }
+  static __device__ __forceinline__ float to_float(uint16_t v) {
+    return (float)__builtin_bit_cast(_Float16, v);
+  }
+};
+
+struct BF16 {
+  static constexpr int id = 1;
+  static __device__ __forceinline__ f32x4 mfma(i16x8 a, i16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                   __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ uint16_t from_float(float x) {
+    return __builtin_bit_cast(uint16_t, (__bf16)x);
+  }
+  static __device__ __forceinline__ float to_float(uint16_t v) {
+    return __builtin_bit_cast(float, (uint32_t)v << 16);
+  }
+};
+
+// splitmix64 finaliser, identical to videovector_amd/synth.py:mix64
+__host__ __device__ inline uint64_t mix64(uint64_t seed, uint64_t x) {
+  uint64_t z = seed * 0x9E3779B97F4A7C15ull + x;
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+}  // namespace vv

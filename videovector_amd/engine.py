@@ -1,0 +1,286 @@
+"""ctypes binding of include/videovec.h and a small host-side engine object.
+
+Mirrors the reference's solver-side view of the path (Solver::Solve loop body, solver.cpp:194-220):
+`forward_backward()` == Net::ForwardBackward, `apply_update()` == ComputeUpdateValue + Net::Update.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PREC = {"f16": 0, "bf16": 1}
+
+
+class VVError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libvideovec.so")
+
+
+class _StepCfg(C.Structure):
+    _fields_ = [("B", C.c_int32), ("C", C.c_int32), ("Nn", C.c_int32),
+                ("margin", C.c_float), ("norm", C.c_int32), ("loss_weight", C.c_float),
+                ("ctx_coeff", C.c_void_p),
+                ("dropout_ratio", C.c_float), ("dropout_mask", C.c_void_p),
+                ("dropout_seed", C.c_uint64), ("global_count", C.c_int64),
+                ("lr", C.c_float), ("momentum", C.c_float), ("weight_decay", C.c_float),
+                ("lr_mult", C.c_float * 2), ("decay_mult", C.c_float * 2), ("reg", C.c_int32)]
+
+
+_lib = None
+
+
+def load_library():
+    """Load libvideovec.so; raises (never falls back) when the HIP library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise VVError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(hipcc --offload-arch=gfx950); there is no CPU fallback" % p)
+    L = C.CDLL(p)
+    L.vv_last_error.restype = C.c_char_p
+    L.vv_version.restype = C.c_char_p
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    sigs = {
+        "vv_create": [C.c_int, C.c_int, C.POINTER(vp)],
+        "vv_destroy": [vp], "vv_set_stream": [vp, vp], "vv_synchronize": [vp],
+        "vv_table_set": [vp, vp, i64, i32], "vv_table_synth": [vp, C.c_uint64, i64, i32],
+        "vv_table_get": [vp, vp, i64, vp],
+        "vv_params_set": [vp, i32, vp, vp, vp, vp], "vv_params_get": [vp, vp, vp, vp, vp],
+        "vv_step_cfg_default": [vp],
+        "vv_forward_backward": [vp, vp, vp, C.c_int], "vv_apply_update": [vp, vp],
+        "vv_step": [vp, vp, vp, C.c_int],
+        "vv_loss_get": [vp, C.POINTER(f32), C.POINTER(f32)],
+        "vv_grads_device": [vp, C.POINTER(vp), C.POINTER(i64)], "vv_grads_get": [vp, vp, vp],
+        "vv_grads_bind": [vp, vp],
+        "vv_blobs_get": [vp, vp, vp, vp, vp],
+        "vv_embed": [vp, vp, i64, C.c_int, C.c_int, vp],
+        "vv_profile_enable": [vp, C.c_int],
+        "vv_profile_get": [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)],
+    }
+    for name, args in sigs.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = None if name == "vv_step_cfg_default" else C.c_int
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class StepConfig:
+    """vv_step_cfg with the shipped project defaults (vv_step_cfg_default)."""
+
+    def __init__(self, B, C_, Nn, **kw):
+        self.c = _StepCfg()
+        load_library().vv_step_cfg_default(C.byref(self.c))
+        self.c.B, self.c.C, self.c.Nn = B, C_, Nn
+        self._keep = {}
+        for k, v in kw.items():
+            self.set(k, v)
+
+    def set(self, k, v):
+        if k == "ctx_coeff":
+            a = None if v is None else np.ascontiguousarray(v, dtype=np.float32)
+            self._keep[k] = a
+            self.c.ctx_coeff = None if a is None else a.ctypes.data
+        elif k == "dropout_mask":
+            a = None if v is None else np.ascontiguousarray(v, dtype=np.uint8)
+            self._keep[k] = a
+            self.c.dropout_mask = None if a is None else a.ctypes.data
+        elif k in ("lr_mult", "decay_mult"):
+            getattr(self.c, k)[0], getattr(self.c, k)[1] = float(v[0]), float(v[1])
+        elif k == "reg":
+            self.c.reg = {"L1": 1, "L2": 2}.get(v, v)
+        elif k == "norm":
+            self.c.norm = {"L1": 1, "L2": 2}.get(v, v)
+        else:
+            if not hasattr(self.c, k):
+                raise AttributeError(k)
+            setattr(self.c, k, v)
+        return self
+
+
+class Engine:
+    """One context per process / GPU (vv_create)."""
+
+    def __init__(self, device=0, prec="f16"):
+        self.L = load_library()
+        self.h = C.c_void_p()
+        self.prec = prec
+        self._chk(self.L.vv_create(device, PREC[prec], C.byref(self.h)))
+        self.F = self.D = 0
+        self.n_rows = 0
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise VVError("videovec error %d: %s" % (rc, self.L.vv_last_error().decode()))
+
+    def close(self):
+        if getattr(self, "h", None) and self.h:
+            self.L.vv_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- setup
+    def set_stream(self, raw_stream):
+        self._chk(self.L.vv_set_stream(self.h, C.c_void_p(raw_stream)))
+
+    def synchronize(self):
+        self._chk(self.L.vv_synchronize(self.h))
+
+    def table_set(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        self.n_rows, self.F = rows.shape
+        self._chk(self.L.vv_table_set(self.h, _ptr(rows), rows.shape[0], rows.shape[1]))
+
+    def table_synth(self, seed, n_rows, F):
+        self.n_rows, self.F = n_rows, F
+        self._chk(self.L.vv_table_synth(self.h, seed, n_rows, F))
+
+    def table_get(self, rows=None, n=None):
+        r = None if rows is None else np.ascontiguousarray(rows, dtype=np.int32)
+        n = len(r) if r is not None else n
+        out = np.empty((n, self.F), np.float32)
+        self._chk(self.L.vv_table_get(self.h, _ptr(r), n, _ptr(out)))
+        return out
+
+    def params_set(self, W, b=None, hW=None, hb=None):
+        W = np.ascontiguousarray(W, dtype=np.float32)
+        self.D = W.shape[0]
+        assert W.shape[1] == self.F, "W must be D x F with the table's F"
+        cv = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+        b, hW, hb = cv(b), cv(hW), cv(hb)
+        self._chk(self.L.vv_params_set(self.h, self.D, _ptr(W), _ptr(b), _ptr(hW), _ptr(hb)))
+
+    def params_get(self):
+        W = np.empty((self.D, self.F), np.float32); b = np.empty(self.D, np.float32)
+        hW = np.empty_like(W); hb = np.empty_like(b)
+        self._chk(self.L.vv_params_get(self.h, _ptr(W), _ptr(b), _ptr(hW), _ptr(hb)))
+        return W, b, hW, hb
+
+    # ---- iteration
+    def forward_backward(self, cfg, idx=None, idx_dev_ptr=None):
+        if idx_dev_ptr is not None:
+            self._chk(self.L.vv_forward_backward(self.h, C.byref(cfg.c), C.c_void_p(idx_dev_ptr), 1))
+        else:
+            idx = np.ascontiguousarray(idx, dtype=np.int32)
+            assert idx.shape == (cfg.c.B, cfg.c.C + cfg.c.Nn)
+            self._chk(self.L.vv_forward_backward(self.h, C.byref(cfg.c), _ptr(idx), 0))
+
+    def apply_update(self, cfg):
+        self._chk(self.L.vv_apply_update(self.h, C.byref(cfg.c)))
+
+    def step(self, cfg, idx=None, idx_dev_ptr=None):
+        self.forward_backward(cfg, idx, idx_dev_ptr)
+        self.apply_update(cfg)
+
+    def loss(self):
+        l, v = C.c_float(), C.c_float()
+        self._chk(self.L.vv_loss_get(self.h, C.byref(l), C.byref(v)))
+        return l.value, v.value
+
+    def grads_device(self):
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk(self.L.vv_grads_device(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def grads_bind(self, dev_ptr):
+        self._chk(self.L.vv_grads_bind(self.h, C.c_void_p(dev_ptr)))
+
+    def grads(self):
+        dW = np.empty((self.D, self.F), np.float32); db = np.empty(self.D, np.float32)
+        self._chk(self.L.vv_grads_get(self.h, _ptr(dW), _ptr(db)))
+        return dW, db
+
+    def blobs(self, cfg, ip2=True, scores=True, ip1_diff=False):
+        B, CN, Nn = cfg.c.B, cfg.c.C + cfg.c.Nn, cfg.c.Nn
+        out = {}
+        a = np.empty((CN * B, self.D), np.float32) if ip2 else None
+        st = np.empty((B, Nn), np.float32) if scores else None
+        sn = np.empty((B, Nn), np.float32) if scores else None
+        dy = np.empty((CN * B, self.D), np.float32) if ip1_diff else None
+        self._chk(self.L.vv_blobs_get(self.h, _ptr(a), _ptr(st), _ptr(sn), _ptr(dy)))
+        if ip2: out["ip2"] = a
+        if scores: out["target_score"], out["negative_scores"] = st, sn
+        if ip1_diff: out["ip1_diff"] = dy
+        return out
+
+    def embed(self, rows=None, n=None, relu=True, l2norm=False):
+        r = None if rows is None else np.ascontiguousarray(rows, dtype=np.int32)
+        n = len(r) if r is not None else n
+        out = np.empty((n, self.D), np.float32)
+        self._chk(self.L.vv_embed(self.h, _ptr(r), n, int(relu), int(l2norm), _ptr(out)))
+        return out
+
+    # ---- profiling
+    def profile_enable(self, on=True):
+        self._chk(self.L.vv_profile_enable(self.h, int(on)))
+
+    def profile_get(self, kernel):
+        ms, n = C.c_double(), C.c_int64()
+        self._chk(self.L.vv_profile_get(self.h, kernel.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+class _SamplerParam(C.Structure):
+    _fields_ = [("batch_size", C.c_int32), ("context_size", C.c_int32),
+                ("num_negative_samples", C.c_int32), ("max_buffer_size", C.c_int32),
+                ("negative_swap_percentage", C.c_int32), ("max_same_video_negs", C.c_int32),
+                ("max_tries_for_negs", C.c_int32)]
+
+
+class Sampler:
+    """Host-side triplet sampler of the product library (vv_sampler_*): the reference's
+    VideoSampledShotsDataLayer with row indices instead of feature copies (WINDOW context)."""
+
+    def __init__(self, video_id, n_shots, row_base, *, batch_size, context_size,
+                 num_negative_samples, max_buffer_size=5000, negative_swap_percentage=50,
+                 max_same_video_negs=0, max_tries_for_negs=100, shot_ids=None):
+        L = load_library()
+        L.vv_sampler_create.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.POINTER(C.c_void_p)]
+        L.vv_sampler_next.argtypes = [C.c_void_p] * 4
+        L.vv_sampler_destroy.argtypes = [C.c_void_p]
+        self.L = L
+        vid = np.ascontiguousarray(video_id, dtype=np.int32)
+        ns = np.ascontiguousarray(n_shots, dtype=np.int32)
+        rb = np.ascontiguousarray(row_base, dtype=np.int64)
+        sid = None if shot_ids is None else np.ascontiguousarray(shot_ids, dtype=np.int32)
+        p = _SamplerParam(batch_size, context_size, num_negative_samples, max_buffer_size,
+                          negative_swap_percentage, max_same_video_negs, max_tries_for_negs)
+        self.h = C.c_void_p()
+        rc = L.vv_sampler_create(C.byref(p), len(vid), _ptr(vid), _ptr(ns), _ptr(rb), _ptr(sid),
+                                 C.byref(self.h))
+        if rc != 0:
+            raise VVError("vv_sampler_create failed (%d): the reference would CHECK-fail on these "
+                          "parameters" % rc)
+        self.B, self.CN = batch_size, context_size + num_negative_samples
+
+    def next(self, want_last=False, want_label=False):
+        idx = np.empty((self.B, self.CN), np.int32)
+        last = np.empty((self.B, self.CN), np.int32) if want_last else None
+        label = np.empty((self.B,), np.int32) if want_label else None
+        rc = self.L.vv_sampler_next(self.h, _ptr(idx), _ptr(last), _ptr(label))
+        if rc != 0:
+            raise VVError("vv_sampler_next failed (%d)" % rc)
+        if want_last or want_label:
+            return idx, last, label
+        return idx
+
+    def __del__(self):
+        if getattr(self, "h", None) and self.h:
+            self.L.vv_sampler_destroy(self.h)
+            self.h = C.c_void_p()
