@@ -13,7 +13,7 @@
 
 #include "vv_internal.h"
 
-namespace vv { void set_wgrad_tr(bool on); void set_gemm_variant(int v); int wgrad_max_ksteps_per_split(); }
+namespace vv { void set_wgrad_tr(bool on); void set_gemm_variant(int v); void set_ablate(int v); int wgrad_max_ksteps_per_split(); }
 using namespace vv;
 
 static thread_local char g_err[512] = "";
@@ -127,6 +127,8 @@ int vv_create(int device, int prec, vv_ctx** out) {
   if (tr) set_wgrad_tr(atoi(tr) != 0);
   const char* gv = getenv("VV_GEMM_VARIANT");
   if (gv) set_gemm_variant(atoi(gv));
+  const char* ab = getenv("VV_ABLATE");
+  set_ablate(ab ? atoi(ab) : 0);
   *out = c;
   return VV_OK;
 }

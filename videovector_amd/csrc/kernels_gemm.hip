@@ -31,10 +31,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return (nblk % 8 == 0) ? (bid % 8) * (nblk / 8) + bid / 8 : bid;
 }
 
+// Ablation switches for timing studies only (VV_ABLATE; results are wrong when set):
+//   1 = no LDS-DMA staging inside the K loop, 2 = no MFMA (fragments kept alive), 4 = no LDS reads
+template <typename T, int ABL>
+__device__ __forceinline__ f32x4 mfma_abl(i16x8 x, i16x8 y, f32x4 c) {
+  if constexpr (ABL & 2) { asm volatile("" ::"v"(x), "v"(y)); return c; }
+  else return T::mfma(x, y, c);
+}
+
 // ------------------------------------------------------------------------------- forward ------
 // LDS operand image: [256 rows][64 halves] = 128-B rows of 8 16-B chunks, chunk' = chunk ^ (row&7)
 // (conflict-free for the ds_read_b128 fragment reads: tools/lds_banks.py).
-template <typename T, bool DROP, bool VEC>
+template <typename T, bool DROP, bool VEC, int ABL = 0>
 __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -80,7 +88,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm(FwdArgs a) {
   const int frow = lane & 15, fq = lane >> 4;
   for (int t = 0; t < nk; ++t) {
     const int p = t & 1;
-    if (t + 1 < nk) stage(p ^ 1, t + 1);
+    if constexpr (!(ABL & 1)) { if (t + 1 < nk) stage(p ^ 1, t + 1); }
     const unsigned char* As = smem + p * 2 * LDS_TILE_BYTES;
     const unsigned char* Bs = As + LDS_TILE_BYTES;
 #pragma unroll
@@ -89,14 +97,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm(FwdArgs a) {
       i16x8 af[8], bf[4];
 #pragma unroll
       for (int mi = 0; mi < 8; ++mi)
-        af[mi] = *(const i16x8*)(As + (wm * 128 + mi * 16 + frow) * 128 + coff);
+        af[mi] = (ABL & 4) ? i16x8{1, 2, 3, 4, 5, 6, 7, (short)mi}
+                           : *(const i16x8*)(As + (wm * 128 + mi * 16 + frow) * 128 + coff);
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
-        bf[ni] = *(const i16x8*)(Bs + (wn * 64 + ni * 16 + frow) * 128 + coff);
+        bf[ni] = (ABL & 4) ? i16x8{1, 2, 3, 4, 5, 6, 7, (short)ni}
+                           : *(const i16x8*)(Bs + (wn * 64 + ni * 16 + frow) * 128 + coff);
 #pragma unroll
       for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = T::mfma(bf[ni], af[mi], acc[mi][ni]);
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma_abl<T, ABL>(bf[ni], af[mi], acc[mi][ni]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -148,9 +158,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm(FwdArgs a) {
 // consecutive k for one m (or n): read with ds_read_b64_tr_b16 (4 k-rows x 16 columns per 16-lane
 // group, delivered column-major).  chunk' = chunk ^ (h(row) << 1), h = (row&3) | ((row>>3)&1)<<2,
 // puts the 8 row segments of one 32-lane half on disjoint banks (tools/lds_banks.py).
+template <int ABL>
+__device__ __forceinline__ i16x4 tr_read(const unsigned char* p) {
+  if constexpr (ABL & 4) return i16x4{1, 2, 3, 4};
+  else return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(p));
+}
 __device__ __forceinline__ int wg_h(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
-template <typename T, bool TR>
+template <typename T, bool TR, int ABL = 0>
 __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -208,9 +223,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm(WgradArgs a) {
   const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
   for (int t = 0; t < nk; ++t) {
     const int p = t & 1;
-    if (t + 1 < nk) {
-      stage(p ^ 1, t + 1);
-      if (t + 2 < nk) load_ids(t + 2);
+    if constexpr (!(ABL & 1)) {
+      if (t + 1 < nk) {
+        stage(p ^ 1, t + 1);
+        if (t + 2 < nk) load_ids(t + 2);
+      }
     }
     const unsigned char* As = smem + p * 2 * LDS_TILE_BYTES;
     const unsigned char* Bs = As + LDS_TILE_BYTES;
@@ -224,19 +241,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm(WgradArgs a) {
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {
           const int off = rbase + (((wm * 16 + mi * 2 + (pp >> 1)) ^ hx) << 4);
-          const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) i16x4*)(As + off));
-          const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) i16x4*)(As + off + 4 * 512));
+          const i16x4 lo = tr_read<ABL>(As + off);
+          const i16x4 hi = tr_read<ABL>(As + off + 4 * 512);
           af[mi] = i16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
           const int off = rbase + (((wn * 8 + ni * 2 + (pp >> 1)) ^ hx) << 4);
-          const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) i16x4*)(Bs + off));
-          const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) i16x4*)(Bs + off + 4 * 512));
+          const i16x4 lo = tr_read<ABL>(Bs + off);
+          const i16x4 hi = tr_read<ABL>(Bs + off + 4 * 512);
           bf[ni] = i16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
       } else {
@@ -265,7 +278,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm(WgradArgs a) {
 #pragma unroll
       for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = T::mfma(bf[ni], af[mi], acc[mi][ni]);
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma_abl<T, ABL>(bf[ni], af[mi], acc[mi][ni]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -316,7 +329,7 @@ __device__ __forceinline__ void ring_wait_and_barrier(int u, int nu) {
 // chunk' = chunk ^ ((-(row>>2)) & 3)  (conflict-free ds_read_b128: tools/lds_banks.py)
 __device__ __forceinline__ int fw_f(int row) { return (-(row >> 2)) & 3; }
 
-template <typename T, bool DROP, bool VEC>
+template <typename T, bool DROP, bool VEC, int ABL = 0>
 __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ring(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -365,19 +378,21 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ring(FwdArgs a) {
   const int aoff = (wm * 128 + frow) * 64 + ((fq ^ fw_f(frow)) << 4);   // fw_f(row) depends on row&15 only
   const int boff = (wn * 64 + frow) * 64 + ((fq ^ fw_f(frow)) << 4);
   for (int u = 0; u < nu; ++u) {
-    if (u + 3 < nu) stage(u + 3);
+    if constexpr (!(ABL & 1)) { if (u + 3 < nu) stage(u + 3); }
     const unsigned char* As = smem + (u & (RING - 1)) * UNIT_BYTES;
     const unsigned char* Bs = As + UNIT_OP_BYTES;
     i16x8 af[8], bf[4];
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi) af[mi] = *(const i16x8*)(As + aoff + mi * 16 * 64);
+    for (int mi = 0; mi < 8; ++mi)
+      af[mi] = (ABL & 4) ? i16x8{1, 2, 3, 4, 5, 6, 7, (short)mi} : *(const i16x8*)(As + aoff + mi * 16 * 64);
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) bf[ni] = *(const i16x8*)(Bs + boff + ni * 16 * 64);
+    for (int ni = 0; ni < 4; ++ni)
+      bf[ni] = (ABL & 4) ? i16x8{1, 2, 3, 4, 5, 6, 7, (short)ni} : *(const i16x8*)(Bs + boff + ni * 16 * 64);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = T::mfma(bf[ni], af[mi], acc[mi][ni]);
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma_abl<T, ABL>(bf[ni], af[mi], acc[mi][ni]);
     __builtin_amdgcn_s_setprio(0);
     ring_wait_and_barrier(u, nu);
   }
@@ -426,7 +441,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ring(FwdArgs a) {
 constexpr int WG_IDS_MAX = 8192;
 constexpr int WG_RING_LDS_BYTES = RING_LDS_BYTES + WG_IDS_MAX * 4;   // 160 KiB
 
-template <typename T>
+template <typename T, int ABL = 0>
 __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ring(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int32_t* ids = (int32_t*)(smem + RING_LDS_BYTES);
@@ -485,33 +500,29 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ring(WgradArgs a) {
   const int hx = wg_h(row1) << 1;
   const int rbase = row1 * 512 + (pp & 1) * 8;
   for (int u = 0; u < nu; ++u) {
-    if (u + 3 < nu) stage(u + 3);
+    if constexpr (!(ABL & 1)) { if (u + 3 < nu) stage(u + 3); }
     const unsigned char* As = smem + (u & (RING - 1)) * UNIT_BYTES;
     const unsigned char* Bs = As + UNIT_OP_BYTES;
     i16x8 af[8], bf[4];
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
       const int off = rbase + (((wm * 16 + mi * 2 + (pp >> 1)) ^ hx) << 4);
-      const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (__attribute__((address_space(3))) i16x4*)(As + off));
-      const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (__attribute__((address_space(3))) i16x4*)(As + off + 4 * 512));
+      const i16x4 lo = tr_read<ABL>(As + off);
+      const i16x4 hi = tr_read<ABL>(As + off + 4 * 512);
       af[mi] = i16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     }
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       const int off = rbase + (((wn * 8 + ni * 2 + (pp >> 1)) ^ hx) << 4);
-      const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (__attribute__((address_space(3))) i16x4*)(Bs + off));
-      const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (__attribute__((address_space(3))) i16x4*)(Bs + off + 4 * 512));
+      const i16x4 lo = tr_read<ABL>(Bs + off);
+      const i16x4 hi = tr_read<ABL>(Bs + off + 4 * 512);
       bf[ni] = i16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = T::mfma(bf[ni], af[mi], acc[mi][ni]);
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma_abl<T, ABL>(bf[ni], af[mi], acc[mi][ni]);
     __builtin_amdgcn_s_setprio(0);
     ring_wait_and_barrier(u, nu);
   }
@@ -531,6 +542,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ring(WgradArgs a) {
 
 // ------------------------------------------------------------------------------- launchers ----
 static bool g_wgrad_tr = true;
+static int g_ablate = 0;
+void set_ablate(int v) { g_ablate = v; }
 static int g_gemm_variant = 1;     // 0 = two-buffer K=64 kernels, 1 = 4-slot ring K=32 kernels
 void set_wgrad_tr(bool on) { g_wgrad_tr = on; }
 void set_gemm_variant(int v) { g_gemm_variant = v; }
@@ -543,6 +556,25 @@ static void launch_fwd_t(const FwdArgs& a, hipStream_t s) {
   (void)once;
   const int Rp = (int)round_up(a.R, R_ALIGN), Dp = (int)round_up(a.D, D_ALIGN);
   const dim3 grid((Rp / BM) * (Dp / BN)), block(GEMM_THREADS);
+  if constexpr (T::id == 0 && !DROP && VEC) {
+    if (g_ablate) {
+#define VV_ABL_FWD(N)                                                                              \
+      if (g_ablate == N) {                                                                         \
+        if (g_gemm_variant == 1) {                                                                 \
+          (void)hipFuncSetAttribute((const void*)k_fwd_gemm_ring<T, DROP, VEC, N>,                 \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES);   \
+          hipLaunchKernelGGL((k_fwd_gemm_ring<T, DROP, VEC, N>), grid, block, RING_LDS_BYTES, s, a); \
+        } else {                                                                                   \
+          (void)hipFuncSetAttribute((const void*)k_fwd_gemm<T, DROP, VEC, N>,                      \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);   \
+          hipLaunchKernelGGL((k_fwd_gemm<T, DROP, VEC, N>), grid, block, GEMM_LDS_BYTES, s, a);    \
+        }                                                                                          \
+        return;                                                                                    \
+      }
+      VV_ABL_FWD(1) VV_ABL_FWD(2) VV_ABL_FWD(3) VV_ABL_FWD(6) VV_ABL_FWD(7)
+#undef VV_ABL_FWD
+    }
+  }
   if (g_gemm_variant == 1) {
     static bool once2 = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ring<T, DROP, VEC>,
                          hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES), true);
@@ -583,6 +615,24 @@ static void launch_wgrad_ring_t(const WgradArgs& a, hipStream_t s) {
 }
 
 void launch_wgrad_gemm(int prec, const WgradArgs& a, hipStream_t s) {
+  if (g_ablate && prec == 0) {
+    const dim3 grid((a.Dp / BM) * (a.Fp / BN) * a.S), block(GEMM_THREADS);
+#define VV_ABL_WG(N)                                                                               \
+    if (g_ablate == N) {                                                                           \
+      if (g_gemm_variant == 1) {                                                                   \
+        (void)hipFuncSetAttribute((const void*)k_wgrad_gemm_ring<F16, N>,                          \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, WG_RING_LDS_BYTES);  \
+        hipLaunchKernelGGL((k_wgrad_gemm_ring<F16, N>), grid, block, WG_RING_LDS_BYTES, s, a);     \
+      } else {                                                                                     \
+        (void)hipFuncSetAttribute((const void*)k_wgrad_gemm<F16, true, N>,                         \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);     \
+        hipLaunchKernelGGL((k_wgrad_gemm<F16, true, N>), grid, block, GEMM_LDS_BYTES, s, a);       \
+      }                                                                                            \
+      return;                                                                                      \
+    }
+    VV_ABL_WG(1) VV_ABL_WG(2) VV_ABL_WG(3) VV_ABL_WG(6) VV_ABL_WG(7)
+#undef VV_ABL_WG
+  }
   if (g_gemm_variant == 1 && g_wgrad_tr && a.ksteps_per_split * BK <= WG_IDS_MAX) {
     if (prec == 0) launch_wgrad_ring_t<F16>(a, s); else launch_wgrad_ring_t<BF16>(a, s);
     return;
