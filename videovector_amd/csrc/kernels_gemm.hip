@@ -544,7 +544,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ring(WgradArgs a) {
 static bool g_wgrad_tr = true;
 static int g_ablate = 0;
 void set_ablate(int v) { g_ablate = v; }
-static int g_gemm_variant = 1;     // 0 = two-buffer K=64 kernels, 1 = 4-slot ring K=32 kernels
+static int g_gemm_variant = 0;     // 0 = two-buffer K=64 kernels (default, faster), 1 = 4-slot ring K=32 kernels
 void set_wgrad_tr(bool on) { g_wgrad_tr = on; }
 void set_gemm_variant(int v) { g_gemm_variant = v; }
 int wgrad_max_ksteps_per_split() { return g_gemm_variant == 1 ? WG_IDS_MAX / BK : (1 << 30); }
