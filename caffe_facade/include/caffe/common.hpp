@@ -1,0 +1,75 @@
+// common.hpp -- process-wide runtime state and glog-style logging for the videovec facade.
+// Mirrors the reference's include/caffe/common.hpp:70-147 (class Caffe: mode / phase / device / seed;
+// a process-global singleton, so one process drives one GPU).  Caffe::GPU means HIP on gfx950.
+#pragma once
+#include <cstdlib>
+#include <iostream>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../../include/videovec.h"
+
+namespace caffe {
+
+using std::string;
+using std::vector;
+using std::shared_ptr;
+
+// ---- logging (format of glog: "I0102 15:04:05.123456 tid file:line] msg"; FATAL aborts like
+// the reference's CHECK / LOG(FATAL) convention, e.g. src/caffe/net.cpp:353)
+class LogMessage {
+ public:
+  LogMessage(const char* file, int line, char sev);
+  ~LogMessage();
+  std::ostream& stream() { return ss_; }
+ private:
+  std::ostringstream ss_;
+  char sev_;
+};
+struct LogVoidify { void operator&(std::ostream&) {} };
+void SetLogFile(const std::string& path);    // GLOG_log_dir equivalent: also tee to a file
+
+#define LOG(sev) ::caffe::LogMessage(__FILE__, __LINE__, #sev[0]).stream()
+#define CHECK(c) (c) ? (void)0 : ::caffe::LogVoidify() & ::caffe::LogMessage(__FILE__, __LINE__, 'F').stream() << "Check failed: " #c " "
+#define CHECK_OP(a, b, op) CHECK((a) op (b)) << "(" << (a) << " vs. " << (b) << ") "
+#define CHECK_EQ(a, b) CHECK_OP(a, b, ==)
+#define CHECK_NE(a, b) CHECK_OP(a, b, !=)
+#define CHECK_LE(a, b) CHECK_OP(a, b, <=)
+#define CHECK_LT(a, b) CHECK_OP(a, b, <)
+#define CHECK_GE(a, b) CHECK_OP(a, b, >=)
+#define CHECK_GT(a, b) CHECK_OP(a, b, >)
+#define VV_CHECK(call) do { int rc_ = (call); CHECK(rc_ == 0) << #call << " failed (" << rc_ << "): " << vv_last_error(); } while (0)
+
+class Caffe {
+ public:
+  enum Brew { CPU, GPU };
+  enum Phase { TRAIN, TEST };
+  static Caffe& Get();
+  static Brew mode() { return Get().mode_; }
+  static Phase phase() { return Get().phase_; }
+  // There is no CPU execution path in this build: set_mode(CPU) is fatal (the reference's CPU
+  // path is restated only as the test oracle).
+  static void set_mode(Brew mode);
+  static void set_phase(Phase phase) { Get().phase_ = phase; }
+  static void SetDevice(const int device_id);              // common.cpp:127-145
+  static void set_random_seed(const unsigned int seed) { Get().seed_ = seed; }
+  static unsigned int random_seed() { return Get().seed_; }
+  static int device() { return Get().device_; }
+  // MFMA operand precision of the context ("f16" default, "bf16"); env VV_PREC overrides
+  static void set_precision(const std::string& p);
+  // The HIP context of this process (created on first use)
+  static vv_ctx* ctx();
+  static void Reset();                                     // destroy the context (tests)
+ private:
+  Caffe() {}
+  Brew mode_ = GPU;
+  Phase phase_ = TRAIN;
+  int device_ = 0;
+  int prec_ = VV_PREC_F16;
+  unsigned int seed_ = 1701;
+  vv_ctx* ctx_ = nullptr;
+};
+
+}  // namespace caffe

@@ -1,0 +1,423 @@
+// net.cpp -- Net (reference: src/caffe/net.cpp) with the fused videovec plan.
+#include "caffe/net.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace caffe {
+
+template <typename Dtype>
+Net<Dtype>::Net(const string& param_file, Caffe::Phase phase) {
+  NetParameter param("NetParameter");
+  pl::ReadProtoFromTextFileOrDie(param_file, &param);
+  param.mutable_msg("state")->set_enum("phase", phase == Caffe::TRAIN ? "TRAIN" : "TEST");
+  Init(param);
+}
+
+template <typename Dtype>
+bool Net<Dtype>::StateMeetsRule(const NetState& state, const pl::Message& rule, const string& layer_name) {
+  if (rule.has("phase") && rule.get_int("phase") != state.get_int("phase")) {
+    LOG(INFO) << "The NetState phase (" << state.get_int("phase") << ") differed from the phase (" << rule.get_int("phase")
+              << ") specified by a rule in layer " << layer_name;
+    return false;
+  }
+  if (rule.has("min_level") && state.get_int("level") < rule.get_int("min_level")) return false;
+  if (rule.has("max_level") && state.get_int("level") > rule.get_int("max_level")) return false;
+  for (int i = 0; i < rule.size("stage"); ++i) {
+    bool has = false;
+    for (int j = 0; !has && j < state.size("stage"); ++j) has = rule.get_str("stage", i) == state.get_str("stage", j);
+    if (!has) return false;
+  }
+  for (int i = 0; i < rule.size("not_stage"); ++i)
+    for (int j = 0; j < state.size("stage"); ++j)
+      if (rule.get_str("not_stage", i) == state.get_str("stage", j)) return false;
+  return true;
+}
+
+template <typename Dtype>
+void Net<Dtype>::FilterNet(const NetParameter& param, NetParameter* out) {
+  NetState state(param.get_msg("state"));
+  if (!state.has("phase")) state.set_enum("phase", Caffe::phase() == Caffe::TRAIN ? "TRAIN" : "TEST");
+  *out = param;
+  out->clear("layers");
+  for (int i = 0; i < param.size("layers"); ++i) {
+    const LayerParameter& lp = param.get_msg("layers", i);
+    const string lname = lp.get_str("name");
+    CHECK(lp.size("include") == 0 || lp.size("exclude") == 0) << "Specify either include rules or exclude rules; not both.";
+    bool included = lp.size("include") == 0;
+    for (int j = 0; included && j < lp.size("exclude"); ++j) if (StateMeetsRule(state, lp.get_msg("exclude", j), lname)) included = false;
+    for (int j = 0; !included && j < lp.size("include"); ++j) if (StateMeetsRule(state, lp.get_msg("include", j), lname)) included = true;
+    if (included) *out->add_msg("layers") = lp;
+  }
+}
+
+template <typename Dtype>
+void Net<Dtype>::Init(const NetParameter& in_param) {
+  NetParameter param("NetParameter");
+  FilterNet(in_param, &param);                                                        // net.cpp:36-37
+  LOG(INFO) << "Initializing net from parameters: " << param.size("layers") << " layers after phase filtering";
+  name_ = param.get_str("name");
+  CHECK_EQ(param.size("input"), 0) << "net-level input blobs are not used by the videovec graph";
+  std::set<string> available, consumed;
+  const int L = param.size("layers");
+  bottom_vecs_.resize(L); top_vecs_.resize(L); bottom_id_vecs_.resize(L); top_id_vecs_.resize(L);
+  for (int li = 0; li < L; ++li) {
+    const LayerParameter& lp = param.get_msg("layers", li);
+    layers_.push_back(shared_ptr<Layer<Dtype> >(GetLayer<Dtype>(lp)));                // net.cpp:63-66
+    layer_names_.push_back(lp.get_str("name"));
+    layer_names_index_[lp.get_str("name")] = li;
+    LOG(INFO) << "Creating Layer " << lp.get_str("name");
+    for (int b = 0; b < lp.size("bottom"); ++b) {                                     // AppendBottom, net.cpp:381-402
+      const string bn = lp.get_str("bottom", b);
+      CHECK(available.count(bn)) << "Unknown blob input " << bn << " (at index " << b << ") to layer " << li;
+      const int id = blob_names_index_[bn];
+      LOG(INFO) << lp.get_str("name") << " <- " << bn;
+      bottom_vecs_[li].push_back(blobs_[id].get());
+      bottom_id_vecs_[li].push_back(id);
+      consumed.insert(bn);     // the reference erases here and relies on InsertSplits for fan-out
+                               // (insert_splits.cpp); the fused plan sums fan-in diffs itself, so no
+                               // SPLIT layers are materialised and a blob may simply be read again
+    }
+    for (int t = 0; t < lp.size("top"); ++t) {                                        // AppendTop, net.cpp:333-379
+      const string tn = lp.get_str("top", t);
+      if (t < lp.size("bottom") && lp.get_str("bottom", t) == tn) {                   // in-place
+        LOG(INFO) << lp.get_str("name") << " -> " << tn << " (in-place)";
+        const int id = blob_names_index_[tn];
+        top_vecs_[li].push_back(blobs_[id].get());
+        top_id_vecs_[li].push_back(id);
+      } else {
+        CHECK(!blob_names_index_.count(tn)) << "Duplicate blobs produced by multiple sources.";
+        LOG(INFO) << lp.get_str("name") << " -> " << tn;
+        blobs_.push_back(shared_ptr<Blob<Dtype> >(new Blob<Dtype>()));
+        blob_names_.push_back(tn);
+        blob_names_index_[tn] = (int)blobs_.size() - 1;
+        top_vecs_[li].push_back(blobs_.back().get());
+        top_id_vecs_[li].push_back((int)blobs_.size() - 1);
+      }
+      available.insert(tn);
+    }
+    layers_[li]->SetUp(bottom_vecs_[li], &top_vecs_[li]);                            // net.cpp:97
+    blob_loss_weights_.resize(blobs_.size(), Dtype(0));
+    for (size_t t = 0; t < top_vecs_[li].size(); ++t) {
+      blob_loss_weights_[top_id_vecs_[li][t]] = layers_[li]->loss((int)t);
+      LOG(INFO) << "Top shape: " << top_vecs_[li][t]->num() << " " << top_vecs_[li][t]->channels() << " "
+                << top_vecs_[li][t]->height() << " " << top_vecs_[li][t]->width() << " (" << top_vecs_[li][t]->count() << ")";
+      if (layers_[li]->loss((int)t)) LOG(INFO) << "    with loss weight " << layers_[li]->loss((int)t);
+    }
+    // parameter bookkeeping (net.cpp:99-140, 404-464): lr / decay multipliers per blob
+    const int nb = (int)layers_[li]->blobs().size();
+    CHECK(lp.size("blobs_lr") == nb || lp.size("blobs_lr") == 0) << "Incorrect blobs lr size: should be either 0 or the same as the number of the layer's parameter blobs.";
+    CHECK(lp.size("weight_decay") == nb || lp.size("weight_decay") == 0) << "Incorrect blobs weight decay size";
+    CHECK_EQ(lp.size("param"), 0) << "shared parameters (param:) are not used by the videovec graph";
+    for (int b = 0; b < nb; ++b) {
+      params_.push_back(layers_[li]->blobs()[b]);
+      params_lr_.push_back(lp.size("blobs_lr") ? (float)lp.get_num("blobs_lr", b) : 1.f);
+      params_weight_decay_.push_back(lp.size("weight_decay") ? (float)lp.get_num("weight_decay", b) : 1.f);
+    }
+  }
+  // remaining blobs are the net outputs (net.cpp:200-208; a std::set, hence sorted by name)
+  for (const string& n : available) {
+    if (consumed.count(n)) continue;
+    LOG(INFO) << "This network produces output " << n;
+    net_output_blobs_.push_back(blobs_[blob_names_index_[n]].get());
+    net_output_blob_indices_.push_back(blob_names_index_[n]);
+  }
+  MatchVideovecTrainGraph();
+  // device side: feature table, parameters
+  auto* data = static_cast<VideoSampledShotsDataLayer<Dtype>*>(layers_[plan_.data_layer].get());
+  data->dataset()->UploadTable(Caffe::ctx());
+  PushParamsToDevice();
+  LOG(INFO) << "Network initialization done.";
+}
+
+// ---------------------------------------------------------------------------------------------
+// Graph matcher: symbolic forward execution of the filtered graph.  Every blob gets a description
+// of what it is in terms of the fused plan; a layer whose inputs fit no rule is fatal.
+// ---------------------------------------------------------------------------------------------
+namespace {
+enum Kind { K_NONE, K_DATA, K_DATUM, K_XROWS, K_Y, K_H, K_EMB, K_CTXMEAN, K_CTXNORM, K_PN, K_PNNORM, K_PNORM,
+            K_PROD, K_SCORE, K_NEGSCORES, K_LOSS, K_VIOL, K_LABEL };
+struct Sym { Kind k = K_NONE; int a = 0; int reps = 1; };
+}
+
+template <typename Dtype>
+void Net<Dtype>::MatchVideovecTrainGraph() {
+  const char* why = "This build runs only the videovec_embedding TRAIN graph "
+                    "(projects/videovec_embedding/mednet_embedding_train.prototxt); ";
+  std::map<int, Sym> sym;      // blob id -> symbol
+  FusedPlan& P = plan_;
+  int CN = 0;
+  bool have_dropout = false;
+  for (size_t li = 0; li < layers_.size(); ++li) {
+    Layer<Dtype>* layer = layers_[li].get();
+    const string type = layer->type();
+    const string lname = layer_names_[li];
+    const vector<int>& bi = bottom_id_vecs_[li];
+    const vector<int>& ti = top_id_vecs_[li];
+    auto in = [&](int i) -> Sym { return sym[bi[i]]; };
+    auto bad = [&](const string& what) { LOG(FATAL) << why << "layer " << lname << " (" << type << "): " << what; };
+    if (type == "VIDEO_SAMPLED_SHOTS_DATA") {
+      if (P.data_layer >= 0) bad("second data layer");
+      auto* d = static_cast<VideoSampledShotsDataLayer<Dtype>*>(layer);
+      P.data_layer = (int)li; P.B = d->batch_size(); P.C = d->context_size(); P.Nn = d->num_negative_samples(); P.F = d->feature_size();
+      CN = P.C + P.Nn;
+      if (P.Nn < 1) bad("num_negative_samples must be >= 1 for the ranking loss");
+      sym[ti[0]].k = K_DATA;
+      if (ti.size() > 1) sym[ti[1]].k = K_LABEL;
+    } else if (type == "SLICE") {
+      const int dim = (int)layer->layer_param().get_msg("slice_param").get_int("slice_dim");
+      const Sym s = in(0);
+      if (s.k == K_DATA && dim == 1) {
+        if ((int)ti.size() != CN) bad("the input slice must produce context_size + num_negative_samples tops");
+        for (int c = 0; c < CN; ++c) { sym[ti[c]].k = K_DATUM; sym[ti[c]].a = c; }
+      } else if (s.k == K_H && dim == 0) {
+        if ((int)ti.size() != CN) bad("the embedding slice must produce context_size + num_negative_samples tops");
+        for (int c = 0; c < CN; ++c) { sym[ti[c]].k = K_EMB; sym[ti[c]].a = c; }
+      } else if (s.k == K_PNNORM && dim == 0) {
+        if ((int)ti.size() != 1 + P.Nn) bad("the normalised target/negative slice must produce 1 + num_negative_samples tops");
+        for (int q = 0; q <= P.Nn; ++q) { sym[ti[q]].k = K_PNORM; sym[ti[q]].a = q; }
+      } else bad("unexpected SLICE input");
+    } else if (type == "CONCAT") {
+      const int dim = (int)layer->layer_param().get_msg("concat_param").get_int("concat_dim");
+      if (in(0).k == K_DATUM && dim == 0) {
+        if ((int)bi.size() != CN) bad("the input concat must take every sliced datum");
+        for (int c = 0; c < CN; ++c) if (in(c).k != K_DATUM || in(c).a != c) bad("datum order must be target, context.., negatives.. (channel-major rows)");
+        sym[ti[0]].k = K_XROWS;
+      } else if (in(0).k == K_EMB && dim == 0) {
+        if ((int)bi.size() != 1 + P.Nn) bad("concat_pos_neg must take the target and every negative embedding");
+        if (in(0).a != 0) bad("first bottom must be the target embedding");
+        for (int q = 1; q <= P.Nn; ++q) if (in(q).k != K_EMB || in(q).a != P.C + q - 1) bad("negative embeddings out of order");
+        sym[ti[0]].k = K_PN;
+      } else if (in(0).k == K_SCORE && dim == 1) {
+        if ((int)bi.size() != P.Nn) bad("the score concat must take every negative score");
+        for (int q = 0; q < P.Nn; ++q) if (in(q).k != K_SCORE || in(q).a != q + 1 || in(q).reps != 1) bad("negative scores out of order");
+        sym[ti[0]].k = K_NEGSCORES;
+        P.negative_scores_blob = blob_names_[ti[0]];
+      } else bad("unexpected CONCAT inputs");
+    } else if (type == "FLATTEN") {
+      if (in(0).k != K_XROWS) bad("FLATTEN is expected on the concatenated input rows");
+      sym[ti[0]].k = K_XROWS;
+    } else if (type == "INNER_PRODUCT") {
+      if (in(0).k != K_XROWS) bad("fc layer must consume the gathered feature rows");
+      if (P.ip_layer >= 0) bad("second INNER_PRODUCT layer");
+      P.ip_layer = (int)li;
+      P.D = static_cast<InnerProductLayer<Dtype>*>(layer)->num_output();
+      if (!layer->layer_param().get_msg("inner_product_param").get_bool("bias_term")) bad("bias_term: false is not built");
+      if (layer->layer_param().get_msg("inner_product_param").get_num("regularization") != 0) bad("InnerProduct regularization is not built");
+      sym[ti[0]].k = K_Y;
+    } else if (type == "RELU") {
+      if (in(0).k != K_Y) bad("RELU is expected on the fc output");
+      if (layer->layer_param().get_msg("relu_param").get_num("negative_slope") != 0) bad("negative_slope != 0 is not built");
+      sym[ti[0]].k = K_H;
+      P.ip2_blob = blob_names_[ti[0]];
+    } else if (type == "DROPOUT") {
+      if (in(0).k != K_H || have_dropout) bad("DROPOUT is expected once, on the ReLU output");
+      have_dropout = true;
+      P.dropout_ratio = (float)layer->layer_param().get_msg("dropout_param").get_num("dropout_ratio");
+      sym[ti[0]].k = K_H;
+      P.ip2_blob = blob_names_[ti[0]];
+    } else if (type == "ELTWISE") {
+      auto* e = static_cast<EltwiseLayer<Dtype>*>(layer);
+      if (e->op() == "SUM") {
+        if ((int)bi.size() != P.C - 1) bad("context_average must sum the C-1 context embeddings");
+        for (int j = 0; j < P.C - 1; ++j) if (in(j).k != K_EMB || in(j).a != j + 1) bad("context embeddings out of order");
+        P.ctx_coeff.assign(e->coeffs().begin(), e->coeffs().end());
+        sym[ti[0]].k = K_CTXMEAN;
+      } else if (e->op() == "PROD") {
+        if (bi.size() != 2) bad("PROD takes the context feature and one embedding");
+        if (!layer->layer_param().get_msg("eltwise_param").get_bool("stable_prod_grad")) bad("stable_prod_grad: false is not built");
+        Sym a = in(0), b = in(1);
+        if (a.k == K_PNORM && b.k == K_CTXNORM) std::swap(a, b);
+        if (a.k != K_CTXNORM || b.k != K_PNORM) bad("PROD must pair context_feature with a normalised target / negative embedding");
+        sym[ti[0]].k = K_PROD; sym[ti[0]].a = b.a;
+      } else bad("Eltwise MAX is not part of the graph");
+    } else if (type == "NORMALIZATION") {
+      if (in(0).k == K_CTXMEAN) sym[ti[0]].k = K_CTXNORM;
+      else if (in(0).k == K_PN) sym[ti[0]].k = K_PNNORM;
+      else bad("unexpected NORMALIZATION input");
+    } else if (type == "SUM") {
+      if (in(0).k != K_PROD) bad("SUM is expected on a PROD output");
+      const int reps = (int)layer->layer_param().get_msg("sum_param").get_num("num_output");
+      sym[ti[0]].k = K_SCORE; sym[ti[0]].a = in(0).a; sym[ti[0]].reps = reps;
+      if (in(0).a == 0) {
+        if (reps != P.Nn) bad("sum_true num_output must equal num_negative_samples (quirk Q3)");
+        P.target_score_blob = blob_names_[ti[0]];
+      } else if (reps != 1) bad("negative score SUM layers must have num_output 1");
+    } else if (type == "MAX_MARGIN_LOSS") {
+      if (P.loss_layer >= 0) bad("second loss layer");
+      if (bi.size() != 2) bad("the weighted loss (third bottom) is not built yet");
+      if (in(0).k != K_SCORE || in(0).a != 0 || in(1).k != K_NEGSCORES) bad("bottoms must be target_score, negative_scores");
+      P.loss_layer = (int)li;
+      const pl::Message& mp = layer->layer_param().get_msg("max_margin_loss_param");
+      P.margin = (float)mp.get_num("margin");
+      P.norm = mp.get_enum("norm") == "L2" ? VV_NORM_L2 : VV_NORM_L1;
+      P.loss_weight = (float)layer->loss(0);
+      if (ti.size() > 1 && layer->loss(1) != 0) bad("a loss weight on train_violations is not built");
+      sym[ti[0]].k = K_LOSS; P.loss_blob = blob_names_[ti[0]];
+      if (ti.size() > 1) { sym[ti[1]].k = K_VIOL; P.violations_blob = blob_names_[ti[1]]; }
+    } else if (type == "SPLIT") {
+      for (size_t t = 0; t < ti.size(); ++t) sym[ti[t]] = in(0);
+    } else {
+      bad("layer type outside the path");
+    }
+  }
+  if (P.data_layer < 0 || P.ip_layer < 0 || P.loss_layer < 0)
+    LOG(FATAL) << why << "the graph needs a VIDEO_SAMPLED_SHOTS_DATA layer, one INNER_PRODUCT layer and a MAX_MARGIN_LOSS layer";
+  vv_step_cfg_default(&cfg_);
+  cfg_.B = P.B; cfg_.C = P.C; cfg_.Nn = P.Nn;
+  cfg_.margin = P.margin; cfg_.norm = P.norm; cfg_.loss_weight = P.loss_weight;
+  cfg_.ctx_coeff = P.ctx_coeff.data();
+  cfg_.dropout_ratio = P.dropout_ratio;
+  cfg_.dropout_seed = Caffe::random_seed();
+  // blobs_lr / weight_decay multipliers of fc7's {W, b} (mednet_embedding_train.prototxt:195-198)
+  int p0 = 0;
+  for (int li = 0; li < P.ip_layer; ++li) p0 += (int)layers_[li]->blobs().size();
+  for (int k = 0; k < 2; ++k) { cfg_.lr_mult[k] = params_lr_[p0 + k]; cfg_.decay_mult[k] = params_weight_decay_[p0 + k]; }
+  LOG(INFO) << "Fused videovec plan: B=" << P.B << " C=" << P.C << " Nn=" << P.Nn << " F=" << P.F << " D=" << P.D
+            << " margin=" << P.margin << " norm=L" << P.norm << " dropout=" << P.dropout_ratio;
+}
+
+template <typename Dtype>
+void Net<Dtype>::PushParamsToDevice() {
+  Layer<Dtype>* ip = layers_[plan_.ip_layer].get();
+  CHECK_EQ(ip->blobs()[0]->count(), plan_.D * plan_.F);
+  VV_CHECK(vv_params_set(Caffe::ctx(), plan_.D, ip->blobs()[0]->cpu_data(), ip->blobs()[1]->cpu_data(), NULL, NULL));
+  params_stale_ = false;
+}
+template <typename Dtype>
+void Net<Dtype>::PullParamsFromDevice() {
+  if (!params_stale_) return;
+  Layer<Dtype>* ip = layers_[plan_.ip_layer].get();
+  VV_CHECK(vv_params_get(Caffe::ctx(), ip->blobs()[0]->mutable_cpu_data(), ip->blobs()[1]->mutable_cpu_data(), NULL, NULL));
+  params_stale_ = false;
+}
+template <typename Dtype>
+vector<shared_ptr<Blob<Dtype> > >& Net<Dtype>::params() { PullParamsFromDevice(); return params_; }
+
+template <typename Dtype>
+void Net<Dtype>::GetHistory(vector<shared_ptr<Blob<Dtype> > >* history) {
+  history->resize(2);
+  (*history)[0].reset(new Blob<Dtype>(1, 1, plan_.D, plan_.F));
+  (*history)[1].reset(new Blob<Dtype>(1, 1, 1, plan_.D));
+  VV_CHECK(vv_params_get(Caffe::ctx(), NULL, NULL, (*history)[0]->mutable_cpu_data(), (*history)[1]->mutable_cpu_data()));
+}
+template <typename Dtype>
+void Net<Dtype>::SetHistory(const vector<shared_ptr<Blob<Dtype> > >& history) {
+  CHECK_EQ((int)history.size(), 2) << "Incorrect length of history blobs.";
+  CHECK_EQ(history[0]->count(), plan_.D * plan_.F); CHECK_EQ(history[1]->count(), plan_.D);
+  PullParamsFromDevice();
+  Layer<Dtype>* ip = layers_[plan_.ip_layer].get();
+  VV_CHECK(vv_params_set(Caffe::ctx(), plan_.D, ip->blobs()[0]->cpu_data(), ip->blobs()[1]->cpu_data(),
+                         history[0]->cpu_data(), history[1]->cpu_data()));
+}
+
+template <typename Dtype>
+Dtype Net<Dtype>::ForwardBackward(const vector<Blob<Dtype>*>&) {
+  auto* data = static_cast<VideoSampledShotsDataLayer<Dtype>*>(layers_[plan_.data_layer].get());
+  data->NextBatch(&idx_, &last_src_, &label_);
+  cfg_.ctx_coeff = plan_.ctx_coeff.data();
+  bool q1 = false;
+  for (size_t i = 0; i < idx_.size() && !q1; ++i) q1 = idx_[i] != last_src_[i];
+  if (q1) VV_CHECK(vv_forward_backward_q1(Caffe::ctx(), &cfg_, idx_.data(), last_src_.data()));
+  else VV_CHECK(vv_forward_backward(Caffe::ctx(), &cfg_, idx_.data(), 0));
+  float loss = 0, viol = 0;
+  VV_CHECK(vv_loss_get(Caffe::ctx(), &loss, &viol));
+  // keep the two scalar output blobs current (they feed the solver's display lines)
+  if (has_blob(plan_.loss_blob)) blobs_[blob_names_index_[plan_.loss_blob]]->mutable_cpu_data()[0] = loss / (plan_.loss_weight ? plan_.loss_weight : 1.f);
+  if (!plan_.violations_blob.empty()) blobs_[blob_names_index_[plan_.violations_blob]]->mutable_cpu_data()[0] = viol;
+  ++iter_;
+  return loss;
+}
+template <typename Dtype>
+const vector<Blob<Dtype>*>& Net<Dtype>::Forward(const vector<Blob<Dtype>*>& bottom, Dtype* loss) {
+  const Dtype l = ForwardBackward(bottom);
+  if (loss) *loss = l;
+  return net_output_blobs_;
+}
+template <typename Dtype>
+const vector<Blob<Dtype>*>& Net<Dtype>::ForwardPrefilled(Dtype* loss) { return Forward(vector<Blob<Dtype>*>(), loss); }
+
+template <typename Dtype>
+void Net<Dtype>::SetUpdateHyperParams(float rate, float momentum, float weight_decay, const string& reg) {
+  cfg_.lr = rate; cfg_.momentum = momentum; cfg_.weight_decay = weight_decay;
+  if (reg == "L2") cfg_.reg = VV_REG_L2;
+  else if (reg == "L1") cfg_.reg = VV_REG_L1;
+  else LOG(FATAL) << "Unknown regularization type: " << reg;                          // solver.cpp:523
+}
+template <typename Dtype>
+void Net<Dtype>::Update() {
+  VV_CHECK(vv_apply_update(Caffe::ctx(), &cfg_));
+  params_stale_ = true;
+}
+
+template <typename Dtype>
+bool Net<Dtype>::has_blob(const string& n) { return blob_names_index_.count(n) != 0; }
+template <typename Dtype>
+bool Net<Dtype>::has_layer(const string& n) { return layer_names_index_.count(n) != 0; }
+template <typename Dtype>
+const shared_ptr<Layer<Dtype> > Net<Dtype>::layer_by_name(const string& n) {
+  if (!has_layer(n)) { LOG(WARNING) << "Unknown layer name " << n; return shared_ptr<Layer<Dtype> >(); }
+  return layers_[layer_names_index_[n]];
+}
+template <typename Dtype>
+const shared_ptr<Blob<Dtype> > Net<Dtype>::blob_by_name(const string& n) {
+  if (!has_blob(n)) { LOG(WARNING) << "Unknown blob name " << n; return shared_ptr<Blob<Dtype> >(); }   // net.cpp:846-857
+  shared_ptr<Blob<Dtype> > b = blobs_[blob_names_index_[n]];
+  if (iter_ > 0) {
+    const int B = plan_.B, Nn = plan_.Nn;
+    if (n == plan_.ip2_blob) VV_CHECK(vv_blobs_get(Caffe::ctx(), b->mutable_cpu_data(), NULL, NULL, NULL));
+    else if (n == plan_.target_score_blob) { CHECK_EQ(b->count(), B * Nn); VV_CHECK(vv_blobs_get(Caffe::ctx(), NULL, b->mutable_cpu_data(), NULL, NULL)); }
+    else if (n == plan_.negative_scores_blob) { CHECK_EQ(b->count(), B * Nn); VV_CHECK(vv_blobs_get(Caffe::ctx(), NULL, NULL, b->mutable_cpu_data(), NULL)); }
+  }
+  return b;
+}
+
+template <typename Dtype>
+void Net<Dtype>::CopyTrainedLayersFrom(const NetParameter& param) {
+  for (int i = 0; i < param.size("layers"); ++i) {
+    const LayerParameter& src = param.get_msg("layers", i);
+    const string sname = src.get_str("name");
+    if (!layer_names_index_.count(sname)) { LOG(INFO) << "Ignoring source layer " << sname; continue; }   // net.cpp:703-706
+    LOG(INFO) << "Copying source layer " << sname;
+    vector<shared_ptr<Blob<Dtype> > >& tgt = layers_[layer_names_index_[sname]]->blobs();
+    CHECK_EQ((int)tgt.size(), src.size("blobs")) << "Incompatible number of blobs for layer " << sname;
+    for (size_t j = 0; j < tgt.size(); ++j) {
+      const pl::Message& bp = src.get_msg("blobs", (int)j);
+      CHECK_EQ(tgt[j]->num(), bp.get_int("num")); CHECK_EQ(tgt[j]->channels(), bp.get_int("channels"));
+      CHECK_EQ(tgt[j]->height(), bp.get_int("height")); CHECK_EQ(tgt[j]->width(), bp.get_int("width"));
+      tgt[j]->FromProto(bp);
+    }
+  }
+  // keep the momentum history that is on the device
+  vector<shared_ptr<Blob<Dtype> > > hist;
+  GetHistory(&hist);
+  params_stale_ = false;
+  Layer<Dtype>* ip = layers_[plan_.ip_layer].get();
+  VV_CHECK(vv_params_set(Caffe::ctx(), plan_.D, ip->blobs()[0]->cpu_data(), ip->blobs()[1]->cpu_data(),
+                         hist[0]->cpu_data(), hist[1]->cpu_data()));
+}
+template <typename Dtype>
+void Net<Dtype>::CopyTrainedLayersFrom(const string trained_filename) {
+  NetParameter param("NetParameter");
+  pl::ReadProtoFromBinaryFileOrDie(trained_filename, &param);
+  CopyTrainedLayersFrom(param);
+}
+template <typename Dtype>
+void Net<Dtype>::ToProto(NetParameter* param, bool write_diff) {
+  PullParamsFromDevice();
+  if (write_diff) {
+    Layer<Dtype>* ip = layers_[plan_.ip_layer].get();
+    if (iter_ > 0) VV_CHECK(vv_grads_get(Caffe::ctx(), ip->blobs()[0]->mutable_cpu_diff(), ip->blobs()[1]->mutable_cpu_diff()));
+  }
+  *param = NetParameter("NetParameter");
+  param->set_str("name", name_);
+  LOG(INFO) << "Serializing " << layers_.size() << " layers";                          // net.cpp:784
+  for (size_t i = 0; i < layers_.size(); ++i) {
+    LayerParameter* lp = param->add_msg("layers");
+    layers_[i]->ToProto(lp, write_diff);
+  }
+}
+
+template class Net<float>;
+
+}  // namespace caffe

@@ -102,6 +102,12 @@ void vv_step_cfg_default(vv_step_cfg* cfg);
  * (video_sampled_shots_data_layer.cpp:214-220: channel 0 target, 1..C-1 context, C.. negatives),
  * -1 = all-zero row; idx_on_device != 0 means idx is a device pointer. */
 int vv_forward_backward(vv_ctx* ctx, const vv_step_cfg* cfg, const int32_t* idx, int idx_on_device);
+/* The same with the reference's quirk Q1 honoured: a same-video negative (max_same_video_negs > 0)
+ * is copied WITHOUT its last feature (video_sampled_shots_data_layer.cpp:492), so that element of
+ * the slot keeps what the previous batch left there.  last_src: int32 [B][C+Nn] = the table row
+ * whose LAST feature each slot holds (-1 = zero), as vv_sampler_next reports it; both host arrays. */
+int vv_forward_backward_q1(vv_ctx* ctx, const vv_step_cfg* cfg, const int32_t* idx,
+                           const int32_t* last_src);
 /* SGDSolver::ComputeUpdateValue + Net::Update (solver.cpp:485-531, net.cpp:803-839,
  * blob.cpp:112-136) on the gradients currently in the gradient buffer. */
 int vv_apply_update(vv_ctx* ctx, const vv_step_cfg* cfg);

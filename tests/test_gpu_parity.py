@@ -266,6 +266,34 @@ def test_sgd_steps_match_oracle(vv, oracle, prec):
     assert rel_fro(Wg, f["W"]) <= TOL[prec]["grad"] and rel_fro(hWg, f["hW"]) <= TOL[prec]["grad"]
 
 
+def test_q1_same_video_negatives(vv, oracle):
+    # shipped setting max_same_video_negs: 6 -- the data layer copies those rows without their last
+    # feature (video_sampled_shots_data_layer.cpp:492); indices from the product sampler
+    B, C, Nn, F, D = 16, 5, 10, 256, 64
+    ds = SyntheticVideos(seed=13, n_videos=60)
+    table = ds.table(F)
+    W, b = init_weights(13, D, F, std=0.01)
+    smp = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, batch_size=B, context_size=C, num_negative_samples=Nn,
+                     max_buffer_size=300, negative_swap_percentage=50, max_same_video_negs=6)
+    eng = vv.Engine(0, "f16")
+    eng.table_set(table); eng.params_set(W, b)
+    cfg = vv.StepConfig(B, C, Nn)
+    for _ in range(3):            # later batches inherit last features from earlier ones
+        idx, last, _ = smp.next(want_last=True, want_label=True)
+    assert (idx != last).sum() >= B
+    eng.forward_backward_q1(cfg, idx, last)
+    got = dict(loss=eng.loss()[0], **eng.blobs(cfg, ip1_diff=True))
+    got["dW"], got["db"] = eng.grads()
+    kw = dict(C_=C, Nn=Nn, last_src=last)
+    ref = oracle.forward_backward(table, idx, W, b, want=("H", "s_true", "s_bogus", "dY", "dW", "db"), **kw)
+    ref["q"] = oracle.forward_backward(round_table(table, "f16"), idx, round_operand(W, "f16"), b,
+                                       want=("dY", "dW", "db"), **kw)
+    check(got, ref, TOL["f16"], "q1")
+    # and it differs from ignoring the quirk
+    eng.forward_backward(cfg, idx)
+    assert abs(eng.loss()[0] - got["loss"]) > 0
+
+
 def test_embed_matches_oracle(vv, oracle):
     ds, table, idx, W, b = make_case(12, 20, 4, 3, 2, 512, 96)
     eng = vv.Engine(0, "f16")

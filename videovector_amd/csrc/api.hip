@@ -39,6 +39,8 @@ struct vv_ctx {
   hipStream_t stream = nullptr, own_stream = nullptr;
   // feature table
   uint16_t* table = nullptr; int64_t n_rows = 0; int F = 0, Fp = 0; float sx = 1.f;
+  int64_t patch_cap = 0;            // scratch rows after the zero row (quirk Q1 composites)
+  int32_t* patch_desc = nullptr; int64_t patch_desc_cap = 0;
   // parameters
   int D = 0, Dp = 0;
   float *W = nullptr, *b = nullptr, *hW = nullptr, *hb = nullptr;
@@ -148,7 +150,7 @@ int vv_destroy(vv_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   free_batch(c);
-  dfree(c->table); dfree(c->W); dfree(c->b); dfree(c->hW); dfree(c->hb); dfree(c->Wh);
+  dfree(c->table); dfree(c->patch_desc); dfree(c->W); dfree(c->b); dfree(c->hW); dfree(c->hb); dfree(c->Wh);
   dfree(c->scales); dfree(c->wmax_blocks); dfree(c->grads_own); dfree(c->mask); dfree(c->loss2);
   for (auto& kv : c->prof_map)
     for (auto& e : kv.second.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -177,7 +179,7 @@ static int table_alloc(vv_ctx* c, int64_t n_rows, int F) {
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamSynchronize(c->stream));
   if (c->D && F != c->F) return fail(VV_ERR_STATE, "table: F=%d differs from the parameters' F=%d", F, c->F);
-  dfree(c->table); c->table = nullptr;
+  dfree(c->table); c->table = nullptr; c->patch_cap = 0;
   c->n_rows = n_rows; c->F = F; c->Fp = (int)round_up(F, F_ALIGN);
   const size_t bytes = (size_t)(n_rows + 1) * c->Fp * sizeof(uint16_t);   // +1: the all-zero row
   HIPCHK(hipMalloc(&c->table, bytes));
@@ -352,7 +354,7 @@ static int check_cfg(vv_ctx* c, const vv_step_cfg* cfg) {
   return VV_OK;
 }
 
-int vv_forward_backward(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int idx_on_device) {
+static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int idx_on_device, int64_t row_limit) {
   int rc = check_cfg(c, cfg);
   if (rc) return rc;
   if (!idx) return fail(VV_ERR_ARG, "vv_forward_backward: idx is NULL");
@@ -364,7 +366,7 @@ int vv_forward_backward(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, i
   const int32_t* didx = idx;
   if (!idx_on_device) {
     for (int i = 0; i < c->R; ++i)
-      if (idx[i] < -1 || idx[i] >= c->n_rows) return fail(VV_ERR_ARG, "idx[%d] = %d out of range [-1, %lld)", i, idx[i], (long long)c->n_rows);
+      if (idx[i] < -1 || idx[i] >= row_limit) return fail(VV_ERR_ARG, "idx[%d] = %d out of range [-1, %lld)", i, idx[i], (long long)c->n_rows);
     HIPCHK(hipMemcpyAsync(c->idx_dev, idx, (size_t)c->R * 4, hipMemcpyHostToDevice, s));
     didx = c->idx_dev;
   }
@@ -424,6 +426,48 @@ int vv_forward_backward(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, i
   HIPCHK(hipGetLastError());
   c->have_fwd = true;
   return VV_OK;
+}
+
+int vv_forward_backward(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int idx_on_device) {
+  return fb_impl(c, cfg, idx, idx_on_device, c ? c->n_rows : 0);
+}
+
+// Quirk Q1 (video_sampled_shots_data_layer.cpp:492): a same-video negative is copied WITHOUT its
+// last feature, which keeps whatever the prefetch slot held before.  Such a slot is described by
+// (idx = row of features 0..F-2, last_src = row of feature F-1, -1 = zero).  Each one is
+// materialised as a scratch row behind the table and the batch then points at the scratch row.
+int vv_forward_backward_q1(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, const int32_t* last_src) {
+  int rc = check_cfg(c, cfg);
+  if (rc) return rc;
+  if (!idx || !last_src) return fail(VV_ERR_ARG, "vv_forward_backward_q1: NULL index array");
+  HIPCHK(hipSetDevice(c->device));
+  const int64_t R = (int64_t)cfg->B * (cfg->C + cfg->Nn);
+  std::vector<int32_t> patched(idx, idx + R), desc;
+  for (int64_t i = 0; i < R; ++i) {
+    if (idx[i] < -1 || idx[i] >= c->n_rows || last_src[i] < -1 || last_src[i] >= c->n_rows)
+      return fail(VV_ERR_ARG, "index %lld out of range", (long long)i);
+    if (idx[i] != last_src[i] && idx[i] >= 0) {
+      patched[i] = (int32_t)(c->n_rows + 1 + (int64_t)desc.size() / 2);
+      desc.push_back(idx[i]); desc.push_back(last_src[i]);
+    }
+  }
+  const int64_t P = (int64_t)desc.size() / 2;
+  if (P > 0) {
+    if (P > c->patch_cap) {          // grow the table allocation once (device-to-device copy)
+      HIPCHK(hipStreamSynchronize(c->stream));
+      const int64_t cap = std::max<int64_t>(2 * P, 1024);
+      uint16_t* nt = nullptr;
+      const size_t old_bytes = (size_t)(c->n_rows + 1) * c->Fp * 2;
+      HIPCHK(hipMalloc(&nt, (size_t)(c->n_rows + 1 + cap) * c->Fp * 2));
+      HIPCHK(hipMemcpy(nt, c->table, old_bytes, hipMemcpyDeviceToDevice));
+      dfree(c->table); c->table = nt; c->patch_cap = cap;
+    }
+    if (2 * P > c->patch_desc_cap) { dfree(c->patch_desc); c->patch_desc = nullptr; HIPCHK(hipMalloc(&c->patch_desc, 4 * P * sizeof(int32_t))); c->patch_desc_cap = 4 * P; }
+    HIPCHK(hipMemcpyAsync(c->patch_desc, desc.data(), desc.size() * 4, hipMemcpyHostToDevice, c->stream));
+    launch_patch_rows(c->table, c->patch_desc, P, c->n_rows + 1, c->F, c->Fp, c->stream);
+    HIPCHK(hipStreamSynchronize(c->stream));     // desc is a host temporary
+  }
+  return fb_impl(c, cfg, patched.data(), 0, c->n_rows + 1 + P);
 }
 
 int vv_apply_update(vv_ctx* c, const vv_step_cfg* cfg) {

@@ -472,6 +472,24 @@ void launch_table_read(int prec, const uint16_t* table, const int32_t* rows, int
   else hipLaunchKernelGGL(k_table_read<BF16>, dim3(1024), dim3(256), 0, s, table, rows, n, F, Fp, inv_sx, out);
 }
 
+// composite rows for quirk Q1: row first_row+p = features 0..F-2 of desc[2p], feature F-1 of desc[2p+1]
+__global__ __launch_bounds__(256) void k_patch_rows(uint16_t* table, const int32_t* desc, int64_t first_row,
+                                                    int F, int Fp) {
+  const int64_t p = blockIdx.x;
+  const uint16_t* src = table + (int64_t)desc[2 * p] * Fp;
+  const int32_t ls = desc[2 * p + 1];
+  uint16_t* dst = table + (first_row + p) * Fp;
+  for (int f = threadIdx.x; f < Fp; f += 256) {
+    uint16_t v = src[f];
+    if (f == F - 1) v = ls >= 0 ? table[(int64_t)ls * Fp + f] : (uint16_t)0;
+    dst[f] = v;
+  }
+}
+void launch_patch_rows(uint16_t* table, const int32_t* desc, int64_t n_patch, int64_t first_row, int F,
+                       int Fp, hipStream_t s) {
+  hipLaunchKernelGGL(k_patch_rows, dim3((unsigned)n_patch), dim3(256), 0, s, table, desc, first_row, F, Fp);
+}
+
 // idx (data-layer layout, -1 = empty slot) -> table rows, padded to Rp with the all-zero row
 __global__ void k_map_rows(const int32_t* idx, int32_t* rows, int R, int Rp, int32_t zero_row) {
   const int i = blockIdx.x * 256 + threadIdx.x;

@@ -54,6 +54,7 @@ def load_library():
         "vv_params_set": [vp, i32, vp, vp, vp, vp], "vv_params_get": [vp, vp, vp, vp, vp],
         "vv_step_cfg_default": [vp],
         "vv_forward_backward": [vp, vp, vp, C.c_int], "vv_apply_update": [vp, vp],
+        "vv_forward_backward_q1": [vp, vp, vp, vp],
         "vv_step": [vp, vp, vp, C.c_int],
         "vv_loss_get": [vp, C.POINTER(f32), C.POINTER(f32)],
         "vv_grads_device": [vp, C.POINTER(vp), C.POINTER(i64)], "vv_grads_get": [vp, vp, vp],
@@ -179,6 +180,12 @@ class Engine:
             idx = np.ascontiguousarray(idx, dtype=np.int32)
             assert idx.shape == (cfg.c.B, cfg.c.C + cfg.c.Nn)
             self._chk(self.L.vv_forward_backward(self.h, C.byref(cfg.c), _ptr(idx), 0))
+
+    def forward_backward_q1(self, cfg, idx, last_src):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        last_src = np.ascontiguousarray(last_src, dtype=np.int32)
+        assert idx.shape == last_src.shape == (cfg.c.B, cfg.c.C + cfg.c.Nn)
+        self._chk(self.L.vv_forward_backward_q1(self.h, C.byref(cfg.c), _ptr(idx), _ptr(last_src)))
 
     def apply_update(self, cfg):
         self._chk(self.L.vv_apply_update(self.h, C.byref(cfg.c)))

@@ -1,0 +1,88 @@
+"""Writes net / solver prototxts with the graph structure of the reference's
+projects/videovec_embedding/mednet_embedding_train.prototxt (TRAIN phase) for any batch size,
+context size, negative count and embedding width -- the shipped file is hand-unrolled for
+num_negative_samples = 10; BASELINE configs need 2, 50 and 200.  Layer and blob names follow the
+shipped file so that snapshots and tools keyed on names (fc7, ip2, target_score, ...) carry over."""
+
+
+def train_net(source, B, C, Nn, D, *, max_buffer=5000, swap=50, max_same=0, dropout=0.0, margin=2.0,
+              norm="L2", name="videovec_train", w_std=0.001):
+    L = []
+    a = L.append
+    a('name: "%s"' % name)
+    a('layers {\n  name: "shot_windows"\n  type: VIDEO_SAMPLED_SHOTS_DATA\n  top: "data"\n'
+      '  video_sampled_shots_data_param {\n    source: "%s"\n    backend: LMDB\n    batch_size: %d\n'
+      '    num_negative_samples: %d\n    max_buffer_size: %d\n    negative_swap_percentage: %d\n'
+      '    max_same_video_negs: %d\n    context_type: WINDOW\n    context_size: %d\n  }\n'
+      '  include: { phase: TRAIN }\n}' % (source, B, Nn, max_buffer, swap, max_same, C))
+    datums = ["target_datum"] + ["context_datum_%d" % j for j in range(1, C)] + \
+             ["negative_datum_%d" % k for k in range(1, Nn + 1)]
+    a('layers {\n  name: "slice_input_data"\n  type: SLICE\n  bottom: "data"\n%s\n  include: { phase: TRAIN }\n}'
+      % "\n".join('  top: "%s"' % d for d in datums))
+    a('layers {\n  name: "batch_concat_input"\n  type: CONCAT\n%s\n  top: "concat_input_datums"\n'
+      '  concat_param { concat_dim: 0 }\n  include: { phase: TRAIN }\n}'
+      % "\n".join('  bottom: "%s"' % d for d in datums))
+    a('layers {\n  name: "flatten_input"\n  type: FLATTEN\n  bottom: "concat_input_datums"\n'
+      '  top: "original_feature"\n  include: { phase: TRAIN }\n}')
+    a('layers {\n  name: "fc7"\n  type: INNER_PRODUCT\n  bottom: "original_feature"\n  top: "ip1_nonorm"\n'
+      '  blobs_lr: 1\n  blobs_lr: 2\n  weight_decay: 1\n  weight_decay: 0\n  inner_product_param {\n'
+      '    num_output: %d\n    weight_filler { type: "gaussian" std: %g }\n'
+      '    bias_filler { type: "constant" }\n  }\n}' % (D, w_std))
+    a('layers {\n  name: "fc7_relu"\n  type: RELU\n  top: "ip2"\n  bottom: "ip1_nonorm"\n}')
+    if dropout > 0:
+        a('layers {\n  name: "drop2"\n  type: DROPOUT\n  bottom: "ip2"\n  top: "ip2"\n'
+          '  dropout_param { dropout_ratio: %g }\n  include: { phase: TRAIN }\n}' % dropout)
+    embs = ["target_emb_nonorm"] + ["context_window_emb_%d_nonorm" % j for j in range(1, C)] + \
+           ["negative_emb_%d_nonorm" % k for k in range(1, Nn + 1)]
+    a('layers {\n  name: "slice_emb"\n  type: SLICE\n  bottom: "ip2"\n%s\n  slice_param { slice_dim: 0 }\n'
+      '  include: { phase: TRAIN }\n}' % "\n".join('  top: "%s"' % e for e in embs))
+    a('layers {\n  name: "context_average"\n  type: ELTWISE\n%s\n  top: "context_feature_nonorm"\n'
+      '  eltwise_param {\n    operation: SUM\n%s\n  }\n  include: { phase: TRAIN }\n}'
+      % ("\n".join('  bottom: "%s"' % e for e in embs[1:C]),
+         "\n".join("    coeff: %.10g" % (1.0 / (C - 1)) for _ in range(C - 1))))
+    a('layers {\n  name: "word_embedding_norm"\n  type: NORMALIZATION\n  bottom: "context_feature_nonorm"\n'
+      '  top: "context_feature"\n  include: { phase: TRAIN }\n}')
+    pn = [embs[0]] + embs[C:]
+    a('layers {\n  name: "concat_pos_neg_nonorm"\n  type: CONCAT\n  top: "pos_neg_nonorm"\n%s\n'
+      '  concat_param { concat_dim: 0 }\n  include: { phase: TRAIN }\n}'
+      % "\n".join('  bottom: "%s"' % e for e in pn))
+    a('layers {\n  name: "pos_neg_norm"\n  type: NORMALIZATION\n  bottom: "pos_neg_nonorm"\n  top: "pos_neg"\n'
+      '  include: { phase: TRAIN }\n}')
+    normed = ["target_emb"] + ["negative_emb_%d" % k for k in range(1, Nn + 1)]
+    a('layers {\n  name: "slice_pos_neg"\n  type: SLICE\n  bottom: "pos_neg"\n%s\n  slice_param { slice_dim: 0 }\n'
+      '  include: { phase: TRAIN }\n}' % "\n".join('  top: "%s"' % e for e in normed))
+    a('layers {\n  name: "prod_true"\n  type: ELTWISE\n  bottom: "context_feature"\n  bottom: "target_emb"\n'
+      '  top: "target_prod"\n  eltwise_param { operation: PROD }\n  include: { phase: TRAIN }\n}')
+    a('layers {\n  name: "sum_true"\n  type: SUM\n  bottom: "target_prod"\n  top: "target_score"\n'
+      '  sum_param { num_output: %d }\n  include: { phase: TRAIN }\n}' % Nn)
+    for k in range(1, Nn + 1):
+        a('layers {\n  name: "prod_neg_%d"\n  type: ELTWISE\n  bottom: "context_feature"\n  bottom: "negative_emb_%d"\n'
+          '  top: "neg_prod_%d"\n  eltwise_param { operation: PROD }\n  include: { phase: TRAIN }\n}' % (k, k, k))
+        a('layers {\n  name: "sum_neg_%d"\n  type: SUM\n  bottom: "neg_prod_%d"\n  top: "neg_score_%d"\n'
+          '  sum_param { num_output: 1 }\n  include: { phase: TRAIN }\n}' % (k, k, k))
+    a('layers {\n  name: "concat_negative_scores"\n  type: CONCAT\n%s\n  top: "negative_scores"\n'
+      '  concat_param { concat_dim: 1 }\n  include: { phase: TRAIN }\n}'
+      % "\n".join('  bottom: "neg_score_%d"' % k for k in range(1, Nn + 1)))
+    a('layers {\n  name: "max_margin_loss"\n  type: MAX_MARGIN_LOSS\n  bottom: "target_score"\n'
+      '  bottom: "negative_scores"\n  top: "loss_output"\n  top: "train_violations"\n  loss_weight: 1.0\n'
+      '  loss_weight: 0.0\n  max_margin_loss_param {\n    norm: %s\n    margin: %g\n  }\n'
+      '  include: { phase: TRAIN }\n}' % (norm, margin))
+    return "\n".join(L) + "\n"
+
+
+def solver(net_path, *, base_lr=0.001, momentum=0.9, weight_decay=0.0005, lr_policy="inv", gamma=0.001,
+           power=0.75, stepsize=0, display=10, max_iter=100, snapshot=0, snapshot_prefix="videovec",
+           random_seed=-1, snapshot_after_train=True):
+    """Same fields as projects/videovec_embedding/mednet_embedding_train_solver.prototxt (test_* omitted:
+    the TEST branch is not built yet)."""
+    s = ['net: "%s"' % net_path, "base_lr: %g" % base_lr, "momentum: %g" % momentum,
+         "weight_decay: %g" % weight_decay, 'lr_policy: "%s"' % lr_policy, "gamma: %g" % gamma,
+         "power: %g" % power, "display: %d" % display, "max_iter: %d" % max_iter,
+         "snapshot: %d" % snapshot, 'snapshot_prefix: "%s"' % snapshot_prefix, "solver_mode: GPU"]
+    if stepsize:
+        s.append("stepsize: %d" % stepsize)
+    if random_seed >= 0:
+        s.append("random_seed: %d" % random_seed)
+    if not snapshot_after_train:
+        s.append("snapshot_after_train: false")
+    return "\n".join(s) + "\n"
