@@ -13,7 +13,7 @@
 
 #include "vv_internal.h"
 
-namespace vv { void set_wgrad_tr(bool on); void set_gemm_variant(int v); void set_ablate(int v); int wgrad_max_ksteps_per_split(); }
+namespace vv { void set_wgrad_tr(bool on); void set_gemm_variant(int v); void set_ablate(int v); void set_fwd_mi(int v); void set_score_reg(int v); int wgrad_max_ksteps_per_split(); }
 using namespace vv;
 
 static thread_local char g_err[512] = "";
@@ -131,6 +131,10 @@ int vv_create(int device, int prec, vv_ctx** out) {
   if (gv) set_gemm_variant(atoi(gv));
   const char* ab = getenv("VV_ABLATE");
   set_ablate(ab ? atoi(ab) : 0);
+  const char* fm = getenv("VV_FWD_MI");
+  set_fwd_mi(fm ? atoi(fm) : 0);
+  const char* sr = getenv("VV_SCORE_REG");
+  set_score_reg(sr ? atoi(sr) : 1);
   *out = c;
   return VV_OK;
 }
@@ -388,7 +392,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
 
   FwdArgs fa;
   fa.table = c->table; fa.rows = c->rows; fa.Wh = c->Wh; fa.bias = c->b; fa.scales = c->scales;
-  fa.H = c->H; fa.R = c->R; fa.D = D; fa.Fp = c->Fp; fa.relu = 1;
+  fa.H = c->H; fa.R = c->R; fa.D = D; fa.Fp = c->Fp; fa.relu = 1; fa.zero_row = (int32_t)c->n_rows;
   fa.drop_ratio = cfg->dropout_ratio;
   fa.mask = (cfg->dropout_ratio > 0.f && cfg->dropout_mask) ? c->mask : nullptr;
   fa.drop_seed = cfg->dropout_seed * 0x9E3779B97F4A7C15ull + c->iter;
@@ -591,7 +595,7 @@ int vv_embed(vv_ctx* c, const int32_t* rows, int64_t n, int relu, int l2norm, fl
   HIPCHK(hipMemcpyAsync(drows, h.data(), (size_t)Rp * 4, hipMemcpyHostToDevice, c->stream));
   FwdArgs fa;
   fa.table = c->table; fa.rows = drows; fa.Wh = c->Wh; fa.bias = c->b; fa.scales = c->scales;
-  fa.H = dout; fa.R = (int)n; fa.D = D; fa.Fp = c->Fp; fa.relu = relu ? 1 : 0;
+  fa.H = dout; fa.R = (int)n; fa.D = D; fa.Fp = c->Fp; fa.relu = relu ? 1 : 0; fa.zero_row = (int32_t)c->n_rows;
   fa.drop_ratio = 0.f; fa.mask = nullptr; fa.drop_seed = 0; fa.B = 1; fa.CN = 1;
   launch_fwd_gemm(c->prec, fa, c->stream);
   if (l2norm) launch_row_normalize(dout, (int)n, D, c->stream);

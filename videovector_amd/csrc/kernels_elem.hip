@@ -189,7 +189,171 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
   }
 }
 
+// Register-resident variant for small (1+Nn) x D: each wave keeps its target / negative rows in
+// VGPRs between the forward reductions and the backward pass, so every row of ip2 is read from HBM
+// exactly once (the streaming kernel above re-reads them, and at ~8 workgroups per CU the 110 KB per
+// item do not survive in L2).  RPW = rows per wave, DV = float4 chunks per lane (D = 256*DV).
+template <typename T, int RPW, int DV>
+__global__ __launch_bounds__(SL_THREADS) void k_score_loss_reg(ScoreArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int D = a.D, C = a.C, Nn = a.Nn, CN = C + Nn;
+  float* A = sm;               // [D]
+  float* Ah = A + D;           // [D]
+  float* acc0 = Ah + D;        // [4][D] per-wave partial dAh
+  float* acc1 = acc0 + 4 * D;  // [4][D] per-wave partial db
+  float* n2 = acc1 + 4 * D;    // [CN]
+  float* tq = n2 + CN;         // [CN]
+  float* cq = tq + CN;         // [CN]
+  float* red = cq + CN;        // [8]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* Hb = a.H + (int64_t)b * CN * D;
+  const float eps = 1e-10f;
+
+  // rows of this wave: qi = wave, wave+4, ... ; issue every load up front
+  float4 x[RPW][DV];
+#pragma unroll
+  for (int k = 0; k < RPW; ++k) {
+    const int qi = wave + 4 * k;
+    const int ch = qi == 0 ? 0 : C + qi - 1;
+#pragma unroll
+    for (int v = 0; v < DV; ++v)
+      x[k][v] = qi <= Nn ? *(const float4*)(Hb + (int64_t)ch * D + lane * 4 + v * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  // ---- phase 1: context mean and its norm
+  float ssq = 0.f;
+  for (int d = tid; d < D; d += SL_THREADS) {
+    float s = 0.f;
+    for (int j = 1; j < C; ++j) s += a.coeff[j - 1] * Hb[(int64_t)j * D + d];
+    A[d] = s;
+    ssq += s * s;
+  }
+  const float sA = block_sum(ssq, red);
+  const float nA = sqrtf(sA) + eps;
+  for (int d = tid; d < D; d += SL_THREADS) Ah[d] = A[d] / nA;
+  __syncthreads();
+
+  // ---- phase 2: norms and dots from registers
+  float4 y[DV];
+#pragma unroll
+  for (int v = 0; v < DV; ++v) y[v] = *(const float4*)(Ah + lane * 4 + v * 256);
+#pragma unroll
+  for (int k = 0; k < RPW; ++k) {
+    const int qi = wave + 4 * k;
+    float s = 0.f, t = 0.f;
+#pragma unroll
+    for (int v = 0; v < DV; ++v) {
+      const float4 xx = x[k][v];
+      s += xx.x * xx.x + xx.y * xx.y + xx.z * xx.z + xx.w * xx.w;
+      t += xx.x * y[v].x + xx.y * y[v].y + xx.z * y[v].z + xx.w * y[v].w;
+    }
+    s = wave_sum(s); t = wave_sum(t);
+    if (lane == 0 && qi <= Nn) { const int ch = qi == 0 ? 0 : C + qi - 1; n2[ch] = s; tq[ch] = t; }
+  }
+  __syncthreads();
+
+  // ---- phase 3: scores, hinge, loss, coefficients
+  const float sp = tq[0] / (sqrtf(n2[0]) + eps);
+  float lsum = 0.f, vsum = 0.f, gsum = 0.f;
+  for (int k = tid; k < Nn; k += SL_THREADS) {
+    const int ch = C + k;
+    const float sn = tq[ch] / (sqrtf(n2[ch]) + eps);
+    const float d = sp - sn;
+    const float h = fmaxf(0.f, a.margin - d);
+    float g;
+    if (a.norm == 2) { lsum += h * h; g = 2.f * h * a.grad_scale; }
+    else { lsum += fabsf(h); g = h > 0.f ? a.grad_scale : 0.f; }
+    vsum += d < 0.f ? 1.f : 0.f;
+    gsum += g;
+    cq[ch] = g;
+    if (a.s_bogus) a.s_bogus[(int64_t)b * Nn + k] = sn;
+  }
+  lsum = block_sum(lsum, red);
+  vsum = block_sum(vsum, red);
+  gsum = block_sum(gsum, red);
+  if (tid == 0) {
+    cq[0] = -gsum;
+    a.loss_part[b] = lsum;
+    a.viol_part[b] = vsum;
+    if (a.s_true) a.s_true[b] = sp;
+  }
+  __syncthreads();
+
+  // ---- phase 4: backward of this wave's rows from registers; one coalesced 512-B store per chunk
+  const int64_t rbase = (int64_t)b * CN;
+  float4 pa[DV], pb[DV];
+#pragma unroll
+  for (int v = 0; v < DV; ++v) { pa[v] = make_float4(0.f, 0.f, 0.f, 0.f); pb[v] = pa[v]; }
+#pragma unroll
+  for (int k = 0; k < RPW; ++k) {
+    const int qi = wave + 4 * k;
+    if (qi > Nn) continue;                         // wave-uniform
+    const int ch = qi == 0 ? 0 : C + qi - 1;
+    const float c = cq[ch], s = n2[ch], t = tq[ch];
+    const float inv_n = 1.f / (sqrtf(s) + eps);
+    const float inv_den = 1.f / (s * sqrtf(s) + eps);
+    uint16_t* dy = a.dYh + (rbase + ch) * a.Dp;
+#pragma unroll
+    for (int v = 0; v < DV; ++v) {
+      const float xv[4] = {x[k][v].x, x[k][v].y, x[k][v].z, x[k][v].w};
+      const float yv[4] = {y[v].x, y[v].y, y[v].z, y[v].w};
+      float g[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        g[e] = c * (s * yv[e] - xv[e] * t) * inv_den * a.drop_scale;
+        g[e] = xv[e] > 0.f ? g[e] : 0.f;
+      }
+      pa[v].x += c * xv[0] * inv_n; pa[v].y += c * xv[1] * inv_n; pa[v].z += c * xv[2] * inv_n; pa[v].w += c * xv[3] * inv_n;
+      pb[v].x += g[0]; pb[v].y += g[1]; pb[v].z += g[2]; pb[v].w += g[3];
+      const uint32_t lo = T::from_float(g[0] * a.sg) | ((uint32_t)T::from_float(g[1] * a.sg) << 16);
+      const uint32_t hi = T::from_float(g[2] * a.sg) | ((uint32_t)T::from_float(g[3] * a.sg) << 16);
+      *(uint2*)(dy + lane * 4 + v * 256) = make_uint2(lo, hi);
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < DV; ++v) {
+    *(float4*)(acc0 + wave * D + lane * 4 + v * 256) = pa[v];
+    *(float4*)(acc1 + wave * D + lane * 4 + v * 256) = pb[v];
+  }
+  __syncthreads();
+
+  // ---- phase 5: backward of the context normalisation and mean
+  float dot = 0.f;
+  for (int d = tid; d < D; d += SL_THREADS) {
+    const float u = acc0[d] + acc0[D + d] + acc0[2 * D + d] + acc0[3 * D + d];
+    acc0[d] = u;
+    dot += A[d] * u;
+  }
+  dot = block_sum(dot, red);
+  const float inv_denA = 1.f / (sA * sqrtf(sA) + eps);
+  for (int d = tid; d < D; d += SL_THREADS) {
+    const float dA = (sA * acc0[d] - A[d] * dot) * inv_denA;
+    float dbv = acc1[d] + acc1[D + d] + acc1[2 * D + d] + acc1[3 * D + d];
+    for (int j = 1; j < C; ++j) {
+      const float xx = Hb[(int64_t)j * D + d];
+      float g = a.coeff[j - 1] * dA * a.drop_scale;
+      g = xx > 0.f ? g : 0.f;
+      dbv += g;
+      a.dYh[(rbase + j) * a.Dp + d] = T::from_float(g * a.sg);
+    }
+    a.dbp[(int64_t)b * D + d] = dbv;
+  }
+}
+
+template <typename T>
+static bool launch_score_loss_reg(const ScoreArgs& a, hipStream_t s) {
+  // fast path: D == 512 and at most 52 target/negative rows (13 per wave)
+  if (a.D != 512 || 1 + a.Nn > 52) return false;
+  const size_t lds = sizeof(float) * ((size_t)10 * a.D + 3 * (a.C + a.Nn) + 8);
+  hipLaunchKernelGGL((k_score_loss_reg<T, 13, 2>), dim3(a.B), dim3(SL_THREADS), lds, s, a);
+  return true;
+}
+
+static int g_score_reg = 1;
+void set_score_reg(int v) { g_score_reg = v; }
+
 void launch_score_loss(int prec, const ScoreArgs& a, hipStream_t s) {
+  if (g_score_reg && (prec == 0 ? launch_score_loss_reg<F16>(a, s) : launch_score_loss_reg<BF16>(a, s))) return;
   const size_t lds = sizeof(float) * ((size_t)2 * a.D + 2 * (a.D > 1024 ? a.D : 1024) + 3 * (a.C + a.Nn) + 8);
   const bool vec = a.D % 4 == 0;
   const dim3 grid(a.B), block(SL_THREADS);

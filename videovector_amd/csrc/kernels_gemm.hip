@@ -42,31 +42,44 @@ __device__ __forceinline__ f32x4 mfma_abl(i16x8 x, i16x8 y, f32x4 c) {
 // ------------------------------------------------------------------------------- forward ------
 // LDS operand image: [256 rows][64 halves] = 128-B rows of 8 16-B chunks, chunk' = chunk ^ (row&7)
 // (conflict-free for the ds_read_b128 fragment reads: tools/lds_banks.py).
-template <typename T, bool DROP, bool VEC, int ABL = 0>
+// MI = 16-row MFMA sub-tiles per wave along M: the tile is (32*MI) x 256.  MI = 8 is the square
+// 256x256 tile; the launcher picks a smaller MI when that fills the 256 CUs in fewer, fuller rounds
+// (56 320 rows: 220 tiles of 256 rows x 2 = 440 WGs = 2 rounds at 86 %, but 252 tiles of 224 rows
+// x 2 = 504 WGs = 2 rounds of tiles that are 12.5 % shorter).
+template <typename T, bool DROP, bool VEC, int ABL = 0, int MI = 8>
 __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int BMK = 32 * MI;                   // rows of this tile
+  constexpr int NA = (BMK * 8 + 511) / 512;      // A staging instructions per thread and K-step
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int Dp = (int)round_up(a.D, D_ALIGN);
   const int tilesN = Dp / BN;
   const int L = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (L / tilesN) * BM, n0 = (L % tilesN) * BN;
+  const int m0 = (L / tilesN) * BMK, n0 = (L % tilesN) * BN;
   const int Fp = a.Fp;
 
-  const uint16_t* a_src[4];
+  const uint16_t* a_src[NA];
   const uint16_t* b_src[4];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int c = (i * 8 + wave) * 64 + lane;
+    const int row = c >> 3, lc = (c & 7) ^ (row & 7);
+    const int grow = m0 + row;
+    const int trow = (row < BMK && grow < a.R) ? a.rows[grow] : a.zero_row;
+    a_src[i] = a.table + (int64_t)trow * Fp + lc * 8;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = (i * 8 + wave) * 64 + lane;
     const int row = c >> 3, lc = (c & 7) ^ (row & 7);
-    a_src[i] = a.table + (int64_t)a.rows[m0 + row] * Fp + lc * 8;
     b_src[i] = a.Wh + (int64_t)(n0 + row) * Fp + lc * 8;
   }
 
-  f32x4 acc[8][4];
+  f32x4 acc[MI][4];
 #pragma unroll
-  for (int mi = 0; mi < 8; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -74,10 +87,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm(FwdArgs a) {
     unsigned char* As = smem + p * 2 * LDS_TILE_BYTES;
     unsigned char* Bs = As + LDS_TILE_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      glds16(a_src[i] + kt * BK, As + (i * 8 + wave) * 1024);
-      glds16(b_src[i] + kt * BK, Bs + (i * 8 + wave) * 1024);
-    }
+    for (int i = 0; i < NA; ++i)
+      if ((i * 8 + wave) * 8 < BMK)       // wave-uniform: the last instruction may cover only 4 waves
+        glds16(a_src[i] + kt * BK, As + (i * 8 + wave) * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(b_src[i] + kt * BK, Bs + (i * 8 + wave) * 1024);
   };
 
   const int nk = Fp / BK;
@@ -94,17 +108,17 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm(FwdArgs a) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int coff = ((kk * 4 + fq) ^ (frow & 7)) << 4;
-      i16x8 af[8], bf[4];
+      i16x8 af[MI], bf[4];
 #pragma unroll
-      for (int mi = 0; mi < 8; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
         af[mi] = (ABL & 4) ? i16x8{1, 2, 3, 4, 5, 6, 7, (short)mi}
-                           : *(const i16x8*)(As + (wm * 128 + mi * 16 + frow) * 128 + coff);
+                           : *(const i16x8*)(As + (wm * (MI * 16) + mi * 16 + frow) * 128 + coff);
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
         bf[ni] = (ABL & 4) ? i16x8{1, 2, 3, 4, 5, 6, 7, (short)ni}
                            : *(const i16x8*)(Bs + (wn * 64 + ni * 16 + frow) * 128 + coff);
 #pragma unroll
-      for (int mi = 0; mi < 8; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma_abl<T, ABL>(bf[ni], af[mi], acc[mi][ni]);
     }
@@ -119,8 +133,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm(FwdArgs a) {
   const float dscale = DROP ? 1.0f / (1.0f - a.drop_ratio) : 1.0f;
   const float lo = a.relu ? 0.f : -INFINITY;
 #pragma unroll
-  for (int mi = 0; mi < 8; ++mi) {
-    const int m = m0 + wm * 128 + mi * 16 + frow;
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = m0 + wm * (MI * 16) + mi * 16 + frow;
     if (m >= a.R) continue;
     int64_t ref_row = 0;
     if (DROP) {
@@ -542,6 +556,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ring(WgradArgs a) {
 
 // ------------------------------------------------------------------------------- launchers ----
 static bool g_wgrad_tr = true;
+static int g_fwd_mi = 0;            // VV_FWD_MI: force the forward tile height (0 = automatic)
+void set_fwd_mi(int v) { g_fwd_mi = v; }
 static int g_ablate = 0;
 void set_ablate(int v) { g_ablate = v; }
 static int g_gemm_variant = 0;     // 0 = two-buffer K=64 kernels (default, faster), 1 = 4-slot ring K=32 kernels
@@ -573,6 +589,31 @@ static void launch_fwd_t(const FwdArgs& a, hipStream_t s) {
       }
       VV_ABL_FWD(1) VV_ABL_FWD(2) VV_ABL_FWD(3) VV_ABL_FWD(6) VV_ABL_FWD(7)
 #undef VV_ABL_FWD
+    }
+  }
+  if constexpr (!DROP && VEC) {
+    // balanced M tiling: the MI in {8,7,6} that needs the least (rounds of 256 WGs) x (tile height)
+    if (g_gemm_variant == 0) {
+      int best = 8; long best_cost = -1;
+      for (int mi = 8; mi >= 6; --mi) {
+        const long tiles = ((a.R + 32 * mi - 1) / (32 * mi)) * (long)(Dp / BN);
+        const long cost = ((tiles + 255) / 256) * mi;
+        if (best_cost < 0 || cost < best_cost) { best = mi; best_cost = cost; }
+      }
+      if (g_fwd_mi) best = g_fwd_mi;
+      if (best != 8) {
+        const dim3 g2(((a.R + 32 * best - 1) / (32 * best)) * (Dp / BN));
+        if (best == 7) {
+          static bool o7 = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm<T, DROP, VEC, 0, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES), true);
+          (void)o7;
+          hipLaunchKernelGGL((k_fwd_gemm<T, DROP, VEC, 0, 7>), g2, block, GEMM_LDS_BYTES, s, a);
+        } else {
+          static bool o6 = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm<T, DROP, VEC, 0, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES), true);
+          (void)o6;
+          hipLaunchKernelGGL((k_fwd_gemm<T, DROP, VEC, 0, 6>), g2, block, GEMM_LDS_BYTES, s, a);
+        }
+        return;
+      }
     }
   }
   if (g_gemm_variant == 1) {

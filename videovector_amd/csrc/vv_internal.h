@@ -44,6 +44,7 @@ struct FwdArgs {
   const Scales* scales;
   float* H;                // [R][D] fp32 output (ip2)
   int R, D, Fp;
+  int32_t zero_row;        // table row of zeros (for rows past R inside the last tile)
   int relu;
   // dropout
   float drop_ratio;        // 0 = off
