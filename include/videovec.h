@@ -142,6 +142,24 @@ int vv_blobs_get(vv_ctx* ctx, float* ip2, float* target_score, float* negative_s
  * out host fp32 [n][D]. */
 int vv_embed(vv_ctx* ctx, const int32_t* rows, int64_t n, int relu, int l2norm, float* out);
 
+/* The TEST branch's input: each sample is the coefficient-weighted sum of k table rows
+ * (SLICE/CONCAT/SLICE + ELTWISE SUM `average_for_test`, mednet_embedding_train.prototxt:75-177), then
+ * fc7 -> ReLU -> optional NORMALIZATION (`test_norm`, :344-352).  rows: host int32 [n][k];
+ * coeff: host [k] or NULL for 1/k; out: host fp32 [n][D]. */
+int vv_embed_mean(vv_ctx* ctx, const int32_t* rows, int64_t n, int32_t k, const float* coeff, int relu,
+                  int l2norm, float* out);
+
+/* RetrievalStatsLayer::Forward_cpu, per-shot retrieval (src/caffe/layers/retrieval_stats_layer.cpp:
+ * 104-141, 143-355): distance = -2 X X^T (computed on the GPU), self excluded, ascending sort,
+ * mean AP / hit@1 / hit@5 over samples whose class is >= 0.  feat: host fp32 [n][dim]; video_ids [n];
+ * the id_to_class_file as two parallel arrays (ids absent from it read as class 0, as the
+ * reference's map operator[] does).  Equal distances are ordered by ascending index (std::sort
+ * leaves them unspecified; this order reproduces test_retrieval_stats_layer.cpp:82-84).
+ * video_level_retrieval and stats_output_file are not built. */
+int vv_retrieval_stats(vv_ctx* ctx, const float* feat, int32_t n, int32_t dim, const int32_t* video_ids,
+                       const int32_t* map_ids, const int32_t* map_cls, int32_t n_map,
+                       int exclude_same_video_shots, float* mean_ap, float* hit_at_1, float* hit_at_5);
+
 /* ---- triplet sampler (host side, integer only).  Replaces VideoSampledShotsDataLayer's
  * DataLayerSetUp / AddSamplesToTop / InternalThreadEntry / AddToBuffer / RandomShuffleTopids
  * (src/caffe/layers/video_sampled_shots_data_layer.cpp:24-44,64-369,371-507,768-909) with the

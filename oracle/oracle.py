@@ -93,6 +93,7 @@ def lib():
         L.orc_forward_backward.argtypes = [C.c_void_p] * 7
         L.orc_embed.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_retrieval_stats.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_int] + [C.c_void_p] * 3
         _lib = L
     return _lib
 
@@ -299,3 +300,15 @@ def embed(table, rows, W, b, relu=True, l2norm=False):
     out = np.empty((n, D), np.float32)
     lib().orc_embed(n, F, D, _p(table), _p(rows), _p(W), _p(b), int(relu), int(l2norm), _p(out))
     return out
+
+
+def retrieval_stats(feat, video_ids, id2class, exclude_same_video=True):
+    """RetrievalStatsLayer forward: returns (mAP, hit@1, hit@5).  id2class: dict video_id -> class."""
+    feat = _f32(feat)
+    vid = np.ascontiguousarray(video_ids, dtype=np.int32)
+    mi = np.ascontiguousarray(list(id2class.keys()), dtype=np.int32)
+    mc = np.ascontiguousarray(list(id2class.values()), dtype=np.int32)
+    out = [C.c_float(), C.c_float(), C.c_float()]
+    lib().orc_retrieval_stats(feat.shape[0], feat.shape[1], _p(feat), _p(vid), _p(mi), _p(mc), len(mi),
+                              int(exclude_same_video), *[C.byref(o) for o in out])
+    return tuple(o.value for o in out)

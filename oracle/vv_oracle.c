@@ -629,3 +629,50 @@ void orc_embed(int n, int F, int D, const float* table, const int32_t* rows, con
   }
   free(X);
 }
+
+/* ============================================================ retrieval statistics ========== */
+static int cls_of(int id, const int32_t* map_ids, const int32_t* map_cls, int n_map) {
+  for (int i = 0; i < n_map; ++i) if (map_ids[i] == id) return map_cls[i];
+  return 0;
+}
+typedef struct { float d; int i; } orc_di;
+static int cmp_di(const void* a, const void* b) {
+  const orc_di* x = (const orc_di*)a; const orc_di* y = (const orc_di*)b;
+  if (x->d < y->d) return -1;
+  if (x->d > y->d) return 1;
+  return x->i - y->i;
+}
+/* retrieval_stats_layer.cpp:104-141, 143-355 */
+void orc_retrieval_stats(int n, int dim, const float* feat, const int32_t* video_ids,
+                         const int32_t* map_ids, const int32_t* map_cls, int n_map,
+                         int exclude_same_video, float* mean_ap, float* hit1, float* hit5) {
+  float* dist = falloc((size_t)n * n);
+  orc_sgemm(0, 1, n, n, dim, -2.f, feat, feat, 0.f, dist);                           /* :208-209 */
+  orc_di* row = (orc_di*)malloc(sizeof(orc_di) * (size_t)n);
+  double s_ap = 0, s_1 = 0, s_5 = 0, npos = 0;
+  for (int i = 0; i < n; ++i) {
+    for (int j = 0; j < n; ++j) { row[j].d = dist[(size_t)i * n + j]; row[j].i = j; }
+    row[i].d = -1e15f;                                                               /* :228-229 */
+    qsort(row, (size_t)n, sizeof(orc_di), cmp_di);                                    /* :233 */
+    const int label = cls_of(video_ids[i], map_ids, map_cls, n_map);
+    if (label < 0) continue;                                                          /* :246-248 */
+    double ap = 0, a1 = 0, a5 = 0, val = 0, ret = 0;                                  /* :104-141 */
+    for (int k = 1; k < n; ++k) {
+      const int j = row[k].i;
+      if (video_ids[j] != video_ids[i] || !exclude_same_video) {
+        val += 1;
+        if (cls_of(video_ids[j], map_ids, map_cls, n_map) == label) {
+          if (val <= 1) a1 += 1;
+          if (val <= 5) a5 += 1;
+          ret += 1;
+          ap += ret / val;
+        }
+      }
+    }
+    if (ret > 0) ap /= ret;
+    a5 /= 5;
+    s_ap += ap; s_1 += a1; s_5 += a5; npos += 1;
+  }
+  *mean_ap = (float)(s_ap / npos); *hit1 = (float)(s_1 / npos); *hit5 = (float)(s_5 / npos);   /* :347-349 */
+  free(row); free(dist);
+}

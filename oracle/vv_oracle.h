@@ -144,6 +144,16 @@ void orc_forward_backward(const orc_step_cfg* cfg, const float* table, const int
 void orc_embed(int n, int F, int D, const float* table, const int32_t* rows, const float* W,
                const float* b, int relu, int l2norm, float* out);
 
+/* retrieval_stats_layer.cpp:104-141 (ComputeStats), 143-355 (Forward_cpu, per-shot retrieval):
+ * distance = -2 X X^T, self set to -1e15, ascending sort, AP / hit@1 / hit@5 over the samples whose
+ * class is >= 0.  std::sort leaves the order of equal distances unspecified; ties are broken here by
+ * ascending index, which is the order that reproduces the reference's own known-answer test
+ * (test_retrieval_stats_layer.cpp:34-39,82-84).  id->class pairs: map_ids / map_cls (ids absent from
+ * the map read as class 0, as operator[] of the reference's unordered_map does). */
+void orc_retrieval_stats(int n, int dim, const float* feat, const int32_t* video_ids,
+                         const int32_t* map_ids, const int32_t* map_cls, int n_map,
+                         int exclude_same_video, float* mean_ap, float* hit1, float* hit5);
+
 #ifdef __cplusplus
 }
 #endif

@@ -180,3 +180,23 @@ def test_sgemm_against_numpy(oracle, ta, tb):
     out = oracle.sgemm(ta, tb, A, B, alpha=0.5, beta=2.0, Cmat=C0.copy())
     ref = 0.5 * ((A.T if ta else A).astype(np.float64) @ (B.T if tb else B)) + 2.0 * C0
     assert np.allclose(out, ref, rtol=1e-5, atol=1e-4)
+
+
+# ---------------------------------------------------------------- RetrievalStats -------------
+def test_retrieval_stats_known_answer(oracle):
+    # test_retrieval_stats_layer.cpp:34-39,71-86: 5 samples x 2 features, video ids 2..6 with classes
+    # {1,2,1,2,2} (comment on line 39) -> mAP 0.7833333, hit@1 0.60, hit@5 0.32 (+-1e-3)
+    feat = np.array([[1.0, 0.0], [0.0, 1.0], [1.0, 0.06], [0.0, 1.0], [1.0, 0.1]], np.float32)
+    m, h1, h5 = oracle.retrieval_stats(feat, [2, 3, 4, 5, 6], {2: 1, 3: 2, 4: 1, 5: 2, 6: 2})
+    assert abs(m - 0.7833333) <= 1e-3 and abs(h1 - 0.60) <= 1e-3 and abs(h5 - 0.32) <= 1e-3
+
+
+def test_retrieval_stats_options(oracle):
+    rng = np.random.default_rng(0)
+    feat = rng.standard_normal((40, 8)).astype(np.float32)
+    feat /= np.linalg.norm(feat, axis=1, keepdims=True)
+    vids = np.repeat(np.arange(10), 4)
+    cls = {v: v % 3 - (v == 9) * 5 for v in range(10)}        # video 9 has a negative class: skipped
+    a = oracle.retrieval_stats(feat, vids, cls, True)
+    b = oracle.retrieval_stats(feat, vids, cls, False)
+    assert all(0 <= x <= 1 for x in a + b) and a != b

@@ -7,7 +7,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <map>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -440,6 +442,19 @@ int vv_forward_backward(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, i
 // last feature, which keeps whatever the prefetch slot held before.  Such a slot is described by
 // (idx = row of features 0..F-2, last_src = row of feature F-1, -1 = zero).  Each one is
 // materialised as a scratch row behind the table and the batch then points at the scratch row.
+// scratch rows behind the table's zero row (quirk-Q1 composites, TEST-branch means)
+static int ensure_scratch_rows(vv_ctx* c, int64_t need) {
+  if (need <= c->patch_cap) return VV_OK;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const int64_t cap = std::max<int64_t>(2 * need, 1024);
+  uint16_t* nt = nullptr;
+  const size_t old_bytes = (size_t)(c->n_rows + 1) * c->Fp * 2;
+  HIPCHK(hipMalloc(&nt, (size_t)(c->n_rows + 1 + cap) * c->Fp * 2));
+  HIPCHK(hipMemcpy(nt, c->table, old_bytes, hipMemcpyDeviceToDevice));
+  dfree(c->table); c->table = nt; c->patch_cap = cap;
+  return VV_OK;
+}
+
 int vv_forward_backward_q1(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, const int32_t* last_src) {
   int rc = check_cfg(c, cfg);
   if (rc) return rc;
@@ -457,15 +472,7 @@ int vv_forward_backward_q1(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx
   }
   const int64_t P = (int64_t)desc.size() / 2;
   if (P > 0) {
-    if (P > c->patch_cap) {          // grow the table allocation once (device-to-device copy)
-      HIPCHK(hipStreamSynchronize(c->stream));
-      const int64_t cap = std::max<int64_t>(2 * P, 1024);
-      uint16_t* nt = nullptr;
-      const size_t old_bytes = (size_t)(c->n_rows + 1) * c->Fp * 2;
-      HIPCHK(hipMalloc(&nt, (size_t)(c->n_rows + 1 + cap) * c->Fp * 2));
-      HIPCHK(hipMemcpy(nt, c->table, old_bytes, hipMemcpyDeviceToDevice));
-      dfree(c->table); c->table = nt; c->patch_cap = cap;
-    }
+    if ((rc = ensure_scratch_rows(c, P))) return rc;
     if (2 * P > c->patch_desc_cap) { dfree(c->patch_desc); c->patch_desc = nullptr; HIPCHK(hipMalloc(&c->patch_desc, 4 * P * sizeof(int32_t))); c->patch_desc_cap = 4 * P; }
     HIPCHK(hipMemcpyAsync(c->patch_desc, desc.data(), desc.size() * 4, hipMemcpyHostToDevice, c->stream));
     launch_patch_rows(c->table, c->patch_desc, P, c->n_rows + 1, c->F, c->Fp, c->stream);
@@ -603,6 +610,87 @@ int vv_embed(vv_ctx* c, const int32_t* rows, int64_t n, int relu, int l2norm, fl
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipMemcpy(out, dout, (size_t)n * D * 4, hipMemcpyDeviceToHost));
   dfree(drows); dfree(dout);
+  return VV_OK;
+}
+
+int vv_embed_mean(vv_ctx* c, const int32_t* rows, int64_t n, int32_t k, const float* coeff, int relu,
+                  int l2norm, float* out) {
+  if (!c || !rows || !out || n <= 0 || k <= 0) return fail(VV_ERR_ARG, "vv_embed_mean: bad argument");
+  if (!c->table || !c->W) return fail(VV_ERR_STATE, "vv_embed_mean: table and parameters must be set first");
+  if (n > (1ll << 24)) return fail(VV_ERR_ARG, "vv_embed_mean: n too large");
+  HIPCHK(hipSetDevice(c->device));
+  for (int64_t i = 0; i < n * k; ++i)
+    if (rows[i] < 0 || rows[i] >= c->n_rows) return fail(VV_ERR_ARG, "vv_embed_mean: row %d out of range", rows[i]);
+  int rc = ensure_scratch_rows(c, n);
+  if (rc) return rc;
+  std::vector<float> hc(k);
+  for (int j = 0; j < k; ++j) hc[j] = coeff ? coeff[j] : 1.0f / k;
+  const int D = c->D;
+  const int Rp = (int)round_up(n, R_ALIGN);
+  std::vector<int32_t> h(Rp, (int32_t)c->n_rows);
+  for (int64_t i = 0; i < n; ++i) h[i] = (int32_t)(c->n_rows + 1 + i);
+  int32_t *drows_in = nullptr, *drows = nullptr; float *dcoeff = nullptr, *dout = nullptr;
+  HIPCHK(hipMalloc(&drows_in, (size_t)n * k * 4)); HIPCHK(hipMalloc(&drows, (size_t)Rp * 4));
+  HIPCHK(hipMalloc(&dcoeff, (size_t)k * 4)); HIPCHK(hipMalloc(&dout, (size_t)n * D * 4));
+  HIPCHK(hipMemcpyAsync(drows_in, rows, (size_t)n * k * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(drows, h.data(), (size_t)Rp * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(dcoeff, hc.data(), (size_t)k * 4, hipMemcpyHostToDevice, c->stream));
+  launch_mean_rows(c->prec, c->table, drows_in, n, k, dcoeff, c->n_rows + 1, c->Fp, c->stream);
+  FwdArgs fa;
+  fa.table = c->table; fa.rows = drows; fa.Wh = c->Wh; fa.bias = c->b; fa.scales = c->scales;
+  fa.H = dout; fa.R = (int)n; fa.D = D; fa.Fp = c->Fp; fa.relu = relu ? 1 : 0; fa.zero_row = (int32_t)c->n_rows;
+  fa.drop_ratio = 0.f; fa.mask = nullptr; fa.drop_seed = 0; fa.B = 1; fa.CN = 1;
+  launch_fwd_gemm(c->prec, fa, c->stream);
+  if (l2norm) launch_row_normalize(dout, (int)n, D, c->stream);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(out, dout, (size_t)n * D * 4, hipMemcpyDeviceToHost));
+  dfree(drows_in); dfree(drows); dfree(dcoeff); dfree(dout);
+  return VV_OK;
+}
+
+int vv_retrieval_stats(vv_ctx* c, const float* feat, int32_t n, int32_t dim, const int32_t* video_ids,
+                       const int32_t* map_ids, const int32_t* map_cls, int32_t n_map,
+                       int exclude_same, float* mean_ap, float* hit1, float* hit5) {
+  if (!c || !feat || !video_ids || n < 2 || dim < 1 || (n_map > 0 && (!map_ids || !map_cls)))
+    return fail(VV_ERR_ARG, "vv_retrieval_stats: bad argument");
+  if (n_map < 1) return fail(VV_ERR_ARG, "need atleast one entry in id-to-class map!");   // retrieval_stats_layer.cpp:49
+  HIPCHK(hipSetDevice(c->device));
+  float *dx = nullptr, *dd = nullptr;
+  HIPCHK(hipMalloc(&dx, (size_t)n * dim * 4)); HIPCHK(hipMalloc(&dd, (size_t)n * n * 4));
+  HIPCHK(hipMemcpyAsync(dx, feat, (size_t)n * dim * 4, hipMemcpyHostToDevice, c->stream));
+  launch_gram(dx, n, dim, -2.0f, dd, c->stream);                                           // :208-209
+  std::vector<float> dist((size_t)n * n);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(dist.data(), dd, dist.size() * 4, hipMemcpyDeviceToHost));
+  dfree(dx); dfree(dd);
+  std::unordered_map<int, int> cls;
+  for (int i = 0; i < n_map; ++i) cls[map_ids[i]] = map_cls[i];
+  auto cls_of = [&](int id) { auto it = cls.find(id); return it == cls.end() ? 0 : it->second; };
+  std::vector<int> order(n);
+  double s_ap = 0, s_1 = 0, s_5 = 0, npos = 0;
+  for (int i = 0; i < n; ++i) {
+    float* row = dist.data() + (size_t)i * n;
+    row[i] = -1e15f;                                                                       // :228-229
+    for (int j = 0; j < n; ++j) order[j] = j;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return row[a] < row[b] || (row[a] == row[b] && a < b); });
+    const int label = cls_of(video_ids[i]);
+    if (label < 0) continue;                                                               // :246-248
+    double ap = 0, a1 = 0, a5 = 0, val = 0, ret = 0;                                       // :104-141
+    for (int kk = 1; kk < n; ++kk) {
+      const int j = order[kk];
+      if (video_ids[j] != video_ids[i] || !exclude_same) {
+        val += 1;
+        if (cls_of(video_ids[j]) == label) { if (val <= 1) a1 += 1; if (val <= 5) a5 += 1; ret += 1; ap += ret / val; }
+      }
+    }
+    if (ret > 0) ap /= ret;
+    s_ap += ap; s_1 += a1; s_5 += a5 / 5; npos += 1;
+  }
+  if (npos == 0) return fail(VV_ERR_ARG, "vv_retrieval_stats: no sample with a non-negative class");
+  if (mean_ap) *mean_ap = (float)(s_ap / npos);
+  if (hit1) *hit1 = (float)(s_1 / npos);
+  if (hit5) *hit5 = (float)(s_5 / npos);
   return VV_OK;
 }
 

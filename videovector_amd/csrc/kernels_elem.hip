@@ -654,6 +654,61 @@ void launch_patch_rows(uint16_t* table, const int32_t* desc, int64_t n_patch, in
   hipLaunchKernelGGL(k_patch_rows, dim3((unsigned)n_patch), dim3(256), 0, s, table, desc, first_row, F, Fp);
 }
 
+// scratch row first_row+i = sum_j coeff[j] * table[rows[i*k+j]]   (TEST branch: average_for_test)
+template <typename T>
+__global__ __launch_bounds__(256) void k_mean_rows(uint16_t* table, const int32_t* rows, int k, const float* coeff,
+                                                   int64_t first_row, int Fp) {
+  const int64_t i = blockIdx.x;
+  uint16_t* dst = table + (first_row + i) * Fp;
+  for (int f = threadIdx.x; f < Fp; f += 256) {
+    float s = 0.f;
+    for (int j = 0; j < k; ++j) s += coeff[j] * T::to_float(table[(int64_t)rows[i * k + j] * Fp + f]);
+    dst[f] = T::from_float(s);
+  }
+}
+void launch_mean_rows(int prec, uint16_t* table, const int32_t* rows, int64_t n, int k, const float* coeff,
+                      int64_t first_row, int Fp, hipStream_t s) {
+  if (prec == 0) hipLaunchKernelGGL(k_mean_rows<F16>, dim3((unsigned)n), dim3(256), 0, s, table, rows, k, coeff, first_row, Fp);
+  else hipLaunchKernelGGL(k_mean_rows<BF16>, dim3((unsigned)n), dim3(256), 0, s, table, rows, k, coeff, first_row, Fp);
+}
+
+// out[i][j] = alpha * sum_d x[i][d] x[j][d]  (fp32; retrieval_stats_layer.cpp:208-209 uses alpha = -2).
+// 64x64 tile per 256-thread block, 4x4 outputs per thread; n is a few hundred to a few thousand.
+__global__ __launch_bounds__(256) void k_gram(const float* x, int n, int dim, float alpha, float* out) {
+  __shared__ float As[16][64 + 1], Bs[16][64 + 1];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  float acc[4][4] = {};
+  for (int k0 = 0; k0 < dim; k0 += 16) {
+    for (int t = threadIdx.x; t < 64 * 16; t += 256) {
+      const int r = t >> 4, c = t & 15;
+      As[c][r] = (i0 + r < n && k0 + c < dim) ? x[(int64_t)(i0 + r) * dim + k0 + c] : 0.f;
+      Bs[c][r] = (j0 + r < n && k0 + c < dim) ? x[(int64_t)(j0 + r) * dim + k0 + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      float a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a[u] = As[c][ty * 4 + u]; b[u] = Bs[c][tx * 4 + u]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] += a[u] * b[v];
+    }
+    __syncthreads();
+  }
+  for (int u = 0; u < 4; ++u)
+    for (int v = 0; v < 4; ++v) {
+      const int i = i0 + ty * 4 + u, j = j0 + tx * 4 + v;
+      if (i < n && j < n) out[(int64_t)i * n + j] = alpha * acc[u][v];
+    }
+}
+void launch_gram(const float* x, int n, int dim, float alpha, float* out, hipStream_t s) {
+  const dim3 grid((n + 63) / 64, (n + 63) / 64);
+  hipLaunchKernelGGL(k_gram, grid, dim3(256), 0, s, x, n, dim, alpha, out);
+}
+
 // idx (data-layer layout, -1 = empty slot) -> table rows, padded to Rp with the all-zero row
 __global__ void k_map_rows(const int32_t* idx, int32_t* rows, int R, int Rp, int32_t zero_row) {
   const int i = blockIdx.x * 256 + threadIdx.x;

@@ -123,6 +123,9 @@ void launch_dyh_to_float(int prec, const uint16_t* dYh, int R, int D, int Dp, fl
                          float* out, hipStream_t s);
 void launch_row_normalize(float* x, int n, int D, hipStream_t s);
 void launch_absmax(const float* x, int64_t n, unsigned* out_bits, hipStream_t s);
+void launch_mean_rows(int prec, uint16_t* table, const int32_t* rows, int64_t n, int k, const float* coeff,
+                      int64_t first_row, int Fp, hipStream_t s);
+void launch_gram(const float* x, int n, int dim, float alpha, float* out, hipStream_t s);
 void launch_patch_rows(uint16_t* table, const int32_t* desc, int64_t n_patch, int64_t first_row, int F,
                        int Fp, hipStream_t s);
 

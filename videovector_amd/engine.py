@@ -61,6 +61,8 @@ def load_library():
         "vv_grads_bind": [vp, vp],
         "vv_blobs_get": [vp, vp, vp, vp, vp],
         "vv_embed": [vp, vp, i64, C.c_int, C.c_int, vp],
+        "vv_embed_mean": [vp, vp, i64, i32, vp, C.c_int, C.c_int, vp],
+        "vv_retrieval_stats": [vp, vp, i32, i32, vp, vp, vp, i32, C.c_int, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32)],
         "vv_profile_enable": [vp, C.c_int],
         "vv_profile_get": [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)],
     }
@@ -231,6 +233,26 @@ class Engine:
         out = np.empty((n, self.D), np.float32)
         self._chk(self.L.vv_embed(self.h, _ptr(r), n, int(relu), int(l2norm), _ptr(out)))
         return out
+
+    def embed_mean(self, rows, coeff=None, relu=True, l2norm=False):
+        """TEST-branch embedding: fc7(+ReLU)(+normalise) of the weighted sum of k rows per sample."""
+        r = np.ascontiguousarray(rows, dtype=np.int32)
+        n, k = r.shape
+        cf = None if coeff is None else np.ascontiguousarray(coeff, dtype=np.float32)
+        out = np.empty((n, self.D), np.float32)
+        self._chk(self.L.vv_embed_mean(self.h, _ptr(r), n, k, _ptr(cf), int(relu), int(l2norm), _ptr(out)))
+        return out
+
+    def retrieval_stats(self, feat, video_ids, id2class, exclude_same_video=True):
+        """RetrievalStatsLayer forward: (mAP, hit@1, hit@5)."""
+        feat = np.ascontiguousarray(feat, dtype=np.float32)
+        vid = np.ascontiguousarray(video_ids, dtype=np.int32)
+        mi = np.ascontiguousarray(list(id2class.keys()), dtype=np.int32)
+        mc = np.ascontiguousarray(list(id2class.values()), dtype=np.int32)
+        o = [C.c_float(), C.c_float(), C.c_float()]
+        self._chk(self.L.vv_retrieval_stats(self.h, _ptr(feat), feat.shape[0], feat.shape[1], _ptr(vid), _ptr(mi),
+                                            _ptr(mc), len(mi), int(exclude_same_video), *[C.byref(x) for x in o]))
+        return tuple(x.value for x in o)
 
     # ---- profiling
     def profile_enable(self, on=True):
