@@ -77,6 +77,11 @@ struct VideoDataset {
   int F = 0;
   bool synthetic = false; uint64_t seed = 0;
   vector<float> features;          // [n_rows][F] when not synthetic
+  // TEST-phase records (proto TestVideoShotWindows, video_shot_sentences.proto:22-30): each window is
+  // win_k context frames of one video, stored as table rows
+  int win_k = 0;
+  vector<int32_t> win_rows, win_video_id;
+  bool SameTable(const VideoDataset& o) const { return synthetic && o.synthetic && seed == o.seed && n_rows == o.n_rows && F == o.F; }
   static shared_ptr<VideoDataset> Open(const string& source);
   void UploadTable(vv_ctx* ctx) const;   // vv_table_synth / vv_table_set
 };
@@ -214,6 +219,41 @@ class MaxMarginLossLayer : public Layer<Dtype> {  // max_margin_loss_layer.cpp:1
   virtual bool AutoTopBlobs() const { return true; }
   virtual void LayerSetUp(const vector<Blob<Dtype>*>& bottom, vector<Blob<Dtype>*>* top);
   virtual void Reshape(const vector<Blob<Dtype>*>& bottom, vector<Blob<Dtype>*>* top);
+};
+
+// VIDEO_SHOT_WINDOW_TEST_DATA (video_shot_window_test_data_layer.cpp:37-265): one record per item,
+// channels = context frames (then positives, negatives -- not present in the windows built here);
+// second top = video id.  Produces table rows of the context frames.
+template <typename Dtype>
+class VideoShotWindowTestDataLayer : public Layer<Dtype> {
+  VV_LAYER_BOILER(VideoShotWindowTestDataLayer, "VIDEO_SHOT_WINDOW_TEST_DATA")
+  virtual int ExactNumBottomBlobs() const { return 0; }
+  virtual int MinTopBlobs() const { return 1; }
+  virtual int MaxTopBlobs() const { return 2; }
+  virtual void LayerSetUp(const vector<Blob<Dtype>*>& bottom, vector<Blob<Dtype>*>* top);
+  virtual void Reshape(const vector<Blob<Dtype>*>& bottom, vector<Blob<Dtype>*>* top) {}
+  void NextBatch(vector<int32_t>* rows, vector<int32_t>* video_ids);    // rows [B][k]
+  int batch_size() const { return batch_size_; }
+  int context_size() const { return dataset_->win_k; }
+  const shared_ptr<VideoDataset>& dataset() const { return dataset_; }
+ private:
+  shared_ptr<VideoDataset> dataset_;
+  int batch_size_ = 0;
+  size_t cursor_ = 0;
+};
+// RETRIEVAL_STATS (retrieval_stats_layer.cpp:19-90): tops = mean AP, hit@1, hit@5
+template <typename Dtype>
+class RetrievalStatsLayer : public Layer<Dtype> {
+  VV_LAYER_BOILER(RetrievalStatsLayer, "RETRIEVAL_STATS")
+  virtual int ExactNumBottomBlobs() const { return 2; }
+  virtual int ExactNumTopBlobs() const { return 3; }
+  virtual void LayerSetUp(const vector<Blob<Dtype>*>& bottom, vector<Blob<Dtype>*>* top);
+  virtual void Reshape(const vector<Blob<Dtype>*>& bottom, vector<Blob<Dtype>*>* top);
+  const vector<int32_t>& map_ids() const { return map_ids_; }
+  const vector<int32_t>& map_cls() const { return map_cls_; }
+  bool exclude_same_video_shots() const { return this->layer_param_.get_msg("retrieval_stats_param").get_bool("exclude_same_video_shots"); }
+ private:
+  vector<int32_t> map_ids_, map_cls_;
 };
 
 // layer_factory.cpp:177-309: the 13 hot-path types (+SPLIT); LOG(FATAL) on anything else

@@ -20,7 +20,7 @@ class Net {
  public:
   explicit Net(const NetParameter& param) { Init(param); }
   explicit Net(const string& param_file, Caffe::Phase phase = Caffe::TRAIN);
-  virtual ~Net() {}
+  virtual ~Net() { if (own_ctx_ && ctx_) vv_destroy(ctx_); }
   void Init(const NetParameter& param);
 
   // net.hpp:78-83: forward + backward of one prefetched batch; returns the weighted loss
@@ -32,6 +32,8 @@ class Net {
   void Update();
   void SetUpdateHyperParams(float rate, float momentum, float weight_decay, const string& reg);
 
+  // net.cpp:638-667: a TEST net takes the weights of the train net (device-to-device through the host)
+  void ShareTrainedLayersWith(Net* other);
   void CopyTrainedLayersFrom(const NetParameter& param);        // net.cpp:691-764
   void CopyTrainedLayersFrom(const string trained_filename);
   void ToProto(NetParameter* param, bool write_diff = false);   // net.cpp:773-801
@@ -69,11 +71,20 @@ class Net {
     vector<float> ctx_coeff; float dropout_ratio = 0.f;
     int data_layer = -1, ip_layer = -1, loss_layer = -1;
     string ip2_blob, target_score_blob, negative_scores_blob, loss_blob, violations_blob;
+    // TEST / extraction graph: window-mean -> fc7 -> ReLU [-> NORMALIZATION] [-> RETRIEVAL_STATS]
+    bool test = false;
+    int stats_layer = -1; bool relu = false;
+    string ip1_blob, norm_blob, label_blob;
+    string stat_blobs[3];
   };
   const FusedPlan& plan() const { return plan_; }
 
  protected:
   void MatchVideovecTrainGraph();
+  void MatchVideovecTestGraph();
+  Dtype ForwardTest();
+  vv_ctx* ctx_ = nullptr;            // train net: the process context; a TEST net owns a second one
+  bool own_ctx_ = false;
   void PushParamsToDevice();
   void PullParamsFromDevice();
   vector<shared_ptr<Layer<Dtype> > > layers_;

@@ -197,6 +197,35 @@ shared_ptr<VideoDataset> VideoDataset::Open(const string& source) {
     LOG(INFO) << "Opening synthetic dataset: " << videos << " videos, " << ds->n_rows << " frames, " << feat << " features";
     return ds;
   }
+  const string synw = "synthetic-windows://";
+  if (source.compare(0, synw.size(), synw) == 0) {
+    // the synthetic videos above plus `windows` test records of `context` consecutive frames each:
+    // window w -> video mix64(wseed, w) % videos, first frame mix64(wseed, 2^32 + w) % (n - context + 1)
+    long windows = 673, context = 4, wseed = 7;
+    string base = "synthetic://", rest = source.substr(synw.size());
+    size_t p = 0;
+    while (p < rest.size()) {
+      size_t e = rest.find(';', p); if (e == string::npos) e = rest.size();
+      const string kv = rest.substr(p, e - p);
+      const size_t eq = kv.find('=');
+      CHECK(eq != string::npos) << "bad source option '" << kv << "'";
+      const string k = kv.substr(0, eq); const long v = atol(kv.c_str() + eq + 1);
+      if (k == "windows") windows = v; else if (k == "context") context = v; else if (k == "wseed") wseed = v;
+      else base += kv + ";";
+      p = e + 1;
+    }
+    if (base.back() == ';') base.pop_back();
+    ds = Open(base);
+    ds->win_k = (int)context;
+    for (long w = 0; w < windows; ++w) {
+      const int v = (int)(mix64((uint64_t)wseed, (uint64_t)w) % ds->video_id.size());
+      CHECK_GE(ds->n_shots[v], (int)context);
+      const int64_t st = (int64_t)(mix64((uint64_t)wseed, (1ull << 32) + (uint64_t)w) % (uint64_t)(ds->n_shots[v] - context + 1));
+      ds->win_video_id.push_back(ds->video_id[v]);
+      for (long j = 0; j < context; ++j) ds->win_rows.push_back((int32_t)(ds->row_base[v] + st + j));
+    }
+    return ds;
+  }
   std::ifstream f(source, std::ios::binary);
   CHECK(f.good()) << "Failed to open dataset " << source << " (LMDB / LevelDB sources need the LMDB reader, which is "
                   << "not built yet; use synthetic://... or a .vvds file)";
@@ -263,6 +292,55 @@ void VideoSampledShotsDataLayer<Dtype>::NextBatch(vector<int32_t>* idx, vector<i
   CHECK_EQ(vv_sampler_next(sampler_, idx->data(), last_src->data(), label->data()), 0);
 }
 template class VideoSampledShotsDataLayer<float>;
+
+template <typename Dtype>
+void VideoShotWindowTestDataLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>&, vector<Blob<Dtype>*>* top) {
+  const pl::Message& p = this->layer_param_.get_msg("video_shot_window_test_data_param");
+  dataset_ = VideoDataset::Open(p.get_str("source"));
+  CHECK_GE(dataset_->win_k, 1) << "source " << p.get_str("source") << " holds no test windows";   // …test_data_layer.cpp:121
+  batch_size_ = (int)p.get_int("batch_size");
+  CHECK_GE(batch_size_, 1);
+  (*top)[0]->Reshape(batch_size_, dataset_->win_k, dataset_->F, 1);                              // …:123-126
+  LOG(INFO) << "output data size: " << (*top)[0]->num() << "," << (*top)[0]->channels() << "," << (*top)[0]->height()
+            << "," << (*top)[0]->width();
+  if (top->size() > 1) (*top)[1]->Reshape(batch_size_, 1, 1, 1);
+}
+template <typename Dtype>
+void VideoShotWindowTestDataLayer<Dtype>::NextBatch(vector<int32_t>* rows, vector<int32_t>* video_ids) {
+  const int k = dataset_->win_k;
+  const size_t nw = dataset_->win_video_id.size();
+  rows->resize((size_t)batch_size_ * k); video_ids->resize(batch_size_);
+  for (int i = 0; i < batch_size_; ++i) {                          // cursor wraps (…:250-262)
+    for (int j = 0; j < k; ++j) (*rows)[(size_t)i * k + j] = dataset_->win_rows[cursor_ * k + j];
+    (*video_ids)[i] = dataset_->win_video_id[cursor_];
+    cursor_ = (cursor_ + 1) % nw;
+  }
+}
+template class VideoShotWindowTestDataLayer<float>;
+
+template <typename Dtype>
+void RetrievalStatsLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>&, vector<Blob<Dtype>*>*) {
+  const pl::Message& p = this->layer_param_.get_msg("retrieval_stats_param");
+  CHECK(!p.get_bool("video_level_retrieval")) << "video_level_retrieval is not built";
+  CHECK(p.get_str("stats_output_file").empty()) << "stats_output_file is not built";
+  std::ifstream f(p.get_str("id_to_class_file"));
+  string line;
+  while (std::getline(f, line)) {                                  // retrieval_stats_layer.cpp:31-43
+    if (line.empty()) continue;
+    const size_t c = line.find(',');
+    CHECK(c != string::npos && line.find(',', c + 1) == string::npos) << "Line: " << line;
+    map_ids_.push_back(atoi(line.substr(0, c).c_str()));
+    map_cls_.push_back(atoi(line.substr(c + 1).c_str()));
+  }
+  CHECK_GE(map_ids_.size(), 1u) << "need atleast one entry in id-to-class map!";      // :49
+}
+template <typename Dtype>
+void RetrievalStatsLayer<Dtype>::Reshape(const vector<Blob<Dtype>*>& bottom, vector<Blob<Dtype>*>* top) {
+  CHECK_EQ(bottom[0]->num(), bottom[1]->num()) << "The data and label should have the same number.";   // :76-77
+  CHECK_EQ(bottom[1]->channels(), 1); CHECK_EQ(bottom[1]->height(), 1); CHECK_EQ(bottom[1]->width(), 1);
+  for (int i = 0; i < 3; ++i) (*top)[i]->Reshape(1, 1, 1, 1);
+}
+template class RetrievalStatsLayer<float>;
 
 // ------------------------------------------------------------------------------- shape layers --
 template <typename Dtype>
@@ -369,6 +447,8 @@ Layer<Dtype>* GetLayer(const LayerParameter& param) {
   if (type == "NORMALIZATION") return new NormalizationLayer<Dtype>(param);
   if (type == "SUM") return new SumLayer<Dtype>(param);
   if (type == "MAX_MARGIN_LOSS") return new MaxMarginLossLayer<Dtype>(param);
+  if (type == "VIDEO_SHOT_WINDOW_TEST_DATA") return new VideoShotWindowTestDataLayer<Dtype>(param);
+  if (type == "RETRIEVAL_STATS") return new RetrievalStatsLayer<Dtype>(param);
   if (type == "NONE") LOG(FATAL) << "Layer " << name << " has unspecified type.";            // layer_factory.cpp:303
   LOG(FATAL) << "Layer " << name << " has type " << type << ", which is outside the videovec training path built here.";
   return nullptr;

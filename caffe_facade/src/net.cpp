@@ -2,6 +2,7 @@
 #include "caffe/net.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 
 namespace caffe {
@@ -122,10 +123,19 @@ void Net<Dtype>::Init(const NetParameter& in_param) {
     net_output_blobs_.push_back(blobs_[blob_names_index_[n]].get());
     net_output_blob_indices_.push_back(blob_names_index_[n]);
   }
-  MatchVideovecTrainGraph();
-  // device side: feature table, parameters
-  auto* data = static_cast<VideoSampledShotsDataLayer<Dtype>*>(layers_[plan_.data_layer].get());
-  data->dataset()->UploadTable(Caffe::ctx());
+  bool is_test = false;
+  for (size_t li = 0; li < layers_.size(); ++li) is_test |= layers_[li]->type() == "VIDEO_SHOT_WINDOW_TEST_DATA";
+  if (is_test) {
+    // a TEST / extraction net has its own feature table, hence its own context on the same device
+    MatchVideovecTestGraph();
+    VV_CHECK(vv_create(Caffe::device(), getenv("VV_PREC") && !strcmp(getenv("VV_PREC"), "bf16") ? VV_PREC_BF16 : VV_PREC_F16, &ctx_));
+    own_ctx_ = true;
+    static_cast<VideoShotWindowTestDataLayer<Dtype>*>(layers_[plan_.data_layer].get())->dataset()->UploadTable(ctx_);
+  } else {
+    MatchVideovecTrainGraph();
+    ctx_ = Caffe::ctx();
+    static_cast<VideoSampledShotsDataLayer<Dtype>*>(layers_[plan_.data_layer].get())->dataset()->UploadTable(ctx_);
+  }
   PushParamsToDevice();
   LOG(INFO) << "Network initialization done.";
 }
@@ -281,14 +291,14 @@ template <typename Dtype>
 void Net<Dtype>::PushParamsToDevice() {
   Layer<Dtype>* ip = layers_[plan_.ip_layer].get();
   CHECK_EQ(ip->blobs()[0]->count(), plan_.D * plan_.F);
-  VV_CHECK(vv_params_set(Caffe::ctx(), plan_.D, ip->blobs()[0]->cpu_data(), ip->blobs()[1]->cpu_data(), NULL, NULL));
+  VV_CHECK(vv_params_set(ctx_, plan_.D, ip->blobs()[0]->cpu_data(), ip->blobs()[1]->cpu_data(), NULL, NULL));
   params_stale_ = false;
 }
 template <typename Dtype>
 void Net<Dtype>::PullParamsFromDevice() {
   if (!params_stale_) return;
   Layer<Dtype>* ip = layers_[plan_.ip_layer].get();
-  VV_CHECK(vv_params_get(Caffe::ctx(), ip->blobs()[0]->mutable_cpu_data(), ip->blobs()[1]->mutable_cpu_data(), NULL, NULL));
+  VV_CHECK(vv_params_get(ctx_, ip->blobs()[0]->mutable_cpu_data(), ip->blobs()[1]->mutable_cpu_data(), NULL, NULL));
   params_stale_ = false;
 }
 template <typename Dtype>
@@ -299,7 +309,7 @@ void Net<Dtype>::GetHistory(vector<shared_ptr<Blob<Dtype> > >* history) {
   history->resize(2);
   (*history)[0].reset(new Blob<Dtype>(1, 1, plan_.D, plan_.F));
   (*history)[1].reset(new Blob<Dtype>(1, 1, 1, plan_.D));
-  VV_CHECK(vv_params_get(Caffe::ctx(), NULL, NULL, (*history)[0]->mutable_cpu_data(), (*history)[1]->mutable_cpu_data()));
+  VV_CHECK(vv_params_get(ctx_, NULL, NULL, (*history)[0]->mutable_cpu_data(), (*history)[1]->mutable_cpu_data()));
 }
 template <typename Dtype>
 void Net<Dtype>::SetHistory(const vector<shared_ptr<Blob<Dtype> > >& history) {
@@ -307,21 +317,22 @@ void Net<Dtype>::SetHistory(const vector<shared_ptr<Blob<Dtype> > >& history) {
   CHECK_EQ(history[0]->count(), plan_.D * plan_.F); CHECK_EQ(history[1]->count(), plan_.D);
   PullParamsFromDevice();
   Layer<Dtype>* ip = layers_[plan_.ip_layer].get();
-  VV_CHECK(vv_params_set(Caffe::ctx(), plan_.D, ip->blobs()[0]->cpu_data(), ip->blobs()[1]->cpu_data(),
+  VV_CHECK(vv_params_set(ctx_, plan_.D, ip->blobs()[0]->cpu_data(), ip->blobs()[1]->cpu_data(),
                          history[0]->cpu_data(), history[1]->cpu_data()));
 }
 
 template <typename Dtype>
 Dtype Net<Dtype>::ForwardBackward(const vector<Blob<Dtype>*>&) {
+  if (plan_.test) return ForwardTest();
   auto* data = static_cast<VideoSampledShotsDataLayer<Dtype>*>(layers_[plan_.data_layer].get());
   data->NextBatch(&idx_, &last_src_, &label_);
   cfg_.ctx_coeff = plan_.ctx_coeff.data();
   bool q1 = false;
   for (size_t i = 0; i < idx_.size() && !q1; ++i) q1 = idx_[i] != last_src_[i];
-  if (q1) VV_CHECK(vv_forward_backward_q1(Caffe::ctx(), &cfg_, idx_.data(), last_src_.data()));
-  else VV_CHECK(vv_forward_backward(Caffe::ctx(), &cfg_, idx_.data(), 0));
+  if (q1) VV_CHECK(vv_forward_backward_q1(ctx_, &cfg_, idx_.data(), last_src_.data()));
+  else VV_CHECK(vv_forward_backward(ctx_, &cfg_, idx_.data(), 0));
   float loss = 0, viol = 0;
-  VV_CHECK(vv_loss_get(Caffe::ctx(), &loss, &viol));
+  VV_CHECK(vv_loss_get(ctx_, &loss, &viol));
   // keep the two scalar output blobs current (they feed the solver's display lines)
   if (has_blob(plan_.loss_blob)) blobs_[blob_names_index_[plan_.loss_blob]]->mutable_cpu_data()[0] = loss / (plan_.loss_weight ? plan_.loss_weight : 1.f);
   if (!plan_.violations_blob.empty()) blobs_[blob_names_index_[plan_.violations_blob]]->mutable_cpu_data()[0] = viol;
@@ -345,8 +356,127 @@ void Net<Dtype>::SetUpdateHyperParams(float rate, float momentum, float weight_d
   else LOG(FATAL) << "Unknown regularization type: " << reg;                          // solver.cpp:523
 }
 template <typename Dtype>
+void Net<Dtype>::ShareTrainedLayersWith(Net* other) {
+  CHECK_EQ(plan_.D, other->plan_.D); CHECK_EQ(plan_.F, other->plan_.F);
+  other->PullParamsFromDevice();
+  Layer<Dtype>* src = other->layers_[other->plan_.ip_layer].get();
+  Layer<Dtype>* dst = layers_[plan_.ip_layer].get();
+  CHECK(layer_names_[plan_.ip_layer] == other->layer_names_[other->plan_.ip_layer])
+      << "layers are shared by name (net.cpp:641-648)";
+  for (int k = 0; k < 2; ++k) dst->blobs()[k]->CopyFrom(*src->blobs()[k]);
+  PushParamsToDevice();
+}
+
+// ---------------------------------------------------------------------------------------------
+// TEST / extraction graph (mednet_embedding_train.prototxt TEST phase: 30-45, 75-104, 133-177, 190-217,
+// 344-352, 673-688; videovec_extraction.prototxt:179-205): VIDEO_SHOT_WINDOW_TEST_DATA -> SLICE dim 1
+// -> CONCAT dim 0 -> FLATTEN -> SLICE dim 0 -> ELTWISE SUM(coeff) -> fc -> RELU [-> NORMALIZATION]
+// [-> RETRIEVAL_STATS].  With a single context frame the data blob may feed FLATTEN / fc directly.
+// ---------------------------------------------------------------------------------------------
+template <typename Dtype>
+void Net<Dtype>::MatchVideovecTestGraph() {
+  const char* why = "This build runs only the TEST / extraction graph of projects/videovec_embedding; ";
+  enum TK { T_NONE, T_DATA, T_DATUM, T_XROWS, T_FRAME, T_MEAN, T_Y, T_H, T_HN, T_LABEL, T_STAT };
+  struct TS { TK k = T_NONE; int a = 0; };
+  std::map<int, TS> sym;
+  FusedPlan& P = plan_;
+  P.test = true;
+  int k = 0;
+  for (size_t li = 0; li < layers_.size(); ++li) {
+    Layer<Dtype>* layer = layers_[li].get();
+    const string type = layer->type(), lname = layer_names_[li];
+    const vector<int>& bi = bottom_id_vecs_[li];
+    const vector<int>& ti = top_id_vecs_[li];
+    auto in = [&](int i) -> TS { return sym[bi[i]]; };
+    auto bad = [&](const string& what) { LOG(FATAL) << why << "layer " << lname << " (" << type << "): " << what; };
+    if (type == "VIDEO_SHOT_WINDOW_TEST_DATA") {
+      auto* d = static_cast<VideoShotWindowTestDataLayer<Dtype>*>(layer);
+      P.data_layer = (int)li; P.B = d->batch_size(); P.C = k = d->context_size(); P.F = d->dataset()->F;
+      sym[ti[0]].k = k == 1 ? T_MEAN : T_DATA;
+      if (k == 1) P.ctx_coeff.assign(1, 1.f);
+      if (ti.size() > 1) { sym[ti[1]].k = T_LABEL; P.label_blob = blob_names_[ti[1]]; }
+    } else if (type == "SLICE") {
+      const int dim = (int)layer->layer_param().get_msg("slice_param").get_int("slice_dim");
+      if (in(0).k == T_DATA && dim == 1 && (int)ti.size() == k) for (int j = 0; j < k; ++j) { sym[ti[j]].k = T_DATUM; sym[ti[j]].a = j; }
+      else if (in(0).k == T_XROWS && dim == 0 && (int)ti.size() == k) for (int j = 0; j < k; ++j) { sym[ti[j]].k = T_FRAME; sym[ti[j]].a = j; }
+      else bad("unexpected SLICE");
+    } else if (type == "CONCAT") {
+      const int dim = (int)layer->layer_param().get_msg("concat_param").get_int("concat_dim");
+      if (dim != 0 || (int)bi.size() != k) bad("unexpected CONCAT");
+      for (int j = 0; j < k; ++j) if (in(j).k != T_DATUM || in(j).a != j) bad("context datums out of order");
+      sym[ti[0]].k = T_XROWS;
+    } else if (type == "FLATTEN") {
+      if (in(0).k != T_XROWS && in(0).k != T_MEAN) bad("unexpected FLATTEN input");
+      sym[ti[0]] = in(0);
+    } else if (type == "ELTWISE") {
+      auto* e = static_cast<EltwiseLayer<Dtype>*>(layer);
+      if (e->op() != "SUM" || (int)bi.size() != k) bad("average_for_test must SUM the context frames");
+      for (int j = 0; j < k; ++j) if (in(j).k != T_FRAME || in(j).a != j) bad("frames out of order");
+      P.ctx_coeff.assign(e->coeffs().begin(), e->coeffs().end());
+      sym[ti[0]].k = T_MEAN;
+    } else if (type == "INNER_PRODUCT") {
+      if (in(0).k != T_MEAN || P.ip_layer >= 0) bad("the fc layer must consume the averaged input");
+      P.ip_layer = (int)li; P.D = static_cast<InnerProductLayer<Dtype>*>(layer)->num_output();
+      sym[ti[0]].k = T_Y; P.ip1_blob = blob_names_[ti[0]]; P.ip2_blob = P.ip1_blob;
+    } else if (type == "RELU") {
+      if (in(0).k != T_Y) bad("RELU is expected on the fc output");
+      P.relu = true; sym[ti[0]].k = T_H; P.ip2_blob = blob_names_[ti[0]];
+    } else if (type == "NORMALIZATION") {
+      if (in(0).k != T_H && in(0).k != T_Y) bad("unexpected NORMALIZATION input");
+      sym[ti[0]].k = T_HN; P.norm_blob = blob_names_[ti[0]];
+    } else if (type == "RETRIEVAL_STATS") {
+      if (in(1).k != T_LABEL) bad("second bottom must be the video ids");
+      if (in(0).k != T_HN && in(0).k != T_H) bad("first bottom must be the (normalised) embedding");
+      if (in(0).k == T_H) P.norm_blob.clear();
+      P.stats_layer = (int)li;
+      for (int t = 0; t < 3; ++t) { sym[ti[t]].k = T_STAT; P.stat_blobs[t] = blob_names_[ti[t]]; }
+    } else bad("layer type outside the TEST path");
+  }
+  if (P.data_layer < 0 || P.ip_layer < 0) LOG(FATAL) << why << "need a VIDEO_SHOT_WINDOW_TEST_DATA layer and one INNER_PRODUCT layer";
+  LOG(INFO) << "Fused videovec TEST plan: B=" << P.B << " frames=" << P.C << " F=" << P.F << " D=" << P.D
+            << (P.stats_layer >= 0 ? " + retrieval stats" : "");
+}
+
+template <typename Dtype>
+Dtype Net<Dtype>::ForwardTest() {
+  auto* data = static_cast<VideoShotWindowTestDataLayer<Dtype>*>(layers_[plan_.data_layer].get());
+  data->NextBatch(&idx_, &label_);
+  Blob<Dtype>* ip2 = blobs_[blob_names_index_[plan_.ip2_blob]].get();
+  CHECK_EQ(ip2->count(), plan_.B * plan_.D);
+  VV_CHECK(vv_embed_mean(ctx_, idx_.data(), plan_.B, plan_.C, plan_.ctx_coeff.data(), plan_.relu ? 1 : 0, 0,
+                         ip2->mutable_cpu_data()));
+  if (!plan_.label_blob.empty()) {
+    Dtype* l = blobs_[blob_names_index_[plan_.label_blob]]->mutable_cpu_data();
+    for (int i = 0; i < plan_.B; ++i) l[i] = (Dtype)label_[i];
+  }
+  const Dtype* feat = ip2->cpu_data();
+  if (!plan_.norm_blob.empty()) {      // NORMALIZATION forward (normalization_layer.cpp:29-61): y = x / (|x| + 1e-10)
+    Blob<Dtype>* nb = blobs_[blob_names_index_[plan_.norm_blob]].get();
+    for (int i = 0; i < plan_.B; ++i) {
+      const Dtype* x = ip2->cpu_data() + (size_t)i * plan_.D;
+      double s = 0;
+      for (int d = 0; d < plan_.D; ++d) s += (double)x[d] * x[d];
+      const Dtype inv = (Dtype)(1.0 / (std::sqrt(s) + 1e-10));
+      Dtype* y = nb->mutable_cpu_data() + (size_t)i * plan_.D;
+      for (int d = 0; d < plan_.D; ++d) y[d] = x[d] * inv;
+    }
+    feat = nb->cpu_data();
+  }
+  if (plan_.stats_layer >= 0) {
+    auto* rs = static_cast<RetrievalStatsLayer<Dtype>*>(layers_[plan_.stats_layer].get());
+    float m = 0, h1 = 0, h5 = 0;
+    VV_CHECK(vv_retrieval_stats(ctx_, feat, plan_.B, plan_.D, label_.data(), rs->map_ids().data(), rs->map_cls().data(),
+                                (int)rs->map_ids().size(), rs->exclude_same_video_shots() ? 1 : 0, &m, &h1, &h5));
+    const float v[3] = {m, h1, h5};
+    for (int t = 0; t < 3; ++t) blobs_[blob_names_index_[plan_.stat_blobs[t]]]->mutable_cpu_data()[0] = v[t];
+  }
+  ++iter_;
+  return 0;
+}
+
+template <typename Dtype>
 void Net<Dtype>::Update() {
-  VV_CHECK(vv_apply_update(Caffe::ctx(), &cfg_));
+  VV_CHECK(vv_apply_update(ctx_, &cfg_));
   params_stale_ = true;
 }
 
@@ -363,11 +493,11 @@ template <typename Dtype>
 const shared_ptr<Blob<Dtype> > Net<Dtype>::blob_by_name(const string& n) {
   if (!has_blob(n)) { LOG(WARNING) << "Unknown blob name " << n; return shared_ptr<Blob<Dtype> >(); }   // net.cpp:846-857
   shared_ptr<Blob<Dtype> > b = blobs_[blob_names_index_[n]];
-  if (iter_ > 0) {
+  if (iter_ > 0 && !plan_.test) {
     const int B = plan_.B, Nn = plan_.Nn;
-    if (n == plan_.ip2_blob) VV_CHECK(vv_blobs_get(Caffe::ctx(), b->mutable_cpu_data(), NULL, NULL, NULL));
-    else if (n == plan_.target_score_blob) { CHECK_EQ(b->count(), B * Nn); VV_CHECK(vv_blobs_get(Caffe::ctx(), NULL, b->mutable_cpu_data(), NULL, NULL)); }
-    else if (n == plan_.negative_scores_blob) { CHECK_EQ(b->count(), B * Nn); VV_CHECK(vv_blobs_get(Caffe::ctx(), NULL, NULL, b->mutable_cpu_data(), NULL)); }
+    if (n == plan_.ip2_blob) VV_CHECK(vv_blobs_get(ctx_, b->mutable_cpu_data(), NULL, NULL, NULL));
+    else if (n == plan_.target_score_blob) { CHECK_EQ(b->count(), B * Nn); VV_CHECK(vv_blobs_get(ctx_, NULL, b->mutable_cpu_data(), NULL, NULL)); }
+    else if (n == plan_.negative_scores_blob) { CHECK_EQ(b->count(), B * Nn); VV_CHECK(vv_blobs_get(ctx_, NULL, NULL, b->mutable_cpu_data(), NULL)); }
   }
   return b;
 }
@@ -393,7 +523,7 @@ void Net<Dtype>::CopyTrainedLayersFrom(const NetParameter& param) {
   GetHistory(&hist);
   params_stale_ = false;
   Layer<Dtype>* ip = layers_[plan_.ip_layer].get();
-  VV_CHECK(vv_params_set(Caffe::ctx(), plan_.D, ip->blobs()[0]->cpu_data(), ip->blobs()[1]->cpu_data(),
+  VV_CHECK(vv_params_set(ctx_, plan_.D, ip->blobs()[0]->cpu_data(), ip->blobs()[1]->cpu_data(),
                          hist[0]->cpu_data(), hist[1]->cpu_data()));
 }
 template <typename Dtype>
@@ -407,7 +537,7 @@ void Net<Dtype>::ToProto(NetParameter* param, bool write_diff) {
   PullParamsFromDevice();
   if (write_diff) {
     Layer<Dtype>* ip = layers_[plan_.ip_layer].get();
-    if (iter_ > 0) VV_CHECK(vv_grads_get(Caffe::ctx(), ip->blobs()[0]->mutable_cpu_diff(), ip->blobs()[1]->mutable_cpu_diff()));
+    if (iter_ > 0) VV_CHECK(vv_grads_get(ctx_, ip->blobs()[0]->mutable_cpu_diff(), ip->blobs()[1]->mutable_cpu_diff()));
   }
   *param = NetParameter("NetParameter");
   param->set_str("name", name_);

@@ -49,11 +49,37 @@ void Solver<Dtype>::InitTrainNet() {
 
 template <typename Dtype>
 void Solver<Dtype>::InitTestNets() {
-  // solver.cpp:84-157.  The TEST branch of the project net (VIDEO_SHOT_WINDOW_TEST_DATA +
-  // RETRIEVAL_STATS) is a later row of the build plan; test nets are not instantiated yet.
-  const int n = param_.size("test_iter");
-  if (n && param_.get_int("test_interval") > 0)
-    LOG(WARNING) << "test_interval is set, but the TEST-phase net (retrieval statistics) is not built yet; skipping tests";
+  // solver.cpp:84-157.  Sources of test nets, in the reference's order: test_net_param, test_net
+  // files, then the generic net_param / net (instantiated test_iter.size() - (others) times).
+  const bool has_net_param = param_.has("net_param"), has_net_file = param_.has("net");
+  const int num_generic_nets = has_net_param + has_net_file;
+  CHECK_LE(num_generic_nets, 1) << "Both net_param and net_file may not be specified.";
+  const int num_test_net_params = param_.size("test_net_param"), num_test_net_files = param_.size("test_net");
+  const int num_test_nets = num_test_net_params + num_test_net_files;
+  if (num_generic_nets) CHECK_GE(param_.size("test_iter"), num_test_nets) << "test_iter must be specified for each test network.";
+  else CHECK_EQ(param_.size("test_iter"), num_test_nets) << "test_iter must be specified for each test network.";
+  const int num_generic_net_instances = param_.size("test_iter") - num_test_nets;
+  const int num_test_net_instances = num_test_nets + num_generic_net_instances;
+  if (param_.size("test_state")) CHECK_EQ(param_.size("test_state"), num_test_net_instances) << "test_state must be unspecified or specified once per test net.";
+  if (num_test_net_instances) CHECK_GT(param_.get_int("test_interval"), 0);
+  vector<NetParameter> net_params;
+  for (int i = 0; i < num_test_net_params; ++i) net_params.push_back(param_.get_msg("test_net_param", i));
+  for (int i = 0; i < num_test_net_files; ++i) { NetParameter np("NetParameter"); pl::ReadProtoFromTextFileOrDie(param_.get_str("test_net", i), &np); net_params.push_back(np); }
+  for (int i = 0; i < num_generic_net_instances; ++i) {
+    NetParameter np("NetParameter");
+    if (has_net_param) np = param_.get_msg("net_param"); else pl::ReadProtoFromTextFileOrDie(param_.get_str("net"), &np);
+    net_params.push_back(np);
+  }
+  Caffe::set_phase(Caffe::TEST);
+  for (int i = 0; i < num_test_net_instances; ++i) {
+    NetState state("NetState");
+    state.set_enum("phase", "TEST");
+    if (param_.size("test_state")) { const NetState& s = param_.get_msg("test_state", i); if (s.has("level")) state.set_int("level", s.get_int("level")); for (int k = 0; k < s.size("stage"); ++k) state.add_str("stage", s.get_str("stage", k)); }
+    *net_params[i].mutable_msg("state") = state;
+    LOG(INFO) << "Creating test net (#" << i << ")";
+    test_nets_.push_back(shared_ptr<Net<Dtype> >(new Net<Dtype>(net_params[i])));
+  }
+  Caffe::set_phase(Caffe::TRAIN);
 }
 
 template <typename Dtype>
@@ -107,7 +133,39 @@ void Solver<Dtype>::Solve(const char* resume_file) {
 template <typename Dtype>
 void Solver<Dtype>::TestAll() { for (size_t i = 0; i < test_nets_.size(); ++i) Test((int)i); }
 template <typename Dtype>
-void Solver<Dtype>::Test(const int) {}
+void Solver<Dtype>::Test(const int test_net_id) {                                      // solver.cpp:251-317
+  LOG(INFO) << "Iteration " << iter_ << ", Testing net (#" << test_net_id << ")";
+  Caffe::set_phase(Caffe::TEST);
+  const shared_ptr<Net<Dtype> >& test_net = test_nets_[test_net_id];
+  test_net->ShareTrainedLayersWith(net_.get());
+  vector<Dtype> test_score;
+  vector<int> test_score_output_id;
+  vector<Blob<Dtype>*> bottom_vec;
+  Dtype loss = 0;
+  const int iters = (int)param_.get_int("test_iter", test_net_id);
+  for (int i = 0; i < iters; ++i) {
+    Dtype iter_loss;
+    const vector<Blob<Dtype>*>& result = test_net->Forward(bottom_vec, &iter_loss);
+    if (param_.get_bool("test_compute_loss")) loss += iter_loss;
+    int idx = 0;
+    for (size_t j = 0; j < result.size(); ++j)
+      for (int k = 0; k < result[j]->count(); ++k) {
+        if (i == 0) { test_score.push_back(result[j]->cpu_data()[k]); test_score_output_id.push_back((int)j); }
+        else test_score[idx++] += result[j]->cpu_data()[k];
+      }
+  }
+  if (param_.get_bool("test_compute_loss")) LOG(INFO) << "Test loss: " << loss / iters;
+  for (size_t i = 0; i < test_score.size(); ++i) {
+    const int output_blob_index = test_net->output_blob_indices()[test_score_output_id[i]];
+    const string& output_name = test_net->blob_names()[output_blob_index];
+    const Dtype loss_weight = test_net->blob_loss_weights()[output_blob_index];
+    std::ostringstream loss_msg_stream;
+    const Dtype mean_score = test_score[i] / iters;
+    if (loss_weight) loss_msg_stream << " (* " << loss_weight << " = " << loss_weight * mean_score << " loss)";
+    LOG(INFO) << "    Test net output #" << i << ": " << output_name << " = " << mean_score << loss_msg_stream.str();
+  }
+  Caffe::set_phase(Caffe::TRAIN);
+}
 
 template <typename Dtype>
 void Solver<Dtype>::Snapshot() {

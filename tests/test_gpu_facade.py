@@ -122,3 +122,55 @@ def test_unsupported_graph_is_fatal(tool, tmp_path):
     sol_p.write_text(solver(str(net_p), max_iter=1, snapshot_prefix=str(tmp_path / "x")))
     r = subprocess.run([CAFFE, "train", "--solver=%s" % sol_p], capture_output=True, text=True)
     assert r.returncode != 0 and "videovec_embedding TRAIN graph" in r.stderr
+
+
+def test_caffe_train_with_test_net_and_extract_features(tool, pb, oracle, tmp_path):
+    # the whole shipped net: TRAIN branch + TEST branch (retrieval statistics every test_interval
+    # iterations through Solver::Test, solver.cpp:251-317), then extract_features on the snapshot
+    from videovector_amd.prototxt import extraction_net
+    from videovector_amd.synth import synthetic_windows
+    B, C, Nn, F, D, V, NW = 16, 5, 3, 128, 64, 60, 90
+    ds = SyntheticVideos(seed=9, n_videos=V)
+    cls = {int(v): int(v % 5) + 1 for v in range(V)}
+    (tmp_path / "id2class.txt").write_text("".join("%d,%d\n" % kv for kv in cls.items()))
+    src = "synthetic://videos=%d;seed=9;features=%d" % (V, F)
+    wsrc = "synthetic-windows://videos=%d;seed=9;features=%d;windows=%d;context=4;wseed=5" % (V, F, NW)
+    net_p, sol_p = tmp_path / "net.prototxt", tmp_path / "solver.prototxt"
+    net_p.write_text(train_net(src, B, C, Nn, D, max_buffer=300, w_std=0.02, test_source=wsrc, test_batch=NW,
+                               test_frames=4, id_to_class_file=str(tmp_path / "id2class.txt")))
+    sol_p.write_text(solver(str(net_p), base_lr=0.01, max_iter=4, display=2, snapshot_prefix=str(tmp_path / "s"),
+                            test_iter=1, test_interval=2))
+    W0, b0 = init_weights(4, D, F, std=0.02)
+    write_caffemodel(pb, str(tmp_path / "init.caffemodel"), W0, b0)
+    log = run_caffe(["train", "--solver=%s" % sol_p, "--weights=%s" % (tmp_path / "init.caffemodel")],
+                    str(tmp_path / "t.log"))
+    assert "Fused videovec TEST plan: B=%d frames=4 F=%d D=%d + retrieval stats" % (NW, F, D) in log
+    tests = re.findall(r"Iteration (\d+), Testing net \(#0\)", log)
+    assert tests == ["0", "2", "4"]
+    # net outputs are listed in name order (net.cpp:200-208 iterates a std::set)
+    maps = [float(x) for x in re.findall(r"Test net output #2: test_map = ([0-9.eE+-]+)", log)]
+    h1 = [float(x) for x in re.findall(r"Test net output #0: test_hit_at_1 = ([0-9.eE+-]+)", log)]
+    assert len(maps) == 3 and len(h1) == 3
+    # iteration-0 statistics are those of the initial weights: check against the oracle
+    rows, vids = synthetic_windows(ds, NW, 4, 5)
+    table = ds.table(F)
+    emb = oracle.embed(table[rows].mean(1).astype(np.float32), None, W0, b0, relu=True, l2norm=True)
+    ref = oracle.retrieval_stats(emb, vids, cls)
+    assert abs(maps[0] - ref[0]) <= 5e-3 and abs(h1[0] - ref[1]) <= 2e-2, (maps[0], h1[0], ref)
+
+    # extract_features: ip2 of single frames with the trained snapshot
+    ex_p = tmp_path / "extract.prototxt"
+    xsrc = "synthetic-windows://videos=%d;seed=9;features=%d;windows=25;context=1;wseed=11" % (V, F)
+    ex_p.write_text(extraction_net(xsrc, 10, D))
+    r = subprocess.run([os.path.join(ROOT, "caffe_facade", "build", "extract_features"),
+                        str(tmp_path / "s_iter_4.caffemodel"), "none", str(ex_p), "ip2", str(tmp_path / "feat"), "2", "GPU", "0"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = (tmp_path / "feat" / "text_output.txt").read_text().strip().split("\n")
+    assert lines[0] == "#features" and len(lines) == 21
+    got = np.array([[float(x) for x in l.rstrip(",").split(",")] for l in lines[1:]], np.float32)
+    Wt, bt, _ = read_caffemodel(pb, str(tmp_path / "s_iter_4.caffemodel"))
+    xrows, _ = synthetic_windows(ds, 25, 1, 11)
+    ref = oracle.embed(table, xrows[:20, 0], Wt, bt, relu=True, l2norm=False)
+    assert got.shape == (20, D)
+    assert (np.linalg.norm(got - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-20)).max() <= 1e-3

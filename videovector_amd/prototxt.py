@@ -5,11 +5,36 @@ num_negative_samples = 10; BASELINE configs need 2, 50 and 200.  Layer and blob 
 shipped file so that snapshots and tools keyed on names (fc7, ip2, target_score, ...) carry over."""
 
 
+def _test_branch_front(a, test_source, test_batch, frames):
+    """TEST-phase layers in front of fc7 (mednet_embedding_train.prototxt:30-45,75-104,133-177)."""
+    a('layers {\n  name: "shot_windows"\n  type: VIDEO_SHOT_WINDOW_TEST_DATA\n  top: "data"\n  top: "video_ids"\n'
+      '  video_shot_window_test_data_param {\n    source: "%s"\n    backend: LMDB\n    batch_size: %d\n  }\n'
+      '  include: { phase: TEST }\n}' % (test_source, test_batch))
+    d = ["context_datum_%d" % j for j in range(1, frames + 1)]
+    a('layers {\n  name: "slice_input_data"\n  type: SLICE\n  bottom: "data"\n%s\n  slice_param { slice_dim: 1 }\n'
+      '  include: { phase: TEST }\n}' % "\n".join('  top: "%s"' % x for x in d))
+    a('layers {\n  name: "batch_concat_input_test"\n  type: CONCAT\n%s\n  top: "concat_input_datums"\n'
+      '  concat_param { concat_dim: 0 }\n  include: { phase: TEST }\n}' % "\n".join('  bottom: "%s"' % x for x in d))
+    a('layers {\n  name: "flatten_input"\n  type: FLATTEN\n  bottom: "concat_input_datums"\n'
+      '  top: "concat_input_datums_flat"\n  include: { phase: TEST }\n}')
+    f = ["test_sample_frame_%d" % j for j in range(1, frames + 1)]
+    a('layers {\n  name: "slice_test"\n  type: SLICE\n  bottom: "concat_input_datums_flat"\n%s\n'
+      '  slice_param { slice_dim: 0 }\n  include: { phase: TEST }\n}' % "\n".join('  top: "%s"' % x for x in f))
+    a('layers {\n  name: "average_for_test"\n  type: ELTWISE\n%s\n  top: "original_feature"\n  eltwise_param {\n'
+      '    operation: SUM\n%s\n  }\n  include: { phase: TEST }\n}'
+      % ("\n".join('  bottom: "%s"' % x for x in f), "\n".join("    coeff: %.10g" % (1.0 / frames) for _ in f)))
+
+
 def train_net(source, B, C, Nn, D, *, max_buffer=5000, swap=50, max_same=0, dropout=0.0, margin=2.0,
-              norm="L2", name="videovec_train", w_std=0.001):
+              norm="L2", name="videovec_train", w_std=0.001, test_source=None, test_batch=673, test_frames=4,
+              id_to_class_file=None):
+    """test_source: also emit the TEST branch of the shipped file (window data -> average_for_test ->
+    [shared fc7 / fc7_relu] -> test_norm -> retrieval_stats)."""
     L = []
     a = L.append
     a('name: "%s"' % name)
+    if test_source:
+        _test_branch_front(a, test_source, test_batch, test_frames)
     a('layers {\n  name: "shot_windows"\n  type: VIDEO_SAMPLED_SHOTS_DATA\n  top: "data"\n'
       '  video_sampled_shots_data_param {\n    source: "%s"\n    backend: LMDB\n    batch_size: %d\n'
       '    num_negative_samples: %d\n    max_buffer_size: %d\n    negative_swap_percentage: %d\n'
@@ -67,18 +92,42 @@ def train_net(source, B, C, Nn, D, *, max_buffer=5000, swap=50, max_same=0, drop
       '  bottom: "negative_scores"\n  top: "loss_output"\n  top: "train_violations"\n  loss_weight: 1.0\n'
       '  loss_weight: 0.0\n  max_margin_loss_param {\n    norm: %s\n    margin: %g\n  }\n'
       '  include: { phase: TRAIN }\n}' % (norm, margin))
+    if test_source:
+        a('layers {\n  name: "test_norm"\n  type: NORMALIZATION\n  bottom: "ip2"\n  top: "ip2_norm"\n'
+          '  include: { phase: TEST }\n}')
+        a('layers {\n  name: "retrieval_stats"\n  type: RETRIEVAL_STATS\n  bottom: "ip2_norm"\n  bottom: "video_ids"\n'
+          '  top: "test_map"\n  top: "test_hit_at_1"\n  top: "test_hit_at_5"\n  retrieval_stats_param {\n'
+          '    id_to_class_file: "%s"\n  }\n  include: { phase: TEST }\n}' % id_to_class_file)
+    return "\n".join(L) + "\n"
+
+
+def extraction_net(source, batch, D, *, normalize=False, w_std=0.001):
+    """The tail of projects/videovec_embedding/videovec_extraction.prototxt:179-205 (fc7 + ReLU `ip2`) on
+    pre-extracted fc6 rows (one context frame per record stands for the upstream CaffeNet)."""
+    L = ['name: "videovec_extraction"',
+         'layers {\n  name: "fc6_rows"\n  type: VIDEO_SHOT_WINDOW_TEST_DATA\n  top: "fc6"\n  top: "label"\n'
+         '  video_shot_window_test_data_param {\n    source: "%s"\n    backend: LMDB\n    batch_size: %d\n  }\n}'
+         % (source, batch),
+         'layers {\n  name: "fc7"\n  type: INNER_PRODUCT\n  bottom: "fc6"\n  top: "ip1_nonorm"\n  blobs_lr: 1\n'
+         '  blobs_lr: 2\n  weight_decay: 1\n  weight_decay: 0\n  inner_product_param {\n    num_output: %d\n'
+         '    weight_filler { type: "gaussian" std: %g }\n    bias_filler { type: "constant" }\n  }\n}' % (D, w_std),
+         'layers {\n  name: "fc7_relu"\n  type: RELU\n  bottom: "ip1_nonorm"\n  top: "ip2"\n}']
+    if normalize:
+        L.append('layers {\n  name: "test_norm"\n  type: NORMALIZATION\n  bottom: "ip2"\n  top: "ip2_norm"\n}')
     return "\n".join(L) + "\n"
 
 
 def solver(net_path, *, base_lr=0.001, momentum=0.9, weight_decay=0.0005, lr_policy="inv", gamma=0.001,
            power=0.75, stepsize=0, display=10, max_iter=100, snapshot=0, snapshot_prefix="videovec",
-           random_seed=-1, snapshot_after_train=True):
+           random_seed=-1, snapshot_after_train=True, test_iter=0, test_interval=0):
     """Same fields as projects/videovec_embedding/mednet_embedding_train_solver.prototxt (test_* omitted:
     the TEST branch is not built yet)."""
     s = ['net: "%s"' % net_path, "base_lr: %g" % base_lr, "momentum: %g" % momentum,
          "weight_decay: %g" % weight_decay, 'lr_policy: "%s"' % lr_policy, "gamma: %g" % gamma,
          "power: %g" % power, "display: %d" % display, "max_iter: %d" % max_iter,
          "snapshot: %d" % snapshot, 'snapshot_prefix: "%s"' % snapshot_prefix, "solver_mode: GPU"]
+    if test_iter:
+        s += ["test_iter: %d" % test_iter, "test_interval: %d" % test_interval]
     if stepsize:
         s.append("stepsize: %d" % stepsize)
     if random_seed >= 0:

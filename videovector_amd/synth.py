@@ -64,3 +64,14 @@ def init_weights(seed, D, F, std=1e-3):
     reference's boost RNG: weights are an INPUT that tests hand to both sides explicitly."""
     rng = np.random.default_rng(seed)
     return (rng.standard_normal((D, F)) * std).astype(np.float32), np.zeros(D, np.float32)
+
+
+def synthetic_windows(ds, windows=673, context=4, wseed=7):
+    """TEST-phase records of the `synthetic-windows://` source (caffe_facade VideoDataset::Open): window w
+    is `context` consecutive frames of video mix64(wseed, w) % V starting at
+    mix64(wseed, 2^32 + w) % (n - context + 1).  Returns (rows [windows][context], video_ids [windows])."""
+    w = np.arange(windows, dtype=np.uint64)
+    v = (mix64(wseed, w) % np.uint64(ds.n_videos)).astype(np.int64)
+    st = (mix64(wseed, np.uint64(1 << 32) + w) % (ds.n_shots[v] - context + 1).astype(np.uint64)).astype(np.int64)
+    rows = (ds.row_base[v] + st)[:, None] + np.arange(context)[None, :]
+    return rows.astype(np.int32), ds.video_id[v].astype(np.int32)
