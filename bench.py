@@ -30,7 +30,7 @@ MFMA_PEAK_TFLOPS = 2500.0     # dense bf16/f16 MFMA peak, /opt/skills/guides/MI3
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(ds, idx, W, b, items=256, iters=3):
+def cpu_baseline(ds, idx, W, b, items=512, iters=5):
     """The oracle (CPU restatement of the reference path, layer by layer with an sgemm for fc7)
     timed on a bounded sample of the same workload: `items` batch items of the first batch."""
     from oracle import oracle as orc

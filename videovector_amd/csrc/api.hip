@@ -15,7 +15,7 @@
 
 #include "vv_internal.h"
 
-namespace vv { void set_wgrad_tr(bool on); void set_gemm_variant(int v); void set_ablate(int v); void set_fwd_mi(int v); void set_score_reg(int v); int wgrad_max_ksteps_per_split(); }
+namespace vv { void set_wgrad_tr(bool on); void set_gemm_variant(int v); void set_ablate(int v); void set_fwd_mi(int v); void set_score_reg(int v); void set_wgrad_sched(int v); int wgrad_max_ksteps_per_split(); }
 using namespace vv;
 
 static thread_local char g_err[512] = "";
@@ -137,6 +137,8 @@ int vv_create(int device, int prec, vv_ctx** out) {
   set_fwd_mi(fm ? atoi(fm) : 0);
   const char* sr = getenv("VV_SCORE_REG");
   set_score_reg(sr ? atoi(sr) : 1);
+  const char* ws = getenv("VV_WGRAD_SCHED");
+  set_wgrad_sched(ws ? atoi(ws) : 0);
   *out = c;
   return VV_OK;
 }

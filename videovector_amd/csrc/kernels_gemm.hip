@@ -46,7 +46,7 @@ __device__ __forceinline__ f32x4 mfma_abl(i16x8 x, i16x8 y, f32x4 c) {
 // 256x256 tile; the launcher picks a smaller MI when that fills the 256 CUs in fewer, fuller rounds
 // (56 320 rows: 220 tiles of 256 rows x 2 = 440 WGs = 2 rounds at 86 %, but 252 tiles of 224 rows
 // x 2 = 504 WGs = 2 rounds of tiles that are 12.5 % shorter).
-template <typename T, bool DROP, bool VEC, int ABL = 0, int MI = 8>
+template <typename T, bool DROP, bool VEC, int ABL = 0, int MI = 8, int SCHED = 0>
 __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BMK = 32 * MI;                   // rows of this tile
@@ -99,16 +99,25 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm(FwdArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+  // SCHED 1: the 8 LDS-DMA instructions of the next K-step are not issued as one burst but two
+  // at a time in front of each quarter of the MFMA work, with the quarters pinned by sched_barrier
+  auto stage_part = [&](int p, int kt, int q) {
+    unsigned char* As = smem + p * 2 * LDS_TILE_BYTES;
+    unsigned char* Bs = As + LDS_TILE_BYTES;
+    if (q < NA && (q * 8 + wave) * 8 < BMK) glds16(a_src[q] + kt * BK, As + (q * 8 + wave) * 1024);
+    glds16(b_src[q] + kt * BK, Bs + (q * 8 + wave) * 1024);
+  };
   const int frow = lane & 15, fq = lane >> 4;
   for (int t = 0; t < nk; ++t) {
     const int p = t & 1;
-    if constexpr (!(ABL & 1)) { if (t + 1 < nk) stage(p ^ 1, t + 1); }
+    if constexpr (!(ABL & 1) && SCHED == 0) { if (t + 1 < nk) stage(p ^ 1, t + 1); }
     const unsigned char* As = smem + p * 2 * LDS_TILE_BYTES;
     const unsigned char* Bs = As + LDS_TILE_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int coff = ((kk * 4 + fq) ^ (frow & 7)) << 4;
       i16x8 af[MI], bf[4];
+      if constexpr (SCHED == 1 && !(ABL & 1)) { if (t + 1 < nk) stage_part(p ^ 1, t + 1, 2 * kk); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
         af[mi] = (ABL & 4) ? i16x8{1, 2, 3, 4, 5, 6, 7, (short)mi}
@@ -117,10 +126,28 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm(FwdArgs a) {
       for (int ni = 0; ni < 4; ++ni)
         bf[ni] = (ABL & 4) ? i16x8{1, 2, 3, 4, 5, 6, 7, (short)ni}
                            : *(const i16x8*)(Bs + (wn * 64 + ni * 16 + frow) * 128 + coff);
+      if constexpr (SCHED == 1) {
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
+        for (int mi = 0; mi < MI / 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma_abl<T, ABL>(bf[ni], af[mi], acc[mi][ni]);
+          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma_abl<T, ABL>(bf[ni], af[mi], acc[mi][ni]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!(ABL & 1)) { if (t + 1 < nk) stage_part(p ^ 1, t + 1, 2 * kk + 1); __builtin_amdgcn_sched_barrier(0); }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mi = MI / 2; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma_abl<T, ABL>(bf[ni], af[mi], acc[mi][ni]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma_abl<T, ABL>(bf[ni], af[mi], acc[mi][ni]);
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -179,7 +206,7 @@ __device__ __forceinline__ i16x4 tr_read(const unsigned char* p) {
 }
 __device__ __forceinline__ int wg_h(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
-template <typename T, bool TR, int ABL = 0>
+template <typename T, bool TR, int ABL = 0, int SCHED = 0>
 __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -237,7 +264,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm(WgradArgs a) {
   const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
   for (int t = 0; t < nk; ++t) {
     const int p = t & 1;
-    if constexpr (!(ABL & 1)) {
+    if constexpr (!(ABL & 1) && !(SCHED & 1)) {
       if (t + 1 < nk) {
         stage(p ^ 1, t + 1);
         if (t + 2 < nk) load_ids(t + 2);
@@ -245,9 +272,18 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm(WgradArgs a) {
     }
     const unsigned char* As = smem + p * 2 * LDS_TILE_BYTES;
     const unsigned char* Bs = As + LDS_TILE_BYTES;
+    auto stage_part = [&](int q) {       // SCHED 1: two LDS-DMA instructions in front of each MFMA quarter
+      if (t + 1 >= nk) return;
+      unsigned char* An = smem + (p ^ 1) * 2 * LDS_TILE_BYTES;
+      unsigned char* Bn = An + LDS_TILE_BYTES;
+      const int64_t kg = (int64_t)(k_begin + t + 1) * BK;
+      glds16(a.dYh + (kg + srow[q]) * a.Dp + m0 + slc[q] * 8, An + (q * 8 + wave) * 1024);
+      glds16(a.table + (int64_t)rid[q] * a.Fp + n0 + slc[q] * 8, Bn + (q * 8 + wave) * 1024);
+    };
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       i16x8 af[8], bf[4];
+      if constexpr ((SCHED & 1) && !(ABL & 1)) { stage_part(2 * kk); __builtin_amdgcn_sched_barrier(0); }
       if constexpr (TR) {
         const int row1 = kk * 32 + 8 * g + q;
         const int hx = wg_h(row1) << 1;       // identical for row1 + 4
@@ -289,11 +325,32 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm(WgradArgs a) {
           }
         }
       }
+      if constexpr (SCHED != 0) {
+        if constexpr (SCHED & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int mi = 0; mi < 8; ++mi)
+        for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma_abl<T, ABL>(bf[ni], af[mi], acc[mi][ni]);
+          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma_abl<T, ABL>(bf[ni], af[mi], acc[mi][ni]);
+        if constexpr (SCHED & 2) __builtin_amdgcn_s_setprio(0);
+        if constexpr (SCHED & 1) {
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (!(ABL & 1)) { stage_part(2 * kk + 1); __builtin_amdgcn_sched_barrier(0); }
+        }
+        if constexpr (SCHED & 2) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mi = 4; mi < 8; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma_abl<T, ABL>(bf[ni], af[mi], acc[mi][ni]);
+        if constexpr (SCHED & 2) __builtin_amdgcn_s_setprio(0);
+        if constexpr (SCHED & 1) __builtin_amdgcn_sched_barrier(0);
+      } else {
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma_abl<T, ABL>(bf[ni], af[mi], acc[mi][ni]);
+      }
     }
+    if constexpr ((SCHED & 1) && !(ABL & 1)) { if (t + 2 < nk) load_ids(t + 2); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -556,6 +613,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ring(WgradArgs a) {
 
 // ------------------------------------------------------------------------------- launchers ----
 static bool g_wgrad_tr = true;
+static int g_wgrad_sched = 0;       // VV_WGRAD_SCHED: bit0 interleaved staging, bit1 setprio (experiments)
+void set_wgrad_sched(int v) { g_wgrad_sched = v; }
 static int g_fwd_mi = 0;            // VV_FWD_MI: force the forward tile height (0 = automatic)
 void set_fwd_mi(int v) { g_fwd_mi = v; }
 static int g_ablate = 0;
@@ -593,7 +652,7 @@ static void launch_fwd_t(const FwdArgs& a, hipStream_t s) {
   }
   if constexpr (!DROP && VEC) {
     // balanced M tiling: the MI in {8,7,6} that needs the least (rounds of 256 WGs) x (tile height)
-    if (g_gemm_variant == 0) {
+    if (g_gemm_variant != 1) {
       int best = 8; long best_cost = -1;
       for (int mi = 8; mi >= 6; --mi) {
         const long tiles = ((a.R + 32 * mi - 1) / (32 * mi)) * (long)(Dp / BN);
@@ -601,6 +660,20 @@ static void launch_fwd_t(const FwdArgs& a, hipStream_t s) {
         if (best_cost < 0 || cost < best_cost) { best = mi; best_cost = cost; }
       }
       if (g_fwd_mi) best = g_fwd_mi;
+      if (g_gemm_variant != 3) {     // default: interleaved staging + setprio (variant 3 = burst staging, for A/B)
+        if (best == 6) best = 7;
+        const dim3 g2(((a.R + 32 * best - 1) / (32 * best)) * (Dp / BN));
+        if (best == 7) {
+          static bool o7 = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm<T, DROP, VEC, 0, 7, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES), true);
+          (void)o7;
+          hipLaunchKernelGGL((k_fwd_gemm<T, DROP, VEC, 0, 7, 1>), g2, block, GEMM_LDS_BYTES, s, a);
+        } else {
+          static bool o8 = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm<T, DROP, VEC, 0, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES), true);
+          (void)o8;
+          hipLaunchKernelGGL((k_fwd_gemm<T, DROP, VEC, 0, 8, 1>), g2, block, GEMM_LDS_BYTES, s, a);
+        }
+        return;
+      }
       if (best != 8) {
         const dim3 g2(((a.R + 32 * best - 1) / (32 * best)) * (Dp / BN));
         if (best == 7) {
@@ -673,6 +746,17 @@ void launch_wgrad_gemm(int prec, const WgradArgs& a, hipStream_t s) {
     }
     VV_ABL_WG(1) VV_ABL_WG(2) VV_ABL_WG(3) VV_ABL_WG(6) VV_ABL_WG(7)
 #undef VV_ABL_WG
+  }
+  if (g_wgrad_sched && g_wgrad_tr && prec == 0 && g_gemm_variant != 1) {    // experimental schedules (f16 only)
+    const dim3 grid((a.Dp / BM) * (a.Fp / BN) * a.S), block(GEMM_THREADS);
+#define VV_WG_SCHED(N)                                                                                         \
+    if (g_wgrad_sched == N) {                                                                                  \
+      (void)hipFuncSetAttribute((const void*)k_wgrad_gemm<F16, true, 0, N>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES); \
+      hipLaunchKernelGGL((k_wgrad_gemm<F16, true, 0, N>), grid, block, GEMM_LDS_BYTES, s, a);                    \
+      return;                                                                                                  \
+    }
+    VV_WG_SCHED(1) VV_WG_SCHED(2) VV_WG_SCHED(3)
+#undef VV_WG_SCHED
   }
   if (g_gemm_variant == 1 && g_wgrad_tr && a.ksteps_per_split * BK <= WG_IDS_MAX) {
     if (prec == 0) launch_wgrad_ring_t<F16>(a, s); else launch_wgrad_ring_t<BF16>(a, s);
