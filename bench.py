@@ -94,7 +94,14 @@ def main():
 
     W0, b0 = init_weights(SEED, D, F)
     eng = vv.Engine(local_rank, args.prec)
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    # Everything (kernels of the context and the collective) is issued under ONE explicit, non-default
+    # torch stream: torch orders the RCCL all-reduce after the kernels already queued on the current
+    # stream and the following kernels after the all-reduce.  (The default stream's raw handle is 0,
+    # which vv_set_stream reads as "the context's own stream".)
+    work_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(work_stream)
+    assert work_stream.cuda_stream != 0
+    eng.set_stream(work_stream.cuda_stream)
     eng.table_synth(ds.seed, ds.n_rows, F)
     eng.params_set(W0, b0)
     grads = None

@@ -30,7 +30,11 @@ class GpuBackend:
     def __init__(self, engine, cfg):
         import torch
         self.torch, self.eng, self.cfg = torch, engine, cfg
-        self.eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        # one explicit non-default stream for kernels and collective (the default stream's raw handle
+        # is 0, which vv_set_stream reads as "the context's own stream")
+        self.stream = torch.cuda.Stream()
+        torch.cuda.set_stream(self.stream)
+        self.eng.set_stream(self.stream.cuda_stream)
         n = engine.D * engine.F + engine.D
         self.grads = torch.zeros(n, dtype=torch.float32, device="cuda")
         self.eng.grads_bind(self.grads.data_ptr())
