@@ -8,6 +8,8 @@
 // Net::Init (net.hpp).  Calling Forward/Backward on a single layer is fatal, with the same
 // abort-on-error convention the reference uses for unsupported configurations.
 #pragma once
+#include <thread>
+
 #include "caffe/blob.hpp"
 
 namespace caffe {
@@ -111,6 +113,12 @@ class VideoSampledShotsDataLayer : public Layer<Dtype> {
   const shared_ptr<VideoDataset>& dataset() const { return dataset_; }
  private:
   shared_ptr<VideoDataset> dataset_;
+  // prefetch: one host thread per data layer produces the next index batch while the GPU works on
+  // the current one (BasePrefetchingDataLayer, base_data_layer.cpp:52-95; InternalThread)
+  void CreatePrefetchThread();
+  void JoinPrefetchThread();
+  std::thread thread_;
+  vector<int32_t> pf_idx_, pf_last_, pf_label_;
   vv_sampler* sampler_ = nullptr;
   int batch_size_ = 0, context_size_ = 0, num_negative_samples_ = 0, feature_size_ = 0;
 };

@@ -255,7 +255,18 @@ void VideoDataset::UploadTable(vv_ctx* ctx) const {
 
 // ------------------------------------------------------------------------------- data layer ----
 template <typename Dtype>
-VideoSampledShotsDataLayer<Dtype>::~VideoSampledShotsDataLayer() { if (sampler_) vv_sampler_destroy(sampler_); }
+VideoSampledShotsDataLayer<Dtype>::~VideoSampledShotsDataLayer() {
+  JoinPrefetchThread();
+  if (sampler_) vv_sampler_destroy(sampler_);
+}
+template <typename Dtype>
+void VideoSampledShotsDataLayer<Dtype>::CreatePrefetchThread() {
+  const size_t n = (size_t)batch_size_ * (context_size_ + num_negative_samples_);
+  pf_idx_.resize(n); pf_last_.resize(n); pf_label_.resize(batch_size_);
+  thread_ = std::thread([this]() { CHECK_EQ(vv_sampler_next(sampler_, pf_idx_.data(), pf_last_.data(), pf_label_.data()), 0); });
+}
+template <typename Dtype>
+void VideoSampledShotsDataLayer<Dtype>::JoinPrefetchThread() { if (thread_.joinable()) thread_.join(); }
 
 template <typename Dtype>
 void VideoSampledShotsDataLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>&, vector<Blob<Dtype>*>* top) {
@@ -284,12 +295,13 @@ void VideoSampledShotsDataLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>&, 
   LOG(INFO) << "output data size: " << (*top)[0]->num() << "," << (*top)[0]->channels() << "," << (*top)[0]->height()
             << "," << (*top)[0]->width();
   if (top->size() > 1) (*top)[1]->Reshape(batch_size_, 1, 1, 1);
+  CreatePrefetchThread();                                          // base_data_layer.cpp:63-66
 }
 template <typename Dtype>
 void VideoSampledShotsDataLayer<Dtype>::NextBatch(vector<int32_t>* idx, vector<int32_t>* last_src, vector<int32_t>* label) {
-  const size_t n = (size_t)batch_size_ * (context_size_ + num_negative_samples_);
-  idx->resize(n); last_src->resize(n); label->resize(batch_size_);
-  CHECK_EQ(vv_sampler_next(sampler_, idx->data(), last_src->data(), label->data()), 0);
+  JoinPrefetchThread();                                            // base_data_layer.cpp:81-95: join, hand over, respawn
+  idx->swap(pf_idx_); last_src->swap(pf_last_); label->swap(pf_label_);
+  CreatePrefetchThread();
 }
 template class VideoSampledShotsDataLayer<float>;
 

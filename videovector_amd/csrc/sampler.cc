@@ -59,7 +59,18 @@ struct vv_sampler {
   std::vector<int32_t> buffer_ids;            // persistent permutation (…data_layer.cpp:81-83)
   std::vector<int32_t> buf_row;               // slot -> table row
   std::vector<uint64_t> buf_key;              // slot -> (video_id, shot_id)
-  std::unordered_set<uint64_t> keys;          // negative_keys_set_
+  std::unordered_set<uint64_t> keys;          // negative_keys_set_ (general case)
+  // fast path: when every (video_id, shot_id) key names exactly one table row, membership in the key
+  // set is a bitmap over table rows
+  bool dense_keys = false;
+  std::vector<uint8_t> row_in_buf;
+  bool contains(int v, int j) const {
+    return dense_keys ? row_in_buf[(size_t)(row_base[v] - row_min + j)] != 0 : keys.count(key(video_id[v], shot_id(v, j))) != 0;
+  }
+  void insert_key(int v, int j) {
+    if (dense_keys) row_in_buf[(size_t)(row_base[v] - row_min + j)] = 1; else keys.insert(key(video_id[v], shot_id(v, j)));
+  }
+  int64_t row_min = 0;
   std::vector<Slot> slots;                    // persistent prefetch_data_ contents [B][C+Nn]
   std::vector<int32_t> perm;
 
@@ -106,6 +117,26 @@ int vv_sampler_create(const vv_sampler_param* p, int32_t n_videos, const int32_t
   }
   if (shot_ids) { s->has_ids = true; s->shot_ids.assign(shot_ids, shot_ids + total); }
   s->perm.reserve(max_n);
+  {  // keys are in bijection with rows iff video ids are distinct, shot ids distinct within a video and
+     // the records' row ranges do not overlap
+    std::unordered_set<int32_t> vids(video_id, video_id + n_videos);
+    bool ok = (int)vids.size() == n_videos;
+    int64_t lo = row_base[0], hi = row_base[0];
+    std::vector<std::pair<int64_t, int64_t>> ranges;
+    for (int v = 0; v < n_videos && ok; ++v) {
+      lo = std::min(lo, row_base[v]); hi = std::max(hi, row_base[v] + n_shots[v]);
+      ranges.emplace_back(row_base[v], row_base[v] + n_shots[v]);
+      if (shot_ids) {
+        std::unordered_set<int32_t> sids(shot_ids + s->shot_off[v], shot_ids + s->shot_off[v] + n_shots[v]);
+        ok = (int)sids.size() == n_shots[v];
+      }
+    }
+    if (ok) {
+      std::sort(ranges.begin(), ranges.end());
+      for (size_t i = 1; i < ranges.size() && ok; ++i) ok = ranges[i].first >= ranges[i - 1].second;
+    }
+    if (ok && hi - lo < (1ll << 31)) { s->dense_keys = true; s->row_min = lo; s->row_in_buf.assign((size_t)(hi - lo), 0); }
+  }
   const int CN = p->context_size + Nn;
   s->slots.assign((size_t)p->batch_size * CN, Slot());
   const int mb = Nn > 0 ? p->max_buffer_size : 0;
@@ -119,10 +150,10 @@ int vv_sampler_create(const vv_sampler_param* p, int32_t n_videos, const int32_t
       const int v = s->cursor;
       s->cursor = (s->cursor + 1) % n_videos;
       const int j = s->rng.next() % s->n_shots[v];
-      const uint64_t k = vv_sampler::key(s->video_id[v], s->shot_id(v, j));
-      if (s->keys.insert(k).second) {
+      if (!s->contains(v, j)) {
+        s->insert_key(v, j);
         s->buf_row.push_back((int32_t)(s->row_base[v] + j));
-        s->buf_key.push_back(k);
+        s->buf_key.push_back(vv_sampler::key(s->video_id[v], s->shot_id(v, j)));
       }
     }
     if ((int)s->buf_row.size() != mb) { delete s; return VV_ERR_ARG; }           // :344
@@ -175,13 +206,13 @@ int vv_sampler_next(vv_sampler* s, int32_t* idx, int32_t* last_src, int32_t* lab
     ++item;
     if (Nn > 0 && p.negative_swap_percentage > 0) {                                // :888-906
       for (int j = 0; j < n; ++j) {
-        const uint64_t k = vv_sampler::key(s->video_id[v], s->shot_id(v, j));
-        if (s->keys.count(k)) continue;
+        if (s->contains(v, j)) continue;
         if (s->rng.next() % 100 < p.negative_swap_percentage) {                    // :27
           const int pos = s->rng.next() % p.max_buffer_size;                       // :29
-          s->keys.erase(s->buf_key[pos]);
-          s->keys.insert(k);
-          s->buf_key[pos] = k;
+          if (s->dense_keys) s->row_in_buf[(size_t)(s->buf_row[pos] - s->row_min)] = 0;
+          else s->keys.erase(s->buf_key[pos]);
+          s->insert_key(v, j);
+          s->buf_key[pos] = vv_sampler::key(s->video_id[v], s->shot_id(v, j));
           s->buf_row[pos] = (int32_t)(base + j);
         }
       }
