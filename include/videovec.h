@@ -123,7 +123,9 @@ int vv_loss_get(vv_ctx* ctx, float* loss, float* violations);
  * the reference (single GPU). */
 int vv_grads_device(vv_ctx* ctx, void** dev_ptr, int64_t* n_floats);
 /* Make the context write its gradients into caller-owned device memory of D*F + D floats (e.g. a
- * tensor of the collective library); NULL returns to the context's own buffer. */
+ * tensor of the collective library); NULL returns to the context's own buffer.  Takes effect for the
+ * kernels launched afterwards and does not synchronise, so a host can alternate two buffers: one being
+ * all-reduced while the next iteration's gradients are written to the other. */
 int vv_grads_bind(vv_ctx* ctx, void* dev_ptr);
 /* InnerProductLayer blobs_[0]/[1] cpu_diff() after Backward (inner_product_layer.cpp:76-98). */
 int vv_grads_get(vv_ctx* ctx, float* dW, float* db);

@@ -294,6 +294,37 @@ def test_q1_same_video_negatives(vv, oracle):
     assert abs(eng.loss()[0] - got["loss"]) > 0
 
 
+def test_pipelined_trainer_single_gpu_matches_delayed_gradient_oracle(vv, oracle):
+    # the schedule bench.py uses for N > 1 (videovector_amd/dist.py PipelinedTrainer), run with world 1:
+    # gradients of iteration t+1 are taken before the update with g_t is applied
+    from videovector_amd.dist import GpuBackend, PipelinedTrainer
+    B, C, Nn, F, D = 32, 5, 4, 256, 128
+    ds, table, idx0, W, b = make_case(17, 40, B, C, Nn, F, D, wstd=0.01)
+    eng = vv.Engine(0, "f16")
+    eng.table_set(table); eng.params_set(W, b)
+    cfg = vv.StepConfig(B, C, Nn, momentum=0.9, weight_decay=5e-4)
+    tr = PipelinedTrainer(GpuBackend(eng, cfg), None, Nn, dist=None, rank=0, world=1)
+    tq = round_table(table, "f16")
+    Wo, bo, hW, hb = W.copy(), b.copy(), np.zeros_like(W), np.zeros_like(b)
+    rng = np.random.default_rng(5)
+    pending = None
+
+    def apply(r):
+        oracle.sgd_update(Wo, r["dW"], hW, 0.05, 1.0, 0.9, 5e-4, 1.0)
+        oracle.sgd_update(bo, r["db"], hb, 0.05, 2.0, 0.9, 5e-4, 0.0)
+    for it in range(5):
+        idx = rng.integers(0, ds.n_rows, size=(B, C + Nn)).astype(np.int32)
+        tr.step(0.05, idx_local=idx, global_batch=B)
+        r = oracle.forward_backward(tq, idx, round_operand(Wo, "f16"), bo, C_=C, Nn=Nn, want=("dW", "db"))
+        if pending is not None:
+            apply(pending)
+        pending = r
+    tr.flush(); apply(pending)
+    Wg, bg, hWg, _ = eng.params_get()
+    print("PIPELINED W=%.3e hW=%.3e" % (rel_fro(Wg, Wo), rel_fro(hWg, hW)))
+    assert rel_fro(Wg, Wo) <= 1e-3 and rel_fro(hWg, hW) <= 4e-3 and rel_fro(bg, bo) <= 2e-3
+
+
 def test_embed_matches_oracle(vv, oracle):
     ds, table, idx, W, b = make_case(12, 20, 4, 3, 2, 512, 96)
     eng = vv.Engine(0, "f16")

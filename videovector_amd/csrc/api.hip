@@ -531,9 +531,9 @@ int vv_grads_device(vv_ctx* c, void** dev_ptr, int64_t* n_floats) {
 int vv_grads_bind(vv_ctx* c, void* dev_ptr) {
   if (!c) return fail(VV_ERR_ARG, "vv_grads_bind: ctx is NULL");
   if (!c->grads_own) return fail(VV_ERR_STATE, "vv_grads_bind: no parameters");
-  HIPCHK(hipStreamSynchronize(c->stream));
+  // no synchronisation: kernels already queued keep the pointer they were launched with; the next
+  // vv_forward_backward writes, and the next vv_apply_update reads, the newly bound buffer
   c->grads = dev_ptr ? (float*)dev_ptr : c->grads_own;
-  c->have_fwd = false;
   return VV_OK;
 }
 

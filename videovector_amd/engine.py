@@ -38,6 +38,15 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch wheels bundle their own libamdhip64 with the same SONAME as /opt/rocm's.  Whichever is
+    # loaded first serves the whole process, and torch fails ("no ROCm-capable device") when it finds the
+    # system runtime already loaded: import torch first so streams / tensors / RCCL and this library
+    # share ONE HIP runtime.
+    if "torch" not in __import__("sys").modules and not os.environ.get("VV_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     p = lib_path()
     if not os.path.exists(p):
         raise VVError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -177,7 +186,7 @@ class Engine:
     # ---- iteration
     def forward_backward(self, cfg, idx=None, idx_dev_ptr=None):
         if idx_dev_ptr is not None:
-            self._chk(self.L.vv_forward_backward(self.h, C.byref(cfg.c), C.c_void_p(idx_dev_ptr), 1))
+            self._chk(self.L.vv_forward_backward(self.h, C.byref(cfg.c), C.c_void_p(int(idx_dev_ptr)), 1))
         else:
             idx = np.ascontiguousarray(idx, dtype=np.int32)
             assert idx.shape == (cfg.c.B, cfg.c.C + cfg.c.Nn)
