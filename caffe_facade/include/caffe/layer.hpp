@@ -84,7 +84,11 @@ struct VideoDataset {
   int win_k = 0;
   vector<int32_t> win_rows, win_video_id;
   bool SameTable(const VideoDataset& o) const { return synthetic && o.synthetic && seed == o.seed && n_rows == o.n_rows && F == o.F; }
-  static shared_ptr<VideoDataset> Open(const string& source);
+  int win_pos = 0, win_neg = 0;    // positive / negative shot words per DB test record (not consumed)
+  enum Kind { kShots, kTestWindows };
+  static shared_ptr<VideoDataset> Open(const string& source, Kind kind = kShots, const string& backend = "LMDB");
+  static shared_ptr<VideoDataset> OpenLmdbVideoShots(const string& source);
+  static shared_ptr<VideoDataset> OpenLmdbTestWindows(const string& source);
   void UploadTable(vv_ctx* ctx) const;   // vv_table_synth / vv_table_set
 };
 

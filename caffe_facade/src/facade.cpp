@@ -6,6 +6,9 @@
 #include <cstdio>
 #include <cstring>
 #include <ctime>
+#include <sys/stat.h>
+#include "caffe/lmdb_reader.hpp"
+
 #include <fstream>
 #include <random>
 
@@ -165,11 +168,119 @@ static uint64_t mix64(uint64_t seed, uint64_t x) {     // == videovector_amd/syn
 }
 
 // `source:` forms understood here (the reference opens an LMDB of VideoShots records,
-// video_sampled_shots_data_layer.cpp:121-135; an LMDB reader is not built yet):
+// video_sampled_shots_data_layer.cpp:121-135):
+//   <directory>  : LMDB environment (backend: LMDB) of VideoShots / TestVideoShotWindows records
 //   synthetic://videos=2048;seed=1701;features=4096[;lo=16;span=49]
 //   <file>.vvds : "VVDS1\0\0\0", int32 n_videos, int32 F, per video {int32 video_id, int32 n_shots,
 //                 int32 shot_ids[n_shots]}, then float32 features[total_shots][F]
-shared_ptr<VideoDataset> VideoDataset::Open(const string& source) {
+// ---- protobuf wire decoding of the DB records (generic pl::Message parsing would box every float) ----
+namespace {
+struct Wire {
+  const uint8_t* p; const uint8_t* e; bool ok = true;
+  Wire(const void* d, size_t n) : p((const uint8_t*)d), e((const uint8_t*)d + n) {}
+  bool more() const { return ok && p < e; }
+  uint64_t varint() {
+    uint64_t v = 0; int sh = 0;
+    while (p < e && sh < 64) { const uint8_t b = *p++; v |= (uint64_t)(b & 0x7F) << sh; if (!(b & 0x80)) return v; sh += 7; }
+    ok = false; return 0;
+  }
+  Wire sub() { const uint64_t n = varint(); if (!ok || n > (uint64_t)(e - p)) { ok = false; return Wire(p, 0); } Wire w(p, (size_t)n); p += n; return w; }
+  void skip(int wt) {
+    if (wt == 0) varint(); else if (wt == 1) { if (e - p < 8) ok = false; else p += 8; }
+    else if (wt == 2) sub(); else if (wt == 5) { if (e - p < 4) ok = false; else p += 4; } else ok = false;
+  }
+};
+// caffe.Datum (src/caffe/proto/caffe.proto:23-37): only float_data (field 6, repeated float, packed or not) matters
+void ParseDatumFloats(Wire w, vector<float>* out, bool* ok) {
+  while (w.more()) {
+    const uint64_t tag = w.varint(); const int fn = (int)(tag >> 3), wt = (int)(tag & 7);
+    if (fn == 6 && wt == 5) { if (w.e - w.p < 4) { w.ok = false; break; } float v; memcpy(&v, w.p, 4); w.p += 4; out->push_back(v); }
+    else if (fn == 6 && wt == 2) { Wire s = w.sub(); const size_t n = (size_t)(s.e - s.p) / 4, o = out->size(); out->resize(o + n); memcpy(out->data() + o, s.p, 4 * n); }
+    else w.skip(wt);
+  }
+  if (!w.ok) *ok = false;
+}
+void ParseInt32s(Wire& w, int wt, vector<int32_t>* out) {        // repeated int32, packed or not
+  if (wt == 0) out->push_back((int32_t)w.varint());
+  else if (wt == 2) { Wire s = w.sub(); while (s.more()) out->push_back((int32_t)s.varint()); if (!s.ok) w.ok = false; }
+  else w.skip(wt);
+}
+}  // namespace
+
+// VideoShots records (video_shot_sentences.proto:14-19), read in key order like the reference's cursor
+// (video_sampled_shots_data_layer.cpp:121-135, 285-293): one video per record
+shared_ptr<VideoDataset> VideoDataset::OpenLmdbVideoShots(const string& source) {
+  shared_ptr<VideoDataset> ds(new VideoDataset());
+  LmdbReader db; string err;
+  CHECK(db.Open(source, &err)) << err;
+  LOG(INFO) << "Opening lmdb " << source;
+  bool ok = true;
+  vector<float> feat;
+  CHECK(db.ForEach([&](const string& key, const string& val) {
+    Wire w(val.data(), val.size());
+    int32_t vid = 0; vector<int32_t> ids; int n = 0;
+    while (w.more()) {
+      const uint64_t tag = w.varint(); const int fn = (int)(tag >> 3), wt = (int)(tag & 7);
+      if (fn == 1 && wt == 0) vid = (int32_t)w.varint();
+      else if (fn == 2) ParseInt32s(w, wt, &ids);
+      else if (fn == 3 && wt == 2) {
+        feat.clear(); ParseDatumFloats(w.sub(), &feat, &ok);
+        if (ds->F == 0) ds->F = (int)feat.size();
+        CHECK_EQ((int)feat.size(), ds->F) << "record " << key << ": shot word with " << feat.size() << " features";
+        ds->features.insert(ds->features.end(), feat.begin(), feat.end());
+        ++n;
+      } else w.skip(wt);
+    }
+    CHECK(w.ok && ok) << "record " << key << " is not a valid VideoShots message";
+    CHECK_GE(n, 1) << "No shot word found: " << vid;
+    CHECK_EQ((int)ids.size(), n) << "record " << key << ": shot_ids / shot_words size mismatch";
+    ds->video_id.push_back(vid); ds->n_shots.push_back(n); ds->row_base.push_back(ds->n_rows);
+    ds->shot_ids.insert(ds->shot_ids.end(), ids.begin(), ids.end());
+    ds->n_rows += n;
+  }, &err)) << err;
+  CHECK_GE(ds->video_id.size(), 1u) << "empty database " << source;
+  LOG(INFO) << "Read " << ds->video_id.size() << " videos, " << ds->n_rows << " frames, " << ds->F << " features";
+  return ds;
+}
+
+// TestVideoShotWindows records (video_shot_sentences.proto:22-30; video_shot_window_test_data_layer.cpp:153-235):
+// each record's context words become consecutive table rows
+shared_ptr<VideoDataset> VideoDataset::OpenLmdbTestWindows(const string& source) {
+  shared_ptr<VideoDataset> ds(new VideoDataset());
+  LmdbReader db; string err;
+  CHECK(db.Open(source, &err)) << err;
+  LOG(INFO) << "Opening lmdb " << source;
+  bool ok = true;
+  vector<float> feat;
+  CHECK(db.ForEach([&](const string& key, const string& val) {
+    Wire w(val.data(), val.size());
+    bool has_vid = false; int32_t vid = 0; int k = 0, npos = 0, nneg = 0;
+    while (w.more()) {
+      const uint64_t tag = w.varint(); const int fn = (int)(tag >> 3), wt = (int)(tag & 7);
+      if (fn == 1 && wt == 0) { vid = (int32_t)w.varint(); has_vid = true; }
+      else if (fn == 5 && wt == 2) {
+        feat.clear(); ParseDatumFloats(w.sub(), &feat, &ok);
+        if (ds->F == 0) ds->F = (int)feat.size();
+        CHECK_EQ((int)feat.size(), ds->F) << "record " << key << ": context word with " << feat.size() << " features";
+        ds->features.insert(ds->features.end(), feat.begin(), feat.end());
+        ds->win_rows.push_back((int32_t)ds->n_rows++);
+        ++k;
+      } else if (fn == 4 && wt == 2) { ++npos; w.skip(wt); }
+      else if (fn == 6 && wt == 2) { ++nneg; w.skip(wt); }
+      else w.skip(wt);
+    }
+    CHECK(w.ok && ok) << "record " << key << " is not a valid TestVideoShotWindows message";
+    CHECK(has_vid) << "No video id found for shot window";                          // …test_data_layer.cpp:188
+    if (ds->win_k == 0) { ds->win_k = k; ds->win_pos = npos; ds->win_neg = nneg; }
+    CHECK_EQ(k, ds->win_k);                                                         // …:193
+    ds->win_video_id.push_back(vid);
+  }, &err)) << err;
+  CHECK_GE(ds->win_video_id.size(), 1u) << "empty database " << source;
+  LOG(INFO) << "Read " << ds->win_video_id.size() << " test windows of " << ds->win_k << " context frames, " << ds->F << " features";
+  return ds;
+}
+
+shared_ptr<VideoDataset> VideoDataset::Open(const string& source, Kind kind, const string& backend) {
   shared_ptr<VideoDataset> ds(new VideoDataset());
   const string syn = "synthetic://";
   if (source.compare(0, syn.size(), syn) == 0) {
@@ -215,7 +326,7 @@ shared_ptr<VideoDataset> VideoDataset::Open(const string& source) {
       p = e + 1;
     }
     if (base.back() == ';') base.pop_back();
-    ds = Open(base);
+    ds = Open(base, kShots, backend);
     ds->win_k = (int)context;
     for (long w = 0; w < windows; ++w) {
       const int v = (int)(mix64((uint64_t)wseed, (uint64_t)w) % ds->video_id.size());
@@ -226,9 +337,14 @@ shared_ptr<VideoDataset> VideoDataset::Open(const string& source) {
     }
     return ds;
   }
+  struct stat st;
+  if (stat(source.c_str(), &st) == 0 && S_ISDIR(st.st_mode)) {
+    CHECK(backend == "LMDB") << "source " << source << " is a database directory with backend " << backend
+                             << ": only LMDB databases are readable (LevelDB is not built)";
+    return kind == kTestWindows ? OpenLmdbTestWindows(source) : OpenLmdbVideoShots(source);
+  }
   std::ifstream f(source, std::ios::binary);
-  CHECK(f.good()) << "Failed to open dataset " << source << " (LMDB / LevelDB sources need the LMDB reader, which is "
-                  << "not built yet; use synthetic://... or a .vvds file)";
+  CHECK(f.good()) << "Failed to open dataset " << source;
   char magic[8]; f.read(magic, 8);
   CHECK(!memcmp(magic, "VVDS1\0\0\0", 8)) << source << " is not a .vvds dataset";
   int32_t nv = 0, F = 0; f.read((char*)&nv, 4); f.read((char*)&F, 4);
@@ -276,7 +392,7 @@ void VideoSampledShotsDataLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>&, 
   CHECK(p.get_str("negative_dataset").empty()) << "negative_dataset is not supported";
   CHECK(!p.get_bool("output_shot_distance")) << "output_shot_distance is PAIRWISE-only";
   CHECK_EQ(p.get_int("rand_skip"), 0) << "rand_skip is not supported";
-  dataset_ = VideoDataset::Open(p.get_str("source"));
+  dataset_ = VideoDataset::Open(p.get_str("source"), VideoDataset::kShots, p.get_enum("backend"));
   vv_sampler_param sp;
   vv_sampler_param_default(&sp);
   sp.batch_size = batch_size_ = (int)p.get_int("batch_size");
@@ -308,7 +424,9 @@ template class VideoSampledShotsDataLayer<float>;
 template <typename Dtype>
 void VideoShotWindowTestDataLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>&, vector<Blob<Dtype>*>* top) {
   const pl::Message& p = this->layer_param_.get_msg("video_shot_window_test_data_param");
-  dataset_ = VideoDataset::Open(p.get_str("source"));
+  dataset_ = VideoDataset::Open(p.get_str("source"), VideoDataset::kTestWindows, p.get_enum("backend"));
+  CHECK(!(p.get_bool("include_positives") && dataset_->win_pos) && !(p.get_bool("include_negatives") && dataset_->win_neg))
+      << "test windows with positive / negative shot words are not built (set include_positives / include_negatives to false)";
   CHECK_GE(dataset_->win_k, 1) << "source " << p.get_str("source") << " holds no test windows";   // …test_data_layer.cpp:121
   batch_size_ = (int)p.get_int("batch_size");
   CHECK_GE(batch_size_, 1);
