@@ -41,6 +41,15 @@ const char* vv_version(void);
  * The reference has only the default CUDA stream. */
 int vv_set_stream(vv_ctx* ctx, void* hip_stream);
 int vv_synchronize(vv_ctx* ctx);
+/* Row de-duplication (default on; also VV_DEDUP=0/1 in the environment).  The reference sampler draws
+ * every item's negatives from one shared buffer (video_sampled_shots_data_layer.cpp:836-875), so the
+ * (C+Nn)*B rows of a batch repeat table rows.  With de-duplication the fc projection
+ * (InnerProductLayer::Forward, inner_product_layer.cu:12-27) runs once per distinct row and the gradient rows of
+ * a row's instances are summed before the weight-gradient product (inner_product_layer.cu:36-42): the same
+ * sums, reassociated.  Steps with dropout always take the dense path.  vv_dedup_stats reports the rows of
+ * the last forward/backward pass and how many were distinct (rows == unique_rows on the dense path). */
+int vv_set_dedup(vv_ctx* ctx, int on);
+int vv_dedup_stats(vv_ctx* ctx, int64_t* rows, int64_t* unique_rows);
 
 /* ---- feature table: stands for the rows the data layer copies out of the VideoShots DB
  * (VideoSampledShotsDataLayer::AddSamplesToTop, src/caffe/layers/video_sampled_shots_data_layer.cpp:

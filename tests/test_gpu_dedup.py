@@ -1,0 +1,105 @@
+"""GPU tests of the row de-duplication path (videovector_amd/csrc/kernels_dedup.hip): the projection runs
+once per distinct table row of the batch and the instances' gradient rows are summed before the
+weight-gradient GEMM.  Checked against the dense path of the same library (bit-exact where the arithmetic
+is the same, tight where a sum is reassociated) and against the oracle."""
+import numpy as np
+import pytest
+
+from tests.test_gpu_parity import TOL, check, make_case, rel_fro, round_operand, round_table, run_both, vv  # noqa: F401
+from videovector_amd.synth import SyntheticVideos, init_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def run_mode(vv, prec, table, idx, W, b, C, Nn, dedup, **kw):
+    eng = vv.Engine(0, prec)
+    eng.set_dedup(dedup)
+    eng.table_set(table)
+    eng.params_set(W, b)
+    cfg = vv.StepConfig(idx.shape[0], C, Nn, **kw)
+    eng.forward_backward(cfg, idx)
+    out = dict(loss=eng.loss(), stats=eng.dedup_stats(), **eng.blobs(cfg, ip1_diff=True))
+    out["dW"], out["db"] = eng.grads()
+    return eng, cfg, out
+
+
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+def test_dedup_equals_dense_on_a_heavily_repeated_batch(vv, oracle, prec):
+    B, C, Nn, F, D = 96, 5, 20, 384, 320
+    ds, table, idx, W, b = make_case(21, 6, B, C, Nn, F, D, wstd=0.02)      # ~240 table rows, 2400 batch rows
+    idx[3, 2] = -1; idx[17, 9] = -1                                         # empty slots de-duplicate too
+    _, _, dn = run_mode(vv, prec, table, idx, W, b, C, Nn, False)
+    _, _, dd = run_mode(vv, prec, table, idx, W, b, C, Nn, True)
+    n_unique = len(np.unique(idx))
+    assert dn["stats"] == (B * (C + Nn), B * (C + Nn))
+    assert dd["stats"] == (B * (C + Nn), n_unique) and n_unique < 300
+    # same arithmetic, shared: embeddings, scores, loss and per-instance gradients are bit-identical
+    for k in ("ip2", "target_score", "negative_scores", "ip1_diff", "db"):
+        assert np.array_equal(dn[k], dd[k]), k
+    assert dn["loss"] == dd["loss"]
+    # dW: the sum over instances is taken before the 16-bit rounding and the GEMM instead of inside it
+    assert rel_fro(dd["dW"], dn["dW"]) <= (5e-4 if prec == "f16" else 4e-3)
+    # and against the oracle, like every other parity case
+    eng, cfg, got, ref = run_both(vv, oracle, prec, table, idx, W, b, C, Nn)
+    assert eng.dedup_stats()[1] == n_unique
+    check(got, ref, TOL[prec], "dedup-" + prec)
+
+
+def test_dedup_degenerate_batches(vv, oracle):
+    B, C, Nn, F, D = 40, 3, 6, 256, 64
+    ds, table, idx, W, b = make_case(5, 30, B, C, Nn, F, D, wstd=0.05)
+    # (a) every slot names the same row: one segment holding all B*(C+Nn) instances
+    same = np.full_like(idx, 7)
+    _, _, dn = run_mode(vv, "f16", table, same, W, b, C, Nn, False)
+    _, _, dd = run_mode(vv, "f16", table, same, W, b, C, Nn, True)
+    assert dd["stats"] == (B * (C + Nn), 1)
+    assert np.array_equal(dn["ip2"], dd["ip2"]) and dn["loss"] == dd["loss"]
+    assert np.allclose(dd["dW"], dn["dW"], rtol=0, atol=2e-3 * np.abs(dn["dW"]).max() + 1e-12)
+    # (b) no repeats at all: identity mapping
+    uniq = np.arange(B * (C + Nn), dtype=np.int32).reshape(B, C + Nn) % len(table)
+    _, _, dn = run_mode(vv, "f16", table, uniq, W, b, C, Nn, False)
+    _, _, dd = run_mode(vv, "f16", table, uniq, W, b, C, Nn, True)
+    assert dd["stats"][1] == len(np.unique(uniq))
+    assert np.array_equal(dn["ip2"], dd["ip2"]) and rel_fro(dd["dW"], dn["dW"]) <= 5e-4
+
+
+def test_dedup_is_deterministic_and_survives_shape_changes(vv):
+    F, D = 512, 128
+    ds = SyntheticVideos(seed=4, n_videos=12)
+    table = ds.table(F)
+    W, b = init_weights(9, D, F, std=0.02)
+    eng = vv.Engine(0, "f16")
+    eng.table_set(table); eng.params_set(W, b)
+    seen = {}
+    for rep in range(3):
+        for (B, C, Nn) in [(64, 5, 12), (33, 3, 7), (64, 5, 12)]:
+            idx = np.random.default_rng(B + rep * 0).integers(0, ds.n_rows, size=(B, C + Nn)).astype(np.int32)
+            cfg = vv.StepConfig(B, C, Nn)
+            eng.forward_backward(cfg, idx)
+            dW = eng.grads()[0].copy()
+            key = (B, C, Nn)
+            if key in seen:
+                assert np.array_equal(seen[key], dW), key       # f64 segment sums: arrival order cannot matter
+            seen[key] = dW
+
+
+def test_dedup_sgd_trajectory_matches_dense(vv):
+    B, C, Nn, F, D = 128, 5, 10, 512, 256
+    ds = SyntheticVideos(seed=1701, n_videos=30)
+    table = ds.table(F)
+    W, b = init_weights(3, D, F, std=0.02)
+    rng = np.random.default_rng(0)
+    batches = [rng.integers(0, ds.n_rows, size=(B, C + Nn)).astype(np.int32) for _ in range(10)]
+    res = []
+    for mode in (False, True):
+        eng = vv.Engine(0, "f16")
+        eng.set_dedup(mode)
+        eng.table_set(table); eng.params_set(W, b)
+        cfg = vv.StepConfig(B, C, Nn, lr=0.01)
+        losses = []
+        for idx in batches:
+            eng.step(cfg, idx)
+            losses.append(eng.loss()[0])
+        res.append((np.array(losses), eng.params_get()[0]))
+    assert np.allclose(res[0][0], res[1][0], rtol=2e-5)
+    assert rel_fro(res[1][1], res[0][1]) <= 5e-4

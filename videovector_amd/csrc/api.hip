@@ -15,7 +15,7 @@
 
 #include "vv_internal.h"
 
-namespace vv { void set_wgrad_tr(bool on); void set_gemm_variant(int v); void set_ablate(int v); void set_fwd_mi(int v); void set_score_reg(int v); void set_wgrad_sched(int v); int wgrad_max_ksteps_per_split(); }
+namespace vv { void set_wgrad_tr(bool on); void set_gemm_variant(int v); void set_ablate(int v); void set_fwd_mi(int v); void set_score_reg(int v); void set_wgrad_sched(int v); int wgrad_max_ksteps_per_split(); int gemm_variant(); bool ablate_on(); }
 using namespace vv;
 
 static thread_local char g_err[512] = "";
@@ -61,6 +61,16 @@ struct vv_ctx {
   float sg = 1.f; float last_loss_weight = 1.f;
   uint64_t iter = 0;
   bool have_fwd = false;
+  // row de-duplication (kernels_dedup.hip)
+  int dedup = 1;                    // 1 = on whenever dropout is off (VV_DEDUP / vv_set_dedup)
+  bool last_dedup = false;          // what the last forward/backward pass used
+  unsigned long long* dd_key = nullptr; int64_t dd_key_cap = 0;
+  unsigned long long* dd_agg = nullptr; int dd_agg_stride = 0;
+  int32_t *dd_slot_of = nullptr, *dd_uniq = nullptr, *dd_map = nullptr, *dd_ord = nullptr, *dd_cnt = nullptr,
+          *dd_seg = nullptr, *dd_pos = nullptr, *dd_info = nullptr;
+  uint16_t* dYu = nullptr;
+  int32_t* U_host = nullptr;        // pinned; refreshed by an async copy every step, read one step late
+  uint32_t dd_epoch = 0;
   // profiling
   bool prof = false;
   std::map<std::string, ProfEntry> prof_map;
@@ -139,6 +149,12 @@ int vv_create(int device, int prec, vv_ctx** out) {
   set_score_reg(sr ? atoi(sr) : 1);
   const char* ws = getenv("VV_WGRAD_SCHED");
   set_wgrad_sched(ws ? atoi(ws) : 0);
+  const char* dd = getenv("VV_DEDUP");
+  if (dd) c->dedup = atoi(dd) != 0;
+  HIPCHK(hipMalloc(&c->dd_info, 4 * sizeof(int32_t)));
+  HIPCHK(hipMemset(c->dd_info, 0, 4 * sizeof(int32_t)));
+  HIPCHK(hipHostMalloc((void**)&c->U_host, sizeof(int32_t), hipHostMallocDefault));
+  *c->U_host = 0;
   *out = c;
   return VV_OK;
 }
@@ -147,6 +163,10 @@ static void free_batch(vv_ctx* c) {
   dfree(c->idx_dev); dfree(c->rows); dfree(c->H); dfree(c->dYh); dfree(c->dbp);
   dfree(c->loss_part); dfree(c->viol_part); dfree(c->s_true); dfree(c->s_bogus);
   dfree(c->coeff); dfree(c->slabs);
+  dfree(c->dd_agg); dfree(c->dd_slot_of); dfree(c->dd_uniq); dfree(c->dd_map); dfree(c->dd_ord); dfree(c->dd_cnt);
+  dfree(c->dd_seg); dfree(c->dd_pos); dfree(c->dYu);
+  c->dd_agg = nullptr; c->dd_slot_of = c->dd_uniq = c->dd_map = c->dd_ord = c->dd_cnt = c->dd_seg = c->dd_pos = nullptr;
+  c->dYu = nullptr;
   c->idx_dev = c->rows = nullptr; c->H = nullptr; c->dYh = nullptr; c->dbp = nullptr;
   c->loss_part = c->viol_part = c->s_true = c->s_bogus = c->coeff = nullptr; c->slabs = nullptr;
   c->slab_bytes = 0; c->B = c->C = c->Nn = c->R = c->Rp = 0; c->coeff_host.clear();
@@ -160,10 +180,30 @@ int vv_destroy(vv_ctx* c) {
   free_batch(c);
   dfree(c->table); dfree(c->patch_desc); dfree(c->W); dfree(c->b); dfree(c->hW); dfree(c->hb); dfree(c->Wh);
   dfree(c->scales); dfree(c->wmax_blocks); dfree(c->grads_own); dfree(c->mask); dfree(c->loss2);
+  dfree(c->dd_key); dfree(c->dd_info);
+  if (c->U_host) (void)hipHostFree(c->U_host);
   for (auto& kv : c->prof_map)
     for (auto& e : kv.second.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
+  return VV_OK;
+}
+
+int vv_set_dedup(vv_ctx* c, int on) {
+  if (!c) return fail(VV_ERR_ARG, "vv_set_dedup: ctx is NULL");
+  c->dedup = on != 0;
+  return VV_OK;
+}
+
+int vv_dedup_stats(vv_ctx* c, int64_t* rows, int64_t* unique_rows) {
+  if (!c) return fail(VV_ERR_ARG, "vv_dedup_stats: ctx is NULL");
+  if (!c->have_fwd) return fail(VV_ERR_STATE, "vv_dedup_stats: no forward pass yet");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  int32_t U = c->R;
+  if (c->last_dedup) HIPCHK(hipMemcpy(&U, c->dd_info, sizeof(U), hipMemcpyDeviceToHost));
+  if (rows) *rows = c->R;
+  if (unique_rows) *unique_rows = U;
   return VV_OK;
 }
 
@@ -347,6 +387,20 @@ static int ensure_batch(vv_ctx* c, int B, int C, int Nn) {
   c->S = S; c->kps = (total_steps + S - 1) / S;
   c->slab_bytes = (size_t)S * c->Dp * c->Fp * 4;
   HIPCHK(hipMalloc(&c->slabs, c->slab_bytes));
+  // de-duplication work arrays
+  c->dd_agg_stride = c->R / 1024 + 2;
+  HIPCHK(hipMalloc(&c->dd_agg, (size_t)2 * c->dd_agg_stride * sizeof(unsigned long long)));
+  HIPCHK(hipMemset(c->dd_agg, 0, (size_t)2 * c->dd_agg_stride * sizeof(unsigned long long)));
+  HIPCHK(hipMalloc(&c->dd_slot_of, (size_t)c->Rp * 4));
+  HIPCHK(hipMalloc(&c->dd_uniq, (size_t)c->Rp * 4));
+  HIPCHK(hipMalloc(&c->dd_map, (size_t)c->Rp * 4));
+  HIPCHK(hipMalloc(&c->dd_ord, (size_t)c->Rp * 4));
+  HIPCHK(hipMalloc(&c->dd_cnt, (size_t)c->Rp * 4));
+  HIPCHK(hipMalloc(&c->dd_seg, (size_t)(c->Rp + 1) * 4));
+  HIPCHK(hipMalloc(&c->dd_pos, (size_t)c->Rp * 4));
+  HIPCHK(hipMalloc(&c->dYu, (size_t)c->Rp * c->Dp * 2));
+  HIPCHK(hipMemset(c->dYu, 0, (size_t)c->Rp * c->Dp * 2));
+  *c->U_host = 0;
   return VV_OK;
 }
 
@@ -394,9 +448,38 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
     HIPCHK(hipMemcpyAsync(c->mask, cfg->dropout_mask, nb, hipMemcpyHostToDevice, s));
   }
 
+  // De-duplicate the batch rows when dropout is off (with dropout every instance has its own mask on
+  // top of the shared projection; that path stays dense).  Needs the default two-buffer GEMM kernels.
+  const bool dd = c->dedup && cfg->dropout_ratio == 0.f && (gemm_variant() == 0 || gemm_variant() == 3) && !ablate_on();
+  c->last_dedup = dd;
+  if (dd) {
+    const int64_t need = c->n_rows + 1 + c->patch_cap;
+    if (need > c->dd_key_cap) {
+      HIPCHK(hipStreamSynchronize(s));
+      dfree(c->dd_key); c->dd_key = nullptr;
+      HIPCHK(hipMalloc(&c->dd_key, (size_t)need * sizeof(unsigned long long)));
+      HIPCHK(hipMemsetAsync(c->dd_key, 0, (size_t)need * sizeof(unsigned long long), s));
+      c->dd_key_cap = need;
+    }
+    if (++c->dd_epoch == 0) {        // epoch tags wrapped: start over with clean tag words
+      HIPCHK(hipMemsetAsync(c->dd_key, 0, (size_t)c->dd_key_cap * sizeof(unsigned long long), s));
+      HIPCHK(hipMemsetAsync(c->dd_agg, 0, (size_t)2 * c->dd_agg_stride * sizeof(unsigned long long), s));
+      c->dd_epoch = 1;
+    }
+    DedupArgs da;
+    da.rows = c->rows; da.key = c->dd_key; da.agg = c->dd_agg; da.agg_stride = c->dd_agg_stride;
+    da.slot_of = c->dd_slot_of; da.uniq_rows = c->dd_uniq; da.map = c->dd_map; da.ord = c->dd_ord; da.cnt = c->dd_cnt;
+    da.seg_start = c->dd_seg; da.pos = c->dd_pos; da.info = c->dd_info;
+    da.R = c->R; da.Rp = c->Rp; da.zero_row = (int32_t)c->n_rows; da.epoch = c->dd_epoch;
+    PROFILED(c, "dedup", launch_dedup(da, s));
+  }
+
   FwdArgs fa;
-  fa.table = c->table; fa.rows = c->rows; fa.Wh = c->Wh; fa.bias = c->b; fa.scales = c->scales;
+  fa.table = c->table; fa.rows = dd ? c->dd_uniq : c->rows; fa.Wh = c->Wh; fa.bias = c->b; fa.scales = c->scales;
   fa.H = c->H; fa.R = c->R; fa.D = D; fa.Fp = c->Fp; fa.relu = 1; fa.zero_row = (int32_t)c->n_rows;
+  fa.n_dev = dd ? c->dd_info : nullptr;
+  fa.R_hint = dd ? *(volatile int32_t*)c->U_host : 0;
+  if (dd) HIPCHK(hipMemcpyAsync(c->U_host, c->dd_info, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   fa.drop_ratio = cfg->dropout_ratio;
   fa.mask = (cfg->dropout_ratio > 0.f && cfg->dropout_mask) ? c->mask : nullptr;
   fa.drop_seed = cfg->dropout_seed * 0x9E3779B97F4A7C15ull + c->iter;
@@ -418,12 +501,19 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   sa.grad_scale = cfg->loss_weight / (float)gcount;
   sa.drop_scale = cfg->dropout_ratio > 0.f ? 1.f / (1.f - cfg->dropout_ratio) : 1.f;
   sa.sg = c->sg;
+  sa.map = dd ? c->dd_map : nullptr; sa.pos = dd ? c->dd_pos : nullptr;
   PROFILED(c, "score_loss", launch_score_loss(c->prec, sa, s));
   launch_final_loss(c->loss_part, c->viol_part, B, cfg->loss_weight / (float)count, c->loss2, s);
 
+  if (dd) {
+    SegsumArgs ga;
+    ga.dYh = c->dYh; ga.seg_start = c->dd_seg; ga.info = c->dd_info; ga.dYu = c->dYu; ga.Rp = c->Rp; ga.Dp = c->Dp;
+    PROFILED(c, "segsum", launch_segsum(c->prec, ga, s));
+  }
   WgradArgs wa;
-  wa.dYh = c->dYh; wa.table = c->table; wa.rows = c->rows; wa.slabs = c->slabs;
+  wa.dYh = dd ? c->dYu : c->dYh; wa.table = c->table; wa.rows = dd ? c->dd_uniq : c->rows; wa.slabs = c->slabs;
   wa.Rp = c->Rp; wa.Dp = c->Dp; wa.Fp = c->Fp; wa.S = c->S; wa.ksteps_per_split = c->kps;
+  wa.n_dev = dd ? c->dd_info : nullptr;
   PROFILED(c, "wgrad_gemm", launch_wgrad_gemm(c->prec, wa, s));
 
   ReduceArgs ra;
@@ -562,7 +652,16 @@ int vv_blobs_get(vv_ctx* c, float* ip2, float* target_score, float* negative_sco
   };
   if (ip2) {
     std::vector<float> tmp(n);
-    HIPCHK(hipMemcpy(tmp.data(), c->H, n * 4, hipMemcpyDeviceToHost));
+    if (c->last_dedup) {               // expand the per-slot rows back to one row per instance
+      float* d = nullptr;
+      HIPCHK(hipMalloc(&d, n * 4));
+      launch_gather_rows_f32(c->H, c->dd_map, c->R, D, d, c->stream);
+      HIPCHK(hipStreamSynchronize(c->stream));
+      HIPCHK(hipMemcpy(tmp.data(), d, n * 4, hipMemcpyDeviceToHost));
+      dfree(d);
+    } else {
+      HIPCHK(hipMemcpy(tmp.data(), c->H, n * 4, hipMemcpyDeviceToHost));
+    }
     reorder(tmp, ip2);
   }
   if (target_score) {
@@ -574,8 +673,14 @@ int vv_blobs_get(vv_ctx* c, float* ip2, float* target_score, float* negative_sco
   if (ip1_diff) {
     float* d = nullptr;
     HIPCHK(hipMalloc(&d, n * 4));
-    launch_dyh_to_float(c->prec, c->dYh, c->R, D, c->Dp, 1.f / c->sg, d, c->stream);
+    uint16_t* ungrouped = nullptr;
+    if (c->last_dedup) {
+      HIPCHK(hipMalloc(&ungrouped, (size_t)c->R * c->Dp * 2));
+      launch_gather_rows_u16(c->dYh, c->dd_pos, c->R, c->Dp, ungrouped, c->stream);
+    }
+    launch_dyh_to_float(c->prec, ungrouped ? ungrouped : c->dYh, c->R, D, c->Dp, 1.f / c->sg, d, c->stream);
     HIPCHK(hipStreamSynchronize(c->stream));
+    dfree(ungrouped);
     std::vector<float> tmp(n);
     HIPCHK(hipMemcpy(tmp.data(), d, n * 4, hipMemcpyDeviceToHost));
     dfree(d);

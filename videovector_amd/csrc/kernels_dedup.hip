@@ -1,0 +1,192 @@
+// kernels_dedup.hip -- row de-duplication of one batch (gfx950 only).
+//
+// Why: VideoSampledShotsDataLayer draws the Nn negatives of every batch item from ONE shared ring
+// buffer of at most max_buffer_size frames (video_sampled_shots_data_layer.cpp:836-875), so the
+// (C+Nn)*B rows of a batch name far fewer distinct frames (cfg 2: 56 320 rows, ~20 700 distinct).
+// The reference copies every repeat and multiplies it again.  Here the fc projection runs once per
+// distinct table row, every instance reads the shared output row, and the gradient rows of the
+// instances are summed per distinct row before the weight-gradient GEMM:
+//     dW = sum_r dY[r]^T X[row(r)] = sum_u (sum_{r -> u} dY[r])^T X[u].
+// Same results (the projection of equal inputs is equal; the gradient sum is reassociated).
+//
+//   k_dd_claim    : leader election, atomicMax of (epoch, ~r) per table row -> the smallest instance
+//                   index of every distinct row wins; epoch tags make a reset pass unnecessary.
+//   k_dd_leaders  : slot = rank of the leader among leaders (single-pass scan: every block publishes
+//                   its count as an epoch-tagged word, later blocks sum the words of earlier ones).
+//                   Slots are ordered by first appearance, so the order is deterministic.
+//   k_dd_map      : instance -> slot, per-slot instance count, arrival order inside the slot.
+//   k_dd_segstart : exclusive scan of the counts (same single-pass scan).
+//   k_dd_pos      : instance -> row of the grouped gradient buffer.
+//   k_segsum      : per slot, sum of its instances' 16-bit gradient rows.  f16: accumulated in f64,
+//                   which is EXACT for up to 2^13 f16 addends, so the arrival order (atomics) cannot
+//                   change the result.  bf16: f64 as well (order-independent unless the addends span
+//                   more than ~40 binades).
+#include "vv_internal.h"
+
+namespace vv {
+
+constexpr int DD_BLOCK = 1024;
+
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(256) void k_dd_claim(DedupArgs a) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r < a.Rp) { a.uniq_rows[r] = a.zero_row; a.cnt[r] = 0; }
+  if (r < a.R)
+    atomicMax(&a.key[a.rows[r]], ((unsigned long long)a.epoch << 32) | (0xFFFFFFFFu - (unsigned)r));
+}
+
+// exclusive block scan of one int per thread (DD_BLOCK threads); returns the prefix, *total = block sum
+__device__ __forceinline__ int block_excl_scan(int v, int* total, int* sm /* >= 17 ints */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+  if (lane == 63) sm[wave] = inc;
+  __syncthreads();
+  if (wave == 0) {
+    int w = lane < DD_BLOCK / 64 ? sm[lane] : 0;
+    int winc = w;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { const int t = __shfl_up(winc, o, 64); if (lane >= o) winc += t; }
+    if (lane < DD_BLOCK / 64) sm[lane] = winc - w;
+    if (lane == DD_BLOCK / 64 - 1) sm[16] = winc;
+  }
+  __syncthreads();
+  const int res = sm[wave] + inc - v;
+  *total = sm[16];
+  __syncthreads();
+  return res;
+}
+
+// sum of the aggregates of blocks [0, blockIdx.x): spin on each word until it carries this epoch.
+// Blocks are dispatched in index order, so every block waited on is resident or finished.
+__device__ __forceinline__ int lookback_sum(const unsigned long long* agg, unsigned epoch, int* sm) {
+  int s = 0;
+  for (int j = threadIdx.x; j < (int)blockIdx.x; j += DD_BLOCK) {
+    unsigned long long w;
+    do { w = ld_agent(agg + j); } while ((unsigned)(w >> 32) != epoch);
+    s += (int)(unsigned)w;
+  }
+  int tot;
+  block_excl_scan(s, &tot, sm);
+  return tot;
+}
+
+__global__ __launch_bounds__(DD_BLOCK) void k_dd_leaders(DedupArgs a) {
+  __shared__ int sm[20];
+  const int r = blockIdx.x * DD_BLOCK + threadIdx.x;
+  int row = 0, flag = 0;
+  if (r < a.R) {
+    row = a.rows[r];
+    flag = (unsigned)a.key[row] == 0xFFFFFFFFu - (unsigned)r;
+  }
+  int bt;
+  const int lp = block_excl_scan(flag, &bt, sm);
+  if (threadIdx.x == 0) st_agent(a.agg + blockIdx.x, ((unsigned long long)a.epoch << 32) | (unsigned)bt);
+  const int off = lookback_sum(a.agg, a.epoch, sm);
+  if (flag) {
+    a.slot_of[r] = off + lp;
+    a.uniq_rows[off + lp] = row;
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) a.info[0] = off + bt;
+}
+
+__global__ __launch_bounds__(256) void k_dd_map(DedupArgs a) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= a.R) return;
+  const unsigned lead = 0xFFFFFFFFu - (unsigned)a.key[a.rows[r]];
+  const int s = a.slot_of[lead];
+  a.map[r] = s;
+  a.ord[r] = atomicAdd(&a.cnt[s], 1);
+}
+
+__global__ __launch_bounds__(DD_BLOCK) void k_dd_segstart(DedupArgs a) {
+  __shared__ int sm[20];
+  const int U = a.info[0];
+  const int u = blockIdx.x * DD_BLOCK + threadIdx.x;
+  const int v = u < U ? a.cnt[u] : 0;
+  int bt;
+  const int lp = block_excl_scan(v, &bt, sm);
+  unsigned long long* agg = a.agg + a.agg_stride;
+  if (threadIdx.x == 0) st_agent(agg + blockIdx.x, ((unsigned long long)a.epoch << 32) | (unsigned)bt);
+  if (blockIdx.x * DD_BLOCK > U) return;             // nothing to write (block-uniform)
+  const int off = lookback_sum(agg, a.epoch, sm);
+  if (u <= U) a.seg_start[u] = off + lp;             // u == U: the total (= R)
+}
+
+__global__ __launch_bounds__(256) void k_dd_pos(DedupArgs a) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r < a.R) a.pos[r] = a.seg_start[a.map[r]] + a.ord[r];
+}
+
+void launch_dedup(const DedupArgs& a, hipStream_t s) {
+  const int g256 = (a.Rp + 255) / 256;
+  hipLaunchKernelGGL(k_dd_claim, dim3(g256), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_dd_leaders, dim3((a.R + DD_BLOCK - 1) / DD_BLOCK), dim3(DD_BLOCK), 0, s, a);
+  hipLaunchKernelGGL(k_dd_map, dim3((a.R + 255) / 256), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_dd_segstart, dim3(a.R / DD_BLOCK + 1), dim3(DD_BLOCK), 0, s, a);
+  hipLaunchKernelGGL(k_dd_pos, dim3((a.R + 255) / 256), dim3(256), 0, s, a);
+}
+
+// One wave per slot; a lane owns 8 consecutive columns (16-B loads) of every 512-column chunk.
+template <typename T>
+__global__ __launch_bounds__(256) void k_segsum(SegsumArgs a) {
+  const int U = a.info[0];
+  const int Uk = (U + BK - 1) / BK * BK;             // the wgrad K loop reads whole BK-row steps
+  const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (u >= Uk || u >= a.Rp) return;
+  int b = 0, e = 0;
+  if (u < U) { b = a.seg_start[u]; e = a.seg_start[u + 1]; }
+  for (int c0 = lane * 8; c0 < a.Dp; c0 += 512) {
+    double acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0;
+    for (int i = b; i < e; ++i) {
+      const uint4 v = *(const uint4*)(a.dYh + (int64_t)i * a.Dp + c0);
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[2 * j] += (double)T::to_float((uint16_t)(w[j] & 0xFFFFu));
+        acc[2 * j + 1] += (double)T::to_float((uint16_t)(w[j] >> 16));
+      }
+    }
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      o[j] = T::from_float((float)acc[2 * j]) | ((uint32_t)T::from_float((float)acc[2 * j + 1]) << 16);
+    *(uint4*)(a.dYu + (int64_t)u * a.Dp + c0) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+void launch_segsum(int prec, const SegsumArgs& a, hipStream_t s) {
+  const dim3 grid((a.Rp + 3) / 4), block(256);
+  if (prec == 0) hipLaunchKernelGGL(k_segsum<F16>, grid, block, 0, s, a);
+  else hipLaunchKernelGGL(k_segsum<BF16>, grid, block, 0, s, a);
+}
+
+// debug / parity accessors: expand per-slot rows back to per-instance rows
+__global__ __launch_bounds__(256) void k_gather_rows_f32(const float* src, const int32_t* map, int R, int D, float* dst) {
+  const int r = blockIdx.x;
+  const float* sp = src + (int64_t)map[r] * D;
+  for (int d = threadIdx.x; d < D; d += 256) dst[(int64_t)r * D + d] = sp[d];
+}
+void launch_gather_rows_f32(const float* src, const int32_t* map, int R, int D, float* dst, hipStream_t s) {
+  if (R > 0) hipLaunchKernelGGL(k_gather_rows_f32, dim3(R), dim3(256), 0, s, src, map, R, D, dst);
+}
+__global__ __launch_bounds__(256) void k_gather_rows_u16(const uint16_t* src, const int32_t* pos, int R, int Dp, uint16_t* dst) {
+  const int r = blockIdx.x;
+  const uint16_t* sp = src + (int64_t)pos[r] * Dp;
+  for (int d = threadIdx.x; d < Dp; d += 256) dst[(int64_t)r * Dp + d] = sp[d];
+}
+void launch_gather_rows_u16(const uint16_t* src, const int32_t* pos, int R, int Dp, uint16_t* dst, hipStream_t s) {
+  if (R > 0) hipLaunchKernelGGL(k_gather_rows_u16, dim3(R), dim3(256), 0, s, src, pos, R, Dp, dst);
+}
+
+}  // namespace vv

@@ -57,15 +57,23 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
   float* tq = n2 + CN;         // [CN] dots with Ah
   float* cq = tq + CN;         // [CN] upstream coefficients
   float* red = cq + CN;        // [8]
+  int* hoff = (int*)(red + 8); // [CN] row of H holding channel ch (dedup: the shared per-slot row)
+  int* ooff = hoff + CN;       // [CN] row of dYh receiving channel ch's gradient
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* Hb = a.H + (int64_t)b * CN * D;
   const float eps = 1e-10f;
+  for (int ch = tid; ch < CN; ch += SL_THREADS) {
+    const int r = b * CN + ch;
+    hoff[ch] = a.map ? a.map[r] : r;
+    ooff[ch] = a.pos ? a.pos[r] : r;
+  }
+  __syncthreads();
+#define HROW(ch) (a.H + (int64_t)hoff[ch] * D)
 
   // ---- phase 1: context mean (column-parallel) and its norm
   float ssq = 0.f;
   for (int d = tid; d < D; d += SL_THREADS) {
     float s = 0.f;
-    for (int j = 1; j < C; ++j) s += a.coeff[j - 1] * Hb[(int64_t)j * D + d];
+    for (int j = 1; j < C; ++j) s += a.coeff[j - 1] * HROW(j)[d];
     A[d] = s;
     ssq += s * s;
   }
@@ -77,7 +85,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
   // ---- phase 2: norms and dots of target / negative rows (one row per wave at a time)
   for (int qi = wave; qi < 1 + Nn; qi += 4) {
     const int ch = qi == 0 ? 0 : C + qi - 1;
-    const float* h = Hb + (int64_t)ch * D;
+    const float* h = HROW(ch);
     float s = 0.f, t = 0.f;
     if (VEC) {
       for (int d = lane * 4; d < D; d += 256) {
@@ -124,7 +132,6 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
   // ---- phase 4: backward of the normalised target / negative rows, column-parallel: a thread
   // owns one group of W consecutive columns (16-B loads) and walks the rows of its row group,
   // keeping its dAh / db partial sums in registers (deterministic order, no atomics).
-  const int64_t rbase = (int64_t)b * CN;
   constexpr int W = VEC ? 4 : 1;
   const int Dv = D / W;                       // column groups
   const int Dvp = Dv < SL_THREADS ? Dv : SL_THREADS;
@@ -141,8 +148,8 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
         const float c = cq[ch], s = n2[ch], t = tq[ch];
         const float inv_n = 1.f / (sqrtf(s) + eps);
         const float inv_den = 1.f / (s * sqrtf(s) + eps);
-        const float* h = Hb + (int64_t)ch * D + d;
-        uint16_t* dy = a.dYh + (rbase + ch) * a.Dp + d;
+        const float* h = HROW(ch) + d;
+        uint16_t* dy = a.dYh + (int64_t)ooff[ch] * a.Dp + d;
         float xv[W];
         if (VEC) { const float4 x = *(const float4*)h; xv[0] = x.x; xv[1 % W] = x.y; xv[2 % W] = x.z; xv[3 % W] = x.w; }
         else xv[0] = h[0];
@@ -179,11 +186,11 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
     float dbv = 0.f;
     for (int gI = 0; gI < G; ++gI) dbv += acc1[gI * D + d];
     for (int j = 1; j < C; ++j) {
-      const float x = Hb[(int64_t)j * D + d];
+      const float x = HROW(j)[d];
       float g = a.coeff[j - 1] * dA * a.drop_scale;
       g = x > 0.f ? g : 0.f;
       dbv += g;
-      a.dYh[(rbase + j) * a.Dp + d] = T::from_float(g * a.sg);
+      a.dYh[(int64_t)ooff[j] * a.Dp + d] = T::from_float(g * a.sg);
     }
     a.dbp[(int64_t)b * D + d] = dbv;
   }
@@ -205,8 +212,9 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss_reg(ScoreArgs a) {
   float* tq = n2 + CN;         // [CN]
   float* cq = tq + CN;         // [CN]
   float* red = cq + CN;        // [8]
+  int* hoff = (int*)(red + 8); // [CN]
+  int* ooff = hoff + CN;       // [CN]
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* Hb = a.H + (int64_t)b * CN * D;
   const float eps = 1e-10f;
 
   // rows of this wave: qi = wave, wave+4, ... ; issue every load up front
@@ -215,16 +223,24 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss_reg(ScoreArgs a) {
   for (int k = 0; k < RPW; ++k) {
     const int qi = wave + 4 * k;
     const int ch = qi == 0 ? 0 : C + qi - 1;
+    const int r = b * CN + (qi <= Nn ? ch : 0);
+    const int hr = a.map ? a.map[r] : r;
 #pragma unroll
     for (int v = 0; v < DV; ++v)
-      x[k][v] = qi <= Nn ? *(const float4*)(Hb + (int64_t)ch * D + lane * 4 + v * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+      x[k][v] = qi <= Nn ? *(const float4*)(a.H + (int64_t)hr * D + lane * 4 + v * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  for (int ch = tid; ch < CN; ch += SL_THREADS) {
+    const int r = b * CN + ch;
+    hoff[ch] = a.map ? a.map[r] : r;
+    ooff[ch] = a.pos ? a.pos[r] : r;
+  }
+  __syncthreads();
 
   // ---- phase 1: context mean and its norm
   float ssq = 0.f;
   for (int d = tid; d < D; d += SL_THREADS) {
     float s = 0.f;
-    for (int j = 1; j < C; ++j) s += a.coeff[j - 1] * Hb[(int64_t)j * D + d];
+    for (int j = 1; j < C; ++j) s += a.coeff[j - 1] * HROW(j)[d];
     A[d] = s;
     ssq += s * s;
   }
@@ -280,7 +296,6 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss_reg(ScoreArgs a) {
   __syncthreads();
 
   // ---- phase 4: backward of this wave's rows from registers; one coalesced 512-B store per chunk
-  const int64_t rbase = (int64_t)b * CN;
   float4 pa[DV], pb[DV];
 #pragma unroll
   for (int v = 0; v < DV; ++v) { pa[v] = make_float4(0.f, 0.f, 0.f, 0.f); pb[v] = pa[v]; }
@@ -292,7 +307,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss_reg(ScoreArgs a) {
     const float c = cq[ch], s = n2[ch], t = tq[ch];
     const float inv_n = 1.f / (sqrtf(s) + eps);
     const float inv_den = 1.f / (s * sqrtf(s) + eps);
-    uint16_t* dy = a.dYh + (rbase + ch) * a.Dp;
+    uint16_t* dy = a.dYh + (int64_t)ooff[ch] * a.Dp;
 #pragma unroll
     for (int v = 0; v < DV; ++v) {
       const float xv[4] = {x[k][v].x, x[k][v].y, x[k][v].z, x[k][v].w};
@@ -330,21 +345,22 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss_reg(ScoreArgs a) {
     const float dA = (sA * acc0[d] - A[d] * dot) * inv_denA;
     float dbv = acc1[d] + acc1[D + d] + acc1[2 * D + d] + acc1[3 * D + d];
     for (int j = 1; j < C; ++j) {
-      const float xx = Hb[(int64_t)j * D + d];
+      const float xx = HROW(j)[d];
       float g = a.coeff[j - 1] * dA * a.drop_scale;
       g = xx > 0.f ? g : 0.f;
       dbv += g;
-      a.dYh[(rbase + j) * a.Dp + d] = T::from_float(g * a.sg);
+      a.dYh[(int64_t)ooff[j] * a.Dp + d] = T::from_float(g * a.sg);
     }
     a.dbp[(int64_t)b * D + d] = dbv;
   }
 }
+#undef HROW
 
 template <typename T>
 static bool launch_score_loss_reg(const ScoreArgs& a, hipStream_t s) {
   // fast path: D == 512 and at most 52 target/negative rows (13 per wave)
   if (a.D != 512 || 1 + a.Nn > 52) return false;
-  const size_t lds = sizeof(float) * ((size_t)10 * a.D + 3 * (a.C + a.Nn) + 8);
+  const size_t lds = sizeof(float) * ((size_t)10 * a.D + 5 * (a.C + a.Nn) + 8);
   hipLaunchKernelGGL((k_score_loss_reg<T, 13, 2>), dim3(a.B), dim3(SL_THREADS), lds, s, a);
   return true;
 }
@@ -354,7 +370,7 @@ void set_score_reg(int v) { g_score_reg = v; }
 
 void launch_score_loss(int prec, const ScoreArgs& a, hipStream_t s) {
   if (g_score_reg && (prec == 0 ? launch_score_loss_reg<F16>(a, s) : launch_score_loss_reg<BF16>(a, s))) return;
-  const size_t lds = sizeof(float) * ((size_t)2 * a.D + 2 * (a.D > 1024 ? a.D : 1024) + 3 * (a.C + a.Nn) + 8);
+  const size_t lds = sizeof(float) * ((size_t)2 * a.D + 2 * (a.D > 1024 ? a.D : 1024) + 5 * (a.C + a.Nn) + 8);
   const bool vec = a.D % 4 == 0;
   const dim3 grid(a.B), block(SL_THREADS);
 #define VV_SL(T, V)                                                                              \

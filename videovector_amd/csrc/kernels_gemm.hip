@@ -28,7 +28,8 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   // Blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous run of
   // logical tiles so tiles that share operand rows also share an L2.  Speed only.
-  return (nblk % 8 == 0) ? (bid % 8) * (nblk / 8) + bid / 8 : bid;
+  const int x = bid & 7, q = nblk >> 3, rem = nblk & 7;
+  return x * q + (x < rem ? x : rem) + (bid >> 3);
 }
 
 // Ablation switches for timing studies only (VV_ABLATE; results are wrong when set):
@@ -56,7 +57,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm(FwdArgs a) {
   const int wm = wave >> 2, wn = wave & 3;
   const int Dp = (int)round_up(a.D, D_ALIGN);
   const int tilesN = Dp / BN;
-  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  // dedup mode: the grid covers the worst case, the live row count sits in device memory
+  const int R = a.n_dev ? *a.n_dev : a.R;
+  const int nact = a.n_dev ? ((R + BMK - 1) / BMK) * tilesN : (int)gridDim.x;
+  if ((int)blockIdx.x >= nact) return;
+  const int L = xcd_remap(blockIdx.x, nact);
   const int m0 = (L / tilesN) * BMK, n0 = (L % tilesN) * BN;
   const int Fp = a.Fp;
 
@@ -67,7 +72,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm(FwdArgs a) {
     const int c = (i * 8 + wave) * 64 + lane;
     const int row = c >> 3, lc = (c & 7) ^ (row & 7);
     const int grow = m0 + row;
-    const int trow = (row < BMK && grow < a.R) ? a.rows[grow] : a.zero_row;
+    const int trow = (row < BMK && grow < R) ? a.rows[grow] : a.zero_row;
     a_src[i] = a.table + (int64_t)trow * Fp + lc * 8;
   }
 #pragma unroll
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm(FwdArgs a) {
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int m = m0 + wm * (MI * 16) + mi * 16 + frow;
-    if (m >= a.R) continue;
+    if (m >= R) continue;
     int64_t ref_row = 0;
     if (DROP) {
       const int bb = m / a.CN, ch = m - bb * a.CN;
@@ -217,9 +222,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm(WgradArgs a) {
   const int L = xcd_remap(blockIdx.x, gridDim.x);
   const int tm = L % tilesM, tn = (L / tilesM) % tilesN, sp = L / (tilesM * tilesN);
   const int m0 = tm * BM, n0 = tn * BN;
-  const int total_steps = a.Rp / BK;
-  const int k_begin = sp * a.ksteps_per_split;
-  int k_end = k_begin + a.ksteps_per_split;
+  int total_steps = a.Rp / BK, kps = a.ksteps_per_split;
+  if (a.n_dev) {                      // dedup mode: live K extent in device memory
+    total_steps = (*a.n_dev + BK - 1) / BK;
+    kps = (total_steps + a.S - 1) / a.S;
+  }
+  const int k_begin = sp * kps;
+  int k_end = k_begin + kps;
   if (k_end > total_steps) k_end = total_steps;
   const int nk = k_end > k_begin ? k_end - k_begin : 0;
 
@@ -622,6 +631,8 @@ void set_ablate(int v) { g_ablate = v; }
 static int g_gemm_variant = 0;     // 0 = two-buffer K=64 kernels (default, faster), 1 = 4-slot ring K=32 kernels
 void set_wgrad_tr(bool on) { g_wgrad_tr = on; }
 void set_gemm_variant(int v) { g_gemm_variant = v; }
+int gemm_variant() { return g_gemm_variant; }
+bool ablate_on() { return g_ablate != 0; }
 int wgrad_max_ksteps_per_split() { return g_gemm_variant == 1 ? WG_IDS_MAX / BK : (1 << 30); }
 
 template <typename T, bool DROP, bool VEC>
@@ -651,42 +662,31 @@ static void launch_fwd_t(const FwdArgs& a, hipStream_t s) {
     }
   }
   if constexpr (!DROP && VEC) {
-    // balanced M tiling: the MI in {8,7,6} that needs the least (rounds of 256 WGs) x (tile height)
+    // balanced M tiling: the tile height 32*MI that needs the least (rounds of 256 WGs) x (tile height).
+    // Dedup mode sizes the tiles for the expected row count (R_hint, the previous step's) while the grid
+    // covers the worst case R; surplus workgroups exit at once.
     if (g_gemm_variant != 1) {
+      const int Rh = a.n_dev && a.R_hint > 0 ? a.R_hint : a.R;
       int best = 8; long best_cost = -1;
-      for (int mi = 8; mi >= 6; --mi) {
-        const long tiles = ((a.R + 32 * mi - 1) / (32 * mi)) * (long)(Dp / BN);
+      for (int mi = 8; mi >= (a.n_dev ? 4 : 7); --mi) {
+        const long tiles = ((Rh + 32 * mi - 1) / (32 * mi)) * (long)(Dp / BN);
         const long cost = ((tiles + 255) / 256) * mi;
         if (best_cost < 0 || cost < best_cost) { best = mi; best_cost = cost; }
       }
       if (g_fwd_mi) best = g_fwd_mi;
-      if (g_gemm_variant != 3) {     // default: interleaved staging + setprio (variant 3 = burst staging, for A/B)
-        if (best == 6) best = 7;
-        const dim3 g2(((a.R + 32 * best - 1) / (32 * best)) * (Dp / BN));
-        if (best == 7) {
-          static bool o7 = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm<T, DROP, VEC, 0, 7, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES), true);
-          (void)o7;
-          hipLaunchKernelGGL((k_fwd_gemm<T, DROP, VEC, 0, 7, 1>), g2, block, GEMM_LDS_BYTES, s, a);
-        } else {
-          static bool o8 = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm<T, DROP, VEC, 0, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES), true);
-          (void)o8;
-          hipLaunchKernelGGL((k_fwd_gemm<T, DROP, VEC, 0, 8, 1>), g2, block, GEMM_LDS_BYTES, s, a);
-        }
-        return;
+      const int sched = g_gemm_variant != 3;     // default: interleaved staging + setprio (variant 3 = burst staging, for A/B)
+#define VV_FWD_MI(M, SC)                                                                                      \
+      if (best == M && sched == SC) {                                                                        \
+        static bool o = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm<T, DROP, VEC, 0, M, SC>,          \
+                         hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES), true);                 \
+        (void)o;                                                                                             \
+        const dim3 g2(((a.R + 32 * M - 1) / (32 * M)) * (Dp / BN));                                          \
+        hipLaunchKernelGGL((k_fwd_gemm<T, DROP, VEC, 0, M, SC>), g2, block, GEMM_LDS_BYTES, s, a);           \
+        return;                                                                                              \
       }
-      if (best != 8) {
-        const dim3 g2(((a.R + 32 * best - 1) / (32 * best)) * (Dp / BN));
-        if (best == 7) {
-          static bool o7 = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm<T, DROP, VEC, 0, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES), true);
-          (void)o7;
-          hipLaunchKernelGGL((k_fwd_gemm<T, DROP, VEC, 0, 7>), g2, block, GEMM_LDS_BYTES, s, a);
-        } else {
-          static bool o6 = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm<T, DROP, VEC, 0, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES), true);
-          (void)o6;
-          hipLaunchKernelGGL((k_fwd_gemm<T, DROP, VEC, 0, 6>), g2, block, GEMM_LDS_BYTES, s, a);
-        }
-        return;
-      }
+      VV_FWD_MI(8, 1) VV_FWD_MI(7, 1) VV_FWD_MI(6, 1) VV_FWD_MI(5, 1) VV_FWD_MI(4, 1)
+      VV_FWD_MI(7, 0) VV_FWD_MI(6, 0)
+#undef VV_FWD_MI
     }
   }
   if (g_gemm_variant == 1) {

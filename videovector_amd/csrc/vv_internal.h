@@ -51,6 +51,8 @@ struct FwdArgs {
   const uint8_t* mask;     // explicit mask [(C+Nn)*B][D] in reference row order, or null
   uint64_t drop_seed;
   int B, CN;               // to map an internal row (b*CN+ch) to the reference row (ch*B+b)
+  const int32_t* n_dev = nullptr;   // dedup mode: device count of valid rows (overrides R; the grid covers R)
+  int R_hint = 0;              // dedup mode: expected row count, sizes the tiles (0 = R)
 };
 
 struct ScoreArgs {
@@ -67,6 +69,38 @@ struct ScoreArgs {
   float grad_scale;        // loss_weight / global_count
   float drop_scale;        // 1/(1-ratio) or 1
   float sg;                // half-precision gradient scale
+  // row-dedup mode (both NULL otherwise): H holds one row per UNIQUE table row, instance r reads
+  // H[map[r]] and writes its gradient row to dYh[pos[r]] (instances of one unique row contiguous)
+  const int32_t* map = nullptr;      // [R]
+  const int32_t* pos = nullptr;      // [R]
+};
+
+// Row de-duplication of one batch (kernels_dedup.hip).  The sampler draws the negatives of every item
+// from one shared buffer (video_sampled_shots_data_layer.cpp:836-875), so a batch repeats table rows;
+// the projection is computed once per unique row and the gradient rows of its instances are summed
+// before the weight-gradient GEMM.
+struct DedupArgs {
+  const int32_t* rows;           // [Rp] instance -> table row (k_map_rows)
+  unsigned long long* key;       // [table rows + scratch] epoch-tagged leader election
+  unsigned long long* agg;       // [2][agg_stride] epoch-tagged block aggregates of the two scans
+  int agg_stride;
+  int32_t* slot_of;              // [R] slot of the leader instances
+  int32_t* uniq_rows;            // [Rp] slot -> table row (zero_row past U)
+  int32_t* map;                  // [R] instance -> slot
+  int32_t* ord;                  // [R] arrival order of the instance inside its segment
+  int32_t* cnt;                  // [Rp] instances per slot
+  int32_t* seg_start;            // [Rp + 1]
+  int32_t* pos;                  // [R] instance -> row of the grouped gradient buffer
+  int32_t* info;                 // device {U, ...}
+  int R, Rp; int32_t zero_row; uint32_t epoch;
+};
+
+struct SegsumArgs {
+  const uint16_t* dYh;           // [R][Dp] instance gradient rows grouped by slot
+  const int32_t* seg_start;      // [U + 1]
+  const int32_t* info;           // {U}
+  uint16_t* dYu;                 // [Rp][Dp] per-slot sums (zero rows up to the next multiple of BK)
+  int Rp, Dp;
 };
 
 struct WgradArgs {
@@ -77,6 +111,7 @@ struct WgradArgs {
   int Rp, Dp, Fp;
   int S;                   // split-K factor
   int ksteps_per_split;    // BK-steps per split
+  const int32_t* n_dev = nullptr;    // dedup mode: device count of valid K rows (overrides Rp / ksteps_per_split)
 };
 
 struct ReduceArgs {
@@ -104,6 +139,10 @@ struct SgdArgs {
 void launch_fwd_gemm(int prec, const FwdArgs& a, hipStream_t s);
 void launch_wgrad_gemm(int prec, const WgradArgs& a, hipStream_t s);
 void launch_score_loss(int prec, const ScoreArgs& a, hipStream_t s);
+void launch_dedup(const DedupArgs& a, hipStream_t s);
+void launch_segsum(int prec, const SegsumArgs& a, hipStream_t s);
+void launch_gather_rows_f32(const float* src, const int32_t* map, int R, int D, float* dst, hipStream_t s);
+void launch_gather_rows_u16(const uint16_t* src, const int32_t* pos, int R, int Dp, uint16_t* dst, hipStream_t s);
 void launch_reduce(const ReduceArgs& a, hipStream_t s);
 void launch_sgd(int prec, const SgdArgs& a, hipStream_t s);
 void launch_scale_update(int prec, Scales* sc, const float* wmax_blocks, hipStream_t s);

@@ -58,6 +58,7 @@ def load_library():
     sigs = {
         "vv_create": [C.c_int, C.c_int, C.POINTER(vp)],
         "vv_destroy": [vp], "vv_set_stream": [vp, vp], "vv_synchronize": [vp],
+        "vv_set_dedup": [vp, C.c_int], "vv_dedup_stats": [vp, C.POINTER(i64), C.POINTER(i64)],
         "vv_table_set": [vp, vp, i64, i32], "vv_table_synth": [vp, C.c_uint64, i64, i32],
         "vv_table_get": [vp, vp, i64, vp],
         "vv_params_set": [vp, i32, vp, vp, vp, vp], "vv_params_get": [vp, vp, vp, vp, vp],
@@ -152,6 +153,16 @@ class Engine:
 
     def synchronize(self):
         self._chk(self.L.vv_synchronize(self.h))
+
+    def set_dedup(self, on):
+        """Row de-duplication of the batch (include/videovec.h: vv_set_dedup); default on."""
+        self._chk(self.L.vv_set_dedup(self.h, int(bool(on))))
+
+    def dedup_stats(self):
+        """(rows, distinct rows) of the last forward/backward pass."""
+        r, u = C.c_int64(0), C.c_int64(0)
+        self._chk(self.L.vv_dedup_stats(self.h, C.byref(r), C.byref(u)))
+        return r.value, u.value
 
     def table_set(self, rows):
         rows = np.ascontiguousarray(rows, dtype=np.float32)
