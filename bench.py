@@ -6,8 +6,12 @@
 
 Workload = BASELINE.json configs[1] per GPU: synthetic fc7 features 4096-d -> 512-d embedding, batch
 1024 per GPU (global batch N*1024, weak scaling), context window +-2 (context_size 5), 50 negatives.
-A step = one full training iteration on one batch: gather-GEMM forward, fused score/loss
-forward+backward, gather-GEMM^T weight gradient, (RCCL all-reduce for N>1), fused SGD update.
+A step = one full training iteration on one batch: (row de-duplication,) gather-GEMM forward, fused
+score/loss forward+backward, (per-row gradient sums,) gather-GEMM^T weight gradient, (RCCL all-reduce
+for N>1), fused SGD update.  --dedup on (default) projects every distinct table row of the batch once
+(allowed with the factor disclosed); the JSON line then also carries the same K steps
+timed with --dedup off ("dense_execution": every sampled row projected separately, as the reference
+does), and the roofline fraction is computed from the FLOPs the kernel really executed.
 Triplet index batches are sampled beforehand by the product sampler and are resident in HBM when
 the timed region starts (the sampler is integer host work that does not depend on the model).
 Prints ONE JSON line on rank 0.
@@ -60,6 +64,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--prec", default=os.environ.get("VV_PREC", "f16"), choices=["f16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dedup", default="on", choices=["on", "off"],
+                    help="row de-duplication of the batch (results identical up to the rounding of reassociated "
+                         "sums); 'off' executes the reference-equivalent dense work")
+    ap.add_argument("--no-dense-leg", action="store_true", help="skip the extra dense_execution timing")
     ap.add_argument("--allreduce", default="auto", choices=["auto", "overlap", "sync"],
                     help="N>1: 'overlap' (default) runs the RCCL all-reduce of iteration t's gradients during "
                          "iteration t+1's forward/backward (one-update delayed gradients, the overlap the "
@@ -108,6 +116,7 @@ def main():
     eng.set_stream(work_stream.cuda_stream)
     eng.table_synth(ds.seed, ds.n_rows, F)
     eng.params_set(W0, b0)
+    eng.set_dedup(args.dedup == "on")
     cfg = vv.StepConfig(B_PER_GPU, C, NN, global_count=Bg * NN)
     stride = B_PER_GPU * (C + NN) * 4
     mode = args.allreduce if args.allreduce != "auto" else ("overlap" if world > 1 else "none")
@@ -135,42 +144,81 @@ def main():
         else:
             eng.step(cfg, idx_dev_ptr=ptr)
 
-    for i in range(Wm):
-        step(i)
-    if dist: dist.barrier()
-    torch.cuda.synchronize()
-    eng.profile_enable(True)
-    t0 = time.perf_counter()
-    for i in range(Wm, Wm + K):
-        step(i)
-    if trainer is not None:
-        trainer.flush()
-    torch.cuda.synchronize()
-    if dist: dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    KERNELS = ("dedup", "fwd_gemm", "score_loss", "segsum", "wgrad_gemm", "reduce", "sgd")
+
+    def timed_run():
+        """W warm-up steps, then exactly K steps between barrier + synchronize; max over ranks."""
+        for i in range(Wm):
+            step(i)
+        if trainer is not None:
+            trainer.flush()
+        if dist: dist.barrier()
+        torch.cuda.synchronize()
+        eng.profile_enable(True)
+        t0 = time.perf_counter()
+        for i in range(Wm, Wm + K):
+            step(i)
+        if trainer is not None:
+            trainer.flush()
+        torch.cuda.synchronize()
+        if dist: dist.barrier()
+        el = time.perf_counter() - t0
+        if dist:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        kern = {k: eng.profile_get(k) for k in KERNELS}
+        eng.profile_enable(False)
+        return el, kern
+
+    elapsed, kern = timed_run()
     loss, viol = eng.loss()
-    kern = {k: eng.profile_get(k) for k in ("fwd_gemm", "score_loss", "wgrad_gemm", "reduce", "sgd")}
-    eng.profile_enable(False)
+    dense = None
+    if args.dedup == "on" and not args.no_dense_leg:
+        # the same K batches again with every sampled row projected separately (reference-equivalent execution)
+        eng.set_dedup(False)
+        eng.params_set(W0, b0)
+        d_el, d_kern = timed_run()
+        dense = {"value": Bg * NN * K / d_el, "unit": "triplets/s", "ms_per_step": d_el / K * 1e3,
+                 "kernels_ms": {k: round(v[0], 4) for k, v in d_kern.items() if v[1] > 0}}
+        eng.set_dedup(True)
 
     if rank == 0:
         ms = elapsed / K * 1e3
         value = Bg * NN * K / elapsed
         R = B_PER_GPU * (C + NN)
-        gemm_flop = 2.0 * R * F * D          # per launch of either GEMM kernel
-        dom = max(("fwd_gemm", "wgrad_gemm"), key=lambda k: kern[k][0])
-        dom_ms = kern[dom][0]
-        ach = gemm_flop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        dense_flop = 2.0 * R * F * D         # per launch of either GEMM kernel, every sampled row (SURVEY 8d figure)
+        # rows the GEMMs really processed: distinct table rows per timed batch of this rank (host recount)
+        if args.dedup == "on":
+            U = float(np.mean([len(np.unique(batches[i])) for i in range(Wm, Wm + K)]))
+        else:
+            U = float(R)
+        gemm_flop = 2.0 * U * F * D
+        live = {k: v[0] for k, v in kern.items() if v[1] > 0}
+        dom = max(live, key=live.get)
+        dom_ms = live[dom]
+        if dom in ("fwd_gemm", "wgrad_gemm"):
+            ach = gemm_flop / (dom_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / MFMA_PEAK_TFLOPS, "algorithmic_flop_per_launch": gemm_flop,
+                    "dense_equivalent_flop_per_launch": dense_flop,
+                    "dense_equivalent_achieved": dense_flop / (dom_ms * 1e-3) / 1e12}
+        else:
+            # score_loss: reads every instance's ip2 row (fp32) once, writes its 16-bit gradient row once
+            nbytes = R * D * 4.0 + R * D * 2.0
+            ach = nbytes / (dom_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes}
+        roof["avg_launch_ms"] = dom_ms
+        roof["dedup_factor"] = R / U
         pmc = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_path):
             try:
-                pmc = json.load(open(pmc_path)).get(dom, {}).get("hbm_bytes_per_launch")
+                pmc = json.load(open(pmc_path)).get("dedup_" + args.dedup, {}).get(dom, {}).get("hbm_bytes_per_launch")
             except Exception:
                 pmc = None
+        roof["traffic"] = pmc
         out = {
             "metric": "triplets/sec (whole node), 4096->512-d embed, batch 1024/GPU, C5, Nn50",
             "value": value, "unit": "triplets/s", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -182,19 +230,24 @@ def main():
                                    "max_buffer 5000, swap 50%%, margin 2 L2, SGD momentum .9 wd 5e-4 inv lr"
                                    % (B_PER_GPU, Bg),
                        "global_batch": Bg, "triplets_per_step": Bg * NN,
-                       "parallelism": "dp%d" % world, "items_per_s": value / NN,
+                       "parallelism": "dp%d" % world, "items_per_s": value / NN, "dedup": args.dedup,
                        "allreduce": {"none": "none (1 GPU)", "sync": "synchronous, exposed",
                                      "overlap": "overlapped with the next iteration's forward/backward "
                                                 "(one-update delayed gradients)"}[mode]},
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": pmc,
-                         "algorithmic_flop_per_launch": gemm_flop, "avg_launch_ms": dom_ms},
-            "kernels_ms": {k: round(v[0], 4) for k, v in kern.items()},
-            "step_tflops": 2 * gemm_flop / (ms * 1e-3) / 1e12,
+            "roofline": roof,
+            "kernels_ms": {k: round(v, 4) for k, v in live.items()},
+            "dedup": {"mode": args.dedup, "rows_per_step": R, "distinct_rows_per_step": U, "factor": R / U,
+                      "note": "the reference sampler draws all negatives of a batch from one shared 5000-frame "
+                              "buffer, so sampled rows repeat; each distinct row is projected once and its "
+                              "instances' gradient rows are summed before the weight-gradient GEMM"},
+            "step_tflops_executed": 2 * gemm_flop / (ms * 1e-3) / 1e12,
+            "step_tflops_dense_equivalent": 2 * dense_flop / (ms * 1e-3) / 1e12,
             "gather_GBs": 2.0 * R * F * 2 / (ms * 1e-3) / 1e9,
             "sampler_ms_per_global_batch": sampler_s * 1e3,
             "final_loss": loss, "final_violations": viol,
         }
+        if dense is not None:
+            out["dense_execution"] = dense
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ds, batches[0], W0, b0)
         print(json.dumps(out))

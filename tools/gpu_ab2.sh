@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 for rep in 1 2; do for v in $2; do
-  env $1=$v timeout 300 python bench.py --steps 50 --warmup 10 --no-cpu-baseline > gpurun_out/ab_bench.log 2>&1
+  env $1=$v timeout 300 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-dense-leg > gpurun_out/ab_bench.log 2>&1
   echo "$1=$v: $(python3 -c "
 import json
 l=[x for x in open('gpurun_out/ab_bench.log') if x.startswith('{')]

@@ -69,7 +69,8 @@ struct vv_ctx {
   int32_t *dd_slot_of = nullptr, *dd_uniq = nullptr, *dd_map = nullptr, *dd_ord = nullptr, *dd_cnt = nullptr,
           *dd_seg = nullptr, *dd_pos = nullptr, *dd_info = nullptr;
   uint16_t* dYu = nullptr;
-  int32_t* U_host = nullptr;        // pinned; refreshed by an async copy every step, read one step late
+  int32_t* U_host = nullptr;        // pinned + mapped: k_dd_leaders stores U here every step, the launcher reads it late
+  int32_t* U_host_dev = nullptr;    // device alias of U_host
   uint32_t dd_epoch = 0;
   // profiling
   bool prof = false;
@@ -153,8 +154,9 @@ int vv_create(int device, int prec, vv_ctx** out) {
   if (dd) c->dedup = atoi(dd) != 0;
   HIPCHK(hipMalloc(&c->dd_info, 4 * sizeof(int32_t)));
   HIPCHK(hipMemset(c->dd_info, 0, 4 * sizeof(int32_t)));
-  HIPCHK(hipHostMalloc((void**)&c->U_host, sizeof(int32_t), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&c->U_host, sizeof(int32_t), hipHostMallocMapped));
   *c->U_host = 0;
+  HIPCHK(hipHostGetDevicePointer((void**)&c->U_host_dev, c->U_host, 0));
   *out = c;
   return VV_OK;
 }
@@ -432,7 +434,6 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
     HIPCHK(hipMemcpyAsync(c->idx_dev, idx, (size_t)c->R * 4, hipMemcpyHostToDevice, s));
     didx = c->idx_dev;
   }
-  launch_map_rows(didx, c->rows, c->R, c->Rp, (int32_t)c->n_rows, s);
 
   // eltwise coefficients (cached on the device until they change)
   std::vector<float> coeff(C - 1);
@@ -452,6 +453,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   // top of the shared projection; that path stays dense).  Needs the default two-buffer GEMM kernels.
   const bool dd = c->dedup && cfg->dropout_ratio == 0.f && (gemm_variant() == 0 || gemm_variant() == 3) && !ablate_on();
   c->last_dedup = dd;
+  if (!dd) launch_map_rows(didx, c->rows, c->R, c->Rp, (int32_t)c->n_rows, s);
   if (dd) {
     const int64_t need = c->n_rows + 1 + c->patch_cap;
     if (need > c->dd_key_cap) {
@@ -467,7 +469,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
       c->dd_epoch = 1;
     }
     DedupArgs da;
-    da.rows = c->rows; da.key = c->dd_key; da.agg = c->dd_agg; da.agg_stride = c->dd_agg_stride;
+    da.idx = didx; da.rows = c->rows; da.u_host = c->U_host_dev; da.key = c->dd_key; da.agg = c->dd_agg; da.agg_stride = c->dd_agg_stride;
     da.slot_of = c->dd_slot_of; da.uniq_rows = c->dd_uniq; da.map = c->dd_map; da.ord = c->dd_ord; da.cnt = c->dd_cnt;
     da.seg_start = c->dd_seg; da.pos = c->dd_pos; da.info = c->dd_info;
     da.R = c->R; da.Rp = c->Rp; da.zero_row = (int32_t)c->n_rows; da.epoch = c->dd_epoch;
@@ -479,7 +481,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   fa.H = c->H; fa.R = c->R; fa.D = D; fa.Fp = c->Fp; fa.relu = 1; fa.zero_row = (int32_t)c->n_rows;
   fa.n_dev = dd ? c->dd_info : nullptr;
   fa.R_hint = dd ? *(volatile int32_t*)c->U_host : 0;
-  if (dd) HIPCHK(hipMemcpyAsync(c->U_host, c->dd_info, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+
   fa.drop_ratio = cfg->dropout_ratio;
   fa.mask = (cfg->dropout_ratio > 0.f && cfg->dropout_mask) ? c->mask : nullptr;
   fa.drop_seed = cfg->dropout_seed * 0x9E3779B97F4A7C15ull + c->iter;
@@ -503,7 +505,6 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   sa.sg = c->sg;
   sa.map = dd ? c->dd_map : nullptr; sa.pos = dd ? c->dd_pos : nullptr;
   PROFILED(c, "score_loss", launch_score_loss(c->prec, sa, s));
-  launch_final_loss(c->loss_part, c->viol_part, B, cfg->loss_weight / (float)count, c->loss2, s);
 
   if (dd) {
     SegsumArgs ga;
@@ -519,6 +520,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   ReduceArgs ra;
   ra.slabs = c->slabs; ra.S = c->S; ra.Dp = c->Dp; ra.Fp = c->Fp; ra.dbp = c->dbp; ra.B = B;
   ra.scales = c->scales; ra.sg = c->sg; ra.grads = c->grads; ra.D = D; ra.F = c->F; ra.ip_scale = 1.f;
+  ra.loss_part = c->loss_part; ra.viol_part = c->viol_part; ra.loss_scale = cfg->loss_weight / (float)count; ra.loss_out = c->loss2;
   PROFILED(c, "reduce", launch_reduce(ra, s));
 
   HIPCHK(hipGetLastError());

@@ -9,7 +9,7 @@
 //     dW = sum_r dY[r]^T X[row(r)] = sum_u (sum_{r -> u} dY[r])^T X[u].
 // Same results (the projection of equal inputs is equal; the gradient sum is reassociated).
 //
-//   k_dd_claim    : leader election, atomicMax of (epoch, ~r) per table row -> the smallest instance
+//   k_dd_claim    : index -> table row (empty slots -> the zero row), then leader election, atomicMax of (epoch, ~r) per table row -> the smallest instance
 //                   index of every distinct row wins; epoch tags make a reset pass unnecessary.
 //   k_dd_leaders  : slot = rank of the leader among leaders (single-pass scan: every block publishes
 //                   its count as an epoch-tagged word, later blocks sum the words of earlier ones).
@@ -36,9 +36,13 @@ __device__ __forceinline__ void st_agent(unsigned long long* p, unsigned long lo
 
 __global__ __launch_bounds__(256) void k_dd_claim(DedupArgs a) {
   const int r = blockIdx.x * 256 + threadIdx.x;
-  if (r < a.Rp) { a.uniq_rows[r] = a.zero_row; a.cnt[r] = 0; }
+  if (r >= a.Rp) return;
+  int row = a.zero_row;
+  if (r < a.R) { const int i = a.idx[r]; if (i >= 0) row = i; }
+  a.rows[r] = row;                     // what k_map_rows does on the dense path
+  a.uniq_rows[r] = a.zero_row; a.cnt[r] = 0;
   if (r < a.R)
-    atomicMax(&a.key[a.rows[r]], ((unsigned long long)a.epoch << 32) | (0xFFFFFFFFu - (unsigned)r));
+    atomicMax(&a.key[row], ((unsigned long long)a.epoch << 32) | (0xFFFFFFFFu - (unsigned)r));
 }
 
 // exclusive block scan of one int per thread (DD_BLOCK threads); returns the prefix, *total = block sum
@@ -94,7 +98,10 @@ __global__ __launch_bounds__(DD_BLOCK) void k_dd_leaders(DedupArgs a) {
     a.slot_of[r] = off + lp;
     a.uniq_rows[off + lp] = row;
   }
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) a.info[0] = off + bt;
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    a.info[0] = off + bt;
+    __hip_atomic_store(a.u_host, off + bt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 __global__ __launch_bounds__(256) void k_dd_map(DedupArgs a) {

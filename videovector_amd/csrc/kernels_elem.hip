@@ -200,9 +200,21 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
 // VGPRs between the forward reductions and the backward pass, so every row of ip2 is read from HBM
 // exactly once (the streaming kernel above re-reads them, and at ~8 workgroups per CU the 110 KB per
 // item do not survive in L2).  RPW = rows per wave, DV = float4 chunks per lane (D = 256*DV).
+// three block-wide sums at once (256 threads; red must hold >= 12 floats)
+__device__ __forceinline__ void block_sum3(float& x, float& y, float& z, float* red) {
+  x = wave_sum(x); y = wave_sum(y); z = wave_sum(z);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; red[w] = x; red[4 + w] = y; red[8 + w] = z; }
+  __syncthreads();
+  x = red[0] + red[1] + red[2] + red[3];
+  y = red[4] + red[5] + red[6] + red[7];
+  z = red[8] + red[9] + red[10] + red[11];
+}
+
 template <typename T, int RPW, int DV>
 __global__ __launch_bounds__(SL_THREADS) void k_score_loss_reg(ScoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int CXM = 6;       // context rows kept in registers (C - 1 <= CXM on this path)
   const int D = a.D, C = a.C, Nn = a.Nn, CN = C + Nn;
   float* A = sm;               // [D]
   float* Ah = A + D;           // [D]
@@ -211,13 +223,13 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss_reg(ScoreArgs a) {
   float* n2 = acc1 + 4 * D;    // [CN]
   float* tq = n2 + CN;         // [CN]
   float* cq = tq + CN;         // [CN]
-  float* red = cq + CN;        // [8]
-  int* hoff = (int*)(red + 8); // [CN]
-  int* ooff = hoff + CN;       // [CN]
+  float* red = cq + CN;        // [12]
+  int* ooff = (int*)(red + 12);// [CN] row of dYh receiving channel ch's gradient
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float eps = 1e-10f;
 
-  // rows of this wave: qi = wave, wave+4, ... ; issue every load up front
+  // Every global read of ip2 is issued up front: the target / negative rows of this wave
+  // (qi = wave, wave+4, ...) and the context rows (thread tid owns columns tid + 256 v).
   float4 x[RPW][DV];
 #pragma unroll
   for (int k = 0; k < RPW; ++k) {
@@ -229,24 +241,36 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss_reg(ScoreArgs a) {
     for (int v = 0; v < DV; ++v)
       x[k][v] = qi <= Nn ? *(const float4*)(a.H + (int64_t)hr * D + lane * 4 + v * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  float cx[CXM][DV];
+#pragma unroll
+  for (int j = 0; j < CXM; ++j) {
+    const int r = b * CN + (j + 1 < C ? j + 1 : 0);
+    const int hr = a.map ? a.map[r] : r;
+#pragma unroll
+    for (int v = 0; v < DV; ++v) cx[j][v] = j + 1 < C ? a.H[(int64_t)hr * D + tid + v * 256] : 0.f;
+  }
+  float cf[CXM];
+#pragma unroll
+  for (int j = 0; j < CXM; ++j) cf[j] = j + 1 < C ? a.coeff[j] : 0.f;
   for (int ch = tid; ch < CN; ch += SL_THREADS) {
     const int r = b * CN + ch;
-    hoff[ch] = a.map ? a.map[r] : r;
     ooff[ch] = a.pos ? a.pos[r] : r;
   }
-  __syncthreads();
 
   // ---- phase 1: context mean and its norm
   float ssq = 0.f;
-  for (int d = tid; d < D; d += SL_THREADS) {
+#pragma unroll
+  for (int v = 0; v < DV; ++v) {
     float s = 0.f;
-    for (int j = 1; j < C; ++j) s += a.coeff[j - 1] * HROW(j)[d];
-    A[d] = s;
+#pragma unroll
+    for (int j = 0; j < CXM; ++j) s += cf[j] * cx[j][v];
+    A[tid + v * 256] = s;
     ssq += s * s;
   }
   const float sA = block_sum(ssq, red);
   const float nA = sqrtf(sA) + eps;
-  for (int d = tid; d < D; d += SL_THREADS) Ah[d] = A[d] / nA;
+#pragma unroll
+  for (int v = 0; v < DV; ++v) Ah[tid + v * 256] = A[tid + v * 256] / nA;
   __syncthreads();
 
   // ---- phase 2: norms and dots from registers
@@ -284,9 +308,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss_reg(ScoreArgs a) {
     cq[ch] = g;
     if (a.s_bogus) a.s_bogus[(int64_t)b * Nn + k] = sn;
   }
-  lsum = block_sum(lsum, red);
-  vsum = block_sum(vsum, red);
-  gsum = block_sum(gsum, red);
+  block_sum3(lsum, vsum, gsum, red);
   if (tid == 0) {
     cq[0] = -gsum;
     a.loss_part[b] = lsum;
@@ -332,24 +354,30 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss_reg(ScoreArgs a) {
   }
   __syncthreads();
 
-  // ---- phase 5: backward of the context normalisation and mean
+  // ---- phase 5: backward of the context normalisation and mean (context rows still in registers)
   float dot = 0.f;
-  for (int d = tid; d < D; d += SL_THREADS) {
-    const float u = acc0[d] + acc0[D + d] + acc0[2 * D + d] + acc0[3 * D + d];
-    acc0[d] = u;
-    dot += A[d] * u;
+  float u[DV];
+#pragma unroll
+  for (int v = 0; v < DV; ++v) {
+    const int d = tid + v * 256;
+    u[v] = acc0[d] + acc0[D + d] + acc0[2 * D + d] + acc0[3 * D + d];
+    dot += A[d] * u[v];
   }
   dot = block_sum(dot, red);
   const float inv_denA = 1.f / (sA * sqrtf(sA) + eps);
-  for (int d = tid; d < D; d += SL_THREADS) {
-    const float dA = (sA * acc0[d] - A[d] * dot) * inv_denA;
+#pragma unroll
+  for (int v = 0; v < DV; ++v) {
+    const int d = tid + v * 256;
+    const float dA = (sA * u[v] - A[d] * dot) * inv_denA;
     float dbv = acc1[d] + acc1[D + d] + acc1[2 * D + d] + acc1[3 * D + d];
-    for (int j = 1; j < C; ++j) {
-      const float xx = HROW(j)[d];
-      float g = a.coeff[j - 1] * dA * a.drop_scale;
-      g = xx > 0.f ? g : 0.f;
-      dbv += g;
-      a.dYh[(int64_t)ooff[j] * a.Dp + d] = T::from_float(g * a.sg);
+#pragma unroll
+    for (int j = 0; j < CXM; ++j) {
+      if (j + 1 < C) {
+        float g = cf[j] * dA * a.drop_scale;
+        g = cx[j][v] > 0.f ? g : 0.f;
+        dbv += g;
+        a.dYh[(int64_t)ooff[j + 1] * a.Dp + d] = T::from_float(g * a.sg);
+      }
     }
     a.dbp[(int64_t)b * D + d] = dbv;
   }
@@ -358,9 +386,9 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss_reg(ScoreArgs a) {
 
 template <typename T>
 static bool launch_score_loss_reg(const ScoreArgs& a, hipStream_t s) {
-  // fast path: D == 512 and at most 52 target/negative rows (13 per wave)
-  if (a.D != 512 || 1 + a.Nn > 52) return false;
-  const size_t lds = sizeof(float) * ((size_t)10 * a.D + 5 * (a.C + a.Nn) + 8);
+  // fast path: D == 512, at most 52 target/negative rows (13 per wave) and at most 6 context rows
+  if (a.D != 512 || 1 + a.Nn > 52 || a.C - 1 > 6) return false;
+  const size_t lds = sizeof(float) * ((size_t)10 * a.D + 4 * (a.C + a.Nn) + 12);
   hipLaunchKernelGGL((k_score_loss_reg<T, 13, 2>), dim3(a.B), dim3(SL_THREADS), lds, s, a);
   return true;
 }
@@ -432,8 +460,19 @@ __device__ __forceinline__ void reduce_db(const ReduceArgs& a, int blk) {
   }
 }
 
+// loss = scale * sum(loss_part), violations = sum(viol_part); fixed-order (deterministic)
+__device__ __forceinline__ void reduce_loss(const ReduceArgs& a) {
+  __shared__ float red[8];
+  float l = 0.f, v = 0.f;
+  for (int i = threadIdx.x; i < a.B; i += 256) { l += a.loss_part[i]; v += a.viol_part[i]; }
+  l = block_sum(l, red);
+  v = block_sum(v, red + 4);
+  if (threadIdx.x == 0) { a.loss_out[0] = l * a.loss_scale; a.loss_out[1] = v; }
+}
+
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
+  if (blockIdx.x == gridDim.x - 1) { reduce_loss(a); return; }
   if (blockIdx.x >= RED_DW_BLOCKS) { reduce_db(a, blockIdx.x - RED_DW_BLOCKS); return; }
   const float inv = a.ip_scale / (a.sg * a.scales->sx);
   const int64_t slab_sz = (int64_t)a.Dp * a.Fp;
@@ -471,7 +510,7 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
   }
 }
 void launch_reduce(const ReduceArgs& a, hipStream_t s) {
-  const dim3 grid(RED_DW_BLOCKS + (a.D + 15) / 16);
+  const dim3 grid(RED_DW_BLOCKS + (a.D + 15) / 16 + 1);      // + the loss block
   if (a.F % 4 == 0) hipLaunchKernelGGL(k_reduce<true>, grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL(k_reduce<false>, grid, dim3(256), 0, s, a);
 }

@@ -13,6 +13,9 @@
 // Both: 256x256 output tile per 512-thread workgroup, K advanced 64 at a time, operand tiles
 // brought HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, 16 B per lane; the gather is simply the
 // per-lane source address), double buffered; 8 waves x (8x4) MFMA 16x16x32 accumulators.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include "vv_internal.h"
 
 namespace vv {
@@ -666,7 +669,9 @@ static void launch_fwd_t(const FwdArgs& a, hipStream_t s) {
     // Dedup mode sizes the tiles for the expected row count (R_hint, the previous step's) while the grid
     // covers the worst case R; surplus workgroups exit at once.
     if (g_gemm_variant != 1) {
-      const int Rh = a.n_dev && a.R_hint > 0 ? a.R_hint : a.R;
+      // the hint is a few steps old: leave 3 % + 64 rows of slack so that a slightly larger batch does not
+      // spill into one more round of workgroups
+      const int Rh = a.n_dev && a.R_hint > 0 ? (int)std::min<long>(a.R, a.R_hint + a.R_hint / 32 + 64) : a.R;
       int best = 8; long best_cost = -1;
       for (int mi = 8; mi >= (a.n_dev ? 4 : 7); --mi) {
         const long tiles = ((Rh + 32 * mi - 1) / (32 * mi)) * (long)(Dp / BN);
@@ -674,6 +679,7 @@ static void launch_fwd_t(const FwdArgs& a, hipStream_t s) {
         if (best_cost < 0 || cost < best_cost) { best = mi; best_cost = cost; }
       }
       if (g_fwd_mi) best = g_fwd_mi;
+      if (getenv("VV_DEBUG_MI")) fprintf(stderr, "fwd tile: hint %d R %d -> MI %d\n", a.R_hint, a.R, best);
       const int sched = g_gemm_variant != 3;     // default: interleaved staging + setprio (variant 3 = burst staging, for A/B)
 #define VV_FWD_MI(M, SC)                                                                                      \
       if (best == M && sched == SC) {                                                                        \

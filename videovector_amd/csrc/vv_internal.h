@@ -80,7 +80,8 @@ struct ScoreArgs {
 // the projection is computed once per unique row and the gradient rows of its instances are summed
 // before the weight-gradient GEMM.
 struct DedupArgs {
-  const int32_t* rows;           // [Rp] instance -> table row (k_map_rows)
+  const int32_t* idx;            // [R] batch indices as sampled (-1 = empty slot)
+  int32_t* rows;                 // [Rp] instance -> table row, written by k_dd_claim (what k_map_rows writes)
   unsigned long long* key;       // [table rows + scratch] epoch-tagged leader election
   unsigned long long* agg;       // [2][agg_stride] epoch-tagged block aggregates of the two scans
   int agg_stride;
@@ -92,6 +93,7 @@ struct DedupArgs {
   int32_t* seg_start;            // [Rp + 1]
   int32_t* pos;                  // [R] instance -> row of the grouped gradient buffer
   int32_t* info;                 // device {U, ...}
+  int32_t* u_host;               // host-mapped copy of U (read one or more steps late by the launcher)
   int R, Rp; int32_t zero_row; uint32_t epoch;
 };
 
@@ -122,6 +124,8 @@ struct ReduceArgs {
   float* grads;            // [D*F + D]
   int D, F;
   float ip_scale;          // 1 + regularization/2 (inner_product_layer.cpp:80-90), normally 1
+  // the loss reduction rides in one extra workgroup: loss = loss_scale * sum(loss_part), violations = sum(viol_part)
+  const float* loss_part; const float* viol_part; float loss_scale; float* loss_out;
 };
 
 struct SgdArgs {
