@@ -132,10 +132,15 @@ __global__ __launch_bounds__(256) void k_dd_pos(DedupArgs a) {
   if (r < a.R) a.pos[r] = a.seg_start[a.map[r]] + a.ord[r];
 }
 
+// part 1: what the forward GEMM needs (distinct rows and their count)
 void launch_dedup(const DedupArgs& a, hipStream_t s) {
   const int g256 = (a.Rp + 255) / 256;
   hipLaunchKernelGGL(k_dd_claim, dim3(g256), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_dd_leaders, dim3((a.R + DD_BLOCK - 1) / DD_BLOCK), dim3(DD_BLOCK), 0, s, a);
+}
+// part 2: what the score kernel needs (instance -> slot / grouped gradient row); independent of the
+// forward GEMM, so the caller may run it on a second stream beside it
+void launch_dedup_groups(const DedupArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_dd_map, dim3((a.R + 255) / 256), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_dd_segstart, dim3(a.R / DD_BLOCK + 1), dim3(DD_BLOCK), 0, s, a);
   hipLaunchKernelGGL(k_dd_pos, dim3((a.R + 255) / 256), dim3(256), 0, s, a);

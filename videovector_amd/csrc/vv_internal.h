@@ -144,6 +144,7 @@ void launch_fwd_gemm(int prec, const FwdArgs& a, hipStream_t s);
 void launch_wgrad_gemm(int prec, const WgradArgs& a, hipStream_t s);
 void launch_score_loss(int prec, const ScoreArgs& a, hipStream_t s);
 void launch_dedup(const DedupArgs& a, hipStream_t s);
+void launch_dedup_groups(const DedupArgs& a, hipStream_t s);
 void launch_segsum(int prec, const SegsumArgs& a, hipStream_t s);
 void launch_gather_rows_f32(const float* src, const int32_t* map, int R, int D, float* dst, hipStream_t s);
 void launch_gather_rows_u16(const uint16_t* src, const int32_t* pos, int R, int Dp, uint16_t* dst, hipStream_t s);
