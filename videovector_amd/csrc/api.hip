@@ -454,7 +454,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
 
   // De-duplicate the batch rows when dropout is off (with dropout every instance has its own mask on
   // top of the shared projection; that path stays dense).  Needs the default two-buffer GEMM kernels.
-  const bool dd = c->dedup && cfg->dropout_ratio == 0.f && (gemm_variant() == 0 || gemm_variant() == 3) && !ablate_on();
+  const bool dd = c->dedup && cfg->dropout_ratio == 0.f && (gemm_variant() == 0 || gemm_variant() == 3 || gemm_variant() == 4) && !ablate_on();
   c->last_dedup = dd;
   if (!dd) launch_map_rows(didx, c->rows, c->R, c->Rp, (int32_t)c->n_rows, s);
   if (dd) {

@@ -420,7 +420,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ring(FwdArgs a) {
   const int wm = wave >> 2, wn = wave & 3;
   const int Dp = (int)round_up(a.D, D_ALIGN);
   const int tilesN = Dp / BN;
-  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int R = a.n_dev ? *a.n_dev : a.R;
+  const int nact = a.n_dev ? ((R + BM - 1) / BM) * tilesN : (int)gridDim.x;
+  if ((int)blockIdx.x >= nact) return;
+  const int L = xcd_remap(blockIdx.x, nact);
   const int m0 = (L / tilesN) * BM, n0 = (L % tilesN) * BN;
   const int Fp = a.Fp;
 
@@ -430,7 +433,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ring(FwdArgs a) {
   for (int i = 0; i < 2; ++i) {
     const int c = (i * 8 + wave) * 64 + lane;
     const int row = c >> 2, lc = (c & 3) ^ fw_f(row);
-    a_src[i] = a.table + (int64_t)a.rows[m0 + row] * Fp + lc * 8;
+    a_src[i] = a.table + (int64_t)(m0 + row < R ? a.rows[m0 + row] : a.zero_row) * Fp + lc * 8;
     b_src[i] = a.Wh + (int64_t)(n0 + row) * Fp + lc * 8;
   }
 
@@ -486,7 +489,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ring(FwdArgs a) {
 #pragma unroll
   for (int mi = 0; mi < 8; ++mi) {
     const int m = m0 + wm * 128 + mi * 16 + frow;
-    if (m >= a.R) continue;
+    if (m >= R) continue;
     int64_t ref_row = 0;
     if (DROP) {
       const int bb = m / a.CN, ch = m - bb * a.CN;
@@ -695,7 +698,7 @@ static void launch_fwd_t(const FwdArgs& a, hipStream_t s) {
 #undef VV_FWD_MI
     }
   }
-  if (g_gemm_variant == 1) {
+  if (g_gemm_variant == 1 || g_gemm_variant == 4) {
     static bool once2 = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ring<T, DROP, VEC>,
                          hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES), true);
     (void)once2;
