@@ -30,7 +30,8 @@ class Net {
   void Backward() {}                              // gradients are produced by ForwardBackward
   // net.cpp:803-839: applies the update prepared by the solver (fused decay + momentum + step)
   void Update();
-  void SetUpdateHyperParams(float rate, float momentum, float weight_decay, const string& reg);
+  void SetUpdateHyperParams(float rate, float momentum, float weight_decay, const string& reg, int solver_type = 0,
+                            float delta = 1e-8f);
 
   // net.cpp:638-667: a TEST net takes the weights of the train net (device-to-device through the host)
   void ShareTrainedLayersWith(Net* other);
@@ -68,7 +69,7 @@ class Net {
   struct FusedPlan {
     int B = 0, C = 0, Nn = 0, F = 0, D = 0;
     float margin = 1.f; int norm = VV_NORM_L1; float loss_weight = 1.f;
-    vector<float> ctx_coeff; float dropout_ratio = 0.f;
+    vector<float> ctx_coeff; float dropout_ratio = 0.f; float ip_regularization = 0.f;
     int data_layer = -1, ip_layer = -1, loss_layer = -1;
     string ip2_blob, target_score_blob, negative_scores_blob, loss_blob, violations_blob;
     // TEST / extraction graph: window-mean -> fc7 -> ReLU [-> NORMALIZATION] [-> RETRIEVAL_STATS]

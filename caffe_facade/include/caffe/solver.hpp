@@ -48,9 +48,33 @@ class SGDSolver : public Solver<Dtype> {
   virtual void PreSolve();
   Dtype GetLearningRate();                          // solver.cpp:440-460
   virtual void ComputeUpdateValue();                // solver.cpp:485-531
+  virtual int solver_type() const { return VV_SOLVER_SGD; }
   virtual void SnapshotSolverState(SolverState* state);     // solver.cpp:578-586
   virtual void RestoreSolverState(const SolverState& state);  // solver.cpp:588-596
   vector<shared_ptr<Blob<Dtype> > > history_;
+};
+
+// solver.hpp:96-113: same hyper-parameters, the update rule differs (solver.cpp:599-655) -- in the fused k_sgd kernel
+template <typename Dtype>
+class NesterovSolver : public SGDSolver<Dtype> {
+ public:
+  explicit NesterovSolver(const SolverParameter& param) : SGDSolver<Dtype>(param) {}
+  explicit NesterovSolver(const string& param_file) : SGDSolver<Dtype>(param_file) {}
+ protected:
+  virtual int solver_type() const { return VV_SOLVER_NESTEROV; }
+};
+
+// solver.hpp:115-126, solver.cpp:714-781
+template <typename Dtype>
+class AdaGradSolver : public SGDSolver<Dtype> {
+ public:
+  explicit AdaGradSolver(const SolverParameter& param) : SGDSolver<Dtype>(param) { constructor_sanity_check(); }
+  explicit AdaGradSolver(const string& param_file) : SGDSolver<Dtype>(param_file) { constructor_sanity_check(); }
+ protected:
+  virtual int solver_type() const { return VV_SOLVER_ADAGRAD; }
+  void constructor_sanity_check() {
+    CHECK_EQ(0, this->param_.get_num("momentum")) << "Momentum cannot be used with AdaGrad.";       // solver.hpp:121-122
+  }
 };
 
 template <typename Dtype>

@@ -213,7 +213,7 @@ void Net<Dtype>::MatchVideovecTrainGraph() {
       P.ip_layer = (int)li;
       P.D = static_cast<InnerProductLayer<Dtype>*>(layer)->num_output();
       if (!layer->layer_param().get_msg("inner_product_param").get_bool("bias_term")) bad("bias_term: false is not built");
-      if (layer->layer_param().get_msg("inner_product_param").get_num("regularization") != 0) bad("InnerProduct regularization is not built");
+      P.ip_regularization = (float)layer->layer_param().get_msg("inner_product_param").get_num("regularization");
       sym[ti[0]].k = K_Y;
     } else if (type == "RELU") {
       if (in(0).k != K_Y) bad("RELU is expected on the fc output");
@@ -278,6 +278,7 @@ void Net<Dtype>::MatchVideovecTrainGraph() {
   cfg_.margin = P.margin; cfg_.norm = P.norm; cfg_.loss_weight = P.loss_weight;
   cfg_.ctx_coeff = P.ctx_coeff.data();
   cfg_.dropout_ratio = P.dropout_ratio;
+  cfg_.ip_regularization = P.ip_regularization;
   cfg_.dropout_seed = Caffe::random_seed();
   // blobs_lr / weight_decay multipliers of fc7's {W, b} (mednet_embedding_train.prototxt:195-198)
   int p0 = 0;
@@ -349,8 +350,10 @@ template <typename Dtype>
 const vector<Blob<Dtype>*>& Net<Dtype>::ForwardPrefilled(Dtype* loss) { return Forward(vector<Blob<Dtype>*>(), loss); }
 
 template <typename Dtype>
-void Net<Dtype>::SetUpdateHyperParams(float rate, float momentum, float weight_decay, const string& reg) {
+void Net<Dtype>::SetUpdateHyperParams(float rate, float momentum, float weight_decay, const string& reg, int solver_type,
+                                      float delta) {
   cfg_.lr = rate; cfg_.momentum = momentum; cfg_.weight_decay = weight_decay;
+  cfg_.solver_type = solver_type; cfg_.delta = delta;
   if (reg == "L2") cfg_.reg = VV_REG_L2;
   else if (reg == "L1") cfg_.reg = VV_REG_L1;
   else LOG(FATAL) << "Unknown regularization type: " << reg;                          // solver.cpp:523

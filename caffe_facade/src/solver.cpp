@@ -222,7 +222,7 @@ void SGDSolver<Dtype>::ComputeUpdateValue() {
   if (this->param_.get_int("display") && this->iter_ % this->param_.get_int("display") == 0)
     LOG(INFO) << "Iteration " << this->iter_ << ", lr = " << rate;                    // solver.cpp:492-494
   this->net_->SetUpdateHyperParams(rate, (float)this->param_.get_num("momentum"), (float)this->param_.get_num("weight_decay"),
-                                   this->param_.get_str("regularization_type"));
+                                   this->param_.get_str("regularization_type"), solver_type(), (float)this->param_.get_num("delta"));
 }
 template <typename Dtype>
 const vector<shared_ptr<Blob<Dtype> > >& SGDSolver<Dtype>::history() { this->net_->GetHistory(&history_); return history_; }
@@ -245,12 +245,16 @@ template <typename Dtype>
 Solver<Dtype>* GetSolver(const SolverParameter& param) {
   const string type = param.get_enum("solver_type");
   if (type == "SGD") return new SGDSolver<Dtype>(param);
-  LOG(FATAL) << "Solver type " << type << " is not built (the project's solver file uses SGD)";
+  if (type == "NESTEROV") return new NesterovSolver<Dtype>(param);
+  if (type == "ADAGRAD") return new AdaGradSolver<Dtype>(param);
+  LOG(FATAL) << "Unknown SolverType: " << type;                                        // solver.hpp:141
   return nullptr;
 }
 
 template class Solver<float>;
 template class SGDSolver<float>;
+template class NesterovSolver<float>;
+template class AdaGradSolver<float>;
 template Solver<float>* GetSolver(const SolverParameter& param);
 
 }  // namespace caffe

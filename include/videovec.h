@@ -30,6 +30,8 @@ enum { VV_PREC_F16 = 0, VV_PREC_BF16 = 1 };
 enum { VV_NORM_L1 = 1, VV_NORM_L2 = 2 };
 /* SolverParameter.regularization_type (caffe.proto:130-132). */
 enum { VV_REG_L1 = 1, VV_REG_L2 = 2 };
+/* SolverParameter.solver_type (caffe.proto SolverType). */
+enum { VV_SOLVER_SGD = 0, VV_SOLVER_NESTEROV = 1, VV_SOLVER_ADAGRAD = 2 };
 
 /* One context per process / GPU.  Replaces Caffe::SetDevice + Caffe::set_mode(GPU)
  * (src/caffe/common.cpp:127-145, tools/caffe.cpp:92-104). */
@@ -96,6 +98,14 @@ typedef struct {
   float lr, momentum, weight_decay;
   float lr_mult[2], decay_mult[2];
   int32_t reg;
+  /* SolverParameter.solver_type (caffe.proto: SGD = 0, NESTEROV = 1, ADAGRAD = 2; GetSolver, solver.hpp:128-143):
+   * NesterovSolver / AdaGradSolver::ComputeUpdateValue (solver.cpp:599-655, 714-781).  delta = AdaGrad's
+   * stability constant (SolverParameter.delta, default 1e-8); AdaGrad requires momentum == 0 (solver.hpp:121). */
+  int32_t solver_type;
+  float delta;
+  /* InnerProductParameter.regularization (inner_product_layer.cpp:80-90): the weight gradient is scaled by
+   * 1 + regularization / 2 when regularization > 0.  0 = the shipped files' default. */
+  float ip_regularization;
 } vv_step_cfg;
 
 /* Defaults of the shipped project files (mednet_embedding_train.prototxt:195-198,655-671,

@@ -82,6 +82,8 @@ def lib():
                                         C.c_int]
         L.orc_sgd_update.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                      C.c_float, C.c_float, C.c_float, C.c_float, C.c_int]
+        L.orc_solver_update.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                        C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float]
         L.orc_normalize_fwd.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_normalize_bwd.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_max_margin_fwd.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
@@ -252,12 +254,16 @@ def learning_rate(policy, base_lr, gamma, power, stepsize, it):
     return lib().orc_learning_rate(policy.encode(), base_lr, gamma, power, stepsize, it)
 
 
-def sgd_update(w, grad, hist, rate, lr_mult, momentum, weight_decay, decay_mult, reg="L2"):
-    """In place on float32 contiguous arrays (as Blob::Update does)."""
+SOLVER_TYPES = {"SGD": 0, "NESTEROV": 1, "ADAGRAD": 2}
+
+
+def sgd_update(w, grad, hist, rate, lr_mult, momentum, weight_decay, decay_mult, reg="L2", solver="SGD",
+               delta=1e-8):
+    """In place on float32 contiguous arrays (as Blob::Update does).  solver: SGD / NESTEROV / ADAGRAD."""
     for a in (w, grad, hist):
         assert a.dtype == np.float32 and a.flags.c_contiguous
-    lib().orc_sgd_update(w.size, _p(w), _p(grad), _p(hist), rate, lr_mult, momentum, weight_decay,
-                         decay_mult, 2 if reg == "L2" else 1)
+    lib().orc_solver_update(w.size, _p(w), _p(grad), _p(hist), rate, lr_mult, momentum, weight_decay,
+                            decay_mult, 2 if reg == "L2" else 1, SOLVER_TYPES[solver], delta)
 
 
 def forward_backward(table, idx, W, b, *, C_, Nn, margin=2.0, norm=2, loss_weight=1.0,

@@ -443,6 +443,36 @@ void orc_sgd_update(int64_t n, float* w, float* grad, float* hist, float rate, f
   for (int64_t i = 0; i < n; ++i) w[i] -= grad[i];
 }
 
+/* NesterovSolver / AdaGradSolver::ComputeUpdateValue, CPU branches (solver.cpp:599-655, 714-781), then
+ * Blob::Update.  solver_type: 0 SGD, 1 NESTEROV, 2 ADAGRAD (caffe.proto SolverParameter.SolverType). */
+void orc_solver_update(int64_t n, float* w, float* grad, float* hist, float rate, float lr_mult,
+                       float momentum, float weight_decay, float decay_mult, int reg, int solver_type,
+                       float delta) {
+  if (solver_type == 0) { orc_sgd_update(n, w, grad, hist, rate, lr_mult, momentum, weight_decay, decay_mult, reg); return; }
+  const float local_rate = rate * lr_mult, local_decay = weight_decay * decay_mult;
+  if (local_decay != 0.f) {
+    if (reg == 2) for (int64_t i = 0; i < n; ++i) grad[i] += local_decay * w[i];
+    else for (int64_t i = 0; i < n; ++i)
+      grad[i] += local_decay * (float)((w[i] > 0.f) - (w[i] < 0.f));
+  }
+  float* update = (float*)malloc((size_t)(n ? n : 1) * sizeof(float));
+  if (solver_type == 1) {
+    for (int64_t i = 0; i < n; ++i) update[i] = hist[i];                               /* save history momentum */
+    for (int64_t i = 0; i < n; ++i) hist[i] = local_rate * grad[i] + momentum * hist[i];
+    for (int64_t i = 0; i < n; ++i) update[i] = (1.f + momentum) * hist[i] + -momentum * update[i];   /* step back then over step */
+    for (int64_t i = 0; i < n; ++i) grad[i] = update[i];
+  } else {
+    for (int64_t i = 0; i < n; ++i) update[i] = powf(grad[i], 2.f);                    /* caffe_powx(diff, 2) */
+    for (int64_t i = 0; i < n; ++i) hist[i] = update[i] + hist[i];
+    for (int64_t i = 0; i < n; ++i) update[i] = powf(hist[i], 0.5f);
+    for (int64_t i = 0; i < n; ++i) update[i] += delta;
+    for (int64_t i = 0; i < n; ++i) update[i] = grad[i] / update[i];
+    for (int64_t i = 0; i < n; ++i) grad[i] = local_rate * update[i];
+  }
+  free(update);
+  for (int64_t i = 0; i < n; ++i) w[i] -= grad[i];
+}
+
 /* ============================================================ whole step ==================== */
 static float* falloc(size_t n) {
   float* p = (float*)calloc(n ? n : 1, sizeof(float));

@@ -104,6 +104,9 @@ float orc_learning_rate(const char* policy, float base_lr, float gamma, float po
 /* solver.cpp:502-531 + blob.cpp:112-136 for one parameter blob; reg: 2 = L2, 1 = L1 */
 void orc_sgd_update(int64_t n, float* w, float* grad, float* hist, float rate, float lr_mult,
                     float momentum, float weight_decay, float decay_mult, int reg);
+void orc_solver_update(int64_t n, float* w, float* grad, float* hist, float rate, float lr_mult,
+                       float momentum, float weight_decay, float decay_mult, int reg, int solver_type,
+                       float delta);
 
 /* ------------------------------------------------------------------ whole training step ---- */
 typedef struct {

@@ -106,6 +106,43 @@ def test_caffe_train_matches_oracle_trajectory(tool, pb, oracle, tmp_path, dedup
     assert np.array_equal(np.array(st2.history[0].data, np.float32), np.array(st.history[0].data, np.float32))
 
 
+@pytest.mark.parametrize("stype,mom", [("NESTEROV", 0.9), ("ADAGRAD", 0.0)])
+def test_caffe_train_nesterov_and_adagrad_solvers(tool, pb, oracle, tmp_path, stype, mom):
+    # GetSolver (solver.hpp:128-143) -> NesterovSolver / AdaGradSolver; two iterations against the oracle
+    # (short enough that the chaotic growth of rounding differences stays below the bound)
+    B, C, Nn, F, D, V = 32, 5, 2, 128, 32, 50
+    net_p, sol_p = tmp_path / "net.prototxt", tmp_path / "solver.prototxt"
+    net_p.write_text(train_net("synthetic://videos=%d;seed=1701;features=%d" % (V, F), B, C, Nn, D, max_buffer=500,
+                               w_std=0.02))
+    sol_p.write_text(solver(str(net_p), base_lr=0.01, momentum=mom, max_iter=2, display=1, lr_policy="fixed",
+                            snapshot_prefix=str(tmp_path / "snap"), solver_type=stype, delta=1e-6))
+    W0, b0 = init_weights(3, D, F, std=0.02)
+    write_caffemodel(pb, str(tmp_path / "init.caffemodel"), W0, b0)
+    run_caffe(["train", "--solver=%s" % sol_p, "--weights=%s" % (tmp_path / "init.caffemodel")],
+              str(tmp_path / "train.log"), {"VV_DEDUP": "0"})
+    ds = SyntheticVideos(seed=1701, n_videos=V)
+    table = ds.table(F)
+    smp = oracle.Sampler(ds.video_id, ds.n_shots, ds.row_base, batch_size=B, context_size=C, num_negative_samples=Nn,
+                         max_buffer_size=500, negative_swap_percentage=50)
+    Wq, bq = W0.copy(), b0.copy()
+    hW, hb = np.zeros_like(W0), np.zeros_like(b0)
+    for it in range(2):
+        idx = smp.next()[0]
+        r = oracle.forward_backward(table, idx, round_operand(Wq, "f16"), bq, C_=C, Nn=Nn, want=("dW", "db"))
+        oracle.sgd_update(Wq, r["dW"], hW, 0.01, 1.0, mom, 5e-4, 1.0, solver=stype, delta=1e-6)
+        oracle.sgd_update(bq, r["db"], hb, 0.01, 2.0, mom, 5e-4, 0.0, solver=stype, delta=1e-6)
+    Wg, bg, _ = read_caffemodel(pb, str(tmp_path / "snap_iter_2.caffemodel"))
+    st = pb["SolverState"]()
+    st.ParseFromString(open(tmp_path / "snap_iter_2.solverstate", "rb").read())
+    hist = np.array(st.history[0].data, np.float32).reshape(D, F)
+    assert rel_fro(Wg, Wq) <= 1e-3 and rel_fro(bg, bq) <= 2e-3 and rel_fro(hist, hW) <= 5e-3
+    if stype == "ADAGRAD":       # AdaGradSolver's constructor check (solver.hpp:121-122)
+        bad = tmp_path / "bad_solver.prototxt"
+        bad.write_text(solver(str(net_p), momentum=0.9, max_iter=1, solver_type="ADAGRAD"))
+        r = subprocess.run([CAFFE, "train", "--solver=%s" % bad], capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0 and "Momentum cannot be used with AdaGrad" in (r.stderr + r.stdout)
+
+
 def test_caffe_train_shipped_configuration(tool, tmp_path):
     # The shipped project settings (mednet_embedding_train.prototxt:13-23,200,226 and its solver):
     # batch 128, window 5, 10 negatives of which up to 6 from the same video (quirk Q1), 4096 -> 4096,

@@ -301,6 +301,44 @@ def test_sgd_update_rule_teacher_forced(vv, oracle, prec, dedup):
         assert m[0] <= wtol and m[2] <= 2 * wtol and m[1] <= htol and m[3] <= htol
 
 
+@pytest.mark.parametrize("solver,mom", [("NESTEROV", 0.9), ("ADAGRAD", 0.0), ("SGD", 0.9)])
+def test_solver_types_and_ip_regularization_teacher_forced(vv, oracle, solver, mom):
+    # NesterovSolver / AdaGradSolver (solver.cpp:599-655, 714-781) and InnerProduct.regularization
+    # (inner_product_layer.cpp:80-90) in the fused update, each step started from the oracle's state; L1 decay.
+    B, C, Nn, F, D = 32, 5, 4, 256, 128
+    ds, table, idx, W, b = make_case(13, 40, B, C, Nn, F, D, wstd=0.02)
+    eng = vv.Engine(0, "f16")
+    eng.table_set(table)
+    tq = round_table(table, "f16")
+    # AdaGrad starts from a non-zero history: with h = 0 the first update is lr * sign(g), and a gradient element
+    # within rounding of zero would flip a whole +-lr step
+    h0 = 1e-4 if solver == "ADAGRAD" else 0.0
+    t = dict(W=W.copy(), b=b.copy(), hW=np.full_like(W, h0), hb=np.full_like(b, h0))
+    rng = np.random.default_rng(1)
+    for it in range(4):
+        lr = oracle.learning_rate("step", 0.05, 0.5, 0, 2, it)
+        idx = rng.integers(0, ds.n_rows, size=(B, C + Nn)).astype(np.int32)
+        cfg = vv.StepConfig(B, C, Nn, lr=lr, momentum=mom, weight_decay=1e-3, solver_type=solver, delta=1e-6,
+                            ip_regularization=0.5, reg="L1" if it % 2 else "L2")
+        eng.params_set(t["W"], t["b"], t["hW"], t["hb"])
+        eng.step(cfg, idx)
+        r = oracle.forward_backward(tq, idx, round_operand(t["W"], "f16"), t["b"], C_=C, Nn=Nn, ip_regularization=0.5,
+                                    want=("dW", "db"))
+        g_gpu = eng.grads()[0]
+        assert rel_fro(g_gpu, r["dW"]) <= 1e-3
+        kw = dict(reg="L1" if it % 2 else "L2", solver=solver, delta=1e-6)
+        oracle.sgd_update(t["W"], r["dW"], t["hW"], lr, 1.0, mom, 1e-3, 1.0, **kw)
+        oracle.sgd_update(t["b"], r["db"], t["hb"], lr, 2.0, mom, 1e-3, 0.0, **kw)
+        Wg, bg, hWg, hbg = eng.params_get()
+        m = (rel_fro(Wg, t["W"]), rel_fro(hWg, t["hW"]), rel_fro(bg, t["b"]), rel_fro(hbg, t["hb"]))
+        print("SOLVER %s it %d: W=%.3e hW=%.3e b=%.3e hb=%.3e" % ((solver, it) + m))
+        # the update is O(lr) per element with AdaGrad, so the gradient's 2e-4 shows up in W undiminished
+        assert m[0] <= (1e-3 if solver == "ADAGRAD" else 2e-4) and m[2] <= 4e-4 and m[1] <= 2e-3 and m[3] <= 2e-3
+    cfg = vv.StepConfig(B, C, Nn, solver_type="ADAGRAD", momentum=0.9)
+    with pytest.raises(vv.VVError, match="Momentum cannot be used with AdaGrad"):
+        eng.step(cfg, idx)
+
+
 def test_q1_same_video_negatives(vv, oracle):
     # shipped setting max_same_video_negs: 6 -- the data layer copies those rows without their last
     # feature (video_sampled_shots_data_layer.cpp:492); indices from the product sampler

@@ -145,6 +145,38 @@ def test_sgd_update_matches_least_squares_algebra(oracle, lr, wd, mom, iters):
         assert np.allclose(w, w64, rtol=1e-2, atol=1e-4)
 
 
+@pytest.mark.parametrize("solver,lr,wd,mom,iters", [
+    ("NESTEROV", 1.0, 0.0, 0.0, 1), ("NESTEROV", 0.1, 0.0, 0.0, 1), ("NESTEROV", 1.0, 0.5, 0.0, 1),
+    ("NESTEROV", 1.0, 0.0, 0.5, 2), ("NESTEROV", 0.1, 0.0, 0.9, 4), ("NESTEROV", 0.01, 0.1, 0.9, 4),
+    ("ADAGRAD", 1.0, 0.0, 0.0, 1), ("ADAGRAD", 0.1, 0.0, 0.0, 1), ("ADAGRAD", 1.0, 0.5, 0.0, 1),
+    ("ADAGRAD", 0.01, 0.1, 0.0, 4)])
+def test_nesterov_adagrad_updates_match_least_squares_algebra(oracle, solver, lr, wd, mom, iters):
+    # test_gradient_based_solver.cpp:392-485 (AdaGradSolverTest / NesterovSolverTest cases) with the expected update
+    # of ComputeLeastSquaresUpdate (:196-211):
+    #   NESTEROV: u = lr*g + m*h ; update = (1+m)*u - m*h      ADAGRAD: update = lr*g / (sqrt(h + g^2) + delta)
+    # (g includes the weight decay term; precision 1e-2 relative as CheckLeastSquaresUpdate :227-236)
+    delta = 1e-8
+    rng = np.random.default_rng(1701)
+    X = rng.standard_normal((5, 300)).astype(np.float64)
+    yv = rng.standard_normal(5)
+    w = rng.standard_normal(300).astype(np.float32)
+    hist = np.zeros_like(w)
+    w64, h64 = w.astype(np.float64), np.zeros(300)
+    for _ in range(iters + 1):
+        g64 = X.T @ (X @ w64 - yv) / 5 + wd * w64
+        grad = (X.T @ (X @ w.astype(np.float64) - yv) / 5).astype(np.float32)
+        oracle.sgd_update(w, grad, hist, lr, 1.0, mom, wd, 1.0, solver=solver, delta=delta)
+        if solver == "NESTEROV":
+            u = lr * g64 + mom * h64
+            upd, h64 = (1 + mom) * u - mom * h64, u
+        else:
+            h64 = h64 + g64 * g64
+            upd = lr * g64 / (np.sqrt(h64) + delta)
+        w64 = w64 - upd
+        assert np.allclose(hist, h64, rtol=1e-2, atol=1e-4)
+        assert np.allclose(w, w64, rtol=1e-2, atol=1e-4)
+
+
 def test_sgd_lr_and_decay_multipliers_and_l1(oracle):
     # solver.cpp:502-531: local_rate = rate*lr_mult, local_decay = wd*decay_mult; L1 uses sign(w)
     w = np.array([1.0, -2.0, 0.0, 3.0], np.float32)

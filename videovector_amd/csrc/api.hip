@@ -113,6 +113,7 @@ void vv_step_cfg_default(vv_step_cfg* cfg) {
   cfg->lr_mult[0] = 1.f; cfg->lr_mult[1] = 2.f;
   cfg->decay_mult[0] = 1.f; cfg->decay_mult[1] = 0.f;
   cfg->reg = VV_REG_L2;
+  cfg->solver_type = VV_SOLVER_SGD; cfg->delta = 1e-8f; cfg->ip_regularization = 0.f;
 }
 
 int vv_create(int device, int prec, vv_ctx** out) {
@@ -418,6 +419,9 @@ static int check_cfg(vv_ctx* c, const vv_step_cfg* cfg) {
   if (cfg->norm != VV_NORM_L1 && cfg->norm != VV_NORM_L2) return fail(VV_ERR_ARG, "Unknown Norm (max_margin_loss_layer.cpp:120)");
   if (cfg->dropout_ratio < 0.f || cfg->dropout_ratio >= 1.f) return fail(VV_ERR_ARG, "dropout_ratio must be in [0,1)");
   if (cfg->reg != VV_REG_L1 && cfg->reg != VV_REG_L2) return fail(VV_ERR_ARG, "Unknown regularization type (solver.cpp:523)");
+  if (cfg->solver_type < VV_SOLVER_SGD || cfg->solver_type > VV_SOLVER_ADAGRAD) return fail(VV_ERR_ARG, "Unknown SolverType (solver.hpp:141)");
+  if (cfg->solver_type == VV_SOLVER_ADAGRAD && cfg->momentum != 0.f) return fail(VV_ERR_ARG, "Momentum cannot be used with AdaGrad. (solver.hpp:121-122)");
+  if (cfg->ip_regularization < 0.f) return fail(VV_ERR_ARG, "ip_regularization must be >= 0");
   return VV_OK;
 }
 
@@ -525,7 +529,8 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
 
   ReduceArgs ra;
   ra.slabs = c->slabs; ra.S = c->S; ra.Dp = c->Dp; ra.Fp = c->Fp; ra.dbp = c->dbp; ra.B = B;
-  ra.scales = c->scales; ra.sg = c->sg; ra.grads = c->grads; ra.D = D; ra.F = c->F; ra.ip_scale = 1.f;
+  ra.scales = c->scales; ra.sg = c->sg; ra.grads = c->grads; ra.D = D; ra.F = c->F;
+  ra.ip_scale = cfg->ip_regularization > 0.f ? 1.f + cfg->ip_regularization * 0.5f : 1.f;     // inner_product_layer.cpp:80-90
   ra.loss_part = c->loss_part; ra.viol_part = c->viol_part; ra.loss_scale = cfg->loss_weight / (float)count; ra.loss_out = c->loss2;
   PROFILED(c, "reduce", launch_reduce(ra, s));
 
@@ -592,7 +597,7 @@ int vv_apply_update(vv_ctx* c, const vv_step_cfg* cfg) {
   a.rate = cfg->lr; a.momentum = cfg->momentum; a.weight_decay = cfg->weight_decay;
   a.lr_mult_w = cfg->lr_mult[0]; a.lr_mult_b = cfg->lr_mult[1];
   a.decay_mult_w = cfg->decay_mult[0]; a.decay_mult_b = cfg->decay_mult[1];
-  a.reg = cfg->reg;
+  a.reg = cfg->reg; a.solver_type = cfg->solver_type; a.delta = cfg->delta;
   PROFILED(c, "sgd", launch_sgd(c->prec, a, c->stream));
   launch_scale_update(c->prec, c->scales, c->wmax_blocks, c->stream);
   HIPCHK(hipGetLastError());

@@ -525,10 +525,17 @@ __global__ __launch_bounds__(256) void k_sgd(SgdArgs a) {
   const int64_t nW = (int64_t)a.D * a.F;
   const float lr_w = a.rate * a.lr_mult_w, dc_w = a.weight_decay * a.decay_mult_w;
   float wmax = 0.f;
+  // one parameter element: regulariser, then SGD (solver.cpp:502-531), Nesterov (:599-655) or AdaGrad (:714-781)
+  auto rule = [&](float w, float g, float& h, float lr, float dc) {
+    if (dc != 0.f) g += dc * (a.reg == 2 ? w : (float)((w > 0.f) - (w < 0.f)));
+    float u;
+    if (a.solver_type == 1) { const float h0 = h; h = lr * g + a.momentum * h0; u = (1.f + a.momentum) * h - a.momentum * h0; }
+    else if (a.solver_type == 2) { h += g * g; u = lr * (g / (sqrtf(h) + a.delta)); }
+    else { h = lr * g + a.momentum * h; u = h; }
+    return w - u;
+  };
   auto upd = [&](float w, float g, float& h) {
-    if (dc_w != 0.f) g += dc_w * (a.reg == 2 ? w : (float)((w > 0.f) - (w < 0.f)));
-    h = lr_w * g + a.momentum * h;
-    w -= h;
+    w = rule(w, g, h, lr_w, dc_w);
     wmax = fmaxf(wmax, fabsf(w));
     return w;
   };
@@ -559,11 +566,9 @@ __global__ __launch_bounds__(256) void k_sgd(SgdArgs a) {
   }
   const float lr_b = a.rate * a.lr_mult_b, dc_b = a.weight_decay * a.decay_mult_b;
   for (int d = blockIdx.x * 256 + threadIdx.x; d < a.D; d += gridDim.x * 256) {
-    float w = a.b[d], g = a.grads[nW + d];
-    if (dc_b != 0.f) g += dc_b * (a.reg == 2 ? w : (float)((w > 0.f) - (w < 0.f)));
-    const float h = lr_b * g + a.momentum * a.hb[d];
+    float h = a.hb[d];
+    a.b[d] = rule(a.b[d], a.grads[nW + d], h, lr_b, dc_b);
     a.hb[d] = h;
-    a.b[d] = w - h;
   }
   // per-block max |w| -> one slot per block (no atomics: thousands of adds on one address
   // serialise at ~12 ns each); k_scale_update folds the slots

@@ -137,6 +137,8 @@ struct SgdArgs {
   float rate, momentum, weight_decay;
   float lr_mult_w, lr_mult_b, decay_mult_w, decay_mult_b;
   int reg;
+  int solver_type;         // 0 SGD, 1 Nesterov, 2 AdaGrad
+  float delta;             // AdaGrad stability constant
 };
 
 // kernel launchers (defined in the .hip files); prec: 0 = f16, 1 = bf16

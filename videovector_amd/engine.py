@@ -27,7 +27,8 @@ class _StepCfg(C.Structure):
                 ("dropout_ratio", C.c_float), ("dropout_mask", C.c_void_p),
                 ("dropout_seed", C.c_uint64), ("global_count", C.c_int64),
                 ("lr", C.c_float), ("momentum", C.c_float), ("weight_decay", C.c_float),
-                ("lr_mult", C.c_float * 2), ("decay_mult", C.c_float * 2), ("reg", C.c_int32)]
+                ("lr_mult", C.c_float * 2), ("decay_mult", C.c_float * 2), ("reg", C.c_int32),
+                ("solver_type", C.c_int32), ("delta", C.c_float), ("ip_regularization", C.c_float)]
 
 
 _lib = None
@@ -112,6 +113,8 @@ class StepConfig:
             getattr(self.c, k)[0], getattr(self.c, k)[1] = float(v[0]), float(v[1])
         elif k == "reg":
             self.c.reg = {"L1": 1, "L2": 2}.get(v, v)
+        elif k == "solver_type":
+            self.c.solver_type = {"SGD": 0, "NESTEROV": 1, "ADAGRAD": 2}.get(v, v)
         elif k == "norm":
             self.c.norm = {"L1": 1, "L2": 2}.get(v, v)
         else:
