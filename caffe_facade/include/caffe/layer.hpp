@@ -8,6 +8,7 @@
 // Net::Init (net.hpp).  Calling Forward/Backward on a single layer is fatal, with the same
 // abort-on-error convention the reference uses for unsupported configurations.
 #pragma once
+#include <map>
 #include <thread>
 
 #include "caffe/blob.hpp"
@@ -231,6 +232,12 @@ class MaxMarginLossLayer : public Layer<Dtype> {  // max_margin_loss_layer.cpp:1
   virtual bool AutoTopBlobs() const { return true; }
   virtual void LayerSetUp(const vector<Blob<Dtype>*>& bottom, vector<Blob<Dtype>*>* top);
   virtual void Reshape(const vector<Blob<Dtype>*>& bottom, vector<Blob<Dtype>*>* top);
+  // third bottom -> weight of one loss term: the value itself (use_direct_weight) or the id_to_weight_file entry,
+  // 0 for ids the file does not list (std::map::operator[], max_margin_loss_layer.cpp:90-96)
+  float WeightOf(float third_bottom_value) const;
+ private:
+  std::map<int, float> video_id_to_weight_;
+  bool use_direct_weight_ = false;
 };
 
 // VIDEO_SHOT_WINDOW_TEST_DATA (video_shot_window_test_data_layer.cpp:37-265): one record per item,

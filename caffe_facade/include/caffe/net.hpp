@@ -69,7 +69,7 @@ class Net {
   struct FusedPlan {
     int B = 0, C = 0, Nn = 0, F = 0, D = 0;
     float margin = 1.f; int norm = VV_NORM_L1; float loss_weight = 1.f;
-    vector<float> ctx_coeff; float dropout_ratio = 0.f; float ip_regularization = 0.f;
+    vector<float> ctx_coeff; float dropout_ratio = 0.f; float ip_regularization = 0.f; bool weighted_loss = false;
     int data_layer = -1, ip_layer = -1, loss_layer = -1;
     string ip2_blob, target_score_blob, negative_scores_blob, loss_blob, violations_blob;
     // TEST / extraction graph: window-mean -> fc7 -> ReLU [-> NORMALIZATION] [-> RETRIEVAL_STATS]
@@ -107,6 +107,7 @@ class Net {
   FusedPlan plan_;
   vv_step_cfg cfg_;
   vector<int32_t> idx_, last_src_, label_;
+  vector<float> item_weight_;
   uint64_t iter_ = 0;
 };
 

@@ -543,8 +543,30 @@ template <typename Dtype>
 void MaxMarginLossLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>&, vector<Blob<Dtype>*>*) {
   // LossLayer::LayerSetUp (loss_layer.cpp:13-20): default loss weight 1 on the first top
   if (this->layer_param_.size("loss_weight") == 0) this->layer_param_.add_num("loss_weight", 1.0);
-  CHECK(this->layer_param_.get_msg("max_margin_loss_param").get_str("id_to_weight_file").empty())
-      << "id_to_weight_file (weighted loss) is not built yet";
+  const pl::Message& mp = this->layer_param_.get_msg("max_margin_loss_param");
+  const string file = mp.get_str("id_to_weight_file");
+  if (!file.empty()) {                                               // max_margin_loss_layer.cpp:21-37
+    std::ifstream f(file);
+    string line;
+    while (std::getline(f, line)) {
+      const size_t c = line.find(',');
+      CHECK(c != string::npos && line.find(',', c + 1) == string::npos) << "Line: " << line;
+      size_t sval = 0;
+      const int video_id = std::stoi(line.substr(0, c), &sval);
+      CHECK_EQ(sval, c);
+      const float weight = std::stof(line.substr(c + 1), &sval);
+      CHECK_EQ(sval, line.size() - c - 1);
+      CHECK_GE(weight, 0) << "All weights should be greater than 0";
+      video_id_to_weight_.insert(std::make_pair(video_id, weight));
+    }
+  }
+  use_direct_weight_ = mp.get_bool("use_direct_weight");
+}
+template <typename Dtype>
+float MaxMarginLossLayer<Dtype>::WeightOf(float v) const {
+  if (use_direct_weight_) { CHECK_GE(v, 0.f); return v; }            // :85
+  auto it = video_id_to_weight_.find(static_cast<int>(v));
+  return it == video_id_to_weight_.end() ? 0.f : it->second;
 }
 template <typename Dtype>
 void MaxMarginLossLayer<Dtype>::Reshape(const vector<Blob<Dtype>*>& bottom, vector<Blob<Dtype>*>* top) {

@@ -146,7 +146,7 @@ void Net<Dtype>::Init(const NetParameter& in_param) {
 // ---------------------------------------------------------------------------------------------
 namespace {
 enum Kind { K_NONE, K_DATA, K_DATUM, K_XROWS, K_Y, K_H, K_EMB, K_CTXMEAN, K_CTXNORM, K_PN, K_PNNORM, K_PNORM,
-            K_PROD, K_SCORE, K_NEGSCORES, K_LOSS, K_VIOL, K_LABEL };
+            K_PROD, K_SCORE, K_NEGSCORES, K_LOSS, K_VIOL, K_LABEL, K_LABELREP };
 struct Sym { Kind k = K_NONE; int a = 0; int reps = 1; };
 }
 
@@ -245,6 +245,10 @@ void Net<Dtype>::MatchVideovecTrainGraph() {
       if (in(0).k == K_CTXMEAN) sym[ti[0]].k = K_CTXNORM;
       else if (in(0).k == K_PN) sym[ti[0]].k = K_PNNORM;
       else bad("unexpected NORMALIZATION input");
+    } else if (type == "SUM" && in(0).k == K_LABEL) {
+      // video ids replicated over the Nn loss terms of an item: the weighted loss's third bottom
+      if ((int)layer->layer_param().get_msg("sum_param").get_num("num_output") != P.Nn) bad("the replicated video ids need num_output == num_negative_samples");
+      sym[ti[0]].k = K_LABELREP;
     } else if (type == "SUM") {
       if (in(0).k != K_PROD) bad("SUM is expected on a PROD output");
       const int reps = (int)layer->layer_param().get_msg("sum_param").get_num("num_output");
@@ -255,7 +259,10 @@ void Net<Dtype>::MatchVideovecTrainGraph() {
       } else if (reps != 1) bad("negative score SUM layers must have num_output 1");
     } else if (type == "MAX_MARGIN_LOSS") {
       if (P.loss_layer >= 0) bad("second loss layer");
-      if (bi.size() != 2) bad("the weighted loss (third bottom) is not built yet");
+      if (bi.size() == 3) {
+        if (in(2).k != K_LABELREP && !(in(2).k == K_LABEL && P.Nn == 1)) bad("the third bottom must be the data layer's video ids replicated to (B, Nn) by a SUM layer");
+        P.weighted_loss = true;
+      }
       if (in(0).k != K_SCORE || in(0).a != 0 || in(1).k != K_NEGSCORES) bad("bottoms must be target_score, negative_scores");
       P.loss_layer = (int)li;
       const pl::Message& mp = layer->layer_param().get_msg("max_margin_loss_param");
@@ -328,6 +335,13 @@ Dtype Net<Dtype>::ForwardBackward(const vector<Blob<Dtype>*>&) {
   auto* data = static_cast<VideoSampledShotsDataLayer<Dtype>*>(layers_[plan_.data_layer].get());
   data->NextBatch(&idx_, &last_src_, &label_);
   cfg_.ctx_coeff = plan_.ctx_coeff.data();
+  cfg_.item_weight = nullptr;
+  if (plan_.weighted_loss) {
+    auto* ml = static_cast<MaxMarginLossLayer<Dtype>*>(layers_[plan_.loss_layer].get());
+    item_weight_.resize(plan_.B);
+    for (int i = 0; i < plan_.B; ++i) item_weight_[i] = ml->WeightOf((float)label_[i]);
+    cfg_.item_weight = item_weight_.data();
+  }
   bool q1 = false;
   for (size_t i = 0; i < idx_.size() && !q1; ++i) q1 = idx_[i] != last_src_[i];
   if (q1) VV_CHECK(vv_forward_backward_q1(ctx_, &cfg_, idx_.data(), last_src_.data()));

@@ -106,6 +106,11 @@ typedef struct {
   /* InnerProductParameter.regularization (inner_product_layer.cpp:80-90): the weight gradient is scaled by
    * 1 + regularization / 2 when regularization > 0.  0 = the shipped files' default. */
   float ip_regularization;
+  /* MAX_MARGIN_LOSS's optional third bottom (max_margin_loss_layer.cpp:60-62, 82-97, 152-161, 173-186): a
+   * non-negative weight per loss term, here one per batch item (the reference replicates a per-item blob over the
+   * Nn terms with a SUM layer): L2 loss term w*max(0,m-d)^2, L1 term w*max(0,m-d).  Either the weights themselves
+   * (use_direct_weight) or the values looked up from id_to_weight_file by the caller.  Host [B]; NULL = unweighted. */
+  const float* item_weight;
 } vv_step_cfg;
 
 /* Defaults of the shipped project files (mednet_embedding_train.prototxt:195-198,655-671,

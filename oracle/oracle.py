@@ -44,7 +44,7 @@ class _StepCfg(C.Structure):
                 ("loss_weight", C.c_float), ("ctx_coeff", C.c_void_p),
                 ("dropout_ratio", C.c_float), ("dropout_mask", C.c_void_p),
                 ("relu_negative_slope", C.c_float), ("ip_regularization", C.c_float),
-                ("global_count", C.c_int64)]
+                ("global_count", C.c_int64), ("item_weight", C.c_void_p)]
 
 
 class _StepOut(C.Structure):
@@ -268,7 +268,7 @@ def sgd_update(w, grad, hist, rate, lr_mult, momentum, weight_decay, decay_mult,
 
 def forward_backward(table, idx, W, b, *, C_, Nn, margin=2.0, norm=2, loss_weight=1.0,
                      ctx_coeff=None, dropout_ratio=0.0, dropout_mask=None, last_src=None,
-                     global_count=0, ip_regularization=0.0, want=("dW", "db")):
+                     global_count=0, ip_regularization=0.0, item_weight=None, want=("dW", "db")):
     """One Net::ForwardBackward.  Returns a dict with loss, violations and the requested arrays
     (names of orc_step_out)."""
     table, W = _f32(table), _f32(W)
@@ -281,8 +281,9 @@ def forward_backward(table, idx, W, b, *, C_, Nn, margin=2.0, norm=2, loss_weigh
     coeff = _f32(np.full(C_ - 1, 1.0 / (C_ - 1)) if ctx_coeff is None else ctx_coeff)
     mask = None if dropout_mask is None else np.ascontiguousarray(dropout_mask, dtype=np.uint8)
     last = None if last_src is None else np.ascontiguousarray(last_src, dtype=np.int32)
+    iw = None if item_weight is None else _f32(item_weight)
     cfg = _StepCfg(B, C_, Nn, F, D, margin, norm, loss_weight, _p(coeff), dropout_ratio, _p(mask),
-                   0.0, ip_regularization, global_count)
+                   0.0, ip_regularization, global_count, _p(iw))
     R, Q = CN * B, 1 + Nn
     shapes = dict(Y=(R, D), H=(R, D), ctx=(B, D), posneg=(Q * B, D), s_true=(B, Nn),
                   s_bogus=(B, Nn), dY=(R, D), dW=(D, F), db=(D,))

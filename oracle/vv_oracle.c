@@ -558,15 +558,21 @@ void orc_forward_backward(const orc_step_cfg* cfg, const float* table, const int
   }
   /* --- MAX_MARGIN_LOSS (prototxt :655-671) */
   const int count = B * Nn;
-  orc_max_margin_fwd(count, s_true, s_bogus, NULL, cfg->margin, cfg->norm, &out->loss,
+  float* wrep = NULL;                 /* the 3rd bottom: item weight replicated over the Nn terms (a SUM layer) */
+  if (cfg->item_weight) {
+    wrep = falloc((size_t)count);
+    for (int bb = 0; bb < B; ++bb) for (int k = 0; k < Nn; ++k) wrep[(size_t)bb * Nn + k] = cfg->item_weight[bb];
+  }
+  orc_max_margin_fwd(count, s_true, s_bogus, wrep, cfg->margin, cfg->norm, &out->loss,
                      &out->violations);
   out->loss *= cfg->loss_weight;                                                      /* layer.hpp:416-422 */
 
   /* ================= backward (Net::BackwardFromTo, net.cpp:567-578) ================= */
   float* d_true = falloc((size_t)count + 1);
   float* d_bogus = falloc((size_t)count + 1);
-  orc_max_margin_bwd(count, s_true, s_bogus, NULL, cfg->margin, cfg->norm, cfg->loss_weight,
+  orc_max_margin_bwd(count, s_true, s_bogus, wrep, cfg->margin, cfg->norm, cfg->loss_weight,
                      d_true, d_bogus);
+  free(wrep);
   if (cfg->global_count > 0 && cfg->global_count != count) {
     /* data-parallel shard: the loss normaliser is the GLOBAL B*Nn */
     const float f = (float)count / (float)cfg->global_count;

@@ -119,6 +119,8 @@ typedef struct {
   float   relu_negative_slope;        /* 0 */
   float   ip_regularization;          /* InnerProductParameter.regularization (…:80-90) */
   int64_t global_count;               /* 0 => B*Nn; data-parallel shards pass the global B*Nn */
+  const float* item_weight;           /* [B] or NULL: MAX_MARGIN_LOSS's 3rd bottom (the weight of item b, replicated
+                                         over its Nn terms; max_margin_loss_layer.cpp:82-97, 152-161) */
 } orc_step_cfg;
 
 typedef struct {                      /* every pointer optional (NULL = not wanted) */

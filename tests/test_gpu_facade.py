@@ -143,6 +143,44 @@ def test_caffe_train_nesterov_and_adagrad_solvers(tool, pb, oracle, tmp_path, st
         assert r.returncode != 0 and "Momentum cannot be used with AdaGrad" in (r.stderr + r.stdout)
 
 
+@pytest.mark.parametrize("direct", [False, True])
+def test_caffe_train_weighted_loss_and_ip_regularization(tool, pb, oracle, tmp_path, direct):
+    # third bottom of MAX_MARGIN_LOSS = the data layer's video ids replicated by a SUM layer; weights from
+    # id_to_weight_file (ids missing from the file weigh 0) or the ids themselves (use_direct_weight);
+    # InnerProduct regularization: 0.5 scales dW by 1.25
+    B, C, Nn, F, D, V = 32, 5, 2, 128, 32, 50
+    wfile = tmp_path / "id2w.txt"
+    wmap = {v: 0.25 * (v % 5) + 0.5 for v in range(0, V, 2)}
+    wfile.write_text("".join("%d,%g\n" % kv for kv in wmap.items()))
+    net_p, sol_p = tmp_path / "net.prototxt", tmp_path / "solver.prototxt"
+    net_p.write_text(train_net("synthetic://videos=%d;seed=1701;features=%d" % (V, F), B, C, Nn, D, max_buffer=500, w_std=0.02,
+                               id_to_weight_file=None if direct else str(wfile), use_direct_weight=direct,
+                               ip_regularization=0.5))
+    sol_p.write_text(solver(str(net_p), base_lr=0.002, max_iter=3, display=1, lr_policy="fixed",
+                            snapshot_prefix=str(tmp_path / "snap")))
+    W0, b0 = init_weights(3, D, F, std=0.02)
+    write_caffemodel(pb, str(tmp_path / "init.caffemodel"), W0, b0)
+    log = run_caffe(["train", "--solver=%s" % sol_p, "--weights=%s" % (tmp_path / "init.caffemodel")],
+                    str(tmp_path / "train.log"), {"VV_DEDUP": "0"})
+    losses = [float(x) for x in re.findall(r"Iteration \d+, loss = ([0-9.eE+-]+)", log)]
+    ds = SyntheticVideos(seed=1701, n_videos=V)
+    table = ds.table(F)
+    smp = oracle.Sampler(ds.video_id, ds.n_shots, ds.row_base, batch_size=B, context_size=C, num_negative_samples=Nn,
+                         max_buffer_size=500, negative_swap_percentage=50)
+    Wq, bq = W0.copy(), b0.copy()
+    hW, hb = np.zeros_like(W0), np.zeros_like(b0)
+    for it in range(3):
+        idx, _, label = smp.next()
+        w = label.astype(np.float32) if direct else np.array([wmap.get(int(v), 0.0) for v in label], np.float32)
+        r = oracle.forward_backward(table, idx, round_operand(Wq, "f16"), bq, C_=C, Nn=Nn, item_weight=w,
+                                    ip_regularization=0.5, want=("dW", "db"))
+        assert abs(losses[it] - r["loss"]) <= 1e-3 * r["loss"], (it, losses[it], r["loss"])
+        oracle.sgd_update(Wq, r["dW"], hW, 0.002, 1.0, 0.9, 5e-4, 1.0)
+        oracle.sgd_update(bq, r["db"], hb, 0.002, 2.0, 0.9, 5e-4, 0.0)
+    Wg, bg, _ = read_caffemodel(pb, str(tmp_path / "snap_iter_3.caffemodel"))
+    assert rel_fro(Wg, Wq) <= 2e-3 and rel_fro(bg, bq) <= 4e-3
+
+
 def test_caffe_train_shipped_configuration(tool, tmp_path):
     # The shipped project settings (mednet_embedding_train.prototxt:13-23,200,226 and its solver):
     # batch 128, window 5, 10 negatives of which up to 6 from the same video (quirk Q1), 4096 -> 4096,

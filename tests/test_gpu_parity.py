@@ -89,6 +89,7 @@ def run_both(vv, oracle, prec, table, idx, W, b, C, Nn, **kw):
     okw = dict(C_=C, Nn=Nn, margin=cfg.c.margin, norm=cfg.c.norm, loss_weight=cfg.c.loss_weight,
                ctx_coeff=kw.get("ctx_coeff"), dropout_ratio=kw.get("dropout_ratio", 0.0),
                dropout_mask=kw.get("dropout_mask"), global_count=kw.get("global_count", 0),
+               item_weight=kw.get("item_weight"), ip_regularization=kw.get("ip_regularization", 0.0),
                want=("H", "s_true", "s_bogus", "dY", "dW", "db"))
     ref = oracle.forward_backward(table, idx, W, b, **okw)
     okw["want"] = ("dY", "dW", "db")
@@ -337,6 +338,21 @@ def test_solver_types_and_ip_regularization_teacher_forced(vv, oracle, solver, m
     cfg = vv.StepConfig(B, C, Nn, solver_type="ADAGRAD", momentum=0.9)
     with pytest.raises(vv.VVError, match="Momentum cannot be used with AdaGrad"):
         eng.step(cfg, idx)
+
+
+@pytest.mark.parametrize("norm", ["L1", "L2"])
+def test_weighted_loss_third_bottom(vv, oracle, norm):
+    # MAX_MARGIN_LOSS with per-item term weights (max_margin_loss_layer.cpp:82-97, 152-186), zeros included
+    B, C, Nn, F, D = 48, 5, 6, 256, 96
+    ds, table, idx, W, b = make_case(17, 30, B, C, Nn, F, D, wstd=0.03)
+    w = np.random.default_rng(3).uniform(0, 3, B).astype(np.float32)
+    w[::7] = 0.0
+    eng, cfg, got, ref = run_both(vv, oracle, "f16", table, idx, W, b, C, Nn, item_weight=w, norm=norm, margin=1.5)
+    check(got, ref, TOL["f16"], "weighted-" + norm)
+    plain = oracle.forward_backward(table, idx, W, b, C_=C, Nn=Nn, norm=2 if norm == "L2" else 1, margin=1.5)
+    assert abs(plain["loss"] - ref["loss"]) > 1e-3 * ref["loss"]          # the weights do change the loss
+    with pytest.raises(vv.VVError, match="All weights should be greater than 0"):
+        eng.forward_backward(vv.StepConfig(B, C, Nn, item_weight=-w - 1), idx)
 
 
 def test_q1_same_video_negatives(vv, oracle):

@@ -56,6 +56,7 @@ struct vv_ctx {
   float* H = nullptr; uint16_t* dYh = nullptr; float* dbp = nullptr;
   float *loss_part = nullptr, *viol_part = nullptr, *s_true = nullptr, *s_bogus = nullptr;
   float* coeff = nullptr; std::vector<float> coeff_host;
+  float* item_w = nullptr;          // [B] loss-term weights of the current batch
   uint8_t* mask = nullptr; size_t mask_bytes = 0;
   float* slabs = nullptr; size_t slab_bytes = 0; int S = 1, kps = 0;
   float* loss2 = nullptr;           // {loss, violations}
@@ -167,7 +168,7 @@ int vv_create(int device, int prec, vv_ctx** out) {
 static void free_batch(vv_ctx* c) {
   dfree(c->idx_dev); dfree(c->rows); dfree(c->H); dfree(c->dYh); dfree(c->dbp);
   dfree(c->loss_part); dfree(c->viol_part); dfree(c->s_true); dfree(c->s_bogus);
-  dfree(c->coeff); dfree(c->slabs);
+  dfree(c->coeff); dfree(c->slabs); dfree(c->item_w); c->item_w = nullptr;
   dfree(c->dd_agg); dfree(c->dd_slot_of); dfree(c->dd_uniq); dfree(c->dd_map); dfree(c->dd_ord); dfree(c->dd_cnt);
   dfree(c->dd_seg); dfree(c->dd_pos); dfree(c->dYu);
   c->dd_agg = nullptr; c->dd_slot_of = c->dd_uniq = c->dd_map = c->dd_ord = c->dd_cnt = c->dd_seg = c->dd_pos = nullptr;
@@ -382,6 +383,7 @@ static int ensure_batch(vv_ctx* c, int B, int C, int Nn) {
   HIPCHK(hipMalloc(&c->s_true, (size_t)B * 4));
   HIPCHK(hipMalloc(&c->s_bogus, (size_t)B * std::max(Nn, 1) * 4));
   HIPCHK(hipMalloc(&c->coeff, (size_t)std::max(C - 1, 1) * 4));
+  HIPCHK(hipMalloc(&c->item_w, (size_t)B * 4));
   // split-K so that tiles * S is about one wave of workgroups over the 256 CUs
   const int tiles = (c->Dp / BM) * (c->Fp / BN);
   const int total_steps = c->Rp / BK;
@@ -450,6 +452,11 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
     HIPCHK(hipStreamSynchronize(s));
     c->coeff_host = coeff;
   }
+  if (cfg->item_weight) {
+    for (int i = 0; i < B; ++i)
+      if (!(cfg->item_weight[i] >= 0.f)) return fail(VV_ERR_ARG, "item_weight[%d] = %g: All weights should be greater than 0 (max_margin_loss_layer.cpp:34)", i, (double)cfg->item_weight[i]);
+    HIPCHK(hipMemcpyAsync(c->item_w, cfg->item_weight, (size_t)B * 4, hipMemcpyHostToDevice, s));
+  }
   if (cfg->dropout_ratio > 0.f && cfg->dropout_mask) {
     const size_t nb = (size_t)c->R * D;
     if (nb > c->mask_bytes) { dfree(c->mask); c->mask = nullptr; HIPCHK(hipMalloc(&c->mask, nb)); c->mask_bytes = nb; }
@@ -513,6 +520,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   sa.drop_scale = cfg->dropout_ratio > 0.f ? 1.f / (1.f - cfg->dropout_ratio) : 1.f;
   sa.sg = c->sg;
   sa.map = dd ? c->dd_map : nullptr; sa.pos = dd ? c->dd_pos : nullptr;
+  sa.item_w = cfg->item_weight ? c->item_w : nullptr;
 
   PROFILED(c, "score_loss", launch_score_loss(c->prec, sa, s));
 

@@ -39,8 +39,8 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // Math:
 //   A = sum_j c_j H[j],  Ah = A/(|A|+eps)
 //   per q in {0, C..}: n_q = |H[q]|, t_q = Ah.H[q], score_q = t_q/(n_q+eps)
-//   d_k = s+ - s-_k, h = max(0, margin - d), loss += h^2 (L2) or |h| (L1), viol += d < 0
-//   g_k = grad_scale * (2h | [h>0]);  c_0 = -sum_k g_k, c_{C+k} = g_k
+//   d_k = s+ - s-_k, h = max(0, margin - d), loss += w_b h^2 (L2) or w_b |h| (L1), viol += d < 0
+//   g_k = grad_scale * w_b * (2h | [h>0]);  c_0 = -sum_k g_k, c_{C+k} = g_k
 //   dAh = sum_q c_q H[q]/(n_q+eps);   dH[q] = c_q (n_q^2 Ah - H[q] t_q)/(n_q^3 + eps)
 //   dA  = (sA dAh - A (A.dAh))/(sA^1.5 + eps), dH[j] = c_j dA
 //   dY  = dH * drop_scale * [H > 0]
@@ -104,15 +104,16 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
 
   // ---- phase 3: scores, hinge, loss, coefficients
   const float sp = tq[0] / (sqrtf(n2[0]) + eps);
+  const float wb = a.item_w ? a.item_w[b] : 1.f;
   float lsum = 0.f, vsum = 0.f, gsum = 0.f;
   for (int k = tid; k < Nn; k += SL_THREADS) {
     const int ch = C + k;
     const float sn = tq[ch] / (sqrtf(n2[ch]) + eps);
     const float d = sp - sn;
     const float h = fmaxf(0.f, a.margin - d);
-    float g;
-    if (a.norm == 2) { lsum += h * h; g = 2.f * h * a.grad_scale; }
-    else { lsum += fabsf(h); g = h > 0.f ? a.grad_scale : 0.f; }
+    float g;     // wb: max_margin_loss_layer.cpp:82-97 (sqrt(w)*h squared, or w*h) and :152-186
+    if (a.norm == 2) { lsum += wb * h * h; g = 2.f * wb * h * a.grad_scale; }
+    else { lsum += wb * fabsf(h); g = h > 0.f ? wb * a.grad_scale : 0.f; }
     vsum += d < 0.f ? 1.f : 0.f;
     gsum += g;
     cq[ch] = g;
@@ -294,15 +295,16 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss_reg(ScoreArgs a) {
 
   // ---- phase 3: scores, hinge, loss, coefficients
   const float sp = tq[0] / (sqrtf(n2[0]) + eps);
+  const float wb = a.item_w ? a.item_w[b] : 1.f;
   float lsum = 0.f, vsum = 0.f, gsum = 0.f;
   for (int k = tid; k < Nn; k += SL_THREADS) {
     const int ch = C + k;
     const float sn = tq[ch] / (sqrtf(n2[ch]) + eps);
     const float d = sp - sn;
     const float h = fmaxf(0.f, a.margin - d);
-    float g;
-    if (a.norm == 2) { lsum += h * h; g = 2.f * h * a.grad_scale; }
-    else { lsum += fabsf(h); g = h > 0.f ? a.grad_scale : 0.f; }
+    float g;     // wb: max_margin_loss_layer.cpp:82-97 (sqrt(w)*h squared, or w*h) and :152-186
+    if (a.norm == 2) { lsum += wb * h * h; g = 2.f * wb * h * a.grad_scale; }
+    else { lsum += wb * fabsf(h); g = h > 0.f ? wb * a.grad_scale : 0.f; }
     vsum += d < 0.f ? 1.f : 0.f;
     gsum += g;
     cq[ch] = g;

@@ -71,6 +71,7 @@ struct ScoreArgs {
   float sg;                // half-precision gradient scale
   // row-dedup mode (both NULL otherwise): H holds one row per UNIQUE table row, instance r reads
   // H[map[r]] and writes its gradient row to dYh[pos[r]] (instances of one unique row contiguous)
+  const float* item_w = nullptr;     // [B] loss-term weight of each item (MAX_MARGIN_LOSS 3rd bottom) or null
   const int32_t* map = nullptr;      // [R]
   const int32_t* pos = nullptr;      // [R]
 };

@@ -28,7 +28,8 @@ class _StepCfg(C.Structure):
                 ("dropout_seed", C.c_uint64), ("global_count", C.c_int64),
                 ("lr", C.c_float), ("momentum", C.c_float), ("weight_decay", C.c_float),
                 ("lr_mult", C.c_float * 2), ("decay_mult", C.c_float * 2), ("reg", C.c_int32),
-                ("solver_type", C.c_int32), ("delta", C.c_float), ("ip_regularization", C.c_float)]
+                ("solver_type", C.c_int32), ("delta", C.c_float), ("ip_regularization", C.c_float),
+                ("item_weight", C.c_void_p)]
 
 
 _lib = None
@@ -109,6 +110,10 @@ class StepConfig:
             a = None if v is None else np.ascontiguousarray(v, dtype=np.uint8)
             self._keep[k] = a
             self.c.dropout_mask = None if a is None else a.ctypes.data
+        elif k == "item_weight":
+            a = None if v is None else np.ascontiguousarray(v, dtype=np.float32)
+            self._keep[k] = a
+            self.c.item_weight = None if a is None else a.ctypes.data
         elif k in ("lr_mult", "decay_mult"):
             getattr(self.c, k)[0], getattr(self.c, k)[1] = float(v[0]), float(v[1])
         elif k == "reg":

@@ -27,15 +27,19 @@ def _test_branch_front(a, test_source, test_batch, frames):
 
 def train_net(source, B, C, Nn, D, *, max_buffer=5000, swap=50, max_same=0, dropout=0.0, margin=2.0,
               norm="L2", name="videovec_train", w_std=0.001, test_source=None, test_batch=673, test_frames=4,
-              id_to_class_file=None):
+              id_to_class_file=None, id_to_weight_file=None, use_direct_weight=False, ip_regularization=0.0):
     """test_source: also emit the TEST branch of the shipped file (window data -> average_for_test ->
-    [shared fc7 / fc7_relu] -> test_norm -> retrieval_stats)."""
+    [shared fc7 / fc7_relu] -> test_norm -> retrieval_stats).
+    id_to_weight_file / use_direct_weight: the weighted loss -- the data layer's video ids, replicated to (B, Nn)
+    by a SUM layer, become MAX_MARGIN_LOSS's third bottom (max_margin_loss_layer.cpp:18-37, 82-97)."""
+    weighted = bool(id_to_weight_file) or use_direct_weight
     L = []
     a = L.append
     a('name: "%s"' % name)
     if test_source:
         _test_branch_front(a, test_source, test_batch, test_frames)
-    a('layers {\n  name: "shot_windows"\n  type: VIDEO_SAMPLED_SHOTS_DATA\n  top: "data"\n'
+    a('layers {\n  name: "shot_windows"\n  type: VIDEO_SAMPLED_SHOTS_DATA\n  top: "data"\n' +
+      ('  top: "train_video_ids"\n' if weighted else '') +
       '  video_sampled_shots_data_param {\n    source: "%s"\n    backend: LMDB\n    batch_size: %d\n'
       '    num_negative_samples: %d\n    max_buffer_size: %d\n    negative_swap_percentage: %d\n'
       '    max_same_video_negs: %d\n    context_type: WINDOW\n    context_size: %d\n  }\n'
@@ -51,8 +55,9 @@ def train_net(source, B, C, Nn, D, *, max_buffer=5000, swap=50, max_same=0, drop
       '  top: "original_feature"\n  include: { phase: TRAIN }\n}')
     a('layers {\n  name: "fc7"\n  type: INNER_PRODUCT\n  bottom: "original_feature"\n  top: "ip1_nonorm"\n'
       '  blobs_lr: 1\n  blobs_lr: 2\n  weight_decay: 1\n  weight_decay: 0\n  inner_product_param {\n'
-      '    num_output: %d\n    weight_filler { type: "gaussian" std: %g }\n'
-      '    bias_filler { type: "constant" }\n  }\n}' % (D, w_std))
+      '    num_output: %d\n%s    weight_filler { type: "gaussian" std: %g }\n'
+      '    bias_filler { type: "constant" }\n  }\n}'
+      % (D, "    regularization: %g\n" % ip_regularization if ip_regularization else "", w_std))
     a('layers {\n  name: "fc7_relu"\n  type: RELU\n  top: "ip2"\n  bottom: "ip1_nonorm"\n}')
     if dropout > 0:
         a('layers {\n  name: "drop2"\n  type: DROPOUT\n  bottom: "ip2"\n  top: "ip2"\n'
@@ -88,10 +93,16 @@ def train_net(source, B, C, Nn, D, *, max_buffer=5000, swap=50, max_same=0, drop
     a('layers {\n  name: "concat_negative_scores"\n  type: CONCAT\n%s\n  top: "negative_scores"\n'
       '  concat_param { concat_dim: 1 }\n  include: { phase: TRAIN }\n}'
       % "\n".join('  bottom: "neg_score_%d"' % k for k in range(1, Nn + 1)))
+    if weighted:
+        a('layers {\n  name: "replicate_video_ids"\n  type: SUM\n  bottom: "train_video_ids"\n  top: "term_video_ids"\n'
+          '  sum_param { num_output: %d }\n  include: { phase: TRAIN }\n}' % Nn)
     a('layers {\n  name: "max_margin_loss"\n  type: MAX_MARGIN_LOSS\n  bottom: "target_score"\n'
-      '  bottom: "negative_scores"\n  top: "loss_output"\n  top: "train_violations"\n  loss_weight: 1.0\n'
-      '  loss_weight: 0.0\n  max_margin_loss_param {\n    norm: %s\n    margin: %g\n  }\n'
-      '  include: { phase: TRAIN }\n}' % (norm, margin))
+      '  bottom: "negative_scores"\n%s  top: "loss_output"\n  top: "train_violations"\n  loss_weight: 1.0\n'
+      '  loss_weight: 0.0\n  max_margin_loss_param {\n    norm: %s\n    margin: %g\n%s%s  }\n'
+      '  include: { phase: TRAIN }\n}'
+      % ('  bottom: "term_video_ids"\n' if weighted else '', norm, margin,
+         '    id_to_weight_file: "%s"\n' % id_to_weight_file if id_to_weight_file else '',
+         '    use_direct_weight: true\n' if use_direct_weight else ''))
     if test_source:
         a('layers {\n  name: "test_norm"\n  type: NORMALIZATION\n  bottom: "ip2"\n  top: "ip2_norm"\n'
           '  include: { phase: TEST }\n}')
