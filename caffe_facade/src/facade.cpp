@@ -387,8 +387,8 @@ void VideoSampledShotsDataLayer<Dtype>::JoinPrefetchThread() { if (thread_.joina
 template <typename Dtype>
 void VideoSampledShotsDataLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>&, vector<Blob<Dtype>*>* top) {
   const pl::Message& p = this->layer_param_.get_msg("video_sampled_shots_data_param");
-  CHECK(p.get_enum("context_type") == "WINDOW")
-      << "context_type " << p.get_enum("context_type") << ": only WINDOW is built (the project's setting)";
+  const string ctype = p.get_enum("context_type");
+  CHECK(ctype != "PAIRWISE") << "context_type PAIRWISE feeds a two-frame graph, not the videovec_embedding graph: not built";
   CHECK(p.get_str("negative_dataset").empty()) << "negative_dataset is not supported";
   CHECK(!p.get_bool("output_shot_distance")) << "output_shot_distance is PAIRWISE-only";
   CHECK_EQ(p.get_int("rand_skip"), 0) << "rand_skip is not supported";
@@ -403,7 +403,9 @@ void VideoSampledShotsDataLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>&, 
   sp.max_same_video_negs = (int)p.get_int("max_same_video_negs");
   feature_size_ = dataset_->F;
   CHECK_GE(feature_size_, 1); CHECK_GE(context_size_, 2); CHECK_GE(batch_size_, 1);      // …data_layer.cpp:206-209
-  CHECK(context_size_ % 2 == 1) << "Context size should be even in this setting!";       // …:434 (sic)
+  if (ctype == "WINDOW") { CHECK(context_size_ % 2 == 1) << "Context size should be even in this setting!"; }   // …:434 (sic)
+  sp.context_type = ctype == "WINDOW" ? VV_CONTEXT_WINDOW : ctype == "PAST" ? VV_CONTEXT_PAST :
+                    ctype == "PAST_CONTINUOUS" ? VV_CONTEXT_PAST_CONTINUOUS : VV_CONTEXT_PAST_CONTINUOUS_FIXED;
   const int rc = vv_sampler_create(&sp, (int)dataset_->video_id.size(), dataset_->video_id.data(), dataset_->n_shots.data(),
                                    dataset_->row_base.data(), dataset_->shot_ids.data(), &sampler_);
   CHECK_EQ(rc, 0) << "Could not add requested number of negatives";                       // …:344

@@ -194,13 +194,19 @@ int vv_retrieval_stats(vv_ctx* ctx, const float* feat, int32_t n, int32_t dim, c
  * libstdc++'s std::random_shuffle are reproduced exactly, so indices are bit-identical.
  * One DB record = one video: record v has video_id[v], n_shots[v] frames whose features are table
  * rows row_base[v] .. row_base[v]+n_shots[v]-1, and shot ids shot_ids[shot_off..] (NULL = 0..n-1).
- * Only context_type WINDOW (caffe.proto VideoSampledShotsDataParameter.ContextType) is built. */
+ * context_type: see VV_CONTEXT_* below. */
 typedef struct vv_sampler vv_sampler;
 typedef struct {
   int32_t batch_size, context_size, num_negative_samples;
   int32_t max_buffer_size, negative_swap_percentage, max_same_video_negs;
   int32_t max_tries_for_negs;      /* gflag --max_tries_for_negs, default 100 (...data_layer.cpp:20) */
+  int32_t context_type;            /* VV_CONTEXT_* (VideoSampledShotsDataParameter.ContextType) */
 } vv_sampler_param;
+/* WINDOW (...data_layer.cpp:425-507): target = the middle of C sorted random frames.  PAST (:510-596): target = the
+ * last of C sorted random frames.  PAST_CONTINUOUS (:599-674): C equally spaced frames, random stride and start,
+ * target = the last.  PAST_CONTINUOUS_FIXED (:677-757): the same with the largest stride minus one, ending at the
+ * video's end.  All fill the same (B, C+Nn) layout.  PAIRWISE (:396-422) feeds a different graph and is not built. */
+enum { VV_CONTEXT_WINDOW = 0, VV_CONTEXT_PAST = 1, VV_CONTEXT_PAST_CONTINUOUS = 2, VV_CONTEXT_PAST_CONTINUOUS_FIXED = 3 };
 void vv_sampler_param_default(vv_sampler_param* p);
 int vv_sampler_create(const vv_sampler_param* p, int32_t n_videos, const int32_t* video_id,
                       const int32_t* n_shots, const int64_t* row_base, const int32_t* shot_ids,

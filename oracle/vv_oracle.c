@@ -133,6 +133,7 @@ void orc_sampler_destroy(orc_sampler* s) {
 /* video_sampled_shots_data_layer.cpp:64-369 (DataLayerSetUp) */
 orc_sampler* orc_sampler_create(const orc_dataset* ds, const orc_sampler_param* p, unsigned seed) {
   if (p->context_size < 2 || p->batch_size < 1 || ds->n_videos < 1) return NULL;   /* :207,:209 */
+  if (p->context_type < ORC_CONTEXT_WINDOW || p->context_type > ORC_CONTEXT_PAST_CONTINUOUS_FIXED) return NULL;  /* :760 */
   if (p->num_negative_samples > 0 &&
       (p->negative_swap_percentage < 0 || p->negative_swap_percentage > 99)) return NULL; /* :79-80 */
   orc_sampler* s = (orc_sampler*)calloc(1, sizeof(*s));
@@ -219,6 +220,63 @@ static int add_samples_window(orc_sampler* s, int v, int item, int* added_negs) 
   return 1;
 }
 
+/* video_sampled_shots_data_layer.cpp:510-596 (CONTEXT_PAST), 599-674 (PAST_CONTINUOUS), 677-757 (PAST_CONTINUOUS_FIXED):
+ * the target is the LAST of the C chosen frames, the context the C-1 before it, in time order. */
+static int add_samples_past(orc_sampler* s, int v, int item, int* added_negs) {
+  const orc_sampler_param* p = &s->p;
+  const int C = p->context_size, CN = C + p->num_negative_samples;
+  const int n = s->ds.n_shots[v];
+  const int64_t base = s->ds.row_base[v];
+  *added_negs = 0;
+  if (n < 2) return 0;                                                                 /* :387 */
+  if (n < C) return 0;                                                                 /* :512, :601, :679 */
+  int32_t* perm = s->perm;
+  for (int i = 0; i < n; ++i) perm[i] = i;                                             /* :391 */
+  int32_t* row = s->slot_row + (size_t)item * CN;
+  int32_t* last = s->slot_last + (size_t)item * CN;
+  int begin_frame = 0, sample_length = 0;
+  if (p->context_type == ORC_CONTEXT_PAST) {
+    s_random_unique(s, perm, n, C);                                                    /* :517 */
+    for (int i = 1; i < C; ++i) {                                                      /* :522 std::sort */
+      int32_t x = perm[i]; int j = i - 1;
+      while (j >= 0 && perm[j] > x) { perm[j + 1] = perm[j]; --j; }
+      perm[j + 1] = x;
+    }
+  } else {
+    const int max_sample_length = (n - C) / (C - 1);                                   /* :609, :687 */
+    if (p->context_type == ORC_CONTEXT_PAST_CONTINUOUS) {
+      sample_length = s_rand(s) % (max_sample_length + 1);                             /* :610 */
+      begin_frame = s_rand(s) % (n - (C - 1) * sample_length - C + 1);                 /* :612-613 */
+    } else {
+      sample_length = max_sample_length >= 1 ? max_sample_length - 1 : 0;              /* :688 */
+      begin_frame = n - (C - 1) * sample_length - C;                                   /* :690-691 */
+    }
+  }
+  int ctx = 0;
+  for (int i = 0; i < C; ++i) {                                                        /* :525-541, :617-632, :695-710 */
+    const int frame = p->context_type == ORC_CONTEXT_PAST ? perm[i] : begin_frame + i * (sample_length + 1);
+    const int32_t r = (int32_t)(base + frame);
+    if (i == C - 1) { row[0] = r; last[0] = r; }
+    else { row[ctx + 1] = r; last[ctx + 1] = r; ++ctx; }
+  }
+  if (p->context_type == ORC_CONTEXT_PAST) {
+    if (p->num_negative_samples > 0 && n > C) {                                        /* :563-583 */
+      s_random_shuffle(s, perm + C, n - C);                                            /* :566 */
+      for (int nid = C; nid < n && *added_negs < p->max_same_video_negs; ++nid)
+        if (perm[nid] < perm[1]) {                                                     /* :570 */
+          row[C + *added_negs] = (int32_t)(base + perm[nid]);                          /* :572-577: F-1 values */
+          ++*added_negs;
+        }
+    }
+  } else if (p->num_negative_samples > 0 && begin_frame > 0) {                         /* :652-670, :730-748 */
+    for (int nid = begin_frame - 1; nid >= 0 && *added_negs < p->max_same_video_negs; --nid) {
+      row[C + *added_negs] = (int32_t)(base + nid);
+      ++*added_negs;
+    }
+  }
+  return 1;
+}
+
 /* video_sampled_shots_data_layer.cpp:768-909 (InternalThreadEntry) */
 void orc_sampler_next(orc_sampler* s, int32_t* idx, int32_t* last_src, int32_t* label) {
   const orc_sampler_param* p = &s->p;
@@ -227,7 +285,8 @@ void orc_sampler_next(orc_sampler* s, int32_t* idx, int32_t* last_src, int32_t* 
   while (item < p->batch_size) {
     const int v = s->cursor;
     int added = 0;
-    const int ok = add_samples_window(s, v, item, &added);                             /* :820 */
+    const int ok = p->context_type == ORC_CONTEXT_WINDOW ? add_samples_window(s, v, item, &added)   /* :820 */
+                                                         : add_samples_past(s, v, item, &added);
     s->cursor = (s->cursor + 1) % s->ds.n_videos;                                      /* :826-846 */
     if (!ok) continue;                                                                 /* :848 */
     if (Nn > 0) {

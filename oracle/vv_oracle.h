@@ -56,7 +56,9 @@ typedef struct {
   int32_t batch_size, context_size, num_negative_samples;
   int32_t max_buffer_size, negative_swap_percentage, max_same_video_negs;
   int32_t max_tries_for_negs;   /* gflag, default 100 (…data_layer.cpp:20) */
+  int32_t context_type;         /* VideoSampledShotsDataParameter.ContextType; PAIRWISE feeds a different graph */
 } orc_sampler_param;
+enum { ORC_CONTEXT_WINDOW = 0, ORC_CONTEXT_PAST = 1, ORC_CONTEXT_PAST_CONTINUOUS = 2, ORC_CONTEXT_PAST_CONTINUOUS_FIXED = 3 };
 
 typedef struct orc_sampler orc_sampler;
 /* DataLayerSetUp (…data_layer.cpp:64-369): fills the negative buffer from the cursor position.

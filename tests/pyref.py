@@ -17,8 +17,9 @@ _libc = ctypes.CDLL("libc.so.6")
 
 class PySampler:
     def __init__(self, video_id, n_shots, row_base, B, C, Nn, max_buffer, swap, max_same=0,
-                 max_tries=100):
+                 max_tries=100, context_type="WINDOW"):
         _libc.srand(1)            # identical to never having called srand
+        self.context_type = context_type
         self.calls = 0
         self.vid, self.ns, self.rb = list(video_id), list(n_shots), list(row_base)
         self.B, self.C, self.Nn, self.mb, self.swap, self.max_same = B, C, Nn, max_buffer, swap, max_same
@@ -61,7 +62,45 @@ class PySampler:
             v = self.cursor
             n = self.ns[v]
             added, ok = 0, False
-            if n >= 2 and n >= C:
+            if self.context_type != "WINDOW" and n >= 2 and n >= C:
+                # …data_layer.cpp:510-757: target = the last of the C frames, context = the C-1 before it
+                perm = list(range(n))
+                if self.context_type == "PAST":
+                    self.random_unique(perm, 0, C)
+                    perm[:C] = sorted(perm[:C])
+                    frames = perm[:C]
+                else:
+                    msl = (n - C) // (C - 1)
+                    if self.context_type == "PAST_CONTINUOUS":
+                        sl = self.rand() % (msl + 1)
+                        begin = self.rand() % (n - (C - 1) * sl - C + 1)
+                    else:
+                        sl = msl - 1 if msl >= 1 else 0
+                        begin = n - (C - 1) * sl - C
+                    frames = [begin + i * (sl + 1) for i in range(C)]
+                for i, fr in enumerate(frames):
+                    c = 0 if i == C - 1 else i + 1
+                    self.slot_row[item][c] = self.slot_last[item][c] = self.rb[v] + fr
+                ok = True
+                if self.context_type == "PAST":
+                    if Nn > 0 and n > C:
+                        for i in range(C + 1, n):
+                            j = C + self.rand() % (i - C + 1)
+                            if i != j:
+                                perm[i], perm[j] = perm[j], perm[i]
+                        nid = C
+                        while nid < n and added < self.max_same:
+                            if perm[nid] < perm[1]:
+                                self.slot_row[item][C + added] = self.rb[v] + perm[nid]
+                                added += 1
+                            nid += 1
+                elif Nn > 0 and begin > 0:
+                    nid = begin - 1
+                    while nid >= 0 and added < self.max_same:
+                        self.slot_row[item][C + added] = self.rb[v] + nid
+                        added += 1
+                        nid -= 1
+            elif n >= 2 and n >= C:
                 perm = list(range(n))
                 self.random_unique(perm, 0, C)
                 perm[:C] = sorted(perm[:C])

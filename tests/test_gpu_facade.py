@@ -181,6 +181,40 @@ def test_caffe_train_weighted_loss_and_ip_regularization(tool, pb, oracle, tmp_p
     assert rel_fro(Wg, Wq) <= 2e-3 and rel_fro(bg, bq) <= 4e-3
 
 
+@pytest.mark.parametrize("ctype,C", [("PAST", 4), ("PAST_CONTINUOUS", 3), ("PAST_CONTINUOUS_FIXED", 5)])
+def test_caffe_train_past_context_types(tool, pb, oracle, tmp_path, ctype, C):
+    # context_type PAST* (video_sampled_shots_data_layer.cpp:510-757) through the data layer, with same-video
+    # negatives (quirk Q1 slots) and an even context size
+    B, Nn, F, D, V = 32, 3, 128, 32, 50
+    net_p, sol_p = tmp_path / "net.prototxt", tmp_path / "solver.prototxt"
+    net_p.write_text(train_net("synthetic://videos=%d;seed=1701;features=%d" % (V, F), B, C, Nn, D, max_buffer=500, w_std=0.02,
+                               context_type=ctype, max_same=2))
+    sol_p.write_text(solver(str(net_p), base_lr=0.002, max_iter=3, display=1, lr_policy="fixed",
+                            snapshot_prefix=str(tmp_path / "snap")))
+    W0, b0 = init_weights(3, D, F, std=0.02)
+    write_caffemodel(pb, str(tmp_path / "init.caffemodel"), W0, b0)
+    log = run_caffe(["train", "--solver=%s" % sol_p, "--weights=%s" % (tmp_path / "init.caffemodel")],
+                    str(tmp_path / "train.log"), {"VV_DEDUP": "0"})
+    losses = [float(x) for x in re.findall(r"Iteration \d+, loss = ([0-9.eE+-]+)", log)]
+    ds = SyntheticVideos(seed=1701, n_videos=V)
+    table = ds.table(F)
+    smp = oracle.Sampler(ds.video_id, ds.n_shots, ds.row_base, batch_size=B, context_size=C, num_negative_samples=Nn,
+                         max_buffer_size=500, negative_swap_percentage=50, max_same_video_negs=2, context_type=ctype)
+    Wq, bq = W0.copy(), b0.copy()
+    hW, hb = np.zeros_like(W0), np.zeros_like(b0)
+    saw_q1 = False
+    for it in range(3):
+        idx, last, _ = smp.next()
+        saw_q1 |= bool((idx != last).any())
+        r = oracle.forward_backward(table, idx, round_operand(Wq, "f16"), bq, C_=C, Nn=Nn, last_src=last, want=("dW", "db"))
+        assert abs(losses[it] - r["loss"]) <= 1e-3 * r["loss"], (it, losses[it], r["loss"])
+        oracle.sgd_update(Wq, r["dW"], hW, 0.002, 1.0, 0.9, 5e-4, 1.0)
+        oracle.sgd_update(bq, r["db"], hb, 0.002, 2.0, 0.9, 5e-4, 0.0)
+    assert saw_q1
+    Wg, bg, _ = read_caffemodel(pb, str(tmp_path / "snap_iter_3.caffemodel"))
+    assert rel_fro(Wg, Wq) <= 2e-3 and rel_fro(bg, bq) <= 4e-3
+
+
 def test_caffe_train_shipped_configuration(tool, tmp_path):
     # The shipped project settings (mednet_embedding_train.prototxt:13-23,200,226 and its solver):
     # batch 128, window 5, 10 negatives of which up to 6 from the same video (quirk Q1), 4096 -> 4096,

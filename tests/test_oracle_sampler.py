@@ -37,6 +37,52 @@ def test_c_oracle_equals_python_restatement_on_real_glibc(oracle, B, C, Nn, mb, 
         assert s.buffer_ids().tolist() == p.buffer_ids
 
 
+@pytest.mark.parametrize("ctype", ["PAST", "PAST_CONTINUOUS", "PAST_CONTINUOUS_FIXED"])
+@pytest.mark.parametrize("B,C,Nn,mb,swap,max_same", [(16, 5, 10, 200, 50, 6), (8, 4, 4, 64, 99, 2), (8, 2, 3, 50, 0, 3),
+                                                    (4, 6, 0, 0, 0, 0)])
+def test_past_context_modes_equal_python_restatement_on_real_glibc(oracle, ctype, B, C, Nn, mb, swap, max_same):
+    # video_sampled_shots_data_layer.cpp:510-757; even context sizes are legal here (only WINDOW needs an odd one)
+    ds = SyntheticVideos(seed=9, n_videos=60, lo=2, span=24)
+    s = _mk(oracle, ds, batch_size=B, context_size=C, num_negative_samples=Nn, max_buffer_size=mb,
+            negative_swap_percentage=swap, max_same_video_negs=max_same, context_type=ctype)
+    p = PySampler(ds.video_id, ds.n_shots, ds.row_base, B, C, Nn, mb, swap, max_same, context_type=ctype)
+    for _ in range(6):
+        i1, l1, y1 = s.next()
+        i2, l2, y2 = p.next()
+        assert np.array_equal(i1, i2) and np.array_equal(l1, l2) and np.array_equal(y1, y2)
+        assert s.rand_calls() == p.calls and s.cursor() == p.cursor
+
+
+@pytest.mark.parametrize("ctype", ["PAST", "PAST_CONTINUOUS", "PAST_CONTINUOUS_FIXED"])
+def test_past_context_structure(oracle, ctype):
+    ds = SyntheticVideos(seed=3, n_videos=80)
+    C, Nn, B, max_same = 4, 6, 64, 3
+    s = _mk(oracle, ds, batch_size=B, context_size=C, num_negative_samples=Nn, max_buffer_size=300,
+            negative_swap_percentage=50, max_same_video_negs=max_same, context_type=ctype)
+    row2vid = np.repeat(ds.video_id, ds.n_shots)
+    vid_end = {int(v): int(ds.row_base[i] + ds.n_shots[i]) for i, v in enumerate(ds.video_id)}
+    for _ in range(3):
+        idx, last, label = s.next()
+        for b in range(B):
+            t, ctx = idx[b, 0], idx[b, 1:C]
+            assert np.all(row2vid[idx[b, :C]] == label[b])
+            assert np.all(np.diff(ctx) > 0) and ctx[-1] < t            # the context precedes the target, in time order
+            if ctype != "PAST":
+                steps = np.diff(np.append(ctx, t))
+                assert np.all(steps == steps[0])                       # equally spaced frames
+            if ctype == "PAST_CONTINUOUS_FIXED":
+                # largest stride minus one, window ending at the video's last frame (:688-691)
+                n = int(ds.n_shots[list(ds.video_id).index(label[b])])
+                msl = (n - C) // (C - 1)
+                assert steps[0] == (msl - 1 if msl >= 1 else 0) + 1 and t == vid_end[int(label[b])] - 1
+            same = [c for c in range(C, C + Nn) if idx[b, c] != last[b, c]]   # Q1 slots = same-video negatives
+            assert len(same) <= max_same
+            for c in same:
+                # PAST: frames before the SECOND chosen frame (rand_perm_ids[1], :570); continuous: before the window
+                bound = np.append(ctx, t)[1] if ctype == "PAST" else ctx[0]
+                assert row2vid[idx[b, c]] == label[b] and idx[b, c] < bound
+
+
 def test_window_structure(oracle):
     ds = SyntheticVideos(seed=3, n_videos=80)
     C, Nn, B = 5, 6, 64

@@ -57,6 +57,20 @@ def test_sampler_bit_exact_vs_oracle(oracle, B, C, Nn, mb, swap, max_same):
         assert np.array_equal(i1, i2) and np.array_equal(l1, l2) and np.array_equal(y1, y2)
 
 
+@pytest.mark.parametrize("ctype", ["PAST", "PAST_CONTINUOUS", "PAST_CONTINUOUS_FIXED"])
+def test_sampler_past_context_modes_bit_exact_vs_oracle(oracle, ctype):
+    ds = SyntheticVideos(seed=7, n_videos=120, lo=2, span=40)
+    for (B, C, Nn, mb, swap, max_same) in [(16, 5, 10, 200, 50, 6), (8, 4, 4, 64, 99, 2), (32, 2, 3, 50, 0, 3)]:
+        kw = dict(batch_size=B, context_size=C, num_negative_samples=Nn, max_buffer_size=mb,
+                  negative_swap_percentage=swap, max_same_video_negs=max_same, context_type=ctype)
+        a = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, **kw)
+        o = oracle.Sampler(ds.video_id, ds.n_shots, ds.row_base, **kw)
+        for _ in range(6):
+            i1, l1, y1 = a.next(want_last=True, want_label=True)
+            i2, l2, y2 = o.next()
+            assert np.array_equal(i1, i2) and np.array_equal(l1, l2) and np.array_equal(y1, y2)
+
+
 def test_sampler_with_explicit_shot_ids_and_errors(oracle):
     ds = SyntheticVideos(seed=9, n_videos=30)
     sid = np.concatenate([np.arange(n)[::-1] * 3 for n in ds.n_shots]).astype(np.int32)

@@ -98,7 +98,8 @@ int vv_sampler_create(const vv_sampler_param* p, int32_t n_videos, const int32_t
                       vv_sampler** out) {
   if (!p || !video_id || !n_shots || !row_base || !out || n_videos < 1) return VV_ERR_ARG;
   if (p->batch_size < 1 || p->context_size < 2) return VV_ERR_ARG;                // :207,:209
-  if (p->context_size % 2 != 1) return VV_ERR_ARG;                                // :434 (WINDOW)
+  if (p->context_type < VV_CONTEXT_WINDOW || p->context_type > VV_CONTEXT_PAST_CONTINUOUS_FIXED) return VV_ERR_ARG;   // :760
+  if (p->context_type == VV_CONTEXT_WINDOW && p->context_size % 2 != 1) return VV_ERR_ARG;   // :434
   const int Nn = p->num_negative_samples;
   if (Nn < 0) return VV_ERR_ARG;
   if (Nn > 0 && (p->negative_swap_percentage < 0 || p->negative_swap_percentage > 99 ||
@@ -173,8 +174,47 @@ int vv_sampler_next(vv_sampler* s, int32_t* idx, int32_t* last_src, int32_t* lab
     const int64_t base = s->row_base[v];
     Slot* sl = &s->slots[(size_t)item * CN];
     int added = 0;
-    const bool ok = n >= 2 && n >= C;                                              // :387,:427
-    if (ok) {
+    const bool ok = n >= 2 && n >= C;                                              // :387,:427,:512,:601,:679
+    if (ok && p.context_type != VV_CONTEXT_WINDOW) {
+      // :510-757 -- target = the last of the C frames, context = the C-1 before it, in time order
+      std::vector<int32_t>& perm = s->perm;
+      perm.resize(n);
+      for (int i = 0; i < n; ++i) perm[i] = i;
+      int begin = 0, stride = 1;
+      if (p.context_type == VV_CONTEXT_PAST) {
+        s->random_unique(perm, C);                                                 // :517
+        std::sort(perm.begin(), perm.begin() + C);                                 // :522
+      } else {
+        const int msl = (n - C) / (C - 1);                                         // :609,:687
+        int sl;
+        if (p.context_type == VV_CONTEXT_PAST_CONTINUOUS) {
+          sl = s->rng.next() % (msl + 1);                                          // :610
+          begin = s->rng.next() % (n - (C - 1) * sl - C + 1);                      // :612-613
+        } else {
+          sl = msl >= 1 ? msl - 1 : 0;                                             // :688
+          begin = n - (C - 1) * sl - C;                                            // :690-691
+        }
+        stride = sl + 1;
+      }
+      for (int i = 0; i < C; ++i) {
+        const int frame = p.context_type == VV_CONTEXT_PAST ? perm[i] : begin + i * stride;
+        Slot& d = (i == C - 1) ? sl[0] : sl[i + 1];
+        d.row = d.last = (int32_t)(base + frame);
+      }
+      if (p.context_type == VV_CONTEXT_PAST) {
+        if (Nn > 0 && n > C) {                                                     // :563-583
+          for (int i = C + 1; i < n; ++i) {
+            const int j = C + s->rng.next() % (i - C + 1);
+            if (i != j) std::swap(perm[i], perm[j]);
+          }
+          for (int nid = C; nid < n && added < p.max_same_video_negs; ++nid)
+            if (perm[nid] < perm[1]) sl[C + added++].row = (int32_t)(base + perm[nid]);   // :570-577, F-1 values
+        }
+      } else if (Nn > 0 && begin > 0) {                                            // :652-670, :730-748
+        for (int nid = begin - 1; nid >= 0 && added < p.max_same_video_negs; --nid)
+          sl[C + added++].row = (int32_t)(base + nid);
+      }
+    } else if (ok) {
       std::vector<int32_t>& perm = s->perm;
       perm.resize(n);
       for (int i = 0; i < n; ++i) perm[i] = i;
