@@ -8,7 +8,9 @@
 // Net::Init (net.hpp).  Calling Forward/Backward on a single layer is fatal, with the same
 // abort-on-error convention the reference uses for unsupported configurations.
 #pragma once
+#include <condition_variable>
 #include <map>
+#include <mutex>
 #include <thread>
 
 #include "caffe/blob.hpp"
@@ -120,9 +122,15 @@ class VideoSampledShotsDataLayer : public Layer<Dtype> {
   shared_ptr<VideoDataset> dataset_;
   // prefetch: one host thread per data layer produces the next index batch while the GPU works on
   // the current one (BasePrefetchingDataLayer, base_data_layer.cpp:52-95; InternalThread)
-  void CreatePrefetchThread();
-  void JoinPrefetchThread();
+  // The reference starts a new thread per batch (internal_thread.cpp:14-37); one persistent worker with the same
+  // hand-over points keeps the sampler's state (slots, buffer, key bitmap: ~1 MB) warm in one core's caches.
+  void CreatePrefetchThread();     // ask the worker for the next batch
+  void JoinPrefetchThread();       // wait until that batch is complete
+  void WorkerLoop();
   std::thread thread_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  bool want_ = false, ready_ = false, quit_ = false;
   vector<int32_t> pf_idx_, pf_last_, pf_label_;
   vv_sampler* sampler_ = nullptr;
   int batch_size_ = 0, context_size_ = 0, num_negative_samples_ = 0, feature_size_ = 0;

@@ -58,6 +58,10 @@ class Net {
   bool has_layer(const string& layer_name);
   const shared_ptr<Layer<Dtype> > layer_by_name(const string& layer_name);
   void set_debug_info(const bool value) { debug_info_ = value; }
+  // The reference's Solver::Solve uses ForwardBackward's return value only on display iterations
+  // (solver.cpp:194-196).  Reading the loss back costs a device synchronisation, so the solver says when it
+  // wants it; otherwise ForwardBackward returns the last value read and the GPU keeps running ahead.
+  void set_loss_needed(const bool value) { loss_needed_ = value; }
   // SGD history of the parameter blobs (owned by the device context; host views on demand)
   void GetHistory(vector<shared_ptr<Blob<Dtype> > >* history);
   void SetHistory(const vector<shared_ptr<Blob<Dtype> > >& history);
@@ -108,6 +112,8 @@ class Net {
   vv_step_cfg cfg_;
   vector<int32_t> idx_, last_src_, label_;
   vector<float> item_weight_;
+  bool loss_needed_ = true;
+  float last_loss_ = 0.f;
   uint64_t iter_ = 0;
 };
 

@@ -372,17 +372,40 @@ void VideoDataset::UploadTable(vv_ctx* ctx) const {
 // ------------------------------------------------------------------------------- data layer ----
 template <typename Dtype>
 VideoSampledShotsDataLayer<Dtype>::~VideoSampledShotsDataLayer() {
-  JoinPrefetchThread();
+  if (thread_.joinable()) {
+    { std::lock_guard<std::mutex> l(mu_); quit_ = true; }
+    cv_.notify_all();
+    thread_.join();
+  }
   if (sampler_) vv_sampler_destroy(sampler_);
+}
+template <typename Dtype>
+void VideoSampledShotsDataLayer<Dtype>::WorkerLoop() {
+  std::unique_lock<std::mutex> l(mu_);
+  for (;;) {
+    cv_.wait(l, [this]() { return want_ || quit_; });
+    if (quit_) return;
+    want_ = false;
+    l.unlock();
+    CHECK_EQ(vv_sampler_next(sampler_, pf_idx_.data(), pf_last_.data(), pf_label_.data()), 0);
+    l.lock();
+    ready_ = true;
+    cv_.notify_all();
+  }
 }
 template <typename Dtype>
 void VideoSampledShotsDataLayer<Dtype>::CreatePrefetchThread() {
   const size_t n = (size_t)batch_size_ * (context_size_ + num_negative_samples_);
   pf_idx_.resize(n); pf_last_.resize(n); pf_label_.resize(batch_size_);
-  thread_ = std::thread([this]() { CHECK_EQ(vv_sampler_next(sampler_, pf_idx_.data(), pf_last_.data(), pf_label_.data()), 0); });
+  if (!thread_.joinable()) thread_ = std::thread([this]() { WorkerLoop(); });
+  { std::lock_guard<std::mutex> l(mu_); want_ = true; ready_ = false; }
+  cv_.notify_all();
 }
 template <typename Dtype>
-void VideoSampledShotsDataLayer<Dtype>::JoinPrefetchThread() { if (thread_.joinable()) thread_.join(); }
+void VideoSampledShotsDataLayer<Dtype>::JoinPrefetchThread() {
+  std::unique_lock<std::mutex> l(mu_);
+  cv_.wait(l, [this]() { return ready_; });
+}
 
 template <typename Dtype>
 void VideoSampledShotsDataLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>&, vector<Blob<Dtype>*>* top) {

@@ -1,4 +1,5 @@
 // net.cpp -- Net (reference: src/caffe/net.cpp) with the fused videovec plan.
+#include <ctime>
 #include "caffe/net.hpp"
 
 #include <algorithm>
@@ -329,11 +330,25 @@ void Net<Dtype>::SetHistory(const vector<shared_ptr<Blob<Dtype> > >& history) {
                          history[0]->cpu_data(), history[1]->cpu_data()));
 }
 
+namespace {
+// VV_FACADE_PROFILE=1: where the host thread of `caffe train` spends an iteration (printed at exit)
+struct HostProf {
+  double t_batch = 0, t_fb = 0, t_loss = 0; long n = 0; bool on = getenv("VV_FACADE_PROFILE") != nullptr;
+  static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
+  ~HostProf() {
+    if (on && n) fprintf(stderr, "facade host profile over %ld iterations: wait-for-batch %.1f us, forward_backward call %.1f us, "
+                                 "loss read-back %.1f us (averages)\n", n, t_batch / n * 1e6, t_fb / n * 1e6, t_loss / n * 1e6);
+  }
+} g_hprof;
+}
+
 template <typename Dtype>
 Dtype Net<Dtype>::ForwardBackward(const vector<Blob<Dtype>*>&) {
   if (plan_.test) return ForwardTest();
   auto* data = static_cast<VideoSampledShotsDataLayer<Dtype>*>(layers_[plan_.data_layer].get());
+  const double tp0 = g_hprof.on ? HostProf::now() : 0;
   data->NextBatch(&idx_, &last_src_, &label_);
+  const double tp1 = g_hprof.on ? HostProf::now() : 0;
   cfg_.ctx_coeff = plan_.ctx_coeff.data();
   cfg_.item_weight = nullptr;
   if (plan_.weighted_loss) {
@@ -346,12 +361,17 @@ Dtype Net<Dtype>::ForwardBackward(const vector<Blob<Dtype>*>&) {
   for (size_t i = 0; i < idx_.size() && !q1; ++i) q1 = idx_[i] != last_src_[i];
   if (q1) VV_CHECK(vv_forward_backward_q1(ctx_, &cfg_, idx_.data(), last_src_.data()));
   else VV_CHECK(vv_forward_backward(ctx_, &cfg_, idx_.data(), 0));
+  ++iter_;
+  const double tp2 = g_hprof.on ? HostProf::now() : 0;
+  if (g_hprof.on) { g_hprof.t_batch += tp1 - tp0; g_hprof.t_fb += tp2 - tp1; ++g_hprof.n; }
+  if (!loss_needed_) return last_loss_;
   float loss = 0, viol = 0;
   VV_CHECK(vv_loss_get(ctx_, &loss, &viol));
+  if (g_hprof.on) g_hprof.t_loss += HostProf::now() - tp2;
   // keep the two scalar output blobs current (they feed the solver's display lines)
   if (has_blob(plan_.loss_blob)) blobs_[blob_names_index_[plan_.loss_blob]]->mutable_cpu_data()[0] = loss / (plan_.loss_weight ? plan_.loss_weight : 1.f);
   if (!plan_.violations_blob.empty()) blobs_[blob_names_index_[plan_.violations_blob]]->mutable_cpu_data()[0] = viol;
-  ++iter_;
+  last_loss_ = loss;
   return loss;
 }
 template <typename Dtype>

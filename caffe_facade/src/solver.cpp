@@ -100,6 +100,7 @@ void Solver<Dtype>::Solve(const char* resume_file) {
         (iter_ > 0 || param_.get_bool("test_initialization"))) TestAll();
     const bool display = param_.get_int("display") && iter_ % param_.get_int("display") == 0;
     net_->set_debug_info(display && param_.get_bool("debug_info"));
+    net_->set_loss_needed(display);
     Dtype loss = net_->ForwardBackward(bottom_vec);
     if (display) {
       LOG(INFO) << "Iteration " << iter_ << ", loss = " << loss;                      // solver.cpp:196
@@ -120,6 +121,7 @@ void Solver<Dtype>::Solve(const char* resume_file) {
     ComputeUpdateValue();
     net_->Update();
   }
+  net_->set_loss_needed(true);
   if (param_.get_bool("snapshot_after_train")) Snapshot();
   if (param_.get_int("display") && iter_ % param_.get_int("display") == 0) {
     Dtype loss;

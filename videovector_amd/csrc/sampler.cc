@@ -23,29 +23,69 @@ namespace {
 class LibcRand {
  public:
   LibcRand() {
+    uint32_t st[31];
     int64_t w = 1;
-    st_[0] = 1;
+    st[0] = 1;
     for (int i = 1; i < 31; ++i) {
       w = (16807 * w) % 2147483647;     // exact in 64 bits; equals glibc's overflow-free form
-      st_[i] = (uint32_t)w;
+      st[i] = (uint32_t)w;
     }
-    f_ = 3; r_ = 0;
-    for (int i = 0; i < 310; ++i) (void)step();
+    int f = 3, r = 0;
+    for (int i = 0; i < 310; ++i) {     // srandom discards the first 310 outputs
+      st[f] += st[r];
+      f = f == 30 ? 0 : f + 1;
+      r = r == 30 ? 0 : r + 1;
+    }
+    // Linear history: the word at st[f] is the oldest, x[k-31].  From here on the stream is
+    // x[k] = x[k-31] + x[k-3]; it does not depend on how the outputs are consumed, so it is produced a
+    // block at a time (three independent dependency chains) instead of one value per call.
+    for (int i = 0; i < 31; ++i) h_[i] = st[(f + i) % 31];
+    pos_ = kBlock;
   }
-  int32_t next() { return (int32_t)(step() >> 1); }
+  int32_t next() {
+    if (pos_ == kBlock) refill();
+    return (int32_t)(h_[31 + pos_++] >> 1);
+  }
+  // consume k values whose results nobody looks at (a shuffle of frames that are not used afterwards)
+  void discard(int k) {
+    while (k > 0) {
+      if (pos_ == kBlock) refill();
+      const int step = std::min(k, kBlock - pos_);
+      pos_ += step; k -= step;
+    }
+  }
 
  private:
-  uint32_t step() {
-    const uint32_t v = (st_[f_] += st_[r_]);
-    f_ = f_ == 30 ? 0 : f_ + 1;
-    r_ = r_ == 30 ? 0 : r_ + 1;
-    return v;
+  static constexpr int kBlock = 1024;
+  void refill() {
+    if (pos_ == kBlock && filled_) memcpy(h_, h_ + kBlock, 31 * sizeof(uint32_t));
+    for (int i = 31; i < 31 + kBlock; ++i) h_[i] = h_[i - 31] + h_[i - 3];
+    pos_ = 0; filled_ = true;
   }
-  uint32_t st_[31];
-  int f_, r_;
+  uint32_t h_[31 + kBlock];
+  int pos_;
+  bool filled_ = false;
 };
 
 struct Slot { int32_t row = -1, last = -1; };
+
+// a % d for 0 <= a < 2^32 and the divisors this sampler meets (1 .. max(max_buffer_size, longest video, 100)),
+// by two multiplications with a precomputed reciprocal instead of a hardware division (Lemire, Kaser, Kurz:
+// "Faster remainder by direct computation", 2019): M = floor((2^64 - 1) / d) + 1, a % d = floor(((M * a) mod 2^64) * d / 2^64).
+// The sampler is a chain of ~110 rand() % k per batch item; on the host this chain, not memory, sets its speed.
+class FastMod {
+ public:
+  void init(int dmax) {
+    m_.resize((size_t)dmax + 1);
+    for (int d = 1; d <= dmax; ++d) m_[d] = UINT64_C(0xFFFFFFFFFFFFFFFF) / (uint64_t)d + 1;
+  }
+  int32_t mod(int32_t a, int32_t d) const {
+    const uint64_t low = m_[d] * (uint64_t)(uint32_t)a;
+    return (int32_t)(((unsigned __int128)low * (uint64_t)d) >> 64);
+  }
+ private:
+  std::vector<uint64_t> m_;
+};
 
 }  // namespace
 
@@ -55,6 +95,8 @@ struct vv_sampler {
   std::vector<int64_t> row_base, shot_off;
   bool has_ids = false;
   LibcRand rng;
+  FastMod fm;
+  int32_t rmod(int32_t d) { return fm.mod(rng.next(), d); }     // rand() % d
   int32_t cursor = 0;
   std::vector<int32_t> buffer_ids;            // persistent permutation (…data_layer.cpp:81-83)
   std::vector<int32_t> buf_row;               // slot -> table row
@@ -80,7 +122,7 @@ struct vv_sampler {
   // include/caffe/util/rng.hpp:43-54
   void random_unique(std::vector<int32_t>& a, int n) {
     int left = (int)a.size();
-    for (int first = 0; first < n; ++first, --left) std::swap(a[first], a[first + rng.next() % left]);
+    for (int first = 0; first < n; ++first, --left) std::swap(a[first], a[first + rmod(left)]);
   }
 };
 
@@ -118,6 +160,7 @@ int vv_sampler_create(const vv_sampler_param* p, int32_t n_videos, const int32_t
   }
   if (shot_ids) { s->has_ids = true; s->shot_ids.assign(shot_ids, shot_ids + total); }
   s->perm.reserve(max_n);
+  s->fm.init(std::max(std::max(max_n, p->max_buffer_size), 100) + 1);
   {  // keys are in bijection with rows iff video ids are distinct, shot ids distinct within a video and
      // the records' row ranges do not overlap
     std::unordered_set<int32_t> vids(video_id, video_id + n_videos);
@@ -150,7 +193,7 @@ int vv_sampler_create(const vv_sampler_param* p, int32_t n_videos, const int32_t
     for (int64_t t = 0; t < tries && (int)s->buf_row.size() < mb; ++t) {
       const int v = s->cursor;
       s->cursor = (s->cursor + 1) % n_videos;
-      const int j = s->rng.next() % s->n_shots[v];
+      const int j = s->rmod(s->n_shots[v]);
       if (!s->contains(v, j)) {
         s->insert_key(v, j);
         s->buf_row.push_back((int32_t)(s->row_base[v] + j));
@@ -188,8 +231,8 @@ int vv_sampler_next(vv_sampler* s, int32_t* idx, int32_t* last_src, int32_t* lab
         const int msl = (n - C) / (C - 1);                                         // :609,:687
         int sl;
         if (p.context_type == VV_CONTEXT_PAST_CONTINUOUS) {
-          sl = s->rng.next() % (msl + 1);                                          // :610
-          begin = s->rng.next() % (n - (C - 1) * sl - C + 1);                      // :612-613
+          sl = s->rmod(msl + 1);                                                   // :610
+          begin = s->rmod(n - (C - 1) * sl - C + 1);                               // :612-613
         } else {
           sl = msl >= 1 ? msl - 1 : 0;                                             // :688
           begin = n - (C - 1) * sl - C;                                            // :690-691
@@ -202,9 +245,11 @@ int vv_sampler_next(vv_sampler* s, int32_t* idx, int32_t* last_src, int32_t* lab
         d.row = d.last = (int32_t)(base + frame);
       }
       if (p.context_type == VV_CONTEXT_PAST) {
-        if (Nn > 0 && n > C) {                                                     // :563-583
+        if (Nn > 0 && n > C && p.max_same_video_negs <= 0) {
+          s->rng.discard(n - C - 1);
+        } else if (Nn > 0 && n > C) {                                              // :563-583
           for (int i = C + 1; i < n; ++i) {
-            const int j = C + s->rng.next() % (i - C + 1);
+            const int j = C + s->rmod(i - C + 1);
             if (i != j) std::swap(perm[i], perm[j]);
           }
           for (int nid = C; nid < n && added < p.max_same_video_negs; ++nid)
@@ -225,9 +270,11 @@ int vv_sampler_next(vv_sampler* s, int32_t* idx, int32_t* last_src, int32_t* lab
         Slot& d = (i == half) ? sl[0] : sl[++ctx];
         d.row = d.last = r;
       }
-      if (Nn > 0 && n > C) {                                                       // :479-503
+      if (Nn > 0 && n > C && p.max_same_video_negs <= 0) {
+        s->rng.discard(n - C - 1);                // the shuffle below draws n-C-1 values; its result is unused here
+      } else if (Nn > 0 && n > C) {                                                // :479-503
         for (int i = C + 1; i < n; ++i) {         // std::random_shuffle(perm + C, perm + n)
-          const int j = C + s->rng.next() % (i - C + 1);
+          const int j = C + s->rmod(i - C + 1);
           if (i != j) std::swap(perm[i], perm[j]);
         }
         for (int nid = C; nid < n && added < p.max_same_video_negs; ++nid)
@@ -238,19 +285,40 @@ int vv_sampler_next(vv_sampler* s, int32_t* idx, int32_t* last_src, int32_t* lab
     s->cursor = (s->cursor + 1) % V;                                               // :826-846
     if (!ok) continue;                                                             // :848
     if (Nn > 0) {
-      s->random_unique(s->buffer_ids, Nn - added);                                 // :855
-      for (int c = C + added; c < CN; ++c)
-        sl[c].row = sl[c].last = s->buf_row[s->buffer_ids[c - C - added]];         // :856-875
+      // :855 random_unique over the persistent slot permutation, fused with :856-875 (read the drawn slots' rows)
+      int32_t* ids = s->buffer_ids.data();
+      const int32_t* brow = s->buf_row.data();
+      int left = p.max_buffer_size;
+      for (int first = 0; first < Nn - added; ++first, --left) {
+        const int r = first + s->rmod(left);
+        const int32_t t = ids[r]; ids[r] = ids[first]; ids[first] = t;
+        sl[C + added + first].row = sl[C + added + first].last = brow[t];
+      }
     }
     if (label) label[item] = s->video_id[v];                                       // :879
     ++item;
-    if (Nn > 0 && p.negative_swap_percentage > 0) {                                // :888-906
+    if (Nn > 0 && p.negative_swap_percentage > 0 && s->dense_keys) {               // :888-906, bitmap key set
+      uint8_t* inb = s->row_in_buf.data() - s->row_min;      // indexed by table row
+      int32_t* brow = s->buf_row.data();
+      const int swap = p.negative_swap_percentage, mb = p.max_buffer_size;
+      const int32_t vid = s->video_id[v];
+      for (int j = 0; j < n; ++j) {
+        const int64_t r = base + j;
+        if (inb[r]) continue;
+        if (s->rng.next() % 100 < swap) {                                          // :27
+          const int pos = s->rmod(mb);                                             // :29
+          inb[brow[pos]] = 0;
+          inb[r] = 1;
+          s->buf_key[pos] = vv_sampler::key(vid, s->shot_id(v, j));
+          brow[pos] = (int32_t)r;
+        }
+      }
+    } else if (Nn > 0 && p.negative_swap_percentage > 0) {                         // :888-906, general key set
       for (int j = 0; j < n; ++j) {
         if (s->contains(v, j)) continue;
         if (s->rng.next() % 100 < p.negative_swap_percentage) {                    // :27
-          const int pos = s->rng.next() % p.max_buffer_size;                       // :29
-          if (s->dense_keys) s->row_in_buf[(size_t)(s->buf_row[pos] - s->row_min)] = 0;
-          else s->keys.erase(s->buf_key[pos]);
+          const int pos = s->rmod(p.max_buffer_size);                              // :29
+          s->keys.erase(s->buf_key[pos]);
           s->insert_key(v, j);
           s->buf_key[pos] = vv_sampler::key(s->video_id[v], s->shot_id(v, j));
           s->buf_row[pos] = (int32_t)(base + j);
@@ -259,8 +327,10 @@ int vv_sampler_next(vv_sampler* s, int32_t* idx, int32_t* last_src, int32_t* lab
     }
   }
   const size_t n = s->slots.size();
-  if (idx) for (size_t i = 0; i < n; ++i) idx[i] = s->slots[i].row;
-  if (last_src) for (size_t i = 0; i < n; ++i) last_src[i] = s->slots[i].last;
+  const Slot* sp = s->slots.data();
+  if (idx && last_src) for (size_t i = 0; i < n; ++i) { idx[i] = sp[i].row; last_src[i] = sp[i].last; }
+  else if (idx) for (size_t i = 0; i < n; ++i) idx[i] = sp[i].row;
+  else if (last_src) for (size_t i = 0; i < n; ++i) last_src[i] = sp[i].last;
   return VV_OK;
 }
 
