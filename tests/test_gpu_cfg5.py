@@ -1,0 +1,67 @@
+"""BASELINE config 5 shapes on one GPU (the "bf16 MFMA path: 4096 -> 1024-d, batch 4096, 200 negatives" case, here
+the per-GPU work of that configuration): 839 680 batch rows, D = 1024 (four N tiles, the streaming score kernel),
+bf16 operands.  Checks the de-duplicated path against the dense path at full size, and a shard against the oracle
+with the tolerance the bf16 operand rounding allows (fp32-tol check vs CPU)."""
+import numpy as np
+import pytest
+
+from videovector_amd.synth import SyntheticVideos, init_weights
+
+pytestmark = pytest.mark.gpu
+
+B, C, Nn, F, D = 4096, 5, 200, 4096, 1024
+
+
+@pytest.fixture(scope="module")
+def setup():
+    import videovector_amd as vv
+    ds = SyntheticVideos(seed=1701, n_videos=2048)
+    smp = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, batch_size=B, context_size=C, num_negative_samples=Nn,
+                     max_buffer_size=5000, negative_swap_percentage=50)
+    idx = smp.next()
+    W, b = init_weights(5, D, F)
+    return vv, ds, idx, W, b
+
+
+def test_cfg5_dedup_equals_dense_at_full_size(setup):
+    vv, ds, idx, W, b = setup
+    out = {}
+    for mode in (False, True):
+        eng = vv.Engine(0, "bf16")
+        eng.set_dedup(mode)
+        eng.table_synth(ds.seed, ds.n_rows, F)
+        eng.params_set(W, b)
+        cfg = vv.StepConfig(B, C, Nn)
+        eng.forward_backward(cfg, idx)
+        dW, db = eng.grads()
+        out[mode] = (eng.loss(), dW.copy(), db.copy(), eng.dedup_stats())
+        del eng
+    (l0, dW0, db0, st0), (l1, dW1, db1, st1) = out[False], out[True]
+    n_unique = len(np.unique(idx))
+    assert st0 == (B * (C + Nn), B * (C + Nn)) and st1 == (B * (C + Nn), n_unique)
+    print("CFG5 rows %d distinct %d (factor %.1f) loss %.6f violations %.0f" % (st1 + (st1[0] / st1[1],) + l1))
+    assert l0 == l1 and np.array_equal(db0, db1)                  # same forward, same per-instance gradients
+    rel = np.linalg.norm(dW1 - dW0) / np.linalg.norm(dW0)
+    assert rel <= 4e-3, rel                                       # bf16 rounding of the per-row gradient sums
+    assert np.isfinite(l1[0]) and 0 < l1[0] < 16 and 0 <= l1[1] <= B * Nn
+
+
+def test_cfg5_shard_matches_oracle_within_bf16_tolerance(setup, oracle):
+    vv, ds, idx, W, b = setup
+    sh = idx[1000:1032]
+    uniq, inv = np.unique(sh.reshape(-1), return_inverse=True)
+    table = ds.table(F, uniq)
+    idx_local = inv.reshape(sh.shape).astype(np.int32)
+    ref = oracle.forward_backward(table, idx_local, W, b, C_=C, Nn=Nn, global_count=B * Nn,
+                                  want=("H", "s_true", "s_bogus"))
+    eng = vv.Engine(0, "bf16")
+    eng.table_synth(ds.seed, ds.n_rows, F)
+    eng.params_set(W, b)
+    cfg = vv.StepConfig(32, C, Nn, global_count=B * Nn)
+    eng.forward_backward(cfg, sh)
+    got = eng.blobs(cfg)
+    e_emb = (np.linalg.norm(got["ip2"] - ref["H"], axis=1) / np.maximum(np.linalg.norm(ref["H"], axis=1), 1e-30)).max()
+    print("CFG5 shard emb=%.3e loss=%.6f/%.6f" % (e_emb, eng.loss()[0], ref["loss"]))
+    assert e_emb <= 4e-3                                           # bf16 operands: 8 significant bits
+    assert abs(eng.loss()[0] - ref["loss"]) <= 1e-3 * ref["loss"]
+    assert np.abs(got["negative_scores"] - ref["s_bogus"]).max() <= 2e-3
