@@ -519,7 +519,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   sa.grad_scale = cfg->loss_weight / (float)gcount;
   sa.drop_scale = cfg->dropout_ratio > 0.f ? 1.f / (1.f - cfg->dropout_ratio) : 1.f;
   sa.sg = c->sg;
-  sa.map = dd ? c->dd_map : nullptr; sa.pos = dd ? c->dd_pos : nullptr;
+  sa.map = dd ? c->dd_map : nullptr; sa.seg_start = dd ? c->dd_seg : nullptr; sa.ord = dd ? c->dd_ord : nullptr;
   sa.item_w = cfg->item_weight ? c->item_w : nullptr;
 
   PROFILED(c, "score_loss", launch_score_loss(c->prec, sa, s));
@@ -697,6 +697,10 @@ int vv_blobs_get(vv_ctx* c, float* ip2, float* target_score, float* negative_sco
     uint16_t* ungrouped = nullptr;
     if (c->last_dedup) {
       HIPCHK(hipMalloc(&ungrouped, (size_t)c->R * c->Dp * 2));
+      DedupArgs da;
+      memset(&da, 0, sizeof(da));
+      da.map = c->dd_map; da.ord = c->dd_ord; da.seg_start = c->dd_seg; da.pos = c->dd_pos; da.R = c->R;
+      launch_dedup_pos(da, c->stream);
       launch_gather_rows_u16(c->dYh, c->dd_pos, c->R, c->Dp, ungrouped, c->stream);
     }
     launch_dyh_to_float(c->prec, ungrouped ? ungrouped : c->dYh, c->R, D, c->Dp, 1.f / c->sg, d, c->stream);

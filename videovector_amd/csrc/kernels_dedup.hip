@@ -16,7 +16,8 @@
 //                   Slots are ordered by first appearance, so the order is deterministic.
 //   k_dd_map      : instance -> slot, per-slot instance count, arrival order inside the slot.
 //   k_dd_segstart : exclusive scan of the counts (same single-pass scan).
-//   k_dd_pos      : instance -> row of the grouped gradient buffer.
+//   k_dd_pos      : instance -> row of the grouped gradient buffer (debug accessor only; the score kernel
+//                   computes seg_start[map[r]] + ord[r] inline).
 //   k_segsum      : per slot, sum of its instances' 16-bit gradient rows.  f16: accumulated in f64,
 //                   which is EXACT for up to 2^13 f16 addends, so the arrival order (atomics) cannot
 //                   change the result.  bf16: f64 as well (order-independent unless the addends span
@@ -143,6 +144,10 @@ void launch_dedup(const DedupArgs& a, hipStream_t s) {
 void launch_dedup_groups(const DedupArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_dd_map, dim3((a.R + 255) / 256), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_dd_segstart, dim3(a.R / DD_BLOCK + 1), dim3(DD_BLOCK), 0, s, a);
+}
+// instance -> grouped gradient row as an array; the score kernel computes the same value inline, only the
+// debug accessor (vv_blobs_get ip1_diff) needs it materialised
+void launch_dedup_pos(const DedupArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_dd_pos, dim3((a.R + 255) / 256), dim3(256), 0, s, a);
 }
 

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
   for (int ch = tid; ch < CN; ch += SL_THREADS) {
     const int r = b * CN + ch;
     hoff[ch] = a.map ? a.map[r] : r;
-    ooff[ch] = a.pos ? a.pos[r] : r;
+    ooff[ch] = a.map ? a.seg_start[a.map[r]] + a.ord[r] : r;
   }
   __syncthreads();
 #define HROW(ch) (a.H + (int64_t)hoff[ch] * D)
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss_reg(ScoreArgs a) {
   for (int j = 0; j < CXM; ++j) cf[j] = j + 1 < C ? a.coeff[j] : 0.f;
   for (int ch = tid; ch < CN; ch += SL_THREADS) {
     const int r = b * CN + ch;
-    ooff[ch] = a.pos ? a.pos[r] : r;
+    ooff[ch] = a.map ? a.seg_start[a.map[r]] + a.ord[r] : r;
   }
 
   // ---- phase 1: context mean and its norm

@@ -70,10 +70,11 @@ struct ScoreArgs {
   float drop_scale;        // 1/(1-ratio) or 1
   float sg;                // half-precision gradient scale
   // row-dedup mode (both NULL otherwise): H holds one row per UNIQUE table row, instance r reads
-  // H[map[r]] and writes its gradient row to dYh[pos[r]] (instances of one unique row contiguous)
+  // H[map[r]] and writes its gradient row to dYh[seg_start[map[r]] + ord[r]] (instances of one unique row contiguous)
   const float* item_w = nullptr;     // [B] loss-term weight of each item (MAX_MARGIN_LOSS 3rd bottom) or null
   const int32_t* map = nullptr;      // [R]
-  const int32_t* pos = nullptr;      // [R]
+  const int32_t* seg_start = nullptr;  // [U + 1]   pos[r] = seg_start[map[r]] + ord[r]
+  const int32_t* ord = nullptr;      // [R]
 };
 
 // Row de-duplication of one batch (kernels_dedup.hip).  The sampler draws the negatives of every item
@@ -148,6 +149,7 @@ void launch_wgrad_gemm(int prec, const WgradArgs& a, hipStream_t s);
 void launch_score_loss(int prec, const ScoreArgs& a, hipStream_t s);
 void launch_dedup(const DedupArgs& a, hipStream_t s);
 void launch_dedup_groups(const DedupArgs& a, hipStream_t s);
+void launch_dedup_pos(const DedupArgs& a, hipStream_t s);   // pos[] for the debug accessors only
 void launch_segsum(int prec, const SegsumArgs& a, hipStream_t s);
 void launch_gather_rows_f32(const float* src, const int32_t* map, int R, int D, float* dst, hipStream_t s);
 void launch_gather_rows_u16(const uint16_t* src, const int32_t* pos, int R, int Dp, uint16_t* dst, hipStream_t s);
