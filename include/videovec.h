@@ -222,6 +222,8 @@ int vv_sampler_destroy(vv_sampler* s);
  * "score_loss", "wgrad_gemm", "reduce", "sgd") over the launches since the last reset, measured
  * with hipEvents on the context's stream (only while enabled; enabling adds two event records
  * per launch). */
+/* on: 0 = off, 1 = every step, N > 1 = every N-th step (a step ends with vv_apply_update).  The events ride on the
+ * kernels' own dispatch packets (hipExtLaunchKernelGGL); no extra packets are queued. */
 int vv_profile_enable(vv_ctx* ctx, int on);
 int vv_profile_get(vv_ctx* ctx, const char* kernel, double* avg_ms, int64_t* launches);
 

@@ -76,22 +76,36 @@ struct vv_ctx {
   uint32_t dd_epoch = 0;
   // profiling
   bool prof = false;
+  int prof_every = 1;               // record every prof_every-th forward/backward + update (vv_profile_enable's argument)
+  uint64_t prof_calls = 0;
   std::map<std::string, ProfEntry> prof_map;
+  std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;    // events are reused across profiling sessions
 };
 
 static void dfree(void* p) { if (p) (void)hipFree(p); }
 
+namespace vv { thread_local ProfPair g_prof; }
+
+// Arms a pair of events for the launcher called next: its (first / last) kernel is dispatched with
+// hipExtLaunchKernelGGL, which stamps them from the dispatch packet itself (vv_internal.h: VV_LAUNCH).
 static void prof_begin(vv_ctx* c, const char* name, hipEvent_t* e0, hipEvent_t* e1) {
   *e0 = *e1 = nullptr;
-  if (!c->prof) return;
+  if (!c->prof || (c->prof_calls % (uint64_t)c->prof_every) != 0) return;
   auto& pe = c->prof_map[name];
   if (pe.ev.size() >= 8192) return;
-  if (hipEventCreate(e0) != hipSuccess || hipEventCreate(e1) != hipSuccess) { *e0 = *e1 = nullptr; return; }
-  (void)hipEventRecord(*e0, c->stream);
+  while (c->ev_pool.size() < c->ev_used + 2) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    c->ev_pool.push_back(e);
+  }
+  *e0 = c->ev_pool[c->ev_used++]; *e1 = c->ev_pool[c->ev_used++];
+  vv::g_prof.start = *e0; vv::g_prof.stop = *e1;
 }
 static void prof_end(vv_ctx* c, const char* name, hipEvent_t e0, hipEvent_t e1) {
   if (!e0) return;
-  (void)hipEventRecord(e1, c->stream);
+  // a launcher that did not take the events (a kernel variant launched the plain way): fall back to stream records
+  if (vv::g_prof.start) { (void)hipEventRecord(e0, c->stream); vv::g_prof.start = nullptr; }
+  if (vv::g_prof.stop) { (void)hipEventRecord(e1, c->stream); vv::g_prof.stop = nullptr; }
   c->prof_map[name].ev.emplace_back(e0, e1);
 }
 #define PROFILED(c, name, call)                 \
@@ -188,8 +202,7 @@ int vv_destroy(vv_ctx* c) {
   dfree(c->scales); dfree(c->wmax_blocks); dfree(c->grads_own); dfree(c->mask); dfree(c->loss2);
   dfree(c->dd_key); dfree(c->dd_info);
   if (c->U_host) (void)hipHostFree(c->U_host);
-  for (auto& kv : c->prof_map)
-    for (auto& e : kv.second.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
 
   delete c;
@@ -610,6 +623,7 @@ int vv_apply_update(vv_ctx* c, const vv_step_cfg* cfg) {
   launch_scale_update(c->prec, c->scales, c->wmax_blocks, c->stream);
   HIPCHK(hipGetLastError());
   c->iter++;
+  c->prof_calls++;
   return VV_OK;
 }
 
@@ -830,10 +844,11 @@ int vv_retrieval_stats(vv_ctx* c, const float* feat, int32_t n, int32_t dim, con
 int vv_profile_enable(vv_ctx* c, int on) {
   if (!c) return fail(VV_ERR_ARG, "vv_profile_enable: ctx is NULL");
   HIPCHK(hipStreamSynchronize(c->stream));
-  for (auto& kv : c->prof_map)
-    for (auto& e : kv.second.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   c->prof_map.clear();
+  c->ev_used = 0;
   c->prof = on != 0;
+  c->prof_every = on > 1 ? on : 1;
+  c->prof_calls = 0;
   return VV_OK;
 }
 

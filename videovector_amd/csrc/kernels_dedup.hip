@@ -136,14 +136,14 @@ __global__ __launch_bounds__(256) void k_dd_pos(DedupArgs a) {
 // part 1: what the forward GEMM needs (distinct rows and their count)
 void launch_dedup(const DedupArgs& a, hipStream_t s) {
   const int g256 = (a.Rp + 255) / 256;
-  hipLaunchKernelGGL(k_dd_claim, dim3(g256), dim3(256), 0, s, a);
+  VV_LAUNCH_FIRST(k_dd_claim, dim3(g256), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_dd_leaders, dim3((a.R + DD_BLOCK - 1) / DD_BLOCK), dim3(DD_BLOCK), 0, s, a);
 }
 // part 2: what the score kernel needs (instance -> slot / grouped gradient row); independent of the
 // forward GEMM, so the caller may run it on a second stream beside it
 void launch_dedup_groups(const DedupArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_dd_map, dim3((a.R + 255) / 256), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_dd_segstart, dim3(a.R / DD_BLOCK + 1), dim3(DD_BLOCK), 0, s, a);
+  VV_LAUNCH_LAST(k_dd_segstart, dim3(a.R / DD_BLOCK + 1), dim3(DD_BLOCK), 0, s, a);
 }
 // instance -> grouped gradient row as an array; the score kernel computes the same value inline, only the
 // debug accessor (vv_blobs_get ip1_diff) needs it materialised
@@ -184,8 +184,8 @@ __global__ __launch_bounds__(256) void k_segsum(SegsumArgs a) {
 
 void launch_segsum(int prec, const SegsumArgs& a, hipStream_t s) {
   const dim3 grid((a.Rp + 3) / 4), block(256);
-  if (prec == 0) hipLaunchKernelGGL(k_segsum<F16>, grid, block, 0, s, a);
-  else hipLaunchKernelGGL(k_segsum<BF16>, grid, block, 0, s, a);
+  if (prec == 0) VV_LAUNCH(k_segsum<F16>, grid, block, 0, s, a);
+  else VV_LAUNCH(k_segsum<BF16>, grid, block, 0, s, a);
 }
 
 // debug / parity accessors: expand per-slot rows back to per-instance rows

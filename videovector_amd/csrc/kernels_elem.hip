@@ -391,7 +391,7 @@ static bool launch_score_loss_reg(const ScoreArgs& a, hipStream_t s) {
   // fast path: D == 512, at most 52 target/negative rows (13 per wave) and at most 6 context rows
   if (a.D != 512 || 1 + a.Nn > 52 || a.C - 1 > 6) return false;
   const size_t lds = sizeof(float) * ((size_t)10 * a.D + 4 * (a.C + a.Nn) + 12);
-  hipLaunchKernelGGL((k_score_loss_reg<T, 13, 2>), dim3(a.B), dim3(SL_THREADS), lds, s, a);
+  VV_LAUNCH((k_score_loss_reg<T, 13, 2>), dim3(a.B), dim3(SL_THREADS), lds, s, a);
   return true;
 }
 
@@ -407,7 +407,7 @@ void launch_score_loss(int prec, const ScoreArgs& a, hipStream_t s) {
   do {                                                                                           \
     (void)hipFuncSetAttribute((const void*)k_score_loss<T, V>,                                   \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
-    hipLaunchKernelGGL((k_score_loss<T, V>), grid, block, lds, s, a);                            \
+    VV_LAUNCH((k_score_loss<T, V>), grid, block, lds, s, a);                            \
   } while (0)
   if (prec == 0) { if (vec) VV_SL(F16, true); else VV_SL(F16, false); }
   else { if (vec) VV_SL(BF16, true); else VV_SL(BF16, false); }
@@ -513,8 +513,8 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
 }
 void launch_reduce(const ReduceArgs& a, hipStream_t s) {
   const dim3 grid(RED_DW_BLOCKS + (a.D + 15) / 16 + 1);      // + the loss block
-  if (a.F % 4 == 0) hipLaunchKernelGGL(k_reduce<true>, grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(k_reduce<false>, grid, dim3(256), 0, s, a);
+  if (a.F % 4 == 0) VV_LAUNCH(k_reduce<true>, grid, dim3(256), 0, s, a);
+  else VV_LAUNCH(k_reduce<false>, grid, dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------- SGD ----------
@@ -587,8 +587,8 @@ __global__ __launch_bounds__(256) void k_sgd(SgdArgs a) {
 void launch_sgd(int prec, const SgdArgs& a, hipStream_t s) {
   const bool vec = a.F % 4 == 0;
   const dim3 grid(SGD_BLOCKS), block(256);
-  if (prec == 0) { if (vec) hipLaunchKernelGGL((k_sgd<F16, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_sgd<F16, false>), grid, block, 0, s, a); }
-  else { if (vec) hipLaunchKernelGGL((k_sgd<BF16, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_sgd<BF16, false>), grid, block, 0, s, a); }
+  if (prec == 0) { if (vec) VV_LAUNCH((k_sgd<F16, true>), grid, block, 0, s, a); else VV_LAUNCH((k_sgd<F16, false>), grid, block, 0, s, a); }
+  else { if (vec) VV_LAUNCH((k_sgd<BF16, true>), grid, block, 0, s, a); else VV_LAUNCH((k_sgd<BF16, false>), grid, block, 0, s, a); }
 }
 
 // next W->half scale from the running max: f16 keeps max|W|*sw in [2^11, 2^12); bf16 needs none.

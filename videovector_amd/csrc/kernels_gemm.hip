@@ -655,11 +655,11 @@ static void launch_fwd_t(const FwdArgs& a, hipStream_t s) {
         if (g_gemm_variant == 1) {                                                                 \
           (void)hipFuncSetAttribute((const void*)k_fwd_gemm_ring<T, DROP, VEC, N>,                 \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES);   \
-          hipLaunchKernelGGL((k_fwd_gemm_ring<T, DROP, VEC, N>), grid, block, RING_LDS_BYTES, s, a); \
+          VV_LAUNCH((k_fwd_gemm_ring<T, DROP, VEC, N>), grid, block, RING_LDS_BYTES, s, a); \
         } else {                                                                                   \
           (void)hipFuncSetAttribute((const void*)k_fwd_gemm<T, DROP, VEC, N>,                      \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);   \
-          hipLaunchKernelGGL((k_fwd_gemm<T, DROP, VEC, N>), grid, block, GEMM_LDS_BYTES, s, a);    \
+          VV_LAUNCH((k_fwd_gemm<T, DROP, VEC, N>), grid, block, GEMM_LDS_BYTES, s, a);    \
         }                                                                                          \
         return;                                                                                    \
       }
@@ -690,7 +690,7 @@ static void launch_fwd_t(const FwdArgs& a, hipStream_t s) {
                          hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES), true);                 \
         (void)o;                                                                                             \
         const dim3 g2(((a.R + 32 * M - 1) / (32 * M)) * (Dp / BN));                                          \
-        hipLaunchKernelGGL((k_fwd_gemm<T, DROP, VEC, 0, M, SC>), g2, block, GEMM_LDS_BYTES, s, a);           \
+        VV_LAUNCH((k_fwd_gemm<T, DROP, VEC, 0, M, SC>), g2, block, GEMM_LDS_BYTES, s, a);           \
         return;                                                                                              \
       }
       VV_FWD_MI(8, 1) VV_FWD_MI(7, 1) VV_FWD_MI(6, 1) VV_FWD_MI(5, 1) VV_FWD_MI(4, 1)
@@ -702,10 +702,10 @@ static void launch_fwd_t(const FwdArgs& a, hipStream_t s) {
     static bool once2 = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ring<T, DROP, VEC>,
                          hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES), true);
     (void)once2;
-    hipLaunchKernelGGL((k_fwd_gemm_ring<T, DROP, VEC>), grid, block, RING_LDS_BYTES, s, a);
+    VV_LAUNCH((k_fwd_gemm_ring<T, DROP, VEC>), grid, block, RING_LDS_BYTES, s, a);
     return;
   }
-  hipLaunchKernelGGL((k_fwd_gemm<T, DROP, VEC>), grid, block, GEMM_LDS_BYTES, s, a);
+  VV_LAUNCH((k_fwd_gemm<T, DROP, VEC>), grid, block, GEMM_LDS_BYTES, s, a);
 }
 
 template <typename T>
@@ -725,7 +725,7 @@ static void launch_wgrad_t(const WgradArgs& a, hipStream_t s) {
                       hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES), true);
   (void)once;
   const dim3 grid((a.Dp / BM) * (a.Fp / BN) * a.S), block(GEMM_THREADS);
-  hipLaunchKernelGGL((k_wgrad_gemm<T, TR>), grid, block, GEMM_LDS_BYTES, s, a);
+  VV_LAUNCH((k_wgrad_gemm<T, TR>), grid, block, GEMM_LDS_BYTES, s, a);
 }
 
 template <typename T>
@@ -734,7 +734,7 @@ static void launch_wgrad_ring_t(const WgradArgs& a, hipStream_t s) {
                       hipFuncAttributeMaxDynamicSharedMemorySize, WG_RING_LDS_BYTES), true);
   (void)once;
   const dim3 grid((a.Dp / BM) * (a.Fp / BN) * a.S), block(GEMM_THREADS);
-  hipLaunchKernelGGL((k_wgrad_gemm_ring<T>), grid, block, WG_RING_LDS_BYTES, s, a);
+  VV_LAUNCH((k_wgrad_gemm_ring<T>), grid, block, WG_RING_LDS_BYTES, s, a);
 }
 
 void launch_wgrad_gemm(int prec, const WgradArgs& a, hipStream_t s) {
@@ -745,11 +745,11 @@ void launch_wgrad_gemm(int prec, const WgradArgs& a, hipStream_t s) {
       if (g_gemm_variant == 1) {                                                                   \
         (void)hipFuncSetAttribute((const void*)k_wgrad_gemm_ring<F16, N>,                          \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, WG_RING_LDS_BYTES);  \
-        hipLaunchKernelGGL((k_wgrad_gemm_ring<F16, N>), grid, block, WG_RING_LDS_BYTES, s, a);     \
+        VV_LAUNCH((k_wgrad_gemm_ring<F16, N>), grid, block, WG_RING_LDS_BYTES, s, a);     \
       } else {                                                                                     \
         (void)hipFuncSetAttribute((const void*)k_wgrad_gemm<F16, true, N>,                         \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);     \
-        hipLaunchKernelGGL((k_wgrad_gemm<F16, true, N>), grid, block, GEMM_LDS_BYTES, s, a);       \
+        VV_LAUNCH((k_wgrad_gemm<F16, true, N>), grid, block, GEMM_LDS_BYTES, s, a);       \
       }                                                                                            \
       return;                                                                                      \
     }
@@ -761,7 +761,7 @@ void launch_wgrad_gemm(int prec, const WgradArgs& a, hipStream_t s) {
 #define VV_WG_SCHED(N)                                                                                         \
     if (g_wgrad_sched == N) {                                                                                  \
       (void)hipFuncSetAttribute((const void*)k_wgrad_gemm<F16, true, 0, N>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES); \
-      hipLaunchKernelGGL((k_wgrad_gemm<F16, true, 0, N>), grid, block, GEMM_LDS_BYTES, s, a);                    \
+      VV_LAUNCH((k_wgrad_gemm<F16, true, 0, N>), grid, block, GEMM_LDS_BYTES, s, a);                    \
       return;                                                                                                  \
     }
     VV_WG_SCHED(1) VV_WG_SCHED(2) VV_WG_SCHED(3)

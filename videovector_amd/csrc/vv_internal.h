@@ -2,6 +2,7 @@
 // gfx950 (MI355X, CDNA4) only.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 namespace vv {
@@ -142,6 +143,25 @@ struct SgdArgs {
   int solver_type;         // 0 SGD, 1 Nesterov, 2 AdaGrad
   float delta;             // AdaGrad stability constant
 };
+
+// Kernel timing without extra queue packets: when the ABI layer has armed a pair of events (vv_profile_enable),
+// the launch goes through hipExtLaunchKernelGGL, which stamps the events from the dispatch packet's own
+// start / completion signal.  (A hipEventRecord pair around every kernel costs ~3 us of queue time per record on
+// this runtime -- 50 us per step over the seven timed kernels -- and would distort the very step being measured.)
+struct ProfPair { hipEvent_t start = nullptr, stop = nullptr; };
+extern thread_local ProfPair g_prof;
+#define VV_LAUNCH_EV(kern, grid, block, lds, s, use_start, use_stop, ...)                                   \
+  do {                                                                                                     \
+    hipEvent_t e0_ = (use_start) ? vv::g_prof.start : nullptr, e1_ = (use_stop) ? vv::g_prof.stop : nullptr; \
+    if (e0_ || e1_) {                                                                                      \
+      hipExtLaunchKernelGGL(kern, grid, block, lds, s, e0_, e1_, 0, __VA_ARGS__);                           \
+      if (use_start) vv::g_prof.start = nullptr;                                                           \
+      if (use_stop) vv::g_prof.stop = nullptr;                                                             \
+    } else hipLaunchKernelGGL(kern, grid, block, lds, s, __VA_ARGS__);                                      \
+  } while (0)
+#define VV_LAUNCH(kern, grid, block, lds, s, ...) VV_LAUNCH_EV(kern, grid, block, lds, s, true, true, __VA_ARGS__)
+#define VV_LAUNCH_FIRST(kern, grid, block, lds, s, ...) VV_LAUNCH_EV(kern, grid, block, lds, s, true, false, __VA_ARGS__)
+#define VV_LAUNCH_LAST(kern, grid, block, lds, s, ...) VV_LAUNCH_EV(kern, grid, block, lds, s, false, true, __VA_ARGS__)
 
 // kernel launchers (defined in the .hip files); prec: 0 = f16, 1 = bf16
 void launch_fwd_gemm(int prec, const FwdArgs& a, hipStream_t s);
