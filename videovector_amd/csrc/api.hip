@@ -498,7 +498,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
     DedupArgs da;
     da.idx = didx; da.rows = c->rows; da.u_host = c->U_host_dev; da.key = c->dd_key; da.agg = c->dd_agg; da.agg_stride = c->dd_agg_stride;
     da.slot_of = c->dd_slot_of; da.uniq_rows = c->dd_uniq; da.map = c->dd_map; da.ord = c->dd_ord; da.cnt = c->dd_cnt;
-    da.seg_start = c->dd_seg; da.pos = c->dd_pos; da.info = c->dd_info;
+    da.seg_start = c->dd_seg; da.pos = c->dd_pos; da.info = c->dd_info; da.tickets = c->dd_info + 2;
     da.R = c->R; da.Rp = c->Rp; da.zero_row = (int32_t)c->n_rows; da.epoch = c->dd_epoch;
     // (Running the grouping kernels on a second stream beside the forward GEMM was measured: the two
     // cross-stream event waits cost more than the ~15 us they hide -- 0.405 vs 0.394 ms per step.)

@@ -11,8 +11,8 @@
 //
 //   k_dd_claim    : index -> table row (empty slots -> the zero row), then leader election, atomicMax of (epoch, ~r) per table row -> the smallest instance
 //                   index of every distinct row wins; epoch tags make a reset pass unnecessary.
-//   k_dd_leaders  : slot = rank of the leader among leaders (single-pass scan: every block publishes
-//                   its count as an epoch-tagged word, later blocks sum the words of earlier ones).
+//   k_dd_leaders  : slot = rank of the leader among leaders (single-pass scan: every workgroup takes a ticket,
+//                   publishes its count as an epoch-tagged word and sums the words of the earlier tickets).
 //                   Slots are ordered by first appearance, so the order is deterministic.
 //   k_dd_map      : instance -> slot, per-slot instance count, arrival order inside the slot.
 //   k_dd_segstart : exclusive scan of the counts (same single-pass scan).
@@ -37,6 +37,7 @@ __device__ __forceinline__ void st_agent(unsigned long long* p, unsigned long lo
 
 __global__ __launch_bounds__(256) void k_dd_claim(DedupArgs a) {
   const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r == 0) a.tickets[0] = 0;        // k_dd_leaders' ticket counter (kernel boundary orders the reset)
   if (r >= a.Rp) return;
   int row = a.zero_row;
   if (r < a.R) { const int i = a.idx[r]; if (i >= 0) row = i; }
@@ -69,11 +70,21 @@ __device__ __forceinline__ int block_excl_scan(int v, int* total, int* sm /* >= 
   return res;
 }
 
-// sum of the aggregates of blocks [0, blockIdx.x): spin on each word until it carries this epoch.
-// Blocks are dispatched in index order, so every block waited on is resident or finished.
-__device__ __forceinline__ int lookback_sum(const unsigned long long* agg, unsigned epoch, int* sm) {
+// Logical workgroup index = arrival order (a ticket), not blockIdx: a workgroup only ever waits for tickets
+// smaller than its own, whose owners have already started, so the scan cannot deadlock whatever order the
+// hardware dispatches workgroups in.
+__device__ __forceinline__ int take_ticket(int32_t* counter, int* sm) {
+  if (threadIdx.x == 0) sm[19] = atomicAdd(counter, 1);
+  __syncthreads();
+  const int t = sm[19];
+  __syncthreads();
+  return t;
+}
+
+// sum of the aggregates of logical workgroups [0, bid): spin on each word until it carries this epoch
+__device__ __forceinline__ int lookback_sum(const unsigned long long* agg, unsigned epoch, int bid, int* sm) {
   int s = 0;
-  for (int j = threadIdx.x; j < (int)blockIdx.x; j += DD_BLOCK) {
+  for (int j = threadIdx.x; j < bid; j += DD_BLOCK) {
     unsigned long long w;
     do { w = ld_agent(agg + j); } while ((unsigned)(w >> 32) != epoch);
     s += (int)(unsigned)w;
@@ -84,8 +95,9 @@ __device__ __forceinline__ int lookback_sum(const unsigned long long* agg, unsig
 }
 
 __global__ __launch_bounds__(DD_BLOCK) void k_dd_leaders(DedupArgs a) {
-  __shared__ int sm[20];
-  const int r = blockIdx.x * DD_BLOCK + threadIdx.x;
+  __shared__ int sm[24];
+  const int bid = take_ticket(a.tickets, sm);
+  const int r = bid * DD_BLOCK + threadIdx.x;
   int row = 0, flag = 0;
   if (r < a.R) {
     row = a.rows[r];
@@ -93,13 +105,13 @@ __global__ __launch_bounds__(DD_BLOCK) void k_dd_leaders(DedupArgs a) {
   }
   int bt;
   const int lp = block_excl_scan(flag, &bt, sm);
-  if (threadIdx.x == 0) st_agent(a.agg + blockIdx.x, ((unsigned long long)a.epoch << 32) | (unsigned)bt);
-  const int off = lookback_sum(a.agg, a.epoch, sm);
+  if (threadIdx.x == 0) st_agent(a.agg + bid, ((unsigned long long)a.epoch << 32) | (unsigned)bt);
+  const int off = lookback_sum(a.agg, a.epoch, bid, sm);
   if (flag) {
     a.slot_of[r] = off + lp;
     a.uniq_rows[off + lp] = row;
   }
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+  if (bid == (int)gridDim.x - 1 && threadIdx.x == 0) {
     a.info[0] = off + bt;
     __hip_atomic_store(a.u_host, off + bt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
@@ -107,6 +119,7 @@ __global__ __launch_bounds__(DD_BLOCK) void k_dd_leaders(DedupArgs a) {
 
 __global__ __launch_bounds__(256) void k_dd_map(DedupArgs a) {
   const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r == 0) a.tickets[1] = 0;        // k_dd_segstart's ticket counter
   if (r >= a.R) return;
   const unsigned lead = 0xFFFFFFFFu - (unsigned)a.key[a.rows[r]];
   const int s = a.slot_of[lead];
@@ -115,16 +128,17 @@ __global__ __launch_bounds__(256) void k_dd_map(DedupArgs a) {
 }
 
 __global__ __launch_bounds__(DD_BLOCK) void k_dd_segstart(DedupArgs a) {
-  __shared__ int sm[20];
+  __shared__ int sm[24];
   const int U = a.info[0];
-  const int u = blockIdx.x * DD_BLOCK + threadIdx.x;
+  const int bid = take_ticket(a.tickets + 1, sm);
+  const int u = bid * DD_BLOCK + threadIdx.x;
   const int v = u < U ? a.cnt[u] : 0;
   int bt;
   const int lp = block_excl_scan(v, &bt, sm);
   unsigned long long* agg = a.agg + a.agg_stride;
-  if (threadIdx.x == 0) st_agent(agg + blockIdx.x, ((unsigned long long)a.epoch << 32) | (unsigned)bt);
-  if (blockIdx.x * DD_BLOCK > U) return;             // nothing to write (block-uniform)
-  const int off = lookback_sum(agg, a.epoch, sm);
+  if (threadIdx.x == 0) st_agent(agg + bid, ((unsigned long long)a.epoch << 32) | (unsigned)bt);
+  if (bid * DD_BLOCK > U) return;                    // nothing to write (block-uniform)
+  const int off = lookback_sum(agg, a.epoch, bid, sm);
   if (u <= U) a.seg_start[u] = off + lp;             // u == U: the total (= R)
 }
 

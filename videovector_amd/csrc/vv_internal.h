@@ -96,6 +96,7 @@ struct DedupArgs {
   int32_t* seg_start;            // [Rp + 1]
   int32_t* pos;                  // [R] instance -> row of the grouped gradient buffer
   int32_t* info;                 // device {U, ...}
+  int32_t* tickets;              // device [2]: arrival counters of the two single-pass scans
   int32_t* u_host;               // host-mapped copy of U (read one or more steps late by the launcher)
   int R, Rp; int32_t zero_row; uint32_t epoch;
 };
