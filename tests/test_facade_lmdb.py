@@ -142,3 +142,18 @@ def test_test_window_records_decode(tool, pb, tmp_path):
     assert head[:10] == ["rows", "228", "F", "64", "videos", "0", "windows", "57", "k", "4"]
     assert abs(float(head[-1]) - total) < 1e-3
     assert lines[1:] == want
+
+
+def test_large_records_spanning_hundreds_of_overflow_pages(tool, pb, tmp_path):
+    # fc7-sized records: 4096 unpacked floats per shot (5 bytes each on the wire), ~60 shots -> >1 MB per value
+    import time
+    vids = make_shots_db(pb, str(tmp_path / "big_db"), n_videos=6, F=4096, seed=21)
+    out = tmp_path / "ds.txt"
+    t0 = time.time()
+    subprocess.check_call([tool, "dbload", str(tmp_path / "big_db"), "shots", str(out)], stderr=subprocess.DEVNULL)
+    dt = time.time() - t0
+    head = out.read_text().splitlines()[0].split()
+    rows = sum(len(i) for _, i, _ in vids)
+    total = float(sum(f.astype(np.float64).sum() for _, _, f in vids))
+    assert head[:4] == ["rows", str(rows), "F", "4096"] and abs(float(head[-1]) - total) < 1e-2
+    assert os.path.getsize(tmp_path / "big_db" / "data.mdb") > 2 * 1024 * 1024 and dt < 20
