@@ -103,3 +103,26 @@ def test_dedup_sgd_trajectory_matches_dense(vv):
         res.append((np.array(losses), eng.params_get()[0]))
     assert np.allclose(res[0][0], res[1][0], rtol=2e-5)
     assert rel_fro(res[1][1], res[0][1]) <= 5e-4
+
+
+@pytest.mark.parametrize("dedup", [False, True])
+def test_out_of_range_device_indices_read_the_zero_row(vv, dedup):
+    # a device-resident index array cannot be validated on the host: entries outside the table behave like -1
+    import torch
+    B, C, Nn, F, D = 16, 3, 4, 256, 64
+    ds, table, idx, W, b = make_case(2, 10, B, C, Nn, F, D, wstd=0.05)
+    bad = idx.copy()
+    bad[1, 3] = 10 ** 9; bad[5, 0] = -7; bad[9, 6] = len(table)
+    ok = bad.copy()
+    ok[1, 3] = ok[5, 0] = ok[9, 6] = -1
+    outs = []
+    for arr in (bad, ok):
+        eng = vv.Engine(0, "f16")
+        eng.set_dedup(dedup)
+        eng.table_set(table); eng.params_set(W, b)
+        t = torch.from_numpy(arr).to("cuda:0")
+        torch.cuda.synchronize()
+        cfg = vv.StepConfig(B, C, Nn)
+        eng.forward_backward(cfg, idx_dev_ptr=t.data_ptr())
+        outs.append((eng.loss(), eng.grads()[0].copy()))
+    assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])

@@ -480,7 +480,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   // top of the shared projection; that path stays dense).  Needs the default two-buffer GEMM kernels.
   const bool dd = c->dedup && cfg->dropout_ratio == 0.f && (gemm_variant() == 0 || gemm_variant() == 3 || gemm_variant() == 4) && !ablate_on();
   c->last_dedup = dd;
-  if (!dd) launch_map_rows(didx, c->rows, c->R, c->Rp, (int32_t)c->n_rows, s);
+  if (!dd) launch_map_rows(didx, c->rows, c->R, c->Rp, (int32_t)c->n_rows, (int32_t)row_limit, s);
   if (dd) {
     const int64_t need = c->n_rows + 1 + c->patch_cap;
     if (need > c->dd_key_cap) {
@@ -499,7 +499,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
     da.idx = didx; da.rows = c->rows; da.u_host = c->U_host_dev; da.key = c->dd_key; da.agg = c->dd_agg; da.agg_stride = c->dd_agg_stride;
     da.slot_of = c->dd_slot_of; da.uniq_rows = c->dd_uniq; da.map = c->dd_map; da.ord = c->dd_ord; da.cnt = c->dd_cnt;
     da.seg_start = c->dd_seg; da.pos = c->dd_pos; da.info = c->dd_info; da.tickets = c->dd_info + 2;
-    da.R = c->R; da.Rp = c->Rp; da.zero_row = (int32_t)c->n_rows; da.epoch = c->dd_epoch;
+    da.R = c->R; da.Rp = c->Rp; da.zero_row = (int32_t)c->n_rows; da.row_limit = (int32_t)row_limit; da.epoch = c->dd_epoch;
     // (Running the grouping kernels on a second stream beside the forward GEMM was measured: the two
     // cross-stream event waits cost more than the ~15 us they hide -- 0.405 vs 0.394 ms per step.)
     PROFILED(c, "dedup", (launch_dedup(da, s), launch_dedup_groups(da, s)));

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void k_dd_claim(DedupArgs a) {
   if (r == 0) a.tickets[0] = 0;        // k_dd_leaders' ticket counter (kernel boundary orders the reset)
   if (r >= a.Rp) return;
   int row = a.zero_row;
-  if (r < a.R) { const int i = a.idx[r]; if (i >= 0) row = i; }
+  if (r < a.R) { const int i = a.idx[r]; if (i >= 0 && i < a.row_limit) row = i; }   // as k_map_rows
   a.rows[r] = row;                     // what k_map_rows does on the dense path
   a.uniq_rows[r] = a.zero_row; a.cnt[r] = 0;
   if (r < a.R)

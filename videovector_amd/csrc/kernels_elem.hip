@@ -772,13 +772,15 @@ void launch_gram(const float* x, int n, int dim, float alpha, float* out, hipStr
 }
 
 // idx (data-layer layout, -1 = empty slot) -> table rows, padded to Rp with the all-zero row
-__global__ void k_map_rows(const int32_t* idx, int32_t* rows, int R, int Rp, int32_t zero_row) {
+// An index outside [0, row_limit) -- -1 is the documented "empty slot", anything else can only come from a device
+// index array the host never saw -- reads the all-zero row instead of memory outside the table.
+__global__ void k_map_rows(const int32_t* idx, int32_t* rows, int R, int Rp, int32_t zero_row, int32_t row_limit) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < Rp) rows[i] = (i < R && idx[i] >= 0) ? idx[i] : zero_row;
+  if (i < Rp) rows[i] = (i < R && idx[i] >= 0 && idx[i] < row_limit) ? idx[i] : zero_row;
 }
-void launch_map_rows(const int32_t* idx, int32_t* rows, int R, int Rp, int32_t zero_row,
+void launch_map_rows(const int32_t* idx, int32_t* rows, int R, int Rp, int32_t zero_row, int32_t row_limit,
                      hipStream_t s) {
-  hipLaunchKernelGGL(k_map_rows, dim3((Rp + 255) / 256), dim3(256), 0, s, idx, rows, R, Rp, zero_row);
+  hipLaunchKernelGGL(k_map_rows, dim3((Rp + 255) / 256), dim3(256), 0, s, idx, rows, R, Rp, zero_row, row_limit);
 }
 
 template <typename T>

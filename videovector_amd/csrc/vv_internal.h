@@ -98,7 +98,7 @@ struct DedupArgs {
   int32_t* info;                 // device {U, ...}
   int32_t* tickets;              // device [2]: arrival counters of the two single-pass scans
   int32_t* u_host;               // host-mapped copy of U (read one or more steps late by the launcher)
-  int R, Rp; int32_t zero_row; uint32_t epoch;
+  int R, Rp; int32_t zero_row; int32_t row_limit; uint32_t epoch;
 };
 
 struct SegsumArgs {
@@ -185,7 +185,7 @@ void launch_table_read(int prec, const uint16_t* table, const int32_t* rows, int
                        int Fp, float inv_sx, float* out, hipStream_t s);
 void launch_w_convert(int prec, const float* W, uint16_t* Wh, int D, int F, int Dp, int Fp,
                       Scales* sc, hipStream_t s);
-void launch_map_rows(const int32_t* idx, int32_t* rows, int R, int Rp, int32_t zero_row,
+void launch_map_rows(const int32_t* idx, int32_t* rows, int R, int Rp, int32_t zero_row, int32_t row_limit,
                      hipStream_t s);
 void launch_final_loss(const float* loss_part, const float* viol_part, int B, float scale,
                        float* out2, hipStream_t s);
