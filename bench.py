@@ -234,7 +234,8 @@ def main():
             "metric": "triplets/sec (whole node), 4096->%d-d embed, batch %d/GPU, C5, Nn%d" % (D, B_PER_GPU, NN),
             "value": value, "unit": "triplets/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.prec + " MFMA operands, fp32 accumulate / fp32 everything else",
+            "dtype": args.prec,
+            "dtype_note": args.prec + " MFMA operands with fp32 accumulation; fp32 master weights, activations, loss and update",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[%d] per GPU: synthetic fc7 4096-d -> %d-d, batch "
                                    "%d/GPU (global %d), context_size 5 (window +-2), %d negatives, "
