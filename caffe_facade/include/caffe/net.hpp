@@ -109,6 +109,9 @@ class Net {
   bool params_stale_ = false;        // device copy is newer than the host blobs
   bool debug_info_ = false;
   FusedPlan plan_;
+  struct BlobSym { int kind = 0, a = 0, reps = 1; };
+  vector<BlobSym> blob_sym_;     // what every named blob of the TRAIN graph is in terms of the fused plan (blob_by_name)
+  void MaterializeTrainBlob(int blob_id);
   vv_step_cfg cfg_;
   vector<int32_t> idx_, last_src_, label_;
   vector<float> item_weight_;

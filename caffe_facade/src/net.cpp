@@ -281,6 +281,8 @@ void Net<Dtype>::MatchVideovecTrainGraph() {
   }
   if (P.data_layer < 0 || P.ip_layer < 0 || P.loss_layer < 0)
     LOG(FATAL) << why << "the graph needs a VIDEO_SAMPLED_SHOTS_DATA layer, one INNER_PRODUCT layer and a MAX_MARGIN_LOSS layer";
+  blob_sym_.assign(blobs_.size(), BlobSym());
+  for (auto& kv : sym) { blob_sym_[kv.first].kind = kv.second.k; blob_sym_[kv.first].a = kv.second.a; blob_sym_[kv.first].reps = kv.second.reps; }
   vv_step_cfg_default(&cfg_);
   cfg_.B = P.B; cfg_.C = P.C; cfg_.Nn = P.Nn;
   cfg_.margin = P.margin; cfg_.norm = P.norm; cfg_.loss_weight = P.loss_weight;
@@ -530,13 +532,103 @@ template <typename Dtype>
 const shared_ptr<Blob<Dtype> > Net<Dtype>::blob_by_name(const string& n) {
   if (!has_blob(n)) { LOG(WARNING) << "Unknown blob name " << n; return shared_ptr<Blob<Dtype> >(); }   // net.cpp:846-857
   shared_ptr<Blob<Dtype> > b = blobs_[blob_names_index_[n]];
-  if (iter_ > 0 && !plan_.test) {
-    const int B = plan_.B, Nn = plan_.Nn;
-    if (n == plan_.ip2_blob) VV_CHECK(vv_blobs_get(ctx_, b->mutable_cpu_data(), NULL, NULL, NULL));
-    else if (n == plan_.target_score_blob) { CHECK_EQ(b->count(), B * Nn); VV_CHECK(vv_blobs_get(ctx_, NULL, b->mutable_cpu_data(), NULL, NULL)); }
-    else if (n == plan_.negative_scores_blob) { CHECK_EQ(b->count(), B * Nn); VV_CHECK(vv_blobs_get(ctx_, NULL, NULL, b->mutable_cpu_data(), NULL)); }
-  }
+  if (iter_ > 0 && !plan_.test) MaterializeTrainBlob(blob_names_index_[n]);
   return b;
+}
+
+// The fused plan keeps only ip2, the scores and the gradients on the device.  Any other named blob of the TRAIN graph
+// is rebuilt here, on demand, from those and from the feature table, following the layer that produces it in the
+// reference (slice_layer.cpp, concat_layer.cpp, eltwise_layer.cpp:52-73, normalization_layer.cpp:29-48, sum_layer.cpp:31-54):
+// a debugging / inspection path (Net::blob_by_name, net.cpp:846-857), not a hot one.
+template <typename Dtype>
+void Net<Dtype>::MaterializeTrainBlob(int id) {
+  if (blob_sym_.empty()) return;
+  const BlobSym sy = blob_sym_[id];
+  Blob<Dtype>* b = blobs_[id].get();
+  const int B = plan_.B, C = plan_.C, Nn = plan_.Nn, CN = C + Nn, D = plan_.D, F = plan_.F;
+  Dtype* out = b->mutable_cpu_data();
+  auto feature_rows = [&](const vector<int32_t>& rows, const vector<int32_t>& lasts, Dtype* dst) {
+    // rows of the table; -1 = all-zero; a slot whose last feature comes from another row (quirk Q1) is patched
+    vector<int32_t> valid; vector<size_t> where;
+    for (size_t i = 0; i < rows.size(); ++i) if (rows[i] >= 0) { valid.push_back(rows[i]); where.push_back(i); }
+    std::fill(dst, dst + rows.size() * (size_t)F, Dtype(0));
+    if (valid.empty()) return;
+    vector<float> tmp(valid.size() * (size_t)F);
+    VV_CHECK(vv_table_get(ctx_, valid.data(), (int64_t)valid.size(), tmp.data()));
+    for (size_t k = 0; k < valid.size(); ++k) memcpy(dst + where[k] * (size_t)F, &tmp[k * (size_t)F], sizeof(float) * F);
+    for (size_t i = 0; i < rows.size(); ++i) {
+      if (lasts[i] == rows[i]) continue;
+      float lastv = 0.f;
+      if (lasts[i] >= 0) { vector<float> r1((size_t)F); int32_t rr = lasts[i]; VV_CHECK(vv_table_get(ctx_, &rr, 1, r1.data())); lastv = r1[F - 1]; }
+      dst[i * (size_t)F + F - 1] = lastv;
+    }
+  };
+  auto slot = [&](int bb, int ch) { return (size_t)bb * CN + ch; };
+  if (sy.kind == K_DATA) {                                     // (B, C+Nn, F, 1), item-major
+    feature_rows(idx_, last_src_, out);
+    return;
+  }
+  if (sy.kind == K_DATUM || sy.kind == K_XROWS) {              // one channel (B,1,F,1) / all channels channel-major (CN*B, F)
+    vector<int32_t> rows, lasts;
+    for (int ch = sy.kind == K_DATUM ? sy.a : 0; ch < (sy.kind == K_DATUM ? sy.a + 1 : CN); ++ch)
+      for (int bb = 0; bb < B; ++bb) { rows.push_back(idx_[slot(bb, ch)]); lasts.push_back(last_src_[slot(bb, ch)]); }
+    feature_rows(rows, lasts, out);
+    return;
+  }
+  if (sy.kind == K_LABEL) { for (int i = 0; i < B; ++i) out[i] = (Dtype)label_[i]; return; }
+  if (sy.kind == K_LABELREP) { for (int i = 0; i < B; ++i) for (int k = 0; k < Nn; ++k) out[(size_t)i * Nn + k] = (Dtype)label_[i]; return; }
+  if (sy.kind == K_LOSS || sy.kind == K_VIOL || sy.kind == K_NONE) return;      // scalars are kept current by ForwardBackward
+  if (sy.kind == K_SCORE && sy.a == 0) { CHECK_EQ(b->count(), B * Nn); VV_CHECK(vv_blobs_get(ctx_, NULL, out, NULL, NULL)); return; }
+  if (sy.kind == K_NEGSCORES) { CHECK_EQ(b->count(), B * Nn); VV_CHECK(vv_blobs_get(ctx_, NULL, NULL, out, NULL)); return; }
+  if (sy.kind == K_SCORE) {                                    // neg_score_q = column q-1 of negative_scores
+    vector<float> ns((size_t)B * Nn);
+    VV_CHECK(vv_blobs_get(ctx_, NULL, NULL, ns.data(), NULL));
+    for (int i = 0; i < B; ++i) out[i] = ns[(size_t)i * Nn + sy.a - 1];
+    return;
+  }
+  if (sy.kind == K_Y) {                                        // ip1_nonorm: the projection without ReLU, recomputed
+    CHECK(last_src_ == idx_) << "ip1_nonorm of a batch with quirk-Q1 slots is not rebuilt";
+    vector<int32_t> rows;
+    for (int ch = 0; ch < CN; ++ch) for (int bb = 0; bb < B; ++bb) rows.push_back(idx_[slot(bb, ch)]);
+    for (int32_t r : rows) CHECK_GE(r, 0) << "ip1_nonorm of a batch with empty slots is not rebuilt";
+    VV_CHECK(vv_embed(ctx_, rows.data(), (int64_t)rows.size(), 0, 0, out));
+    return;
+  }
+  // everything else is a function of ip2 (channel-major rows ch*B + b)
+  vector<float> H((size_t)CN * B * D);
+  VV_CHECK(vv_blobs_get(ctx_, H.data(), NULL, NULL, NULL));
+  auto hrow = [&](int ch, int bb) { return &H[((size_t)ch * B + bb) * D]; };
+  auto normalize = [&](const float* x, float* y) {            // normalization_layer.cpp:29-48
+    double s = 0; for (int d = 0; d < D; ++d) s += (double)x[d] * x[d];
+    const float nrm = (float)std::sqrt(s) + 1e-10f;
+    for (int d = 0; d < D; ++d) y[d] = x[d] / nrm;
+  };
+  auto ctx_mean = [&](int bb, float* y) {
+    for (int d = 0; d < D; ++d) { float s = 0; for (int j = 1; j < C; ++j) s += plan_.ctx_coeff[j - 1] * hrow(j, bb)[d]; y[d] = s; }
+  };
+  vector<float> t1(D), t2(D);
+  switch (sy.kind) {
+    case K_H: memcpy(out, H.data(), sizeof(float) * H.size()); break;
+    case K_EMB: memcpy(out, hrow(sy.a, 0), sizeof(float) * (size_t)B * D); break;
+    case K_CTXMEAN: for (int bb = 0; bb < B; ++bb) ctx_mean(bb, out + (size_t)bb * D); break;
+    case K_CTXNORM: for (int bb = 0; bb < B; ++bb) { ctx_mean(bb, t1.data()); normalize(t1.data(), out + (size_t)bb * D); } break;
+    case K_PN: case K_PNNORM:
+      for (int q = 0; q <= Nn; ++q) for (int bb = 0; bb < B; ++bb) {
+        const float* x = hrow(q == 0 ? 0 : C + q - 1, bb);
+        Dtype* y = out + ((size_t)q * B + bb) * D;
+        if (sy.kind == K_PN) memcpy(y, x, sizeof(float) * D); else normalize(x, y);
+      }
+      break;
+    case K_PNORM: for (int bb = 0; bb < B; ++bb) normalize(hrow(sy.a == 0 ? 0 : C + sy.a - 1, bb), out + (size_t)bb * D); break;
+    case K_PROD:
+      for (int bb = 0; bb < B; ++bb) {
+        ctx_mean(bb, t1.data()); normalize(t1.data(), t2.data());
+        normalize(hrow(sy.a == 0 ? 0 : C + sy.a - 1, bb), t1.data());
+        for (int d = 0; d < D; ++d) out[(size_t)bb * D + d] = t2[d] * t1[d];
+      }
+      break;
+    default: break;
+  }
 }
 
 template <typename Dtype>

@@ -215,6 +215,62 @@ def test_caffe_train_past_context_types(tool, pb, oracle, tmp_path, ctype, C):
     assert rel_fro(Wg, Wq) <= 2e-3 and rel_fro(bg, bq) <= 4e-3
 
 
+def test_every_named_blob_of_the_train_graph_is_materialisable(tool, pb, oracle, tmp_path):
+    # Net::blob_by_name (net.cpp:846-857) on a graph that runs as a fused plan: every intermediate blob is rebuilt on
+    # demand; values against the oracle's layer-by-layer forward of the same batch
+    B, C, Nn, F, D, V = 16, 5, 3, 128, 32, 50
+    net_p = tmp_path / "net.prototxt"
+    net_p.write_text(train_net("synthetic://videos=%d;seed=1701;features=%d" % (V, F), B, C, Nn, D, max_buffer=500, w_std=0.05))
+    W0, b0 = init_weights(3, D, F, std=0.05)
+    b0 = (np.random.default_rng(1).standard_normal(D) * 0.05).astype(np.float32)
+    write_caffemodel(pb, str(tmp_path / "init.caffemodel"), W0, b0)
+    names = ["data", "target_datum", "context_datum_2", "negative_datum_3", "concat_input_datums", "original_feature",
+             "ip1_nonorm", "ip2", "target_emb_nonorm", "context_window_emb_3_nonorm", "negative_emb_2_nonorm",
+             "context_feature_nonorm", "context_feature", "pos_neg_nonorm", "pos_neg", "target_emb", "negative_emb_1",
+             "target_prod", "neg_prod_2", "target_score", "neg_score_3", "negative_scores", "loss_output", "train_violations"]
+    out = tmp_path / "blobs"
+    r = subprocess.run([os.path.join(ROOT, "caffe_facade", "build", "dump_blobs"), str(net_p), str(tmp_path / "init.caffemodel"),
+                        str(out), ",".join(names)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+    def load(n):
+        raw = open(out / (n + ".bin"), "rb").read()
+        shape = np.frombuffer(raw[:16], np.int32)
+        return shape, np.frombuffer(raw[16:], np.float32)
+    ds = SyntheticVideos(seed=1701, n_videos=V)
+    table = ds.table(F)
+    smp = oracle.Sampler(ds.video_id, ds.n_shots, ds.row_base, batch_size=B, context_size=C, num_negative_samples=Nn,
+                         max_buffer_size=500, negative_swap_percentage=50)
+    idx = smp.next()[0]
+    ref = oracle.forward_backward(table, idx, W0, b0, C_=C, Nn=Nn, want=("Y", "H", "ctx", "posneg", "s_true", "s_bogus"))
+    X = table[idx]                                            # [B][CN][F]
+    Xcm = X.transpose(1, 0, 2).reshape(-1, F)                 # channel-major rows
+    H = ref["H"].reshape(C + Nn, B, D)
+    PN = ref["posneg"].reshape(1 + Nn, B, D)
+    ctx_mean = H[1:C].mean(0)
+    pn_nonorm = np.concatenate([H[0:1], H[C:]], 0)
+    want = {
+        "data": ((B, C + Nn, F, 1), X), "target_datum": ((B, 1, F, 1), X[:, 0]), "context_datum_2": ((B, 1, F, 1), X[:, 2]),
+        "negative_datum_3": ((B, 1, F, 1), X[:, C + 2]), "concat_input_datums": (((C + Nn) * B, 1, F, 1), Xcm),
+        "original_feature": (((C + Nn) * B, F, 1, 1), Xcm), "ip1_nonorm": (((C + Nn) * B, D, 1, 1), ref["Y"]),
+        "ip2": (((C + Nn) * B, D, 1, 1), ref["H"]), "target_emb_nonorm": ((B, D, 1, 1), H[0]),
+        "context_window_emb_3_nonorm": ((B, D, 1, 1), H[3]), "negative_emb_2_nonorm": ((B, D, 1, 1), H[C + 1]),
+        "context_feature_nonorm": ((B, D, 1, 1), ctx_mean), "context_feature": ((B, D, 1, 1), ref["ctx"]),
+        "pos_neg_nonorm": (((1 + Nn) * B, D, 1, 1), pn_nonorm), "pos_neg": (((1 + Nn) * B, D, 1, 1), ref["posneg"]),
+        "target_emb": ((B, D, 1, 1), PN[0]), "negative_emb_1": ((B, D, 1, 1), PN[1]),
+        "target_prod": ((B, D, 1, 1), ref["ctx"] * PN[0]), "neg_prod_2": ((B, D, 1, 1), ref["ctx"] * PN[2]),
+        "target_score": ((B, Nn, 1, 1), ref["s_true"]), "neg_score_3": ((B, 1, 1, 1), ref["s_bogus"][:, 2]),
+        "negative_scores": ((B, Nn, 1, 1), ref["s_bogus"]),
+        "loss_output": ((1, 1, 1, 1), np.array([ref["loss"]])), "train_violations": ((1, 1, 1, 1), np.array([ref["violations"]])),
+    }
+    for n, (shape, val) in want.items():
+        got_shape, got = load(n)
+        assert tuple(got_shape) == shape, (n, tuple(got_shape), shape)
+        val = np.asarray(val, np.float32).reshape(-1)
+        err = np.abs(got - val).max() / max(np.abs(val).max(), 1e-12)
+        assert err <= 2e-3, (n, err)
+
+
 def test_caffe_train_shipped_configuration(tool, tmp_path):
     # The shipped project settings (mednet_embedding_train.prototxt:13-23,200,226 and its solver):
     # batch 128, window 5, 10 negatives of which up to 6 from the same video (quirk Q1), 4096 -> 4096,
