@@ -13,6 +13,7 @@
  */
 #ifndef VIDEOVEC_H_
 #define VIDEOVEC_H_
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -36,6 +37,9 @@ enum { VV_SOLVER_SGD = 0, VV_SOLVER_NESTEROV = 1, VV_SOLVER_ADAGRAD = 2 };
 /* One context per process / GPU.  Replaces Caffe::SetDevice + Caffe::set_mode(GPU)
  * (src/caffe/common.cpp:127-145, tools/caffe.cpp:92-104). */
 int vv_create(int device, int prec, vv_ctx** out);
+/* Caffe::DeviceQuery (src/caffe/common.cpp:147-180): a text description of the device (name, architecture, compute
+ * units, clocks, memory, LDS / registers per block) into buf (NUL-terminated, truncated to n). */
+int vv_device_query(int device, char* buf, size_t n);
 int vv_destroy(vv_ctx* ctx);
 const char* vv_last_error(void);
 const char* vv_version(void);

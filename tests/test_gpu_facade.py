@@ -271,6 +271,39 @@ def test_every_named_blob_of_the_train_graph_is_materialisable(tool, pb, oracle,
         assert err <= 2e-3, (n, err)
 
 
+def test_caffe_test_time_and_device_query_commands(tool, pb, oracle, tmp_path):
+    # the other three commands of tools/caffe.cpp (:68-76, :127-189, :193-265)
+    from videovector_amd.synth import synthetic_windows
+    B, C, Nn, F, D, V, NW = 16, 5, 3, 128, 64, 60, 90
+    ds = SyntheticVideos(seed=9, n_videos=V)
+    cls = {int(v): int(v % 5) + 1 for v in range(V)}
+    (tmp_path / "id2class.txt").write_text("".join("%d,%d\n" % kv for kv in cls.items()))
+    src = "synthetic://videos=%d;seed=9;features=%d" % (V, F)
+    wsrc = "synthetic-windows://videos=%d;seed=9;features=%d;windows=%d;context=4;wseed=5" % (V, F, NW)
+    net_p = tmp_path / "net.prototxt"
+    net_p.write_text(train_net(src, B, C, Nn, D, max_buffer=300, w_std=0.02, test_source=wsrc, test_batch=NW,
+                               test_frames=4, id_to_class_file=str(tmp_path / "id2class.txt")))
+    W0, b0 = init_weights(4, D, F, std=0.02)
+    write_caffemodel(pb, str(tmp_path / "init.caffemodel"), W0, b0)
+    # caffe test: two iterations of the TEST-phase net, per-batch lines and the mean of every output
+    log = run_caffe(["test", "--model=%s" % net_p, "--weights=%s" % (tmp_path / "init.caffemodel"), "--iterations=2"],
+                    str(tmp_path / "test.log"))
+    assert "Running for 2 iterations." in log and len(re.findall(r"Batch \d+, test_map = ", log)) == 2
+    mean_map = float(re.findall(r"\] test_map = ([0-9.eE+-]+)", log)[-1])
+    rows, vids = synthetic_windows(ds, NW, 4, 5)
+    emb = oracle.embed(ds.table(F)[rows].mean(1).astype(np.float32), None, W0, b0, relu=True, l2norm=True)
+    assert abs(mean_map - oracle.retrieval_stats(emb, vids, cls)[0]) <= 5e-3
+    # caffe time: the fused plan's kernels and the whole iteration
+    log = run_caffe(["time", "--model=%s" % net_p, "--iterations=20"], str(tmp_path / "time.log"))
+    assert "*** Benchmark begins ***" in log and "*** Benchmark ends ***" in log
+    for k in ("fwd_gemm", "score_loss", "wgrad_gemm", "reduce", "sgd"):
+        assert re.search(r"%s\tkernel: [0-9.eE+-]+ milliseconds" % k, log), k
+    assert re.search(r"Forward-backward-update iteration: [0-9.eE+-]+ milliseconds", log)
+    # caffe device_query
+    log = run_caffe(["device_query", "--gpu=0"], str(tmp_path / "dq.log"))
+    assert "Querying device ID = 0" in log and "gfx950" in log and re.search(r"Compute units:\s+256", log)
+
+
 def test_caffe_train_shipped_configuration(tool, tmp_path):
     # The shipped project settings (mednet_embedding_train.prototxt:13-23,200,226 and its solver):
     # batch 128, window 5, 10 negatives of which up to 6 from the same video (quirk Q1), 4096 -> 4096,

@@ -179,6 +179,27 @@ int vv_create(int device, int prec, vv_ctx** out) {
   return VV_OK;
 }
 
+int vv_device_query(int device, char* buf, size_t n) {
+  if (!buf || n == 0) return fail(VV_ERR_ARG, "vv_device_query: no buffer");
+  int cnt = 0;
+  if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return fail(VV_ERR_NOGPU, "vv_device_query: no HIP device visible");
+  if (device < 0 || device >= cnt) return fail(VV_ERR_ARG, "vv_device_query: device %d out of range (%d)", device, cnt);
+  hipDeviceProp_t p;
+  HIPCHK(hipGetDeviceProperties(&p, device));
+  size_t free_b = 0, total_b = 0;
+  HIPCHK(hipSetDevice(device));
+  (void)hipMemGetInfo(&free_b, &total_b);
+  snprintf(buf, n,
+           "Device id:                     %d\nName:                          %s\nArchitecture:                  %s\n"
+           "Compute units:                 %d\nClock rate:                    %d kHz\nMemory clock rate:             %d kHz\n"
+           "Total global memory:           %zu\nFree global memory:            %zu\nShared memory (LDS) per block: %zu\n"
+           "Registers per block:           %d\nWavefront size:                %d\nMax threads per block:         %d\n"
+           "L2 cache size:                 %d\nConcurrent kernels:            %s\n",
+           device, p.name, p.gcnArchName, p.multiProcessorCount, p.clockRate, p.memoryClockRate, (size_t)p.totalGlobalMem, free_b,
+           (size_t)p.sharedMemPerBlock, p.regsPerBlock, p.warpSize, p.maxThreadsPerBlock, p.l2CacheSize, p.concurrentKernels ? "Yes" : "No");
+  return VV_OK;
+}
+
 static void free_batch(vv_ctx* c) {
   dfree(c->idx_dev); dfree(c->rows); dfree(c->H); dfree(c->dYh); dfree(c->dbp);
   dfree(c->loss_part); dfree(c->viol_part); dfree(c->s_true); dfree(c->s_bogus);

@@ -60,6 +60,7 @@ def load_library():
     sigs = {
         "vv_create": [C.c_int, C.c_int, C.POINTER(vp)],
         "vv_destroy": [vp], "vv_set_stream": [vp, vp], "vv_synchronize": [vp],
+        "vv_device_query": [C.c_int, C.c_char_p, C.c_size_t],
         "vv_set_dedup": [vp, C.c_int], "vv_dedup_stats": [vp, C.POINTER(i64), C.POINTER(i64)],
         "vv_table_set": [vp, vp, i64, i32], "vv_table_synth": [vp, C.c_uint64, i64, i32],
         "vv_table_get": [vp, vp, i64, vp],
