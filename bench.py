@@ -95,8 +95,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # VV_DIST_BACKEND=gloo with several ranks on ONE device is a test hook for the N > 1 code path on a 1-GPU box
+        # (RCCL refuses two ranks on one device); the benchmark proper is nccl = RCCL, one rank per GPU.
+        backend = os.environ.get("VV_DIST_BACKEND", "nccl")
+        if backend != "nccl":
+            local_rank = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
