@@ -34,10 +34,12 @@ MFMA_PEAK_TFLOPS = 2500.0     # dense bf16/f16 MFMA peak, /opt/skills/guides/MI3
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(ds, idx, W, b, items=512, iters=5):
+def cpu_baseline(ds, idx, W, b, items=512, iters=5, threads=0):
     """The oracle (CPU restatement of the reference path, layer by layer with an sgemm for fc7)
-    timed on a bounded sample of the same workload: `items` batch items of the first batch."""
+    timed on a bounded sample of the same workload: `items` batch items of the first batch.
+    threads = 0: all host threads OpenMP offers; 1: the single-thread figure SURVEY 8(d) also asks for."""
     from oracle import oracle as orc
+    orc.set_threads(threads)
     sh = idx[:items]
     uniq, inv = np.unique(sh.reshape(-1), return_inverse=True)
     table = ds.table(F, uniq)
@@ -272,6 +274,8 @@ def main():
             out["dense_execution"] = dense
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ds, batches[0], W0, b0, items=512 if args.workload == "cfg2" else 128)
+            out["cpu_baseline_1_thread"] = cpu_baseline(ds, batches[0], W0, b0, items=16 if args.workload == "cfg2" else 4,
+                                                         iters=2, threads=1)
         print(json.dumps(out))
     if dist:
         dist.destroy_process_group()
