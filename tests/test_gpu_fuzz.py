@@ -1,0 +1,57 @@
+"""Randomised differential test on the GPU: odd shapes (D not a multiple of 4, F not a multiple of 8, single negative,
+two-frame context, tiny and ragged batches, empty slots, heavy repetition), de-duplicated against dense execution of the
+same library (bit-identical forward, gradients equal up to the reassociated sum) and both against the oracle."""
+import numpy as np
+import pytest
+
+from tests.test_gpu_parity import TOL, check, rel_fro, run_both, vv  # noqa: F401
+from videovector_amd.synth import init_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def random_case(rng):
+    B = int(rng.choice([1, 2, 7, 33, 64, 130]))
+    C = int(rng.choice([2, 3, 5, 7]))
+    Nn = int(rng.choice([1, 2, 5, 17, 60]))
+    F = int(rng.choice([7, 64, 100, 256, 515, 1024]))
+    D = int(rng.choice([1, 3, 30, 64, 250, 512, 520]))
+    n_rows = int(rng.choice([3, 40, 500, 5000]))
+    table = (rng.integers(0, 32, (n_rows, F)) / 8).astype(np.float32) * (rng.random((n_rows, F)) < 0.6)
+    idx = rng.integers(0, n_rows, (B, C + Nn)).astype(np.int32)
+    if rng.random() < 0.4:
+        idx[rng.random(idx.shape) < 0.05] = -1
+    W, _ = init_weights(int(rng.integers(1 << 30)), D, F, std=0.05)
+    b = (rng.standard_normal(D) * 0.05).astype(np.float32)
+    return B, C, Nn, F, D, table.astype(np.float32), idx, W, b
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_shapes_dedup_dense_oracle(vv, oracle, seed):
+    rng = np.random.default_rng(1000 + seed)
+    B, C, Nn, F, D, table, idx, W, b = random_case(rng)
+    kw = dict(norm="L1" if seed % 5 == 0 else "L2", margin=float(rng.choice([0.5, 2.0])))
+    outs = {}
+    for mode in (False, True):
+        eng = vv.Engine(0, "f16")
+        eng.set_dedup(mode)
+        eng.table_set(table); eng.params_set(W, b)
+        cfg = vv.StepConfig(B, C, Nn, **kw)
+        eng.forward_backward(cfg, idx)
+        bl = eng.blobs(cfg, ip1_diff=True)
+        dW, db = eng.grads()
+        outs[mode] = (eng.loss(), bl, dW.copy(), db.copy(), eng.dedup_stats())
+    (l0, b0, dW0, db0, _), (l1, b1, dW1, db1, st) = outs[False], outs[True]
+    assert st == (B * (C + Nn), len(np.unique(np.where(idx < 0, -1, idx))))
+    assert l0 == l1
+    for k in ("ip2", "target_score", "negative_scores", "ip1_diff"):
+        assert np.array_equal(b0[k], b1[k]), (k, B, C, Nn, F, D)
+    assert np.array_equal(db0, db1)
+    scale = max(np.abs(dW0).max(), 1e-30)
+    assert np.abs(dW1 - dW0).max() <= 2e-3 * scale, (B, C, Nn, F, D)
+    if seed % 3 == 0:
+        eng, cfg, got, ref = run_both(vv, oracle, "f16", table, idx, W, b, C, Nn, **kw)
+        tol = dict(TOL["f16"], grad_q=5e-3)
+        # degenerate shapes (a single embedding dimension, all-zero rows) make relative row errors meaningless
+        if D >= 30 and np.isfinite(ref["loss"]) and ref["loss"] > 0:
+            check(got, ref, tol, "fuzz-%d" % seed)
