@@ -25,11 +25,28 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Sum over the 64 lanes with DPP row shifts / row broadcasts (no LDS crossbar traffic, six fused add+DPP
+// instructions against twelve bpermute + add for the xor butterfly); the total is valid in LANE 63 only.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, true);
+  return v + __builtin_bit_cast(float, moved);
+}
+__device__ __forceinline__ float wave_sum63(float v) {
+  v = dpp_add<0x111, 0xF>(v);    // row_shr:1
+  v = dpp_add<0x112, 0xF>(v);    // row_shr:2
+  v = dpp_add<0x114, 0xF>(v);    // row_shr:4
+  v = dpp_add<0x118, 0xF>(v);    // row_shr:8   -> lane 15 of every row holds the row's sum
+  v = dpp_add<0x142, 0xA>(v);    // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xC>(v);    // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's sum
+  return v;
+}
+
 // block-wide sum for 256 threads; red must hold >= 4 floats; result broadcast to all threads
 __device__ __forceinline__ float block_sum(float v, float* red) {
-  v = wave_sum(v);
+  v = wave_sum63(v);
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = v;
   __syncthreads();
   return red[0] + red[1] + red[2] + red[3];
 }
@@ -97,8 +114,8 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
     } else {
       for (int d = lane; d < D; d += 64) { const float x = h[d]; s += x * x; t += x * Ah[d]; }
     }
-    s = wave_sum(s); t = wave_sum(t);
-    if (lane == 0) { n2[ch] = s; tq[ch] = t; }
+    s = wave_sum63(s); t = wave_sum63(t);
+    if (lane == 63) { n2[ch] = s; tq[ch] = t; }
   }
   __syncthreads();
 
@@ -203,9 +220,9 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
 // item do not survive in L2).  RPW = rows per wave, DV = float4 chunks per lane (D = 256*DV).
 // three block-wide sums at once (256 threads; red must hold >= 12 floats)
 __device__ __forceinline__ void block_sum3(float& x, float& y, float& z, float* red) {
-  x = wave_sum(x); y = wave_sum(y); z = wave_sum(z);
+  x = wave_sum63(x); y = wave_sum63(y); z = wave_sum63(z);
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; red[w] = x; red[4 + w] = y; red[8 + w] = z; }
+  if ((threadIdx.x & 63) == 63) { const int w = threadIdx.x >> 6; red[w] = x; red[4 + w] = y; red[8 + w] = z; }
   __syncthreads();
   x = red[0] + red[1] + red[2] + red[3];
   y = red[4] + red[5] + red[6] + red[7];
@@ -288,8 +305,8 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss_reg(ScoreArgs a) {
       s += xx.x * xx.x + xx.y * xx.y + xx.z * xx.z + xx.w * xx.w;
       t += xx.x * y[v].x + xx.y * y[v].y + xx.z * y[v].z + xx.w * y[v].w;
     }
-    s = wave_sum(s); t = wave_sum(t);
-    if (lane == 0 && qi <= Nn) { const int ch = qi == 0 ? 0 : C + qi - 1; n2[ch] = s; tq[ch] = t; }
+    s = wave_sum63(s); t = wave_sum63(t);
+    if (lane == 63 && qi <= Nn) { const int ch = qi == 0 ? 0 : C + qi - 1; n2[ch] = s; tq[ch] = t; }
   }
   __syncthreads();
 
@@ -319,7 +336,11 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss_reg(ScoreArgs a) {
   }
   __syncthreads();
 
-  // ---- phase 4: backward of this wave's rows from registers; one coalesced 512-B store per chunk
+  // ---- phase 4: backward of this wave's rows from registers; one coalesced 512-B store per chunk.
+  // The kernel is VALU-bound (no row loads and no gradient stores: 39 of its 49 us remain), so the per-element work
+  // is kept to the minimum: per row three scalars k1 = c n^2/den, k2 = c t/den (both times drop_scale * sg) and
+  // k3 = c/(n+eps); per element g*sg = k1*Ah - k2*x (masked), dAh += k3*x, db*sg += g*sg.  sg is a power of two,
+  // so carrying it through the sums and dividing at the end changes no bit.
   float4 pa[DV], pb[DV];
 #pragma unroll
   for (int v = 0; v < DV; ++v) { pa[v] = make_float4(0.f, 0.f, 0.f, 0.f); pb[v] = pa[v]; }
@@ -329,8 +350,10 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss_reg(ScoreArgs a) {
     if (qi > Nn) continue;                         // wave-uniform
     const int ch = qi == 0 ? 0 : C + qi - 1;
     const float c = cq[ch], s = n2[ch], t = tq[ch];
-    const float inv_n = 1.f / (sqrtf(s) + eps);
-    const float inv_den = 1.f / (s * sqrtf(s) + eps);
+    const float rs = sqrtf(s);
+    const float k3 = c * __builtin_amdgcn_rcpf(rs + eps);
+    const float cd = c * __builtin_amdgcn_rcpf(s * rs + eps) * a.drop_scale * a.sg;
+    const float k1 = cd * s, k2 = cd * t;
     uint16_t* dy = a.dYh + (int64_t)ooff[ch] * a.Dp;
 #pragma unroll
     for (int v = 0; v < DV; ++v) {
@@ -339,20 +362,21 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss_reg(ScoreArgs a) {
       float g[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        g[e] = c * (s * yv[e] - xv[e] * t) * inv_den * a.drop_scale;
+        g[e] = k1 * yv[e] - k2 * xv[e];
         g[e] = xv[e] > 0.f ? g[e] : 0.f;
       }
-      pa[v].x += c * xv[0] * inv_n; pa[v].y += c * xv[1] * inv_n; pa[v].z += c * xv[2] * inv_n; pa[v].w += c * xv[3] * inv_n;
+      pa[v].x += k3 * xv[0]; pa[v].y += k3 * xv[1]; pa[v].z += k3 * xv[2]; pa[v].w += k3 * xv[3];
       pb[v].x += g[0]; pb[v].y += g[1]; pb[v].z += g[2]; pb[v].w += g[3];
-      const uint32_t lo = T::from_float(g[0] * a.sg) | ((uint32_t)T::from_float(g[1] * a.sg) << 16);
-      const uint32_t hi = T::from_float(g[2] * a.sg) | ((uint32_t)T::from_float(g[3] * a.sg) << 16);
+      const uint32_t lo = T::from_float(g[0]) | ((uint32_t)T::from_float(g[1]) << 16);
+      const uint32_t hi = T::from_float(g[2]) | ((uint32_t)T::from_float(g[3]) << 16);
       *(uint2*)(dy + lane * 4 + v * 256) = make_uint2(lo, hi);
     }
   }
+  const float inv_sg = 1.f / a.sg;
 #pragma unroll
   for (int v = 0; v < DV; ++v) {
     *(float4*)(acc0 + wave * D + lane * 4 + v * 256) = pa[v];
-    *(float4*)(acc1 + wave * D + lane * 4 + v * 256) = pb[v];
+    *(float4*)(acc1 + wave * D + lane * 4 + v * 256) = make_float4(pb[v].x * inv_sg, pb[v].y * inv_sg, pb[v].z * inv_sg, pb[v].w * inv_sg);
   }
   __syncthreads();
 
