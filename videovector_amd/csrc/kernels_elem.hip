@@ -76,6 +76,9 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
   float* red = cq + CN;        // [8]
   int* hoff = (int*)(red + 8); // [CN] row of H holding channel ch (dedup: the shared per-slot row)
   int* ooff = hoff + CN;       // [CN] row of dYh receiving channel ch's gradient
+  float* k1 = (float*)(ooff + CN);   // [CN] per-row constants of the backward pass (see phase 4)
+  float* k2 = k1 + CN;
+  float* k3 = k2 + CN;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float eps = 1e-10f;
   for (int ch = tid; ch < CN; ch += SL_THREADS) {
@@ -146,6 +149,14 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
     if (a.s_true) a.s_true[b] = sp;
   }
   __syncthreads();
+  // per-row constants, once per row instead of once per (row, column group): g*sg = k1*Ah - k2*x, dAh += k3*x
+  for (int qi = tid; qi < 1 + Nn; qi += SL_THREADS) {
+    const int ch = qi == 0 ? 0 : C + qi - 1;
+    const float c = cq[ch], s = n2[ch], rs = sqrtf(s);
+    const float cd = c * __builtin_amdgcn_rcpf(s * rs + eps) * a.drop_scale * a.sg;
+    k1[ch] = cd * s; k2[ch] = cd * tq[ch]; k3[ch] = c * __builtin_amdgcn_rcpf(rs + eps);
+  }
+  __syncthreads();
 
   // ---- phase 4: backward of the normalised target / negative rows, column-parallel: a thread
   // owns one group of W consecutive columns (16-B loads) and walks the rows of its row group,
@@ -163,9 +174,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
       for (int e = 0; e < W; ++e) { ya[e] = Ah[d + e]; pa[e] = 0.f; pb[e] = 0.f; }
       for (int qi = rg; qi < 1 + Nn; qi += G) {
         const int ch = qi == 0 ? 0 : C + qi - 1;
-        const float c = cq[ch], s = n2[ch], t = tq[ch];
-        const float inv_n = 1.f / (sqrtf(s) + eps);
-        const float inv_den = 1.f / (s * sqrtf(s) + eps);
+        const float r1 = k1[ch], r2 = k2[ch], r3 = k3[ch];
         const float* h = HROW(ch) + d;
         uint16_t* dy = a.dYh + (int64_t)ooff[ch] * a.Dp + d;
         float xv[W];
@@ -174,17 +183,17 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
         uint16_t o[W];
 #pragma unroll
         for (int e = 0; e < W; ++e) {
-          pa[e] += c * xv[e] * inv_n;
-          float g = c * (s * ya[e] - xv[e] * t) * inv_den * a.drop_scale;
+          pa[e] += r3 * xv[e];
+          float g = r1 * ya[e] - r2 * xv[e];            // already times sg (a power of two: exact)
           g = xv[e] > 0.f ? g : 0.f;
           pb[e] += g;
-          o[e] = T::from_float(g * a.sg);
+          o[e] = T::from_float(g);
         }
         if (VEC) *(uint2*)dy = make_uint2(o[0] | ((uint32_t)o[1 % W] << 16), o[2 % W] | ((uint32_t)o[3 % W] << 16));
         else dy[0] = o[0];
       }
 #pragma unroll
-      for (int e = 0; e < W; ++e) { acc0[rg * D + d + e] = pa[e]; acc1[rg * D + d + e] = pb[e]; }
+      for (int e = 0; e < W; ++e) { acc0[rg * D + d + e] = pa[e]; acc1[rg * D + d + e] = pb[e] * (1.f / a.sg); }
     }
   }
   __syncthreads();
@@ -424,7 +433,7 @@ void set_score_reg(int v) { g_score_reg = v; }
 
 void launch_score_loss(int prec, const ScoreArgs& a, hipStream_t s) {
   if (g_score_reg && (prec == 0 ? launch_score_loss_reg<F16>(a, s) : launch_score_loss_reg<BF16>(a, s))) return;
-  const size_t lds = sizeof(float) * ((size_t)2 * a.D + 2 * (a.D > 1024 ? a.D : 1024) + 5 * (a.C + a.Nn) + 8);
+  const size_t lds = sizeof(float) * ((size_t)2 * a.D + 2 * (a.D > 1024 ? a.D : 1024) + 8 * (a.C + a.Nn) + 8);
   const bool vec = a.D % 4 == 0;
   const dim3 grid(a.B), block(SL_THREADS);
 #define VV_SL(T, V)                                                                              \
