@@ -255,8 +255,8 @@ Solver<Dtype>* GetSolver(const SolverParameter& param) {
 
 template class Solver<float>;
 template class SGDSolver<float>;
-template class NesterovSolver<float>;
-template class AdaGradSolver<float>;
+template class UpdateRuleSolver<float, VV_SOLVER_NESTEROV>;
+template class UpdateRuleSolver<float, VV_SOLVER_ADAGRAD>;
 template Solver<float>* GetSolver(const SolverParameter& param);
 
 }  // namespace caffe
