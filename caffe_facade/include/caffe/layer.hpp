@@ -131,6 +131,7 @@ class VideoSampledShotsDataLayer : public Layer<Dtype> {
   std::mutex mu_;
   std::condition_variable cv_;
   bool want_ = false, ready_ = false, quit_ = false;
+  int rand_skip_ = 0;
   vector<int32_t> pf_idx_, pf_last_, pf_label_;
   vv_sampler* sampler_ = nullptr;
   int batch_size_ = 0, context_size_ = 0, num_negative_samples_ = 0, feature_size_ = 0;

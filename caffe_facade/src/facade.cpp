@@ -414,7 +414,15 @@ void VideoSampledShotsDataLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>&, 
   CHECK(ctype != "PAIRWISE") << "context_type PAIRWISE feeds a two-frame graph, not the videovec_embedding graph: not built";
   CHECK(p.get_str("negative_dataset").empty()) << "negative_dataset is not supported";
   CHECK(!p.get_bool("output_shot_distance")) << "output_shot_distance is PAIRWISE-only";
-  CHECK_EQ(p.get_int("rand_skip"), 0) << "rand_skip is not supported";
+  // rand_skip (…data_layer.cpp:156-180): skip = caffe_rng_rand() % rand_skip records.  caffe_rng_rand is the first draw of
+  // the process-wide mt19937 after Caffe::set_random_seed (the data layer is set up first), and boost::mt19937 is the
+  // standard generator; without `random_seed` in the solver the reference seeds from /dev/urandom, here the default seed is used.
+  if (p.get_int("rand_skip") > 0) {
+    std::mt19937 gen(Caffe::random_seed());
+    const unsigned skip = (unsigned)gen() % (unsigned)p.get_int("rand_skip");
+    LOG(INFO) << "Skipping first " << skip << " data points.";
+    rand_skip_ = (int)skip;
+  }
   dataset_ = VideoDataset::Open(p.get_str("source"), VideoDataset::kShots, p.get_enum("backend"));
   vv_sampler_param sp;
   vv_sampler_param_default(&sp);
@@ -424,6 +432,7 @@ void VideoSampledShotsDataLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>&, 
   sp.max_buffer_size = (int)p.get_int("max_buffer_size");
   sp.negative_swap_percentage = (int)p.get_int("negative_swap_percentage");
   sp.max_same_video_negs = (int)p.get_int("max_same_video_negs");
+  sp.initial_cursor = rand_skip_;
   feature_size_ = dataset_->F;
   CHECK_GE(feature_size_, 1); CHECK_GE(context_size_, 2); CHECK_GE(batch_size_, 1);      // …data_layer.cpp:206-209
   if (ctype == "WINDOW") { CHECK(context_size_ % 2 == 1) << "Context size should be even in this setting!"; }   // …:434 (sic)

@@ -205,6 +205,8 @@ typedef struct {
   int32_t max_buffer_size, negative_swap_percentage, max_same_video_negs;
   int32_t max_tries_for_negs;      /* gflag --max_tries_for_negs, default 100 (...data_layer.cpp:20) */
   int32_t context_type;            /* VV_CONTEXT_* (VideoSampledShotsDataParameter.ContextType) */
+  int32_t initial_cursor;          /* records skipped before anything else (rand_skip, ...data_layer.cpp:156-180): the DB
+                                      cursor starts at this record (modulo the record count) */
 } vv_sampler_param;
 /* WINDOW (...data_layer.cpp:425-507): target = the middle of C sorted random frames.  PAST (:510-596): target = the
  * last of C sorted random frames.  PAST_CONTINUOUS (:599-674): C equally spaced frames, random stride and start,

@@ -35,7 +35,7 @@ class _SamplerParam(C.Structure):
     _fields_ = [("batch_size", C.c_int32), ("context_size", C.c_int32),
                 ("num_negative_samples", C.c_int32), ("max_buffer_size", C.c_int32),
                 ("negative_swap_percentage", C.c_int32), ("max_same_video_negs", C.c_int32),
-                ("max_tries_for_negs", C.c_int32), ("context_type", C.c_int32)]
+                ("max_tries_for_negs", C.c_int32), ("context_type", C.c_int32), ("initial_cursor", C.c_int32)]
 
 
 CONTEXT_TYPES = {"WINDOW": 0, "PAST": 1, "PAST_CONTINUOUS": 2, "PAST_CONTINUOUS_FIXED": 3}
@@ -147,7 +147,7 @@ class Sampler:
 
     def __init__(self, video_id, n_shots, row_base, *, batch_size, context_size,
                  num_negative_samples, max_buffer_size, negative_swap_percentage,
-                 max_same_video_negs=0, max_tries_for_negs=100, shot_ids=None, seed=1, context_type="WINDOW"):
+                 max_same_video_negs=0, max_tries_for_negs=100, shot_ids=None, seed=1, context_type="WINDOW", initial_cursor=0):
         self._vid = np.ascontiguousarray(video_id, dtype=np.int32)
         self._ns = np.ascontiguousarray(n_shots, dtype=np.int32)
         self._rb = np.ascontiguousarray(row_base, dtype=np.int64)
@@ -159,7 +159,7 @@ class Sampler:
                            _p(self._sid), _p(self._soff))
         self.p = _SamplerParam(batch_size, context_size, num_negative_samples, max_buffer_size,
                                negative_swap_percentage, max_same_video_negs, max_tries_for_negs,
-                               CONTEXT_TYPES[context_type])
+                               CONTEXT_TYPES[context_type], initial_cursor)
         self.h = lib().orc_sampler_create(C.byref(self.ds), C.byref(self.p), seed)
         if not self.h:
             raise ValueError("reference would CHECK-fail for these sampler parameters")

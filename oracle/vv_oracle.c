@@ -139,6 +139,7 @@ orc_sampler* orc_sampler_create(const orc_dataset* ds, const orc_sampler_param* 
   orc_sampler* s = (orc_sampler*)calloc(1, sizeof(*s));
   s->ds = *ds; s->p = *p;
   orc_srand(&s->rng, seed);
+  s->cursor = p->initial_cursor % ds->n_videos;                                        /* :156-180 */
   const int CN = p->context_size + p->num_negative_samples;
   const int mb = p->num_negative_samples > 0 ? p->max_buffer_size : 0;
   int max_n = 1;

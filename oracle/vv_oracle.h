@@ -57,6 +57,7 @@ typedef struct {
   int32_t max_buffer_size, negative_swap_percentage, max_same_video_negs;
   int32_t max_tries_for_negs;   /* gflag, default 100 (…data_layer.cpp:20) */
   int32_t context_type;         /* VideoSampledShotsDataParameter.ContextType; PAIRWISE feeds a different graph */
+  int32_t initial_cursor;       /* rand_skip (…data_layer.cpp:156-180): records skipped before the buffer is filled */
 } orc_sampler_param;
 enum { ORC_CONTEXT_WINDOW = 0, ORC_CONTEXT_PAST = 1, ORC_CONTEXT_PAST_CONTINUOUS = 2, ORC_CONTEXT_PAST_CONTINUOUS_FIXED = 3 };
 

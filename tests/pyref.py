@@ -17,13 +17,13 @@ _libc = ctypes.CDLL("libc.so.6")
 
 class PySampler:
     def __init__(self, video_id, n_shots, row_base, B, C, Nn, max_buffer, swap, max_same=0,
-                 max_tries=100, context_type="WINDOW"):
+                 max_tries=100, context_type="WINDOW", initial_cursor=0):
         _libc.srand(1)            # identical to never having called srand
         self.context_type = context_type
         self.calls = 0
         self.vid, self.ns, self.rb = list(video_id), list(n_shots), list(row_base)
         self.B, self.C, self.Nn, self.mb, self.swap, self.max_same = B, C, Nn, max_buffer, swap, max_same
-        self.cursor = 0
+        self.cursor = initial_cursor % len(self.vid)
         self.buffer_ids = list(range(max_buffer if Nn > 0 else 0))
         self.buf_row, self.buf_key, self.keys = [], [], set()
         CN = C + Nn

@@ -304,6 +304,42 @@ def test_caffe_test_time_and_device_query_commands(tool, pb, oracle, tmp_path):
     assert "Querying device ID = 0" in log and "gfx950" in log and re.search(r"Compute units:\s+256", log)
 
 
+def mt19937_first(seed):
+    """first 32-bit output of the standard mt19937 seeded with `seed` (what boost::mt19937 / std::mt19937 give)"""
+    mt = [0] * 624
+    mt[0] = seed & 0xFFFFFFFF
+    for i in range(1, 624):
+        mt[i] = (1812433253 * (mt[i - 1] ^ (mt[i - 1] >> 30)) + i) & 0xFFFFFFFF
+    for k in range(624):
+        y = (mt[k] & 0x80000000) | (mt[(k + 1) % 624] & 0x7FFFFFFF)
+        mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ (0x9908B0DF if y & 1 else 0)
+    y = mt[0]
+    y ^= y >> 11; y ^= (y << 7) & 0x9D2C5680; y ^= (y << 15) & 0xEFC60000; y ^= y >> 18
+    return y & 0xFFFFFFFF
+
+
+def test_caffe_train_rand_skip(tool, pb, oracle, tmp_path):
+    # rand_skip: the data layer skips caffe_rng_rand() % rand_skip records, the first draw of the seeded mt19937
+    assert mt19937_first(5489) == 3499211612                      # the generator's published first output
+    B, C, Nn, F, D, V = 16, 5, 2, 128, 32, 50
+    net_p, sol_p = tmp_path / "net.prototxt", tmp_path / "solver.prototxt"
+    net_p.write_text(train_net("synthetic://videos=%d;seed=1701;features=%d" % (V, F), B, C, Nn, D, max_buffer=300, w_std=0.02,
+                               rand_skip=37))
+    sol_p.write_text(solver(str(net_p), base_lr=0.002, max_iter=2, display=1, lr_policy="fixed", random_seed=99,
+                            snapshot_prefix=str(tmp_path / "snap")))
+    W0, b0 = init_weights(3, D, F, std=0.02)
+    write_caffemodel(pb, str(tmp_path / "init.caffemodel"), W0, b0)
+    log = run_caffe(["train", "--solver=%s" % sol_p, "--weights=%s" % (tmp_path / "init.caffemodel")], str(tmp_path / "t.log"))
+    skip = mt19937_first(99) % 37
+    assert "Skipping first %d data points." % skip in log
+    losses = [float(x) for x in re.findall(r"Iteration \d+, loss = ([0-9.eE+-]+)", log)]
+    ds = SyntheticVideos(seed=1701, n_videos=V)
+    smp = oracle.Sampler(ds.video_id, ds.n_shots, ds.row_base, batch_size=B, context_size=C, num_negative_samples=Nn,
+                         max_buffer_size=300, negative_swap_percentage=50, initial_cursor=skip)
+    r = oracle.forward_backward(ds.table(F), smp.next()[0], round_operand(W0, "f16"), b0, C_=C, Nn=Nn)
+    assert abs(losses[0] - r["loss"]) <= 1e-3 * r["loss"]
+
+
 def test_caffe_train_shipped_configuration(tool, tmp_path):
     # The shipped project settings (mednet_embedding_train.prototxt:13-23,200,226 and its solver):
     # batch 128, window 5, 10 negatives of which up to 6 from the same video (quirk Q1), 4096 -> 4096,

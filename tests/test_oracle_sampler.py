@@ -83,6 +83,24 @@ def test_past_context_structure(oracle, ctype):
                 assert row2vid[idx[b, c]] == label[b] and idx[b, c] < bound
 
 
+def test_rand_skip_initial_cursor(oracle):
+    # rand_skip (…data_layer.cpp:156-180): the cursor starts `skip` records in (wrapping), before the buffer is filled
+    ds = SyntheticVideos(seed=7, n_videos=60, lo=2, span=20)
+    for skip in (0, 7, 59, 60, 131):
+        s = _mk(oracle, ds, batch_size=8, context_size=5, num_negative_samples=4, max_buffer_size=64,
+                negative_swap_percentage=50, initial_cursor=skip)
+        p = PySampler(ds.video_id, ds.n_shots, ds.row_base, 8, 5, 4, 64, 50, initial_cursor=skip)
+        assert s.buffer_rows().tolist() == p.buf_row
+        for _ in range(3):
+            a, b = s.next(), p.next()
+            assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    a = _mk(oracle, ds, batch_size=8, context_size=5, num_negative_samples=4, max_buffer_size=64,
+            negative_swap_percentage=50, initial_cursor=60).next()
+    b = _mk(oracle, ds, batch_size=8, context_size=5, num_negative_samples=4, max_buffer_size=64,
+            negative_swap_percentage=50).next()
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))          # a full lap is no skip
+
+
 def test_window_structure(oracle):
     ds = SyntheticVideos(seed=3, n_videos=80)
     C, Nn, B = 5, 6, 64

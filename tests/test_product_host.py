@@ -71,6 +71,19 @@ def test_sampler_past_context_modes_bit_exact_vs_oracle(oracle, ctype):
             assert np.array_equal(i1, i2) and np.array_equal(l1, l2) and np.array_equal(y1, y2)
 
 
+def test_sampler_initial_cursor_bit_exact_vs_oracle(oracle):
+    ds = SyntheticVideos(seed=7, n_videos=120, lo=2, span=40)
+    for skip in (1, 77, 500):
+        kw = dict(batch_size=16, context_size=5, num_negative_samples=10, max_buffer_size=200, negative_swap_percentage=50,
+                  max_same_video_negs=6, initial_cursor=skip)
+        a = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, **kw)
+        o = oracle.Sampler(ds.video_id, ds.n_shots, ds.row_base, **kw)
+        for _ in range(4):
+            i1, l1, y1 = a.next(want_last=True, want_label=True)
+            i2, l2, y2 = o.next()
+            assert np.array_equal(i1, i2) and np.array_equal(l1, l2) and np.array_equal(y1, y2)
+
+
 def test_sampler_with_explicit_shot_ids_and_errors(oracle):
     ds = SyntheticVideos(seed=9, n_videos=30)
     sid = np.concatenate([np.arange(n)[::-1] * 3 for n in ds.n_shots]).astype(np.int32)

@@ -181,6 +181,8 @@ int vv_sampler_create(const vv_sampler_param* p, int32_t n_videos, const int32_t
     }
     if (ok && hi - lo < (1ll << 31)) { s->dense_keys = true; s->row_min = lo; s->row_in_buf.assign((size_t)(hi - lo), 0); }
   }
+  if (p->initial_cursor < 0) { delete s; return VV_ERR_ARG; }
+  s->cursor = p->initial_cursor % n_videos;                                       // rand_skip, :156-180
   const int CN = p->context_size + Nn;
   s->slots.assign((size_t)p->batch_size * CN, Slot());
   const int mb = Nn > 0 ? p->max_buffer_size : 0;

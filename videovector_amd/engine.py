@@ -297,7 +297,7 @@ class _SamplerParam(C.Structure):
     _fields_ = [("batch_size", C.c_int32), ("context_size", C.c_int32),
                 ("num_negative_samples", C.c_int32), ("max_buffer_size", C.c_int32),
                 ("negative_swap_percentage", C.c_int32), ("max_same_video_negs", C.c_int32),
-                ("max_tries_for_negs", C.c_int32), ("context_type", C.c_int32)]
+                ("max_tries_for_negs", C.c_int32), ("context_type", C.c_int32), ("initial_cursor", C.c_int32)]
 
 
 class Sampler:
@@ -306,7 +306,7 @@ class Sampler:
 
     def __init__(self, video_id, n_shots, row_base, *, batch_size, context_size,
                  num_negative_samples, max_buffer_size=5000, negative_swap_percentage=50,
-                 max_same_video_negs=0, max_tries_for_negs=100, shot_ids=None, context_type="WINDOW"):
+                 max_same_video_negs=0, max_tries_for_negs=100, shot_ids=None, context_type="WINDOW", initial_cursor=0):
         L = load_library()
         L.vv_sampler_create.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.POINTER(C.c_void_p)]
@@ -319,7 +319,8 @@ class Sampler:
         sid = None if shot_ids is None else np.ascontiguousarray(shot_ids, dtype=np.int32)
         p = _SamplerParam(batch_size, context_size, num_negative_samples, max_buffer_size,
                           negative_swap_percentage, max_same_video_negs, max_tries_for_negs,
-                          {"WINDOW": 0, "PAST": 1, "PAST_CONTINUOUS": 2, "PAST_CONTINUOUS_FIXED": 3}[context_type])
+                          {"WINDOW": 0, "PAST": 1, "PAST_CONTINUOUS": 2, "PAST_CONTINUOUS_FIXED": 3}[context_type],
+                          initial_cursor)
         self.h = C.c_void_p()
         rc = L.vv_sampler_create(C.byref(p), len(vid), _ptr(vid), _ptr(ns), _ptr(rb), _ptr(sid),
                                  C.byref(self.h))

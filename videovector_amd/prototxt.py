@@ -28,7 +28,7 @@ def _test_branch_front(a, test_source, test_batch, frames):
 def train_net(source, B, C, Nn, D, *, max_buffer=5000, swap=50, max_same=0, dropout=0.0, margin=2.0,
               norm="L2", name="videovec_train", w_std=0.001, test_source=None, test_batch=673, test_frames=4,
               id_to_class_file=None, id_to_weight_file=None, use_direct_weight=False, ip_regularization=0.0,
-              context_type="WINDOW"):
+              context_type="WINDOW", rand_skip=0):
     """test_source: also emit the TEST branch of the shipped file (window data -> average_for_test ->
     [shared fc7 / fc7_relu] -> test_norm -> retrieval_stats).
     id_to_weight_file / use_direct_weight: the weighted loss -- the data layer's video ids, replicated to (B, Nn)
@@ -43,8 +43,9 @@ def train_net(source, B, C, Nn, D, *, max_buffer=5000, swap=50, max_same=0, drop
       ('  top: "train_video_ids"\n' if weighted else '') +
       '  video_sampled_shots_data_param {\n    source: "%s"\n    backend: LMDB\n    batch_size: %d\n'
       '    num_negative_samples: %d\n    max_buffer_size: %d\n    negative_swap_percentage: %d\n'
-      '    max_same_video_negs: %d\n    context_type: %s\n    context_size: %d\n  }\n'
-      '  include: { phase: TRAIN }\n}' % (source, B, Nn, max_buffer, swap, max_same, context_type, C))
+      '    max_same_video_negs: %d\n    context_type: %s\n    context_size: %d\n%s  }\n'
+      '  include: { phase: TRAIN }\n}' % (source, B, Nn, max_buffer, swap, max_same, context_type, C,
+                                          '    rand_skip: %d\n' % rand_skip if rand_skip else ''))
     datums = ["target_datum"] + ["context_datum_%d" % j for j in range(1, C)] + \
              ["negative_datum_%d" % k for k in range(1, Nn + 1)]
     a('layers {\n  name: "slice_input_data"\n  type: SLICE\n  bottom: "data"\n%s\n  include: { phase: TRAIN }\n}'
