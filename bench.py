@@ -40,6 +40,10 @@ def cpu_baseline(ds, idx, W, b, items=512, iters=5, threads=0):
     threads = 0: all host threads OpenMP offers; 1: the single-thread figure SURVEY 8(d) also asks for."""
     from oracle import oracle as orc
     orc.set_threads(threads)
+    # the reference links an external BLAS for its sgemm (Makefile.config:34); use the one this machine has (MKL ships in the
+    # image), else the oracle's own OpenMP kernel -- which one is stated in the result
+    blas = orc.find_blas()
+    use_blas = bool(blas) and orc.set_blas(blas)
     sh = idx[:items]
     uniq, inv = np.unique(sh.reshape(-1), return_inverse=True)
     table = ds.table(F, uniq)
@@ -54,7 +58,9 @@ def cpu_baseline(ds, idx, W, b, items=512, iters=5, threads=0):
         orc.sgd_update(bo, r["db"], hb, 1e-3, 2.0, 0.9, 5e-4, 0.0)
         ts.append(time.perf_counter() - t0)
     t = float(np.mean(ts[1:]))
+    orc.set_blas(None)
     return {"value": items * NN / t, "unit": "triplets/s", "cores": orc.get_threads(), "kind": "port",
+            "blas": ("cblas_sgemm of " + os.path.basename(blas)) if use_blas else "the oracle's own OpenMP sgemm",
             "sample": "%d of %d batch items (%d rows) of the same 4096->%d, C5, Nn%d step, "
                       "%d timed iterations after 1 warm-up, %.2f s each" % (items, B_PER_GPU, items * (C + NN), D, NN, iters, t)}
 
@@ -273,8 +279,8 @@ def main():
         if dense is not None:
             out["dense_execution"] = dense
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ds, batches[0], W0, b0, items=512 if args.workload == "cfg2" else 128)
-            out["cpu_baseline_1_thread"] = cpu_baseline(ds, batches[0], W0, b0, items=16 if args.workload == "cfg2" else 4,
+            out["cpu_baseline"] = cpu_baseline(ds, batches[0], W0, b0, items=1024 if args.workload == "cfg2" else 256, iters=8)
+            out["cpu_baseline_1_thread"] = cpu_baseline(ds, batches[0], W0, b0, items=64 if args.workload == "cfg2" else 16,
                                                          iters=2, threads=1)
         print(json.dumps(out))
     if dist:

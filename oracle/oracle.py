@@ -204,6 +204,26 @@ def sgemm(transA, transB, A, B, alpha=1.0, beta=0.0, Cmat=None):
     return out
 
 
+def set_blas(path):
+    """Route orc_sgemm through an external BLAS (a shared object exporting cblas_sgemm); None = built-in kernel.
+    Returns True when the library was loaded."""
+    L = lib()
+    L.orc_set_blas.argtypes = [C.c_char_p]
+    L.orc_set_blas.restype = C.c_int
+    return L.orc_set_blas(None if not path else path.encode()) == 0 and bool(path)
+
+
+def find_blas():
+    """A cblas_sgemm provider of this machine, if any: MKL's single dynamic library or OpenBLAS."""
+    import glob
+    os.environ.setdefault("MKL_THREADING_LAYER", "GNU")      # liboracle itself uses GNU OpenMP
+    for pat in ("/opt/conda/lib/libmkl_rt.so*", "/usr/lib/x86_64-linux-gnu/libopenblas.so*",
+                "/usr/lib/x86_64-linux-gnu/libmkl_rt.so*", "/opt/conda/lib/libopenblas.so*"):
+        for f in sorted(glob.glob(pat)):
+            return f
+    return None
+
+
 def set_threads(n):
     lib().orc_set_threads(C.c_int(n))
 

@@ -6,6 +6,7 @@
  */
 #include "vv_oracle.h"
 
+#include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -326,7 +327,12 @@ int64_t orc_sampler_rand_calls(const orc_sampler* s) { return s->rand_calls; }
 
 /* ============================================================ sgemm ========================= */
 static int g_threads = 0;
-void orc_set_threads(int n) { g_threads = n; }
+void orc_set_threads(int n) {
+  g_threads = n;
+#ifdef _OPENMP
+  omp_set_num_threads(n > 0 ? n : omp_get_num_procs());   /* an external BLAS on the GNU OpenMP runtime follows this */
+#endif
+}
 int orc_get_threads(void) {
 #ifdef _OPENMP
   return g_threads > 0 ? g_threads : omp_get_max_threads();
@@ -378,9 +384,30 @@ static void gemm_nn_packed(int M, int N, int K, float alpha, const float* A, int
   }
 }
 
+/* The reference delegates its GEMM to an external BLAS (cblas_sgemm, math_functions.cpp:12-21; which library is
+ * a build choice of the user, Makefile.config:34).  orc_set_blas loads one at run time (a shared object exporting the
+ * standard cblas_sgemm, e.g. MKL's libmkl_rt.so or OpenBLAS) so that the CPU baseline can be timed the way a reference
+ * build would run; without it the self-contained OpenMP kernel below is used. */
+typedef void (*cblas_sgemm_fn)(int order, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                               const float* B, int ldb, float beta, float* C, int ldc);
+static cblas_sgemm_fn g_cblas_sgemm = NULL;
+int orc_set_blas(const char* path) {
+  g_cblas_sgemm = NULL;
+  if (!path || !*path) return 0;
+  void* h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return -1;
+  g_cblas_sgemm = (cblas_sgemm_fn)dlsym(h, "cblas_sgemm");
+  return g_cblas_sgemm ? 0 : -2;
+}
+int orc_has_blas(void) { return g_cblas_sgemm != NULL; }
+
 /* caffe_cpu_gemm (math_functions.cpp:12-21): row-major, lda/ldb derived from the trans flags. */
 void orc_sgemm(int transA, int transB, int M, int N, int K, float alpha, const float* A,
                const float* B, float beta, float* C) {
+  if (g_cblas_sgemm) {          /* CblasRowMajor = 101, CblasNoTrans = 111, CblasTrans = 112 (math_functions.cpp:16-20) */
+    g_cblas_sgemm(101, transA ? 112 : 111, transB ? 112 : 111, M, N, K, alpha, A, transA ? M : K, B, transB ? K : N, beta, C, N);
+    return;
+  }
   const float* Bp = B;
   float* tmp = NULL;
   if (transB) {   /* B given as [N][K]: pack to [K][N] */

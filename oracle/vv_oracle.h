@@ -85,6 +85,9 @@ int64_t        orc_sampler_rand_calls(const orc_sampler* s);
  * which BLAS is a build choice of the reference, so summation order is not specified). */
 void orc_sgemm(int transA, int transB, int M, int N, int K, float alpha,
                const float* A, const float* B, float beta, float* C);
+/* optional external BLAS for orc_sgemm (shared object exporting cblas_sgemm); NULL / "" = the built-in kernel */
+int orc_set_blas(const char* path);
+int orc_has_blas(void);
 void orc_set_threads(int n);   /* 0 = all cores */
 int  orc_get_threads(void);
 
