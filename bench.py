@@ -37,32 +37,40 @@ HBM_PEAK_GBS = 8000.0
 def cpu_baseline(ds, idx, W, b, items=512, iters=5, threads=0):
     """The oracle (CPU restatement of the reference path, layer by layer with an sgemm for fc7)
     timed on a bounded sample of the same workload: `items` batch items of the first batch.
-    threads = 0: all host threads OpenMP offers; 1: the single-thread figure SURVEY 8(d) also asks for."""
+    threads = 0: all host threads OpenMP offers; 1: the single-thread figure SURVEY 8(d) also asks for.
+    The reference links an external BLAS for its sgemm (Makefile.config:34): one warm-up iteration is run with the
+    machine's BLAS (MKL ships in the image) and one with the oracle's own OpenMP kernel, the faster of the two is
+    timed and named in the result (MKL is not always the faster one on an EPYC host)."""
     from oracle import oracle as orc
     orc.set_threads(threads)
-    # the reference links an external BLAS for its sgemm (Makefile.config:34); use the one this machine has (MKL ships in the
-    # image), else the oracle's own OpenMP kernel -- which one is stated in the result
-    blas = orc.find_blas()
-    use_blas = bool(blas) and orc.set_blas(blas)
     sh = idx[:items]
     uniq, inv = np.unique(sh.reshape(-1), return_inverse=True)
     table = ds.table(F, uniq)
     idx_local = inv.reshape(sh.shape).astype(np.int32)
     Wo, bo = W.copy(), b.copy()
     hW, hb = np.zeros_like(W), np.zeros_like(b)
-    ts = []
-    for _ in range(iters + 1):
+
+    def one():
         t0 = time.perf_counter()
         r = orc.forward_backward(table, idx_local, Wo, bo, C_=C, Nn=NN, want=("dW", "db"))
         orc.sgd_update(Wo, r["dW"], hW, 1e-3, 1.0, 0.9, 5e-4, 1.0)
         orc.sgd_update(bo, r["db"], hb, 1e-3, 2.0, 0.9, 5e-4, 0.0)
-        ts.append(time.perf_counter() - t0)
-    t = float(np.mean(ts[1:]))
+        return time.perf_counter() - t0
+    blas = orc.find_blas()
+    t_own = one()
+    t_ext = None
+    if blas and orc.set_blas(blas):
+        t_ext = one()
+    use_ext = t_ext is not None and t_ext < t_own
+    if not use_ext:
+        orc.set_blas(None)
+    ts = [one() for _ in range(iters)]
     orc.set_blas(None)
+    t = float(np.mean(ts))
     return {"value": items * NN / t, "unit": "triplets/s", "cores": orc.get_threads(), "kind": "port",
-            "blas": ("cblas_sgemm of " + os.path.basename(blas)) if use_blas else "the oracle's own OpenMP sgemm",
+            "blas": ("cblas_sgemm of " + os.path.basename(blas)) if use_ext else "the oracle's own OpenMP sgemm",
             "sample": "%d of %d batch items (%d rows) of the same 4096->%d, C5, Nn%d step, "
-                      "%d timed iterations after 1 warm-up, %.2f s each" % (items, B_PER_GPU, items * (C + NN), D, NN, iters, t)}
+                      "%d timed iterations after warm-up, %.2f s each" % (items, B_PER_GPU, items * (C + NN), D, NN, iters, t)}
 
 
 def main():
@@ -279,8 +287,8 @@ def main():
         if dense is not None:
             out["dense_execution"] = dense
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ds, batches[0], W0, b0, items=1024 if args.workload == "cfg2" else 256, iters=8)
-            out["cpu_baseline_1_thread"] = cpu_baseline(ds, batches[0], W0, b0, items=64 if args.workload == "cfg2" else 16,
+            out["cpu_baseline"] = cpu_baseline(ds, batches[0], W0, b0, items=512 if args.workload == "cfg2" else 128, iters=5)
+            out["cpu_baseline_1_thread"] = cpu_baseline(ds, batches[0], W0, b0, items=32 if args.workload == "cfg2" else 8,
                                                          iters=2, threads=1)
         print(json.dumps(out))
     if dist:

@@ -328,10 +328,12 @@ int64_t orc_sampler_rand_calls(const orc_sampler* s) { return s->rand_calls; }
 /* ============================================================ sgemm ========================= */
 static int g_threads = 0;
 void orc_set_threads(int n) {
-  g_threads = n;
 #ifdef _OPENMP
-  omp_set_num_threads(n > 0 ? n : omp_get_num_procs());   /* an external BLAS on the GNU OpenMP runtime follows this */
+  static int default_threads = 0;
+  if (!default_threads) default_threads = omp_get_max_threads();
+  omp_set_num_threads(n > 0 ? n : default_threads);       /* an external BLAS on the GNU OpenMP runtime follows this */
 #endif
+  g_threads = n;
 }
 int orc_get_threads(void) {
 #ifdef _OPENMP
