@@ -224,6 +224,34 @@ int vv_sampler_create(const vv_sampler_param* p, int32_t n_videos, const int32_t
 int vv_sampler_next(vv_sampler* s, int32_t* idx, int32_t* last_src, int32_t* label);
 int vv_sampler_destroy(vv_sampler* s);
 
+/* ---- prefetch.  Replaces BasePrefetchingDataLayer::{CreatePrefetchThread, JoinPrefetchThread}
+ * (src/caffe/layers/base_data_layer.cpp:52-95) and InternalThread (src/caffe/internal_thread.cpp:14-37): the
+ * reference starts one thread per batch that fills prefetch_data_ while the solver consumes the previous one.
+ * Here background threads run `depth` batches ahead of the consumer; afterwards vv_sampler_next pops finished
+ * batches in order (the index stream is exactly the one vv_sampler_next would have produced by itself).
+ *   threads   1 = whole batches on one thread; 2 or 3 = the item's three chains (stream walk + buffer swap-in /
+ *             negative-slot draw / frame draw) as a pipeline of threads (same indices; only for samplers without
+ *             same-video negatives whose (video_id, shot_id) keys name distinct rows, else 1 is used).
+ *   shm_name  NULL = a private ring.  A name = the ring lives in a POSIX shared-memory object of that name, so that
+ *             ONE sampler per node serves `consumers` processes (the data-parallel ranks: every rank takes its
+ *             items of the same global batch) -- see vv_batch_ring_attach.
+ *   consumers number of readers that must each take (a slice of) a batch before its buffer is reused. */
+int vv_sampler_prefetch_start(vv_sampler* s, int32_t depth, int32_t threads, const char* shm_name, int32_t consumers);
+int vv_sampler_prefetch_stop(vv_sampler* s);
+
+/* A reader's view of a sampler's batch ring.  vv_sampler_ring: the producer process's own handle (owned by the
+ * sampler).  vv_batch_ring_attach: map the named ring of another process (waits up to timeout_s for it to appear).
+ * vv_batch_ring_next: wait for this consumer's next batch (timeout_s <= 0: forever; VV_ERR_STATE when the producer
+ * has gone or the wait timed out), copy items [item_begin, item_begin + item_count) -- idx int32 [item_count][C+Nn],
+ * label int32 [item_count], either may be NULL -- and release the batch for this consumer. */
+typedef struct vv_batch_ring vv_batch_ring;
+int vv_sampler_ring(vv_sampler* s, vv_batch_ring** out);
+int vv_batch_ring_attach(const char* shm_name, double timeout_s, vv_batch_ring** out);
+int vv_batch_ring_info(vv_batch_ring* r, int32_t* batch_size, int32_t* slots_per_item, int32_t* consumers, int32_t* depth);
+int vv_batch_ring_next(vv_batch_ring* r, int32_t consumer, int32_t item_begin, int32_t item_count, int32_t* idx,
+                       int32_t* label, double timeout_s);
+int vv_batch_ring_detach(vv_batch_ring* r);
+
 /* Timing hook for the benchmark: average device time in ms of one named kernel ("fwd_gemm",
  * "score_loss", "wgrad_gemm", "reduce", "sgd") over the launches since the last reset, measured
  * with hipEvents on the context's stream (only while enabled; enabling adds two event records

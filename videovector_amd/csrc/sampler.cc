@@ -2,16 +2,44 @@
 // oracle under oracle/ is a separate, independent restatement and is never linked here).
 //
 // Reproduces, with table-row indices in place of feature copies, the reference's
-// VideoSampledShotsDataLayer in CONTEXT_WINDOW mode:
+// VideoSampledShotsDataLayer:
 //   setup   src/caffe/layers/video_sampled_shots_data_layer.cpp:64-369
-//   batch   ...:768-909 (InternalThreadEntry), :371-393,425-507 (AddSamplesToTop), :24-44
+//   batch   ...:768-909 (InternalThreadEntry), :371-393,425-757 (AddSamplesToTop), :24-44
+//   prefetch src/caffe/layers/base_data_layer.cpp:52-95 (a batch is produced while the previous one is consumed)
 // including the exact consumption order of the C library's rand() stream.
+//
+// Structure.  The reference's sampler is ONE sequential stream: every draw is rand() % k, the number of draws an
+// item consumes depends on the data (how many of its video's shots are swapped into the negative buffer), and the
+// negative slots come from a persistent permutation.  Two things make it fast here without changing a single index:
+//   * the libc stream x[k] = x[k-31] + x[k-3] does not depend on how it is consumed, so it is generated a block at a
+//     time together with the swap-in predicate ((x >> 1) % 100 < negative_swap_percentage) of every value;
+//   * the work of an item splits into three chains that touch disjoint state --
+//       walk  : which stream positions the item owns + the swap-in of its video's shots into the buffer
+//               (state: stream position, DB cursor, buffer contents and the membership bitmap),
+//       negs  : the partial Fisher-Yates draw of its negative slots (state: the persistent slot permutation),
+//       frames: its target/context frames (no state at all) --
+//     which run either back to back in the calling thread (vv_sampler_next) or as a three-stage pipeline of threads
+//     that hands finished batches to the consumer(s) through a ring (vv_sampler_prefetch_start), optionally in POSIX
+//     shared memory so that ONE sampler serves every rank of a node.
 #include <algorithm>
+#include <atomic>
+#include <cerrno>
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
+#include <thread>
 #include <unordered_set>
 #include <vector>
+
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "../../include/videovec.h"
 
@@ -22,7 +50,7 @@ namespace {
 // word >> 1; the first 310 outputs are discarded by srandom.  (glibc 2.35 stdlib/random_r.c)
 class LibcRand {
  public:
-  LibcRand() {
+  void init(int block, int swap_pct) {
     uint32_t st[31];
     int64_t w = 1;
     st[0] = 1;
@@ -36,35 +64,55 @@ class LibcRand {
       f = f == 30 ? 0 : f + 1;
       r = r == 30 ? 0 : r + 1;
     }
-    // Linear history: the word at st[f] is the oldest, x[k-31].  From here on the stream is
-    // x[k] = x[k-31] + x[k-3]; it does not depend on how the outputs are consumed, so it is produced a
-    // block at a time (three independent dependency chains) instead of one value per call.
-    for (int i = 0; i < 31; ++i) h_[i] = st[(f + i) % 31];
-    pos_ = kBlock;
+    // Linear history: the word at st[f] is the oldest, x[k-31].  From here on x[k] = x[k-31] + x[k-3].
+    // Substituting the recurrence into itself twice gives x[k] = x[k-9] + x[k-31] + x[k-34] + x[k-37]: no operand
+    // closer than 9 positions, so eight values are produced per vector step instead of one per store-to-load round trip.
+    n_ = block; swap_ = (uint32_t)swap_pct;
+    h_.assign((size_t)kHist + n_, 0u); f_.assign((size_t)n_ + 1, 0);
+    uint32_t* h = h_.data();
+    for (int i = 0; i < 31; ++i) h[kHist - 31 + i] = st[(f + i) % 31];
+    for (int i = kHist - 32; i >= 0; --i) h[i] = h[i + 31] - h[i + 28];     // run the recurrence backwards for the extra history
+    generate(0);
+    pos_ = 0;
   }
-  int32_t next() {
-    if (pos_ == kBlock) refill();
-    return (int32_t)(h_[31 + pos_++] >> 1);
+  int capacity() const { return n_; }
+  // make the next k values addressable as peek(0..k-1) (k <= capacity())
+  void ensure(int k) {
+    if (pos_ + k <= n_) return;
+    const int m = n_ - pos_;                       // unconsumed values
+    memmove(h_.data(), h_.data() + pos_, (size_t)(kHist + m) * sizeof(uint32_t));
+    memmove(f_.data(), f_.data() + pos_, (size_t)m);
+    generate(m);
+    pos_ = 0;
   }
-  // consume k values whose results nobody looks at (a shuffle of frames that are not used afterwards)
-  void discard(int k) {
-    while (k > 0) {
-      if (pos_ == kBlock) refill();
-      const int step = std::min(k, kBlock - pos_);
-      pos_ += step; k -= step;
-    }
+  const uint32_t* peek() const { return h_.data() + kHist + pos_; }     // raw words: rand() = word >> 1
+  const uint8_t* flags() const { return f_.data() + pos_; }          // (rand() % 100) < negative_swap_percentage
+  void skip(int k) { pos_ += k; }
+  int32_t next() { ensure(1); return (int32_t)(h_[kHist + pos_++] >> 1); }
+  void discard(int64_t k) {
+    while (k > 0) { const int step = (int)std::min<int64_t>(k, n_ / 2); ensure(step); pos_ += step; k -= step; }
   }
 
  private:
-  static constexpr int kBlock = 1024;
-  void refill() {
-    if (pos_ == kBlock && filled_) memcpy(h_, h_ + kBlock, 31 * sizeof(uint32_t));
-    for (int i = 31; i < 31 + kBlock; ++i) h_[i] = h_[i - 31] + h_[i - 3];
-    pos_ = 0; filled_ = true;
+  static constexpr int kHist = 40;               // words kept in front of the first unconsumed value (>= 37)
+  void generate(int from) {
+    uint32_t* __restrict h = h_.data() + kHist;
+    const int n = n_;
+    int i = from;
+    for (; i + 8 <= n; i += 8) {                 // every operand of a block lies in front of the block
+      uint32_t t[8];
+      for (int j = 0; j < 8; ++j) t[j] = h[i + j - 9] + h[i + j - 31] + h[i + j - 34] + h[i + j - 37];
+      for (int j = 0; j < 8; ++j) h[i + j] = t[j];
+    }
+    for (; i < n; ++i) h[i] = h[i - 31] + h[i - 3];
+    uint8_t* __restrict f = f_.data();
+    const uint32_t sw = swap_;
+    for (int k = from; k < n; ++k) f[k] = (uint8_t)(((h[k] >> 1) % 100u) < sw);
   }
-  uint32_t h_[31 + kBlock];
-  int pos_;
-  bool filled_ = false;
+  std::vector<uint32_t> h_;
+  std::vector<uint8_t> f_;
+  int n_ = 0, pos_ = 0;
+  uint32_t swap_ = 0;
 };
 
 struct Slot { int32_t row = -1, last = -1; };
@@ -72,48 +120,136 @@ struct Slot { int32_t row = -1, last = -1; };
 // a % d for 0 <= a < 2^32 and the divisors this sampler meets (1 .. max(max_buffer_size, longest video, 100)),
 // by two multiplications with a precomputed reciprocal instead of a hardware division (Lemire, Kaser, Kurz:
 // "Faster remainder by direct computation", 2019): M = floor((2^64 - 1) / d) + 1, a % d = floor(((M * a) mod 2^64) * d / 2^64).
-// The sampler is a chain of ~110 rand() % k per batch item; on the host this chain, not memory, sets its speed.
 class FastMod {
  public:
   void init(int dmax) {
     m_.resize((size_t)dmax + 1);
     for (int d = 1; d <= dmax; ++d) m_[d] = UINT64_C(0xFFFFFFFFFFFFFFFF) / (uint64_t)d + 1;
   }
-  int32_t mod(int32_t a, int32_t d) const {
-    const uint64_t low = m_[d] * (uint64_t)(uint32_t)a;
+  int32_t mod(int32_t a, int32_t d) const { return modm(m_[d], a, d); }
+  uint64_t magic(int d) const { return m_[d]; }
+  const uint64_t* table() const { return m_.data(); }
+  static int32_t modm(uint64_t M, int32_t a, int32_t d) {
+    const uint64_t low = M * (uint64_t)(uint32_t)a;
     return (int32_t)(((unsigned __int128)low * (uint64_t)d) >> 64);
   }
  private:
   std::vector<uint64_t> m_;
 };
 
+void backoff(unsigned& spins) {
+  if (++spins < 64) { __builtin_ia32_pause(); return; }
+  if (spins < 256) { sched_yield(); return; }
+  std::this_thread::sleep_for(std::chrono::microseconds(50));
+}
+
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------------------
+// Batch ring: finished batches between the producer (the sampler's threads) and up to VV_RING_MAX_CONSUMERS
+// consumers (the ranks of a node), in private memory or in a POSIX shared-memory object.
+// ------------------------------------------------------------------------------------------------------------
+enum { VV_RING_MAX_CONSUMERS = 64 };
+struct RingHdr {
+  uint64_t magic;
+  int32_t depth, batch_size, cn, consumers, has_last, pad_;
+  uint64_t batch_bytes;                          // bytes of one batch record
+  alignas(64) std::atomic<int64_t> produced;     // complete batches
+  alignas(64) std::atomic<int32_t> closed;       // producer gone
+  struct alignas(64) Rel { std::atomic<int64_t> v; } released[VV_RING_MAX_CONSUMERS];
+};
+static constexpr uint64_t kRingMagic = 0x5656524e47303031ull;   // "VVRNG001"
+
+struct vv_batch_ring {
+  RingHdr* hdr = nullptr;
+  unsigned char* data = nullptr;
+  size_t map_bytes = 0;
+  bool shm = false, owner = false;
+  std::string name;
+  int64_t next_k[VV_RING_MAX_CONSUMERS];
+  int32_t* idx_of(int64_t k) const { return (int32_t*)(data + (size_t)(k % hdr->depth) * hdr->batch_bytes); }
+  int32_t* label_of(int64_t k) const { return idx_of(k) + (size_t)hdr->batch_size * hdr->cn; }
+  int32_t* last_of(int64_t k) const { return label_of(k) + hdr->batch_size; }
+  int64_t min_released() const {
+    int64_t m = INT64_MAX;
+    for (int i = 0; i < hdr->consumers; ++i) m = std::min(m, hdr->released[i].v.load(std::memory_order_acquire));
+    return m;
+  }
+};
+
+static size_t ring_hdr_bytes() { return (sizeof(RingHdr) + 4095) / 4096 * 4096; }
+
+static vv_batch_ring* ring_create(const char* shm_name, int depth, int B, int CN, int consumers, bool has_last) {
+  vv_batch_ring* r = new (std::nothrow) vv_batch_ring();
+  if (!r) return nullptr;
+  const size_t rec = ((size_t)B * CN * (has_last ? 2 : 1) + B) * sizeof(int32_t);
+  const size_t rec_al = (rec + 63) / 64 * 64;
+  r->map_bytes = ring_hdr_bytes() + rec_al * depth;
+  void* mem = nullptr;
+  if (shm_name && *shm_name) {
+    r->name = shm_name[0] == '/' ? shm_name : std::string("/") + shm_name;
+    shm_unlink(r->name.c_str());
+    const int fd = shm_open(r->name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0) { delete r; return nullptr; }
+    if (ftruncate(fd, (off_t)r->map_bytes) != 0) { close(fd); shm_unlink(r->name.c_str()); delete r; return nullptr; }
+    mem = mmap(nullptr, r->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (mem == MAP_FAILED) { shm_unlink(r->name.c_str()); delete r; return nullptr; }
+    r->shm = true;
+  } else {
+    mem = mmap(nullptr, r->map_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (mem == MAP_FAILED) { delete r; return nullptr; }
+  }
+  r->owner = true;
+  r->hdr = new (mem) RingHdr();
+  r->data = (unsigned char*)mem + ring_hdr_bytes();
+  r->hdr->depth = depth; r->hdr->batch_size = B; r->hdr->cn = CN; r->hdr->consumers = consumers;
+  r->hdr->has_last = has_last ? 1 : 0; r->hdr->batch_bytes = rec_al;
+  r->hdr->produced.store(0); r->hdr->closed.store(0);
+  for (int i = 0; i < VV_RING_MAX_CONSUMERS; ++i) { r->hdr->released[i].v.store(0); r->next_k[i] = 0; }
+  std::atomic_thread_fence(std::memory_order_release);
+  r->hdr->magic = kRingMagic;
+  return r;
+}
+
+static void ring_free(vv_batch_ring* r) {
+  if (!r) return;
+  if (r->hdr) {
+    if (r->owner) r->hdr->closed.store(1, std::memory_order_release);
+    munmap((void*)r->hdr, r->map_bytes);
+  }
+  if (r->owner && r->shm) shm_unlink(r->name.c_str());
+  delete r;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 struct vv_sampler {
   vv_sampler_param p;
   std::vector<int32_t> video_id, n_shots, shot_ids;
   std::vector<int64_t> row_base, shot_off;
   bool has_ids = false;
+  int max_n = 1;
   LibcRand rng;
   FastMod fm;
   int32_t rmod(int32_t d) { return fm.mod(rng.next(), d); }     // rand() % d
   int32_t cursor = 0;
   std::vector<int32_t> buffer_ids;            // persistent permutation (…data_layer.cpp:81-83)
-  std::vector<int32_t> buf_row;               // slot -> table row
+  std::vector<int32_t> buf_row;               // slot -> table row (+ one dummy slot at the end, fast path)
+  std::vector<int32_t> buf_row_negs;          // the negs stage's own view of the buffer (pipelined mode)
   std::vector<uint64_t> buf_key;              // slot -> (video_id, shot_id)
   std::unordered_set<uint64_t> keys;          // negative_keys_set_ (general case)
   // fast path: when every (video_id, shot_id) key names exactly one table row, membership in the key
-  // set is a bitmap over table rows
+  // set is a bitmap over table rows (+ one dummy entry at the end)
   bool dense_keys = false;
   std::vector<uint8_t> row_in_buf;
+  int64_t row_min = 0, row_dummy = 0;
   bool contains(int v, int j) const {
     return dense_keys ? row_in_buf[(size_t)(row_base[v] - row_min + j)] != 0 : keys.count(key(video_id[v], shot_id(v, j))) != 0;
   }
   void insert_key(int v, int j) {
     if (dense_keys) row_in_buf[(size_t)(row_base[v] - row_min + j)] = 1; else keys.insert(key(video_id[v], shot_id(v, j)));
   }
-  int64_t row_min = 0;
-  std::vector<Slot> slots;                    // persistent prefetch_data_ contents [B][C+Nn]
+  std::vector<Slot> slots;                    // persistent prefetch_data_ contents [B][C+Nn] (general path)
   std::vector<int32_t> perm;
 
   static uint64_t key(int32_t vid, int32_t shot) { return ((uint64_t)(uint32_t)vid << 32) | (uint32_t)shot; }
@@ -124,93 +260,162 @@ struct vv_sampler {
     int left = (int)a.size();
     for (int first = 0; first < n; ++first, --left) std::swap(a[first], a[first + rmod(left)]);
   }
+
+  // ---- staged fast path (dense keys, no same-video negatives)
+  static constexpr int kDummies = 8;
+  bool fast = false;
+  int CA = 0;                                 // stream values the frames stage looks at (C, 2 or 0 by context type)
+  int rec_words = 0;                          // words of one item record: {v, n_events, ev_off_lo, ev_off_hi, vals[CA + Nn]}
+  struct Event { int32_t pos, row; };
+  int next_general(int32_t* idx, int32_t* last_src, int32_t* label);
+  void select_item(uint32_t* rec);
+  template <bool LOG> void swap_item(uint32_t* rec, int32_t* brow, Event* ev_ring, uint64_t ev_mask, uint64_t* ev_head);
+  int cur_v = 0, cur_n = 0, cur_a_total = 0;  // the item between select_item and swap_item
+  int sample_batch(int32_t* idx, int32_t* last_src, int32_t* label);
+  void negs_item(const uint32_t* rec, int32_t* out, const int32_t* brow);
+  void frames_item(const uint32_t* rec, int32_t* out, int32_t* label);
+  std::vector<uint32_t> rec1;                 // the serial path's one item record
+
+  // ---- prefetch pipeline
+  vv_batch_ring* ring = nullptr;
+  std::vector<std::thread> threads;
+  std::atomic<int> stop{0};
+  int n_stage_threads = 0;
+  std::vector<uint32_t> recs; int64_t ring_items = 0;
+  std::vector<Event> events; uint64_t ev_mask = 0;
+  alignas(64) std::atomic<int64_t> walked{0};
+  alignas(64) std::atomic<int64_t> negs_done{0};
+  alignas(64) std::atomic<int64_t> frames_done{0};
+  alignas(64) std::atomic<uint64_t> ev_tail{0};
+  void run_batches();
+  void run_walk();
+  void run_negs(bool also_frames);
+  void run_frames();
+  void run_publisher();
 };
 
-extern "C" {
-
-void vv_sampler_param_default(vv_sampler_param* p) {
-  memset(p, 0, sizeof(*p));
-  p->batch_size = 128; p->context_size = 5; p->num_negative_samples = 10;   // shipped prototxt :13-23
-  p->max_buffer_size = 5000; p->negative_swap_percentage = 50; p->max_same_video_negs = 0;
-  p->max_tries_for_negs = 100;
+// ---- the three chains of one item -----------------------------------------------------------------------------
+// walk = select_item + swap_item.  select: pick the item's record (…data_layer.cpp:796-848: a record with fewer than
+// 2 or fewer than C shots adds nothing and consumes no draw) and hand the frames / negs stages the raw stream words they
+// own.  swap: the swap-in loop (:888-906 with AddToBuffer :24-37), branch-free: a shot that is not swapped in writes
+// to a dummy slot / dummy row instead of branching on a coin flip.
+void vv_sampler::select_item(uint32_t* rec) {
+  const int C = p.context_size, Nn = p.num_negative_samples, V = (int)video_id.size();
+  int v, n;
+  for (;;) {
+    v = cursor; n = n_shots[v];
+    cursor = cursor + 1 == V ? 0 : cursor + 1;
+    if (n >= 2 && n >= C) break;
+  }
+  const bool shuffled = (p.context_type == VV_CONTEXT_WINDOW || p.context_type == VV_CONTEXT_PAST) && Nn > 0 && n > C;
+  const int a_total = CA + (shuffled ? n - C - 1 : 0);     // :432/:517 random_unique, :482/:566 random_shuffle
+  rng.ensure(a_total + Nn + 2 * n + 2);
+  rec[0] = (uint32_t)v;
+  const uint32_t* hv = rng.peek();
+  for (int i = 0; i < CA; ++i) rec[4 + i] = hv[i];
+  hv += a_total;
+  for (int i = 0; i < Nn; ++i) rec[4 + CA + i] = hv[i];
+  cur_v = v; cur_n = n; cur_a_total = a_total;
 }
 
-int vv_sampler_create(const vv_sampler_param* p, int32_t n_videos, const int32_t* video_id,
-                      const int32_t* n_shots, const int64_t* row_base, const int32_t* shot_ids,
-                      vv_sampler** out) {
-  if (!p || !video_id || !n_shots || !row_base || !out || n_videos < 1) return VV_ERR_ARG;
-  if (p->batch_size < 1 || p->context_size < 2) return VV_ERR_ARG;                // :207,:209
-  if (p->context_type < VV_CONTEXT_WINDOW || p->context_type > VV_CONTEXT_PAST_CONTINUOUS_FIXED) return VV_ERR_ARG;   // :760
-  if (p->context_type == VV_CONTEXT_WINDOW && p->context_size % 2 != 1) return VV_ERR_ARG;   // :434
-  const int Nn = p->num_negative_samples;
-  if (Nn < 0) return VV_ERR_ARG;
-  if (Nn > 0 && (p->negative_swap_percentage < 0 || p->negative_swap_percentage > 99 ||
-                 p->max_buffer_size < Nn)) return VV_ERR_ARG;                     // :79-80
-  vv_sampler* s = new (std::nothrow) vv_sampler();
-  if (!s) return VV_ERR_STATE;
-  s->p = *p;
-  s->video_id.assign(video_id, video_id + n_videos);
-  s->n_shots.assign(n_shots, n_shots + n_videos);
-  s->row_base.assign(row_base, row_base + n_videos);
-  int max_n = 1; int64_t total = 0;
-  s->shot_off.resize(n_videos);
-  for (int v = 0; v < n_videos; ++v) {
-    if (n_shots[v] < 1) { delete s; return VV_ERR_ARG; }                         // :808
-    s->shot_off[v] = total; total += n_shots[v]; max_n = std::max(max_n, n_shots[v]);
-  }
-  if (shot_ids) { s->has_ids = true; s->shot_ids.assign(shot_ids, shot_ids + total); }
-  s->perm.reserve(max_n);
-  s->fm.init(std::max(std::max(max_n, p->max_buffer_size), 100) + 1);
-  {  // keys are in bijection with rows iff video ids are distinct, shot ids distinct within a video and
-     // the records' row ranges do not overlap
-    std::unordered_set<int32_t> vids(video_id, video_id + n_videos);
-    bool ok = (int)vids.size() == n_videos;
-    int64_t lo = row_base[0], hi = row_base[0];
-    std::vector<std::pair<int64_t, int64_t>> ranges;
-    for (int v = 0; v < n_videos && ok; ++v) {
-      lo = std::min(lo, row_base[v]); hi = std::max(hi, row_base[v] + n_shots[v]);
-      ranges.emplace_back(row_base[v], row_base[v] + n_shots[v]);
-      if (shot_ids) {
-        std::unordered_set<int32_t> sids(shot_ids + s->shot_off[v], shot_ids + s->shot_off[v] + n_shots[v]);
-        ok = (int)sids.size() == n_shots[v];
-      }
+template <bool LOG>
+__attribute__((noinline)) void vv_sampler::swap_item(uint32_t* rec, int32_t* brow, Event* ev_ring, uint64_t evm, uint64_t* ev_head) {
+  const int Nn = p.num_negative_samples, v = cur_v, n = cur_n, a_total = cur_a_total;
+  const uint32_t* hv = rng.peek() + a_total + Nn;
+  int q = 0;
+  uint32_t nev = 0;
+  const uint64_t ev0 = LOG ? *ev_head : 0;
+  if (Nn > 0 && p.negative_swap_percentage > 0) {
+    const uint8_t* fl = rng.flags() + a_total + Nn;
+    uint8_t* inb = row_in_buf.data() - row_min;              // indexed by table row; inb[row_dummy] is scratch
+    const int mb = p.max_buffer_size;
+    const uint64_t M = fm.magic(mb);
+    const int64_t base = row_base[v];
+    for (int j = 0; j < n; ++j) {
+      const int32_t r = (int32_t)(base + j);
+      // kDummies dummy slots / rows used in turn: a not-taken store then never feeds the very next iteration's load
+      // of the same address (a store-to-load dependence the core would have to predict on a coin flip)
+      const int32_t dummy = (int32_t)row_dummy + (j & (kDummies - 1)), mbd = mb + (j & (kDummies - 1));
+      const int notin = inb[r] == 0;                         // :890-893 key not in the buffer
+      const int take = notin & fl[q];                        // :27 rand() % 100 < negative_swap_percentage
+      const int32_t pos = FastMod::modm(M, (int32_t)(hv[q + 1] >> 1), mb);   // :29 rand() % max_buffer_size
+      const int32_t mask = -take;                            // all ones when taken (arithmetic select: the compiler
+      const int32_t pe = mbd ^ ((pos ^ mbd) & mask);         //  must not turn a coin flip back into a branch)
+      const int32_t nr = dummy ^ ((r ^ dummy) & mask);       // not taken: everything lands on the dummy slot / row
+      inb[brow[pe]] = 0;
+      inb[nr] = 1;
+      brow[pe] = nr;
+      if (LOG) { ev_ring[(ev0 + nev) & evm] = Event{pos, r}; nev += (uint32_t)take; }
+      q += notin + take;
     }
-    if (ok) {
-      std::sort(ranges.begin(), ranges.end());
-      for (size_t i = 1; i < ranges.size() && ok; ++i) ok = ranges[i].first >= ranges[i - 1].second;
-    }
-    if (ok && hi - lo < (1ll << 31)) { s->dense_keys = true; s->row_min = lo; s->row_in_buf.assign((size_t)(hi - lo), 0); }
   }
-  if (p->initial_cursor < 0) { delete s; return VV_ERR_ARG; }
-  s->cursor = p->initial_cursor % n_videos;                                       // rand_skip, :156-180
-  const int CN = p->context_size + Nn;
-  s->slots.assign((size_t)p->batch_size * CN, Slot());
-  const int mb = Nn > 0 ? p->max_buffer_size : 0;
-  s->buffer_ids.resize(mb);
-  for (int i = 0; i < mb; ++i) s->buffer_ids[i] = i;
-  s->buf_row.reserve(mb); s->buf_key.reserve(mb);
-  // fill the negative buffer: one random shot of each visited record until full (:240-344)
-  if (mb > 0) {
-    const int64_t tries = (int64_t)p->max_tries_for_negs * mb;
-    for (int64_t t = 0; t < tries && (int)s->buf_row.size() < mb; ++t) {
-      const int v = s->cursor;
-      s->cursor = (s->cursor + 1) % n_videos;
-      const int j = s->rmod(s->n_shots[v]);
-      if (!s->contains(v, j)) {
-        s->insert_key(v, j);
-        s->buf_row.push_back((int32_t)(s->row_base[v] + j));
-        s->buf_key.push_back(vv_sampler::key(s->video_id[v], s->shot_id(v, j)));
-      }
-    }
-    if ((int)s->buf_row.size() != mb) { delete s; return VV_ERR_ARG; }           // :344
-  }
-  *out = s;
-  return VV_OK;
+  rng.skip(a_total + Nn + q);
+  rec[1] = nev; rec[2] = (uint32_t)ev0; rec[3] = (uint32_t)(ev0 >> 32);
+  if (LOG) *ev_head = ev0 + nev;
 }
 
-int vv_sampler_next(vv_sampler* s, int32_t* idx, int32_t* last_src, int32_t* label) {
-  if (!s) return VV_ERR_ARG;
-  const vv_sampler_param& p = s->p;
+// negs: :855 random_unique over the persistent slot permutation, fused with :856-875 (the drawn slots' rows)
+void vv_sampler::negs_item(const uint32_t* rec, int32_t* out, const int32_t* brow) {
+  const int Nn = p.num_negative_samples;
+  if (Nn <= 0) return;
+  int32_t* ids = buffer_ids.data();
+  const uint32_t* x = rec + 4 + CA;
+  const uint64_t* M = fm.table();
+  int left = p.max_buffer_size;
+  for (int first = 0; first < Nn; ++first, --left) {
+    const int r = first + FastMod::modm(M[left], (int32_t)(x[first] >> 1), left);
+    const int32_t t = ids[r]; ids[r] = ids[first]; ids[first] = t;
+    out[first] = brow[t];
+  }
+}
+
+// frames: AddSamplesToTop without same-video negatives (:425-453, :510-538, :599-640, :677-718)
+void vv_sampler::frames_item(const uint32_t* rec, int32_t* out, int32_t* label) {
+  const int C = p.context_size, v = (int)rec[0], n = n_shots[v];
+  const int64_t base = row_base[v];
+  const uint32_t* x = rec + 4;
+  if (label) *label = video_id[v];                                                   // :879
+  if (p.context_type == VV_CONTEXT_WINDOW || p.context_type == VV_CONTEXT_PAST) {
+    // random_unique(perm, C) on the identity permutation of 0..n-1, kept sparse: only the touched entries
+    int32_t oi[64], ov[64]; int no = 0;
+    int32_t fr[32];
+    std::vector<int32_t> big_i, big_v, big_f;
+    int32_t *pi = oi, *pv = ov, *pf = fr;
+    if (2 * C > 64) { big_i.resize(2 * C); big_v.resize(2 * C); big_f.resize(C); pi = big_i.data(); pv = big_v.data(); pf = big_f.data(); }
+    auto get = [&](int i) { for (int k = no - 1; k >= 0; --k) if (pi[k] == i) return pv[k]; return (int32_t)i; };
+    auto set = [&](int i, int32_t val) { for (int k = no - 1; k >= 0; --k) if (pi[k] == i) { pv[k] = val; return; } pi[no] = i; pv[no] = val; ++no; };
+    for (int first = 0, left = n; first < C; ++first, --left) {
+      const int j = first + fm.mod((int32_t)(x[first] >> 1), left);
+      const int32_t vf = get(first), vj = get(j);
+      set(first, vj); set(j, vf);
+    }
+    for (int i = 0; i < C; ++i) pf[i] = get(i);
+    std::sort(pf, pf + C);                                                           // :437, :522
+    if (p.context_type == VV_CONTEXT_WINDOW) {
+      const int half = C / 2;
+      for (int i = 0, ctx = 0; i < C; ++i) {                                         // :439-453: the middle one is the target
+        if (i == half) out[0] = (int32_t)(base + pf[i]); else out[++ctx] = (int32_t)(base + pf[i]);
+      }
+    } else {
+      for (int i = 0; i < C; ++i) out[i == C - 1 ? 0 : i + 1] = (int32_t)(base + pf[i]);   // :524-538: the last one
+    }
+  } else {
+    const int msl = (n - C) / (C - 1);                                               // :609, :687
+    int sl, begin;
+    if (p.context_type == VV_CONTEXT_PAST_CONTINUOUS) {
+      sl = fm.mod((int32_t)(x[0] >> 1), msl + 1);                                    // :610
+      begin = fm.mod((int32_t)(x[1] >> 1), n - (C - 1) * sl - C + 1);                // :612-613
+    } else {
+      sl = msl >= 1 ? msl - 1 : 0;                                                   // :688
+      begin = n - (C - 1) * sl - C;                                                  // :690-691
+    }
+    for (int i = 0; i < C; ++i) out[i == C - 1 ? 0 : i + 1] = (int32_t)(base + begin + i * (sl + 1));
+  }
+}
+
+// ---- general path: same-video negatives (quirk Q1 needs the persistent slot contents) or keys that are not rows ----
+int vv_sampler::next_general(int32_t* idx, int32_t* last_src, int32_t* label) {
+  vv_sampler* s = this;
   const int C = p.context_size, Nn = p.num_negative_samples, CN = C + Nn, half = C / 2;
   const int V = (int)s->video_id.size();
   for (int item = 0; item < p.batch_size;) {
@@ -219,6 +424,7 @@ int vv_sampler_next(vv_sampler* s, int32_t* idx, int32_t* last_src, int32_t* lab
     const int64_t base = s->row_base[v];
     Slot* sl = &s->slots[(size_t)item * CN];
     int added = 0;
+    const int max_same = std::min(p.max_same_video_negs, Nn);                        // never past the item's Nn slots
     const bool ok = n >= 2 && n >= C;                                              // :387,:427,:512,:601,:679
     if (ok && p.context_type != VV_CONTEXT_WINDOW) {
       // :510-757 -- target = the last of the C frames, context = the C-1 before it, in time order
@@ -247,18 +453,18 @@ int vv_sampler_next(vv_sampler* s, int32_t* idx, int32_t* last_src, int32_t* lab
         d.row = d.last = (int32_t)(base + frame);
       }
       if (p.context_type == VV_CONTEXT_PAST) {
-        if (Nn > 0 && n > C && p.max_same_video_negs <= 0) {
+        if (Nn > 0 && n > C && max_same <= 0) {
           s->rng.discard(n - C - 1);
         } else if (Nn > 0 && n > C) {                                              // :563-583
           for (int i = C + 1; i < n; ++i) {
             const int j = C + s->rmod(i - C + 1);
             if (i != j) std::swap(perm[i], perm[j]);
           }
-          for (int nid = C; nid < n && added < p.max_same_video_negs; ++nid)
+          for (int nid = C; nid < n && added < max_same; ++nid)
             if (perm[nid] < perm[1]) sl[C + added++].row = (int32_t)(base + perm[nid]);   // :570-577, F-1 values
         }
       } else if (Nn > 0 && begin > 0) {                                            // :652-670, :730-748
-        for (int nid = begin - 1; nid >= 0 && added < p.max_same_video_negs; --nid)
+        for (int nid = begin - 1; nid >= 0 && added < max_same; --nid)
           sl[C + added++].row = (int32_t)(base + nid);
       }
     } else if (ok) {
@@ -272,14 +478,14 @@ int vv_sampler_next(vv_sampler* s, int32_t* idx, int32_t* last_src, int32_t* lab
         Slot& d = (i == half) ? sl[0] : sl[++ctx];
         d.row = d.last = r;
       }
-      if (Nn > 0 && n > C && p.max_same_video_negs <= 0) {
+      if (Nn > 0 && n > C && max_same <= 0) {
         s->rng.discard(n - C - 1);                // the shuffle below draws n-C-1 values; its result is unused here
       } else if (Nn > 0 && n > C) {                                                // :479-503
         for (int i = C + 1; i < n; ++i) {         // std::random_shuffle(perm + C, perm + n)
           const int j = C + s->rmod(i - C + 1);
           if (i != j) std::swap(perm[i], perm[j]);
         }
-        for (int nid = C; nid < n && added < p.max_same_video_negs; ++nid)
+        for (int nid = C; nid < n && added < max_same; ++nid)
           if (perm[nid] < perm[half - 1] || perm[nid] > perm[half + 1])
             sl[C + added++].row = (int32_t)(base + perm[nid]);   // F-1 values copied: .last stays
       }
@@ -303,7 +509,6 @@ int vv_sampler_next(vv_sampler* s, int32_t* idx, int32_t* last_src, int32_t* lab
       uint8_t* inb = s->row_in_buf.data() - s->row_min;      // indexed by table row
       int32_t* brow = s->buf_row.data();
       const int swap = p.negative_swap_percentage, mb = p.max_buffer_size;
-      const int32_t vid = s->video_id[v];
       for (int j = 0; j < n; ++j) {
         const int64_t r = base + j;
         if (inb[r]) continue;
@@ -311,7 +516,6 @@ int vv_sampler_next(vv_sampler* s, int32_t* idx, int32_t* last_src, int32_t* lab
           const int pos = s->rmod(mb);                                             // :29
           inb[brow[pos]] = 0;
           inb[r] = 1;
-          s->buf_key[pos] = vv_sampler::key(vid, s->shot_id(v, j));
           brow[pos] = (int32_t)r;
         }
       }
@@ -336,6 +540,371 @@ int vv_sampler_next(vv_sampler* s, int32_t* idx, int32_t* last_src, int32_t* lab
   return VV_OK;
 }
 
-int vv_sampler_destroy(vv_sampler* s) { delete s; return VV_OK; }
+// ---- prefetch threads -------------------------------------------------------------------------------------------
+// One thread running whole batches (general path, or threads == 1).
+void vv_sampler::run_batches() {
+  RingHdr* h = ring->hdr;
+  for (int64_t k = 0; !stop.load(std::memory_order_relaxed); ++k) {
+    unsigned spins = 0;
+    while (k - ring->min_released() >= h->depth) { if (stop.load(std::memory_order_relaxed)) return; backoff(spins); }
+    sample_batch(ring->idx_of(k), h->has_last ? ring->last_of(k) : nullptr, ring->label_of(k));
+    h->produced.store(k + 1, std::memory_order_release);
+  }
+}
+
+void vv_sampler::run_walk() {
+  const int B = p.batch_size;
+  uint64_t ev_head = 0;
+  int64_t it = 0, published = 0;
+  const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(32, B));
+  const uint64_t ev_cap = ev_mask + 1;
+  while (!stop.load(std::memory_order_relaxed)) {
+    unsigned spins = 0;
+    // the record slot must have been consumed by both later stages, its batch buffer released by every consumer,
+    // and the event ring must have room for one more video
+    for (;;) {
+      const int64_t done = std::min(negs_done.load(std::memory_order_acquire), frames_done.load(std::memory_order_acquire));
+      if (it - done < ring_items && ev_head + (uint64_t)max_n <= ev_tail.load(std::memory_order_acquire) + ev_cap) break;
+      if (published < it) { walked.store(it, std::memory_order_release); published = it; }
+      if (stop.load(std::memory_order_relaxed)) return;
+      backoff(spins);
+    }
+    uint32_t* rec = recs.data() + (size_t)(it % ring_items) * rec_words;
+    select_item(rec);
+    swap_item<true>(rec, buf_row.data(), events.data(), ev_mask, &ev_head);
+    ++it;
+    if (it - published >= chunk || it % B == 0) { walked.store(it, std::memory_order_release); published = it; }
+  }
+}
+
+void vv_sampler::run_negs(bool also_frames) {
+  const int B = p.batch_size, C = p.context_size, CN = C + p.num_negative_samples;
+  RingHdr* h = ring->hdr;
+  int64_t it = 0, published = 0, avail = 0;
+  int32_t* brow = buf_row_negs.data();
+  while (!stop.load(std::memory_order_relaxed)) {
+    unsigned spins = 0;
+    while (it >= avail) {
+      avail = walked.load(std::memory_order_acquire);
+      if (it < avail) break;
+      if (published < it) { negs_done.store(it, std::memory_order_release); if (also_frames) frames_done.store(it, std::memory_order_release); published = it; }
+      if (stop.load(std::memory_order_relaxed)) return;
+      backoff(spins);
+    }
+    const int64_t k = it / B;
+    if (it % B == 0) {
+      spins = 0;
+      while (k - ring->min_released() >= h->depth) { if (stop.load(std::memory_order_relaxed)) return; backoff(spins); }
+    }
+    const uint32_t* rec = recs.data() + (size_t)(it % ring_items) * rec_words;
+    int32_t* out = ring->idx_of(k) + (size_t)(it % B) * CN;
+    negs_item(rec, out + C, brow);
+    if (also_frames) frames_item(rec, out, ring->label_of(k) + (it % B));
+    const uint64_t e0 = (uint64_t)rec[2] | ((uint64_t)rec[3] << 32);
+    const uint32_t nev = rec[1];
+    for (uint32_t e = 0; e < nev; ++e) { const Event ev = events[(e0 + e) & ev_mask]; brow[ev.pos] = ev.row; }
+    if (nev) ev_tail.store(e0 + nev, std::memory_order_release);
+    ++it;
+    if (it - published >= 32 || it % B == 0) {
+      negs_done.store(it, std::memory_order_release);
+      if (also_frames) frames_done.store(it, std::memory_order_release);
+      published = it;
+    }
+  }
+}
+
+void vv_sampler::run_frames() {
+  const int B = p.batch_size, CN = p.context_size + p.num_negative_samples;
+  RingHdr* h = ring->hdr;
+  int64_t it = 0, published = 0, avail = 0;
+  while (!stop.load(std::memory_order_relaxed)) {
+    unsigned spins = 0;
+    while (it >= avail) {
+      avail = walked.load(std::memory_order_acquire);
+      if (it < avail) break;
+      if (published < it) { frames_done.store(it, std::memory_order_release); published = it; }
+      if (stop.load(std::memory_order_relaxed)) return;
+      backoff(spins);
+    }
+    const int64_t k = it / B;
+    if (it % B == 0) {
+      spins = 0;
+      while (k - ring->min_released() >= h->depth) { if (stop.load(std::memory_order_relaxed)) return; backoff(spins); }
+    }
+    const uint32_t* rec = recs.data() + (size_t)(it % ring_items) * rec_words;
+    frames_item(rec, ring->idx_of(k) + (size_t)(it % B) * CN, ring->label_of(k) + (it % B));
+    ++it;
+    if (it - published >= 32 || it % B == 0) { frames_done.store(it, std::memory_order_release); published = it; }
+  }
+}
+
+// turns "both stages are past the end of batch k" into ring->produced (one writer keeps the hand-off simple)
+void vv_sampler::run_publisher() {
+  const int B = p.batch_size;
+  RingHdr* h = ring->hdr;
+  int64_t k = 0;
+  while (!stop.load(std::memory_order_relaxed)) {
+    const int64_t done = std::min(negs_done.load(std::memory_order_acquire), frames_done.load(std::memory_order_acquire));
+    if (done >= (k + 1) * B) { ++k; h->produced.store(k, std::memory_order_release); continue; }
+    unsigned spins = 200; backoff(spins);
+  }
+}
+
+int vv_sampler::sample_batch(int32_t* idx, int32_t* last_src, int32_t* label) {
+  if (!fast) return next_general(idx, last_src, label);
+  const int B = p.batch_size, C = p.context_size, CN = C + p.num_negative_samples;
+  std::vector<int32_t> tmp;
+  int32_t* out = idx;
+  if (!out) { tmp.resize((size_t)B * CN); out = tmp.data(); }
+  uint32_t* rec = rec1.data();
+  for (int it = 0; it < B; ++it) {
+    int32_t* o = out + (size_t)it * CN;
+    select_item(rec);
+    negs_item(rec, o + C, buf_row.data());       // the buffer as it stands BEFORE this item's swap-in (:855-875 precede :888-906)
+    frames_item(rec, o, label ? label + it : nullptr);
+    swap_item<false>(rec, buf_row.data(), nullptr, 0, nullptr);
+  }
+  if (last_src) memcpy(last_src, out, (size_t)B * CN * 4);     // no same-video negatives on this path: last == row
+  return VV_OK;
+}
+
+extern "C" {
+
+void vv_sampler_param_default(vv_sampler_param* p) {
+  memset(p, 0, sizeof(*p));
+  p->batch_size = 128; p->context_size = 5; p->num_negative_samples = 10;   // shipped prototxt :13-23
+  p->max_buffer_size = 5000; p->negative_swap_percentage = 50; p->max_same_video_negs = 0;
+  p->max_tries_for_negs = 100;
+}
+
+int vv_sampler_create(const vv_sampler_param* p, int32_t n_videos, const int32_t* video_id,
+                      const int32_t* n_shots, const int64_t* row_base, const int32_t* shot_ids,
+                      vv_sampler** out) {
+  if (!p || !video_id || !n_shots || !row_base || !out || n_videos < 1) return VV_ERR_ARG;
+  if (p->batch_size < 1 || p->context_size < 2) return VV_ERR_ARG;                // :207,:209
+  if (p->context_type < VV_CONTEXT_WINDOW || p->context_type > VV_CONTEXT_PAST_CONTINUOUS_FIXED) return VV_ERR_ARG;   // :760
+  if (p->context_type == VV_CONTEXT_WINDOW && p->context_size % 2 != 1) return VV_ERR_ARG;   // :434
+  const int Nn = p->num_negative_samples;
+  if (Nn < 0) return VV_ERR_ARG;
+  if (Nn > 0 && (p->negative_swap_percentage < 0 || p->negative_swap_percentage > 99 ||
+                 p->max_buffer_size < Nn)) return VV_ERR_ARG;                     // :79-80
+  // The reference writes same-video negatives at top_data offset C + added without ever comparing added with
+  // num_negative_samples (:484-502): more same-video negatives than negative slots runs into the next item's slots
+  // (undefined behaviour there).  Rejected here.
+  if (p->max_same_video_negs > Nn) return VV_ERR_ARG;
+  vv_sampler* s = new (std::nothrow) vv_sampler();
+  if (!s) return VV_ERR_STATE;
+  s->p = *p;
+  s->video_id.assign(video_id, video_id + n_videos);
+  s->n_shots.assign(n_shots, n_shots + n_videos);
+  s->row_base.assign(row_base, row_base + n_videos);
+  int max_n = 1; int64_t total = 0;
+  bool any_ok = false;
+  s->shot_off.resize(n_videos);
+  for (int v = 0; v < n_videos; ++v) {
+    if (n_shots[v] < 1) { delete s; return VV_ERR_ARG; }                         // :808
+    s->shot_off[v] = total; total += n_shots[v]; max_n = std::max(max_n, n_shots[v]);
+    any_ok = any_ok || (n_shots[v] >= 2 && n_shots[v] >= p->context_size);
+  }
+  if (!any_ok) { delete s; return VV_ERR_ARG; }                                   // the reference would spin forever (:796-848)
+  s->max_n = max_n;
+  if (shot_ids) { s->has_ids = true; s->shot_ids.assign(shot_ids, shot_ids + total); }
+  s->perm.reserve(max_n);
+  s->fm.init(std::max(std::max(max_n, p->max_buffer_size), 100) + 1);
+  {  // keys are in bijection with rows iff video ids are distinct, shot ids distinct within a video and
+     // the records' row ranges do not overlap
+    std::unordered_set<int32_t> vids(video_id, video_id + n_videos);
+    bool ok = (int)vids.size() == n_videos;
+    int64_t lo = row_base[0], hi = row_base[0];
+    std::vector<std::pair<int64_t, int64_t>> ranges;
+    for (int v = 0; v < n_videos && ok; ++v) {
+      lo = std::min(lo, row_base[v]); hi = std::max(hi, row_base[v] + n_shots[v]);
+      ranges.emplace_back(row_base[v], row_base[v] + n_shots[v]);
+      if (shot_ids) {
+        std::unordered_set<int32_t> sids(shot_ids + s->shot_off[v], shot_ids + s->shot_off[v] + n_shots[v]);
+        ok = (int)sids.size() == n_shots[v];
+      }
+    }
+    if (ok) {
+      std::sort(ranges.begin(), ranges.end());
+      for (size_t i = 1; i < ranges.size() && ok; ++i) ok = ranges[i].first >= ranges[i - 1].second;
+    }
+    if (ok && lo >= 0 && hi < (1ll << 31) - 1 - vv_sampler::kDummies) {
+      s->dense_keys = true; s->row_min = lo; s->row_dummy = hi;
+      s->row_in_buf.assign((size_t)(hi - lo) + vv_sampler::kDummies, 0);          // + the dummy entries
+    }
+  }
+  if (p->initial_cursor < 0) { delete s; return VV_ERR_ARG; }
+  s->cursor = p->initial_cursor % n_videos;                                       // rand_skip, :156-180
+  const int C = p->context_size, CN = C + Nn;
+  s->fast = s->dense_keys && p->max_same_video_negs <= 0;
+  s->CA = (p->context_type == VV_CONTEXT_WINDOW || p->context_type == VV_CONTEXT_PAST) ? C
+          : (p->context_type == VV_CONTEXT_PAST_CONTINUOUS ? 2 : 0);
+  s->rec_words = 4 + s->CA + Nn;
+  s->rec1.assign((size_t)s->rec_words, 0u);
+  {
+    const int64_t per_item = (int64_t)C + Nn + 3ll * max_n + 8;
+    const int64_t block = std::max<int64_t>(16384, 4 * per_item);
+    if (block > (1ll << 28)) { delete s; return VV_ERR_ARG; }
+    s->rng.init((int)block, Nn > 0 ? p->negative_swap_percentage : 0);
+  }
+  if (!s->fast) s->slots.assign((size_t)p->batch_size * CN, Slot());
+  const int mb = Nn > 0 ? p->max_buffer_size : 0;
+  s->buffer_ids.resize(mb);
+  for (int i = 0; i < mb; ++i) s->buffer_ids[i] = i;
+  s->buf_row.reserve((size_t)mb + vv_sampler::kDummies); s->buf_key.reserve(mb);
+  // fill the negative buffer: one random shot of each visited record until full (:240-344)
+  if (mb > 0) {
+    const int64_t tries = (int64_t)p->max_tries_for_negs * mb;
+    for (int64_t t = 0; t < tries && (int)s->buf_row.size() < mb; ++t) {
+      const int v = s->cursor;
+      s->cursor = (s->cursor + 1) % n_videos;
+      const int j = s->rmod(s->n_shots[v]);
+      if (!s->contains(v, j)) {
+        s->insert_key(v, j);
+        s->buf_row.push_back((int32_t)(s->row_base[v] + j));
+        s->buf_key.push_back(vv_sampler::key(s->video_id[v], s->shot_id(v, j)));
+      }
+    }
+    if ((int)s->buf_row.size() != mb) { delete s; return VV_ERR_ARG; }           // :344
+  }
+  for (int k = 0; k < vv_sampler::kDummies; ++k) s->buf_row.push_back((int32_t)s->row_dummy + k);   // dummy slots of the branch-free swap-in
+  *out = s;
+  return VV_OK;
+}
+
+static int pop_batch(vv_batch_ring* r, int consumer, int32_t item_begin, int32_t item_count, int32_t* idx,
+                     int32_t* last_src, int32_t* label, double timeout_s) {
+  RingHdr* h = r->hdr;
+  if (consumer < 0 || consumer >= h->consumers) return VV_ERR_ARG;
+  if (item_begin < 0 || item_count < 0 || item_begin + item_count > h->batch_size) return VV_ERR_ARG;
+  const int64_t k = r->next_k[consumer];
+  unsigned spins = 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  while (h->produced.load(std::memory_order_acquire) <= k) {
+    if (h->closed.load(std::memory_order_acquire)) return VV_ERR_STATE;
+    backoff(spins);
+    if (timeout_s > 0 && (spins & 1023) == 0 &&
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return VV_ERR_STATE;
+  }
+  const size_t cn = (size_t)h->cn;
+  if (idx) memcpy(idx, r->idx_of(k) + (size_t)item_begin * cn, (size_t)item_count * cn * 4);
+  if (last_src) memcpy(last_src, (h->has_last ? r->last_of(k) : r->idx_of(k)) + (size_t)item_begin * cn, (size_t)item_count * cn * 4);
+  if (label) memcpy(label, r->label_of(k) + item_begin, (size_t)item_count * 4);
+  r->next_k[consumer] = k + 1;
+  h->released[consumer].v.store(k + 1, std::memory_order_release);
+  return VV_OK;
+}
+
+int vv_sampler_next(vv_sampler* s, int32_t* idx, int32_t* last_src, int32_t* label) {
+  if (!s) return VV_ERR_ARG;
+  if (s->ring) return pop_batch(s->ring, 0, 0, s->p.batch_size, idx, last_src, label, 0.0);
+  return s->sample_batch(idx, last_src, label);
+}
+
+int vv_sampler_prefetch_start(vv_sampler* s, int32_t depth, int32_t threads, const char* shm_name, int32_t consumers) {
+  if (!s || s->ring || depth < 1 || depth > 1024 || threads < 1 || consumers < 1 || consumers > VV_RING_MAX_CONSUMERS) return VV_ERR_ARG;
+  const int B = s->p.batch_size, CN = s->p.context_size + s->p.num_negative_samples;
+  s->ring = ring_create(shm_name, depth, B, CN, consumers, !s->fast);
+  if (!s->ring) return VV_ERR_STATE;
+  s->stop.store(0);
+  if (!s->fast || threads == 1) {
+    s->n_stage_threads = 1;
+    s->threads.emplace_back([s]() { s->run_batches(); });
+    return VV_OK;
+  }
+  // staged pipeline
+  s->ring_items = (int64_t)B * std::min<int64_t>(depth, 4);
+  if (s->ring_items < 256) s->ring_items = 256;
+  s->recs.assign((size_t)s->ring_items * s->rec_words, 0u);
+  uint64_t cap = 1; while (cap < (uint64_t)s->ring_items * 32 + 4ull * s->max_n) cap <<= 1;
+  s->events.assign(cap, vv_sampler::Event{0, 0}); s->ev_mask = cap - 1;
+  s->buf_row_negs = s->buf_row;
+  s->walked.store(0); s->negs_done.store(0); s->frames_done.store(0); s->ev_tail.store(0);
+  const bool three = threads >= 3;
+  s->n_stage_threads = three ? 3 : 2;
+  s->threads.emplace_back([s]() { s->run_walk(); });
+  s->threads.emplace_back([s, three]() { s->run_negs(!three); });
+  if (three) s->threads.emplace_back([s]() { s->run_frames(); });
+  s->threads.emplace_back([s]() { s->run_publisher(); });
+  return VV_OK;
+}
+
+int vv_sampler_prefetch_stop(vv_sampler* s) {
+  if (!s) return VV_ERR_ARG;
+  if (!s->ring) return VV_OK;
+  s->stop.store(1);
+  for (auto& t : s->threads) if (t.joinable()) t.join();
+  s->threads.clear();
+  ring_free(s->ring);
+  s->ring = nullptr;
+  return VV_OK;
+}
+
+int vv_sampler_ring(vv_sampler* s, vv_batch_ring** out) {
+  if (!s || !out || !s->ring) return VV_ERR_ARG;
+  *out = s->ring;
+  return VV_OK;
+}
+
+int vv_sampler_destroy(vv_sampler* s) {
+  if (s) vv_sampler_prefetch_stop(s);
+  delete s;
+  return VV_OK;
+}
+
+int vv_batch_ring_attach(const char* shm_name, double timeout_s, vv_batch_ring** out) {
+  if (!shm_name || !*shm_name || !out) return VV_ERR_ARG;
+  const std::string name = shm_name[0] == '/' ? shm_name : std::string("/") + shm_name;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const int fd = shm_open(name.c_str(), O_RDWR, 0600);
+    if (fd >= 0) {
+      struct stat st;
+      if (fstat(fd, &st) == 0 && (size_t)st.st_size >= ring_hdr_bytes()) {
+        void* mem = mmap(nullptr, (size_t)st.st_size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (mem != MAP_FAILED) {
+          RingHdr* h = (RingHdr*)mem;
+          if (h->magic == kRingMagic) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            vv_batch_ring* r = new (std::nothrow) vv_batch_ring();
+            if (!r) { munmap(mem, (size_t)st.st_size); return VV_ERR_STATE; }
+            r->hdr = h; r->data = (unsigned char*)mem + ring_hdr_bytes(); r->map_bytes = (size_t)st.st_size;
+            r->shm = true; r->owner = false; r->name = name;
+            for (int i = 0; i < VV_RING_MAX_CONSUMERS; ++i) r->next_k[i] = h->released[i].v.load();
+            *out = r;
+            return VV_OK;
+          }
+          munmap(mem, (size_t)st.st_size);
+        }
+      } else close(fd);
+    }
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return VV_ERR_STATE;
+    std::this_thread::sleep_for(std::chrono::milliseconds(2));
+  }
+}
+
+int vv_batch_ring_info(vv_batch_ring* r, int32_t* batch_size, int32_t* slots_per_item, int32_t* consumers, int32_t* depth) {
+  if (!r) return VV_ERR_ARG;
+  if (batch_size) *batch_size = r->hdr->batch_size;
+  if (slots_per_item) *slots_per_item = r->hdr->cn;
+  if (consumers) *consumers = r->hdr->consumers;
+  if (depth) *depth = r->hdr->depth;
+  return VV_OK;
+}
+
+int vv_batch_ring_next(vv_batch_ring* r, int32_t consumer, int32_t item_begin, int32_t item_count, int32_t* idx,
+                       int32_t* label, double timeout_s) {
+  if (!r) return VV_ERR_ARG;
+  return pop_batch(r, consumer, item_begin, item_count, idx, nullptr, label, timeout_s);
+}
+
+int vv_batch_ring_detach(vv_batch_ring* r) {
+  if (!r) return VV_OK;
+  if (r->owner) return VV_ERR_ARG;            // the sampler owns its ring (vv_sampler_prefetch_stop)
+  ring_free(r);
+  return VV_OK;
+}
 
 }  // extern "C"

@@ -312,6 +312,9 @@ class Sampler:
                                         C.c_void_p, C.POINTER(C.c_void_p)]
         L.vv_sampler_next.argtypes = [C.c_void_p] * 4
         L.vv_sampler_destroy.argtypes = [C.c_void_p]
+        L.vv_sampler_prefetch_start.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int32]
+        L.vv_sampler_prefetch_stop.argtypes = [C.c_void_p]
+        L.vv_sampler_ring.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         self.L = L
         vid = np.ascontiguousarray(video_id, dtype=np.int32)
         ns = np.ascontiguousarray(n_shots, dtype=np.int32)
@@ -340,7 +343,76 @@ class Sampler:
             return idx, last, label
         return idx
 
-    def __del__(self):
+    def prefetch_start(self, depth=4, threads=3, shm_name=None, consumers=1):
+        """Background threads keep `depth` batches ahead (BasePrefetchingDataLayer, base_data_layer.cpp:52-95); next()
+        then pops finished batches.  shm_name: publish the ring in POSIX shared memory for `consumers` processes
+        (BatchRing.attach)."""
+        rc = self.L.vv_sampler_prefetch_start(self.h, depth, threads, None if shm_name is None else shm_name.encode(), consumers)
+        if rc != 0:
+            raise VVError("vv_sampler_prefetch_start failed (%d)" % rc)
+
+    def prefetch_stop(self):
+        self.L.vv_sampler_prefetch_stop(self.h)
+
+    def ring(self):
+        """The producer process's own consumer handle of the prefetch ring."""
+        r = C.c_void_p()
+        if self.L.vv_sampler_ring(self.h, C.byref(r)) != 0:
+            raise VVError("vv_sampler_ring: prefetch is not running")
+        return BatchRing(r, owned=False, keep=self)
+
+    def close(self):
         if getattr(self, "h", None) and self.h:
             self.L.vv_sampler_destroy(self.h)
             self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BatchRing:
+    """A consumer's view of a sampler's prefetch ring (vv_batch_ring_*): one sampler per node, every data-parallel
+    rank takes its items of the same global batch."""
+
+    def __init__(self, handle, owned, keep=None):
+        self.L = load_library()
+        self.L.vv_batch_ring_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int32)] * 4
+        self.L.vv_batch_ring_next.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double]
+        self.L.vv_batch_ring_detach.argtypes = [C.c_void_p]
+        self.h, self.owned, self._keep = handle, owned, keep
+        v = [C.c_int32() for _ in range(4)]
+        self.L.vv_batch_ring_info(self.h, *[C.byref(x) for x in v])
+        self.batch_size, self.CN, self.consumers, self.depth = [x.value for x in v]
+
+    @classmethod
+    def attach(cls, shm_name, timeout_s=60.0):
+        L = load_library()
+        L.vv_batch_ring_attach.argtypes = [C.c_char_p, C.c_double, C.POINTER(C.c_void_p)]
+        h = C.c_void_p()
+        rc = L.vv_batch_ring_attach(shm_name.encode(), float(timeout_s), C.byref(h))
+        if rc != 0:
+            raise VVError("vv_batch_ring_attach(%r) failed (%d)" % (shm_name, rc))
+        return cls(h, owned=True)
+
+    def next(self, consumer=0, item_begin=0, item_count=None, want_label=False, timeout_s=0.0, out=None):
+        n = self.batch_size - item_begin if item_count is None else item_count
+        idx = out if out is not None else np.empty((n, self.CN), np.int32)
+        label = np.empty((n,), np.int32) if want_label else None
+        rc = self.L.vv_batch_ring_next(self.h, consumer, item_begin, n, _ptr(idx), _ptr(label), float(timeout_s))
+        if rc != 0:
+            raise VVError("vv_batch_ring_next failed (%d): producer gone or timeout" % rc)
+        return (idx, label) if want_label else idx
+
+    def close(self):
+        if self.owned and self.h:
+            self.L.vv_batch_ring_detach(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
