@@ -238,6 +238,9 @@ int vv_sampler_destroy(vv_sampler* s);
  *   consumers number of readers that must each take (a slice of) a batch before its buffer is reused. */
 int vv_sampler_prefetch_start(vv_sampler* s, int32_t depth, int32_t threads, const char* shm_name, int32_t consumers);
 int vv_sampler_prefetch_stop(vv_sampler* s);
+/* Counters for tests and tuning: which = 0 swap-in walks that had to restart (a swap-in evicted a later shot of the same
+ * video), 1 = the staged fast path is in use (0/1), 2 = producer threads of the running prefetch.  -1 = unknown. */
+int64_t vv_sampler_stat(vv_sampler* s, int32_t which);
 
 /* A reader's view of a sampler's batch ring.  vv_sampler_ring: the producer process's own handle (owned by the
  * sampler).  vv_batch_ring_attach: map the named ring of another process (waits up to timeout_s for it to appear).

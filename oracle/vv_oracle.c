@@ -137,6 +137,10 @@ orc_sampler* orc_sampler_create(const orc_dataset* ds, const orc_sampler_param* 
   if (p->context_type < ORC_CONTEXT_WINDOW || p->context_type > ORC_CONTEXT_PAST_CONTINUOUS_FIXED) return NULL;  /* :760 */
   if (p->num_negative_samples > 0 &&
       (p->negative_swap_percentage < 0 || p->negative_swap_percentage > 99)) return NULL; /* :79-80 */
+  /* :484-502 write same-video negatives at channel C + added without comparing added with num_negative_samples: more of
+   * them than negative slots runs into the next item's channels (undefined behaviour in the reference); refused here
+   * exactly as the product refuses it. */
+  if (p->max_same_video_negs > p->num_negative_samples) return NULL;
   orc_sampler* s = (orc_sampler*)calloc(1, sizeof(*s));
   s->ds = *ds; s->p = *p;
   orc_srand(&s->rng, seed);

@@ -36,6 +36,7 @@
 #include <vector>
 
 #include <fcntl.h>
+#include <immintrin.h>
 #include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -68,7 +69,7 @@ class LibcRand {
     // Substituting the recurrence into itself twice gives x[k] = x[k-9] + x[k-31] + x[k-34] + x[k-37]: no operand
     // closer than 9 positions, so eight values are produced per vector step instead of one per store-to-load round trip.
     n_ = block; swap_ = (uint32_t)swap_pct;
-    h_.assign((size_t)kHist + n_, 0u); f_.assign((size_t)n_ + 1, 0);
+    h_.assign((size_t)kHist + n_ + 8, 0u);
     uint32_t* h = h_.data();
     for (int i = 0; i < 31; ++i) h[kHist - 31 + i] = st[(f + i) % 31];
     for (int i = kHist - 32; i >= 0; --i) h[i] = h[i + 31] - h[i + 28];     // run the recurrence backwards for the extra history
@@ -81,12 +82,10 @@ class LibcRand {
     if (pos_ + k <= n_) return;
     const int m = n_ - pos_;                       // unconsumed values
     memmove(h_.data(), h_.data() + pos_, (size_t)(kHist + m) * sizeof(uint32_t));
-    memmove(f_.data(), f_.data() + pos_, (size_t)m);
     generate(m);
     pos_ = 0;
   }
   const uint32_t* peek() const { return h_.data() + kHist + pos_; }     // raw words: rand() = word >> 1
-  const uint8_t* flags() const { return f_.data() + pos_; }          // (rand() % 100) < negative_swap_percentage
   void skip(int k) { pos_ += k; }
   int32_t next() { ensure(1); return (int32_t)(h_[kHist + pos_++] >> 1); }
   void discard(int64_t k) {
@@ -105,12 +104,8 @@ class LibcRand {
       for (int j = 0; j < 8; ++j) h[i + j] = t[j];
     }
     for (; i < n; ++i) h[i] = h[i - 31] + h[i - 3];
-    uint8_t* __restrict f = f_.data();
-    const uint32_t sw = swap_;
-    for (int k = from; k < n; ++k) f[k] = (uint8_t)(((h[k] >> 1) % 100u) < sw);
   }
   std::vector<uint32_t> h_;
-  std::vector<uint8_t> f_;
   int n_ = 0, pos_ = 0;
   uint32_t swap_ = 0;
 };
@@ -137,6 +132,36 @@ class FastMod {
   std::vector<uint64_t> m_;
 };
 
+// Stage threads next to the thread that starts them: the stages hand cache lines to each other every few items, and
+// the sampler's state was first touched by the caller, so a stage scheduled on another CCD or socket runs several
+// times slower.  Picks the allowed CPUs that follow the caller's in its aligned group of 8 (one CCD on the EPYC hosts
+// of the MI355X boxes), wrapping inside the group; VV_SAMPLER_CPUS="a,b,c,d" overrides, VV_SAMPLER_PIN=0 disables.
+std::vector<int> pick_stage_cpus(int want) {
+  std::vector<int> out;
+  const char* off = getenv("VV_SAMPLER_PIN");
+  if (off && atoi(off) == 0) return out;
+  if (const char* e = getenv("VV_SAMPLER_CPUS")) {
+    for (const char* q = e; *q;) { out.push_back(atoi(q)); while (*q && *q != ',') ++q; if (*q) ++q; }
+    return out;
+  }
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) != 0) return out;
+  const int cur = sched_getcpu();
+  if (cur < 0) return out;
+  const int g0 = cur & ~7;
+  for (int d = 1; d < 8 && (int)out.size() < want; ++d) {
+    const int c = g0 + ((cur - g0 + d) & 7);
+    if (c < CPU_SETSIZE && CPU_ISSET(c, &set)) out.push_back(c);
+  }
+  if ((int)out.size() < want) out.clear();       // not enough neighbours: leave placement to the scheduler
+  return out;
+}
+void pin_self(int cpu) {
+  if (cpu < 0) return;
+  cpu_set_t set; CPU_ZERO(&set); CPU_SET(cpu, &set);
+  (void)sched_setaffinity(0, sizeof(set), &set);
+}
+
 void backoff(unsigned& spins) {
   if (++spins < 64) { __builtin_ia32_pause(); return; }
   if (spins < 256) { sched_yield(); return; }
@@ -154,7 +179,9 @@ struct RingHdr {
   uint64_t magic;
   int32_t depth, batch_size, cn, consumers, has_last, pad_;
   uint64_t batch_bytes;                          // bytes of one batch record
-  alignas(64) std::atomic<int64_t> produced;     // complete batches
+  // items finished by the negative-slot stage and by the frame stage: batch k is complete when both are past its end
+  alignas(64) std::atomic<int64_t> done_negs;
+  alignas(64) std::atomic<int64_t> done_frames;
   alignas(64) std::atomic<int32_t> closed;       // producer gone
   struct alignas(64) Rel { std::atomic<int64_t> v; } released[VV_RING_MAX_CONSUMERS];
 };
@@ -170,6 +197,10 @@ struct vv_batch_ring {
   int32_t* idx_of(int64_t k) const { return (int32_t*)(data + (size_t)(k % hdr->depth) * hdr->batch_bytes); }
   int32_t* label_of(int64_t k) const { return idx_of(k) + (size_t)hdr->batch_size * hdr->cn; }
   int32_t* last_of(int64_t k) const { return label_of(k) + hdr->batch_size; }
+  bool ready(int64_t k) const {
+    const int64_t need = (k + 1) * (int64_t)hdr->batch_size;
+    return hdr->done_negs.load(std::memory_order_acquire) >= need && hdr->done_frames.load(std::memory_order_acquire) >= need;
+  }
   int64_t min_released() const {
     int64_t m = INT64_MAX;
     for (int i = 0; i < hdr->consumers; ++i) m = std::min(m, hdr->released[i].v.load(std::memory_order_acquire));
@@ -205,7 +236,7 @@ static vv_batch_ring* ring_create(const char* shm_name, int depth, int B, int CN
   r->data = (unsigned char*)mem + ring_hdr_bytes();
   r->hdr->depth = depth; r->hdr->batch_size = B; r->hdr->cn = CN; r->hdr->consumers = consumers;
   r->hdr->has_last = has_last ? 1 : 0; r->hdr->batch_bytes = rec_al;
-  r->hdr->produced.store(0); r->hdr->closed.store(0);
+  r->hdr->done_negs.store(0); r->hdr->done_frames.store(0); r->hdr->closed.store(0);
   for (int i = 0; i < VV_RING_MAX_CONSUMERS; ++i) { r->hdr->released[i].v.store(0); r->next_k[i] = 0; }
   std::atomic_thread_fence(std::memory_order_release);
   r->hdr->magic = kRingMagic;
@@ -234,15 +265,15 @@ struct vv_sampler {
   int32_t rmod(int32_t d) { return fm.mod(rng.next(), d); }     // rand() % d
   int32_t cursor = 0;
   std::vector<int32_t> buffer_ids;            // persistent permutation (…data_layer.cpp:81-83)
-  std::vector<int32_t> buf_row;               // slot -> table row (+ one dummy slot at the end, fast path)
+  std::vector<int32_t> buf_row;               // slot -> table row
   std::vector<int32_t> buf_row_negs;          // the negs stage's own view of the buffer (pipelined mode)
   std::vector<uint64_t> buf_key;              // slot -> (video_id, shot_id)
   std::unordered_set<uint64_t> keys;          // negative_keys_set_ (general case)
   // fast path: when every (video_id, shot_id) key names exactly one table row, membership in the key
-  // set is a bitmap over table rows (+ one dummy entry at the end)
+  // set is a bitmap over table rows (padded, so that vector reads past a video's rows stay inside)
   bool dense_keys = false;
   std::vector<uint8_t> row_in_buf;
-  int64_t row_min = 0, row_dummy = 0;
+  int64_t row_min = 0;
   bool contains(int v, int j) const {
     return dense_keys ? row_in_buf[(size_t)(row_base[v] - row_min + j)] != 0 : keys.count(key(video_id[v], shot_id(v, j))) != 0;
   }
@@ -262,7 +293,6 @@ struct vv_sampler {
   }
 
   // ---- staged fast path (dense keys, no same-video negatives)
-  static constexpr int kDummies = 8;
   bool fast = false;
   int CA = 0;                                 // stream values the frames stage looks at (C, 2 or 0 by context type)
   int rec_words = 0;                          // words of one item record: {v, n_events, ev_off_lo, ev_off_hi, vals[CA + Nn]}
@@ -271,6 +301,7 @@ struct vv_sampler {
   void select_item(uint32_t* rec);
   template <bool LOG> void swap_item(uint32_t* rec, int32_t* brow, Event* ev_ring, uint64_t ev_mask, uint64_t* ev_head);
   int cur_v = 0, cur_n = 0, cur_a_total = 0;  // the item between select_item and swap_item
+  int64_t stat_restarts = 0;
   int sample_batch(int32_t* idx, int32_t* last_src, int32_t* label);
   void negs_item(const uint32_t* rec, int32_t* out, const int32_t* brow);
   void frames_item(const uint32_t* rec, int32_t* out, int32_t* label);
@@ -284,14 +315,11 @@ struct vv_sampler {
   std::vector<uint32_t> recs; int64_t ring_items = 0;
   std::vector<Event> events; uint64_t ev_mask = 0;
   alignas(64) std::atomic<int64_t> walked{0};
-  alignas(64) std::atomic<int64_t> negs_done{0};
-  alignas(64) std::atomic<int64_t> frames_done{0};
   alignas(64) std::atomic<uint64_t> ev_tail{0};
   void run_batches();
   void run_walk();
   void run_negs(bool also_frames);
   void run_frames();
-  void run_publisher();
 };
 
 // ---- the three chains of one item -----------------------------------------------------------------------------
@@ -309,7 +337,7 @@ void vv_sampler::select_item(uint32_t* rec) {
   }
   const bool shuffled = (p.context_type == VV_CONTEXT_WINDOW || p.context_type == VV_CONTEXT_PAST) && Nn > 0 && n > C;
   const int a_total = CA + (shuffled ? n - C - 1 : 0);     // :432/:517 random_unique, :482/:566 random_shuffle
-  rng.ensure(a_total + Nn + 2 * n + 2);
+  rng.ensure(a_total + Nn + 2 * n + 16);      // the swap-in reads whole 8-word groups
   rec[0] = (uint32_t)v;
   const uint32_t* hv = rng.peek();
   for (int i = 0; i < CA; ++i) rec[4 + i] = hv[i];
@@ -318,6 +346,35 @@ void vv_sampler::select_item(uint32_t* rec) {
   cur_v = v; cur_n = n; cur_a_total = a_total;
 }
 
+// (rand() % 100 < swap) for 8 consecutive stream words -> 8 mask bits.  rand() = word >> 1 < 2^31;
+// t / 100 = (t * 0x51EB851F) >> 37 exactly for every 32-bit t.
+static inline uint32_t swap_flags8(const uint32_t* w, __m256i vsw) {
+  const __m256i t = _mm256_srli_epi32(_mm256_loadu_si256((const __m256i*)w), 1);
+  const __m256i magic = _mm256_set1_epi32(0x51EB851F);
+  const __m256i pe = _mm256_srli_epi64(_mm256_mul_epu32(t, magic), 37);                           // lanes 0,2,4,6
+  const __m256i po = _mm256_srli_epi64(_mm256_mul_epu32(_mm256_srli_epi64(t, 32), magic), 37);   // lanes 1,3,5,7
+  const __m256i q = _mm256_blend_epi32(pe, _mm256_slli_epi64(po, 32), 0xAA);
+  const __m256i r = _mm256_sub_epi32(t, _mm256_mullo_epi32(q, _mm256_set1_epi32(100)));
+  return (uint32_t)_mm256_movemask_ps(_mm256_castsi256_ps(_mm256_cmpgt_epi32(vsw, r)));
+}
+
+typedef unsigned __int128 u128;
+static inline int select128(u128 x, int k) {        // position of the k-th (1-based) set bit; k <= popcount(x)
+  const uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
+  const int c0 = __builtin_popcountll(lo);
+  if (k <= c0) return (int)_tzcnt_u64(_pdep_u64(1ull << (k - 1), lo));
+  return 64 + (int)_tzcnt_u64(_pdep_u64(1ull << (k - 1 - c0), hi));
+}
+
+// The swap-in of one video (:888-906 with AddToBuffer :24-37).  The reference walks the video's shots in order; a shot
+// whose key is not in the buffer draws rand() % 100 (a "test") and, below negative_swap_percentage, a second value
+// rand() % max_buffer_size for the slot it replaces.  Which stream positions are tests follows from the predicate bits
+// F alone: a position is a test unless its predecessor is a taken test; inside a run of ones the tests alternate from
+// the run's start.  With E / O the runs that start at an even / odd position (carry trick: F & ~(F + even starts)),
+//   TEST = ~(F << 1) | ((E << 1) & EVEN) | ((O << 1) & ODD).
+// The k-th shot that is not in the buffer owns the k-th test; the taken ones are pdep(pext(F, TEST), notin).  Only the
+// taken shots are then visited.  A swap-in that evicts a LATER shot of the same video changes that shot's membership:
+// the walk restarts behind the evicting shot (rare; counted in stat_restarts).
 template <bool LOG>
 __attribute__((noinline)) void vv_sampler::swap_item(uint32_t* rec, int32_t* brow, Event* ev_ring, uint64_t evm, uint64_t* ev_head) {
   const int Nn = p.num_negative_samples, v = cur_v, n = cur_n, a_total = cur_a_total;
@@ -326,27 +383,61 @@ __attribute__((noinline)) void vv_sampler::swap_item(uint32_t* rec, int32_t* bro
   uint32_t nev = 0;
   const uint64_t ev0 = LOG ? *ev_head : 0;
   if (Nn > 0 && p.negative_swap_percentage > 0) {
-    const uint8_t* fl = rng.flags() + a_total + Nn;
-    uint8_t* inb = row_in_buf.data() - row_min;              // indexed by table row; inb[row_dummy] is scratch
+    uint8_t* inb = row_in_buf.data() - row_min;              // indexed by table row
     const int mb = p.max_buffer_size;
     const uint64_t M = fm.magic(mb);
     const int64_t base = row_base[v];
-    for (int j = 0; j < n; ++j) {
-      const int32_t r = (int32_t)(base + j);
-      // kDummies dummy slots / rows used in turn: a not-taken store then never feeds the very next iteration's load
-      // of the same address (a store-to-load dependence the core would have to predict on a coin flip)
-      const int32_t dummy = (int32_t)row_dummy + (j & (kDummies - 1)), mbd = mb + (j & (kDummies - 1));
-      const int notin = inb[r] == 0;                         // :890-893 key not in the buffer
-      const int take = notin & fl[q];                        // :27 rand() % 100 < negative_swap_percentage
-      const int32_t pos = FastMod::modm(M, (int32_t)(hv[q + 1] >> 1), mb);   // :29 rand() % max_buffer_size
-      const int32_t mask = -take;                            // all ones when taken (arithmetic select: the compiler
-      const int32_t pe = mbd ^ ((pos ^ mbd) & mask);         //  must not turn a coin flip back into a branch)
-      const int32_t nr = dummy ^ ((r ^ dummy) & mask);       // not taken: everything lands on the dummy slot / row
-      inb[brow[pe]] = 0;
-      inb[nr] = 1;
-      brow[pe] = nr;
-      if (LOG) { ev_ring[(ev0 + nev) & evm] = Event{pos, r}; nev += (uint32_t)take; }
-      q += notin + take;
+    const __m256i vsw = _mm256_set1_epi32(p.negative_swap_percentage);
+    int j0 = 0;
+    while (j0 < n) {
+      const int cnt = std::min(n - j0, 64);
+      // shots j0 .. j0+cnt-1 that are not in the buffer (the bitmap is padded: reading 64 bytes is always in bounds)
+      const uint8_t* ib = inb + base + j0;
+      const __m256i z = _mm256_setzero_si256();
+      uint64_t notin = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i*)ib), z));
+      if (cnt > 32) notin |= (uint64_t)(uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i*)(ib + 32)), z)) << 32;
+      if (cnt < 64) notin &= (1ull << cnt) - 1;
+      const int m = __builtin_popcountll(notin);
+      if (m == 0) { j0 += cnt; continue; }
+      // predicate bits of stream positions q .. q + 2m - 1
+      const uint32_t* w = hv + q;
+      uint64_t f0 = 0, f1 = 0;
+      const int groups = (2 * m + 7) >> 3;
+      for (int g = 0; g < groups && g < 8; ++g) f0 |= (uint64_t)swap_flags8(w + 8 * g, vsw) << (8 * g);
+      for (int g = 8; g < groups; ++g) f1 |= (uint64_t)swap_flags8(w + 8 * g, vsw) << (8 * (g - 8));
+      const u128 F = ((u128)f1 << 64) | f0;
+      const u128 EVEN = ((u128)0x5555555555555555ull << 64) | 0x5555555555555555ull;
+      const u128 S = F & ~(F << 1);
+      const u128 E = F & ~(F + (S & EVEN));
+      const u128 O = F & ~E;
+      const u128 TEST = ~(F << 1) | ((E << 1) & EVEN) | ((O << 1) & ~EVEN);
+      const int pm = select128(TEST, m);                     // position of the last test of this chunk
+      const u128 upto = pm == 127 ? ~(u128)0 : (((u128)1 << (pm + 1)) - 1);
+      u128 TK = TEST & F & upto;                             // taken tests, in stream order
+      const uint64_t t_lo = (uint64_t)TEST, t_hi = (uint64_t)(TEST >> 64);
+      const int c0 = __builtin_popcountll(t_lo);
+      uint64_t comp = _pext_u64((uint64_t)F, t_lo);          // predicate of the k-th test at bit k
+      if (c0 < 64) comp |= _pext_u64((uint64_t)(F >> 64), t_hi) << c0;
+      uint64_t TS = _pdep_u64(comp, notin);                  // taken shots, in shot order (same count as TK)
+      int q_end = q + pm + 1 + (int)((F >> pm) & 1);
+      bool restarted = false;
+      while (TS) {
+        const int j = j0 + (int)_tzcnt_u64(TS); TS &= TS - 1;
+        const uint64_t k_lo = (uint64_t)TK;
+        const int tp = k_lo ? (int)_tzcnt_u64(k_lo) : 64 + (int)_tzcnt_u64((uint64_t)(TK >> 64));
+        TK &= TK - 1;
+        const int32_t r = (int32_t)(base + j);
+        const int32_t pos = FastMod::modm(M, (int32_t)(w[tp + 1] >> 1), mb);   // :29 rand() % max_buffer_size
+        const int32_t old = brow[pos];
+        inb[old] = 0; inb[r] = 1; brow[pos] = r;
+        if (LOG) { ev_ring[(ev0 + nev) & evm] = Event{pos, r}; ++nev; }
+        if (old > r && old < (int32_t)(base + j0 + cnt)) {
+          // a later shot of this video left the buffer: its membership bit above is stale
+          j0 = j + 1; q = q + tp + 2; restarted = true; ++stat_restarts;
+          break;
+        }
+      }
+      if (!restarted) { q = q_end; j0 += cnt; }
     }
   }
   rng.skip(a_total + Nn + q);
@@ -548,7 +639,8 @@ void vv_sampler::run_batches() {
     unsigned spins = 0;
     while (k - ring->min_released() >= h->depth) { if (stop.load(std::memory_order_relaxed)) return; backoff(spins); }
     sample_batch(ring->idx_of(k), h->has_last ? ring->last_of(k) : nullptr, ring->label_of(k));
-    h->produced.store(k + 1, std::memory_order_release);
+    h->done_negs.store((k + 1) * (int64_t)h->batch_size, std::memory_order_release);
+    h->done_frames.store((k + 1) * (int64_t)h->batch_size, std::memory_order_release);
   }
 }
 
@@ -563,7 +655,7 @@ void vv_sampler::run_walk() {
     // the record slot must have been consumed by both later stages, its batch buffer released by every consumer,
     // and the event ring must have room for one more video
     for (;;) {
-      const int64_t done = std::min(negs_done.load(std::memory_order_acquire), frames_done.load(std::memory_order_acquire));
+      const int64_t done = std::min(ring->hdr->done_negs.load(std::memory_order_acquire), ring->hdr->done_frames.load(std::memory_order_acquire));
       if (it - done < ring_items && ev_head + (uint64_t)max_n <= ev_tail.load(std::memory_order_acquire) + ev_cap) break;
       if (published < it) { walked.store(it, std::memory_order_release); published = it; }
       if (stop.load(std::memory_order_relaxed)) return;
@@ -587,7 +679,7 @@ void vv_sampler::run_negs(bool also_frames) {
     while (it >= avail) {
       avail = walked.load(std::memory_order_acquire);
       if (it < avail) break;
-      if (published < it) { negs_done.store(it, std::memory_order_release); if (also_frames) frames_done.store(it, std::memory_order_release); published = it; }
+      if (published < it) { ring->hdr->done_negs.store(it, std::memory_order_release); if (also_frames) ring->hdr->done_frames.store(it, std::memory_order_release); published = it; }
       if (stop.load(std::memory_order_relaxed)) return;
       backoff(spins);
     }
@@ -606,8 +698,8 @@ void vv_sampler::run_negs(bool also_frames) {
     if (nev) ev_tail.store(e0 + nev, std::memory_order_release);
     ++it;
     if (it - published >= 32 || it % B == 0) {
-      negs_done.store(it, std::memory_order_release);
-      if (also_frames) frames_done.store(it, std::memory_order_release);
+      ring->hdr->done_negs.store(it, std::memory_order_release);
+      if (also_frames) ring->hdr->done_frames.store(it, std::memory_order_release);
       published = it;
     }
   }
@@ -622,7 +714,7 @@ void vv_sampler::run_frames() {
     while (it >= avail) {
       avail = walked.load(std::memory_order_acquire);
       if (it < avail) break;
-      if (published < it) { frames_done.store(it, std::memory_order_release); published = it; }
+      if (published < it) { ring->hdr->done_frames.store(it, std::memory_order_release); published = it; }
       if (stop.load(std::memory_order_relaxed)) return;
       backoff(spins);
     }
@@ -634,19 +726,7 @@ void vv_sampler::run_frames() {
     const uint32_t* rec = recs.data() + (size_t)(it % ring_items) * rec_words;
     frames_item(rec, ring->idx_of(k) + (size_t)(it % B) * CN, ring->label_of(k) + (it % B));
     ++it;
-    if (it - published >= 32 || it % B == 0) { frames_done.store(it, std::memory_order_release); published = it; }
-  }
-}
-
-// turns "both stages are past the end of batch k" into ring->produced (one writer keeps the hand-off simple)
-void vv_sampler::run_publisher() {
-  const int B = p.batch_size;
-  RingHdr* h = ring->hdr;
-  int64_t k = 0;
-  while (!stop.load(std::memory_order_relaxed)) {
-    const int64_t done = std::min(negs_done.load(std::memory_order_acquire), frames_done.load(std::memory_order_acquire));
-    if (done >= (k + 1) * B) { ++k; h->produced.store(k, std::memory_order_release); continue; }
-    unsigned spins = 200; backoff(spins);
+    if (it - published >= 32 || it % B == 0) { ring->hdr->done_frames.store(it, std::memory_order_release); published = it; }
   }
 }
 
@@ -729,9 +809,9 @@ int vv_sampler_create(const vv_sampler_param* p, int32_t n_videos, const int32_t
       std::sort(ranges.begin(), ranges.end());
       for (size_t i = 1; i < ranges.size() && ok; ++i) ok = ranges[i].first >= ranges[i - 1].second;
     }
-    if (ok && lo >= 0 && hi < (1ll << 31) - 1 - vv_sampler::kDummies) {
-      s->dense_keys = true; s->row_min = lo; s->row_dummy = hi;
-      s->row_in_buf.assign((size_t)(hi - lo) + vv_sampler::kDummies, 0);          // + the dummy entries
+    if (ok && lo >= 0 && hi < (1ll << 31) - 1) {
+      s->dense_keys = true; s->row_min = lo;
+      s->row_in_buf.assign((size_t)(hi - lo) + 64, 0);                            // 64 bytes of slack: the swap-in reads whole vectors
     }
   }
   if (p->initial_cursor < 0) { delete s; return VV_ERR_ARG; }
@@ -743,7 +823,7 @@ int vv_sampler_create(const vv_sampler_param* p, int32_t n_videos, const int32_t
   s->rec_words = 4 + s->CA + Nn;
   s->rec1.assign((size_t)s->rec_words, 0u);
   {
-    const int64_t per_item = (int64_t)C + Nn + 3ll * max_n + 8;
+    const int64_t per_item = (int64_t)C + Nn + 3ll * max_n + 32;
     const int64_t block = std::max<int64_t>(16384, 4 * per_item);
     if (block > (1ll << 28)) { delete s; return VV_ERR_ARG; }
     s->rng.init((int)block, Nn > 0 ? p->negative_swap_percentage : 0);
@@ -752,7 +832,7 @@ int vv_sampler_create(const vv_sampler_param* p, int32_t n_videos, const int32_t
   const int mb = Nn > 0 ? p->max_buffer_size : 0;
   s->buffer_ids.resize(mb);
   for (int i = 0; i < mb; ++i) s->buffer_ids[i] = i;
-  s->buf_row.reserve((size_t)mb + vv_sampler::kDummies); s->buf_key.reserve(mb);
+  s->buf_row.reserve(mb); s->buf_key.reserve(mb);
   // fill the negative buffer: one random shot of each visited record until full (:240-344)
   if (mb > 0) {
     const int64_t tries = (int64_t)p->max_tries_for_negs * mb;
@@ -768,7 +848,6 @@ int vv_sampler_create(const vv_sampler_param* p, int32_t n_videos, const int32_t
     }
     if ((int)s->buf_row.size() != mb) { delete s; return VV_ERR_ARG; }           // :344
   }
-  for (int k = 0; k < vv_sampler::kDummies; ++k) s->buf_row.push_back((int32_t)s->row_dummy + k);   // dummy slots of the branch-free swap-in
   *out = s;
   return VV_OK;
 }
@@ -781,7 +860,7 @@ static int pop_batch(vv_batch_ring* r, int consumer, int32_t item_begin, int32_t
   const int64_t k = r->next_k[consumer];
   unsigned spins = 0;
   const auto t0 = std::chrono::steady_clock::now();
-  while (h->produced.load(std::memory_order_acquire) <= k) {
+  while (!r->ready(k)) {
     if (h->closed.load(std::memory_order_acquire)) return VV_ERR_STATE;
     backoff(spins);
     if (timeout_s > 0 && (spins & 1023) == 0 &&
@@ -810,7 +889,9 @@ int vv_sampler_prefetch_start(vv_sampler* s, int32_t depth, int32_t threads, con
   s->stop.store(0);
   if (!s->fast || threads == 1) {
     s->n_stage_threads = 1;
-    s->threads.emplace_back([s]() { s->run_batches(); });
+    const std::vector<int> cpus = pick_stage_cpus(1);
+    const int c0 = cpus.empty() ? -1 : cpus[0];
+    s->threads.emplace_back([s, c0]() { pin_self(c0); s->run_batches(); });
     return VV_OK;
   }
   // staged pipeline
@@ -820,13 +901,15 @@ int vv_sampler_prefetch_start(vv_sampler* s, int32_t depth, int32_t threads, con
   uint64_t cap = 1; while (cap < (uint64_t)s->ring_items * 32 + 4ull * s->max_n) cap <<= 1;
   s->events.assign(cap, vv_sampler::Event{0, 0}); s->ev_mask = cap - 1;
   s->buf_row_negs = s->buf_row;
-  s->walked.store(0); s->negs_done.store(0); s->frames_done.store(0); s->ev_tail.store(0);
+  s->walked.store(0); s->ev_tail.store(0);
   const bool three = threads >= 3;
   s->n_stage_threads = three ? 3 : 2;
-  s->threads.emplace_back([s]() { s->run_walk(); });
-  s->threads.emplace_back([s, three]() { s->run_negs(!three); });
-  if (three) s->threads.emplace_back([s]() { s->run_frames(); });
-  s->threads.emplace_back([s]() { s->run_publisher(); });
+  const std::vector<int> cpus = pick_stage_cpus(s->n_stage_threads);
+  auto cpu = [&](int i) { return i < (int)cpus.size() ? cpus[i] : -1; };
+  const int ca = cpu(0), cb = cpu(1), cc = cpu(2);
+  s->threads.emplace_back([s, ca]() { pin_self(ca); s->run_walk(); });
+  s->threads.emplace_back([s, three, cb]() { pin_self(cb); s->run_negs(!three); });
+  if (three) s->threads.emplace_back([s, cc]() { pin_self(cc); s->run_frames(); });
   return VV_OK;
 }
 
@@ -838,6 +921,7 @@ int vv_sampler_prefetch_stop(vv_sampler* s) {
   s->threads.clear();
   ring_free(s->ring);
   s->ring = nullptr;
+  s->n_stage_threads = 0;
   return VV_OK;
 }
 
@@ -845,6 +929,16 @@ int vv_sampler_ring(vv_sampler* s, vv_batch_ring** out) {
   if (!s || !out || !s->ring) return VV_ERR_ARG;
   *out = s->ring;
   return VV_OK;
+}
+
+int64_t vv_sampler_stat(vv_sampler* s, int32_t which) {
+  if (!s) return -1;
+  switch (which) {
+    case 0: return s->stat_restarts;             // swap-in walks restarted because a later shot of the video was evicted
+    case 1: return s->fast ? 1 : 0;              // staged fast path in use
+    case 2: return s->n_stage_threads;           // producer threads of the running prefetch (0 = none)
+    default: return -1;
+  }
 }
 
 int vv_sampler_destroy(vv_sampler* s) {

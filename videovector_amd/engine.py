@@ -351,6 +351,11 @@ class Sampler:
         if rc != 0:
             raise VVError("vv_sampler_prefetch_start failed (%d)" % rc)
 
+    def stat(self, which):
+        self.L.vv_sampler_stat.argtypes = [C.c_void_p, C.c_int32]
+        self.L.vv_sampler_stat.restype = C.c_int64
+        return self.L.vv_sampler_stat(self.h, which)
+
     def prefetch_stop(self):
         self.L.vv_sampler_prefetch_stop(self.h)
 
