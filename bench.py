@@ -4,16 +4,26 @@
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Workload = BASELINE.json configs[1] per GPU: synthetic fc7 features 4096-d -> 512-d embedding, batch
-1024 per GPU (global batch N*1024, weak scaling), context window +-2 (context_size 5), 50 negatives.
-A step = one full training iteration on one batch: (row de-duplication,) gather-GEMM forward, fused
-score/loss forward+backward, (per-row gradient sums,) gather-GEMM^T weight gradient, (RCCL all-reduce
-for N>1), fused SGD update.  --dedup on (default) projects every distinct table row of the batch once
-(allowed with the factor disclosed); the JSON line then also carries the same K steps
-timed with --dedup off ("dense_execution": every sampled row projected separately, as the reference
-does), and the roofline fraction is computed from the FLOPs the kernel really executed.
-Triplet index batches are sampled beforehand by the product sampler and are resident in HBM when
-the timed region starts (the sampler is integer host work that does not depend on the model).
+Workload = BASELINE.json configs[1] per GPU: synthetic fc7 features 4096-d -> 512-d embedding, batch 1024 per GPU
+(global batch N*1024, weak scaling), context window +-2 (context_size 5), 50 negatives.
+
+A step = one full training iteration on one batch: (row de-duplication,) gather-GEMM forward, fused score/loss
+forward+backward, (per-row gradient sums,) gather-GEMM^T weight gradient, (all-reduce of [dW|db] for N > 1), fused SGD
+update.  What is timed, and reported as what:
+
+  value            END TO END, sustainable: the triplet sampler (the reference's sequential libc-rand() sampler,
+                   bit-exact) runs on prefetch threads INSIDE the timed region, as BasePrefetchingDataLayer's thread does
+                   in the reference (base_data_layer.cpp:69-95); every step takes its batch out of the prefetch ring,
+                   sends the 225 KB of indices to the GPU (pinned staging, async H2D) and runs the iteration.  For N > 1
+                   ONE sampler per node (rank 0) draws the global batch and publishes it in POSIX shared memory; every
+                   rank takes its 1024 items.
+  gpu_path_only    the same K steps with the index batches already resident in HBM (sampler excluded) -- the kernel path
+                   alone, what round 1 reported as `value`.
+  dense_execution  gpu_path_only with row de-duplication off: every sampled row projected separately, as the reference does.
+  bf16_execution   end to end with bf16 MFMA operands (the north star's operand type; the default is f16: same MFMA rate,
+                   and only f16 meets the 1e-3 embedding tolerance).
+  step_ms_stats    min / median / p95 / max of the individual step times of a further run of the K steps with one HIP event
+                   per step.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -34,13 +44,13 @@ MFMA_PEAK_TFLOPS = 2500.0     # dense bf16/f16 MFMA peak, /opt/skills/guides/MI3
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(ds, idx, W, b, items=512, iters=5, threads=0):
-    """The oracle (CPU restatement of the reference path, layer by layer with an sgemm for fc7)
-    timed on a bounded sample of the same workload: `items` batch items of the first batch.
-    threads = 0: all host threads OpenMP offers; 1: the single-thread figure SURVEY 8(d) also asks for.
-    The reference links an external BLAS for its sgemm (Makefile.config:34): one warm-up iteration is run with the
-    machine's BLAS (MKL ships in the image) and one with the oracle's own OpenMP kernel, the faster of the two is
-    timed and named in the result (MKL is not always the faster one on an EPYC host)."""
+def cpu_baseline(ds, idx, W, b, items, iters, threads=0):
+    """The oracle (CPU restatement of the reference path, layer by layer with an sgemm for fc7) timed like `caffe time`
+    (tools/caffe.cpp:193-266): whole ForwardBackward + ComputeUpdateValue + Update iterations on `items` batch items.
+    threads = 0: all host threads OpenMP offers; 1: the single-thread figure SURVEY 8(d) also asks for.  The reference
+    links an external BLAS for its sgemm (Makefile.config:34): when the machine has one (MKL ships in the image) it is
+    timed against the oracle's own blocked sgemm on one warm-up iteration each and the faster is used and named.  The
+    GFLOP/s of the two fc7 GEMMs alone is reported next to the whole-iteration rate."""
     from oracle import oracle as orc
     orc.set_threads(threads)
     sh = idx[:items]
@@ -65,34 +75,46 @@ def cpu_baseline(ds, idx, W, b, items=512, iters=5, threads=0):
     if not use_ext:
         orc.set_blas(None)
     ts = [one() for _ in range(iters)]
-    orc.set_blas(None)
     t = float(np.mean(ts))
-    return {"value": items * NN / t, "unit": "triplets/s", "cores": orc.get_threads(), "kind": "port",
-            "blas": ("cblas_sgemm of " + os.path.basename(blas)) if use_ext else "the oracle's own OpenMP sgemm",
-            "sample": "%d of %d batch items (%d rows) of the same 4096->%d, C5, Nn%d step, "
-                      "%d timed iterations after warm-up, %.2f s each" % (items, B_PER_GPU, items * (C + NN), D, NN, iters, t)}
+    gemm = None
+    if hasattr(orc, "gemm_gflops"):
+        gemm = orc.gemm_gflops(items * (C + NN), D, F)
+    orc.set_blas(None)
+    out = {"value": items * NN / t, "unit": "triplets/s", "cores": orc.get_threads(), "kind": "port",
+           "blas": ("cblas_sgemm of " + os.path.basename(blas)) if use_ext else "the oracle's own blocked OpenMP sgemm",
+           "sample": "%d of %d batch items (%d rows) of the same 4096->%d, C5, Nn%d step, "
+                     "%d timed iterations after warm-up, %.2f s each" % (items, B_PER_GPU, items * (C + NN), D, NN, iters, t),
+           "iteration_gflops": 4.0 * items * (C + NN) * F * D / t / 1e9}
+    if gemm is not None:
+        out["fc7_gemm_gflops"] = gemm
+    return out
 
 
 def main():
     t_process_start = time.perf_counter()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--prec", default=os.environ.get("VV_PREC", "f16"), choices=["f16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dedup", default="on", choices=["on", "off"],
                     help="row de-duplication of the batch (results identical up to the rounding of reassociated "
                          "sums); 'off' executes the reference-equivalent dense work")
-    ap.add_argument("--no-dense-leg", action="store_true", help="skip the extra dense_execution timing")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="only the end-to-end leg (skips gpu_path_only, dense_execution, bf16_execution, step_ms_stats)")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg5"],
                     help="cfg2 (default, the metric's configuration): batch 1024/GPU, 50 negatives, 4096->512.  cfg5: the "
                          "per-GPU work of BASELINE configs[4] (batch 4096, 200 negatives, 4096->1024, quoted for bf16) -- "
                          "informational, not the contract's bench line")
-    ap.add_argument("--allreduce", default="auto", choices=["auto", "overlap", "sync"],
-                    help="N>1: 'overlap' (default) runs the RCCL all-reduce of iteration t's gradients during "
-                         "iteration t+1's forward/backward (one-update delayed gradients, the overlap the "
-                         "north-star describes); 'sync' is exact synchronous SGD with the all-reduce exposed")
+    ap.add_argument("--allreduce", default="auto", choices=["auto", "sync", "overlap", "stale"],
+                    help="N>1.  'sync' (default): exact synchronous SGD, the all-reduce of [dW|db] between backward and "
+                         "update.  'overlap': the same exact update, the gradient all-reduced in F-chunks on a second "
+                         "stream while the weight-gradient kernel is still producing the next chunk.  'stale': the "
+                         "all-reduce of iteration t overlaps iteration t+1 and gradients are applied one update late "
+                         "(NOT the reference's algorithm; opt-in, labelled)")
+    ap.add_argument("--sampler-threads", type=int, default=int(os.environ.get("VV_SAMPLER_THREADS", "3")))
+    ap.add_argument("--prefetch-depth", type=int, default=8)
     args = ap.parse_args()
 
     global B_PER_GPU, NN, D
@@ -128,108 +150,190 @@ def main():
     K, Wm = args.steps, args.warmup
     Bg = B_PER_GPU * world
     ds = SyntheticVideos(seed=SEED, n_videos=N_VIDEOS)
-    # one logical sampler for the global batch on every rank; each rank keeps its slice
-    smp = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, batch_size=Bg, context_size=C,
-                     num_negative_samples=NN, max_buffer_size=5000, negative_swap_percentage=50)
+    skw = dict(batch_size=Bg, context_size=C, num_negative_samples=NN, max_buffer_size=5000, negative_swap_percentage=50)
+
+    # ---- the node's ONE sampler: rank 0 draws global batches ahead on prefetch threads and publishes them through a
+    # ring (POSIX shared memory when there are other ranks); every rank takes items [rank*B, (rank+1)*B) of each batch.
+    ring_name = "vv_bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", str(os.getppid())))
+    sampler = None
+    if rank == 0:
+        sampler = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, **skw)
+        sampler.prefetch_start(depth=args.prefetch_depth, threads=args.sampler_threads,
+                               shm_name=ring_name if world > 1 else None, consumers=world)
+        ring = sampler.ring()
+    if dist:
+        dist.barrier()
+    if rank != 0:
+        ring = vv.BatchRing.attach(ring_name, timeout_s=120.0)
+
+    # batches for the resident-indices legs come from a second, identical sampler (rank-local slice of the global batch)
+    n_res = 0 if args.no_extra_legs else Wm + K
+    batches = None
+    if n_res:
+        smp2 = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, **skw)
+        batches = np.stack([smp2.next()[rank * B_PER_GPU:(rank + 1) * B_PER_GPU] for _ in range(n_res)])
+        smp2.close()
+    # raw rate of the sampler by itself (calling thread, no pipeline), for the record
+    smp3 = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, **skw)
+    smp3.next()
     t0 = time.perf_counter()
-    batches = np.stack([smp.next()[rank * B_PER_GPU:(rank + 1) * B_PER_GPU] for _ in range(Wm + K)])
-    sampler_s = (time.perf_counter() - t0) / (Wm + K)
-    idx_dev = torch.from_numpy(batches).to(dev)
+    n3 = max(3, 24 // world)
+    for _ in range(n3):
+        smp3.next()
+    sampler_serial_ms = (time.perf_counter() - t0) / n3 * 1e3
+    smp3.close()
 
     W0, b0 = init_weights(SEED, D, F)
-    eng = vv.Engine(local_rank, args.prec)
-    # Everything (kernels of the context and the collective) is issued under ONE explicit, non-default
-    # torch stream: torch orders the RCCL all-reduce after the kernels already queued on the current
-    # stream and the following kernels after the all-reduce.  (The default stream's raw handle is 0,
-    # which vv_set_stream reads as "the context's own stream".)
+    # Everything (kernels of the context and the collective) is issued under ONE explicit, non-default torch stream:
+    # torch orders the RCCL all-reduce after the kernels already queued on the current stream and the following kernels
+    # after the all-reduce.  (The default stream's raw handle is 0, which vv_set_stream reads as "the context's own".)
     work_stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(work_stream)
     assert work_stream.cuda_stream != 0
-    eng.set_stream(work_stream.cuda_stream)
-    eng.table_synth(ds.seed, ds.n_rows, F)
-    eng.params_set(W0, b0)
-    eng.set_dedup(args.dedup == "on")
-    cfg = vv.StepConfig(B_PER_GPU, C, NN, global_count=Bg * NN)
     stride = B_PER_GPU * (C + NN) * 4
-    mode = args.allreduce if args.allreduce != "auto" else ("overlap" if world > 1 else "none")
-    grads, trainer = None, None
-    if mode == "overlap":
-        from videovector_amd.dist import GpuBackend, PipelinedTrainer
-        be = GpuBackend(eng, cfg, stream=work_stream)
-        trainer = PipelinedTrainer(be, None, NN, dist=dist, rank=rank, world=world)
-    elif world > 1:
-        grads = torch.zeros(D * F + D, dtype=torch.float32, device=dev)
-        eng.grads_bind(grads.data_ptr())
+    idx_dev = torch.from_numpy(batches).to(dev) if batches is not None else None
+    mode = args.allreduce if args.allreduce != "auto" else ("sync" if world > 1 else "none")
+    if world == 1 and mode in ("sync", "overlap"):
+        mode = "none"
 
     def lr_at(it):     # shipped solver: inv policy, base 1e-3, gamma 1e-3, power .75
         return 1e-3 * (1.0 + 1e-3 * it) ** -0.75
 
-    def step(i):
-        cfg.set("lr", lr_at(i))
-        ptr = idx_dev.data_ptr() + i * stride
-        if trainer is not None:
-            trainer.step(lr_at(i), global_batch=Bg, idx_dev_ptr=ptr)
-        elif world > 1:
-            eng.forward_backward(cfg, idx_dev_ptr=ptr)
-            dist.all_reduce(grads)
-            eng.apply_update(cfg)
-        else:
-            eng.step(cfg, idx_dev_ptr=ptr)
-
     KERNELS = ("dedup", "fwd_gemm", "score_loss", "segsum", "wgrad_gemm", "reduce", "sgd")
-    # Kernel durations come from HIP events stamped by the kernels' own dispatch packets inside the timed region.
-    # A timed dispatch cannot be pipelined behind its predecessor (~5 us each, 35 us per step if every kernel of
-    # every step carried events), so every prof_every-th step is instrumented: about ten samples per kernel.
-    prof_every = int(os.environ.get("VV_BENCH_PROF_EVERY", "0")) or max(1, K // 10)
 
-    def timed_run():
-        """W warm-up steps, then exactly K steps between barrier + synchronize; max over ranks."""
-        for i in range(Wm):
-            step(i)
-        if trainer is not None:
-            trainer.flush()
-        if dist: dist.barrier()
-        torch.cuda.synchronize()
-        eng.profile_enable(prof_every)
-        t0 = time.perf_counter()
-        for i in range(Wm, Wm + K):
-            step(i)
-        if trainer is not None:
-            trainer.flush()
-        torch.cuda.synchronize()
-        if dist: dist.barrier()
-        el = time.perf_counter() - t0
-        if dist:
-            t = torch.tensor([el], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        kern = {k: eng.profile_get(k) for k in KERNELS}
-        eng.profile_enable(False)
-        return el, kern
+    class Run:
+        """One engine + its step function; source = 'ring' (end to end) or 'resident'."""
 
+        def __init__(self, prec, dedup):
+            self.prec = prec
+            self.eng = vv.Engine(local_rank, prec)
+            self.eng.set_stream(work_stream.cuda_stream)
+            self.eng.table_synth(ds.seed, ds.n_rows, F)
+            self.eng.params_set(W0, b0)
+            self.eng.set_dedup(dedup)
+            self.cfg = vv.StepConfig(B_PER_GPU, C, NN, global_count=Bg * NN)
+            self.grads = None
+            self.trainer = None
+            if mode == "stale":
+                from videovector_amd.dist import GpuBackend, PipelinedTrainer
+                be = GpuBackend(self.eng, self.cfg, stream=work_stream)
+                self.trainer = PipelinedTrainer(be, None, NN, dist=dist, rank=rank, world=world)
+            elif world > 1:
+                self.grads = torch.zeros(D * F + D, dtype=torch.float32, device=dev)
+                self.eng.grads_bind(self.grads.data_ptr())
+            self.it = 0
+
+        def reset(self, dedup):
+            self.eng.set_dedup(dedup)
+            self.eng.params_set(W0, b0)
+            self.it = 0
+
+        def step(self, source, i):
+            eng, cfg = self.eng, self.cfg
+            cfg.set("lr", lr_at(self.it))
+            if self.trainer is not None:
+                assert source == "resident", "--allreduce stale runs on resident indices"
+                self.trainer.step(lr_at(self.it), global_batch=Bg, idx_dev_ptr=idx_dev.data_ptr() + i * stride)
+            else:
+                if source == "ring":
+                    th0 = time.perf_counter()
+                    eng.forward_backward_ring(cfg, ring, consumer=rank, item_begin=rank * B_PER_GPU)
+                    if diag: host_ms.append((time.perf_counter() - th0) * 1e3)
+                else:
+                    eng.forward_backward(cfg, idx_dev_ptr=idx_dev.data_ptr() + i * stride)
+                if world > 1:
+                    dist.all_reduce(self.grads)
+                eng.apply_update(cfg)
+            self.it += 1
+
+        def timed(self, source, per_step_events=False, profile=True):
+            """W warm-up steps, then exactly K steps between barrier + synchronize; max over ranks."""
+            eng = self.eng
+            for i in range(Wm):
+                self.step(source, i)
+            if self.trainer is not None:
+                self.trainer.flush()
+            if dist: dist.barrier()
+            torch.cuda.synchronize()
+            # Kernel durations: HIP events stamped by the kernels' own dispatch packets inside the timed region, on every
+            # prof_every-th step (a timed dispatch cannot be pipelined behind its predecessor, ~5 us each).
+            prof_every = int(os.environ.get("VV_BENCH_PROF_EVERY", "0")) or max(4, K // 8)
+            if profile:
+                eng.profile_enable(prof_every)
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)] if per_step_events else None
+            t0 = time.perf_counter()
+            if evs: evs[0].record(work_stream)
+            for i in range(Wm, Wm + K):
+                self.step(source, i)
+                if evs: evs[i - Wm + 1].record(work_stream)
+            if self.trainer is not None:
+                self.trainer.flush()
+            torch.cuda.synchronize()
+            if dist: dist.barrier()
+            el = time.perf_counter() - t0
+            if dist:
+                t = torch.tensor([el], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            kern = {k: eng.profile_get(k) for k in KERNELS} if profile else {}
+            if profile:
+                eng.profile_enable(False)
+            steps_ms = [evs[j].elapsed_time(evs[j + 1]) for j in range(K)] if evs else None
+            return el, kern, steps_ms
+
+    def stats(ms):
+        a = np.sort(np.asarray(ms))
+        return {"min": float(a[0]), "median": float(np.median(a)), "p95": float(a[int(0.95 * (len(a) - 1))]), "max": float(a[-1]),
+                "mean": float(a.mean()), "n": len(a)}
+
+    diag = os.environ.get("VV_BENCH_DIAG") == "1"
+    host_ms = []
     t_setup_done = time.perf_counter()
-    elapsed, kern = timed_run()
+    main_source = "resident" if mode == "stale" else "ring"
+    run = Run(args.prec, args.dedup == "on")
+    elapsed, kern, diag_ms = run.timed(main_source, per_step_events=diag)
+    if diag and rank == 0:
+        print("main-leg step ms: " + " ".join("%.3f" % x for x in diag_ms), file=sys.stderr)
+        print("host ms in forward_backward_ring (warm-up included): " + " ".join("%.3f" % x for x in host_ms), file=sys.stderr)
     t_main_done = time.perf_counter()
-    loss, viol = eng.loss()
-    dense = None
-    if args.dedup == "on" and not args.no_dense_leg:
-        # the same K batches again with every sampled row projected separately (reference-equivalent execution)
-        eng.set_dedup(False)
-        eng.params_set(W0, b0)
-        d_el, d_kern = timed_run()
-        dense = {"value": Bg * NN * K / d_el, "unit": "triplets/s", "ms_per_step": d_el / K * 1e3,
-                 "kernels_ms": {k: round(v[0], 4) for k, v in d_kern.items() if v[1] > 0}}
-        eng.set_dedup(True)
+    loss, viol = run.eng.loss()
+    extra = {}
+    if not args.no_extra_legs:
+        run.reset(args.dedup == "on")
+        g_el, g_kern, _ = run.timed("resident", profile=False)
+        extra["gpu_path_only"] = {"value": Bg * NN * K / g_el, "unit": "triplets/s", "ms_per_step": g_el / K * 1e3,
+                                  "note": "index batches resident in HBM before the timed region: sampler, ring and H2D excluded"}
+        run.reset(args.dedup == "on")
+        _, _, steps_ms = run.timed(main_source, per_step_events=True, profile=False)
+        extra["step_ms_stats"] = dict(stats(steps_ms), note="end-to-end steps, one HIP event per step (a separate run of the same K steps)")
+        if args.dedup == "on":
+            run.reset(False)
+            d_el, d_kern, _ = run.timed("resident")
+            extra["dense_execution"] = {"value": Bg * NN * K / d_el, "unit": "triplets/s", "ms_per_step": d_el / K * 1e3,
+                                        "source": "resident indices",
+                                        "kernels_ms": {k: round(v[0], 4) for k, v in d_kern.items() if v[1] > 0}}
+        run.eng.close()
+        other = "bf16" if args.prec == "f16" else "f16"
+        if mode != "stale":
+            run2 = Run(other, args.dedup == "on")
+            o_el, o_kern, _ = run2.timed("ring")
+            extra[other + "_execution"] = {"value": Bg * NN * K / o_el, "unit": "triplets/s", "ms_per_step": o_el / K * 1e3,
+                                           "source": "end to end (sampler prefetch + H2D inside the timed region)",
+                                           "kernels_ms": {k: round(v[0], 4) for k, v in o_kern.items() if v[1] > 0}}
+            run2.eng.close()
+    t_legs_done = time.perf_counter()
 
-    t_dense_done = time.perf_counter()
     if rank == 0:
         ms = elapsed / K * 1e3
         value = Bg * NN * K / elapsed
         R = B_PER_GPU * (C + NN)
         dense_flop = 2.0 * R * F * D         # per launch of either GEMM kernel, every sampled row (SURVEY 8d figure)
-        # rows the GEMMs really processed: distinct table rows per timed batch of this rank (host recount)
-        if args.dedup == "on":
+        # rows the GEMMs really processed: distinct table rows per timed batch of this rank (host recount on the identical
+        # stream of the second sampler; the ring's batches are the same batches)
+        if args.dedup == "on" and batches is not None:
             U = float(np.mean([len(np.unique(batches[i])) for i in range(Wm, Wm + K)]))
+        elif args.dedup == "on":
+            U = float(run.eng.dedup_stats()[1])
         else:
             U = float(R)
         gemm_flop = 2.0 * U * F * D
@@ -250,14 +354,18 @@ def main():
                     "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes}
         roof["avg_launch_ms"] = dom_ms
         roof["dedup_factor"] = R / U
-        pmc = None
+        pmc, pmc_src = None, None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_path):
             try:
-                pmc = json.load(open(pmc_path)).get("dedup_" + args.dedup, {}).get(dom, {}).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc_path))
+                pmc = pj.get("dedup_" + args.dedup, {}).get(dom, {}).get("hbm_bytes_per_launch")
+                pmc_src = pj.get("source", "profiles/pmc_latest.json")
             except Exception:
                 pmc = None
         roof["traffic"] = pmc
+        roof["traffic_note"] = ("HBM bytes per launch from rocprofv3 PMC passes recorded in %s -- a committed profile of this "
+                                "kernel, NOT measured by this run" % pmc_src) if pmc is not None else None
         out = {
             "metric": "triplets/sec (whole node), 4096->%d-d embed, batch %d/GPU, C5, Nn%d" % (D, B_PER_GPU, NN),
             "value": value, "unit": "triplets/s", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -265,19 +373,25 @@ def main():
             "dtype": args.prec,
             "dtype_note": args.prec + " MFMA operands with fp32 accumulation; fp32 master weights, activations, loss and update",
             "data": "synthetic",
+            "value_scope": ("end to end: bit-exact reference sampler on %d prefetch thread(s) inside the timed region, "
+                            "225 KB index batch per step through pinned staging + async H2D, full training iteration"
+                            % args.sampler_threads) if main_source == "ring" else "resident indices (stale-gradient schedule)",
             "config": {"workload": "BASELINE configs[%d] per GPU: synthetic fc7 4096-d -> %d-d, batch "
                                    "%d/GPU (global %d), context_size 5 (window +-2), %d negatives, "
                                    "max_buffer 5000, swap 50%%, margin 2 L2, SGD momentum .9 wd 5e-4 inv lr"
                                    % (1 if args.workload == "cfg2" else 4, D, B_PER_GPU, Bg, NN),
                        "global_batch": Bg, "triplets_per_step": Bg * NN,
                        "parallelism": "dp%d" % world, "items_per_s": value / NN, "dedup": args.dedup,
-                       "allreduce": {"none": "none (1 GPU)", "sync": "synchronous, exposed",
-                                     "overlap": "overlapped with the next iteration's forward/backward "
-                                                "(one-update delayed gradients)"}[mode]},
+                       "sampler": "one per node (rank 0), %d stage thread(s), prefetch depth %d%s"
+                                  % (args.sampler_threads, args.prefetch_depth, ", POSIX shared-memory ring" if world > 1 else ""),
+                       "allreduce": {"none": "none (1 GPU)", "sync": "synchronous (exact SGD), exposed",
+                                     "overlap": "exact SGD, chunked all-reduce overlapped with the weight-gradient kernel",
+                                     "stale": "overlapped with the next iteration's forward/backward "
+                                              "(one-update delayed gradients: NOT the reference's algorithm)"}[mode]},
             "roofline": roof,
             "kernels_ms": {k: round(v, 4) for k, v in live.items()},
             "kernel_timing": "HIP events on the kernels' dispatch packets, every %d-th of the %d timed steps (%d samples per kernel)"
-                             % (prof_every, K, max(v[1] for v in kern.values())),
+                             % (max(4, K // 8), K, max([v[1] for v in kern.values()] or [0])),
             "dedup": {"mode": args.dedup, "rows_per_step": R, "distinct_rows_per_step": U, "factor": R / U,
                       "note": "the reference sampler draws all negatives of a batch from one shared 5000-frame "
                               "buffer, so sampled rows repeat; each distinct row is projected once and its "
@@ -285,21 +399,30 @@ def main():
             "step_tflops_executed": 2 * gemm_flop / (ms * 1e-3) / 1e12,
             "step_tflops_dense_equivalent": 2 * dense_flop / (ms * 1e-3) / 1e12,
             "gather_GBs": 2.0 * R * F * 2 / (ms * 1e-3) / 1e9,
-            "sampler_ms_per_global_batch": sampler_s * 1e3,
+            "sampler_ms_per_global_batch_one_thread": sampler_serial_ms,
             "final_loss": loss, "final_violations": viol,
         }
-        if dense is not None:
-            out["dense_execution"] = dense
+        out.update(extra)
         # where the wall-clock time of this process goes besides the K timed steps (for whoever times the whole command)
         out["wall_s"] = {"imports_setup_presampling_table": round(t_setup_done - t_process_start, 3),
                          "warmup_plus_timed_steps": round(t_main_done - t_setup_done, 3),
-                         "dense_execution_leg": round(t_dense_done - t_main_done, 3)}
+                         "extra_legs": round(t_legs_done - t_main_done, 3)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ds, batches[0], W0, b0, items=512 if args.workload == "cfg2" else 128, iters=5)
-            out["cpu_baseline_1_thread"] = cpu_baseline(ds, batches[0], W0, b0, items=32 if args.workload == "cfg2" else 8,
+            b0_idx = batches[0] if batches is not None else None
+            if b0_idx is None:
+                s4 = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, **skw); b0_idx = s4.next(); s4.close()
+            full = B_PER_GPU if args.workload == "cfg2" else 256
+            out["cpu_baseline"] = cpu_baseline(ds, b0_idx, W0, b0, items=full, iters=3)
+            out["cpu_baseline_1_thread"] = cpu_baseline(ds, b0_idx, W0, b0, items=32 if args.workload == "cfg2" else 8,
                                                          iters=2, threads=1)
-            out["wall_s"]["cpu_baselines"] = round(time.perf_counter() - t_dense_done, 3)
+            out["wall_s"]["cpu_baselines"] = round(time.perf_counter() - t_legs_done, 3)
         print(json.dumps(out))
+    if dist:
+        dist.barrier()
+    if rank != 0:
+        ring.close()
+    if sampler is not None:
+        sampler.close()
     if dist:
         dist.destroy_process_group()
 

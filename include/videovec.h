@@ -254,6 +254,12 @@ int vv_batch_ring_info(vv_batch_ring* r, int32_t* batch_size, int32_t* slots_per
 int vv_batch_ring_next(vv_batch_ring* r, int32_t consumer, int32_t item_begin, int32_t item_count, int32_t* idx,
                        int32_t* label, double timeout_s);
 int vv_batch_ring_detach(vv_batch_ring* r);
+/* BasePrefetchingDataLayer::Forward_gpu (src/caffe/layers/base_data_layer.cu:7-21: join the prefetch thread, copy the
+ * batch to the device) + Net::ForwardBackward: take this consumer's next batch out of the ring -- items
+ * [item_begin, item_begin + cfg->B) of it -- send the indices to the device through a pinned staging buffer with an
+ * asynchronous copy on the context's stream, and queue vv_forward_backward on them.  label_out: host int32 [B] or NULL. */
+int vv_forward_backward_ring(vv_ctx* ctx, const vv_step_cfg* cfg, vv_batch_ring* ring, int32_t consumer,
+                             int32_t item_begin, int32_t* label_out, double timeout_s);
 
 /* Timing hook for the benchmark: average device time in ms of one named kernel ("fwd_gemm",
  * "score_loss", "wgrad_gemm", "reduce", "sgd") over the launches since the last reset, measured

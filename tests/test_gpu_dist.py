@@ -1,7 +1,7 @@
 """bench.py's N > 1 code path on ONE GPU: two ranks share device 0 and reduce through gloo (RCCL refuses two ranks
 on one device).  Exercises what the driver's multi-GPU runs execute -- rendezvous, the shared sampler sliced per
-rank, the global loss count, both all-reduce schedules, max-over-ranks timing, the rank-0 JSON line -- except
-RCCL itself."""
+rank out of rank 0's shared-memory prefetch ring, the global loss count, the all-reduce schedules, max-over-ranks
+timing, the rank-0 JSON line -- except RCCL itself."""
 import json
 import os
 import subprocess
@@ -13,14 +13,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("mode", ["sync", "overlap"])
+@pytest.mark.parametrize("mode", ["sync", "stale"])
 def test_bench_two_ranks_on_one_device(mode):
     env = dict(os.environ, VV_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     port = "295%02d" % (17 if mode == "sync" else 23)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"),
-                        "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-dense-leg",
-                        "--allreduce", mode], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+                        "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
+                        "--allreduce", mode] + (["--no-extra-legs"] if mode == "sync" else []), capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                    # rank 0 only
@@ -29,3 +29,7 @@ def test_bench_two_ranks_on_one_device(mode):
     assert d["config"]["global_batch"] == 2048 and d["config"]["parallelism"] == "dp2"
     assert d["value"] > 0 and abs(d["value"] - 2048 * 50 * 4 / (d["ms_per_step"] * 4e-3)) <= 1e-6 * d["value"]
     assert 0 < d["final_loss"] < 16 and d["roofline"]["frac"] > 0
+    if mode == "sync":
+        assert d["value_scope"].startswith("end to end") and "shared-memory ring" in d["config"]["sampler"]
+    else:
+        assert d["gpu_path_only"]["value"] > 0 and d["step_ms_stats"]["n"] == 4

@@ -12,7 +12,7 @@ for mode in on off; do
     i=$((i+1))
     P=gpurun_out/sq_${mode}_$i
     rm -rf $P
-    timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $P -o sq -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-dense-leg --dedup $mode > gpurun_out/sq_${mode}_$i.log 2>&1
+    timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $P -o sq -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra-legs --dedup $mode > gpurun_out/sq_${mode}_$i.log 2>&1
   done
 done
 python3 - <<'PY'

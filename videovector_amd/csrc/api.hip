@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <algorithm>
 #include <map>
 #include <unordered_map>
@@ -74,6 +75,15 @@ struct vv_ctx {
   int32_t* U_host = nullptr;        // pinned + mapped: k_dd_leaders stores U here every step, the launcher reads it late
   int32_t* U_host_dev = nullptr;    // device alias of U_host
   uint32_t dd_epoch = 0;
+  int32_t step_seq = 0;
+  // staging of index batches taken from a sampler's prefetch ring (vv_forward_backward_ring)
+  static constexpr int kStage = 8;
+  int32_t* stage_host[kStage] = {};         // pinned, mapped into the device's address space
+  int32_t* stage_dev[kStage] = {};          // the device's alias of the same memory
+  int32_t stage_seq[kStage] = {};           // sequence number of the step that last read the slot
+  size_t stage_bytes = 0; int32_t stage_next = 0;
+  int32_t* seq_host = nullptr;              // pinned + mapped: the forward GEMM stores the step's sequence number here,
+  int32_t* seq_host_dev = nullptr;          //   i.e. "the kernels that read this step's index batch have finished"
   // profiling
   bool prof = false;
   int prof_every = 1;               // record every prof_every-th forward/backward + update (vv_profile_enable's argument)
@@ -108,11 +118,20 @@ static void prof_end(vv_ctx* c, const char* name, hipEvent_t e0, hipEvent_t e1) 
   if (vv::g_prof.stop) { (void)hipEventRecord(e1, c->stream); vv::g_prof.stop = nullptr; }
   c->prof_map[name].ev.emplace_back(e0, e1);
 }
+// VV_TRACE_HOST=<ms>: report every launcher call that keeps the HOST longer than that (first use of a kernel variant,
+// a runtime pool growing, ...) -- the GPU queue runs dry behind such a call.
+static double g_trace_host_ms = -1.0;
+static inline double host_now_ms() {
+  timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
 #define PROFILED(c, name, call)                 \
   do {                                          \
     hipEvent_t e0_, e1_;                        \
     prof_begin(c, name, &e0_, &e1_);            \
+    const double th_ = g_trace_host_ms >= 0 ? host_now_ms() : 0.0; \
     call;                                       \
+    if (g_trace_host_ms >= 0) { const double d_ = host_now_ms() - th_; if (d_ > g_trace_host_ms) fprintf(stderr, "[vv host] %s: %.3f ms (call %llu)\n", name, d_, (unsigned long long)c->iter); } \
     prof_end(c, name, e0_, e1_);                \
   } while (0)
 
@@ -168,6 +187,8 @@ int vv_create(int device, int prec, vv_ctx** out) {
   set_score_reg(sr ? atoi(sr) : 1);
   const char* ws = getenv("VV_WGRAD_SCHED");
   set_wgrad_sched(ws ? atoi(ws) : 0);
+  const char* th = getenv("VV_TRACE_HOST");
+  g_trace_host_ms = th ? atof(th) : -1.0;
   const char* dd = getenv("VV_DEDUP");
   if (dd) c->dedup = atoi(dd) != 0;
   HIPCHK(hipMalloc(&c->dd_info, 4 * sizeof(int32_t)));
@@ -175,6 +196,9 @@ int vv_create(int device, int prec, vv_ctx** out) {
   HIPCHK(hipHostMalloc((void**)&c->U_host, sizeof(int32_t), hipHostMallocMapped));
   *c->U_host = 0;
   HIPCHK(hipHostGetDevicePointer((void**)&c->U_host_dev, c->U_host, 0));
+  HIPCHK(hipHostMalloc((void**)&c->seq_host, sizeof(int32_t), hipHostMallocMapped));
+  *c->seq_host = 0;
+  HIPCHK(hipHostGetDevicePointer((void**)&c->seq_host_dev, c->seq_host, 0));
   *out = c;
   return VV_OK;
 }
@@ -223,6 +247,9 @@ int vv_destroy(vv_ctx* c) {
   dfree(c->scales); dfree(c->wmax_blocks); dfree(c->grads_own); dfree(c->mask); dfree(c->loss2);
   dfree(c->dd_key); dfree(c->dd_info);
   if (c->U_host) (void)hipHostFree(c->U_host);
+  for (int i = 0; i < vv_ctx::kStage; ++i)
+    if (c->stage_host[i]) (void)hipHostFree(c->stage_host[i]);
+  if (c->seq_host) (void)hipHostFree(c->seq_host);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
 
@@ -461,7 +488,7 @@ static int check_cfg(vv_ctx* c, const vv_step_cfg* cfg) {
   return VV_OK;
 }
 
-static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int idx_on_device, int64_t row_limit) {
+static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int idx_on_device, int64_t row_limit, int32_t seq = 0) {
   int rc = check_cfg(c, cfg);
   if (rc) return rc;
   if (!idx) return fail(VV_ERR_ARG, "vv_forward_backward: idx is NULL");
@@ -531,6 +558,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   fa.H = c->H; fa.R = c->R; fa.D = D; fa.Fp = c->Fp; fa.relu = 1; fa.zero_row = (int32_t)c->n_rows;
   fa.n_dev = dd ? c->dd_info : nullptr;
   fa.R_hint = dd ? *(volatile int32_t*)c->U_host : 0;
+  fa.seq_host = seq ? c->seq_host_dev : nullptr; fa.seq = seq;
 
   fa.drop_ratio = cfg->dropout_ratio;
   fa.mask = (cfg->dropout_ratio > 0.f && cfg->dropout_mask) ? c->mask : nullptr;
@@ -583,6 +611,56 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
 
 int vv_forward_backward(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int idx_on_device) {
   return fb_impl(c, cfg, idx, idx_on_device, c ? c->n_rows : 0);
+}
+
+// BasePrefetchingDataLayer::Forward_gpu (base_data_layer.cu:7-21) joins the prefetch thread and copies the batch to the
+// device; here the batch is 4*B*(C+Nn) bytes of indices out of the sampler's ring.  They are copied into one of kStage
+// pinned buffers that the GPU reads IN PLACE (the first kernel of the step, k_dd_claim / k_map_rows, reads every index
+// exactly once, coalesced, straight over PCIe): no copy engine, no second stream, no event.  (An asynchronous H2D copy
+// per step was measured first: ~25 us per step of queue switching between the copy and the kernels, and a one-off 6-7 ms
+// host stall inside hipMemcpyAsync after a handful of copies.)  A slot is reused only after the forward GEMM of the
+// step that read it has stamped its sequence number into host-visible memory.
+int vv_forward_backward_ring(vv_ctx* c, const vv_step_cfg* cfg, vv_batch_ring* ring, int32_t consumer, int32_t item_begin,
+                             int32_t* label_out, double timeout_s) {
+  int rc = check_cfg(c, cfg);
+  if (rc) return rc;
+  if (!ring) return fail(VV_ERR_ARG, "vv_forward_backward_ring: ring is NULL");
+  int32_t rb = 0, rcn = 0;
+  if (vv_batch_ring_info(ring, &rb, &rcn, nullptr, nullptr)) return fail(VV_ERR_ARG, "vv_forward_backward_ring: bad ring");
+  if (rcn != cfg->C + cfg->Nn || item_begin < 0 || item_begin + cfg->B > rb)
+    return fail(VV_ERR_ARG, "vv_forward_backward_ring: the ring holds batches of %d x %d slots; asked for items [%d, %d) x %d",
+                rb, rcn, item_begin, item_begin + cfg->B, cfg->C + cfg->Nn);
+  HIPCHK(hipSetDevice(c->device));
+  const size_t bytes = (size_t)cfg->B * rcn * sizeof(int32_t);
+  if (bytes != c->stage_bytes) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < vv_ctx::kStage; ++i) {
+      if (c->stage_host[i]) (void)hipHostFree(c->stage_host[i]);
+      c->stage_host[i] = c->stage_dev[i] = nullptr; c->stage_seq[i] = 0;
+      HIPCHK(hipHostMalloc((void**)&c->stage_host[i], bytes, hipHostMallocMapped));
+      HIPCHK(hipHostGetDevicePointer((void**)&c->stage_dev[i], c->stage_host[i], 0));
+    }
+    c->stage_bytes = bytes;
+  }
+  const int sl = c->stage_next;
+  c->stage_next = (c->stage_next + 1) % vv_ctx::kStage;
+  const double t0 = g_trace_host_ms >= 0 ? host_now_ms() : 0.0;
+  // the step that read this slot kStage steps ago must be past its index kernels
+  for (unsigned spins = 0; (int32_t)(__atomic_load_n(c->seq_host, __ATOMIC_ACQUIRE) - c->stage_seq[sl]) < 0; ++spins) {
+    if (spins > 4096) { timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
+    if (hipStreamQuery(c->stream) == hipSuccess) break;     // nothing queued any more: every earlier step is done
+  }
+  const double t1 = g_trace_host_ms >= 0 ? host_now_ms() : 0.0;
+  if (vv_batch_ring_next(ring, consumer, item_begin, cfg->B, c->stage_host[sl], label_out, timeout_s))
+    return fail(VV_ERR_STATE, "vv_forward_backward_ring: no batch (the sampler's prefetch stopped, or timeout)");
+  if (g_trace_host_ms >= 0) {
+    const double t2 = host_now_ms();
+    if (t2 - t0 > g_trace_host_ms)
+      fprintf(stderr, "[vv host] ring stage: slot wait %.3f, batch wait + copy %.3f ms (call %llu)\n", t1 - t0, t2 - t1, (unsigned long long)c->iter);
+  }
+  const int32_t seq = ++c->step_seq;
+  c->stage_seq[sl] = seq;
+  return fb_impl(c, cfg, c->stage_dev[sl], 1, c->n_rows, seq);
 }
 
 // Quirk Q1 (video_sampled_shots_data_layer.cpp:492): a same-video negative is copied WITHOUT its

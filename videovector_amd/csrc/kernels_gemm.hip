@@ -63,6 +63,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm(FwdArgs a) {
   // dedup mode: the grid covers the worst case, the live row count sits in device memory
   const int R = a.n_dev ? *a.n_dev : a.R;
   const int nact = a.n_dev ? ((R + BMK - 1) / BMK) * tilesN : (int)gridDim.x;
+  // the kernels that read this step's index batch ran before this one (same stream): tell the host its staging slot is free
+  if (a.seq_host && blockIdx.x == 0 && tid == 0) __hip_atomic_store(a.seq_host, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if ((int)blockIdx.x >= nact) return;
   const int L = xcd_remap(blockIdx.x, nact);
   const int m0 = (L / tilesN) * BMK, n0 = (L % tilesN) * BN;
@@ -422,6 +424,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ring(FwdArgs a) {
   const int tilesN = Dp / BN;
   const int R = a.n_dev ? *a.n_dev : a.R;
   const int nact = a.n_dev ? ((R + BM - 1) / BM) * tilesN : (int)gridDim.x;
+  if (a.seq_host && blockIdx.x == 0 && tid == 0) __hip_atomic_store(a.seq_host, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if ((int)blockIdx.x >= nact) return;
   const int L = xcd_remap(blockIdx.x, nact);
   const int m0 = (L / tilesN) * BM, n0 = (L % tilesN) * BN;

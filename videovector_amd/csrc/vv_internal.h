@@ -54,6 +54,8 @@ struct FwdArgs {
   int B, CN;               // to map an internal row (b*CN+ch) to the reference row (ch*B+b)
   const int32_t* n_dev = nullptr;   // dedup mode: device count of valid rows (overrides R; the grid covers R)
   int R_hint = 0;              // dedup mode: expected row count, sizes the tiles (0 = R)
+  int32_t* seq_host = nullptr; // host-mapped word that receives `seq` (the step's index batch has been consumed), or null
+  int32_t seq = 0;
 };
 
 struct ScoreArgs {

@@ -69,6 +69,7 @@ def load_library():
         "vv_forward_backward": [vp, vp, vp, C.c_int], "vv_apply_update": [vp, vp],
         "vv_forward_backward_q1": [vp, vp, vp, vp],
         "vv_step": [vp, vp, vp, C.c_int],
+        "vv_forward_backward_ring": [vp, vp, vp, i32, i32, vp, C.c_double],
         "vv_loss_get": [vp, C.POINTER(f32), C.POINTER(f32)],
         "vv_grads_device": [vp, C.POINTER(vp), C.POINTER(i64)], "vv_grads_get": [vp, vp, vp],
         "vv_grads_bind": [vp, vp],
@@ -217,6 +218,11 @@ class Engine:
         last_src = np.ascontiguousarray(last_src, dtype=np.int32)
         assert idx.shape == last_src.shape == (cfg.c.B, cfg.c.C + cfg.c.Nn)
         self._chk(self.L.vv_forward_backward_q1(self.h, C.byref(cfg.c), _ptr(idx), _ptr(last_src)))
+
+    def forward_backward_ring(self, cfg, ring, consumer=0, item_begin=0, label_out=None, timeout_s=60.0):
+        """Next batch of the sampler's prefetch ring -> pinned staging -> async H2D -> forward/backward."""
+        self._chk(self.L.vv_forward_backward_ring(self.h, C.byref(cfg.c), ring.h, consumer, item_begin, _ptr(label_out),
+                                                  float(timeout_s)))
 
     def apply_update(self, cfg):
         self._chk(self.L.vv_apply_update(self.h, C.byref(cfg.c)))
