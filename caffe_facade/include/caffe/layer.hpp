@@ -120,19 +120,13 @@ class VideoSampledShotsDataLayer : public Layer<Dtype> {
   const shared_ptr<VideoDataset>& dataset() const { return dataset_; }
  private:
   shared_ptr<VideoDataset> dataset_;
-  // prefetch: one host thread per data layer produces the next index batch while the GPU works on
-  // the current one (BasePrefetchingDataLayer, base_data_layer.cpp:52-95; InternalThread)
-  // The reference starts a new thread per batch (internal_thread.cpp:14-37); one persistent worker with the same
-  // hand-over points keeps the sampler's state (slots, buffer, key bitmap: ~1 MB) warm in one core's caches.
-  void CreatePrefetchThread();     // ask the worker for the next batch
-  void JoinPrefetchThread();       // wait until that batch is complete
-  void WorkerLoop();
-  std::thread thread_;
-  std::mutex mu_;
-  std::condition_variable cv_;
-  bool want_ = false, ready_ = false, quit_ = false;
+  // prefetch: the sampler's background threads keep kPrefetchDepth index batches ahead of the solver
+  // (BasePrefetchingDataLayer, base_data_layer.cpp:52-95; InternalThread, internal_thread.cpp:14-37)
+  static constexpr int kPrefetchDepth = 4;
+  void CreatePrefetchThread();     // starts the prefetch threads (first call)
+  void JoinPrefetchThread();       // the wait happens inside vv_sampler_next
+  bool prefetching_ = false;
   int rand_skip_ = 0;
-  vector<int32_t> pf_idx_, pf_last_, pf_label_;
   vv_sampler* sampler_ = nullptr;
   int batch_size_ = 0, context_size_ = 0, num_negative_samples_ = 0, feature_size_ = 0;
 };

@@ -372,40 +372,20 @@ void VideoDataset::UploadTable(vv_ctx* ctx) const {
 // ------------------------------------------------------------------------------- data layer ----
 template <typename Dtype>
 VideoSampledShotsDataLayer<Dtype>::~VideoSampledShotsDataLayer() {
-  if (thread_.joinable()) {
-    { std::lock_guard<std::mutex> l(mu_); quit_ = true; }
-    cv_.notify_all();
-    thread_.join();
-  }
-  if (sampler_) vv_sampler_destroy(sampler_);
+  if (sampler_) vv_sampler_destroy(sampler_);        // stops the prefetch threads
 }
-template <typename Dtype>
-void VideoSampledShotsDataLayer<Dtype>::WorkerLoop() {
-  std::unique_lock<std::mutex> l(mu_);
-  for (;;) {
-    cv_.wait(l, [this]() { return want_ || quit_; });
-    if (quit_) return;
-    want_ = false;
-    l.unlock();
-    CHECK_EQ(vv_sampler_next(sampler_, pf_idx_.data(), pf_last_.data(), pf_label_.data()), 0);
-    l.lock();
-    ready_ = true;
-    cv_.notify_all();
-  }
-}
+// BasePrefetchingDataLayer (base_data_layer.cpp:52-95) starts a thread per batch and joins it in Forward.  Here the
+// sampler's own prefetch threads (vv_sampler_prefetch_start) run kPrefetchDepth batches ahead for the whole life of the
+// layer; "create" is a no-op after the first call and "join" is the wait inside vv_sampler_next.
 template <typename Dtype>
 void VideoSampledShotsDataLayer<Dtype>::CreatePrefetchThread() {
-  const size_t n = (size_t)batch_size_ * (context_size_ + num_negative_samples_);
-  pf_idx_.resize(n); pf_last_.resize(n); pf_label_.resize(batch_size_);
-  if (!thread_.joinable()) thread_ = std::thread([this]() { WorkerLoop(); });
-  { std::lock_guard<std::mutex> l(mu_); want_ = true; ready_ = false; }
-  cv_.notify_all();
+  if (prefetching_) return;
+  const int threads = getenv("VV_SAMPLER_THREADS") ? atoi(getenv("VV_SAMPLER_THREADS")) : 3;
+  CHECK_EQ(vv_sampler_prefetch_start(sampler_, kPrefetchDepth, threads < 1 ? 1 : threads, nullptr, 1), 0);
+  prefetching_ = true;
 }
 template <typename Dtype>
-void VideoSampledShotsDataLayer<Dtype>::JoinPrefetchThread() {
-  std::unique_lock<std::mutex> l(mu_);
-  cv_.wait(l, [this]() { return ready_; });
-}
+void VideoSampledShotsDataLayer<Dtype>::JoinPrefetchThread() {}
 
 template <typename Dtype>
 void VideoSampledShotsDataLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>&, vector<Blob<Dtype>*>* top) {
@@ -450,7 +430,9 @@ void VideoSampledShotsDataLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>&, 
 template <typename Dtype>
 void VideoSampledShotsDataLayer<Dtype>::NextBatch(vector<int32_t>* idx, vector<int32_t>* last_src, vector<int32_t>* label) {
   JoinPrefetchThread();                                            // base_data_layer.cpp:81-95: join, hand over, respawn
-  idx->swap(pf_idx_); last_src->swap(pf_last_); label->swap(pf_label_);
+  const size_t n = (size_t)batch_size_ * (context_size_ + num_negative_samples_);
+  idx->resize(n); last_src->resize(n); label->resize(batch_size_);
+  CHECK_EQ(vv_sampler_next(sampler_, idx->data(), last_src->data(), label->data()), 0);
   CreatePrefetchThread();
 }
 template class VideoSampledShotsDataLayer<float>;

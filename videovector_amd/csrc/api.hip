@@ -488,6 +488,30 @@ static int check_cfg(vv_ctx* c, const vv_step_cfg* cfg) {
   return VV_OK;
 }
 
+// Index batches reach the GPU through kStage pinned, device-mapped buffers that the step's first kernel reads in place
+// (see vv_forward_backward_ring).  Returns the slot to fill; waits until the step that last read it is past its index
+// kernels (the forward GEMM stamps seq_host).
+static int stage_acquire(vv_ctx* c, size_t bytes, int* slot) {
+  if (bytes != c->stage_bytes) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < vv_ctx::kStage; ++i) {
+      if (c->stage_host[i]) (void)hipHostFree(c->stage_host[i]);
+      c->stage_host[i] = c->stage_dev[i] = nullptr; c->stage_seq[i] = 0;
+      HIPCHK(hipHostMalloc((void**)&c->stage_host[i], bytes, hipHostMallocMapped));
+      HIPCHK(hipHostGetDevicePointer((void**)&c->stage_dev[i], c->stage_host[i], 0));
+    }
+    c->stage_bytes = bytes;
+  }
+  const int sl = c->stage_next;
+  c->stage_next = (c->stage_next + 1) % vv_ctx::kStage;
+  for (unsigned spins = 0; (int32_t)(__atomic_load_n(c->seq_host, __ATOMIC_ACQUIRE) - c->stage_seq[sl]) < 0; ++spins) {
+    if (spins > 4096) { timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
+    if (hipStreamQuery(c->stream) == hipSuccess) break;     // nothing queued any more: every earlier step is done
+  }
+  *slot = sl;
+  return VV_OK;
+}
+
 static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int idx_on_device, int64_t row_limit, int32_t seq = 0) {
   int rc = check_cfg(c, cfg);
   if (rc) return rc;
@@ -499,10 +523,16 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
 
   const int32_t* didx = idx;
   if (!idx_on_device) {
-    for (int i = 0; i < c->R; ++i)
-      if (idx[i] < -1 || idx[i] >= row_limit) return fail(VV_ERR_ARG, "idx[%d] = %d out of range [-1, %lld)", i, idx[i], (long long)c->n_rows);
-    HIPCHK(hipMemcpyAsync(c->idx_dev, idx, (size_t)c->R * 4, hipMemcpyHostToDevice, s));
-    didx = c->idx_dev;
+    // host indices: checked while they are copied into a pinned staging slot that the first kernel reads in place
+    int sl = 0;
+    if ((rc = stage_acquire(c, (size_t)c->R * 4, &sl))) return rc;
+    int32_t* dst = c->stage_host[sl];
+    int bad = -1;
+    for (int i = 0; i < c->R; ++i) { const int32_t v = idx[i]; dst[i] = v; if (v < -1 || v >= row_limit) bad = i; }
+    if (bad >= 0) return fail(VV_ERR_ARG, "idx[%d] = %d out of range [-1, %lld)", bad, idx[bad], (long long)c->n_rows);
+    if (!seq) seq = ++c->step_seq;
+    c->stage_seq[sl] = seq;
+    didx = c->stage_dev[sl];
   }
 
   // eltwise coefficients (cached on the device until they change)
@@ -632,24 +662,9 @@ int vv_forward_backward_ring(vv_ctx* c, const vv_step_cfg* cfg, vv_batch_ring* r
                 rb, rcn, item_begin, item_begin + cfg->B, cfg->C + cfg->Nn);
   HIPCHK(hipSetDevice(c->device));
   const size_t bytes = (size_t)cfg->B * rcn * sizeof(int32_t);
-  if (bytes != c->stage_bytes) {
-    HIPCHK(hipStreamSynchronize(c->stream));
-    for (int i = 0; i < vv_ctx::kStage; ++i) {
-      if (c->stage_host[i]) (void)hipHostFree(c->stage_host[i]);
-      c->stage_host[i] = c->stage_dev[i] = nullptr; c->stage_seq[i] = 0;
-      HIPCHK(hipHostMalloc((void**)&c->stage_host[i], bytes, hipHostMallocMapped));
-      HIPCHK(hipHostGetDevicePointer((void**)&c->stage_dev[i], c->stage_host[i], 0));
-    }
-    c->stage_bytes = bytes;
-  }
-  const int sl = c->stage_next;
-  c->stage_next = (c->stage_next + 1) % vv_ctx::kStage;
   const double t0 = g_trace_host_ms >= 0 ? host_now_ms() : 0.0;
-  // the step that read this slot kStage steps ago must be past its index kernels
-  for (unsigned spins = 0; (int32_t)(__atomic_load_n(c->seq_host, __ATOMIC_ACQUIRE) - c->stage_seq[sl]) < 0; ++spins) {
-    if (spins > 4096) { timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
-    if (hipStreamQuery(c->stream) == hipSuccess) break;     // nothing queued any more: every earlier step is done
-  }
+  int sl = 0;
+  if ((rc = stage_acquire(c, bytes, &sl))) return rc;
   const double t1 = g_trace_host_ms >= 0 ? host_now_ms() : 0.0;
   if (vv_batch_ring_next(ring, consumer, item_begin, cfg->B, c->stage_host[sl], label_out, timeout_s))
     return fail(VV_ERR_STATE, "vv_forward_backward_ring: no batch (the sampler's prefetch stopped, or timeout)");
