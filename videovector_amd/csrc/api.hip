@@ -16,7 +16,7 @@
 
 #include "vv_internal.h"
 
-namespace vv { void set_wgrad_tr(bool on); void set_gemm_variant(int v); void set_ablate(int v); void set_fwd_mi(int v); void set_score_reg(int v); void set_wgrad_sched(int v); int wgrad_max_ksteps_per_split(); int gemm_variant(); bool ablate_on(); }
+namespace vv { void set_wgrad_tr(bool on); void set_gemm_variant(int v); void set_ablate(int v); void set_fwd_mi(int v); void set_score_reg(int v); void set_wgrad_sched(int v); void set_ph_mq(int v); int wgrad_max_ksteps_per_split(); int gemm_variant(); bool ablate_on(); }
 using namespace vv;
 
 static thread_local char g_err[512] = "";
@@ -185,6 +185,8 @@ int vv_create(int device, int prec, vv_ctx** out) {
   set_fwd_mi(fm ? atoi(fm) : 0);
   const char* sr = getenv("VV_SCORE_REG");
   set_score_reg(sr ? atoi(sr) : 1);
+  const char* pq = getenv("VV_PH_MQ");
+  set_ph_mq(pq ? atoi(pq) : 0);
   const char* ws = getenv("VV_WGRAD_SCHED");
   set_wgrad_sched(ws ? atoi(ws) : 0);
   const char* th = getenv("VV_TRACE_HOST");
@@ -556,7 +558,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
 
   // De-duplicate the batch rows when dropout is off (with dropout every instance has its own mask on
   // top of the shared projection; that path stays dense).  Needs the default two-buffer GEMM kernels.
-  const bool dd = c->dedup && cfg->dropout_ratio == 0.f && (gemm_variant() == 0 || gemm_variant() == 3 || gemm_variant() == 4) && !ablate_on();
+  const bool dd = c->dedup && cfg->dropout_ratio == 0.f && (gemm_variant() == 0 || gemm_variant() == 3 || gemm_variant() == 4 || gemm_variant() == 5) && !ablate_on();
   c->last_dedup = dd;
   if (!dd) launch_map_rows(didx, c->rows, c->R, c->Rp, (int32_t)c->n_rows, (int32_t)row_limit, s);
   if (dd) {

@@ -718,7 +718,9 @@ static void launch_fwd_p(const FwdArgs& a, hipStream_t s) {
   else { if (vec) launch_fwd_t<T, false, true>(a, s); else launch_fwd_t<T, false, false>(a, s); }
 }
 
+void launch_fwd_gemm_ph(int prec, const FwdArgs& a, hipStream_t s);
 void launch_fwd_gemm(int prec, const FwdArgs& a, hipStream_t s) {
+  if (g_gemm_variant == 5 && !g_ablate) { launch_fwd_gemm_ph(prec, a, s); return; }
   if (prec == 0) launch_fwd_p<F16>(a, s); else launch_fwd_p<BF16>(a, s);
 }
 
