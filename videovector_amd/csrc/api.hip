@@ -438,8 +438,9 @@ static int ensure_batch(vv_ctx* c, int B, int C, int Nn) {
   HIPCHK(hipMalloc(&c->idx_dev, (size_t)c->R * 4));
   HIPCHK(hipMalloc(&c->rows, (size_t)c->Rp * 4));
   HIPCHK(hipMalloc(&c->H, (size_t)c->R * D * 4));
-  HIPCHK(hipMalloc(&c->dYh, (size_t)c->Rp * c->Dp * 2));
-  HIPCHK(hipMemset(c->dYh, 0, (size_t)c->Rp * c->Dp * 2));     // padding rows / columns stay zero
+  // + BK rows of slack: the phase-staggered weight-gradient kernel may read one padded K-tile past the last row
+  HIPCHK(hipMalloc(&c->dYh, (size_t)(c->Rp + BK) * c->Dp * 2));
+  HIPCHK(hipMemset(c->dYh, 0, (size_t)(c->Rp + BK) * c->Dp * 2));     // padding rows / columns stay zero
   HIPCHK(hipMalloc(&c->dbp, (size_t)B * D * 4));
   HIPCHK(hipMalloc(&c->loss_part, (size_t)B * 4));
   HIPCHK(hipMalloc(&c->viol_part, (size_t)B * 4));
@@ -469,8 +470,8 @@ static int ensure_batch(vv_ctx* c, int B, int C, int Nn) {
   HIPCHK(hipMalloc(&c->dd_cnt, (size_t)c->Rp * 4));
   HIPCHK(hipMalloc(&c->dd_seg, (size_t)(c->Rp + 1) * 4));
   HIPCHK(hipMalloc(&c->dd_pos, (size_t)c->Rp * 4));
-  HIPCHK(hipMalloc(&c->dYu, (size_t)c->Rp * c->Dp * 2));
-  HIPCHK(hipMemset(c->dYu, 0, (size_t)c->Rp * c->Dp * 2));
+  HIPCHK(hipMalloc(&c->dYu, (size_t)(c->Rp + BK) * c->Dp * 2));
+  HIPCHK(hipMemset(c->dYu, 0, (size_t)(c->Rp + BK) * c->Dp * 2));
   *c->U_host = 0;
   return VV_OK;
 }
@@ -558,7 +559,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
 
   // De-duplicate the batch rows when dropout is off (with dropout every instance has its own mask on
   // top of the shared projection; that path stays dense).  Needs the default two-buffer GEMM kernels.
-  const bool dd = c->dedup && cfg->dropout_ratio == 0.f && (gemm_variant() == 0 || gemm_variant() == 3 || gemm_variant() == 4 || gemm_variant() == 5) && !ablate_on();
+  const bool dd = c->dedup && cfg->dropout_ratio == 0.f && (gemm_variant() == 0 || gemm_variant() == 3 || gemm_variant() == 4 || (gemm_variant() >= 5 && gemm_variant() <= 7)) && !ablate_on();
   c->last_dedup = dd;
   if (!dd) launch_map_rows(didx, c->rows, c->R, c->Rp, (int32_t)c->n_rows, (int32_t)row_limit, s);
   if (dd) {
@@ -626,7 +627,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   WgradArgs wa;
   wa.dYh = dd ? c->dYu : c->dYh; wa.table = c->table; wa.rows = dd ? c->dd_uniq : c->rows; wa.slabs = c->slabs;
   wa.Rp = c->Rp; wa.Dp = c->Dp; wa.Fp = c->Fp; wa.S = c->S; wa.ksteps_per_split = c->kps;
-  wa.n_dev = dd ? c->dd_info : nullptr;
+  wa.n_dev = dd ? c->dd_info : nullptr; wa.zero_row = (int32_t)c->n_rows;
   PROFILED(c, "wgrad_gemm", launch_wgrad_gemm(c->prec, wa, s));
 
   ReduceArgs ra;

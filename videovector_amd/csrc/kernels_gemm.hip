@@ -637,7 +637,8 @@ static int g_fwd_mi = 0;            // VV_FWD_MI: force the forward tile height 
 void set_fwd_mi(int v) { g_fwd_mi = v; }
 static int g_ablate = 0;
 void set_ablate(int v) { g_ablate = v; }
-static int g_gemm_variant = 0;     // 0 = two-buffer K=64 kernels (default, faster), 1 = 4-slot ring K=32 kernels
+static int g_gemm_variant = 5;     // 5 = phase-staggered kernels (kernels_gemm_ph.hip, default); 6 / 7 = only the weight-gradient / forward one;
+                                   // 0 = two-buffer K=64 kernels (round 1), 1 / 4 = 4-slot ring K=32 kernels, 3 = 0 with burst staging
 void set_wgrad_tr(bool on) { g_wgrad_tr = on; }
 void set_gemm_variant(int v) { g_gemm_variant = v; }
 int gemm_variant() { return g_gemm_variant; }
@@ -720,7 +721,7 @@ static void launch_fwd_p(const FwdArgs& a, hipStream_t s) {
 
 void launch_fwd_gemm_ph(int prec, const FwdArgs& a, hipStream_t s);
 void launch_fwd_gemm(int prec, const FwdArgs& a, hipStream_t s) {
-  if (g_gemm_variant == 5 && !g_ablate) { launch_fwd_gemm_ph(prec, a, s); return; }
+  if (g_gemm_variant == 5 || g_gemm_variant == 7) { FwdArgs b = a; b.abl = g_ablate; launch_fwd_gemm_ph(prec, b, s); return; }   // 5: both new, 6: new wgrad only, 7: new fwd only
   if (prec == 0) launch_fwd_p<F16>(a, s); else launch_fwd_p<BF16>(a, s);
 }
 
@@ -742,7 +743,9 @@ static void launch_wgrad_ring_t(const WgradArgs& a, hipStream_t s) {
   VV_LAUNCH((k_wgrad_gemm_ring<T>), grid, block, WG_RING_LDS_BYTES, s, a);
 }
 
+void launch_wgrad_gemm_ph(int prec, const WgradArgs& a, hipStream_t s);
 void launch_wgrad_gemm(int prec, const WgradArgs& a, hipStream_t s) {
+  if ((g_gemm_variant == 5 || g_gemm_variant == 6) && g_wgrad_tr) { WgradArgs b = a; b.abl = g_ablate; launch_wgrad_gemm_ph(prec, b, s); return; }
   if (g_ablate && prec == 0) {
     const dim3 grid((a.Dp / BM) * (a.Fp / BN) * a.S), block(GEMM_THREADS);
 #define VV_ABL_WG(N)                                                                               \

@@ -36,6 +36,13 @@ namespace vv {
 __device__ __forceinline__ void ph_glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc), LDS_PTR(lds_wave_base), 16, 0, 0);
 }
+// the same with the source 256 bytes further on (the upper 128-column half of a k-major operand): an immediate
+// offset of the instruction instead of a second address register pair.  The hardware adds the instruction offset to
+// the LDS address as well as to the global one (LDS_ADDR = M0 base + inst_offset + lane * size), so the LDS base is
+// handed over 256 bytes low.  Only used for slots >= 2: the adjusted base never falls below the start of the LDS.
+__device__ __forceinline__ void ph_glds16_hi(const void* gsrc, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc), LDS_PTR(lds_wave_base - 256), 16, 256, 0);
+}
 __device__ __forceinline__ int ph_xcd_remap(int bid, int nblk) {
   const int x = bid & 7, q = nblk >> 3, rem = nblk & 7;
   return x * q + (x < rem ? x : rem) + (bid >> 3);
@@ -49,7 +56,7 @@ constexpr int PH_LDS_BYTES = 8 * PH_SLOT;      // ring of 8 slots = 128 KiB
 // Half-tile LDS image: [128 rows][64 halves] = 128-B rows of 8 16-B chunks, chunk' = chunk ^ (row & 7)
 // (conflict-free ds_read_b128 fragment reads, as in k_fwd_gemm).  One LDS-DMA wave-instruction = 8 rows.
 // MQ = 16-row MFMA tiles per wave and A half: the tile is (64*MQ) x 256 (MQ 4: 256 rows, 3: 192, 2: 128).
-template <typename T, bool DROP, bool VEC, int MQ>
+template <typename T, bool DROP, bool VEC, int MQ, int ABL = 0>
 __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int HROWS = 32 * MQ;               // live rows of an A half-tile
@@ -76,7 +83,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
     for (int i = 0; i < 2; ++i) {
       const int row = (i * 8 + wave) * 8 + (lane >> 3), lc = (lane & 7) ^ (row & 7);
       const int grow = m0 + hf * HROWS + row;
-      const int trow = (row < HROWS && grow < R) ? a.rows[grow] : a.zero_row;
+      const int trow = (row < HROWS && grow < R && !(ABL & 8)) ? a.rows[grow] : a.zero_row;
       srcA[hf][i] = a.table + (int64_t)trow * Fp + lc * 8;
       srcB[hf][i] = a.Wh + (int64_t)(n0 + hf * 128 + row) * Fp + lc * 8;
     }
@@ -116,15 +123,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
 
   // one phase: LOAD segment (reads + stream + wait), barrier, MFMA segment, barrier
 #define PH_LOAD_A(slot)                                                                              \
-  _Pragma("unroll") for (int mi = 0; mi < MQ; ++mi) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) \
+  if (!abl_rd) _Pragma("unroll") for (int mi = 0; mi < MQ; ++mi) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) \
     af[mi][kk] = *(const i16x8*)(smem + (slot) * PH_SLOT + a_off + mi * 2048 + (((kk * 4 + fq) ^ sw) << 4));
 #define PH_LOAD_B(dst, slot)                                                                         \
-  _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)  \
+  if (!abl_rd) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)  \
     dst[ni][kk] = *(const i16x8*)(smem + (slot) * PH_SLOT + b_off + ni * 2048 + (((kk * 4 + fq) ^ sw) << 4));
 #define PH_MFMA(mh, nh, bfr)                                                                         \
   __builtin_amdgcn_s_barrier();                                                                      \
   __builtin_amdgcn_sched_barrier(0);                                                                 \
-  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int mi = 0; mi < MQ; ++mi) \
+  if (!abl_mm) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int mi = 0; mi < MQ; ++mi) \
     _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                 \
       acc[mh][mi][nh][ni] = T::mfma(bfr[ni][kk], af[mi][kk], acc[mh][mi][nh][ni]);                   \
   __builtin_amdgcn_sched_barrier(0);                                                                 \
@@ -134,8 +141,17 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
 #define PH_STREAM(tpar, t, p, wait)                                                                  \
   {                                                                                                  \
     const int h = 4 * (t) + (p) + 6;                                                                 \
-    if (h < H) { issue(h >> 2, ((p) + 2) & 3, 4 * (((tpar) + (((p) + 6) >> 2)) & 1) + (((p) + 2) & 3)); if (wait) PH_WAIT(8); } \
+    if (h < H && !abl_st) { issue(h >> 2, ((p) + 2) & 3, 4 * (((tpar) + (((p) + 6) >> 2)) & 1) + (((p) + 2) & 3)); if (wait) PH_WAIT(8); } \
     else if (wait) PH_WAIT(0);                                                                       \
+  }
+  // ABL: timing studies only (VV_ABLATE, results wrong): 1 no LDS-DMA stream in the loop, 2 no MFMA, 4 no fragment
+  // reads, 8 every gathered row is the (L2-hot) zero row
+  constexpr bool abl_st = ABL & 1, abl_mm = ABL & 2, abl_rd = ABL & 4;
+  if (abl_rd) {
+#pragma unroll
+    for (int mi = 0; mi < MQ; ++mi) { af[mi][0] = i16x8{1, 2, 3, 4, 5, 6, 7, (short)mi}; af[mi][1] = af[mi][0]; }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) { b0[ni][0] = b0[ni][1] = b1[ni][0] = b1[ni][1] = i16x8{1, 2, 3, 4, 5, 6, 7, (short)ni}; }
   }
 
   for (int t = 0; t < nk; t += 2) {
@@ -199,6 +215,185 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------- wgrad --------
+// dW = dY^T X, one split of K per workgroup.  Both operands are k-major in HBM (dY rows / gathered feature rows), so a
+// half-tile is 64 k-rows x 128 columns: 256-B LDS rows of 16 chunks, chunk' = chunk ^ (h(row) << 1) with
+// h = (row & 3) | ((row >> 3) & 1) << 2, read with ds_read_b64_tr_b16 (4 k-rows x 16 columns per 16-lane group,
+// delivered column-major = the MFMA operand layout): the 8 row segments of a 32-lane half fall on disjoint banks.
+// One LDS-DMA wave-instruction = 4 k-rows.
+//
+// Schedule (one fragment set per operand: 176 of the 256 VGPRs go to accumulators and fragments).  X = the gathered
+// feature rows (n side, 4 fragment tiles per wave and half), Y = dY (m side, 2 tiles per wave and half):
+//     phase 0: X_lo x Y_lo   phase 1: X_lo x Y_hi   phase 2: X_hi x Y_hi   phase 3: X_hi x Y_lo (Y_lo read again)
+// ring slots per K-tile parity: 0 X_lo, 1 Y_lo, 2 Y_hi, 3 X_hi.  The stream issues, in phase p of K-tile t,
+//     p0: X_hi(t+1)   p1: Y_lo(t+1)   p2: X_lo(t+2)   p3: Y_hi(t+2)
+// so the gathered operand (HBM) flies 6 phases, dY (L2 / Infinity Cache) at least 3, and ONE counted wait per K-tile
+// (vmcnt(4) after p3: everything up to Y_lo(t+1) has landed, X_lo(t+2) and Y_hi(t+2) stay in flight) covers all reads
+// of K-tile t+1.  Every slot is restaged at least two segments after its last read was issued.
+// The table-row ids of the K range are copied to LDS first (the last 32 KiB of the 160 KiB), PH_WG_IDS rows at a time,
+// so the loop has no ordinary global load (hipcc would wait vmcnt(0) for it and drain the stream); ids past the
+// split's end name the table's zero row, so a padded K-tile contributes nothing.
+constexpr int PH_WG_IDS = 8192;
+constexpr int PH_WG_LDS_BYTES = PH_LDS_BYTES + PH_WG_IDS * 4;      // 160 KiB
+
+__device__ __forceinline__ int ph_h(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+__device__ __forceinline__ i16x4 ph_tr(const unsigned char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(p));
+}
+
+template <typename T, int ABL = 0>
+__global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int32_t* ids = (int32_t*)(smem + PH_LDS_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int tilesM = a.Dp / BM, tilesN = a.Fp / BN;
+  const int L = ph_xcd_remap(blockIdx.x, gridDim.x);
+  const int tm = L % tilesM, tn = (L / tilesM) % tilesN, sp = L / (tilesM * tilesN);
+  const int m0 = tm * BM, n0 = tn * BN;
+  int total_steps = a.Rp / BK, kps = a.ksteps_per_split;
+  if (a.n_dev) {                      // dedup mode: live K extent in device memory
+    total_steps = (*a.n_dev + BK - 1) / BK;
+    kps = (total_steps + a.S - 1) / a.S;
+  }
+  const int k_begin = sp * kps;
+  int k_end = k_begin + kps;
+  if (k_end > total_steps) k_end = total_steps;
+  const int nk_all = k_end > k_begin ? k_end - k_begin : 0;
+
+  f32x4 acc[2][4][2][2];               // [X half][n tile][Y half][m tile]
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) acc[nh][ni][mh][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // staging: instruction i (0, 1) of this wave fills k-rows (i*8 + wave)*4 .. +3 of a half-tile; lane -> (row, chunk).
+  // dY rows advance by a constant stride, so its two source pointers are simply incremented; the upper column half of
+  // either operand is the same address + 256 B (immediate offset).  dYh / dYu carry BK rows of slack past Rp, so a
+  // padded K-tile reads in bounds (its feature operand is the zero row).
+  const int srow0 = wave * 4 + (lane >> 4), srow1 = srow0 + 32;
+  const int scol0 = ((lane & 15) ^ (ph_h(srow0) << 1)) * 8;   // source column (halves) inside the 128-column half
+  const int scol1 = ((lane & 15) ^ (ph_h(srow1) << 1)) * 8;
+  const int g = lane >> 4, li = lane & 15, q4 = li >> 2, pp = li & 3;
+  const uint16_t* tb0 = a.table + n0 + scol0;
+  const uint16_t* tb1 = a.table + n0 + scol1;
+  // fragment reads: h(row1) does not depend on kk (bits 0, 1, 3 of the row), so kk, the +4-row partner and the slot are
+  // immediate offsets of one address per fragment tile
+  const int hx = ph_h(8 * g + q4) << 1;
+  const int rd = (8 * g + q4) * 256 + (pp & 1) * 8;
+  int xa[4], ya[2];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) xa[ni] = rd + (((wm * 8 + ni * 2 + (pp >> 1)) ^ hx) << 4);
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) ya[mi] = rd + (((wn * 4 + mi * 2 + (pp >> 1)) ^ hx) << 4);
+
+  for (int c0 = 0; c0 < nk_all; c0 += PH_WG_IDS / BK) {      // super-chunks of at most 128 K-tiles
+    const int nk_c = nk_all - c0 < PH_WG_IDS / BK ? nk_all - c0 : PH_WG_IDS / BK;
+    const int nk = (nk_c + 1) & ~1;                           // even number of K-tiles; a padded one multiplies zeros
+    const int64_t kg0 = (int64_t)(k_begin + c0) * BK;
+    const int live = nk_c * BK;
+    __syncthreads();                                          // the previous chunk's stream is drained (tail waits)
+    for (int i = tid; i < nk * BK; i += GEMM_THREADS) ids[i] = (i < live && !(ABL & 8)) ? a.rows[kg0 + i] : a.zero_row;
+    __syncthreads();
+    const uint16_t* pa0 = a.dYh + (kg0 + srow0) * a.Dp + m0 + scol0;
+    const uint16_t* pa1 = a.dYh + (kg0 + srow1) * a.Dp + m0 + scol1;
+    const int64_t a_step = (int64_t)BK * a.Dp;
+    auto issue_y = [&](int kt, bool hi, int slot) {
+      unsigned char* dst = smem + slot * PH_SLOT + wave * 1024;
+      if (!hi) { ph_glds16(pa0 + kt * a_step, dst); ph_glds16(pa1 + kt * a_step, dst + 8192); }
+      else { ph_glds16_hi(pa0 + kt * a_step, dst); ph_glds16_hi(pa1 + kt * a_step, dst + 8192); }
+    };
+    auto issue_x = [&](int id0, int id1, bool hi, int slot) {
+      unsigned char* dst = smem + slot * PH_SLOT + wave * 1024;
+      const int64_t r0 = (int64_t)id0 * a.Fp, r1 = (int64_t)id1 * a.Fp;
+      if (!hi) { ph_glds16(tb0 + r0, dst); ph_glds16(tb1 + r1, dst + 8192); }
+      else { ph_glds16_hi(tb0 + r0, dst); ph_glds16_hi(tb1 + r1, dst + 8192); }
+    };
+    // prologue, in stream order: X_lo(0), Y_hi(0), X_hi(0), Y_lo(0), X_lo(1), Y_hi(1)
+    issue_x(ids[srow0], ids[srow1], false, 0);
+    issue_y(0, true, 2);
+    issue_x(ids[srow0], ids[srow1], true, 3);
+    issue_y(0, false, 1);
+    issue_x(ids[BK + srow0], ids[BK + srow1], false, 4);
+    issue_y(1, true, 6);
+    int idn0 = ids[BK + srow0], idn1 = ids[BK + srow1];      // ids of the next X issue: X_hi(1) in phase (0, 0)
+    PH_WAIT(4);
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();                // waves 4-7 run one segment behind
+    if (wm == 1) __builtin_amdgcn_s_setprio(1);
+
+    i16x8 xf[4][2], yf[2][2];
+    constexpr bool abl_st = ABL & 1, abl_mm = ABL & 2, abl_rd = ABL & 4;
+    if (abl_rd) {
+#pragma unroll
+      for (int x = 0; x < 4; ++x) { xf[x][0] = xf[x][1] = i16x8{1, 2, 3, 4, 5, 6, 7, (short)x}; }
+#pragma unroll
+      for (int x = 0; x < 2; ++x) { yf[x][0] = yf[x][1] = i16x8{1, 2, 3, 4, 5, 6, 7, (short)x}; }
+    }
+#define PW_LOAD(dst, adr, cnt, slot)                                                                   \
+    if (!abl_rd) _Pragma("unroll") for (int x = 0; x < cnt; ++x) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) { \
+      const unsigned char* p_ = smem + (slot) * PH_SLOT + kk * 8192 + adr[x];                          \
+      const i16x4 lo = ph_tr(p_), hi = ph_tr(p_ + 1024);                                               \
+      dst[x][kk] = i16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                      \
+    }
+#define PW_MFMA(nh, mh)                                                                                \
+    __builtin_amdgcn_s_barrier();                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    if (!abl_mm) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)  \
+      _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                 \
+        acc[nh][ni][mh][mi] = T::mfma(xf[ni][kk], yf[mi][kk], acc[nh][ni][mh][mi]);                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    __builtin_amdgcn_s_barrier();                                                                      \
+    __builtin_amdgcn_sched_barrier(0);
+    // one K-tile of parity par (slots 4*par ..), the stream working on K-tiles t+1 and t+2
+#define PW_TILE(par, t)                                                                                \
+    PW_LOAD(xf, xa, 4, 4 * (par) + 0) PW_LOAD(yf, ya, 2, 4 * (par) + 1)                                \
+    if ((t) + 1 < nk && !abl_st) issue_x(idn0, idn1, true, 4 * (1 - (par)) + 3);                       \
+    PW_MFMA(0, 0)                                                                                      \
+    PW_LOAD(yf, ya, 2, 4 * (par) + 2)                                                                  \
+    if ((t) + 1 < nk && !abl_st) issue_y((t) + 1, false, 4 * (1 - (par)) + 1);                         \
+    if ((t) + 2 < nk) { idn0 = ids[((t) + 2) * BK + srow0]; idn1 = ids[((t) + 2) * BK + srow1]; }      \
+    PW_MFMA(0, 1)                                                                                      \
+    PW_LOAD(xf, xa, 4, 4 * (par) + 3)                                                                  \
+    if ((t) + 2 < nk && !abl_st) issue_x(idn0, idn1, false, 4 * (par) + 0);                            \
+    PW_MFMA(1, 1)                                                                                      \
+    PW_LOAD(yf, ya, 2, 4 * (par) + 1)                                                                  \
+    if ((t) + 2 < nk && !abl_st) { issue_y((t) + 2, true, 4 * (par) + 2); PH_WAIT(4); } else PH_WAIT(0); \
+    PW_MFMA(1, 0)
+    for (int t = 0; t < nk; t += 2) {
+      PW_TILE(0, t)
+      PW_TILE(1, t + 1)
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();                // waves 0-3 catch the extra barrier of waves 4-7
+    if (wm == 1) __builtin_amdgcn_s_setprio(0);
+#undef PW_LOAD
+#undef PW_MFMA
+#undef PW_TILE
+  }
+
+  // D' = X_frag^T-major: the lane's column is m (dY column = output row d), its 4 registers 4 consecutive n
+  float* slab = a.slabs + (int64_t)sp * a.Dp * a.Fp;
+#pragma unroll
+  for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int m = m0 + mh * 128 + wn * 32 + mi * 16 + li;
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const int n = n0 + nh * 128 + wm * 64 + ni * 16 + g * 4;
+          const f32x4 v = acc[nh][ni][mh][mi];
+          *(float4*)(slab + (int64_t)m * a.Fp + n) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------- launchers ----
 template <typename T, bool DROP, bool VEC, int MQ>
 static void launch_fwd_ph_q(const FwdArgs& a, hipStream_t s) {
@@ -227,6 +422,19 @@ static void launch_fwd_ph_t(const FwdArgs& a, hipStream_t s) {
     if (best_cost < 0 || cost < best_cost) { best = mq; best_cost = cost; }
   }
   if (g_ph_mq >= 2 && g_ph_mq <= 4) best = g_ph_mq;
+  if constexpr (T::id == 0 && !DROP && VEC) {
+    if (a.abl) {
+      const dim3 grid(((a.R + 255) / 256) * (Dp / BN)), block(GEMM_THREADS);
+#define VV_ABL_FWP(N)                                                                                  \
+      if (a.abl == N) {                                                                                \
+        (void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, 4, N>, hipFuncAttributeMaxDynamicSharedMemorySize, PH_LDS_BYTES); \
+        VV_LAUNCH((k_fwd_gemm_ph<T, DROP, VEC, 4, N>), grid, block, PH_LDS_BYTES, s, a);                \
+        return;                                                                                        \
+      }
+      VV_ABL_FWP(1) VV_ABL_FWP(2) VV_ABL_FWP(3) VV_ABL_FWP(4) VV_ABL_FWP(6) VV_ABL_FWP(7) VV_ABL_FWP(8) VV_ABL_FWP(9)
+#undef VV_ABL_FWP
+    }
+  }
   if (best == 4) launch_fwd_ph_q<T, DROP, VEC, 4>(a, s);
   else if (best == 3) launch_fwd_ph_q<T, DROP, VEC, 3>(a, s);
   else launch_fwd_ph_q<T, DROP, VEC, 2>(a, s);
@@ -237,6 +445,31 @@ static void launch_fwd_ph_p(const FwdArgs& a, hipStream_t s) {
   const bool drop = a.drop_ratio > 0.f, vec = a.D % 4 == 0;
   if (drop) { if (vec) launch_fwd_ph_t<T, true, true>(a, s); else launch_fwd_ph_t<T, true, false>(a, s); }
   else { if (vec) launch_fwd_ph_t<T, false, true>(a, s); else launch_fwd_ph_t<T, false, false>(a, s); }
+}
+
+template <typename T>
+static void launch_wgrad_ph_t(const WgradArgs& a, hipStream_t s) {
+  static bool once = ((void)hipFuncSetAttribute((const void*)k_wgrad_gemm_ph<T>,
+                      hipFuncAttributeMaxDynamicSharedMemorySize, PH_WG_LDS_BYTES), true);
+  (void)once;
+  const dim3 grid((a.Dp / BM) * (a.Fp / BN) * a.S), block(GEMM_THREADS);
+  if constexpr (T::id == 0) {
+    if (a.abl) {
+#define VV_ABL_WGP(N)                                                                                  \
+      if (a.abl == N) {                                                                                \
+        (void)hipFuncSetAttribute((const void*)k_wgrad_gemm_ph<T, N>, hipFuncAttributeMaxDynamicSharedMemorySize, PH_WG_LDS_BYTES); \
+        VV_LAUNCH((k_wgrad_gemm_ph<T, N>), grid, block, PH_WG_LDS_BYTES, s, a);                         \
+        return;                                                                                        \
+      }
+      VV_ABL_WGP(1) VV_ABL_WGP(2) VV_ABL_WGP(3) VV_ABL_WGP(4) VV_ABL_WGP(6) VV_ABL_WGP(7) VV_ABL_WGP(8) VV_ABL_WGP(9)
+#undef VV_ABL_WGP
+    }
+  }
+  VV_LAUNCH((k_wgrad_gemm_ph<T>), grid, block, PH_WG_LDS_BYTES, s, a);
+}
+
+void launch_wgrad_gemm_ph(int prec, const WgradArgs& a, hipStream_t s) {
+  if (prec == 0) launch_wgrad_ph_t<F16>(a, s); else launch_wgrad_ph_t<BF16>(a, s);
 }
 
 void launch_fwd_gemm_ph(int prec, const FwdArgs& a, hipStream_t s) {

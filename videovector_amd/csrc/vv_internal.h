@@ -56,6 +56,7 @@ struct FwdArgs {
   int R_hint = 0;              // dedup mode: expected row count, sizes the tiles (0 = R)
   int32_t* seq_host = nullptr; // host-mapped word that receives `seq` (the step's index batch has been consumed), or null
   int32_t seq = 0;
+  int abl = 0;                 // timing studies only (VV_ABLATE): selects an ablated instantiation of the phase-staggered kernel
 };
 
 struct ScoreArgs {
@@ -120,6 +121,8 @@ struct WgradArgs {
   int S;                   // split-K factor
   int ksteps_per_split;    // BK-steps per split
   const int32_t* n_dev = nullptr;    // dedup mode: device count of valid K rows (overrides Rp / ksteps_per_split)
+  int32_t zero_row = 0;              // the table's all-zero row (K-tiles padded past a split's end read it)
+  int abl = 0;                       // as FwdArgs::abl
 };
 
 struct ReduceArgs {
