@@ -155,6 +155,22 @@ int vv_grads_device(vv_ctx* ctx, void** dev_ptr, int64_t* n_floats);
  * kernels launched afterwards and does not synchronise, so a host can alternate two buffers: one being
  * all-reduced while the next iteration's gradients are written to the other. */
 int vv_grads_bind(vv_ctx* ctx, void* dev_ptr);
+/* ---- data parallel: one process per GPU, the flat gradient buffer summed over the ranks between the backward pass
+ * and the update.  No counterpart in the reference (single device: Caffe::SetDevice, common.cpp:127-145).
+ *   vv_comm_init      after vv_params_set.  transport VV_COMM_RCCL: RCCL (loaded at this call; the copy a host framework
+ *                     already loaded is reused); rank 0 writes the communicator id to the file id_path, the others wait
+ *                     for it.  VV_COMM_SHM: a host-staged all-reduce through POSIX shared memory named after id_path, for
+ *                     tests of the multi-rank path on a box with one device.  Pair it with cfg.global_count = the
+ *                     global B * Nn, and give every rank its items of the same global batch (vv_batch_ring_next).
+ *   vv_allreduce_grads  sums [dW | db] over the ranks on the context's communication stream and makes the compute stream
+ *                     wait for it (the host does not block with RCCL).  vv_apply_update calls it when the caller has not.
+ *   vv_comm_overlap   on: vv_forward_backward produces dW one 256-row block at a time and all-reduces each finished
+ *                     block while the next one is computed (same sums, same update: exact synchronous SGD). */
+enum { VV_COMM_RCCL = 0, VV_COMM_SHM = 1 };
+int vv_comm_init(vv_ctx* ctx, int32_t world, int32_t rank, const char* id_path, int32_t transport);
+int vv_comm_overlap(vv_ctx* ctx, int on);
+int vv_allreduce_grads(vv_ctx* ctx);
+int vv_comm_destroy(vv_ctx* ctx);
 /* InnerProductLayer blobs_[0]/[1] cpu_diff() after Backward (inner_product_layer.cpp:76-98). */
 int vv_grads_get(vv_ctx* ctx, float* dW, float* db);
 

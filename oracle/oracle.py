@@ -204,6 +204,32 @@ def sgemm(transA, transB, A, B, alpha=1.0, beta=0.0, Cmat=None):
     return out
 
 
+def sgemm_isa(force_avx2=None):
+    """Micro-kernel of the built-in sgemm on this CPU; force_avx2=True / False selects / releases the AVX2 kernel."""
+    L = lib()
+    L.orc_sgemm_isa.restype = C.c_char_p
+    if force_avx2 is not None:
+        L.orc_sgemm_force_isa(C.c_int(1 if force_avx2 else 0))
+    return L.orc_sgemm_isa().decode()
+
+
+def gemm_gflops(R, D, F, reps=2):
+    """GFLOP/s of the two fc7 GEMMs of one iteration through orc_sgemm (whatever BLAS is selected): the forward
+    X[R][F] W[D][F]^T (inner_product_layer.cpp:62-64) and the weight gradient dY[R][D]^T X[R][F] (:85-86)."""
+    import time
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((R, F), dtype=np.float32)
+    W = rng.standard_normal((D, F), dtype=np.float32)
+    dY = rng.standard_normal((R, D), dtype=np.float32)
+    sgemm(False, True, X[:64], W); sgemm(True, False, dY[:64], X[:64])
+    best_f = best_w = 1e30
+    for _ in range(reps):
+        t0 = time.perf_counter(); sgemm(False, True, X, W); best_f = min(best_f, time.perf_counter() - t0)
+        t0 = time.perf_counter(); sgemm(True, False, dY, X); best_w = min(best_w, time.perf_counter() - t0)
+    fl = 2.0 * R * D * F / 1e9
+    return {"forward": fl / best_f, "weight_gradient": fl / best_w, "kernel": "external cblas_sgemm" if lib().orc_has_blas() else sgemm_isa()}
+
+
 def set_blas(path):
     """Route orc_sgemm through an external BLAS (a shared object exporting cblas_sgemm); None = built-in kernel.
     Returns True when the library was loaded."""

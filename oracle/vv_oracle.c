@@ -347,47 +347,169 @@ int orc_get_threads(void) {
 #endif
 }
 
-#define MR 4
-#define NR 32
-/* C[M][N] (+)= alpha * A[M][K] * Bp[K][N] with Bp packed row-major (k-major).  The inner body is
- * an outer-product update over an MR x NR register block, vectorised by the compiler. */
-static void gemm_nn_packed(int M, int N, int K, float alpha, const float* A, int lda, int a_trans,
-                           const float* Bp, float beta, float* C) {
-  const int nt = orc_get_threads();
-#pragma omp parallel for schedule(dynamic, 1) num_threads(nt)
-  for (int i0 = 0; i0 < M; i0 += MR) {
-    const int mr = M - i0 < MR ? M - i0 : MR;
-    for (int j0 = 0; j0 < N; j0 += NR) {
-      const int nr = N - j0 < NR ? N - j0 : NR;
-      float acc[MR][NR];
-      for (int i = 0; i < MR; ++i) for (int j = 0; j < NR; ++j) acc[i][j] = 0.f;
-      if (mr == MR && nr == NR) {
-        for (int k = 0; k < K; ++k) {
-          const float* bp = Bp + (size_t)k * N + j0;
-          float a[MR];
-          for (int i = 0; i < MR; ++i)
-            a[i] = a_trans ? A[(size_t)k * lda + i0 + i] : A[(size_t)(i0 + i) * lda + k];
-          for (int i = 0; i < MR; ++i) {
-#pragma omp simd
-            for (int j = 0; j < NR; ++j) acc[i][j] += a[i] * bp[j];
-          }
-        }
-      } else {
-        for (int k = 0; k < K; ++k) {
-          const float* bp = Bp + (size_t)k * N + j0;
-          for (int i = 0; i < mr; ++i) {
-            const float a = a_trans ? A[(size_t)k * lda + i0 + i] : A[(size_t)(i0 + i) * lda + k];
-            for (int j = 0; j < nr; ++j) acc[i][j] += a * bp[j];
-          }
-        }
-      }
-      for (int i = 0; i < mr; ++i) {
-        float* c = C + (size_t)(i0 + i) * N + j0;
-        if (beta == 0.f) for (int j = 0; j < nr; ++j) c[j] = alpha * acc[i][j];
-        else for (int j = 0; j < nr; ++j) c[j] = alpha * acc[i][j] + beta * c[j];
-      }
+/* Blocked, packed sgemm in the GotoBLAS / BLIS arrangement -- what an OpenBLAS or MKL build of the reference would
+ * run for caffe_cpu_gemm (math_functions.cpp:12-21), self-contained so that the CPU baseline does not depend on what
+ * BLAS the box happens to ship:
+ *   for jc (NC columns) / pc (KC deep): pack B[pc.., jc..] once into NR-wide column panels (all threads);
+ *     tasks = (MC-row block of A) x (chunk of B panels): pack the A block into MR-tall row panels (thread-private),
+ *     then MR x NR register-blocked micro-kernels, C accumulated in place.
+ * Micro-kernels: AVX-512 (8 x 32 in 16 zmm accumulators) when the CPU has it, else AVX2 + FMA (6 x 16 in 12 ymm),
+ * chosen at run time. */
+#include <immintrin.h>
+
+#define GK_KC 384
+#define GK_MC 96             /* multiple of both micro-kernels' MR (8 and 6) */
+#define GK_NC 4096
+
+typedef void (*ukr_fn)(int kc, const float* ap, const float* bp, float* c, int ldc, int first);
+
+/* 8 x 32: ap = kc steps of 8 values, bp = kc steps of 32 values; c += (first ? 0 : c) + ap^T bp */
+__attribute__((target("avx512f"))) static void ukr_avx512(int kc, const float* ap, const float* bp, float* c, int ldc, int first) {
+  __m512 acc[8][2];
+  for (int i = 0; i < 8; ++i) { acc[i][0] = _mm512_setzero_ps(); acc[i][1] = _mm512_setzero_ps(); }
+  for (int k = 0; k < kc; ++k) {
+    const __m512 b0 = _mm512_loadu_ps(bp), b1 = _mm512_loadu_ps(bp + 16);
+#pragma GCC unroll 8
+    for (int i = 0; i < 8; ++i) {
+      const __m512 a = _mm512_set1_ps(ap[i]);
+      acc[i][0] = _mm512_fmadd_ps(a, b0, acc[i][0]);
+      acc[i][1] = _mm512_fmadd_ps(a, b1, acc[i][1]);
+    }
+    ap += 8; bp += 32;
+  }
+  for (int i = 0; i < 8; ++i) {
+    float* ci = c + (size_t)i * ldc;
+    if (first) { _mm512_storeu_ps(ci, acc[i][0]); _mm512_storeu_ps(ci + 16, acc[i][1]); }
+    else {
+      _mm512_storeu_ps(ci, _mm512_add_ps(_mm512_loadu_ps(ci), acc[i][0]));
+      _mm512_storeu_ps(ci + 16, _mm512_add_ps(_mm512_loadu_ps(ci + 16), acc[i][1]));
     }
   }
+}
+/* 6 x 16 */
+__attribute__((target("avx2,fma"))) static void ukr_avx2(int kc, const float* ap, const float* bp, float* c, int ldc, int first) {
+  __m256 acc[6][2];
+  for (int i = 0; i < 6; ++i) { acc[i][0] = _mm256_setzero_ps(); acc[i][1] = _mm256_setzero_ps(); }
+  for (int k = 0; k < kc; ++k) {
+    const __m256 b0 = _mm256_loadu_ps(bp), b1 = _mm256_loadu_ps(bp + 8);
+#pragma GCC unroll 6
+    for (int i = 0; i < 6; ++i) {
+      const __m256 a = _mm256_broadcast_ss(ap + i);
+      acc[i][0] = _mm256_fmadd_ps(a, b0, acc[i][0]);
+      acc[i][1] = _mm256_fmadd_ps(a, b1, acc[i][1]);
+    }
+    ap += 6; bp += 16;
+  }
+  for (int i = 0; i < 6; ++i) {
+    float* ci = c + (size_t)i * ldc;
+    if (first) { _mm256_storeu_ps(ci, acc[i][0]); _mm256_storeu_ps(ci + 8, acc[i][1]); }
+    else {
+      _mm256_storeu_ps(ci, _mm256_add_ps(_mm256_loadu_ps(ci), acc[i][0]));
+      _mm256_storeu_ps(ci + 8, _mm256_add_ps(_mm256_loadu_ps(ci + 8), acc[i][1]));
+    }
+  }
+}
+
+static int g_force_isa = 0;                                      /* tests: 1 = AVX2 kernel even on an AVX-512 machine */
+void orc_sgemm_force_isa(int v) { g_force_isa = v; }
+const char* orc_sgemm_isa(void) {
+  return (!g_force_isa && __builtin_cpu_supports("avx512f")) ? "avx512f 8x32" : "avx2+fma 6x16";
+}
+
+/* op(A)[M][K] (a_trans: stored [K][M]) times op(B)[K][N] (b_trans: stored [N][K]) -> C[M][N] row-major, ldc = N.
+ * C = alpha * op(A) op(B) + beta * C. */
+static void gemm_blocked(int M, int N, int K, float alpha, const float* A, int a_trans, const float* B, int b_trans,
+                         float beta, float* C) {
+  const int nt = orc_get_threads();
+  const int use512 = !g_force_isa && __builtin_cpu_supports("avx512f");
+  const int MR = use512 ? 8 : 6, NR = use512 ? 32 : 16;
+  const ukr_fn ukr = use512 ? ukr_avx512 : ukr_avx2;
+  /* beta first, then plain accumulation (alpha is folded into the packed A) */
+  if (beta == 0.f) {
+#pragma omp parallel for num_threads(nt)
+    for (int i = 0; i < M; ++i) memset(C + (size_t)i * N, 0, sizeof(float) * (size_t)N);
+  } else if (beta != 1.f) {
+#pragma omp parallel for num_threads(nt)
+    for (int i = 0; i < M; ++i) for (int j = 0; j < N; ++j) C[(size_t)i * N + j] *= beta;
+  }
+  const int nc_max = N < GK_NC ? N : GK_NC;
+  const int npan_max = (nc_max + NR - 1) / NR;
+  float* Bp = (float*)aligned_alloc(64, sizeof(float) * (size_t)GK_KC * npan_max * NR + 64);
+  const int mblocks = (M + GK_MC - 1) / GK_MC;
+#pragma omp parallel num_threads(nt)
+  {
+    float* Ap = (float*)aligned_alloc(64, sizeof(float) * (size_t)GK_KC * (GK_MC + 8) + 64);
+    float tile[8 * 32];
+    for (int jc = 0; jc < N; jc += GK_NC) {
+      const int nc = N - jc < GK_NC ? N - jc : GK_NC;
+      const int npan = (nc + NR - 1) / NR;
+      /* enough tasks for every thread even when M is one or two blocks (the weight gradient: M = D) */
+      int chunks = (4 * nt + mblocks - 1) / mblocks;
+      if (chunks > npan) chunks = npan;
+      if (chunks < 1) chunks = 1;
+      const int pan_per = (npan + chunks - 1) / chunks;
+      for (int pc = 0; pc < K; pc += GK_KC) {
+        const int kc = K - pc < GK_KC ? K - pc : GK_KC;
+#pragma omp for schedule(static)
+        for (int jp = 0; jp < npan; ++jp) {                       /* pack B: panel jp = kc x NR, k-major */
+          float* dst = Bp + (size_t)jp * GK_KC * NR;
+          const int j0 = jc + jp * NR, nr = N - j0 < NR ? N - j0 : NR;
+          if (!b_trans) {
+            for (int k = 0; k < kc; ++k) {
+              const float* src = B + (size_t)(pc + k) * N + j0;
+              for (int j = 0; j < nr; ++j) dst[(size_t)k * NR + j] = src[j];
+              for (int j = nr; j < NR; ++j) dst[(size_t)k * NR + j] = 0.f;
+            }
+          } else {
+            for (int j = 0; j < nr; ++j) {
+              const float* src = B + (size_t)(j0 + j) * K + pc;
+              for (int k = 0; k < kc; ++k) dst[(size_t)k * NR + j] = src[k];
+            }
+            for (int j = nr; j < NR; ++j) for (int k = 0; k < kc; ++k) dst[(size_t)k * NR + j] = 0.f;
+          }
+        }                                                         /* implicit barrier */
+#pragma omp for schedule(dynamic, 1)
+        for (int task = 0; task < mblocks * chunks; ++task) {
+          const int ib = task / chunks, ch = task % chunks;
+          const int i0 = ib * GK_MC, mc = M - i0 < GK_MC ? M - i0 : GK_MC;
+          const int mpan = (mc + MR - 1) / MR;
+          for (int ip = 0; ip < mpan; ++ip) {                     /* pack A: panel ip = kc x MR, k-major, times alpha */
+            float* dst = Ap + (size_t)ip * GK_KC * MR;
+            const int r0 = i0 + ip * MR, mr = M - r0 < MR ? M - r0 : MR;
+            if (!a_trans) {
+              for (int i = 0; i < mr; ++i) {
+                const float* src = A + (size_t)(r0 + i) * K + pc;
+                for (int k = 0; k < kc; ++k) dst[(size_t)k * MR + i] = alpha * src[k];
+              }
+              for (int i = mr; i < MR; ++i) for (int k = 0; k < kc; ++k) dst[(size_t)k * MR + i] = 0.f;
+            } else {
+              for (int k = 0; k < kc; ++k) {
+                const float* src = A + (size_t)(pc + k) * M + r0;
+                for (int i = 0; i < mr; ++i) dst[(size_t)k * MR + i] = alpha * src[i];
+                for (int i = mr; i < MR; ++i) dst[(size_t)k * MR + i] = 0.f;
+              }
+            }
+          }
+          const int jp0 = ch * pan_per, jp1 = jp0 + pan_per < npan ? jp0 + pan_per : npan;
+          for (int jp = jp0; jp < jp1; ++jp) {
+            const int j0 = jc + jp * NR, nr = N - j0 < NR ? N - j0 : NR;
+            const float* bp = Bp + (size_t)jp * GK_KC * NR;
+            for (int ip = 0; ip < mpan; ++ip) {
+              const int r0 = i0 + ip * MR, mr = M - r0 < MR ? M - r0 : MR;
+              const float* ap = Ap + (size_t)ip * GK_KC * MR;
+              if (mr == MR && nr == NR) ukr(kc, ap, bp, C + (size_t)r0 * N + j0, N, 0);
+              else {                                              /* edge: through a full-size scratch tile */
+                ukr(kc, ap, bp, tile, NR, 1);
+                for (int i = 0; i < mr; ++i) for (int j = 0; j < nr; ++j) C[(size_t)(r0 + i) * N + j0 + j] += tile[i * NR + j];
+              }
+            }
+          }
+        }                                                         /* implicit barrier: Bp is repacked next */
+      }
+    }
+    free(Ap);
+  }
+  free(Bp);
 }
 
 /* The reference delegates its GEMM to an external BLAS (cblas_sgemm, math_functions.cpp:12-21; which library is
@@ -414,21 +536,7 @@ void orc_sgemm(int transA, int transB, int M, int N, int K, float alpha, const f
     g_cblas_sgemm(101, transA ? 112 : 111, transB ? 112 : 111, M, N, K, alpha, A, transA ? M : K, B, transB ? K : N, beta, C, N);
     return;
   }
-  const float* Bp = B;
-  float* tmp = NULL;
-  if (transB) {   /* B given as [N][K]: pack to [K][N] */
-    tmp = (float*)malloc(sizeof(float) * (size_t)K * N);
-    const int nt = orc_get_threads();
-#pragma omp parallel for num_threads(nt)
-    for (int k0 = 0; k0 < K; k0 += 32)
-      for (int n = 0; n < N; ++n) {
-        const int k1 = k0 + 32 < K ? k0 + 32 : K;
-        for (int k = k0; k < k1; ++k) tmp[(size_t)k * N + n] = B[(size_t)n * K + k];
-      }
-    Bp = tmp;
-  }
-  gemm_nn_packed(M, N, K, alpha, A, transA ? M : K, transA, Bp, beta, C);
-  free(tmp);
+  gemm_blocked(M, N, K, alpha, A, transA, B, transB, beta, C);
 }
 
 /* ============================================================ layers ======================== */

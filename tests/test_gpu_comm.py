@@ -1,0 +1,122 @@
+"""The data-parallel exchange through the C ABI (vv_comm_init / vv_allreduce_grads / vv_comm_overlap):
+
+  * two ranks = two PROCESSES on the one visible GPU, host-staged shared-memory transport (RCCL refuses two ranks on one
+    device): both all-reduce schedules -- whole buffer after the backward pass ("sync") and 256-row blocks of dW while
+    the next block is computed ("overlap") -- give bit-identical parameters on both ranks, equal to each other, and the
+    same step as ONE process on the global batch (sums reassociated: <= 5e-4), over three iterations;
+  * one rank over real RCCL: the dlopen'ed library, the communication stream and the event joins run on the GPU box.
+"""
+import multiprocessing as mp
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+B, C, Nn, F, D, ITERS = 64, 5, 10, 512, 512, 3
+
+
+def _case():
+    from videovector_amd.synth import SyntheticVideos, init_weights
+    ds = SyntheticVideos(seed=21, n_videos=300)
+    W, b = init_weights(21, D, F, std=0.02)
+    return ds, W, b
+
+
+def _batches(ds, world):
+    import videovector_amd as vv
+    s = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, batch_size=world * B, context_size=C, num_negative_samples=Nn,
+                   max_buffer_size=1000, negative_swap_percentage=50)
+    out = [s.next() for _ in range(ITERS)]
+    s.close()
+    return out
+
+
+def _rank_main(rank, world, id_path, overlap, transport, q):
+    import videovector_amd as vv
+    ds, W, b = _case()
+    eng = vv.Engine(0, "f16")
+    eng.table_synth(ds.seed, ds.n_rows, F)
+    eng.params_set(W, b)
+    eng.comm_init(world, rank, id_path, transport)
+    eng.comm_overlap(overlap)
+    cfg = vv.StepConfig(B, C, Nn, global_count=world * B * Nn, lr=0.05)
+    losses = []
+    for g in _batches(ds, world):
+        eng.forward_backward(cfg, g[rank * B:(rank + 1) * B])
+        eng.apply_update(cfg)                      # all-reduces first
+        losses.append(eng.loss()[0])
+    Wn, bn, hW, hb = eng.params_get()
+    eng.comm_destroy()
+    q.put((rank, Wn, bn, hW, losses))
+
+
+def _run_world(world, overlap, transport="shm"):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    id_path = os.path.join(tempfile.gettempdir(), "vv_comm_test_%d_%d_%d" % (os.getpid(), world, int(overlap)))
+    if os.path.exists(id_path):
+        os.unlink(id_path)
+    procs = [ctx.Process(target=_rank_main, args=(r, world, id_path, overlap, transport, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r = q.get(timeout=300)
+        res[r[0]] = r[1:]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+def rel(a, r):
+    return float(np.linalg.norm(a.astype(np.float64) - r) / max(np.linalg.norm(r), 1e-30))
+
+
+def test_two_ranks_on_one_gpu_match_the_global_batch():
+    import videovector_amd as vv
+    ds, W, b = _case()
+    # the single-process reference: the same three global batches in one call each
+    eng = vv.Engine(0, "f16")
+    eng.table_synth(ds.seed, ds.n_rows, F)
+    eng.params_set(W, b)
+    cfg = vv.StepConfig(2 * B, C, Nn, lr=0.05)
+    ref_losses = []
+    for g in _batches(ds, 2):
+        eng.step(cfg, g)
+        ref_losses.append(eng.loss()[0])
+    W1, b1, hW1, _ = eng.params_get()
+    eng.close()
+    out = {}
+    for overlap in (False, True):
+        res = _run_world(2, overlap)
+        (Wa, ba, ha, la), (Wb, bb, hb_, lb) = res[0], res[1]
+        assert np.array_equal(Wa, Wb) and np.array_equal(ba, bb) and np.array_equal(ha, hb_), "ranks diverged"
+        e = rel(Wa - W, W1 - W)
+        print("COMM overlap=%s: 3-step parameter change vs one process on the global batch %.3e; losses %s / %s vs %s"
+              % (overlap, e, la, lb, ref_losses))
+        assert e <= 5e-4 and rel(ba - b, b1 - b) <= 5e-4
+        for k in range(ITERS):                     # global loss = mean of the shard losses
+            assert abs(0.5 * (la[k] + lb[k]) - ref_losses[k]) <= 1e-4 * ref_losses[k]
+        out[overlap] = (Wa, ba)
+    # the two schedules reduce the same numbers in the same order: identical results
+    assert np.array_equal(out[False][0], out[True][0]) and np.array_equal(out[False][1], out[True][1])
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_one_rank_over_real_rccl(overlap):
+    import videovector_amd as vv
+    ds, W, b = _case()
+    g = _batches(ds, 1)
+    ref = vv.Engine(0, "f16")
+    ref.table_synth(ds.seed, ds.n_rows, F); ref.params_set(W, b)
+    cfg = vv.StepConfig(B, C, Nn, lr=0.05)
+    for x in g:
+        ref.step(cfg, x)
+    W0 = ref.params_get()[0]
+    ref.close()
+    res = _run_world(1, overlap, transport="rccl")
+    assert np.array_equal(res[0][0], W0), "a one-rank RCCL all-reduce must leave the gradients unchanged"

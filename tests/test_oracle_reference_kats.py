@@ -232,3 +232,26 @@ def test_retrieval_stats_options(oracle):
     a = oracle.retrieval_stats(feat, vids, cls, True)
     b = oracle.retrieval_stats(feat, vids, cls, False)
     assert all(0 <= x <= 1 for x in a + b) and a != b
+
+
+@pytest.mark.parametrize("force_avx2", [False, True])
+def test_blocked_sgemm_edges_and_both_kernels(oracle, force_avx2):
+    """The blocked sgemm of the CPU baseline: every transpose combination, sizes that are not multiples of the register
+    block, the cache blocks or the thread count, alpha / beta, on the AVX-512 kernel (when the CPU has it) and the AVX2 one."""
+    try:
+        oracle.sgemm_isa(force_avx2=force_avx2)
+        rng = np.random.default_rng(5)
+        for (M, N, K) in [(1, 1, 1), (7, 33, 5), (97, 50, 401), (200, 4100, 37), (13, 17, 800), (64, 64, 64)]:
+            for ta in (False, True):
+                for tb in (False, True):
+                    A = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
+                    B = rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32)
+                    C0 = rng.standard_normal((M, N)).astype(np.float32)
+                    ref = 0.75 * ((A.T if ta else A).astype(np.float64) @ (B.T if tb else B).astype(np.float64)) - 1.5 * C0
+                    out = oracle.sgemm(ta, tb, A, B, alpha=0.75, beta=-1.5, Cmat=C0.copy())
+                    assert np.abs(out - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (M, N, K, ta, tb)
+                    out0 = oracle.sgemm(ta, tb, A, B)
+                    ref0 = (A.T if ta else A).astype(np.float64) @ (B.T if tb else B).astype(np.float64)
+                    assert np.abs(out0 - ref0).max() <= 2e-5 * max(1.0, np.abs(ref0).max())
+    finally:
+        oracle.sgemm_isa(force_avx2=False)

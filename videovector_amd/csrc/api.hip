@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "vv_internal.h"
+#include "vv_comm.h"
 
 namespace vv { void set_wgrad_tr(bool on); void set_gemm_variant(int v); void set_ablate(int v); void set_fwd_mi(int v); void set_score_reg(int v); void set_wgrad_sched(int v); void set_ph_mq(int v); int wgrad_max_ksteps_per_split(); int gemm_variant(); bool ablate_on(); }
 using namespace vv;
@@ -84,6 +85,12 @@ struct vv_ctx {
   size_t stage_bytes = 0; int32_t stage_next = 0;
   int32_t* seq_host = nullptr;              // pinned + mapped: the forward GEMM stores the step's sequence number here,
   int32_t* seq_host_dev = nullptr;          //   i.e. "the kernels that read this step's index batch have finished"
+  // data-parallel gradient exchange (comm.hip)
+  vv::Comm* comm = nullptr;
+  bool comm_overlap = false;        // all-reduce row blocks of dW while the weight-gradient kernel produces the next
+  bool grads_pending = false;       // a backward pass has produced gradients that have not been all-reduced / joined yet
+  bool grads_chunked = false;       // ... and their all-reduce is already in flight on the communication stream
+  hipEvent_t ev_chunk = nullptr;
   // profiling
   bool prof = false;
   int prof_every = 1;               // record every prof_every-th forward/backward + update (vv_profile_enable's argument)
@@ -248,6 +255,8 @@ int vv_destroy(vv_ctx* c) {
   dfree(c->table); dfree(c->patch_desc); dfree(c->W); dfree(c->b); dfree(c->hW); dfree(c->hb); dfree(c->Wh);
   dfree(c->scales); dfree(c->wmax_blocks); dfree(c->grads_own); dfree(c->mask); dfree(c->loss2);
   dfree(c->dd_key); dfree(c->dd_info);
+  if (c->comm) vv::comm_destroy(c->comm);
+  if (c->ev_chunk) (void)hipEventDestroy(c->ev_chunk);
   if (c->U_host) (void)hipHostFree(c->U_host);
   for (int i = 0; i < vv_ctx::kStage; ++i)
     if (c->stage_host[i]) (void)hipHostFree(c->stage_host[i]);
@@ -628,14 +637,39 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   wa.dYh = dd ? c->dYu : c->dYh; wa.table = c->table; wa.rows = dd ? c->dd_uniq : c->rows; wa.slabs = c->slabs;
   wa.Rp = c->Rp; wa.Dp = c->Dp; wa.Fp = c->Fp; wa.S = c->S; wa.ksteps_per_split = c->kps;
   wa.n_dev = dd ? c->dd_info : nullptr; wa.zero_row = (int32_t)c->n_rows;
-  PROFILED(c, "wgrad_gemm", launch_wgrad_gemm(c->prec, wa, s));
-
   ReduceArgs ra;
   ra.slabs = c->slabs; ra.S = c->S; ra.Dp = c->Dp; ra.Fp = c->Fp; ra.dbp = c->dbp; ra.B = B;
   ra.scales = c->scales; ra.sg = c->sg; ra.grads = c->grads; ra.D = D; ra.F = c->F;
   ra.ip_scale = cfg->ip_regularization > 0.f ? 1.f + cfg->ip_regularization * 0.5f : 1.f;     // inner_product_layer.cpp:80-90
   ra.loss_part = c->loss_part; ra.viol_part = c->viol_part; ra.loss_scale = cfg->loss_weight / (float)count; ra.loss_out = c->loss2;
-  PROFILED(c, "reduce", launch_reduce(ra, s));
+
+  // Data-parallel overlap (exact synchronous SGD): the weight gradient is produced one 256-row block of dW at a time
+  // (wgrad + slab reduction of that block); while the next block is being computed, the finished one -- a contiguous
+  // piece of the flat gradient buffer -- is all-reduced on the communication stream.  db and the loss scalars ride with
+  // the last block.  Needs the phase-staggered weight-gradient kernel (it can run a subset of the M tiles).
+  const int tilesM = c->Dp / BM;
+  const bool chunked = c->comm && c->comm_overlap && tilesM > 1 &&
+                       (gemm_variant() == 5 || gemm_variant() == 6) && !ablate_on();
+  if (!chunked) {
+    PROFILED(c, "wgrad_gemm", launch_wgrad_gemm(c->prec, wa, s));
+    PROFILED(c, "reduce", launch_reduce(ra, s));
+  } else {
+    for (int tm = 0; tm < tilesM; ++tm) {
+      const int d0 = tm * BM;
+      if (d0 >= D) break;
+      const int dn = std::min(BM, D - d0);
+      const bool last = d0 + dn >= D;
+      wa.tm_begin = tm; wa.tm_count = 1;
+      ra.d_begin = d0; ra.d_count = dn; ra.parts = last ? 3 : 1;
+      if (tm == 0) { PROFILED(c, "wgrad_gemm", launch_wgrad_gemm(c->prec, wa, s)); PROFILED(c, "reduce", launch_reduce(ra, s)); }
+      else { launch_wgrad_gemm(c->prec, wa, s); launch_reduce(ra, s); }
+      HIPCHK(hipEventRecord(c->ev_chunk, s));
+      const size_t off = (size_t)d0 * c->F, n = (size_t)dn * c->F + (last ? (size_t)D : 0);
+      if (vv::comm_allreduce(c->comm, c->grads, off, n, c->ev_chunk)) return fail(VV_ERR_HIP, "all-reduce: %s", vv::comm_error(c->comm));
+    }
+  }
+  c->grads_pending = c->comm != nullptr;       // (a one-rank communicator still runs its collective: same code path)
+  c->grads_chunked = chunked;
 
   HIPCHK(hipGetLastError());
   c->have_fwd = true;
@@ -729,6 +763,7 @@ int vv_apply_update(vv_ctx* c, const vv_step_cfg* cfg) {
   if (rc) return rc;
   if (!c->have_fwd) return fail(VV_ERR_STATE, "vv_apply_update: no gradients (call vv_forward_backward)");
   HIPCHK(hipSetDevice(c->device));
+  if (c->grads_pending && (rc = vv_allreduce_grads(c))) return rc;     // data-parallel: the update consumes the SUM over the ranks
   SgdArgs a;
   a.W = c->W; a.b = c->b; a.hW = c->hW; a.hb = c->hb; a.grads = c->grads; a.Wh = c->Wh; a.scales = c->scales; a.wmax_blocks = c->wmax_blocks;
   a.D = c->D; a.F = c->F; a.Dp = c->Dp; a.Fp = c->Fp;
@@ -954,6 +989,51 @@ int vv_retrieval_stats(vv_ctx* c, const float* feat, int32_t n, int32_t dim, con
   if (mean_ap) *mean_ap = (float)(s_ap / npos);
   if (hit1) *hit1 = (float)(s_1 / npos);
   if (hit5) *hit5 = (float)(s_5 / npos);
+  return VV_OK;
+}
+
+// ------------------------------------------------------------------------------- data parallel -
+int vv_comm_init(vv_ctx* c, int32_t world, int32_t rank, const char* id_path, int32_t transport) {
+  if (!c) return fail(VV_ERR_ARG, "vv_comm_init: ctx is NULL");
+  if (world < 1 || rank < 0 || rank >= world) return fail(VV_ERR_ARG, "vv_comm_init: rank %d of %d", rank, world);
+  if (world > 1 && (!id_path || !*id_path)) return fail(VV_ERR_ARG, "vv_comm_init: id_path is required for world > 1");
+  if (transport != VV_COMM_RCCL && transport != VV_COMM_SHM) return fail(VV_ERR_ARG, "vv_comm_init: unknown transport %d", transport);
+  if (!c->W) return fail(VV_ERR_STATE, "vv_comm_init: set the parameters first (they size the gradient buffer)");
+  if (c->comm) return fail(VV_ERR_STATE, "vv_comm_init: a communicator already exists");
+  HIPCHK(hipSetDevice(c->device));
+  std::string err;
+  c->comm = vv::comm_create(world, rank, id_path ? id_path : "", transport, (size_t)c->D * c->F + c->D, &err);
+  if (!c->comm) return fail(VV_ERR_HIP, "vv_comm_init: %s", err.c_str());
+  if (!c->ev_chunk) HIPCHK(hipEventCreateWithFlags(&c->ev_chunk, hipEventDisableTiming));
+  return VV_OK;
+}
+
+int vv_comm_overlap(vv_ctx* c, int on) {
+  if (!c) return fail(VV_ERR_ARG, "vv_comm_overlap: ctx is NULL");
+  c->comm_overlap = on != 0;
+  return VV_OK;
+}
+
+int vv_allreduce_grads(vv_ctx* c) {
+  if (!c) return fail(VV_ERR_ARG, "vv_allreduce_grads: ctx is NULL");
+  if (!c->comm) { c->grads_pending = false; return VV_OK; }
+  if (!c->have_fwd) return fail(VV_ERR_STATE, "vv_allreduce_grads: no gradients (call vv_forward_backward)");
+  if (!c->grads_pending) return VV_OK;                         // already summed
+  HIPCHK(hipSetDevice(c->device));
+  if (!c->grads_chunked) {                                     // the whole buffer, after everything queued on the compute stream
+    HIPCHK(hipEventRecord(c->ev_chunk, c->stream));
+    if (vv::comm_allreduce(c->comm, c->grads, 0, (size_t)c->D * c->F + c->D, c->ev_chunk))
+      return fail(VV_ERR_HIP, "all-reduce: %s", vv::comm_error(c->comm));
+  }
+  HIPCHK(hipStreamWaitEvent(c->stream, vv::comm_done_event(c->comm), 0));   // the update waits for the sum; the host does not
+  c->grads_pending = false; c->grads_chunked = false;
+  return VV_OK;
+}
+
+int vv_comm_destroy(vv_ctx* c) {
+  if (!c) return VV_OK;
+  if (c->comm) { (void)hipStreamSynchronize(c->stream); vv::comm_destroy(c->comm); c->comm = nullptr; }
+  c->grads_pending = c->grads_chunked = false;
   return VV_OK;
 }
 

@@ -1,0 +1,223 @@
+// comm.hip -- the data-parallel exchange step of the videovec path: ONE fp32 all-reduce (sum) of the flat [dW | db]
+// gradient buffer per iteration, between the backward pass and the update.  The reference has nothing
+// to mirror (single device, src/caffe/common.cpp:127-145); this is the north star's "RCCL all-reduce of the projection
+// gradients over xGMI ... on a second HIP stream".
+//
+//   VV_COMM_RCCL   librccl, one process per GPU.  The library is dlopen'ed (the copy a host framework such as PyTorch has
+//                  already loaded is reused, so the process keeps ONE collective runtime); rank 0 writes the
+//                  ncclUniqueId to id_path (+ ".tmp" and rename), the other ranks wait for the file.
+//   VV_COMM_SHM    a host staged all-reduce through a POSIX shared-memory object named after id_path: every rank copies
+//                  its buffer out, all ranks add the world's buffers in rank order (bit-identical results on every
+//                  rank), copy back.  For tests of the N > 1 path on a box with ONE device (RCCL refuses two ranks on
+//                  one device); never the benchmark's transport.
+//
+// The collective runs on a communication stream owned by the context; events join it with the compute stream, the
+// host never blocks (RCCL transport).
+#include <cerrno>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <atomic>
+
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include "vv_comm.h"
+
+namespace vv {
+
+// ---- the handful of RCCL entry points this path needs (rccl.h: ncclGetUniqueId :187, ncclCommInitRank :220,
+// ncclAllReduce, ncclCommDestroy, ncclGetErrorString); declared here so that building the library does not need the
+// RCCL headers and loading it does not need librccl unless a communicator is created
+struct NcclUniqueId { char internal[128]; };
+typedef void* NcclComm;
+typedef int (*fn_GetUniqueId)(NcclUniqueId*);
+typedef int (*fn_CommInitRank)(NcclComm*, int, NcclUniqueId, int);
+typedef int (*fn_AllReduce)(const void*, void*, size_t, int /*dtype*/, int /*op*/, NcclComm, hipStream_t);
+typedef int (*fn_CommDestroy)(NcclComm);
+typedef const char* (*fn_GetErrorString)(int);
+enum { kNcclFloat32 = 7, kNcclSum = 0 };
+
+struct ShmHdr {
+  uint64_t magic;
+  int32_t world; int32_t pad_;
+  uint64_t n_floats;
+  alignas(64) std::atomic<int64_t> arrive;     // monotonic arrival counter (barrier generations of `world` arrivals)
+};
+static constexpr uint64_t kShmMagic = 0x5656434f4d4d3031ull;   // "VVCOMM01"
+
+struct Comm {
+  int world = 1, rank = 0, transport = VV_COMM_RCCL;
+  hipStream_t stream = nullptr;                 // communication stream
+  hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+  // RCCL
+  void* dl = nullptr; NcclComm nccl = nullptr;
+  fn_AllReduce AllReduce = nullptr; fn_CommDestroy CommDestroy = nullptr; fn_GetErrorString ErrStr = nullptr;
+  // shared-memory stub
+  ShmHdr* shm = nullptr; size_t shm_bytes = 0; std::string shm_name; float* stage = nullptr; size_t stage_floats = 0;
+  int64_t barriers = 0;
+  std::string err;
+};
+
+static size_t shm_hdr_bytes() { return 4096; }
+
+static bool shm_barrier(Comm* c, double timeout_s) {
+  const int64_t target = (++c->barriers) * c->world;
+  c->shm->arrive.fetch_add(1, std::memory_order_acq_rel);
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  while (c->shm->arrive.load(std::memory_order_acquire) < target) {
+    if (++spins > 1000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    if ((spins & 4095) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return false;
+  }
+  return true;
+}
+
+const char* comm_error(Comm* c) { return c ? c->err.c_str() : "no communicator"; }
+int comm_world(Comm* c) { return c ? c->world : 1; }
+int comm_rank(Comm* c) { return c ? c->rank : 0; }
+
+void comm_destroy(Comm* c) {
+  if (!c) return;
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->nccl && c->CommDestroy) c->CommDestroy(c->nccl);
+  if (c->shm) { munmap((void*)c->shm, c->shm_bytes); if (c->rank == 0) shm_unlink(c->shm_name.c_str()); }
+  if (c->stage) (void)hipHostFree(c->stage);
+  if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+  if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  // the dlopen handle is kept: unloading a collective runtime with live device state is not safe
+  delete c;
+}
+
+static std::string shm_name_of(const char* id_path) {
+  std::string n = "/vvcomm_";
+  for (const char* p = id_path; *p; ++p) n += (*p == '/' || *p == '.') ? '_' : *p;
+  if (n.size() > 200) n = "/vvcomm_" + n.substr(n.size() - 180);
+  return n;
+}
+
+Comm* comm_create(int world, int rank, const char* id_path, int transport, size_t n_floats, std::string* err) {
+  Comm* c = new Comm();
+  c->world = world; c->rank = rank; c->transport = transport;
+  auto fail = [&](const std::string& m) { if (err) *err = m; comm_destroy(c); return (Comm*)nullptr; };
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
+  if (hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
+  const double timeout_s = getenv("VV_COMM_TIMEOUT") ? atof(getenv("VV_COMM_TIMEOUT")) : 120.0;
+  if (transport == VV_COMM_RCCL) {
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", nullptr};
+    for (int i = 0; names[i] && !c->dl; ++i) c->dl = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+    if (!c->dl) return fail(std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?"));
+    auto GetUniqueId = (fn_GetUniqueId)dlsym(c->dl, "ncclGetUniqueId");
+    auto CommInitRank = (fn_CommInitRank)dlsym(c->dl, "ncclCommInitRank");
+    c->AllReduce = (fn_AllReduce)dlsym(c->dl, "ncclAllReduce");
+    c->CommDestroy = (fn_CommDestroy)dlsym(c->dl, "ncclCommDestroy");
+    c->ErrStr = (fn_GetErrorString)dlsym(c->dl, "ncclGetErrorString");
+    if (!GetUniqueId || !CommInitRank || !c->AllReduce || !c->CommDestroy) return fail("librccl lacks the expected entry points");
+    NcclUniqueId id;
+    memset(&id, 0, sizeof(id));
+    if (rank == 0) {
+      const int rc = GetUniqueId(&id);
+      if (rc != 0) return fail(std::string("ncclGetUniqueId: ") + (c->ErrStr ? c->ErrStr(rc) : "error"));
+      if (world > 1) {
+        const std::string tmp = std::string(id_path) + ".tmp";
+        FILE* f = fopen(tmp.c_str(), "wb");
+        if (!f || fwrite(&id, sizeof(id), 1, f) != 1) { if (f) fclose(f); return fail("cannot write " + tmp); }
+        fclose(f);
+        if (rename(tmp.c_str(), id_path) != 0) return fail(std::string("cannot rename to ") + id_path);
+      }
+    } else {
+      const auto t0 = std::chrono::steady_clock::now();
+      for (;;) {
+        FILE* f = fopen(id_path, "rb");
+        if (f) { const size_t n = fread(&id, sizeof(id), 1, f); fclose(f); if (n == 1) break; }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
+          return fail(std::string("timed out waiting for the communicator id file ") + id_path);
+        std::this_thread::sleep_for(std::chrono::milliseconds(5));
+      }
+    }
+    const int rc = CommInitRank(&c->nccl, world, id, rank);
+    if (rc != 0) return fail(std::string("ncclCommInitRank: ") + (c->ErrStr ? c->ErrStr(rc) : "error"));
+  } else if (transport == VV_COMM_SHM) {
+    c->shm_name = shm_name_of(id_path);
+    c->shm_bytes = shm_hdr_bytes() + (size_t)world * n_floats * sizeof(float);
+    int fd = -1;
+    if (rank == 0) {
+      shm_unlink(c->shm_name.c_str());
+      fd = shm_open(c->shm_name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+      if (fd < 0 || ftruncate(fd, (off_t)c->shm_bytes) != 0) { if (fd >= 0) close(fd); return fail("cannot create the shared-memory object " + c->shm_name); }
+    } else {
+      const auto t0 = std::chrono::steady_clock::now();
+      for (;;) {
+        fd = shm_open(c->shm_name.c_str(), O_RDWR, 0600);
+        struct stat st;
+        if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= c->shm_bytes) break;
+        if (fd >= 0) { close(fd); fd = -1; }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return fail("timed out waiting for " + c->shm_name);
+        std::this_thread::sleep_for(std::chrono::milliseconds(5));
+      }
+    }
+    void* mem = mmap(nullptr, c->shm_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (mem == MAP_FAILED) return fail("mmap of " + c->shm_name + " failed");
+    c->shm = (ShmHdr*)mem;
+    if (rank == 0) {
+      c->shm->world = world; c->shm->n_floats = n_floats; c->shm->arrive.store(0);
+      std::atomic_thread_fence(std::memory_order_release);
+      c->shm->magic = kShmMagic;
+    } else {
+      const auto t0 = std::chrono::steady_clock::now();
+      while (((volatile ShmHdr*)c->shm)->magic != kShmMagic) {
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return fail("shared-memory object never initialised");
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+      if (c->shm->world != world || c->shm->n_floats != n_floats) return fail("shared-memory object belongs to a different job shape");
+    }
+    c->stage_floats = n_floats;
+    if (hipHostMalloc((void**)&c->stage, n_floats * sizeof(float), hipHostMallocDefault) != hipSuccess) return fail("hipHostMalloc failed");
+    if (!shm_barrier(c, timeout_s)) return fail("ranks did not all arrive");
+  } else {
+    return fail("unknown transport");
+  }
+  return c;
+}
+
+// all-reduce(sum) of buf[0 .. n) in place.  `after`: the collective starts once this event (recorded on the compute
+// stream) has completed; on return ev_done (comm_done_event) marks its end on the communication stream.
+int comm_allreduce(Comm* c, float* buf, size_t off, size_t n, hipEvent_t after) {
+  if (after && hipStreamWaitEvent(c->stream, after, 0) != hipSuccess) { c->err = "hipStreamWaitEvent failed"; return -1; }
+  if (c->transport == VV_COMM_RCCL) {
+    const int rc = c->AllReduce(buf + off, buf + off, n, kNcclFloat32, kNcclSum, c->nccl, c->stream);
+    if (rc != 0) { c->err = std::string("ncclAllReduce: ") + (c->ErrStr ? c->ErrStr(rc) : "error"); return -1; }
+  } else {
+    const double timeout_s = getenv("VV_COMM_TIMEOUT") ? atof(getenv("VV_COMM_TIMEOUT")) : 120.0;
+    float* slabs = (float*)((unsigned char*)c->shm + shm_hdr_bytes());
+    float* mine = slabs + (size_t)c->rank * c->stage_floats + off;
+    if (hipMemcpyAsync(c->stage + off, buf + off, n * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "device-to-host copy failed"; return -1; }
+    memcpy(mine, c->stage + off, n * sizeof(float));
+    if (!shm_barrier(c, timeout_s)) { c->err = "all-reduce barrier timed out (a rank is missing)"; return -1; }
+    float* out = c->stage + off;
+    for (size_t i = 0; i < n; ++i) out[i] = slabs[off + i];                                   // rank 0 first, then in rank order
+    for (int r = 1; r < c->world; ++r) {
+      const float* s = slabs + (size_t)r * c->stage_floats + off;
+      for (size_t i = 0; i < n; ++i) out[i] += s[i];
+    }
+    if (!shm_barrier(c, timeout_s)) { c->err = "all-reduce barrier timed out (a rank is missing)"; return -1; }
+    if (hipMemcpyAsync(buf + off, out, n * sizeof(float), hipMemcpyHostToDevice, c->stream) != hipSuccess) { c->err = "host-to-device copy failed"; return -1; }
+  }
+  if (hipEventRecord(c->ev_done, c->stream) != hipSuccess) { c->err = "hipEventRecord failed"; return -1; }
+  return 0;
+}
+
+hipEvent_t comm_done_event(Comm* c) { return c->ev_done; }
+
+}  // namespace vv

@@ -507,15 +507,21 @@ __device__ __forceinline__ void reduce_loss(const ReduceArgs& a) {
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
-  if (blockIdx.x == gridDim.x - 1) { reduce_loss(a); return; }
-  if (blockIdx.x >= RED_DW_BLOCKS) { reduce_db(a, blockIdx.x - RED_DW_BLOCKS); return; }
+  int bid = blockIdx.x;
+  if (a.parts & 2) {
+    if (bid == (int)gridDim.x - 1) { reduce_loss(a); return; }
+    const int ndb = (a.D + 15) / 16;
+    if (bid >= (int)gridDim.x - 1 - ndb) { reduce_db(a, bid - ((int)gridDim.x - 1 - ndb)); return; }
+  }
+  if (!(a.parts & 1)) return;
   const float inv = a.ip_scale / (a.sg * a.scales->sx);
   const int64_t slab_sz = (int64_t)a.Dp * a.Fp;
+  const int d0 = a.d_begin, dn = a.d_count > 0 ? a.d_count : a.D;
   if (VEC) {
     const int f4 = a.F / 4;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)a.D * f4;
+    for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < (int64_t)dn * f4;
          i += (int64_t)RED_DW_BLOCKS * 256) {
-      const int d = (int)(i / f4), f = (int)(i % f4) * 4;
+      const int d = d0 + (int)(i / f4), f = (int)(i % f4) * 4;
       const float* p = a.slabs + (int64_t)d * a.Fp + f;
       float4 s = *(const float4*)p;
       int k = 1;
@@ -535,17 +541,17 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
           make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
     }
   } else {
-    const int64_t nW = (int64_t)a.D * a.F;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nW; i += (int64_t)RED_DW_BLOCKS * 256) {
-      const int d = (int)(i / a.F), f = (int)(i % a.F);
+    const int64_t nW = (int64_t)dn * a.F;
+    for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < nW; i += (int64_t)RED_DW_BLOCKS * 256) {
+      const int d = d0 + (int)(i / a.F), f = (int)(i % a.F);
       float s = 0.f;
       for (int k = 0; k < a.S; ++k) s += a.slabs[k * slab_sz + (int64_t)d * a.Fp + f];
-      a.grads[i] = s * inv;
+      a.grads[(int64_t)d * a.F + f] = s * inv;
     }
   }
 }
 void launch_reduce(const ReduceArgs& a, hipStream_t s) {
-  const dim3 grid(RED_DW_BLOCKS + (a.D + 15) / 16 + 1);      // + the loss block
+  const dim3 grid(((a.parts & 1) ? RED_DW_BLOCKS : 0) + ((a.parts & 2) ? (a.D + 15) / 16 + 1 : 0));   // dW blocks, db blocks, the loss block
   if (a.F % 4 == 0) VV_LAUNCH(k_reduce<true>, grid, dim3(256), 0, s, a);
   else VV_LAUNCH(k_reduce<false>, grid, dim3(256), 0, s, a);
 }

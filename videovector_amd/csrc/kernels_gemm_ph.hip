@@ -250,7 +250,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
   const int wm = wave >> 2, wn = wave & 3;
   const int tilesM = a.Dp / BM, tilesN = a.Fp / BN;
   const int L = ph_xcd_remap(blockIdx.x, gridDim.x);
-  const int tm = L % tilesM, tn = (L / tilesM) % tilesN, sp = L / (tilesM * tilesN);
+  const int tmc = a.tm_count > 0 ? a.tm_count : tilesM;           // M tiles of this launch
+  const int tm = a.tm_begin + L % tmc, tn = (L / tmc) % tilesN, sp = L / (tmc * tilesN);
   const int m0 = tm * BM, n0 = tn * BN;
   int total_steps = a.Rp / BK, kps = a.ksteps_per_split;
   if (a.n_dev) {                      // dedup mode: live K extent in device memory
@@ -452,7 +453,7 @@ static void launch_wgrad_ph_t(const WgradArgs& a, hipStream_t s) {
   static bool once = ((void)hipFuncSetAttribute((const void*)k_wgrad_gemm_ph<T>,
                       hipFuncAttributeMaxDynamicSharedMemorySize, PH_WG_LDS_BYTES), true);
   (void)once;
-  const dim3 grid((a.Dp / BM) * (a.Fp / BN) * a.S), block(GEMM_THREADS);
+  const dim3 grid((a.tm_count > 0 ? a.tm_count : a.Dp / BM) * (a.Fp / BN) * a.S), block(GEMM_THREADS);
   if constexpr (T::id == 0) {
     if (a.abl) {
 #define VV_ABL_WGP(N)                                                                                  \

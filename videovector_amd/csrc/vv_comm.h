@@ -1,0 +1,21 @@
+// vv_comm.h -- internal interface of comm.hip (the data-parallel gradient exchange behind vv_comm_* in include/videovec.h)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/videovec.h"
+
+namespace vv {
+struct Comm;
+Comm* comm_create(int world, int rank, const char* id_path, int transport, size_t n_floats, std::string* err);
+void comm_destroy(Comm* c);
+// all-reduce(sum) of buf[off .. off+n) in place on the communication stream, started after `after` (an event of the
+// compute stream, or null); comm_done_event marks its completion
+int comm_allreduce(Comm* c, float* buf, size_t off, size_t n, hipEvent_t after);
+hipEvent_t comm_done_event(Comm* c);
+const char* comm_error(Comm* c);
+int comm_world(Comm* c);
+int comm_rank(Comm* c);
+}  // namespace vv

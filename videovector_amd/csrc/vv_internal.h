@@ -122,6 +122,8 @@ struct WgradArgs {
   int ksteps_per_split;    // BK-steps per split
   const int32_t* n_dev = nullptr;    // dedup mode: device count of valid K rows (overrides Rp / ksteps_per_split)
   int32_t zero_row = 0;              // the table's all-zero row (K-tiles padded past a split's end read it)
+  int tm_begin = 0, tm_count = 0;    // restrict the launch to M tiles [tm_begin, tm_begin + tm_count) (0 = all): the
+                                     // data-parallel overlap all-reduces one row block of dW while the next is computed
   int abl = 0;                       // as FwdArgs::abl
 };
 
@@ -135,6 +137,8 @@ struct ReduceArgs {
   float ip_scale;          // 1 + regularization/2 (inner_product_layer.cpp:80-90), normally 1
   // the loss reduction rides in one extra workgroup: loss = loss_scale * sum(loss_part), violations = sum(viol_part)
   const float* loss_part; const float* viol_part; float loss_scale; float* loss_out;
+  int d_begin = 0, d_count = 0;      // rows of dW this launch reduces (d_count 0 = all D)
+  int parts = 3;                     // bit 0: the dW rows, bit 1: db and the loss scalars
 };
 
 struct SgdArgs {

@@ -70,6 +70,8 @@ def load_library():
         "vv_forward_backward_q1": [vp, vp, vp, vp],
         "vv_step": [vp, vp, vp, C.c_int],
         "vv_forward_backward_ring": [vp, vp, vp, i32, i32, vp, C.c_double],
+        "vv_comm_init": [vp, i32, i32, C.c_char_p, i32], "vv_comm_overlap": [vp, C.c_int],
+        "vv_allreduce_grads": [vp], "vv_comm_destroy": [vp],
         "vv_loss_get": [vp, C.POINTER(f32), C.POINTER(f32)],
         "vv_grads_device": [vp, C.POINTER(vp), C.POINTER(i64)], "vv_grads_get": [vp, vp, vp],
         "vv_grads_bind": [vp, vp],
@@ -223,6 +225,20 @@ class Engine:
         """Next batch of the sampler's prefetch ring -> pinned staging -> async H2D -> forward/backward."""
         self._chk(self.L.vv_forward_backward_ring(self.h, C.byref(cfg.c), ring.h, consumer, item_begin, _ptr(label_out),
                                                   float(timeout_s)))
+
+    # ---- data parallel (vv_comm_*)
+    def comm_init(self, world, rank, id_path, transport="rccl"):
+        self._chk(self.L.vv_comm_init(self.h, world, rank, None if id_path is None else id_path.encode(),
+                                      {"rccl": 0, "shm": 1}[transport]))
+
+    def comm_overlap(self, on=True):
+        self._chk(self.L.vv_comm_overlap(self.h, int(bool(on))))
+
+    def allreduce_grads(self):
+        self._chk(self.L.vv_allreduce_grads(self.h))
+
+    def comm_destroy(self):
+        self._chk(self.L.vv_comm_destroy(self.h))
 
     def apply_update(self, cfg):
         self._chk(self.L.vv_apply_update(self.h, C.byref(cfg.c)))
