@@ -113,6 +113,10 @@ def main():
                          "stream while the weight-gradient kernel is still producing the next chunk.  'stale': the "
                          "all-reduce of iteration t overlaps iteration t+1 and gradients are applied one update late "
                          "(NOT the reference's algorithm; opt-in, labelled)")
+    ap.add_argument("--comm", default="lib", choices=["lib", "torch"],
+                    help="N>1: who runs the gradient all-reduce.  'lib' (default): the product library's own RCCL "
+                         "communicator on its communication stream (vv_comm_init / vv_allreduce_grads).  'torch': "
+                         "torch.distributed.all_reduce on the tensor the gradients are bound to (cross-check; no overlap mode)")
     ap.add_argument("--sampler-threads", type=int, default=int(os.environ.get("VV_SAMPLER_THREADS", "3")))
     ap.add_argument("--prefetch-depth", type=int, default=8)
     args = ap.parse_args()
@@ -195,6 +199,12 @@ def main():
     mode = args.allreduce if args.allreduce != "auto" else ("sync" if world > 1 else "none")
     if world == 1 and mode in ("sync", "overlap"):
         mode = "none"
+    comm = args.comm if mode in ("sync", "overlap") else "none"
+    if mode == "overlap" and comm == "torch":
+        raise SystemExit("--allreduce overlap needs --comm lib (the chunked all-reduce lives in the library)")
+    # the library's communicator: RCCL, or the shared-memory transport under the one-device test hook
+    comm_transport = "rccl" if os.environ.get("VV_DIST_BACKEND", "nccl") == "nccl" else "shm"
+    comm_id_path = "/tmp/vv_comm_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", str(os.getppid())))
 
     def lr_at(it):     # shipped solver: inv policy, base 1e-3, gamma 1e-3, power .75
         return 1e-3 * (1.0 + 1e-3 * it) ** -0.75
@@ -203,6 +213,7 @@ def main():
 
     class Run:
         """One engine + its step function; source = 'ring' (end to end) or 'resident'."""
+        n_comm = 0
 
         def __init__(self, prec, dedup):
             self.prec = prec
@@ -218,9 +229,16 @@ def main():
                 from videovector_amd.dist import GpuBackend, PipelinedTrainer
                 be = GpuBackend(self.eng, self.cfg, stream=work_stream)
                 self.trainer = PipelinedTrainer(be, None, NN, dist=dist, rank=rank, world=world)
-            elif world > 1:
+            elif comm == "torch":
                 self.grads = torch.zeros(D * F + D, dtype=torch.float32, device=dev)
                 self.eng.grads_bind(self.grads.data_ptr())
+            elif comm == "lib":
+                Run.n_comm += 1                   # one communicator per engine: its own id file
+                if rank == 0 and os.path.exists(comm_id_path + "_%d" % Run.n_comm):
+                    os.unlink(comm_id_path + "_%d" % Run.n_comm)
+                dist.barrier()
+                self.eng.comm_init(world, rank, comm_id_path + "_%d" % Run.n_comm, comm_transport)
+                self.eng.comm_overlap(mode == "overlap")
             self.it = 0
 
         def reset(self, dedup):
@@ -241,8 +259,10 @@ def main():
                     if diag: host_ms.append((time.perf_counter() - th0) * 1e3)
                 else:
                     eng.forward_backward(cfg, idx_dev_ptr=idx_dev.data_ptr() + i * stride)
-                if world > 1:
+                if comm == "torch":
                     dist.all_reduce(self.grads)
+                elif comm == "lib":
+                    eng.allreduce_grads()          # (vv_apply_update would call it too; explicit for the reader)
                 eng.apply_update(cfg)
             self.it += 1
 
@@ -384,6 +404,9 @@ def main():
                        "parallelism": "dp%d" % world, "items_per_s": value / NN, "dedup": args.dedup,
                        "sampler": "one per node (rank 0), %d stage thread(s), prefetch depth %d%s"
                                   % (args.sampler_threads, args.prefetch_depth, ", POSIX shared-memory ring" if world > 1 else ""),
+                       "comm": {"none": "none", "lib": "the library's RCCL communicator on its own communication stream (vv_comm_*)"
+                                if comm_transport == "rccl" else "the library's shared-memory test transport (one-device hook)",
+                                "torch": "torch.distributed.all_reduce"}[comm],
                        "allreduce": {"none": "none (1 GPU)", "sync": "synchronous (exact SGD), exposed",
                                      "overlap": "exact SGD, chunked all-reduce overlapped with the weight-gradient kernel",
                                      "stale": "overlapped with the next iteration's forward/backward "

@@ -42,6 +42,11 @@ void SetLogFile(const std::string& path);    // GLOG_log_dir equivalent: also te
 #define CHECK_GT(a, b) CHECK_OP(a, b, >)
 #define VV_CHECK(call) do { int rc_ = (call); CHECK(rc_ == 0) << #call << " failed (" << rc_ << "): " << vv_last_error(); } while (0)
 
+// gflags defined in the reference's layer files (video_sampled_shots_data_layer.cpp:20, retrieval_stats_layer.cpp:16);
+// `caffe` and `extract_features` accept --max_tries_for_negs=N and --num_classes=N
+extern int FLAGS_max_tries_for_negs;
+extern int FLAGS_num_classes;
+
 class Caffe {
  public:
   enum Brew { CPU, GPU };
@@ -57,13 +62,22 @@ class Caffe {
   static void set_random_seed(const unsigned int seed) { Get().seed_ = seed; }
   static unsigned int random_seed() { return Get().seed_; }
   static int device() { return Get().device_; }
+  // Data-parallel job shape: one process per GPU (no counterpart in the reference, which is single-device).  Read
+  // once from the environment a launcher such as torch.distributed.run sets: WORLD_SIZE, RANK, LOCAL_RANK (VV_WORLD_SIZE
+  // / VV_RANK / VV_LOCAL_RANK take precedence); job_id() keeps the shared-memory and id-file names of concurrent jobs apart.
+  static int world() { return Get().world_; }
+  static int rank() { return Get().rank_; }
+  static int local_rank() { return Get().local_rank_; }
+  static const std::string& job_id() { return Get().job_id_; }
   // MFMA operand precision of the context ("f16" default, "bf16"); env VV_PREC overrides
   static void set_precision(const std::string& p);
   // The HIP context of this process (created on first use)
   static vv_ctx* ctx();
   static void Reset();                                     // destroy the context (tests)
  private:
-  Caffe() {}
+  Caffe();
+  int world_ = 1, rank_ = 0, local_rank_ = 0;
+  std::string job_id_;
   Brew mode_ = GPU;
   Phase phase_ = TRAIN;
   int device_ = 0;

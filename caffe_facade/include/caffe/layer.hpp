@@ -127,7 +127,8 @@ class VideoSampledShotsDataLayer : public Layer<Dtype> {
   void JoinPrefetchThread();       // the wait happens inside vv_sampler_next
   bool prefetching_ = false;
   int rand_skip_ = 0;
-  vv_sampler* sampler_ = nullptr;
+  vv_sampler* sampler_ = nullptr;          // rank 0 only in a data-parallel job
+  vv_batch_ring* ring_ = nullptr;          // the prefetch ring (rank 0: the sampler's own; other ranks: attached by name)
   int batch_size_ = 0, context_size_ = 0, num_negative_samples_ = 0, feature_size_ = 0;
 };
 

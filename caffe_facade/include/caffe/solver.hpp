@@ -39,6 +39,8 @@ class Solver {
   void Snapshot();                                           // solver.cpp:320-341
   void Restore(const char* solverstate);                     // solver.cpp:418-429
   void TestAll();
+  void Step(bool display);                                   // one iteration of Solve's loop body (solver.cpp:194-220)
+  void ReportOutputs(const Net<Dtype>& net, const char* prefix, bool with_iter, const vector<Dtype>& values);
   void Test(const int which_test_net = 0);                   // solver.cpp:251-317
 
   SolverParameter param_;

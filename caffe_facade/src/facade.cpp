@@ -40,6 +40,26 @@ LogMessage::~LogMessage() {
 }
 
 // ------------------------------------------------------------------------------- Caffe ---------
+// gflags of the reference's layer files, settable from the tools' command lines
+int FLAGS_max_tries_for_negs = 100;      // video_sampled_shots_data_layer.cpp:20
+int FLAGS_num_classes = 15;              // retrieval_stats_layer.cpp:16
+
+static int env_int(const char* a, const char* b, int def) {
+  const char* v = getenv(a);
+  if (!v || !*v) v = getenv(b);
+  return v && *v ? atoi(v) : def;
+}
+Caffe::Caffe() {
+  world_ = env_int("VV_WORLD_SIZE", "WORLD_SIZE", 1);
+  rank_ = env_int("VV_RANK", "RANK", 0);
+  local_rank_ = env_int("VV_LOCAL_RANK", "LOCAL_RANK", rank_);
+  if (world_ < 1 || rank_ < 0 || rank_ >= world_) { world_ = 1; rank_ = 0; local_rank_ = 0; }
+  const char* j = getenv("VV_JOB_ID");
+  if (!j || !*j) j = getenv("TORCHELASTIC_RUN_ID");
+  if (!j || !*j) j = getenv("MASTER_PORT");
+  job_id_ = j && *j ? j : "0";
+  for (char& ch : job_id_) if (!isalnum((unsigned char)ch)) ch = '_';
+}
 Caffe& Caffe::Get() { static Caffe c; return c; }
 void Caffe::set_mode(Brew mode) {
   CHECK(mode == GPU) << "This build has no CPU execution path (the reference's CPU path exists only "
@@ -372,6 +392,7 @@ void VideoDataset::UploadTable(vv_ctx* ctx) const {
 // ------------------------------------------------------------------------------- data layer ----
 template <typename Dtype>
 VideoSampledShotsDataLayer<Dtype>::~VideoSampledShotsDataLayer() {
+  if (ring_ && !sampler_) vv_batch_ring_detach(ring_);
   if (sampler_) vv_sampler_destroy(sampler_);        // stops the prefetch threads
 }
 // BasePrefetchingDataLayer (base_data_layer.cpp:52-95) starts a thread per batch and joins it in Forward.  Here the
@@ -381,7 +402,17 @@ template <typename Dtype>
 void VideoSampledShotsDataLayer<Dtype>::CreatePrefetchThread() {
   if (prefetching_) return;
   const int threads = getenv("VV_SAMPLER_THREADS") ? atoi(getenv("VV_SAMPLER_THREADS")) : 3;
-  CHECK_EQ(vv_sampler_prefetch_start(sampler_, kPrefetchDepth, threads < 1 ? 1 : threads, nullptr, 1), 0);
+  const int world = Caffe::world();
+  // data-parallel: ONE sampler per node (rank 0) draws the global batch and publishes it in shared memory; every rank
+  // takes its batch_size items of it
+  const string ring_name = "vv_caffe_" + Caffe::job_id() + "_" + this->layer_param_.get_str("name");
+  if (sampler_) {
+    CHECK_EQ(vv_sampler_prefetch_start(sampler_, kPrefetchDepth, threads < 1 ? 1 : threads, world > 1 ? ring_name.c_str() : nullptr, world), 0);
+    CHECK_EQ(vv_sampler_ring(sampler_, &ring_), 0);
+  } else {
+    CHECK_EQ(vv_batch_ring_attach(ring_name.c_str(), 300.0, &ring_), 0) << "rank " << Caffe::rank() << ": no batch ring " << ring_name
+                                                                       << " from rank 0";
+  }
   prefetching_ = true;
 }
 template <typename Dtype>
@@ -412,15 +443,24 @@ void VideoSampledShotsDataLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>&, 
   sp.max_buffer_size = (int)p.get_int("max_buffer_size");
   sp.negative_swap_percentage = (int)p.get_int("negative_swap_percentage");
   sp.max_same_video_negs = (int)p.get_int("max_same_video_negs");
+  sp.max_tries_for_negs = FLAGS_max_tries_for_negs;                                       // …data_layer.cpp:20, 245
   sp.initial_cursor = rand_skip_;
   feature_size_ = dataset_->F;
   CHECK_GE(feature_size_, 1); CHECK_GE(context_size_, 2); CHECK_GE(batch_size_, 1);      // …data_layer.cpp:206-209
   if (ctype == "WINDOW") { CHECK(context_size_ % 2 == 1) << "Context size should be even in this setting!"; }   // …:434 (sic)
   sp.context_type = ctype == "WINDOW" ? VV_CONTEXT_WINDOW : ctype == "PAST" ? VV_CONTEXT_PAST :
                     ctype == "PAST_CONTINUOUS" ? VV_CONTEXT_PAST_CONTINUOUS : VV_CONTEXT_PAST_CONTINUOUS_FIXED;
-  const int rc = vv_sampler_create(&sp, (int)dataset_->video_id.size(), dataset_->video_id.data(), dataset_->n_shots.data(),
-                                   dataset_->row_base.data(), dataset_->shot_ids.data(), &sampler_);
-  CHECK_EQ(rc, 0) << "Could not add requested number of negatives";                       // …:344
+  CHECK_LE(sp.max_same_video_negs, sp.num_negative_samples)
+      << "max_same_video_negs exceeds num_negative_samples: the reference writes past the item's channels (…data_layer.cpp:484-502)";
+  if (Caffe::world() > 1) {
+    CHECK_LE(sp.max_same_video_negs, 0) << "data-parallel runs need max_same_video_negs: 0";
+    sp.batch_size = batch_size_ * Caffe::world();      // the prototxt's batch_size is per GPU; the sampler draws the global batch
+  }
+  if (Caffe::rank() == 0) {
+    const int rc = vv_sampler_create(&sp, (int)dataset_->video_id.size(), dataset_->video_id.data(), dataset_->n_shots.data(),
+                                     dataset_->row_base.data(), dataset_->shot_ids.data(), &sampler_);
+    CHECK_EQ(rc, 0) << "Could not add requested number of negatives";                     // …:344
+  }
   (*top)[0]->Reshape(batch_size_, context_size_ + num_negative_samples_, feature_size_, 1);  // …:214-218
   LOG(INFO) << "output data size: " << (*top)[0]->num() << "," << (*top)[0]->channels() << "," << (*top)[0]->height()
             << "," << (*top)[0]->width();
@@ -432,7 +472,13 @@ void VideoSampledShotsDataLayer<Dtype>::NextBatch(vector<int32_t>* idx, vector<i
   JoinPrefetchThread();                                            // base_data_layer.cpp:81-95: join, hand over, respawn
   const size_t n = (size_t)batch_size_ * (context_size_ + num_negative_samples_);
   idx->resize(n); last_src->resize(n); label->resize(batch_size_);
-  CHECK_EQ(vv_sampler_next(sampler_, idx->data(), last_src->data(), label->data()), 0);
+  if (Caffe::world() == 1) {
+    CHECK_EQ(vv_sampler_next(sampler_, idx->data(), last_src->data(), label->data()), 0);
+  } else {                                                         // this rank's items of the global batch
+    CHECK_EQ(vv_batch_ring_next(ring_, Caffe::rank(), Caffe::rank() * batch_size_, batch_size_, idx->data(), label->data(), 600.0), 0)
+        << "no batch from rank 0's sampler";
+    *last_src = *idx;
+  }
   CreatePrefetchThread();
 }
 template class VideoSampledShotsDataLayer<float>;
@@ -479,6 +525,10 @@ void RetrievalStatsLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>&, vector<
     map_cls_.push_back(atoi(line.substr(c + 1).c_str()));
   }
   CHECK_GE(map_ids_.size(), 1u) << "need atleast one entry in id-to-class map!";      // :49
+  // --num_classes (retrieval_stats_layer.cpp:16) sizes the reference's per-class accumulators (:218-223); a class id past
+  // it indexes them out of bounds there.  Checked here instead.
+  for (size_t i = 0; i < map_cls_.size(); ++i)
+    CHECK_LT(map_cls_[i], FLAGS_num_classes) << "class " << map_cls_[i] << " of video " << map_ids_[i] << " needs --num_classes > " << map_cls_[i];
 }
 template <typename Dtype>
 void RetrievalStatsLayer<Dtype>::Reshape(const vector<Blob<Dtype>*>& bottom, vector<Blob<Dtype>*>* top) {

@@ -5,6 +5,8 @@
 
 #include <cmath>
 #include <cstdio>
+#include <sstream>
+#include <string>
 
 namespace caffe {
 
@@ -17,6 +19,79 @@ Solver<Dtype>::Solver(const string& param_file) : param_("SolverParameter"), ite
   Init(param);
 }
 
+// ---- which nets a SolverParameter names -------------------------------------------------------------------------
+// The reference accepts the train net from one of four fields and the test nets from three kinds of source
+// (solver.cpp:46-157).  Here the fields are tables; what is contract is which field wins, the CHECK messages and the
+// "Creating ..." log lines.
+namespace {
+
+// level and stages of `src` laid over `dst` (NetState::MergeFrom for the two fields the path uses)
+void OverlayState(const NetState& src, NetState* dst) {
+  if (src.has("level")) dst->set_int("level", src.get_int("level"));
+  for (int i = 0; i < src.size("stage"); ++i) dst->add_str("stage", src.get_str("stage", i));
+}
+
+struct NetField { const char* name; bool is_file; const char* what; };
+const NetField kTrainFields[] = {     // later entries override earlier ones (solver.cpp:52-71)
+  {"train_net_param", false, "Creating training net specified in train_net_param."},
+  {"train_net", true, "Creating training net from train_net file: "},
+  {"net_param", false, "Creating training net specified in net_param."},
+  {"net", true, "Creating training net from net file: "},
+};
+
+NetParameter ReadNet(const SolverParameter& sp, const char* field, bool is_file, int index) {
+  NetParameter np("NetParameter");
+  if (is_file) pl::ReadProtoFromTextFileOrDie(sp.get_str(field, index), &np);
+  else np = sp.get_msg(field, index);
+  return np;
+}
+
+NetParameter TrainNetOf(const SolverParameter& sp) {
+  int given = 0;
+  for (const NetField& f : kTrainFields) given += sp.has(f.name) ? 1 : 0;
+  const string field_names = "net, net_param, train_net, train_net_param";
+  CHECK_GE(given, 1) << "SolverParameter must specify a train net using one of these fields: " << field_names;
+  CHECK_LE(given, 1) << "SolverParameter must not contain more than one of these fields specifying a train_net: " << field_names;
+  NetParameter np("NetParameter");
+  for (const NetField& f : kTrainFields) {
+    if (!sp.has(f.name)) continue;
+    if (f.is_file) LOG(INFO) << f.what << sp.get_str(f.name); else LOG(INFO) << f.what;
+    np = ReadNet(sp, f.name, f.is_file, 0);
+  }
+  // net state, weakest first: phase TRAIN, the net's own state, the solver's train_state (solver.cpp:73-80)
+  NetState state("NetState");
+  state.set_enum("phase", "TRAIN");
+  if (np.has("state")) OverlayState(np.get_msg("state"), &state);
+  if (sp.has("train_state")) OverlayState(sp.get_msg("train_state"), &state);
+  *np.mutable_msg("state") = state;
+  return np;
+}
+
+vector<NetParameter> TestNetsOf(const SolverParameter& sp) {
+  const bool generic_inline = sp.has("net_param"), generic_file = sp.has("net");
+  CHECK_LE(generic_inline + generic_file, 1) << "Both net_param and net_file may not be specified.";
+  const int explicit_nets = sp.size("test_net_param") + sp.size("test_net");
+  const int iters_given = sp.size("test_iter");
+  if (generic_inline || generic_file) CHECK_GE(iters_given, explicit_nets) << "test_iter must be specified for each test network.";
+  else CHECK_EQ(iters_given, explicit_nets) << "test_iter must be specified for each test network.";
+  const int instances = iters_given;                       // explicit ones first, the generic net fills the rest
+  if (sp.size("test_state")) CHECK_EQ(sp.size("test_state"), instances) << "test_state must be unspecified or specified once per test net.";
+  if (instances) CHECK_GT(sp.get_int("test_interval"), 0);
+  vector<NetParameter> nets;
+  for (int i = 0; i < sp.size("test_net_param"); ++i) nets.push_back(ReadNet(sp, "test_net_param", false, i));
+  for (int i = 0; i < sp.size("test_net"); ++i) nets.push_back(ReadNet(sp, "test_net", true, i));
+  while ((int)nets.size() < instances) nets.push_back(ReadNet(sp, generic_inline ? "net_param" : "net", !generic_inline, 0));
+  for (int i = 0; i < instances; ++i) {
+    NetState state("NetState");
+    state.set_enum("phase", "TEST");
+    if (sp.size("test_state")) OverlayState(sp.get_msg("test_state", i), &state);
+    *nets[i].mutable_msg("state") = state;
+  }
+  return nets;
+}
+
+}  // namespace
+
 template <typename Dtype>
 void Solver<Dtype>::Init(const SolverParameter& param) {
   LOG(INFO) << "Initializing solver from parameters: \n" << param.PrintText();
@@ -28,58 +103,61 @@ void Solver<Dtype>::Init(const SolverParameter& param) {
 }
 
 template <typename Dtype>
-void Solver<Dtype>::InitTrainNet() {
-  const int num_train_nets = param_.has("net") + param_.has("net_param") + param_.has("train_net") + param_.has("train_net_param");
-  const string field_names = "net, net_param, train_net, train_net_param";
-  CHECK_GE(num_train_nets, 1) << "SolverParameter must specify a train net using one of these fields: " << field_names;
-  CHECK_LE(num_train_nets, 1) << "SolverParameter must not contain more than one of these fields specifying a train_net: " << field_names;
-  NetParameter net_param("NetParameter");
-  if (param_.has("train_net_param")) { LOG(INFO) << "Creating training net specified in train_net_param."; net_param = param_.get_msg("train_net_param"); }
-  else if (param_.has("train_net")) { LOG(INFO) << "Creating training net from train_net file: " << param_.get_str("train_net"); pl::ReadProtoFromTextFileOrDie(param_.get_str("train_net"), &net_param); }
-  if (param_.has("net_param")) { LOG(INFO) << "Creating training net specified in net_param."; net_param = param_.get_msg("net_param"); }
-  if (param_.has("net")) { LOG(INFO) << "Creating training net from net file: " << param_.get_str("net"); pl::ReadProtoFromTextFileOrDie(param_.get_str("net"), &net_param); }
-  // precedence of the net state: solver train_state over the net's own (solver.cpp:73-80)
-  NetState state("NetState");
-  state.set_enum("phase", "TRAIN");
-  if (net_param.has("state")) { const NetState& s = net_param.get_msg("state"); if (s.has("level")) state.set_int("level", s.get_int("level")); for (int i = 0; i < s.size("stage"); ++i) state.add_str("stage", s.get_str("stage", i)); state.set_enum("phase", "TRAIN"); }
-  if (param_.has("train_state")) { const NetState& s = param_.get_msg("train_state"); if (s.has("level")) state.set_int("level", s.get_int("level")); for (int i = 0; i < s.size("stage"); ++i) state.add_str("stage", s.get_str("stage", i)); }
-  *net_param.mutable_msg("state") = state;
-  net_.reset(new Net<Dtype>(net_param));
-}
+void Solver<Dtype>::InitTrainNet() { net_.reset(new Net<Dtype>(TrainNetOf(param_))); }
 
 template <typename Dtype>
 void Solver<Dtype>::InitTestNets() {
-  // solver.cpp:84-157.  Sources of test nets, in the reference's order: test_net_param, test_net
-  // files, then the generic net_param / net (instantiated test_iter.size() - (others) times).
-  const bool has_net_param = param_.has("net_param"), has_net_file = param_.has("net");
-  const int num_generic_nets = has_net_param + has_net_file;
-  CHECK_LE(num_generic_nets, 1) << "Both net_param and net_file may not be specified.";
-  const int num_test_net_params = param_.size("test_net_param"), num_test_net_files = param_.size("test_net");
-  const int num_test_nets = num_test_net_params + num_test_net_files;
-  if (num_generic_nets) CHECK_GE(param_.size("test_iter"), num_test_nets) << "test_iter must be specified for each test network.";
-  else CHECK_EQ(param_.size("test_iter"), num_test_nets) << "test_iter must be specified for each test network.";
-  const int num_generic_net_instances = param_.size("test_iter") - num_test_nets;
-  const int num_test_net_instances = num_test_nets + num_generic_net_instances;
-  if (param_.size("test_state")) CHECK_EQ(param_.size("test_state"), num_test_net_instances) << "test_state must be unspecified or specified once per test net.";
-  if (num_test_net_instances) CHECK_GT(param_.get_int("test_interval"), 0);
-  vector<NetParameter> net_params;
-  for (int i = 0; i < num_test_net_params; ++i) net_params.push_back(param_.get_msg("test_net_param", i));
-  for (int i = 0; i < num_test_net_files; ++i) { NetParameter np("NetParameter"); pl::ReadProtoFromTextFileOrDie(param_.get_str("test_net", i), &np); net_params.push_back(np); }
-  for (int i = 0; i < num_generic_net_instances; ++i) {
-    NetParameter np("NetParameter");
-    if (has_net_param) np = param_.get_msg("net_param"); else pl::ReadProtoFromTextFileOrDie(param_.get_str("net"), &np);
-    net_params.push_back(np);
-  }
+  const vector<NetParameter> specs = TestNetsOf(param_);
   Caffe::set_phase(Caffe::TEST);
-  for (int i = 0; i < num_test_net_instances; ++i) {
-    NetState state("NetState");
-    state.set_enum("phase", "TEST");
-    if (param_.size("test_state")) { const NetState& s = param_.get_msg("test_state", i); if (s.has("level")) state.set_int("level", s.get_int("level")); for (int k = 0; k < s.size("stage"); ++k) state.add_str("stage", s.get_str("stage", k)); }
-    *net_params[i].mutable_msg("state") = state;
+  for (size_t i = 0; i < specs.size(); ++i) {
     LOG(INFO) << "Creating test net (#" << i << ")";
-    test_nets_.push_back(shared_ptr<Net<Dtype> >(new Net<Dtype>(net_params[i])));
+    test_nets_.push_back(shared_ptr<Net<Dtype> >(new Net<Dtype>(specs[i])));
   }
   Caffe::set_phase(Caffe::TRAIN);
+}
+
+// ---- the training loop -------------------------------------------------------------------------------------------
+// Solver::Solve (solver.cpp:159-240).  One iteration = periodic work that looks at iter_ (snapshot, test), then
+// ForwardBackward, the display lines, ComputeUpdateValue + Update -- in that order, because the log lines of an
+// iteration (loss, outputs, lr) are parsed as a group by caffe_utils/plot_training_stats.py:10-14.
+// Data-parallel runs (Caffe::world() > 1): every rank runs this loop; only rank 0 writes snapshots.
+namespace {
+bool Every(int64_t period, int iter) { return period > 0 && iter % period == 0; }
+}
+
+template <typename Dtype>
+void Solver<Dtype>::ReportOutputs(const Net<Dtype>& net, const char* prefix, bool with_iter, const vector<Dtype>& values) {
+  // one line per scalar of every output blob: "<prefix> #k: name = [iter = I value = ]v[ (* w = w*v loss)]"  (solver.cpp:211-214, 305-315)
+  size_t k = 0;
+  const vector<Blob<Dtype>*>& outs = net.output_blobs();
+  for (size_t j = 0; j < outs.size(); ++j) {
+    const int blob = net.output_blob_indices()[j];
+    const Dtype w = net.blob_loss_weights()[blob];
+    for (int e = 0; e < outs[j]->count(); ++e, ++k) {
+      std::ostringstream line;
+      line << "    " << prefix << " #" << k << ": " << net.blob_names()[blob] << " = ";
+      if (with_iter) line << "iter = " << iter_ << " value = ";
+      line << values[k];
+      if (w) line << " (* " << w << " = " << w * values[k] << " loss)";
+      LOG(INFO) << line.str();
+    }
+  }
+}
+
+template <typename Dtype>
+void Solver<Dtype>::Step(bool display) {
+  vector<Blob<Dtype>*> no_bottom;
+  net_->set_debug_info(display && param_.get_bool("debug_info"));
+  net_->set_loss_needed(display);                   // the loss is read back from the device only when it is shown
+  const Dtype loss = net_->ForwardBackward(no_bottom);
+  if (display) {
+    LOG(INFO) << "Iteration " << iter_ << ", loss = " << loss;                          // solver.cpp:196
+    vector<Dtype> values;
+    for (Blob<Dtype>* b : net_->output_blobs()) values.insert(values.end(), b->cpu_data(), b->cpu_data() + b->count());
+    ReportOutputs(*net_, "Train net output", true, values);
+  }
+  ComputeUpdateValue();
+  net_->Update();
 }
 
 template <typename Dtype>
@@ -92,110 +170,84 @@ void Solver<Dtype>::Solve(const char* resume_file) {
     LOG(INFO) << "Restoring previous solver status from " << resume_file;
     Restore(resume_file);
   }
-  const int start_iter = iter_;
-  vector<Blob<Dtype>*> bottom_vec;
-  for (; iter_ < param_.get_int("max_iter"); ++iter_) {
-    if (param_.get_int("snapshot") && iter_ > start_iter && iter_ % param_.get_int("snapshot") == 0) Snapshot();
-    if (param_.get_int("test_interval") && iter_ % param_.get_int("test_interval") == 0 &&
-        (iter_ > 0 || param_.get_bool("test_initialization"))) TestAll();
-    const bool display = param_.get_int("display") && iter_ % param_.get_int("display") == 0;
-    net_->set_debug_info(display && param_.get_bool("debug_info"));
-    net_->set_loss_needed(display);
-    Dtype loss = net_->ForwardBackward(bottom_vec);
-    if (display) {
-      LOG(INFO) << "Iteration " << iter_ << ", loss = " << loss;                      // solver.cpp:196
-      const vector<Blob<Dtype>*>& result = net_->output_blobs();
-      int score_index = 0;
-      for (size_t j = 0; j < result.size(); ++j) {
-        const Dtype* result_vec = result[j]->cpu_data();
-        const string& output_name = net_->blob_names()[net_->output_blob_indices()[j]];
-        const Dtype loss_weight = net_->blob_loss_weights()[net_->output_blob_indices()[j]];
-        for (int k = 0; k < result[j]->count(); ++k) {
-          std::ostringstream loss_msg_stream;
-          if (loss_weight) loss_msg_stream << " (* " << loss_weight << " = " << loss_weight * result_vec[k] << " loss)";
-          LOG(INFO) << "    Train net output #" << score_index++ << ": " << output_name << " = "
-                    << "iter = " << iter_ << " value = " << result_vec[k] << loss_msg_stream.str();   // solver.cpp:211-214
-        }
-      }
-    }
-    ComputeUpdateValue();
-    net_->Update();
+  const int first = iter_, last = (int)param_.get_int("max_iter");
+  const int64_t snap = param_.get_int("snapshot"), test = param_.get_int("test_interval"), disp = param_.get_int("display");
+  for (; iter_ < last; ++iter_) {
+    if (iter_ > first && Every(snap, iter_)) Snapshot();
+    if (Every(test, iter_) && (iter_ > 0 || param_.get_bool("test_initialization"))) TestAll();
+    Step(Every(disp, iter_));
   }
+  // after the last update: final snapshot, one more forward pass for the closing loss line, final test
   net_->set_loss_needed(true);
   if (param_.get_bool("snapshot_after_train")) Snapshot();
-  if (param_.get_int("display") && iter_ % param_.get_int("display") == 0) {
+  if (Every(disp, iter_)) {
     Dtype loss;
-    net_->Forward(bottom_vec, &loss);
+    net_->Forward(vector<Blob<Dtype>*>(), &loss);
     LOG(INFO) << "Iteration " << iter_ << ", loss = " << loss;
   }
-  if (param_.get_int("test_interval") && iter_ % param_.get_int("test_interval") == 0) TestAll();
+  if (Every(test, iter_)) TestAll();
   LOG(INFO) << "Optimization Done.";
 }
 
 template <typename Dtype>
 void Solver<Dtype>::TestAll() { for (size_t i = 0; i < test_nets_.size(); ++i) Test((int)i); }
+
+// Solver::Test (solver.cpp:251-317): test_iter forward passes of the test net on the current weights; every scalar
+// of every output blob is averaged over the passes.
 template <typename Dtype>
-void Solver<Dtype>::Test(const int test_net_id) {                                      // solver.cpp:251-317
+void Solver<Dtype>::Test(const int test_net_id) {
   LOG(INFO) << "Iteration " << iter_ << ", Testing net (#" << test_net_id << ")";
   Caffe::set_phase(Caffe::TEST);
-  const shared_ptr<Net<Dtype> >& test_net = test_nets_[test_net_id];
-  test_net->ShareTrainedLayersWith(net_.get());
-  vector<Dtype> test_score;
-  vector<int> test_score_output_id;
-  vector<Blob<Dtype>*> bottom_vec;
-  Dtype loss = 0;
-  const int iters = (int)param_.get_int("test_iter", test_net_id);
-  for (int i = 0; i < iters; ++i) {
-    Dtype iter_loss;
-    const vector<Blob<Dtype>*>& result = test_net->Forward(bottom_vec, &iter_loss);
-    if (param_.get_bool("test_compute_loss")) loss += iter_loss;
-    int idx = 0;
-    for (size_t j = 0; j < result.size(); ++j)
-      for (int k = 0; k < result[j]->count(); ++k) {
-        if (i == 0) { test_score.push_back(result[j]->cpu_data()[k]); test_score_output_id.push_back((int)j); }
-        else test_score[idx++] += result[j]->cpu_data()[k];
+  Net<Dtype>& net = *test_nets_[test_net_id];
+  net.ShareTrainedLayersWith(net_.get());
+  const int passes = (int)param_.get_int("test_iter", test_net_id);
+  const bool want_loss = param_.get_bool("test_compute_loss");
+  vector<Dtype> mean;
+  Dtype loss_sum = 0;
+  for (int pass = 0; pass < passes; ++pass) {
+    Dtype pass_loss = 0;
+    const vector<Blob<Dtype>*>& outs = net.Forward(vector<Blob<Dtype>*>(), &pass_loss);
+    loss_sum += pass_loss;
+    size_t k = 0;
+    for (Blob<Dtype>* b : outs)
+      for (int e = 0; e < b->count(); ++e, ++k) {
+        if (k == mean.size()) mean.push_back(0);
+        mean[k] += b->cpu_data()[e];
       }
   }
-  if (param_.get_bool("test_compute_loss")) LOG(INFO) << "Test loss: " << loss / iters;
-  for (size_t i = 0; i < test_score.size(); ++i) {
-    const int output_blob_index = test_net->output_blob_indices()[test_score_output_id[i]];
-    const string& output_name = test_net->blob_names()[output_blob_index];
-    const Dtype loss_weight = test_net->blob_loss_weights()[output_blob_index];
-    std::ostringstream loss_msg_stream;
-    const Dtype mean_score = test_score[i] / iters;
-    if (loss_weight) loss_msg_stream << " (* " << loss_weight << " = " << loss_weight * mean_score << " loss)";
-    LOG(INFO) << "    Test net output #" << i << ": " << output_name << " = " << mean_score << loss_msg_stream.str();
-  }
+  for (Dtype& m : mean) m /= passes;
+  if (want_loss) LOG(INFO) << "Test loss: " << loss_sum / passes;
+  ReportOutputs(net, "Test net output", false, mean);
   Caffe::set_phase(Caffe::TRAIN);
 }
 
+// Solver::Snapshot (solver.cpp:320-341): <prefix>_iter_<N>.caffemodel + .solverstate naming the model file.
 template <typename Dtype>
 void Solver<Dtype>::Snapshot() {
-  NetParameter net_param("NetParameter");
-  net_->ToProto(&net_param, param_.get_bool("snapshot_diff"));
-  char iter_str[32];
-  snprintf(iter_str, sizeof(iter_str), "_iter_%d", iter_);
-  const string filename = param_.get_str("snapshot_prefix") + iter_str;
-  const string model_filename = filename + ".caffemodel";
-  LOG(INFO) << "Snapshotting to " << model_filename;
-  pl::WriteProtoToBinaryFile(net_param, model_filename);
+  if (Caffe::rank() != 0) return;                     // data-parallel: parameters are identical on every rank
+  const string stem = param_.get_str("snapshot_prefix") + "_iter_" + std::to_string(iter_);
+  const string model_file = stem + ".caffemodel", state_file = stem + ".solverstate";
+  NetParameter learned("NetParameter");
+  net_->ToProto(&learned, param_.get_bool("snapshot_diff"));
+  LOG(INFO) << "Snapshotting to " << model_file;
+  pl::WriteProtoToBinaryFile(learned, model_file);
   SolverState state("SolverState");
   SnapshotSolverState(&state);
   state.set_int("iter", iter_);
-  state.set_str("learned_net", model_filename);
-  const string snapshot_filename = filename + ".solverstate";
-  LOG(INFO) << "Snapshotting solver state to " << snapshot_filename;
-  pl::WriteProtoToBinaryFile(state, snapshot_filename);
+  state.set_str("learned_net", model_file);
+  LOG(INFO) << "Snapshotting solver state to " << state_file;
+  pl::WriteProtoToBinaryFile(state, state_file);
 }
 
+// Solver::Restore (solver.cpp:418-429)
 template <typename Dtype>
 void Solver<Dtype>::Restore(const char* state_file) {
   SolverState state("SolverState");
   pl::ReadProtoFromBinaryFileOrDie(state_file, &state);
   if (state.has("learned_net")) {
-    NetParameter net_param("NetParameter");
-    pl::ReadProtoFromBinaryFileOrDie(state.get_str("learned_net"), &net_param);
-    net_->CopyTrainedLayersFrom(net_param);
+    NetParameter learned("NetParameter");
+    pl::ReadProtoFromBinaryFileOrDie(state.get_str("learned_net"), &learned);
+    net_->CopyTrainedLayersFrom(learned);
   }
   iter_ = (int)state.get_int("iter");
   RestoreSolverState(state);

@@ -4,6 +4,9 @@
 //   caffe time  --model=<net.prototxt> [--iterations=50] [--gpu=N]      (TRAIN-phase net; the graph runs as a fused
 //               plan, so the per-layer lines of the reference become per-kernel lines)
 //   caffe device_query --gpu=N
+// Layer-file gflags of the reference: --max_tries_for_negs=N (video_sampled_shots_data_layer.cpp:20), --num_classes=N
+// (retrieval_stats_layer.cpp:16).  Data-parallel: launch one process per GPU with WORLD_SIZE / RANK / LOCAL_RANK set
+// (python -m torch.distributed.run --no-python ... caffe train ..., or any launcher); --gpu defaults to LOCAL_RANK then.
 // Extra flags of this build: --precision=f16|bf16, --log_file=<path> (what GLOG_log_dir gives the
 // reference's train script, projects/videovec_embedding/train_mednet_embedding.sh:6).
 #include <cstring>
@@ -24,6 +27,7 @@ static int train() {
   SolverParameter solver_param("SolverParameter");
   pl::ReadProtoFromTextFileOrDie(flag("solver"), &solver_param);
   int gpu = atoi(flag("gpu", "-1").c_str());
+  if (gpu < 0 && Caffe::world() > 1) gpu = Caffe::local_rank();      // one process per GPU (torch.distributed.run style launch)
   if (gpu < 0 && solver_param.get_enum("solver_mode") == "GPU") gpu = (int)solver_param.get_int("device_id");
   CHECK_GE(gpu, 0) << "solver_mode: CPU is not available: this build is the GPU path only";
   LOG(INFO) << "Use GPU with device ID " << gpu;
@@ -58,49 +62,49 @@ static int device_query() {
   return 0;
 }
 
-// tools/caffe.cpp:127-189
-static int test() {
-  CHECK_GT(flag("model").size(), 0u) << "Need a model definition to score.";
-  CHECK_GT(flag("weights").size(), 0u) << "Need model weights to score.";
+// device selection shared by test / time: --gpu (default 0); there is no CPU mode in this build
+static void UseGpuFlag() {
   const int gpu = atoi(flag("gpu", "0").c_str());
   CHECK_GE(gpu, 0) << "Use CPU. -- not available: this build is the GPU path only";
   LOG(INFO) << "Use GPU with device ID " << gpu;
   Caffe::SetDevice(gpu);
   Caffe::set_mode(Caffe::GPU);
   if (flag("precision").size()) Caffe::set_precision(flag("precision"));
+}
+
+// `caffe test` (tools/caffe.cpp:127-189): --iterations forward passes of the TEST-phase net; every scalar of every output
+// blob is logged per batch ("Batch i, name = v") and as its mean at the end ("name = mean (* w = w*mean loss)").
+static int test() {
+  CHECK_GT(flag("model").size(), 0u) << "Need a model definition to score.";
+  CHECK_GT(flag("weights").size(), 0u) << "Need model weights to score.";
+  UseGpuFlag();
   Caffe::set_phase(Caffe::TEST);
-  Net<float> caffe_net(flag("model"), Caffe::TEST);
-  caffe_net.CopyTrainedLayersFrom(flag("weights"));
-  const int iterations = atoi(flag("iterations", "50").c_str());
-  LOG(INFO) << "Running for " << iterations << " iterations.";
-  vector<Blob<float>*> bottom_vec;
-  vector<int> test_score_output_id;
-  vector<float> test_score;
-  float loss = 0;
-  for (int i = 0; i < iterations; ++i) {
-    float iter_loss;
-    const vector<Blob<float>*>& result = caffe_net.Forward(bottom_vec, &iter_loss);
-    loss += iter_loss;
-    int idx = 0;
-    for (size_t j = 0; j < result.size(); ++j) {
-      const float* result_vec = result[j]->cpu_data();
-      for (int k = 0; k < result[j]->count(); ++k, ++idx) {
-        const float score = result_vec[k];
-        if (i == 0) { test_score.push_back(score); test_score_output_id.push_back((int)j); }
-        else test_score[idx] += score;
-        LOG(INFO) << "Batch " << i << ", " << caffe_net.blob_names()[caffe_net.output_blob_indices()[j]] << " = " << score;
+  Net<float> net(flag("model"), Caffe::TEST);
+  net.CopyTrainedLayersFrom(flag("weights"));
+  const int passes = atoi(flag("iterations", "50").c_str());
+  LOG(INFO) << "Running for " << passes << " iterations.";
+  struct Scalar { int blob; double sum; };
+  vector<Scalar> scalars;
+  double loss_sum = 0;
+  for (int pass = 0; pass < passes; ++pass) {
+    float pass_loss = 0;
+    const vector<Blob<float>*>& outs = net.Forward(vector<Blob<float>*>(), &pass_loss);
+    loss_sum += pass_loss;
+    size_t k = 0;
+    for (size_t j = 0; j < outs.size(); ++j)
+      for (int e = 0; e < outs[j]->count(); ++e, ++k) {
+        if (k == scalars.size()) scalars.push_back(Scalar{net.output_blob_indices()[j], 0.0});
+        const float v = outs[j]->cpu_data()[e];
+        scalars[k].sum += v;
+        LOG(INFO) << "Batch " << pass << ", " << net.blob_names()[scalars[k].blob] << " = " << v;
       }
-    }
   }
-  loss /= iterations;
-  LOG(INFO) << "Loss: " << loss;
-  for (size_t i = 0; i < test_score.size(); ++i) {
-    const int blob_index = caffe_net.output_blob_indices()[test_score_output_id[i]];
-    const float loss_weight = caffe_net.blob_loss_weights()[blob_index];
-    std::ostringstream loss_msg_stream;
-    const float mean_score = test_score[i] / iterations;
-    if (loss_weight) loss_msg_stream << " (* " << loss_weight << " = " << loss_weight * mean_score << " loss)";
-    LOG(INFO) << caffe_net.blob_names()[blob_index] << " = " << mean_score << loss_msg_stream.str();
+  LOG(INFO) << "Loss: " << (float)(loss_sum / passes);
+  for (const Scalar& sc : scalars) {
+    const float mean = (float)(sc.sum / passes), w = net.blob_loss_weights()[sc.blob];
+    std::ostringstream tail;
+    if (w) tail << " (* " << w << " = " << w * mean << " loss)";
+    LOG(INFO) << net.blob_names()[sc.blob] << " = " << mean << tail.str();
   }
   return 0;
 }
@@ -110,12 +114,7 @@ static int test() {
 // forward-backward(-update) iteration (host clock around the loop, device drained at both ends).
 static int time_net() {
   CHECK_GT(flag("model").size(), 0u) << "Need a model definition to time.";
-  const int gpu = atoi(flag("gpu", "0").c_str());
-  CHECK_GE(gpu, 0) << "Use CPU. -- not available: this build is the GPU path only";
-  LOG(INFO) << "Use GPU with device ID " << gpu;
-  Caffe::SetDevice(gpu);
-  Caffe::set_mode(Caffe::GPU);
-  if (flag("precision").size()) Caffe::set_precision(flag("precision"));
+  UseGpuFlag();
   Caffe::set_phase(Caffe::TRAIN);
   Net<float> caffe_net(flag("model"), Caffe::TRAIN);
   LOG(INFO) << "Performing Forward";
@@ -162,7 +161,10 @@ int main(int argc, char** argv) {
       else g_flags[a.substr(0, eq)] = a.substr(eq + 1);
     } else if (action.empty()) action = a;
   }
-  if (flag("log_file").size()) SetLogFile(flag("log_file"));
+  // every rank of a data-parallel job logs to its own file
+  if (flag("log_file").size()) SetLogFile(Caffe::rank() == 0 ? flag("log_file") : flag("log_file") + ".rank" + std::to_string(Caffe::rank()));
+  if (flag("max_tries_for_negs").size()) FLAGS_max_tries_for_negs = atoi(flag("max_tries_for_negs").c_str());
+  if (flag("num_classes").size()) FLAGS_num_classes = atoi(flag("num_classes").c_str());
   if (action == "train") return train();
   if (action == "test") return test();
   if (action == "time") return time_net();

@@ -357,6 +357,16 @@ int orc_get_threads(void) {
  * chosen at run time. */
 #include <immintrin.h>
 
+/* Threads worth waking for `work` units (multiply-adds, or floats moved): a parallel region over hundreds of threads costs
+ * far more than a small problem -- the fixture-sized cases of the tests ran 10^4 times slower on a 256-thread host than on
+ * one thread.  One thread per 64K units, at most what orc_set_threads allows. */
+static int threads_for(double work) {
+  const int nt = orc_get_threads();
+  const double want = work / 65536.0;
+  if (want <= 1.0) return 1;
+  return want >= nt ? nt : (int)want;
+}
+
 #define GK_KC 384
 #define GK_MC 96             /* multiple of both micro-kernels' MR (8 and 6) */
 #define GK_NC 4096
@@ -420,7 +430,7 @@ const char* orc_sgemm_isa(void) {
  * C = alpha * op(A) op(B) + beta * C. */
 static void gemm_blocked(int M, int N, int K, float alpha, const float* A, int a_trans, const float* B, int b_trans,
                          float beta, float* C) {
-  const int nt = orc_get_threads();
+  const int nt = threads_for((double)M * N * K / 16.0);
   const int use512 = !g_force_isa && __builtin_cpu_supports("avx512f");
   const int MR = use512 ? 8 : 6, NR = use512 ? 32 : 16;
   const ukr_fn ukr = use512 ? ukr_avx512 : ukr_avx2;
@@ -543,7 +553,7 @@ void orc_sgemm(int transA, int transB, int M, int N, int K, float alpha, const f
 /* normalization_layer.cpp:29-61.  caffe_powx -> powf (mkl_alternate.hpp:55). */
 void orc_normalize_fwd(int num, int dim, const float* x, float* y) {
   const float eps = 1e-10f;
-#pragma omp parallel for num_threads(orc_get_threads())
+#pragma omp parallel for num_threads(threads_for((double)num * dim))
   for (int i = 0; i < num; ++i) {
     const float* xi = x + (size_t)i * dim;
     float s = 0.f;
@@ -556,7 +566,7 @@ void orc_normalize_fwd(int num, int dim, const float* x, float* y) {
 /* normalization_layer.cpp:63-112: dx = (s*dy - x*(x.dy)) / (s^1.5 + eps), s = sum x^2 */
 void orc_normalize_bwd(int num, int dim, const float* x, const float* dy, float* dx) {
   const float eps = 1e-10f;
-#pragma omp parallel for num_threads(orc_get_threads())
+#pragma omp parallel for num_threads(threads_for((double)num * dim))
   for (int i = 0; i < num; ++i) {
     const float* xi = x + (size_t)i * dim;
     const float* gi = dy + (size_t)i * dim;
@@ -687,7 +697,7 @@ void orc_forward_backward(const orc_step_cfg* cfg, const float* table, const int
                           orc_step_out* out) {
   const int B = cfg->B, C = cfg->C, Nn = cfg->Nn, F = cfg->F, D = cfg->D;
   const int CN = C + Nn, R = CN * B, Q = 1 + Nn;
-  const int nt = orc_get_threads();
+  const int nt = threads_for((double)R * (F > D ? F : D));
   const float drop_scale = cfg->dropout_ratio > 0.f ? 1.f / (1.f - cfg->dropout_ratio) : 1.f;
 
   /* --- data layer copy (…data_layer.cpp:439-452,856-875) then SLICE dim 1 + CONCAT dim 0

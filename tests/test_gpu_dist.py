@@ -13,14 +13,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("mode", ["sync", "stale"])
+@pytest.mark.parametrize("mode", ["sync", "overlap", "torch-sync", "stale"])
 def test_bench_two_ranks_on_one_device(mode):
     env = dict(os.environ, VV_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    port = "295%02d" % (17 if mode == "sync" else 23)
+    port = "295%02d" % {"sync": 17, "overlap": 19, "torch-sync": 21, "stale": 23}[mode]
+    extra = ["--comm", "torch"] if mode == "torch-sync" else []
+    ar = "sync" if mode == "torch-sync" else mode
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"),
                         "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
-                        "--allreduce", mode] + (["--no-extra-legs"] if mode == "sync" else []), capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+                        "--allreduce", ar] + extra + (["--no-extra-legs"] if mode != "stale" else []), capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                    # rank 0 only
@@ -29,7 +31,8 @@ def test_bench_two_ranks_on_one_device(mode):
     assert d["config"]["global_batch"] == 2048 and d["config"]["parallelism"] == "dp2"
     assert d["value"] > 0 and abs(d["value"] - 2048 * 50 * 4 / (d["ms_per_step"] * 4e-3)) <= 1e-6 * d["value"]
     assert 0 < d["final_loss"] < 16 and d["roofline"]["frac"] > 0
-    if mode == "sync":
+    if mode != "stale":
         assert d["value_scope"].startswith("end to end") and "shared-memory ring" in d["config"]["sampler"]
+        assert ("torch" in d["config"]["comm"]) == (mode == "torch-sync")
     else:
         assert d["gpu_path_only"]["value"] > 0 and d["step_ms_stats"]["n"] == 4

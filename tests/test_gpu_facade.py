@@ -416,3 +416,54 @@ def test_caffe_train_with_test_net_and_extract_features(tool, pb, oracle, tmp_pa
     ref = oracle.embed(table, xrows[:20, 0], Wt, bt, relu=True, l2norm=False)
     assert got.shape == (20, D)
     assert (np.linalg.norm(got - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-20)).max() <= 1e-3
+
+
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_caffe_train_data_parallel_two_ranks(tool, pb, tmp_path, overlap):
+    """`caffe train` as a data-parallel job: two processes (WORLD_SIZE / RANK / LOCAL_RANK as torch.distributed.run sets
+    them) on the one visible GPU, gradients over the shared-memory test transport.  Rank 0's sampler draws the global
+    batch into a shared-memory ring, each rank trains on its half with the global loss count, the gradients are summed
+    before every update.  The result must equal ONE process training on the global batch (same indices, sums
+    reassociated), only rank 0 may write snapshots, and both ranks must log every iteration."""
+    B, C, Nn, F, D, V, IT = 32, 5, 6, 512, 512, 80, 3         # D = 512: two 256-row blocks of dW (the overlap's unit)
+    W0, b0 = init_weights(3, D, F, std=0.02)
+    write_caffemodel(pb, str(tmp_path / "init.caffemodel"), W0, b0)
+    src = "synthetic://videos=%d;seed=1701;features=%d" % (V, F)
+
+    def files(tag, batch):
+        net_p, sol_p = tmp_path / ("net_%s.prototxt" % tag), tmp_path / ("solver_%s.prototxt" % tag)
+        net_p.write_text(train_net(src, batch, C, Nn, D, max_buffer=500, w_std=0.02))
+        sol_p.write_text(solver(str(net_p), base_lr=0.01, max_iter=IT, display=1, snapshot=2,
+                                snapshot_prefix=str(tmp_path / ("snap_" + tag))))
+        return sol_p
+
+    one = files("one", 2 * B)
+    run_caffe(["train", "--solver=%s" % one, "--weights=%s" % (tmp_path / "init.caffemodel")], str(tmp_path / "one.log"))
+    W1, b1, _ = read_caffemodel(pb, str(tmp_path / ("snap_one_iter_%d.caffemodel" % IT)))
+
+    two = files("two", B)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, WORLD_SIZE="2", RANK=str(r), LOCAL_RANK="0", VV_COMM="shm", VV_COMM_OVERLAP=overlap,
+                   VV_JOB_ID="t%d_%s" % (os.getpid(), overlap))
+        procs.append(subprocess.Popen([CAFFE, "train", "--solver=%s" % two, "--weights=%s" % (tmp_path / "init.caffemodel"),
+                                       "--gpu=0", "--log_file=%s" % (tmp_path / "two.log")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[1][-3000:]
+    W2, b2, _ = read_caffemodel(pb, str(tmp_path / ("snap_two_iter_%d.caffemodel" % IT)))
+    e = rel_fro(W2 - W0, W1 - W0)
+    print("FACADE-DP overlap=%s: %d-iteration parameter change, 2 ranks vs 1 process on the global batch: %.3e" % (overlap, IT, e))
+    # (free-running iterations of this small case amplify the reassociation of the gradient sums, as in
+    # test_caffe_train_matches_oracle_trajectory; three iterations keep it near the one-step figure of ~2e-4)
+    assert e <= 3e-3 and rel_fro(b2 - b0, b1 - b0) <= 3e-3
+    log0, log1 = open(tmp_path / "two.log").read(), open(str(tmp_path / "two.log") + ".rank1").read()
+    assert "Data-parallel rank 0 of 2" in log0 and "Data-parallel rank 1 of 2" in log1
+    assert len(re.findall(r"Iteration \d+, lr = ", log0)) == IT and len(re.findall(r"Iteration \d+, lr = ", log1)) == IT
+    assert "Snapshotting to" in log0 and "Snapshotting to" not in log1
+    # each rank reports the loss of its own shard; their mean is the global batch's loss
+    l0 = [float(x) for x in re.findall(r"Iteration \d+, loss = ([0-9.eE+-]+)", log0)]
+    l1 = [float(x) for x in re.findall(r"Iteration \d+, loss = ([0-9.eE+-]+)", log1)]
+    lg = [float(x) for x in re.findall(r"Iteration \d+, loss = ([0-9.eE+-]+)", open(tmp_path / "one.log").read())]
+    assert abs(0.5 * (l0[0] + l1[0]) - lg[0]) <= 1e-4 * lg[0]
