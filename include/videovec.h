@@ -206,6 +206,51 @@ int vv_retrieval_stats(vv_ctx* ctx, const float* feat, int32_t n, int32_t dim, c
                        const int32_t* map_ids, const int32_t* map_cls, int32_t n_map,
                        int exclude_same_video_shots, float* mean_ap, float* hit_at_1, float* hit_at_5);
 
+/* ---- per-layer operators.  The reference's operator interface is Layer<Dtype>::{Forward_gpu, Backward_gpu}
+ * (include/caffe/layer.hpp:308-337); its sequential executor (Net::ForwardFromTo / BackwardFromTo, net.cpp:501-578) calls
+ * them layer by layer.  Training here runs the fused plan above; these entry points are what the C++ facade's layer classes
+ * call when a graph is executed layer by layer (a graph the fused-plan matcher does not recognise, gradient checks, a
+ * single Layer::Forward).  All buffers are fp32 DEVICE memory of this context (vv_dev_alloc; SyncedMemory's GPU side,
+ * src/caffe/syncedmem.cpp:55-109), row-major; everything is queued on the context's stream.
+ *   vv_op_copy2d      rows x cols block copy between strided buffers, optionally accumulating: SLICE / CONCAT forward and
+ *                     backward (slice_layer.cu:10-64, concat_layer.cu:10-75), SPLIT's diff sum (split_layer.cu:18-33)
+ *   vv_op_axpby       y = a x + b y: ELTWISE SUM with coefficients (eltwise_layer.cu:40-45, 99-105), diff accumulation
+ *   vv_op_mul         y (+)= a .* b: ELTWISE PROD forward and its stable-product backward (eltwise_layer.cu:36-38, 83-97)
+ *   vv_op_relu(_bwd)  relu_layer.cu:10-59, with negative_slope
+ *   vv_op_dropout     dropout_layer.cu:14-73: make_mask = 1 draws the mask (counter-based hash of seed and element index)
+ *                     and applies it; make_mask = 0 applies an existing mask -- the TRAIN backward, y = dy, with the same mask
+ *   vv_op_rowsum(_bwd)     SUM (sum_layer.cu:10-55): row sums replicated num_output times; backward broadcasts
+ *   vv_op_normalize(_bwd)  NORMALIZATION (normalization_layer.cu:10-97), eps placement of the reference (quirk Q6)
+ *   vv_op_max_margin(_bwd) MAX_MARGIN_LOSS (max_margin_loss_layer.cpp:53-214; CPU-only in the reference): weight NULL or
+ *                     one non-negative weight per term; forward synchronises and returns loss / violations to the host
+ *   vv_op_gather_rows the data layer's batch copy (base_data_layer.cu:7-21): table rows idx (host int32 [n], -1 = zeros) as fp32
+ *   vv_op_inner_product(_bwd)  INNER_PRODUCT with the context's parameters (inner_product_layer.cu:12-59): Y = X W^T + b;
+ *                     backward writes dW (scaled by 1 + regularization / 2 when > 0) and db into the flat gradient buffer,
+ *                     from which vv_apply_update updates.  No gradient w.r.t. X (the layer sits on the data layer). */
+int vv_dev_alloc(vv_ctx* ctx, size_t bytes, void** out);     /* zero-filled */
+int vv_dev_free(vv_ctx* ctx, void* p);
+int vv_dev_upload(vv_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int vv_dev_download(vv_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int vv_dev_memset(vv_ctx* ctx, void* dst_dev, int value, size_t bytes);
+int vv_op_copy2d(vv_ctx* ctx, const float* src, int64_t src_stride, float* dst, int64_t dst_stride, int64_t rows, int64_t cols,
+                 int accumulate);
+int vv_op_axpby(vv_ctx* ctx, int64_t n, float a, const float* x, float b, float* y);
+int vv_op_mul(vv_ctx* ctx, int64_t n, const float* a, const float* b, float* y, int accumulate);
+int vv_op_relu(vv_ctx* ctx, int64_t n, const float* x, float* y, float negative_slope);
+int vv_op_relu_bwd(vv_ctx* ctx, int64_t n, const float* x, const float* dy, float* dx, float negative_slope);
+int vv_op_dropout(vv_ctx* ctx, int64_t n, const float* x, float* y, uint8_t* mask, float ratio, uint64_t seed, int make_mask);
+int vv_op_rowsum(vv_ctx* ctx, int64_t rows, int32_t cols, const float* x, int32_t num_output, float* y);
+int vv_op_rowsum_bwd(vv_ctx* ctx, int64_t rows, int32_t cols, int32_t num_output, const float* dy, float* dx);
+int vv_op_normalize(vv_ctx* ctx, int64_t rows, int32_t cols, const float* x, float* y);
+int vv_op_normalize_bwd(vv_ctx* ctx, int64_t rows, int32_t cols, const float* x, const float* dy, float* dx);
+int vv_op_max_margin(vv_ctx* ctx, int32_t count, const float* s_true, const float* s_bogus, const float* weight, float margin,
+                     int32_t norm, float* loss, float* violations);
+int vv_op_max_margin_bwd(vv_ctx* ctx, int32_t count, const float* s_true, const float* s_bogus, const float* weight, float margin,
+                         int32_t norm, float loss_weight, float* d_true, float* d_bogus);
+int vv_op_gather_rows(vv_ctx* ctx, const int32_t* idx, int64_t n, float* out);
+int vv_op_inner_product(vv_ctx* ctx, const float* X, int64_t R, float* Y);
+int vv_op_inner_product_bwd(vv_ctx* ctx, const float* dY, int64_t R, float ip_regularization);
+
 /* ---- triplet sampler (host side, integer only).  Replaces VideoSampledShotsDataLayer's
  * DataLayerSetUp / AddSamplesToTop / InternalThreadEntry / AddToBuffer / RandomShuffleTopids
  * (src/caffe/layers/video_sampled_shots_data_layer.cpp:24-44,64-369,371-507,768-909) with the

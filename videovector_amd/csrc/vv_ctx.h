@@ -1,0 +1,90 @@
+// vv_ctx.h -- the context object behind include/videovec.h's vv_ctx, shared by api.hip (the fused training step)
+// and ops.hip (the per-layer operators).  Internal.
+#pragma once
+#include <cstdarg>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/videovec.h"
+#include "vv_internal.h"
+#include "vv_comm.h"
+
+extern thread_local char vv_g_err[512];
+int vv_fail(int code, const char* fmt, ...);
+#define fail vv_fail
+#define HIPCHK(x)                                                                              \
+  do {                                                                                         \
+    hipError_t e_ = (x);                                                                       \
+    if (e_ != hipSuccess)                                                                      \
+      return vv_fail(VV_ERR_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, \
+                     __LINE__);                                                                \
+  } while (0)
+
+struct ProfEntry { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; };
+
+struct vv_ctx {
+  int device = 0, prec = 0;
+  hipStream_t stream = nullptr, own_stream = nullptr;
+
+  // feature table
+  uint16_t* table = nullptr; int64_t n_rows = 0; int F = 0, Fp = 0; float sx = 1.f;
+  int64_t patch_cap = 0;            // scratch rows after the zero row (quirk Q1 composites)
+  int32_t* patch_desc = nullptr; int64_t patch_desc_cap = 0;
+  // parameters
+  int D = 0, Dp = 0;
+  float *W = nullptr, *b = nullptr, *hW = nullptr, *hb = nullptr;
+  uint16_t* Wh = nullptr; vv::Scales* scales = nullptr; float* wmax_blocks = nullptr;
+  float* grads = nullptr;           // [D*F + D] (own buffer, or the bound external one)
+  float* grads_own = nullptr;
+  // per-batch buffers
+  int B = 0, C = 0, Nn = 0, R = 0, Rp = 0;
+  int32_t *idx_dev = nullptr, *rows = nullptr;
+  float* H = nullptr; uint16_t* dYh = nullptr; float* dbp = nullptr;
+  float *loss_part = nullptr, *viol_part = nullptr, *s_true = nullptr, *s_bogus = nullptr;
+  float* coeff = nullptr; std::vector<float> coeff_host;
+  float* item_w = nullptr;          // [B] loss-term weights of the current batch
+  uint8_t* mask = nullptr; size_t mask_bytes = 0;
+  float* slabs = nullptr; size_t slab_bytes = 0; int S = 1, kps = 0;
+  float* loss2 = nullptr;           // {loss, violations}
+  float sg = 1.f; float last_loss_weight = 1.f;
+  uint64_t iter = 0;
+  bool have_fwd = false;
+  // row de-duplication (kernels_dedup.hip)
+  int dedup = 1;                    // 1 = on whenever dropout is off (VV_DEDUP / vv_set_dedup)
+  bool last_dedup = false;          // what the last forward/backward pass used
+  unsigned long long* dd_key = nullptr; int64_t dd_key_cap = 0;
+  unsigned long long* dd_agg = nullptr; int dd_agg_stride = 0;
+  int32_t *dd_slot_of = nullptr, *dd_uniq = nullptr, *dd_map = nullptr, *dd_ord = nullptr, *dd_cnt = nullptr,
+          *dd_seg = nullptr, *dd_pos = nullptr, *dd_info = nullptr;
+  uint16_t* dYu = nullptr;
+  int32_t* U_host = nullptr;        // pinned + mapped: k_dd_leaders stores U here every step, the launcher reads it late
+  int32_t* U_host_dev = nullptr;    // device alias of U_host
+  uint32_t dd_epoch = 0;
+  int32_t step_seq = 0;
+  // staging of index batches taken from a sampler's prefetch ring (vv_forward_backward_ring)
+  static constexpr int kStage = 8;
+  int32_t* stage_host[kStage] = {};         // pinned, mapped into the device's address space
+  int32_t* stage_dev[kStage] = {};          // the device's alias of the same memory
+  int32_t stage_seq[kStage] = {};           // sequence number of the step that last read the slot
+  size_t stage_bytes = 0; int32_t stage_next = 0;
+  int32_t* seq_host = nullptr;              // pinned + mapped: the forward GEMM stores the step's sequence number here,
+  int32_t* seq_host_dev = nullptr;          //   i.e. "the kernels that read this step's index batch have finished"
+  // data-parallel gradient exchange (comm.hip)
+  vv::Comm* comm = nullptr;
+  bool comm_overlap = false;        // all-reduce row blocks of dW while the weight-gradient kernel produces the next
+  bool grads_pending = false;       // a backward pass has produced gradients that have not been all-reduced / joined yet
+  bool grads_chunked = false;       // ... and their all-reduce is already in flight on the communication stream
+  hipEvent_t ev_chunk = nullptr;
+  // profiling
+  bool prof = false;
+  int prof_every = 1;               // record every prof_every-th forward/backward + update (vv_profile_enable's argument)
+  uint64_t prof_calls = 0;
+  std::map<std::string, ProfEntry> prof_map;
+  std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;    // events are reused across profiling sessions
+};
+
+
+// ops.hip keeps per-context scratch for the per-layer INNER_PRODUCT operators; vv_destroy releases it
+void vv_ops_release(vv_ctx* c);

@@ -70,6 +70,19 @@ def load_library():
         "vv_forward_backward_q1": [vp, vp, vp, vp],
         "vv_step": [vp, vp, vp, C.c_int],
         "vv_forward_backward_ring": [vp, vp, vp, i32, i32, vp, C.c_double],
+        "vv_dev_alloc": [vp, C.c_size_t, C.POINTER(vp)], "vv_dev_free": [vp, vp],
+        "vv_dev_upload": [vp, vp, vp, C.c_size_t], "vv_dev_download": [vp, vp, vp, C.c_size_t],
+        "vv_dev_memset": [vp, vp, C.c_int, C.c_size_t],
+        "vv_op_copy2d": [vp, vp, i64, vp, i64, i64, i64, C.c_int],
+        "vv_op_axpby": [vp, i64, f32, vp, f32, vp], "vv_op_mul": [vp, i64, vp, vp, vp, C.c_int],
+        "vv_op_relu": [vp, i64, vp, vp, f32], "vv_op_relu_bwd": [vp, i64, vp, vp, vp, f32],
+        "vv_op_dropout": [vp, i64, vp, vp, vp, f32, C.c_uint64, C.c_int],
+        "vv_op_rowsum": [vp, i64, i32, vp, i32, vp], "vv_op_rowsum_bwd": [vp, i64, i32, i32, vp, vp],
+        "vv_op_normalize": [vp, i64, i32, vp, vp], "vv_op_normalize_bwd": [vp, i64, i32, vp, vp, vp],
+        "vv_op_max_margin": [vp, i32, vp, vp, vp, f32, i32, C.POINTER(f32), C.POINTER(f32)],
+        "vv_op_max_margin_bwd": [vp, i32, vp, vp, vp, f32, i32, f32, vp, vp],
+        "vv_op_gather_rows": [vp, vp, i64, vp],
+        "vv_op_inner_product": [vp, vp, i64, vp], "vv_op_inner_product_bwd": [vp, vp, i64, f32],
         "vv_comm_init": [vp, i32, i32, C.c_char_p, i32], "vv_comm_overlap": [vp, C.c_int],
         "vv_allreduce_grads": [vp], "vv_comm_destroy": [vp],
         "vv_loss_get": [vp, C.POINTER(f32), C.POINTER(f32)],
@@ -226,6 +239,16 @@ class Engine:
         self._chk(self.L.vv_forward_backward_ring(self.h, C.byref(cfg.c), ring.h, consumer, item_begin, _ptr(label_out),
                                                   float(timeout_s)))
 
+    # ---- per-layer operators (vv_dev_* / vv_op_*): device buffers are DevBuf objects
+    def dev(self, array_or_shape):
+        """A device buffer: from a float32 / uint8 array (uploaded) or a shape (zeros, float32)."""
+        return DevBuf(self, array_or_shape)
+
+    def op(self, name, *args):
+        """Call vv_op_<name>(ctx, ...); DevBuf arguments pass their device pointer."""
+        conv = [a.ptr if isinstance(a, DevBuf) else (_ptr(a) if isinstance(a, np.ndarray) else a) for a in args]
+        self._chk(getattr(self.L, "vv_op_" + name)(self.h, *conv))
+
     # ---- data parallel (vv_comm_*)
     def comm_init(self, world, rank, id_path, transport="rccl"):
         self._chk(self.L.vv_comm_init(self.h, world, rank, None if id_path is None else id_path.encode(),
@@ -313,6 +336,47 @@ class Engine:
         ms, n = C.c_double(), C.c_int64()
         self._chk(self.L.vv_profile_get(self.h, kernel.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+class DevBuf:
+    """Device memory of an Engine's context (vv_dev_alloc): the GPU side of a Blob."""
+
+    def __init__(self, eng, array_or_shape):
+        self.eng = eng
+        if isinstance(array_or_shape, np.ndarray):
+            a = np.ascontiguousarray(array_or_shape)
+            self.shape, self.dtype = a.shape, a.dtype
+        else:
+            a = None
+            self.shape, self.dtype = tuple(np.atleast_1d(array_or_shape)), np.dtype(np.float32)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        p = C.c_void_p()
+        eng._chk(eng.L.vv_dev_alloc(eng.h, max(self.nbytes, 4), C.byref(p)))
+        self.ptr = C.c_void_p(p.value)
+        if a is not None and self.nbytes:
+            eng._chk(eng.L.vv_dev_upload(eng.h, self.ptr, _ptr(a), self.nbytes))
+
+    def get(self):
+        out = np.empty(self.shape, self.dtype)
+        if self.nbytes:
+            self.eng._chk(self.eng.L.vv_dev_download(self.eng.h, _ptr(out), self.ptr, self.nbytes))
+        return out
+
+    def set(self, a):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        assert a.shape == self.shape
+        self.eng._chk(self.eng.L.vv_dev_upload(self.eng.h, self.ptr, _ptr(a), self.nbytes))
+
+    def free(self):
+        if self.ptr is not None and getattr(self.eng, "h", None):
+            self.eng.L.vv_dev_free(self.eng.h, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class _SamplerParam(C.Structure):
