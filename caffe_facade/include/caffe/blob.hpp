@@ -1,12 +1,35 @@
-// blob.hpp -- host-side Blob with the reference's interface (include/caffe/blob.hpp:18-141).
-// Device memory lives inside the vv context; a Blob here is the host view that snapshot / inspection
-// code reads (cpu_data / cpu_diff), exactly what Net::ToProto, CopyTrainedLayersFrom and the solver
-// history need.  Only float is instantiated (the reference trains Solver<float>, tools/caffe.cpp:107).
+// blob.hpp -- Blob and SyncedMemory with the reference's interface (include/caffe/blob.hpp:18-141,
+// include/caffe/syncedmem.hpp:40-68).  A blob's data and diff live in a SyncedMemory each: a host copy and a device
+// copy (HIP memory of the process context, through vv_dev_*), allocated on first touch and synchronised on access by
+// the same head state machine (UNINITIALIZED / HEAD_AT_CPU / HEAD_AT_GPU / SYNCED).  The fused training plan keeps
+// its activations inside the context and only the host side of a blob is touched; the layer-by-layer executor
+// (Layer::Forward_gpu / Backward_gpu) works on the device side.  Only float is instantiated (the reference trains
+// Solver<float>, tools/caffe.cpp:107).
 #pragma once
 #include "caffe/common.hpp"
 #include "caffe/proto_lite.hpp"
 
 namespace caffe {
+
+class SyncedMemory {            // syncedmem.hpp:40-68
+ public:
+  explicit SyncedMemory(size_t size) : size_(size) {}
+  ~SyncedMemory();
+  enum SyncedHead { UNINITIALIZED, HEAD_AT_CPU, HEAD_AT_GPU, SYNCED };
+  const void* cpu_data();
+  void* mutable_cpu_data();
+  const void* gpu_data();
+  void* mutable_gpu_data();
+  SyncedHead head() const { return head_; }
+  size_t size() const { return size_; }
+ private:
+  void to_cpu();
+  void to_gpu();
+  std::vector<char> host_;
+  void* dev_ = nullptr;
+  size_t size_;
+  SyncedHead head_ = UNINITIALIZED;
+};
 
 template <typename Dtype>
 class Blob {
@@ -25,10 +48,14 @@ class Blob {
   }
   inline Dtype data_at(const int n, const int c, const int h, const int w) const { return cpu_data()[offset(n, c, h, w)]; }
   inline Dtype diff_at(const int n, const int c, const int h, const int w) const { return cpu_diff()[offset(n, c, h, w)]; }
-  const Dtype* cpu_data() const { return data_ ? data_->data() : nullptr; }
-  const Dtype* cpu_diff() const { return diff_ ? diff_->data() : nullptr; }
-  Dtype* mutable_cpu_data() { return data_ ? data_->data() : nullptr; }
-  Dtype* mutable_cpu_diff() { return diff_ ? diff_->data() : nullptr; }
+  const Dtype* cpu_data() const { return data_ ? (const Dtype*)data_->cpu_data() : nullptr; }
+  const Dtype* cpu_diff() const { return diff_ ? (const Dtype*)diff_->cpu_data() : nullptr; }
+  Dtype* mutable_cpu_data() { return data_ ? (Dtype*)data_->mutable_cpu_data() : nullptr; }
+  Dtype* mutable_cpu_diff() { return diff_ ? (Dtype*)diff_->mutable_cpu_data() : nullptr; }
+  const Dtype* gpu_data() const { return data_ ? (const Dtype*)data_->gpu_data() : nullptr; }
+  const Dtype* gpu_diff() const { return diff_ ? (const Dtype*)diff_->gpu_data() : nullptr; }
+  Dtype* mutable_gpu_data() { return data_ ? (Dtype*)data_->mutable_gpu_data() : nullptr; }
+  Dtype* mutable_gpu_diff() { return diff_ ? (Dtype*)diff_->mutable_gpu_data() : nullptr; }
   void Update();                                   // data -= diff   (blob.cpp:112-136)
   Dtype asum_data() const;
   Dtype asum_diff() const;
@@ -38,8 +65,9 @@ class Blob {
   void ShareData(const Blob& other) { CHECK_EQ(count_, other.count()); data_ = other.data_; }
   void ShareDiff(const Blob& other) { CHECK_EQ(count_, other.count()); diff_ = other.diff_; }
  private:
-  shared_ptr<vector<Dtype> > data_, diff_;
+  shared_ptr<SyncedMemory> data_, diff_;
   int num_, channels_, height_, width_, count_;
+  int capacity_ = 0;
 };
 
 }  // namespace caffe

@@ -73,6 +73,9 @@ class Caffe {
   static void set_precision(const std::string& p);
   // The HIP context of this process (created on first use)
   static vv_ctx* ctx();
+  static bool has_ctx();
+  // what ctx() returns while set (a TEST net's own context during its layer-by-layer pass); returns the previous one
+  static vv_ctx* set_current_ctx(vv_ctx* c);
   static void Reset();                                     // destroy the context (tests)
  private:
   Caffe();
@@ -84,6 +87,7 @@ class Caffe {
   int prec_ = VV_PREC_F16;
   unsigned int seed_ = 1701;
   vv_ctx* ctx_ = nullptr;
+  vv_ctx* current_ = nullptr;
 };
 
 }  // namespace caffe

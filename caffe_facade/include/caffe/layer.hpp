@@ -3,10 +3,12 @@
 // Backward signatures (2014-era `vector<Blob*>* top` API), blob-count checks and factory
 // (src/caffe/layer_factory.cpp:177-309).
 //
-// Execution model of this build: layers carry configuration, parameter blobs and shape inference
-// (Reshape); the arithmetic of the whole TRAIN graph runs as ONE fused HIP plan installed by
-// Net::Init (net.hpp).  Calling Forward/Backward on a single layer is fatal, with the same
-// abort-on-error convention the reference uses for unsupported configurations.
+// Execution model of this build: layers carry configuration, parameter blobs, shape inference (Reshape) and their
+// Forward_gpu / Backward_gpu (layers_gpu.cpp: one small HIP operator each, through vv_op_* of the C ABI).  When
+// Net::Init recognises the videovec TRAIN / TEST graph, the whole graph runs as ONE fused HIP plan instead (net.hpp)
+// and the per-layer functions are not called; any other arrangement of these layers runs layer by layer
+// (Net::ForwardFromTo / BackwardFromTo), as does a single Layer::Forward / Backward.  There is no CPU execution path:
+// Forward_cpu / Backward_cpu are fatal (the reference's CPU path is restated only as the test oracle).
 #pragma once
 #include <condition_variable>
 #include <map>
@@ -35,6 +37,9 @@ class Layer {
   Dtype Forward(const vector<Blob<Dtype>*>& bottom, vector<Blob<Dtype>*>* top);
   void Backward(const vector<Blob<Dtype>*>& top, const vector<bool>& propagate_down,
                 vector<Blob<Dtype>*>* bottom);
+  // Net::BackwardFromTo: bottoms whose diff already holds another consumer's contribution (fan-out without SPLIT
+  // layers, see net.hpp) receive this layer's contribution ADDED instead of written
+  void set_accumulate_bottom(const vector<bool>& acc) { accumulate_bottom_ = acc; }
   vector<shared_ptr<Blob<Dtype> > >& blobs() { return blobs_; }
   const LayerParameter& layer_param() const { return layer_param_; }
   virtual void ToProto(LayerParameter* param, bool write_diff = false);
@@ -64,6 +69,12 @@ class Layer {
   vector<shared_ptr<Blob<Dtype> > > blobs_;
   vector<bool> param_propagate_down_;
   vector<Dtype> loss_;
+  vector<bool> accumulate_bottom_;
+  // layer.hpp:308-337 of the reference.  GPU = HIP here.
+  virtual void Forward_cpu(const vector<Blob<Dtype>*>& bottom, vector<Blob<Dtype>*>* top);
+  virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, vector<Blob<Dtype>*>* top) = 0;
+  virtual void Backward_cpu(const vector<Blob<Dtype>*>& top, const vector<bool>& propagate_down, vector<Blob<Dtype>*>* bottom);
+  virtual void Backward_gpu(const vector<Blob<Dtype>*>& top, const vector<bool>& propagate_down, vector<Blob<Dtype>*>* bottom) = 0;
   virtual void CheckBlobCounts(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);   // layer.hpp:346-380
   inline void SetLossWeights(vector<Blob<Dtype>*>* top) {                                              // layer.hpp:387-401
     const int n = layer_param_.size("loss_weight");
@@ -95,7 +106,12 @@ struct VideoDataset {
   void UploadTable(vv_ctx* ctx) const;   // vv_table_synth / vv_table_set
 };
 
+#define VV_LAYER_GPU_DECL                                                                                              \
+ protected:                                                                                                            \
+  virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, vector<Blob<Dtype>*>* top);                             \
+  virtual void Backward_gpu(const vector<Blob<Dtype>*>& top, const vector<bool>& propagate_down, vector<Blob<Dtype>*>* bottom);
 #define VV_LAYER_BOILER(Name, TypeStr)                                            \
+  VV_LAYER_GPU_DECL                                                               \
  public:                                                                           \
   explicit Name(const LayerParameter& param) : Layer<Dtype>(param) {}            \
   virtual string type() const { return TypeStr; }
@@ -113,6 +129,9 @@ class VideoSampledShotsDataLayer : public Layer<Dtype> {
   virtual void Reshape(const vector<Blob<Dtype>*>& bottom, vector<Blob<Dtype>*>* top) {}
   // next prefetch batch: idx / last_src [B][C+Nn], label [B]
   void NextBatch(vector<int32_t>* idx, vector<int32_t>* last_src, vector<int32_t>* label);
+  // the batch the last Forward_gpu delivered (layer-by-layer execution)
+  const vector<int32_t>& last_idx() const { return fw_idx_; }
+  const vector<int32_t>& last_label() const { return fw_label_; }
   int batch_size() const { return batch_size_; }
   int context_size() const { return context_size_; }
   int num_negative_samples() const { return num_negative_samples_; }
@@ -127,6 +146,7 @@ class VideoSampledShotsDataLayer : public Layer<Dtype> {
   void JoinPrefetchThread();       // the wait happens inside vv_sampler_next
   bool prefetching_ = false;
   int rand_skip_ = 0;
+  vector<int32_t> fw_idx_, fw_last_, fw_label_;
   vv_sampler* sampler_ = nullptr;          // rank 0 only in a data-parallel job
   vv_batch_ring* ring_ = nullptr;          // the prefetch ring (rank 0: the sampler's own; other ranks: attached by name)
   int batch_size_ = 0, context_size_ = 0, num_negative_samples_ = 0, feature_size_ = 0;
@@ -179,7 +199,7 @@ class InnerProductLayer : public Layer<Dtype> {   // inner_product_layer.cpp:12-
   bool bias_term_ = true;
 };
 template <typename Dtype>
-class NeuronShapeLayer : public Layer<Dtype> {    // neuron_layer.cpp: top shaped like bottom
+class NeuronShapeLayer : public Layer<Dtype> {    // neuron_layer.cpp: top shaped like bottom (still abstract: no arithmetic)
  public:
   explicit NeuronShapeLayer(const LayerParameter& param) : Layer<Dtype>(param) {}
   virtual int ExactNumBottomBlobs() const { return 1; }
@@ -187,19 +207,26 @@ class NeuronShapeLayer : public Layer<Dtype> {    // neuron_layer.cpp: top shape
   virtual void Reshape(const vector<Blob<Dtype>*>& bottom, vector<Blob<Dtype>*>* top) { (*top)[0]->ReshapeLike(*bottom[0]); }
 };
 template <typename Dtype>
-class ReLULayer : public NeuronShapeLayer<Dtype> {
+class ReLULayer : public NeuronShapeLayer<Dtype> {            // relu_layer.cpp / .cu
+  VV_LAYER_GPU_DECL
  public:
   explicit ReLULayer(const LayerParameter& param) : NeuronShapeLayer<Dtype>(param) {}
   virtual string type() const { return "RELU"; }
 };
 template <typename Dtype>
-class DropoutLayer : public NeuronShapeLayer<Dtype> {
+class DropoutLayer : public NeuronShapeLayer<Dtype> {         // dropout_layer.cpp / .cu
+  VV_LAYER_GPU_DECL
  public:
   explicit DropoutLayer(const LayerParameter& param) : NeuronShapeLayer<Dtype>(param) {}
+  virtual ~DropoutLayer();
   virtual string type() const { return "DROPOUT"; }
+ private:
+  void* mask_ = nullptr; int mask_count_ = 0;      // uint8 device mask of the last TRAIN forward (rand_vec_ in the reference)
+  uint64_t calls_ = 0;
 };
 template <typename Dtype>
-class NormalizationLayer : public NeuronShapeLayer<Dtype> {
+class NormalizationLayer : public NeuronShapeLayer<Dtype> {   // normalization_layer.cpp / .cu
+  VV_LAYER_GPU_DECL
  public:
   explicit NormalizationLayer(const LayerParameter& param) : NeuronShapeLayer<Dtype>(param) {}
   virtual string type() const { return "NORMALIZATION"; }
@@ -239,9 +266,11 @@ class MaxMarginLossLayer : public Layer<Dtype> {  // max_margin_loss_layer.cpp:1
   // third bottom -> weight of one loss term: the value itself (use_direct_weight) or the id_to_weight_file entry,
   // 0 for ids the file does not list (std::map::operator[], max_margin_loss_layer.cpp:90-96)
   float WeightOf(float third_bottom_value) const;
+  virtual ~MaxMarginLossLayer();
  private:
   std::map<int, float> video_id_to_weight_;
   bool use_direct_weight_ = false;
+  void* weight_dev_ = nullptr; int weight_count_ = 0;    // per-term weights of the last forward (third bottom)
 };
 
 // VIDEO_SHOT_WINDOW_TEST_DATA (video_shot_window_test_data_layer.cpp:37-265): one record per item,

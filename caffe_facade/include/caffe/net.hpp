@@ -28,6 +28,10 @@ class Net {
   const vector<Blob<Dtype>*>& Forward(const vector<Blob<Dtype>*>& bottom, Dtype* loss = NULL);
   const vector<Blob<Dtype>*>& ForwardPrefilled(Dtype* loss = NULL);
   void Backward() {}                              // gradients are produced by ForwardBackward
+  // layer-by-layer execution (net.cpp:501-514, 567-578); used when the graph is not the fused pattern
+  Dtype ForwardFromTo(int start, int end);
+  void BackwardFromTo(int start, int end);
+  bool sequential() const { return sequential_; }
   // net.cpp:803-839: applies the update prepared by the solver (fused decay + momentum + step)
   void Update();
   void SetUpdateHyperParams(float rate, float momentum, float weight_decay, const string& reg, int solver_type = 0,
@@ -87,6 +91,11 @@ class Net {
  protected:
   void MatchVideovecTrainGraph();
   void MatchVideovecTestGraph();
+  void SetUpSequential(bool is_test);
+  Dtype SequentialStep();
+  bool sequential_ = false;
+  vector<bool> layer_need_backward_;
+  vector<vector<bool> > bottom_need_backward_;
   Dtype ForwardTest();
   vv_ctx* ctx_ = nullptr;            // train net: the process context; a TEST net owns a second one
   bool own_ctx_ = false;

@@ -77,8 +77,10 @@ void Caffe::set_precision(const std::string& p) {
   CHECK(p == "f16" || p == "bf16") << "unknown precision " << p;
   Get().prec_ = p == "f16" ? VV_PREC_F16 : VV_PREC_BF16;
 }
+vv_ctx* Caffe::set_current_ctx(vv_ctx* c) { vv_ctx* old = Get().current_; Get().current_ = c; return old; }
 vv_ctx* Caffe::ctx() {
   Caffe& c = Get();
+  if (c.current_) return c.current_;
   if (!c.ctx_) {
     const char* env = getenv("VV_PREC");
     if (env) c.prec_ = !strcmp(env, "bf16") ? VV_PREC_BF16 : VV_PREC_F16;
@@ -86,11 +88,42 @@ vv_ctx* Caffe::ctx() {
   }
   return c.ctx_;
 }
+bool Caffe::has_ctx() { return Get().ctx_ != nullptr; }
 void Caffe::Reset() {
   Caffe& c = Get();
   if (c.ctx_) vv_destroy(c.ctx_);
   c.ctx_ = nullptr;
 }
+
+// ------------------------------------------------------------------------------- SyncedMemory --
+// syncedmem.cpp:10-109 with HIP memory of the process context in place of cudaMalloc / cudaMemcpy
+SyncedMemory::~SyncedMemory() {
+  if (dev_ && Caffe::has_ctx()) vv_dev_free(Caffe::ctx(), dev_);
+}
+void SyncedMemory::to_cpu() {
+  switch (head_) {
+    case UNINITIALIZED: host_.assign(size_, 0); head_ = HEAD_AT_CPU; break;
+    case HEAD_AT_GPU:
+      if (host_.size() != size_) host_.assign(size_, 0);
+      VV_CHECK(vv_dev_download(Caffe::ctx(), host_.data(), dev_, size_));
+      head_ = SYNCED; break;
+    case HEAD_AT_CPU: case SYNCED: break;
+  }
+}
+void SyncedMemory::to_gpu() {
+  switch (head_) {
+    case UNINITIALIZED: VV_CHECK(vv_dev_alloc(Caffe::ctx(), size_, &dev_)); head_ = HEAD_AT_GPU; break;   // zero-filled
+    case HEAD_AT_CPU:
+      if (!dev_) VV_CHECK(vv_dev_alloc(Caffe::ctx(), size_, &dev_));
+      VV_CHECK(vv_dev_upload(Caffe::ctx(), dev_, host_.data(), size_));
+      head_ = SYNCED; break;
+    case HEAD_AT_GPU: case SYNCED: break;
+  }
+}
+const void* SyncedMemory::cpu_data() { to_cpu(); return host_.data(); }
+void* SyncedMemory::mutable_cpu_data() { to_cpu(); head_ = HEAD_AT_CPU; return host_.data(); }
+const void* SyncedMemory::gpu_data() { to_gpu(); return dev_; }
+void* SyncedMemory::mutable_gpu_data() { to_gpu(); head_ = HEAD_AT_GPU; return dev_; }
 
 // ------------------------------------------------------------------------------- Blob ----------
 template <typename Dtype>
@@ -98,9 +131,10 @@ void Blob<Dtype>::Reshape(const int num, const int channels, const int height, c
   CHECK_GE(num, 0); CHECK_GE(channels, 0); CHECK_GE(height, 0); CHECK_GE(width, 0);
   num_ = num; channels_ = channels; height_ = height; width_ = width;
   count_ = num * channels * height * width;
-  if (!data_ || (int)data_->size() < count_) {     // never shrinks (blob.cpp:20-24)
-    data_.reset(new vector<Dtype>(count_, Dtype(0)));
-    diff_.reset(new vector<Dtype>(count_, Dtype(0)));
+  if (!data_ || capacity_ < count_) {              // never shrinks (blob.cpp:20-24); memory is allocated on first touch
+    capacity_ = count_;
+    data_.reset(new SyncedMemory((size_t)count_ * sizeof(Dtype)));
+    diff_.reset(new SyncedMemory((size_t)count_ * sizeof(Dtype)));
   }
 }
 template <typename Dtype>
@@ -147,17 +181,6 @@ Layer<Dtype>::Layer(const LayerParameter& param) : layer_param_(param) {
   const int n = layer_param_.size("blobs");
   blobs_.resize(n);
   for (int i = 0; i < n; ++i) { blobs_[i].reset(new Blob<Dtype>()); blobs_[i]->FromProto(layer_param_.get_msg("blobs", i)); }
-}
-template <typename Dtype>
-Dtype Layer<Dtype>::Forward(const vector<Blob<Dtype>*>&, vector<Blob<Dtype>*>*) {
-  LOG(FATAL) << "Layer " << layer_param_.get_str("name") << " (" << type() << "): layer-by-layer execution is not "
-             << "part of this build; the videovec graph runs as one fused HIP plan (Net::ForwardBackward)";
-  return 0;
-}
-template <typename Dtype>
-void Layer<Dtype>::Backward(const vector<Blob<Dtype>*>&, const vector<bool>&, vector<Blob<Dtype>*>*) {
-  LOG(FATAL) << "Layer " << layer_param_.get_str("name") << " (" << type() << "): layer-by-layer execution is not "
-             << "part of this build; the videovec graph runs as one fused HIP plan (Net::ForwardBackward)";
 }
 template <typename Dtype>
 void Layer<Dtype>::ToProto(LayerParameter* param, bool write_diff) {

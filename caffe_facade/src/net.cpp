@@ -8,6 +8,11 @@
 
 namespace caffe {
 
+namespace {
+// what the graph matchers throw when the net is not (exactly) a videovec graph: Net::Init then runs it layer by layer
+struct GraphMismatch { string what; };
+}
+
 template <typename Dtype>
 Net<Dtype>::Net(const string& param_file, Caffe::Phase phase) {
   NetParameter param("NetParameter");
@@ -126,14 +131,25 @@ void Net<Dtype>::Init(const NetParameter& in_param) {
   }
   bool is_test = false;
   for (size_t li = 0; li < layers_.size(); ++li) is_test |= layers_[li]->type() == "VIDEO_SHOT_WINDOW_TEST_DATA";
+  // The recognised videovec graphs run as ONE fused plan; anything else built from these layer classes runs layer by
+  // layer (ForwardFromTo / BackwardFromTo over Layer::Forward_gpu / Backward_gpu).  VV_FACADE_SEQUENTIAL=1 forces the
+  // layer-by-layer executor on a graph the matcher would accept (tests: both executors must agree).
+  sequential_ = getenv("VV_FACADE_SEQUENTIAL") && atoi(getenv("VV_FACADE_SEQUENTIAL")) != 0;
+  if (!sequential_) {
+    try {
+      if (is_test) MatchVideovecTestGraph(); else MatchVideovecTrainGraph();
+    } catch (const GraphMismatch& m) {
+      LOG(INFO) << "Not the fused videovec pattern -- " << m.what << ".  Running this net layer by layer.";
+      sequential_ = true;
+    }
+  }
+  if (sequential_) SetUpSequential(is_test);
   if (is_test) {
     // a TEST / extraction net has its own feature table, hence its own context on the same device
-    MatchVideovecTestGraph();
     VV_CHECK(vv_create(Caffe::device(), getenv("VV_PREC") && !strcmp(getenv("VV_PREC"), "bf16") ? VV_PREC_BF16 : VV_PREC_F16, &ctx_));
     own_ctx_ = true;
     static_cast<VideoShotWindowTestDataLayer<Dtype>*>(layers_[plan_.data_layer].get())->dataset()->UploadTable(ctx_);
   } else {
-    MatchVideovecTrainGraph();
     ctx_ = Caffe::ctx();
     static_cast<VideoSampledShotsDataLayer<Dtype>*>(layers_[plan_.data_layer].get())->dataset()->UploadTable(ctx_);
   }
@@ -178,7 +194,7 @@ void Net<Dtype>::MatchVideovecTrainGraph() {
     const vector<int>& bi = bottom_id_vecs_[li];
     const vector<int>& ti = top_id_vecs_[li];
     auto in = [&](int i) -> Sym { return sym[bi[i]]; };
-    auto bad = [&](const string& what) { LOG(FATAL) << why << "layer " << lname << " (" << type << "): " << what; };
+    auto bad = [&](const string& what) { throw GraphMismatch{string(why) + "layer " + lname + " (" + type + "): " + what}; };
     if (type == "VIDEO_SAMPLED_SHOTS_DATA") {
       if (P.data_layer >= 0) bad("second data layer");
       auto* d = static_cast<VideoSampledShotsDataLayer<Dtype>*>(layer);
@@ -292,7 +308,7 @@ void Net<Dtype>::MatchVideovecTrainGraph() {
     }
   }
   if (P.data_layer < 0 || P.ip_layer < 0 || P.loss_layer < 0)
-    LOG(FATAL) << why << "the graph needs a VIDEO_SAMPLED_SHOTS_DATA layer, one INNER_PRODUCT layer and a MAX_MARGIN_LOSS layer";
+    throw GraphMismatch{string(why) + "the graph needs a VIDEO_SAMPLED_SHOTS_DATA layer, one INNER_PRODUCT layer and a MAX_MARGIN_LOSS layer"};
   blob_sym_.assign(blobs_.size(), BlobSym());
   for (auto& kv : sym) { blob_sym_[kv.first].kind = kv.second.k; blob_sym_[kv.first].a = kv.second.a; blob_sym_[kv.first].reps = kv.second.reps; }
   vv_step_cfg_default(&cfg_);
@@ -308,6 +324,112 @@ void Net<Dtype>::MatchVideovecTrainGraph() {
   for (int k = 0; k < 2; ++k) { cfg_.lr_mult[k] = params_lr_[p0 + k]; cfg_.decay_mult[k] = params_weight_decay_[p0 + k]; }
   LOG(INFO) << "Fused videovec plan: B=" << P.B << " C=" << P.C << " Nn=" << P.Nn << " F=" << P.F << " D=" << P.D
             << " margin=" << P.margin << " norm=L" << P.norm << " dropout=" << P.dropout_ratio;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Layer-by-layer execution (Net::ForwardFromTo / BackwardFromTo, net.cpp:501-514, 567-578) for nets that are not the
+// fused pattern.  The one INNER_PRODUCT layer still owns the context's parameters, gradient buffer and update kernel,
+// so Solver / Update / snapshots work unchanged; every other blob lives in its SyncedMemory.
+// Fan-out: the reference rewrites the net with SPLIT layers (insert_splits.cpp) so that the diffs of a blob read by
+// several layers are summed.  Here no layer is inserted (blob names stay those of the prototxt): during the backward
+// sweep the first consumer of a blob writes its diff, every later one adds to it (Layer::Backward, accumulate_bottom).
+// ---------------------------------------------------------------------------------------------
+template <typename Dtype>
+void Net<Dtype>::SetUpSequential(bool is_test) {
+  plan_ = FusedPlan();
+  blob_sym_.clear();
+  plan_.test = is_test;
+  const char* data_type = is_test ? "VIDEO_SHOT_WINDOW_TEST_DATA" : "VIDEO_SAMPLED_SHOTS_DATA";
+  for (size_t li = 0; li < layers_.size(); ++li) {
+    const string type = layers_[li]->type();
+    if (type == data_type) { CHECK_LT(plan_.data_layer, 0) << "one data layer per net"; plan_.data_layer = (int)li; }
+    if (type == "INNER_PRODUCT") {
+      CHECK_LT(plan_.ip_layer, 0) << "the context holds the parameters of ONE fc layer (the videovec path has one)";
+      plan_.ip_layer = (int)li;
+      plan_.D = static_cast<InnerProductLayer<Dtype>*>(layers_[li].get())->num_output();
+      plan_.F = bottom_vecs_[li][0]->count() / bottom_vecs_[li][0]->num();
+    }
+    if (type == "RETRIEVAL_STATS") plan_.stats_layer = (int)li;
+  }
+  CHECK_GE(plan_.data_layer, 0) << "the net needs a " << data_type << " layer";
+  CHECK_GE(plan_.ip_layer, 0) << "the net needs an INNER_PRODUCT layer";
+  if (is_test) {
+    auto* d = static_cast<VideoShotWindowTestDataLayer<Dtype>*>(layers_[plan_.data_layer].get());
+    plan_.B = d->batch_size(); plan_.C = d->context_size();
+    CHECK_EQ(plan_.F, d->dataset()->F) << "the fc layer must read rows of the data layer's feature size";
+  } else {
+    auto* d = static_cast<VideoSampledShotsDataLayer<Dtype>*>(layers_[plan_.data_layer].get());
+    plan_.B = d->batch_size(); plan_.C = d->context_size(); plan_.Nn = d->num_negative_samples();
+    CHECK_EQ(plan_.F, d->feature_size()) << "the fc layer must read rows of the data layer's feature size";
+  }
+  vv_step_cfg_default(&cfg_);
+  cfg_.B = plan_.B; cfg_.C = plan_.C; cfg_.Nn = plan_.Nn > 0 ? plan_.Nn : 1;
+  int p0 = 0;
+  for (int li = 0; li < plan_.ip_layer; ++li) p0 += (int)layers_[li]->blobs().size();
+  for (int k = 0; k < 2; ++k) { cfg_.lr_mult[k] = params_lr_[p0 + k]; cfg_.decay_mult[k] = params_weight_decay_[p0 + k]; }
+  // which blobs and layers take part in the backward sweep (net.cpp:99-140): a layer needs it when a bottom does or
+  // when it owns parameters with a nonzero learning rate
+  vector<bool> blob_bw(blobs_.size(), false);
+  layer_need_backward_.assign(layers_.size(), false);
+  bottom_need_backward_.assign(layers_.size(), vector<bool>());
+  for (size_t li = 0; li < layers_.size(); ++li) {
+    bool need = false;
+    for (int id : bottom_id_vecs_[li]) { bottom_need_backward_[li].push_back(blob_bw[id]); need = need || blob_bw[id]; }
+    if ((int)li == plan_.ip_layer) for (int k = 0; k < 2; ++k) need = need || cfg_.lr_mult[k] != 0.f;
+    layer_need_backward_[li] = need && !is_test;
+    for (int id : top_id_vecs_[li]) blob_bw[id] = blob_bw[id] || layer_need_backward_[li];
+  }
+  LOG(INFO) << "Layer-by-layer plan: " << layers_.size() << " layers, B=" << plan_.B << " F=" << plan_.F << " D=" << plan_.D;
+}
+
+template <typename Dtype>
+Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
+  Dtype loss = 0;
+  for (int li = start; li <= end; ++li) {
+    layers_[li]->Reshape(bottom_vecs_[li], &top_vecs_[li]);                             // net.cpp:508 (quirk Q11)
+    const Dtype l = layers_[li]->Forward(bottom_vecs_[li], &top_vecs_[li]);
+    loss += l;
+    if (debug_info_) LOG(INFO) << "    [Forward] Layer " << layer_names_[li] << ", loss " << l;
+  }
+  return loss;
+}
+
+template <typename Dtype>
+void Net<Dtype>::BackwardFromTo(int start, int end) {
+  vector<bool> written(blobs_.size(), false);
+  for (int li = start; li >= end; --li) {
+    if (!layer_need_backward_[li]) continue;
+    vector<bool> acc(bottom_id_vecs_[li].size(), false);
+    for (size_t i = 0; i < bottom_id_vecs_[li].size(); ++i) {
+      const int id = bottom_id_vecs_[li][i];
+      const bool in_place = i < top_id_vecs_[li].size() && top_id_vecs_[li][i] == id;
+      if (!bottom_need_backward_[li][i] || in_place) continue;
+      acc[i] = written[id];
+      written[id] = true;
+    }
+    layers_[li]->set_accumulate_bottom(acc);
+    layers_[li]->Backward(top_vecs_[li], bottom_need_backward_[li], &bottom_vecs_[li]);
+  }
+}
+
+namespace {
+// the per-layer operators run on whatever context is current; a TEST net owns a second one
+struct CurrentCtx {
+  vv_ctx* saved;
+  explicit CurrentCtx(vv_ctx* c) : saved(Caffe::set_current_ctx(c)) {}
+  ~CurrentCtx() { Caffe::set_current_ctx(saved); }
+};
+}
+
+template <typename Dtype>
+Dtype Net<Dtype>::SequentialStep() {
+  CurrentCtx guard(ctx_);
+  const int last = (int)layers_.size() - 1;
+  const Dtype loss = ForwardFromTo(0, last);
+  if (!plan_.test) BackwardFromTo(last, 0);
+  ++iter_;
+  last_loss_ = loss;
+  return loss;
 }
 
 template <typename Dtype>
@@ -358,6 +480,7 @@ struct HostProf {
 
 template <typename Dtype>
 Dtype Net<Dtype>::ForwardBackward(const vector<Blob<Dtype>*>&) {
+  if (sequential_) return SequentialStep();
   if (plan_.test) return ForwardTest();
   auto* data = static_cast<VideoSampledShotsDataLayer<Dtype>*>(layers_[plan_.data_layer].get());
   const double tp0 = g_hprof.on ? HostProf::now() : 0;
@@ -439,7 +562,7 @@ void Net<Dtype>::MatchVideovecTestGraph() {
     const vector<int>& bi = bottom_id_vecs_[li];
     const vector<int>& ti = top_id_vecs_[li];
     auto in = [&](int i) -> TS { return sym[bi[i]]; };
-    auto bad = [&](const string& what) { LOG(FATAL) << why << "layer " << lname << " (" << type << "): " << what; };
+    auto bad = [&](const string& what) { throw GraphMismatch{string(why) + "layer " + lname + " (" + type + "): " + what}; };
     if (type == "VIDEO_SHOT_WINDOW_TEST_DATA") {
       auto* d = static_cast<VideoShotWindowTestDataLayer<Dtype>*>(layer);
       P.data_layer = (int)li; P.B = d->batch_size(); P.C = k = d->context_size(); P.F = d->dataset()->F;
@@ -483,7 +606,7 @@ void Net<Dtype>::MatchVideovecTestGraph() {
       for (int t = 0; t < 3; ++t) { sym[ti[t]].k = T_STAT; P.stat_blobs[t] = blob_names_[ti[t]]; }
     } else bad("layer type outside the TEST path");
   }
-  if (P.data_layer < 0 || P.ip_layer < 0) LOG(FATAL) << why << "need a VIDEO_SHOT_WINDOW_TEST_DATA layer and one INNER_PRODUCT layer";
+  if (P.data_layer < 0 || P.ip_layer < 0) throw GraphMismatch{string(why) + "need a VIDEO_SHOT_WINDOW_TEST_DATA layer and one INNER_PRODUCT layer"};
   LOG(INFO) << "Fused videovec TEST plan: B=" << P.B << " frames=" << P.C << " F=" << P.F << " D=" << P.D
             << (P.stats_layer >= 0 ? " + retrieval stats" : "");
 }
@@ -544,7 +667,7 @@ template <typename Dtype>
 const shared_ptr<Blob<Dtype> > Net<Dtype>::blob_by_name(const string& n) {
   if (!has_blob(n)) { LOG(WARNING) << "Unknown blob name " << n; return shared_ptr<Blob<Dtype> >(); }   // net.cpp:846-857
   shared_ptr<Blob<Dtype> > b = blobs_[blob_names_index_[n]];
-  if (iter_ > 0 && !plan_.test) MaterializeTrainBlob(blob_names_index_[n]);
+  if (iter_ > 0 && !plan_.test && !sequential_) MaterializeTrainBlob(blob_names_index_[n]);
   return b;
 }
 
