@@ -415,7 +415,8 @@ def test_layer_by_layer_executor_matches_the_fused_plan(tool, pb, tmp_path):
     assert r.returncode != 0 and "outside the videovec training path" in r.stderr
 
 
-def test_caffe_train_with_test_net_and_extract_features(tool, pb, oracle, tmp_path):
+@pytest.mark.parametrize("executor", ["fused", "layer-by-layer"])
+def test_caffe_train_with_test_net_and_extract_features(tool, pb, oracle, tmp_path, executor):
     # the whole shipped net: TRAIN branch + TEST branch (retrieval statistics every test_interval
     # iterations through Solver::Test, solver.cpp:251-317), then extract_features on the snapshot
     from videovector_amd.prototxt import extraction_net
@@ -433,9 +434,13 @@ def test_caffe_train_with_test_net_and_extract_features(tool, pb, oracle, tmp_pa
                             test_iter=1, test_interval=2))
     W0, b0 = init_weights(4, D, F, std=0.02)
     write_caffemodel(pb, str(tmp_path / "init.caffemodel"), W0, b0)
+    env = {"VV_FACADE_SEQUENTIAL": "1"} if executor == "layer-by-layer" else {}
     log = run_caffe(["train", "--solver=%s" % sol_p, "--weights=%s" % (tmp_path / "init.caffemodel")],
-                    str(tmp_path / "t.log"))
-    assert "Fused videovec TEST plan: B=%d frames=4 F=%d D=%d + retrieval stats" % (NW, F, D) in log
+                    str(tmp_path / "t.log"), env)
+    if executor == "fused":
+        assert "Fused videovec TEST plan: B=%d frames=4 F=%d D=%d + retrieval stats" % (NW, F, D) in log
+    else:
+        assert log.count("Layer-by-layer plan") == 2          # the TRAIN net and the TEST net
     tests = re.findall(r"Iteration (\d+), Testing net \(#0\)", log)
     assert tests == ["0", "2", "4"]
     # net outputs are listed in name order (net.cpp:200-208 iterates a std::set)
@@ -455,7 +460,7 @@ def test_caffe_train_with_test_net_and_extract_features(tool, pb, oracle, tmp_pa
     ex_p.write_text(extraction_net(xsrc, 10, D))
     r = subprocess.run([os.path.join(ROOT, "caffe_facade", "build", "extract_features"),
                         str(tmp_path / "s_iter_4.caffemodel"), "none", str(ex_p), "ip2", str(tmp_path / "feat"), "2", "GPU", "0"],
-                       capture_output=True, text=True, timeout=600)
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
     assert r.returncode == 0, r.stderr[-2000:]
     lines = (tmp_path / "feat" / "text_output.txt").read_text().strip().split("\n")
     assert lines[0] == "#features" and len(lines) == 21
