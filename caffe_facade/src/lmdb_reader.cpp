@@ -54,22 +54,26 @@ bool LmdbReader::Open(const std::string& path, std::string* err) {
   entries_ = (size_t)rd<uint64_t>(main_db + 32);
   root_ = rd<uint64_t>(main_db + 40);
   last_pg_ = rd<uint64_t>(best + 24 + 2 * 48);
-  if (root_ != ~0ull && (root_ + 1) * psize_ > data_.size()) { *err = file + ": root page beyond the end of the file"; return false; }
+  if (root_ != ~0ull && root_ >= data_.size() / psize_) { *err = file + ": root page beyond the end of the file"; return false; }
   return true;
 }
 
 bool LmdbReader::WalkImpl(uint64_t pgno, int depth, const Fn& f, std::string* err) const {
-  if (depth > 64 || (pgno + 1) * (uint64_t)psize_ > data_.size()) { *err = "corrupt LMDB tree (page out of range)"; return false; }
+  const uint64_t n_pages = data_.size() / psize_;           // page numbers are compared, never multiplied: no 64-bit wrap
+  if (depth > 64 || pgno >= n_pages) { *err = "corrupt LMDB tree (page out of range)"; return false; }
   const uint8_t* pg = Page(pgno);
   const uint16_t flags = rd<uint16_t>(pg + 10);
-  const int nkeys = (rd<uint16_t>(pg + 12) - kPageHdr) / 2;
+  const uint32_t lower = rd<uint16_t>(pg + 12), upper = rd<uint16_t>(pg + 14);
+  if (lower < kPageHdr || lower > upper || upper > psize_) { *err = "corrupt LMDB page header (lower / upper)"; return false; }
+  const int nkeys = (int)(lower - kPageHdr) / 2;
   if (flags & 0x20) { *err = "LEAF2 pages (DUPFIXED) are not supported"; return false; }
   for (int i = 0; i < nkeys; ++i) {
     const uint16_t off = rd<uint16_t>(pg + kPageHdr + 2 * i);
-    if (off + 8u > psize_) { *err = "corrupt LMDB node offset"; return false; }
+    if (off < kPageHdr || off + 8u > psize_) { *err = "corrupt LMDB node offset"; return false; }
     const uint8_t* node = pg + off;
     const uint32_t lo = rd<uint16_t>(node), hi = rd<uint16_t>(node + 2);
     const uint16_t nflags = rd<uint16_t>(node + 4), ksize = rd<uint16_t>(node + 6);
+    if (off + 8u + ksize + ((flags & 0x02) && (nflags & 0x01) ? 8u : 0u) > psize_) { *err = "corrupt LMDB node (key beyond the page)"; return false; }
     if (flags & 0x01) {                 // branch
       const uint64_t child = (uint64_t)lo | ((uint64_t)hi << 16) | ((uint64_t)nflags << 32);
       if (!WalkImpl(child, depth + 1, f, err)) return false;
@@ -79,7 +83,7 @@ bool LmdbReader::WalkImpl(uint64_t pgno, int depth, const Fn& f, std::string* er
       std::string key((const char*)node + 8, ksize), val;
       if (nflags & 0x01) {              // F_BIGDATA: value lives on overflow pages
         const uint64_t ov = rd<uint64_t>(node + 8 + ksize);
-        if ((ov * psize_) + kPageHdr + (uint64_t)dsize > data_.size()) { *err = "overflow value beyond the end of the file"; return false; }
+        if (ov >= n_pages || (uint64_t)kPageHdr + dsize > (n_pages - ov) * psize_) { *err = "overflow value beyond the end of the file"; return false; }
         val.assign((const char*)Page(ov) + kPageHdr, dsize);
       } else {
         if (off + 8u + ksize + dsize > psize_) { *err = "corrupt LMDB leaf node"; return false; }

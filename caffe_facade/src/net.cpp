@@ -768,6 +768,9 @@ void Net<Dtype>::MaterializeTrainBlob(int id) {
 
 template <typename Dtype>
 void Net<Dtype>::CopyTrainedLayersFrom(const NetParameter& param) {
+  // the host blobs must hold the trained parameters before any of them is overwritten: a source model without the fc
+  // layer (or one ignored by name) leaves it untouched, as the reference does (net.cpp:703-706)
+  PullParamsFromDevice();
   for (int i = 0; i < param.size("layers"); ++i) {
     const LayerParameter& src = param.get_msg("layers", i);
     const string sname = src.get_str("name");

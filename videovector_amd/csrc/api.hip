@@ -131,8 +131,8 @@ int vv_create(int device, int prec, vv_ctx** out) {
   if (dd) c->dedup = atoi(dd) != 0;
   HIPCHK(hipMalloc(&c->dd_info, 4 * sizeof(int32_t)));
   HIPCHK(hipMemset(c->dd_info, 0, 4 * sizeof(int32_t)));
-  HIPCHK(hipHostMalloc((void**)&c->U_host, sizeof(int32_t), hipHostMallocMapped));
-  *c->U_host = 0;
+  HIPCHK(hipHostMalloc((void**)&c->U_host, 2 * sizeof(int32_t), hipHostMallocMapped));   // {U, saturated f16 gradient sums}
+  c->U_host[0] = c->U_host[1] = 0;
   HIPCHK(hipHostGetDevicePointer((void**)&c->U_host_dev, c->U_host, 0));
   HIPCHK(hipHostMalloc((void**)&c->seq_host, sizeof(int32_t), hipHostMallocMapped));
   *c->seq_host = 0;
@@ -201,6 +201,7 @@ int vv_destroy(vv_ctx* c) {
 int vv_set_dedup(vv_ctx* c, int on) {
   if (!c) return fail(VV_ERR_ARG, "vv_set_dedup: ctx is NULL");
   c->dedup = on != 0;
+  if (on && c->U_host) { c->U_host[1] = 0; c->dedup_overflowed = false; }   // a fresh start for the overflow guard
   return VV_OK;
 }
 
@@ -498,6 +499,11 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
 
   // De-duplicate the batch rows when dropout is off (with dropout every instance has its own mask on
   // top of the shared projection; that path stays dense).  Needs the default two-buffer GEMM kernels.
+  if (c->dedup && *(volatile int32_t*)(c->U_host + 1) > 0) {
+    // an earlier step's per-row gradient sums left the f16 range (k_segsum saturated them): from here on every sampled
+    // row goes through the GEMMs separately -- the dense path has no multiplicity factor
+    c->dedup = 0; c->dedup_overflowed = true;
+  }
   const bool dd = c->dedup && cfg->dropout_ratio == 0.f && (gemm_variant() == 0 || gemm_variant() == 3 || gemm_variant() == 4 || (gemm_variant() >= 5 && gemm_variant() <= 7)) && !ablate_on();
   c->last_dedup = dd;
   if (!dd) launch_map_rows(didx, c->rows, c->R, c->Rp, (int32_t)c->n_rows, (int32_t)row_limit, s);
@@ -561,6 +567,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   if (dd) {
     SegsumArgs ga;
     ga.dYh = c->dYh; ga.seg_start = c->dd_seg; ga.info = c->dd_info; ga.dYu = c->dYu; ga.Rp = c->Rp; ga.Dp = c->Dp;
+    ga.overflow_host = c->U_host_dev + 1;
     PROFILED(c, "segsum", launch_segsum(c->prec, ga, s));
   }
   WgradArgs wa;

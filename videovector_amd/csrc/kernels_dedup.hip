@@ -173,6 +173,10 @@ __global__ __launch_bounds__(256) void k_segsum(SegsumArgs a) {
   const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (u >= Uk || u >= a.Rp) return;
+  // f16: the sum of a row repeated thousands of times, with gradients far above their usual O(1) scaled size, could pass
+  // 65504.  T::from_float saturates (no inf, no NaN downstream); every saturated value is counted in host-visible
+  // memory and the host switches the context to the dense path, which has no multiplicity factor (api.hip: fb_impl).
+  int saturated = 0;
   int b = 0, e = 0;
   if (u < U) { b = a.seg_start[u]; e = a.seg_start[u + 1]; }
   for (int c0 = lane * 8; c0 < a.Dp; c0 += 512) {
@@ -192,8 +196,13 @@ __global__ __launch_bounds__(256) void k_segsum(SegsumArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       o[j] = T::from_float((float)acc[2 * j]) | ((uint32_t)T::from_float((float)acc[2 * j + 1]) << 16);
+    if (T::id == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) saturated |= fabs(acc[j]) > 65504.0;
+    }
     *(uint4*)(a.dYu + (int64_t)u * a.Dp + c0) = make_uint4(o[0], o[1], o[2], o[3]);
   }
+  if (T::id == 0 && saturated && a.overflow_host) __hip_atomic_fetch_add(a.overflow_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 void launch_segsum(int prec, const SegsumArgs& a, hipStream_t s) {

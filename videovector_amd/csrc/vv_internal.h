@@ -110,6 +110,7 @@ struct SegsumArgs {
   const int32_t* info;           // {U}
   uint16_t* dYu;                 // [Rp][Dp] per-slot sums (zero rows up to the next multiple of BK)
   int Rp, Dp;
+  int32_t* overflow_host = nullptr;   // host-mapped counter of f16 sums that saturated
 };
 
 struct WgradArgs {
