@@ -87,6 +87,18 @@ def lib():
                                      C.c_float, C.c_float, C.c_float, C.c_float, C.c_int]
         L.orc_solver_update.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                         C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float]
+        V = C.c_void_p
+        L.orc_relu_fwd.argtypes = [C.c_int64, V, C.c_float, V]
+        L.orc_relu_bwd.argtypes = [C.c_int64, V, V, C.c_float, V]
+        L.orc_dropout_fwd.argtypes = [C.c_int64, V, V, C.c_float, C.c_int, V]
+        L.orc_dropout_bwd.argtypes = [C.c_int64, V, V, C.c_float, C.c_int, V]
+        L.orc_eltwise_fwd.argtypes = [C.c_int, C.c_int64, C.c_int, V, V, V]
+        L.orc_eltwise_bwd.argtypes = [C.c_int, C.c_int64, C.c_int, V, V, V, V, C.c_int, C.c_int, V]
+        L.orc_split_pieces.argtypes = [C.c_int, C.c_int64, C.c_int, V, V, V]
+        L.orc_join_pieces.argtypes = [C.c_int, C.c_int64, C.c_int, V, V, V]
+        L.orc_split_bwd.argtypes = [C.c_int64, C.c_int, V, V]
+        L.orc_inner_product_fwd.argtypes = [C.c_int] * 3 + [V] * 4
+        L.orc_inner_product_bwd.argtypes = [C.c_int] * 3 + [V] * 6
         L.orc_normalize_fwd.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_normalize_bwd.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_max_margin_fwd.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
@@ -298,6 +310,102 @@ def sum_bwd(dy, dim):
     dy = _f32(dy); n, no = dy.shape; dx = np.empty((n, dim), np.float32)
     lib().orc_sum_bwd(n, dim, no, _p(dy), _p(dx))
     return dx
+
+
+def _pp(arrs):
+    """float** over a list of float32 arrays."""
+    return (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+
+
+def relu_fwd(x, slope=0.0):
+    x = _f32(x); y = np.empty_like(x)
+    lib().orc_relu_fwd(x.size, _p(x), C.c_float(slope), _p(y))
+    return y
+
+
+def relu_bwd(x, dy, slope=0.0):
+    x = _f32(x); dy = _f32(dy); dx = np.empty_like(x)
+    lib().orc_relu_bwd(x.size, _p(x), _p(dy), C.c_float(slope), _p(dx))
+    return dx
+
+
+def dropout_fwd(x, mask, ratio=0.5, train=True):
+    x = _f32(x); mask = np.ascontiguousarray(mask, np.uint8); y = np.empty_like(x)
+    lib().orc_dropout_fwd(x.size, _p(x), _p(mask), C.c_float(ratio), int(train), _p(y))
+    return y
+
+
+def dropout_bwd(dy, mask, ratio=0.5, train=True):
+    dy = _f32(dy); mask = np.ascontiguousarray(mask, np.uint8); dx = np.empty_like(dy)
+    lib().orc_dropout_bwd(dy.size, _p(dy), _p(mask), C.c_float(ratio), int(train), _p(dx))
+    return dx
+
+
+ELTWISE_OPS = {"PROD": 0, "SUM": 1, "MAX": 2}
+
+
+def eltwise_fwd(op, bottoms, coeff=None):
+    bs = [_f32(b) for b in bottoms]; top = np.empty_like(bs[0])
+    cf = _f32(coeff) if coeff is not None else None
+    lib().orc_eltwise_fwd(ELTWISE_OPS[op], top.size, len(bs), _pp(bs), _p(cf) if cf is not None else None, _p(top))
+    return top
+
+
+def eltwise_bwd(op, bottoms, dtop, which, coeff=None, stable=True):
+    bs = [_f32(b) for b in bottoms]; dtop = _f32(dtop); top = eltwise_fwd(op, bs, coeff)
+    cf = _f32(coeff) if coeff is not None else None
+    out = np.empty_like(bs[0])
+    lib().orc_eltwise_bwd(ELTWISE_OPS[op], top.size, len(bs), _pp(bs), _p(cf) if cf is not None else None,
+                          _p(top), _p(dtop), which, int(stable), _p(out))
+    return out
+
+
+def _piece_geometry(shape, dim):
+    shape = tuple(shape) + (1,) * (4 - len(shape))
+    outer = 1 if dim == 0 else shape[0]
+    inner = int(np.prod(shape[dim + 1:]))
+    return shape, outer, inner
+
+
+def slice_fwd(bottom, dim, widths):
+    """SliceLayer::Forward_cpu: a 4-d blob cut along dim 0 or 1 into tops of the given widths."""
+    bottom = _f32(bottom); shape, outer, inner = _piece_geometry(bottom.shape, dim)
+    assert sum(widths) == shape[dim]
+    tops = [np.empty(shape[:dim] + (w,) + shape[dim + 1:], np.float32) for w in widths]
+    wd = np.asarray(widths, np.int32)
+    lib().orc_split_pieces(outer, inner, len(tops), _p(wd), _p(bottom), _pp(tops))
+    return tops
+
+
+def concat_fwd(bottoms, dim):
+    """ConcatLayer::Forward_cpu along dim 0 or 1 (also SliceLayer::Backward_cpu on diffs)."""
+    bs = [_f32(b).reshape(tuple(b.shape) + (1,) * (4 - b.ndim)) for b in bottoms]
+    widths = [b.shape[dim] for b in bs]
+    shape, outer, inner = _piece_geometry(bs[0].shape, dim)
+    top = np.empty(shape[:dim] + (sum(widths),) + shape[dim + 1:], np.float32)
+    wd = np.asarray(widths, np.int32)
+    lib().orc_join_pieces(outer, inner, len(bs), _p(wd), _pp(bs), _p(top))
+    return top
+
+
+def split_bwd(dtops):
+    ds = [_f32(d) for d in dtops]; out = np.empty_like(ds[0])
+    lib().orc_split_bwd(out.size, len(ds), _pp(ds), _p(out))
+    return out
+
+
+def inner_product_fwd(X, W, b=None):
+    X = _f32(X); W = _f32(W); M = X.shape[0]; K = X.size // M; N = W.shape[0]
+    Y = np.empty((M, N), np.float32); bb = _f32(b) if b is not None else None
+    lib().orc_inner_product_fwd(M, N, K, _p(X), _p(W), _p(bb) if bb is not None else None, _p(Y))
+    return Y
+
+
+def inner_product_bwd(X, W, dY):
+    X = _f32(X); W = _f32(W); dY = _f32(dY); M = X.shape[0]; K = X.size // M; N = W.shape[0]
+    dW = np.empty((N, K), np.float32); db = np.empty(N, np.float32); dX = np.empty((M, K), np.float32)
+    lib().orc_inner_product_bwd(M, N, K, _p(X), _p(W), _p(dY), _p(dW), _p(db), _p(dX))
+    return dW, db, dX
 
 
 def learning_rate(policy, base_lr, gamma, power, stepsize, it):

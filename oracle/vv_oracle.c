@@ -630,6 +630,127 @@ void orc_sum_bwd(int num, int dim, int num_output, const float* dy, float* dx) {
   }
 }
 
+/* ============================================================ the plain layers of the graph === */
+/* relu_layer.cpp:10-20 */
+void orc_relu_fwd(int64_t n, const float* x, float slope, float* y) {
+  for (int64_t i = 0; i < n; ++i) y[i] = fmaxf(x[i], 0.f) + slope * fminf(x[i], 0.f);
+}
+/* relu_layer.cpp:23-37: the gate is read from the BOTTOM data */
+void orc_relu_bwd(int64_t n, const float* x, const float* dy, float slope, float* dx) {
+  for (int64_t i = 0; i < n; ++i) dx[i] = dy[i] * ((x[i] > 0.f) + slope * (x[i] <= 0.f));
+}
+/* dropout_layer.cpp:34-50 (TRAIN: x * mask * 1/(1-ratio); TEST: copy).  The mask is an argument: the
+ * reference draws it from its own Bernoulli stream (caffe_rng_bernoulli), which is not part of the path's contract. */
+void orc_dropout_fwd(int64_t n, const float* x, const uint8_t* mask, float ratio, int train, float* y) {
+  const float scale = 1.f / (1.f - ratio);
+  if (train) for (int64_t i = 0; i < n; ++i) y[i] = x[i] * (float)mask[i] * scale;
+  else for (int64_t i = 0; i < n; ++i) y[i] = x[i];
+}
+/* dropout_layer.cpp:52-68 */
+void orc_dropout_bwd(int64_t n, const float* dy, const uint8_t* mask, float ratio, int train, float* dx) {
+  const float scale = 1.f / (1.f - ratio);
+  if (train) for (int64_t i = 0; i < n; ++i) dx[i] = dy[i] * (float)mask[i] * scale;
+  else for (int64_t i = 0; i < n; ++i) dx[i] = dy[i];
+}
+/* eltwise_layer.cpp:53-105.  op: 0 PROD, 1 SUM (coeff may be NULL = all ones), 2 MAX */
+void orc_eltwise_fwd(int op, int64_t n, int nb, const float* const* bottom, const float* coeff, float* top) {
+  if (op == 0) {
+    for (int64_t i = 0; i < n; ++i) top[i] = bottom[0][i] * bottom[1][i];
+    for (int k = 2; k < nb; ++k) for (int64_t i = 0; i < n; ++i) top[i] = top[i] * bottom[k][i];
+  } else if (op == 1) {
+    for (int64_t i = 0; i < n; ++i) top[i] = 0.f;
+    for (int k = 0; k < nb; ++k) {
+      const float c = coeff ? coeff[k] : 1.f;
+      for (int64_t i = 0; i < n; ++i) top[i] += c * bottom[k][i];                     /* caffe_axpy */
+    }
+  } else {
+    for (int64_t i = 0; i < n; ++i) top[i] = bottom[0][i] > bottom[1][i] ? bottom[0][i] : bottom[1][i];
+    for (int k = 2; k < nb; ++k) for (int64_t i = 0; i < n; ++i) if (bottom[k][i] > top[i]) top[i] = bottom[k][i];
+  }
+}
+/* eltwise_layer.cpp:108-159: the diff of bottom `which`.  PROD: stable = product of the other bottoms
+ * (stable_prod_grad, the default), otherwise top / bottom; MAX routes the diff to the arg-max bottom
+ * (first maximum wins between bottoms 0 and 1 only when strictly greater, as the forward's mask does). */
+void orc_eltwise_bwd(int op, int64_t n, int nb, const float* const* bottom, const float* coeff,
+                     const float* top, const float* dtop, int which, int stable, float* dbottom) {
+  if (op == 0) {
+    if (stable) {
+      int started = 0;
+      for (int k = 0; k < nb; ++k) {
+        if (k == which) continue;
+        if (!started) { for (int64_t i = 0; i < n; ++i) dbottom[i] = bottom[k][i]; started = 1; }
+        else for (int64_t i = 0; i < n; ++i) dbottom[i] = bottom[k][i] * dbottom[i];
+      }
+    } else {
+      for (int64_t i = 0; i < n; ++i) dbottom[i] = top[i] / bottom[which][i];
+    }
+    for (int64_t i = 0; i < n; ++i) dbottom[i] = dbottom[i] * dtop[i];
+  } else if (op == 1) {
+    const float c = coeff ? coeff[which] : 1.f;
+    if (c == 1.f) for (int64_t i = 0; i < n; ++i) dbottom[i] = dtop[i];
+    else for (int64_t i = 0; i < n; ++i) dbottom[i] = c * dtop[i];
+  } else {
+    for (int64_t i = 0; i < n; ++i) {
+      int arg = bottom[0][i] > bottom[1][i] ? 0 : 1;
+      float best = bottom[arg][i];
+      for (int k = 2; k < nb; ++k) if (bottom[k][i] > best) { best = bottom[k][i]; arg = k; }
+      dbottom[i] = arg == which ? dtop[i] : 0.f;
+    }
+  }
+}
+/* SLICE forward / CONCAT backward (slice_layer.cpp:79-105, concat_layer.cpp:86-117): a blob cut along num
+ * (outer = 1, inner = channels*height*width, width_k = num_k) or along channels (outer = num,
+ * inner = height*width, width_k = channels_k) into pieces stored one after the other per outer index. */
+void orc_split_pieces(int outer, int64_t inner, int npieces, const int32_t* width, const float* whole,
+                      float* const* piece) {
+  int64_t total = 0;
+  for (int k = 0; k < npieces; ++k) total += width[k];
+  int64_t at = 0;
+  for (int k = 0; k < npieces; ++k) {
+    const int64_t len = width[k] * inner;
+    for (int o = 0; o < outer; ++o)
+      memcpy(piece[k] + (size_t)o * len, whole + ((size_t)o * total + at) * inner, sizeof(float) * (size_t)len);
+    at += width[k];
+  }
+}
+/* CONCAT forward / SLICE backward (concat_layer.cpp:45-83, slice_layer.cpp:107-135) */
+void orc_join_pieces(int outer, int64_t inner, int npieces, const int32_t* width, const float* const* piece,
+                     float* whole) {
+  int64_t total = 0;
+  for (int k = 0; k < npieces; ++k) total += width[k];
+  int64_t at = 0;
+  for (int k = 0; k < npieces; ++k) {
+    const int64_t len = width[k] * inner;
+    for (int o = 0; o < outer; ++o)
+      memcpy(whole + ((size_t)o * total + at) * inner, piece[k] + (size_t)o * len, sizeof(float) * (size_t)len);
+    at += width[k];
+  }
+}
+/* split_layer.cpp:36-51: the bottom diff is the sum of the top diffs (the forward shares the data, :28-34) */
+void orc_split_bwd(int64_t n, int ntop, const float* const* dtop, float* dbottom) {
+  for (int64_t i = 0; i < n; ++i) dbottom[i] = dtop[0][i];
+  for (int k = 1; k < ntop; ++k) for (int64_t i = 0; i < n; ++i) dbottom[i] += dtop[k][i];
+}
+/* inner_product_layer.cpp:61-74: Y (M x N) = X (M x K) W^T (N x K) + 1 b^T */
+void orc_inner_product_fwd(int M, int N, int K, const float* X, const float* W, const float* b, float* Y) {
+  orc_sgemm(0, 1, M, N, K, 1.f, X, W, 0.f, Y);
+  if (b) {
+    const int nt = threads_for((double)M * N);
+#pragma omp parallel for num_threads(nt)
+    for (int r = 0; r < M; ++r) for (int d = 0; d < N; ++d) Y[(size_t)r * N + d] += b[d];
+  }
+}
+/* inner_product_layer.cpp:76-106: dW = dY^T X, db = dY^T 1, dX = dY W (each optional) */
+void orc_inner_product_bwd(int M, int N, int K, const float* X, const float* W, const float* dY,
+                           float* dW, float* db, float* dX) {
+  if (dW) orc_sgemm(1, 0, N, K, M, 1.f, dY, X, 0.f, dW);
+  if (db) {
+    for (int d = 0; d < N; ++d) db[d] = 0.f;
+    for (int r = 0; r < M; ++r) for (int d = 0; d < N; ++d) db[d] += dY[(size_t)r * N + d];
+  }
+  if (dX) orc_sgemm(0, 0, M, K, N, 1.f, dY, W, 0.f, dX);
+}
+
 /* solver.cpp:440-460 */
 float orc_learning_rate(const char* policy, float base_lr, float gamma, float power, int stepsize,
                         int iter) {
@@ -698,10 +819,9 @@ void orc_forward_backward(const orc_step_cfg* cfg, const float* table, const int
   const int B = cfg->B, C = cfg->C, Nn = cfg->Nn, F = cfg->F, D = cfg->D;
   const int CN = C + Nn, R = CN * B, Q = 1 + Nn;
   const int nt = threads_for((double)R * (F > D ? F : D));
-  const float drop_scale = cfg->dropout_ratio > 0.f ? 1.f / (1.f - cfg->dropout_ratio) : 1.f;
 
   /* --- data layer copy (…data_layer.cpp:439-452,856-875) then SLICE dim 1 + CONCAT dim 0
-   * (prototxt :48-131; slice_layer.cpp:75-105, concat_layer.cpp:56-67) + FLATTEN: X row = ch*B+b */
+   * (prototxt :48-131; slice_layer.cpp:79-105, concat_layer.cpp:45-83) + FLATTEN (a reshape): X row = ch*B+b */
   float* data = falloc((size_t)B * CN * F);
 #pragma omp parallel for num_threads(nt)
   for (int i = 0; i < B * CN; ++i) {
@@ -711,45 +831,58 @@ void orc_forward_backward(const orc_step_cfg* cfg, const float* table, const int
       dst[F - 1] = last_src[i] >= 0 ? table[(size_t)last_src[i] * F + F - 1] : 0.f;
   }
   float* X = falloc((size_t)R * F);
+  int32_t* ones = (int32_t*)malloc(sizeof(int32_t) * (size_t)(CN > Q ? CN : Q));
+  for (int k = 0; k < (CN > Q ? CN : Q); ++k) ones[k] = 1;
 #pragma omp parallel for num_threads(nt)
-  for (int r = 0; r < R; ++r) {
-    const int ch = r / B, bb = r % B;
-    memcpy(X + (size_t)r * F, data + ((size_t)bb * CN + ch) * F, sizeof(float) * F);
+  for (int p = 0; p < nt; ++p) {                      /* the slice of items [b0, b1): one piece per channel */
+    const int b0 = (int)((int64_t)B * p / nt), b1 = (int)((int64_t)B * (p + 1) / nt);
+    if (b1 == b0) continue;
+    float** piece = (float**)malloc(sizeof(float*) * (size_t)CN);
+    for (int ch = 0; ch < CN; ++ch) piece[ch] = X + ((size_t)ch * B + b0) * F;
+    orc_split_pieces(b1 - b0, F, CN, ones, data + (size_t)b0 * CN * F, piece);
+    free(piece);
   }
   free(data);
 
-  /* --- fc7 INNER_PRODUCT (inner_product_layer.cpp:60-74): Y = X W^T + 1 b^T */
+  /* --- fc7 INNER_PRODUCT (inner_product_layer.cpp:61-74): Y = X W^T + 1 b^T */
   float* Y = falloc((size_t)R * D);
-  orc_sgemm(0, 1, R, D, F, 1.f, X, W, 0.f, Y);
-  if (b) {
-#pragma omp parallel for num_threads(nt)
-    for (int r = 0; r < R; ++r) for (int d = 0; d < D; ++d) Y[(size_t)r * D + d] += b[d];
-  }
-  /* --- RELU (relu_layer.cpp:9-20), DROPOUT in place on ip2 (dropout_layer.cpp:35-50) */
+  orc_inner_product_fwd(R, D, F, X, W, b, Y);
+  /* --- RELU (relu_layer.cpp:10-20), DROPOUT in place on ip2 (dropout_layer.cpp:34-50) */
   float* H = falloc((size_t)R * D);
   const float slope = cfg->relu_negative_slope;
+  const int64_t RD = (int64_t)R * D, BD = (int64_t)B * D;
 #pragma omp parallel for num_threads(nt)
-  for (size_t i = 0; i < (size_t)R * D; ++i) {
-    float h = fmaxf(Y[i], 0.f) + slope * fminf(Y[i], 0.f);
-    if (cfg->dropout_ratio > 0.f) h = h * (float)cfg->dropout_mask[i] * drop_scale;
-    H[i] = h;
+  for (int p = 0; p < nt; ++p) {
+    const int64_t o = RD * p / nt, n = RD * (p + 1) / nt - o;
+    orc_relu_fwd(n, Y + o, slope, H + o);
+    if (cfg->dropout_ratio > 0.f) orc_dropout_fwd(n, H + o, cfg->dropout_mask + o, cfg->dropout_ratio, 1, H + o);
   }
-  /* --- SLICE dim 0 (prototxt :232-257): E_ch = H[ch*B .. (ch+1)*B) */
+  /* --- SLICE dim 0 (prototxt :232-257): E_ch = H[ch*B .. (ch+1)*B), no copy */
   /* --- ELTWISE SUM with coeffs (eltwise_layer.cpp:65-71): A = sum_j c_j E_cj */
   float* A = falloc((size_t)B * D);
-  for (int j = 1; j < C; ++j) {
-    const float c = cfg->ctx_coeff ? cfg->ctx_coeff[j - 1] : 1.f;
-    const float* E = H + (size_t)j * B * D;
+  if (C > 1) {
 #pragma omp parallel for num_threads(nt)
-    for (size_t i = 0; i < (size_t)B * D; ++i) A[i] += c * E[i];
+    for (int p = 0; p < nt; ++p) {
+      const int64_t o = BD * p / nt, n = BD * (p + 1) / nt - o;
+      const float** E = (const float**)malloc(sizeof(float*) * (size_t)C);
+      for (int j = 1; j < C; ++j) E[j - 1] = H + (size_t)j * BD + o;
+      orc_eltwise_fwd(1, n, C - 1, E, cfg->ctx_coeff, A + o);
+      free(E);
+    }
   }
   /* --- NORMALIZATION of the context mean (prototxt :281-288) */
   float* Ahat = falloc((size_t)B * D);
   orc_normalize_fwd(B, D, A, Ahat);
   /* --- CONCAT dim 0 of target + negatives, NORMALIZATION, SLICE (prototxt :290-342) */
   float* PN = falloc((size_t)Q * B * D);
-  memcpy(PN, H, sizeof(float) * (size_t)B * D);
-  if (Nn > 0) memcpy(PN + (size_t)B * D, H + (size_t)C * B * D, sizeof(float) * (size_t)Nn * B * D);
+  {
+    const float** piece = (const float**)malloc(sizeof(float*) * (size_t)Q);
+    piece[0] = H;
+    for (int k = 0; k < Nn; ++k) piece[1 + k] = H + (size_t)(C + k) * BD;
+    for (int k = 0; k < Q; ++k) ones[k] = B;                                          /* concat_layer.cpp:48-55 */
+    orc_join_pieces(1, D, Q, ones, piece, PN);
+    free(piece);
+  }
   float* Phat = falloc((size_t)Q * B * D);
   orc_normalize_fwd(Q * B, D, PN, Phat);
   /* --- ELTWISE PROD + SUM (prototxt :354-629): s+ replicated Nn times, s-[b][k] */
@@ -760,7 +893,11 @@ void orc_forward_backward(const orc_step_cfg* cfg, const float* table, const int
   for (int q = 0; q < Q; ++q) {
     const float* P = Phat + (size_t)q * B * D;
 #pragma omp parallel for num_threads(nt)
-    for (size_t i = 0; i < (size_t)B * D; ++i) prod[i] = Ahat[i] * P[i];             /* eltwise :62 */
+    for (int p = 0; p < nt; ++p) {                                                    /* eltwise :61-65 */
+      const int64_t o = BD * p / nt, n = BD * (p + 1) / nt - o;
+      const float* two[2] = { Ahat + o, P + o };
+      orc_eltwise_fwd(0, n, 2, two, NULL, prod + o);
+    }
     if (q == 0) orc_sum_fwd(B, D, Nn, prod, s_true);                                  /* sum :43-47 */
     else {
       orc_sum_fwd(B, D, 1, prod, col);
@@ -789,57 +926,71 @@ void orc_forward_backward(const orc_step_cfg* cfg, const float* table, const int
     const float f = (float)count / (float)cfg->global_count;
     for (int i = 0; i < count; ++i) { d_true[i] *= f; d_bogus[i] *= f; }
   }
-  /* SUM / PROD backward per q, SPLIT of context_feature accumulates (split_layer.cpp:38-51) */
+  /* SUM / PROD backward per q; the Q copies of context_feature are tops of a SPLIT (split_layer.cpp:36-51) */
   float* dAhat = falloc((size_t)B * D);
   float* dPhat = falloc((size_t)Q * B * D);
+  float* dAq = falloc((size_t)Q * B * D);
   float* dprod = falloc((size_t)B * D);
   for (int q = 0; q < Q; ++q) {
-    if (q == 0) orc_sum_bwd(B, D, Nn, d_true, dprod);                                 /* sum :70-76 */
+    if (q == 0) orc_sum_bwd(B, D, Nn, d_true, dprod);                                 /* sum :56-82 */
     else {
       for (int bb = 0; bb < B; ++bb) col[bb] = d_bogus[(size_t)bb * Nn + (q - 1)];
       orc_sum_bwd(B, D, 1, col, dprod);
     }
     const float* P = Phat + (size_t)q * B * D;
-    float* dP = dPhat + (size_t)q * B * D;
 #pragma omp parallel for num_threads(nt)
-    for (size_t i = 0; i < (size_t)B * D; ++i) {                                      /* eltwise :116-131 */
-      dP[i] = Ahat[i] * dprod[i];
-      dAhat[i] += P[i] * dprod[i];
+    for (int p = 0; p < nt; ++p) {                                                    /* eltwise :116-131 */
+      const int64_t o = BD * p / nt, n = BD * (p + 1) / nt - o;
+      const float* two[2] = { Ahat + o, P + o };
+      orc_eltwise_bwd(0, n, 2, two, NULL, NULL, dprod + o, 1, 1, dPhat + (size_t)q * BD + o);
+      orc_eltwise_bwd(0, n, 2, two, NULL, NULL, dprod + o, 0, 1, dAq + (size_t)q * BD + o);
     }
   }
+#pragma omp parallel for num_threads(nt)
+  for (int p = 0; p < nt; ++p) {
+    const int64_t o = BD * p / nt, n = BD * (p + 1) / nt - o;
+    const float** tops = (const float**)malloc(sizeof(float*) * (size_t)Q);
+    for (int q = 0; q < Q; ++q) tops[q] = dAq + (size_t)q * BD + o;
+    orc_split_bwd(n, Q, tops, dAhat + o);
+    free(tops);
+  }
+  free(dAq);
   float* dPN = falloc((size_t)Q * B * D);
   orc_normalize_bwd(Q * B, D, PN, dPhat, dPN);
   float* dA = falloc((size_t)B * D);
   orc_normalize_bwd(B, D, A, dAhat, dA);
-  /* gather diffs back to dH rows (slice/concat backward), eltwise SUM backward (:132-138) */
+  /* diffs back to the rows of dH: CONCAT backward (concat_layer.cpp:86-100) hands the target and negative rows
+   * their pieces of dPN, the ELTWISE SUM backward (:132-138) writes c_j dA into the context rows; the SLICE dim 0
+   * backward (slice_layer.cpp:107-120) is then the identity on this layout. */
   float* dH = falloc((size_t)R * D);
-  memcpy(dH, dPN, sizeof(float) * (size_t)B * D);
-  if (Nn > 0) memcpy(dH + (size_t)C * B * D, dPN + (size_t)B * D, sizeof(float) * (size_t)Nn * B * D);
-  for (int j = 1; j < C; ++j) {
-    const float c = cfg->ctx_coeff ? cfg->ctx_coeff[j - 1] : 1.f;
-    float* dE = dH + (size_t)j * B * D;
-#pragma omp parallel for num_threads(nt)
-    for (size_t i = 0; i < (size_t)B * D; ++i) dE[i] = c * dA[i];
+  {
+    float** piece = (float**)malloc(sizeof(float*) * (size_t)Q);
+    piece[0] = dH;
+    for (int k = 0; k < Nn; ++k) piece[1 + k] = dH + (size_t)(C + k) * BD;
+    orc_split_pieces(1, D, Q, ones, dPN, piece);
+    free(piece);
   }
-  /* DROPOUT backward (dropout_layer.cpp:53-68), RELU backward (relu_layer.cpp:23-37) */
-  float* dY = falloc((size_t)R * D);
+  if (C > 1) {
 #pragma omp parallel for num_threads(nt)
-  for (size_t i = 0; i < (size_t)R * D; ++i) {
-    float g = dH[i];
-    if (cfg->dropout_ratio > 0.f) g = g * (float)cfg->dropout_mask[i] * drop_scale;
-    dY[i] = g * ((Y[i] > 0.f) + slope * (Y[i] <= 0.f));
-  }
-  /* INNER_PRODUCT backward (inner_product_layer.cpp:76-106): dW = dY^T X, db = dY^T 1 */
-  if (out->dW) {
-    orc_sgemm(1, 0, D, F, R, 1.f, dY, X, 0.f, out->dW);
-    if (cfg->ip_regularization > 0.f) {
-      const float f = (float)(1.0 + cfg->ip_regularization / 2);
-      for (size_t i = 0; i < (size_t)D * F; ++i) out->dW[i] *= f;
+    for (int p = 0; p < nt; ++p) {
+      const int64_t o = BD * p / nt, n = BD * (p + 1) / nt - o;
+      for (int j = 1; j < C; ++j)
+        orc_eltwise_bwd(1, n, C - 1, NULL, cfg->ctx_coeff, NULL, dA + o, j - 1, 1, dH + (size_t)j * BD + o);
     }
   }
-  if (out->db) {
-    for (int d = 0; d < D; ++d) out->db[d] = 0.f;
-    for (int r = 0; r < R; ++r) for (int d = 0; d < D; ++d) out->db[d] += dY[(size_t)r * D + d];
+  /* DROPOUT backward (dropout_layer.cpp:52-68), RELU backward (relu_layer.cpp:23-37) */
+  float* dY = falloc((size_t)R * D);
+#pragma omp parallel for num_threads(nt)
+  for (int p = 0; p < nt; ++p) {
+    const int64_t o = RD * p / nt, n = RD * (p + 1) / nt - o;
+    if (cfg->dropout_ratio > 0.f) orc_dropout_bwd(n, dH + o, cfg->dropout_mask + o, cfg->dropout_ratio, 1, dH + o);
+    orc_relu_bwd(n, Y + o, dH + o, slope, dY + o);
+  }
+  /* INNER_PRODUCT backward (inner_product_layer.cpp:76-106): dW = dY^T X, db = dY^T 1 */
+  orc_inner_product_bwd(R, D, F, X, W, dY, out->dW, out->db, NULL);
+  if (out->dW && cfg->ip_regularization > 0.f) {
+    const float f = (float)(1.0 + cfg->ip_regularization / 2);
+    for (size_t i = 0; i < (size_t)D * F; ++i) out->dW[i] *= f;
   }
 
   if (out->Y) memcpy(out->Y, Y, sizeof(float) * (size_t)R * D);
@@ -852,7 +1003,7 @@ void orc_forward_backward(const orc_step_cfg* cfg, const float* table, const int
 
   free(X); free(Y); free(H); free(A); free(Ahat); free(PN); free(Phat); free(s_true);
   free(s_bogus); free(prod); free(col); free(d_true); free(d_bogus); free(dAhat); free(dPhat);
-  free(dprod); free(dPN); free(dA); free(dH); free(dY);
+  free(dprod); free(dPN); free(dA); free(dH); free(dY); free(ones);
 }
 
 /* videovec_extraction.prototxt:179-205 (fc7 INNER_PRODUCT + RELU), optional NORMALIZATION as in

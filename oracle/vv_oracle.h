@@ -104,6 +104,30 @@ void orc_max_margin_bwd(int count, const float* s_true, const float* s_bogus, co
 /* sum_layer.cpp:31-54 / 56-82 */
 void orc_sum_fwd(int num, int dim, int num_output, const float* x, float* y);
 void orc_sum_bwd(int num, int dim, int num_output, const float* dy, float* dx);
+/* The plain layers of the graph, one function per Forward_cpu / Backward_cpu; orc_forward_backward is assembled
+ * from these, so the reference's per-layer tests restated in tests/test_oracle_reference_kats.py pin the code the
+ * whole-step oracle runs. */
+/* relu_layer.cpp:10-20 / 23-37 */
+void orc_relu_fwd(int64_t n, const float* x, float slope, float* y);
+void orc_relu_bwd(int64_t n, const float* x, const float* dy, float slope, float* dx);
+/* dropout_layer.cpp:34-50 / 52-68; mask 1 = keep, train 0 = TEST phase (identity) */
+void orc_dropout_fwd(int64_t n, const float* x, const uint8_t* mask, float ratio, int train, float* y);
+void orc_dropout_bwd(int64_t n, const float* dy, const uint8_t* mask, float ratio, int train, float* dx);
+/* eltwise_layer.cpp:53-105 / 108-159; op 0 PROD, 1 SUM, 2 MAX */
+void orc_eltwise_fwd(int op, int64_t n, int nb, const float* const* bottom, const float* coeff, float* top);
+void orc_eltwise_bwd(int op, int64_t n, int nb, const float* const* bottom, const float* coeff,
+                     const float* top, const float* dtop, int which, int stable, float* dbottom);
+/* slice_layer.cpp:79-135, concat_layer.cpp:45-117 (dims 0 and 1) */
+void orc_split_pieces(int outer, int64_t inner, int npieces, const int32_t* width, const float* whole,
+                      float* const* piece);
+void orc_join_pieces(int outer, int64_t inner, int npieces, const int32_t* width, const float* const* piece,
+                     float* whole);
+/* split_layer.cpp:36-51 */
+void orc_split_bwd(int64_t n, int ntop, const float* const* dtop, float* dbottom);
+/* inner_product_layer.cpp:61-74 / 76-106; b, dW, db, dX may be NULL */
+void orc_inner_product_fwd(int M, int N, int K, const float* X, const float* W, const float* b, float* Y);
+void orc_inner_product_bwd(int M, int N, int K, const float* X, const float* W, const float* dY,
+                           float* dW, float* db, float* dX);
 /* solver.cpp:440-460 */
 float orc_learning_rate(const char* policy, float base_lr, float gamma, float power, int stepsize,
                         int iter);

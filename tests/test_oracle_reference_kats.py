@@ -255,3 +255,236 @@ def test_blocked_sgemm_edges_and_both_kernels(oracle, force_avx2):
                     assert np.abs(out0 - ref0).max() <= 2e-5 * max(1.0, np.abs(ref0).max())
     finally:
         oracle.sgemm_isa(force_avx2=False)
+
+
+# ---------------------------------------------------------------- the plain layers -----------
+def layer_gradient(fwd, bwd, bottoms, step, thr, eltwise=False, kink=0.0, kink_range=-1.0, check=None):
+    """GradientChecker::CheckGradientExhaustive / CheckGradientEltwise (test_gradient_check_util.hpp:74-200):
+    for every top element j the objective is 2 * top[j] (GetObjAndGradient with loss_weight 2); every bottom
+    element is compared with a central difference; with `eltwise` only bottom element j is differenced and every
+    other analytic gradient must be exactly zero (:141-147)."""
+    bottoms = [b.copy() for b in bottoms]
+    tops = fwd(bottoms)
+    for t, top in enumerate(tops):
+        for j in range(top.size):
+            dtops = [np.zeros_like(x) for x in tops]
+            dtops[t].reshape(-1)[j] = 2.0
+            grads = bwd(bottoms, dtops)
+            for bi in (range(len(bottoms)) if check is None else check):
+                g = grads[bi].reshape(-1)
+                flat = bottoms[bi].reshape(-1)
+                for i in range(flat.size):
+                    if eltwise and i != j:
+                        assert g[i] == 0.0
+                        continue
+                    feat = float(flat[i])
+                    flat[i] = feat + step
+                    pos = 2.0 * float(fwd(bottoms)[t].reshape(-1)[j])
+                    flat[i] = feat - step
+                    neg = 2.0 * float(fwd(bottoms)[t].reshape(-1)[j])
+                    flat[i] = feat
+                    est = (pos - neg) / step / 2.0
+                    if kink - kink_range > abs(feat) or abs(feat) > kink + kink_range:
+                        scale = max(abs(g[i]), abs(est), 1.0)
+                        assert abs(g[i] - est) <= thr * scale, (t, j, bi, i, g[i], est)
+
+
+@pytest.fixture
+def neuron_bottom():
+    # test_neuron_layer.cpp:20-30: (2,3,4,5), gaussian(0,1)
+    return np.random.default_rng(1701).standard_normal((2, 3, 4, 5)).astype(np.float32)
+
+
+@pytest.mark.parametrize("slope", [0.0, 0.01])
+def test_relu_forward(oracle, neuron_bottom, slope):
+    # test_neuron_layer.cpp:96-109.  The reference's "negative slope" variant (:120-134) hands a TEXT-format string
+    # to ParseFromString (binary wire format), so its layer still runs with slope 0 and asserts the same thing; the
+    # slope 0.01 case here asserts the formula of relu_layer.cpp:16-19 itself.
+    y = oracle.relu_fwd(neuron_bottom, slope)
+    x = neuron_bottom
+    if slope == 0.0:
+        assert np.all(y >= 0)
+        assert np.all((y == 0) | (y == x))
+    assert np.array_equal(y, np.maximum(x, 0) + np.float32(slope) * np.minimum(x, 0))
+
+
+@pytest.mark.parametrize("slope", [0.0, 0.01])
+def test_relu_gradient(oracle, neuron_bottom, slope):
+    # test_neuron_layer.cpp:111-118, 136-144: GradientChecker(1e-2, 1e-3, 1701, kink 0, range 0.01), eltwise
+    layer_gradient(lambda b: [oracle.relu_fwd(b[0], slope)],
+                   lambda b, d: [oracle.relu_bwd(b[0], d[0], slope)],
+                   [neuron_bottom], 1e-2, 1e-3, eltwise=True, kink=0.0, kink_range=0.01)
+
+
+@pytest.mark.parametrize("ratio", [0.5, 0.75])
+def test_dropout_forward_train(oracle, neuron_bottom, ratio):
+    # test_neuron_layer.cpp:38-68 (TestDropoutHalf / ThreeQuarters): kept entries == bottom * 1/(1-ratio), the
+    # rest are zero.  The Bernoulli draw itself is an input of the oracle (the product draws its own on the GPU;
+    # tests/test_gpu_ops.py applies the reference's 1.96 sigma test to that).
+    x = neuron_bottom
+    mask = (np.random.default_rng(7).random(x.shape) >= ratio).astype(np.uint8)
+    y = oracle.dropout_fwd(x, mask, ratio, train=True)
+    scale = np.float32(1.0 / (1.0 - ratio))
+    kept = y != 0
+    assert np.array_equal(y[kept], (x * scale)[kept])
+    assert np.array_equal(kept, (mask != 0) & (x != 0))
+
+
+def test_dropout_forward_test_phase(oracle, neuron_bottom):
+    # test_neuron_layer.cpp:214-229
+    mask = np.zeros(neuron_bottom.shape, np.uint8)        # ignored in the TEST phase
+    assert np.array_equal(oracle.dropout_fwd(neuron_bottom, mask, 0.5, train=False), neuron_bottom)
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_dropout_gradient(oracle, neuron_bottom, train):
+    # test_neuron_layer.cpp:231-249 (the checker re-seeds before every forward, so the mask is fixed)
+    mask = (np.random.default_rng(7).random(neuron_bottom.shape) >= 0.5).astype(np.uint8)
+    layer_gradient(lambda b: [oracle.dropout_fwd(b[0], mask, 0.5, train)],
+                   lambda b, d: [oracle.dropout_bwd(d[0], mask, 0.5, train)],
+                   [neuron_bottom], 1e-2, 1e-3, eltwise=True)
+
+
+@pytest.fixture
+def eltwise_bottoms():
+    # test_eltwise_layer.cpp:21-38: three (2,3,4,5) blobs, uniform [0,1)
+    rng = np.random.default_rng(1701)
+    return [rng.random((2, 3, 4, 5)).astype(np.float32) for _ in range(3)]
+
+
+def test_eltwise_prod(oracle, eltwise_bottoms):
+    a, b, c = eltwise_bottoms                     # test_eltwise_layer.cpp:68-85
+    assert np.array_equal(oracle.eltwise_fwd("PROD", [a, b, c]), a * b * c)
+
+
+def test_eltwise_sum(oracle, eltwise_bottoms):
+    a, b, c = eltwise_bottoms                     # test_eltwise_layer.cpp:87-104
+    assert np.array_equal(oracle.eltwise_fwd("SUM", [a, b, c]), a + b + c)
+
+
+def test_eltwise_sum_coeff(oracle, eltwise_bottoms):
+    a, b, c = eltwise_bottoms                     # test_eltwise_layer.cpp:106-127
+    y = oracle.eltwise_fwd("SUM", [a, b, c], coeff=[1, -0.5, 2])
+    assert np.all(np.abs(y - (a - 0.5 * b + 2 * c)) <= 1e-4)
+
+
+def test_eltwise_max(oracle, eltwise_bottoms):
+    a, b, c = eltwise_bottoms                     # test_eltwise_layer.cpp:181-199
+    assert np.array_equal(oracle.eltwise_fwd("MAX", [a, b, c]), np.maximum(a, np.maximum(b, c)))
+
+
+@pytest.mark.parametrize("op,coeff,stable", [("PROD", None, True), ("PROD", None, False), ("SUM", None, True),
+                                             ("SUM", [1, -0.5, 2], True), ("MAX", None, True)])
+def test_eltwise_gradients(oracle, eltwise_bottoms, op, coeff, stable):
+    # test_eltwise_layer.cpp:129-179: GradientChecker(1e-2, 1e-3), CheckGradientEltwise; MAX (:196-207) steps 1e-4
+    n = len(eltwise_bottoms)
+    step = 1e-4 if op == "MAX" else 1e-2
+    layer_gradient(lambda b: [oracle.eltwise_fwd(op, b, coeff)],
+                   lambda b, d: [oracle.eltwise_bwd(op, b, d[0], k, coeff, stable) for k in range(n)],
+                   eltwise_bottoms, step, 1e-3, eltwise=True)
+
+
+@pytest.fixture
+def slice_bottom():
+    # test_slice_layer.cpp:21-37: (6,12,2,3) gaussian
+    return np.random.default_rng(1701).standard_normal((6, 12, 2, 3)).astype(np.float32)
+
+
+def test_slice_across_num(oracle, slice_bottom):
+    # test_slice_layer.cpp:62-74, 91-119: two tops of num 3
+    t0, t1 = oracle.slice_fwd(slice_bottom, 0, [3, 3])
+    assert t0.shape == (3, 12, 2, 3) and t1.shape == (3, 12, 2, 3)
+    assert np.array_equal(t0, slice_bottom[:3]) and np.array_equal(t1, slice_bottom[3:])
+
+
+def test_slice_across_channels(oracle, slice_bottom):
+    # test_slice_layer.cpp:121-162: slice points 2, 8 -> channels 2, 6, 4
+    t0, t1, t2 = oracle.slice_fwd(slice_bottom, 1, [2, 6, 4])
+    assert (t0.shape[1], t1.shape[1], t2.shape[1]) == (2, 6, 4)
+    assert np.array_equal(t0, slice_bottom[:, :2]) and np.array_equal(t1, slice_bottom[:, 2:8])
+    assert np.array_equal(t2, slice_bottom[:, 8:])
+
+
+@pytest.mark.parametrize("dim,widths", [(0, [2, 2]), (1, [4, 1])])
+def test_slice_gradient(oracle, dim, widths):
+    # test_slice_layer.cpp:164-187: bottom reduced to (4,5,2,2); GradientChecker(1e-2, 1e-3), exhaustive
+    x = np.random.default_rng(1701).standard_normal((4, 5, 2, 2)).astype(np.float32)
+    layer_gradient(lambda b: oracle.slice_fwd(b[0], dim, widths),
+                   lambda b, d: [oracle.concat_fwd(d, dim)], [x], 1e-2, 1e-3)
+
+
+def test_concat_forward_and_shapes(oracle):
+    # test_concat_layer.cpp:21-43 (constant fills 1, 2, 3), :61-85 shapes, :87-111 values
+    b0 = np.full((2, 3, 6, 5), 1, np.float32)
+    b1 = np.full((2, 5, 6, 5), 2, np.float32)
+    b2 = np.full((5, 3, 6, 5), 3, np.float32)
+    top = oracle.concat_fwd([b0, b2], 0)
+    assert top.shape == (7, 3, 6, 5)
+    assert np.array_equal(top[:2], b0) and np.array_equal(top[2:], b2)
+    top = oracle.concat_fwd([b0, b1], 1)
+    assert top.shape == (2, 8, 6, 5)
+    assert np.array_equal(top[:, :3], b0) and np.array_equal(top[:, 3:], b1)
+
+
+@pytest.mark.parametrize("dim", [0, 1])
+def test_concat_gradient(oracle, dim):
+    # test_concat_layer.cpp:113-120: GradientChecker(1e-2, 1e-2); the blobs are cut down to keep the run short
+    rng = np.random.default_rng(1701)
+    shapes = [(2, 3, 2, 2), (2, 5, 2, 2)] if dim == 1 else [(2, 3, 2, 2), (3, 3, 2, 2)]
+    bs = [rng.standard_normal(s).astype(np.float32) for s in shapes]
+    layer_gradient(lambda b: [oracle.concat_fwd(b, dim)],
+                   lambda b, d: oracle.slice_fwd(d[0], dim, [s[dim] for s in shapes]), bs, 1e-2, 1e-2)
+
+
+def test_split_forward_and_gradient(oracle):
+    # test_split_layer.cpp:66-77 (the tops ARE the bottom: split_layer.cpp:28-34 shares the data) and :79-86
+    x = np.random.default_rng(1701).standard_normal((2, 3, 6, 5)).astype(np.float32)
+    layer_gradient(lambda b: [b[0], b[0]], lambda b, d: [oracle.split_bwd(d)], [x], 1e-2, 1e-2, eltwise=True)
+    d = [np.random.default_rng(k).standard_normal(x.shape).astype(np.float32) for k in range(3)]
+    assert np.array_equal(oracle.split_bwd(d), (d[0] + d[1]) + d[2])
+
+
+def test_flatten_is_a_view(oracle):
+    # test_flatten_layer.cpp:40-63: (2,3,6,5) -> (2,90,1,1), top(n, c) == bottom(n, c / 30, (c / 5) % 6, c % 5): the
+    # row-major reshape the oracle relies on when it reads data-layer channels as rows of F values.
+    x = np.random.default_rng(1701).standard_normal((2, 3, 6, 5)).astype(np.float32)
+    top = x.reshape(2, 90)
+    for c in range(90):
+        assert top[0, c] == x[0, c // 30, (c // 5) % 6, c % 5]
+        assert top[1, c] == x[1, c // 30, (c // 5) % 6, c % 5]
+
+
+@pytest.fixture
+def ip_bottom():
+    # test_inner_product_layer.cpp:24-33: (2,3,4,5) uniform [0,1)
+    return np.random.default_rng(1701).random((2, 3, 4, 5)).astype(np.float32)
+
+
+def test_inner_product_forward(oracle, ip_bottom):
+    # test_inner_product_layer.cpp:43-56 (top is (2,10,1,1)) and :58-86 (uniform weights in [0,1), bias in
+    # [1,2): every output >= 1)
+    rng = np.random.default_rng(3)
+    W = rng.random((10, 60)).astype(np.float32)
+    b = (1 + rng.random(10)).astype(np.float32)
+    y = oracle.inner_product_fwd(ip_bottom, W, b)
+    assert y.shape == (2, 10)
+    assert np.all(y >= 1.0)
+    ref = ip_bottom.reshape(2, 60).astype(np.float64) @ W.T.astype(np.float64) + b
+    assert np.allclose(y, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_inner_product_gradient(oracle, ip_bottom):
+    # test_inner_product_layer.cpp:88-111: gaussian weights and bias, GradientChecker(1e-2, 1e-3), exhaustive over
+    # the bottom AND the two parameter blobs (test_gradient_check_util.hpp:86-93 adds the layer's blobs)
+    rng = np.random.default_rng(5)
+    W = rng.standard_normal((10, 60)).astype(np.float32)
+    b = rng.standard_normal(10).astype(np.float32)
+
+    def fwd(bl):
+        return [oracle.inner_product_fwd(bl[0], bl[1], bl[2])]
+
+    def bwd(bl, d):
+        dW, db, dX = oracle.inner_product_bwd(bl[0], bl[1], d[0])
+        return [dX.reshape(bl[0].shape), dW, db]
+
+    layer_gradient(fwd, bwd, [ip_bottom, W, b], 1e-2, 1e-3)
