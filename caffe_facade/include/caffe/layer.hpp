@@ -98,12 +98,19 @@ struct VideoDataset {
   int win_k = 0;
   vector<int32_t> win_rows, win_video_id;
   bool SameTable(const VideoDataset& o) const { return synthetic && o.synthetic && seed == o.seed && n_rows == o.n_rows && F == o.F; }
-  int win_pos = 0, win_neg = 0;    // positive / negative shot words per DB test record (not consumed)
+  // per window win_rows holds win_k context rows, then win_pos positive rows, then win_neg negative rows
+  int win_pos = 0, win_neg = 0;
+  vector<int32_t> win_pos_ids;     // positive_shot_id count of each record
   enum Kind { kShots, kTestWindows };
   static shared_ptr<VideoDataset> Open(const string& source, Kind kind = kShots, const string& backend = "LMDB");
   static shared_ptr<VideoDataset> OpenLmdbVideoShots(const string& source);
   static shared_ptr<VideoDataset> OpenLmdbTestWindows(const string& source);
   void UploadTable(vv_ctx* ctx) const;   // vv_table_synth / vv_table_set
+  // VideoSampledShotsDataParameter.negative_dataset: the records that fill the initial negative buffer; their rows
+  // are appended to `features`
+  vector<int32_t> neg_video_id, neg_n_shots, neg_shot_ids;
+  vector<int64_t> neg_row_base;
+  void AppendNegatives(const VideoDataset& neg);
 };
 
 #define VV_LAYER_GPU_DECL                                                                                              \
@@ -286,11 +293,13 @@ class VideoShotWindowTestDataLayer : public Layer<Dtype> {
   virtual void Reshape(const vector<Blob<Dtype>*>& bottom, vector<Blob<Dtype>*>* top) {}
   void NextBatch(vector<int32_t>* rows, vector<int32_t>* video_ids);    // rows [B][k]
   int batch_size() const { return batch_size_; }
-  int context_size() const { return dataset_->win_k; }
+  // channels of the top: context words, then the included positives, then the included negatives
+  int channels() const { return dataset_->win_k + positive_size_ + negative_size_; }
+  int context_size() const { return channels(); }
   const shared_ptr<VideoDataset>& dataset() const { return dataset_; }
  private:
   shared_ptr<VideoDataset> dataset_;
-  int batch_size_ = 0;
+  int batch_size_ = 0, positive_size_ = 0, negative_size_ = 0;
   size_t cursor_ = 0;
 };
 // RETRIEVAL_STATS (retrieval_stats_layer.cpp:19-90): tops = mean AP, hit@1, hit@5

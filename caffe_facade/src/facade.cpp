@@ -287,39 +287,52 @@ shared_ptr<VideoDataset> VideoDataset::OpenLmdbVideoShots(const string& source) 
 }
 
 // TestVideoShotWindows records (video_shot_sentences.proto:22-30; video_shot_window_test_data_layer.cpp:153-235):
-// each record's context words become consecutive table rows
+// each record's words become consecutive table rows in the layer's channel order -- context words, then positive
+// words, then negative words -- whatever order the fields were serialised in
 shared_ptr<VideoDataset> VideoDataset::OpenLmdbTestWindows(const string& source) {
   shared_ptr<VideoDataset> ds(new VideoDataset());
   LmdbReader db; string err;
   CHECK(db.Open(source, &err)) << err;
   LOG(INFO) << "Opening lmdb " << source;
   bool ok = true;
-  vector<float> feat;
+  vector<float> feat, group[3];                 // 0 context (field 5), 1 positives (field 4), 2 negatives (field 6)
+  bool first = true;
   CHECK(db.ForEach([&](const string& key, const string& val) {
     Wire w(val.data(), val.size());
-    bool has_vid = false; int32_t vid = 0; int k = 0, npos = 0, nneg = 0;
+    bool has_vid = false; int32_t vid = 0; int cnt[3] = {0, 0, 0}; int npos_ids = 0;
+    for (auto& g : group) g.clear();
     while (w.more()) {
       const uint64_t tag = w.varint(); const int fn = (int)(tag >> 3), wt = (int)(tag & 7);
+      const int g = fn == 5 ? 0 : fn == 4 ? 1 : fn == 6 ? 2 : -1;
       if (fn == 1 && wt == 0) { vid = (int32_t)w.varint(); has_vid = true; }
-      else if (fn == 5 && wt == 2) {
+      else if (g >= 0 && wt == 2) {
         feat.clear(); ParseDatumFloats(w.sub(), &feat, &ok);
         if (ds->F == 0) ds->F = (int)feat.size();
-        CHECK_EQ((int)feat.size(), ds->F) << "record " << key << ": context word with " << feat.size() << " features";
-        ds->features.insert(ds->features.end(), feat.begin(), feat.end());
-        ds->win_rows.push_back((int32_t)ds->n_rows++);
-        ++k;
-      } else if (fn == 4 && wt == 2) { ++npos; w.skip(wt); }
-      else if (fn == 6 && wt == 2) { ++nneg; w.skip(wt); }
+        CHECK_EQ((int)feat.size(), ds->F) << "record " << key << ": shot word with " << feat.size() << " features";
+        group[g].insert(group[g].end(), feat.begin(), feat.end());
+        ++cnt[g];
+      } else if (fn == 2 && wt == 0) { ++npos_ids; w.varint(); }
+      else if (fn == 2 && wt == 2) { Wire pk = w.sub(); while (pk.more()) { pk.varint(); ++npos_ids; } }   // packed
       else w.skip(wt);
     }
     CHECK(w.ok && ok) << "record " << key << " is not a valid TestVideoShotWindows message";
     CHECK(has_vid) << "No video id found for shot window";                          // …test_data_layer.cpp:188
-    if (ds->win_k == 0) { ds->win_k = k; ds->win_pos = npos; ds->win_neg = nneg; }
-    CHECK_EQ(k, ds->win_k);                                                         // …:193
+    if (first) { ds->win_k = cnt[0]; ds->win_pos = cnt[1]; ds->win_neg = cnt[2]; first = false; }   // …:98-99, 112
+    CHECK_EQ(cnt[0], ds->win_k);                                                    // …:193
+    // the reference compares positives / negatives with the first record only when they are included (:190-201);
+    // the rows are stored either way, so every record must agree
+    CHECK_EQ(cnt[1], ds->win_pos) << "record " << key << ": positive_shot_words";
+    CHECK_EQ(cnt[2], ds->win_neg) << "record " << key << ": negative_shot_words";
+    ds->win_pos_ids.push_back(npos_ids);
+    for (int g = 0; g < 3; ++g) {
+      ds->features.insert(ds->features.end(), group[g].begin(), group[g].end());
+      for (int j = 0; j < cnt[g]; ++j) ds->win_rows.push_back((int32_t)ds->n_rows++);
+    }
     ds->win_video_id.push_back(vid);
   }, &err)) << err;
   CHECK_GE(ds->win_video_id.size(), 1u) << "empty database " << source;
-  LOG(INFO) << "Read " << ds->win_video_id.size() << " test windows of " << ds->win_k << " context frames, " << ds->F << " features";
+  LOG(INFO) << "Read " << ds->win_video_id.size() << " test windows of " << ds->win_k << " context frames, " << ds->win_pos
+            << " positives, " << ds->win_neg << " negatives, " << ds->F << " features";
   return ds;
 }
 
@@ -407,6 +420,15 @@ shared_ptr<VideoDataset> VideoDataset::Open(const string& source, Kind kind, con
   LOG(INFO) << "Opening dataset " << source << ": " << nv << " videos, " << ds->n_rows << " frames, " << F << " features";
   return ds;
 }
+// negative_dataset: its feature rows follow this dataset's in the one table the context holds
+void VideoDataset::AppendNegatives(const VideoDataset& neg) {
+  CHECK(!synthetic && !neg.synthetic) << "negative_dataset needs stored (not synthetic://) sources";
+  CHECK_EQ(F, neg.F) << "negative_dataset has a different feature size";
+  neg_video_id = neg.video_id; neg_n_shots = neg.n_shots; neg_shot_ids = neg.shot_ids;
+  for (int64_t rb : neg.row_base) neg_row_base.push_back(n_rows + rb);
+  features.insert(features.end(), neg.features.begin(), neg.features.end());
+  n_rows += neg.n_rows;
+}
 void VideoDataset::UploadTable(vv_ctx* ctx) const {
   if (synthetic) VV_CHECK(vv_table_synth(ctx, seed, n_rows, F));
   else VV_CHECK(vv_table_set(ctx, features.data(), n_rows, F));
@@ -445,9 +467,6 @@ template <typename Dtype>
 void VideoSampledShotsDataLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>&, vector<Blob<Dtype>*>* top) {
   const pl::Message& p = this->layer_param_.get_msg("video_sampled_shots_data_param");
   const string ctype = p.get_enum("context_type");
-  CHECK(ctype != "PAIRWISE") << "context_type PAIRWISE feeds a two-frame graph, not the videovec_embedding graph: not built";
-  CHECK(p.get_str("negative_dataset").empty()) << "negative_dataset is not supported";
-  CHECK(!p.get_bool("output_shot_distance")) << "output_shot_distance is PAIRWISE-only";
   // rand_skip (…data_layer.cpp:156-180): skip = caffe_rng_rand() % rand_skip records.  caffe_rng_rand is the first draw of
   // the process-wide mt19937 after Caffe::set_random_seed (the data layer is set up first), and boost::mt19937 is the
   // standard generator; without `random_seed` in the solver the reference seeds from /dev/urandom, here the default seed is used.
@@ -458,6 +477,10 @@ void VideoSampledShotsDataLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>&, 
     rand_skip_ = (int)skip;
   }
   dataset_ = VideoDataset::Open(p.get_str("source"), VideoDataset::kShots, p.get_enum("backend"));
+  if (!p.get_str("negative_dataset").empty()) {                    // …data_layer.cpp:105-151: a second DB of the same backend
+    shared_ptr<VideoDataset> neg = VideoDataset::Open(p.get_str("negative_dataset"), VideoDataset::kShots, p.get_enum("backend"));
+    dataset_->AppendNegatives(*neg);
+  }
   vv_sampler_param sp;
   vv_sampler_param_default(&sp);
   sp.batch_size = batch_size_ = (int)p.get_int("batch_size");
@@ -472,7 +495,11 @@ void VideoSampledShotsDataLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>&, 
   CHECK_GE(feature_size_, 1); CHECK_GE(context_size_, 2); CHECK_GE(batch_size_, 1);      // …data_layer.cpp:206-209
   if (ctype == "WINDOW") { CHECK(context_size_ % 2 == 1) << "Context size should be even in this setting!"; }   // …:434 (sic)
   sp.context_type = ctype == "WINDOW" ? VV_CONTEXT_WINDOW : ctype == "PAST" ? VV_CONTEXT_PAST :
-                    ctype == "PAST_CONTINUOUS" ? VV_CONTEXT_PAST_CONTINUOUS : VV_CONTEXT_PAST_CONTINUOUS_FIXED;
+                    ctype == "PAST_CONTINUOUS" ? VV_CONTEXT_PAST_CONTINUOUS :
+                    ctype == "PAIRWISE" ? VV_CONTEXT_PAIRWISE : VV_CONTEXT_PAST_CONTINUOUS_FIXED;
+  if (ctype == "PAIRWISE") sp.context_size = context_size_ = 2;                           // …data_layer.cpp:200-201
+  sp.output_shot_distance = p.get_bool("output_shot_distance");                           // …:71 (read by PAIRWISE only, :407)
+  sp.max_shot_distance = (float)p.get_num("max_shot_distance");
   CHECK_LE(sp.max_same_video_negs, sp.num_negative_samples)
       << "max_same_video_negs exceeds num_negative_samples: the reference writes past the item's channels (…data_layer.cpp:484-502)";
   if (Caffe::world() > 1) {
@@ -480,8 +507,10 @@ void VideoSampledShotsDataLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>&, 
     sp.batch_size = batch_size_ * Caffe::world();      // the prototxt's batch_size is per GPU; the sampler draws the global batch
   }
   if (Caffe::rank() == 0) {
-    const int rc = vv_sampler_create(&sp, (int)dataset_->video_id.size(), dataset_->video_id.data(), dataset_->n_shots.data(),
-                                     dataset_->row_base.data(), dataset_->shot_ids.data(), &sampler_);
+    const int rc = vv_sampler_create_neg(&sp, (int)dataset_->video_id.size(), dataset_->video_id.data(), dataset_->n_shots.data(),
+                                         dataset_->row_base.data(), dataset_->shot_ids.data(), (int)dataset_->neg_video_id.size(),
+                                         dataset_->neg_video_id.data(), dataset_->neg_n_shots.data(), dataset_->neg_row_base.data(),
+                                         dataset_->neg_shot_ids.data(), &sampler_);
     CHECK_EQ(rc, 0) << "Could not add requested number of negatives";                     // …:344
   }
   (*top)[0]->Reshape(batch_size_, context_size_ + num_negative_samples_, feature_size_, 1);  // …:214-218
@@ -510,23 +539,32 @@ template <typename Dtype>
 void VideoShotWindowTestDataLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>&, vector<Blob<Dtype>*>* top) {
   const pl::Message& p = this->layer_param_.get_msg("video_shot_window_test_data_param");
   dataset_ = VideoDataset::Open(p.get_str("source"), VideoDataset::kTestWindows, p.get_enum("backend"));
-  CHECK(!(p.get_bool("include_positives") && dataset_->win_pos) && !(p.get_bool("include_negatives") && dataset_->win_neg))
-      << "test windows with positive / negative shot words are not built (set include_positives / include_negatives to false)";
-  CHECK_GE(dataset_->win_k, 1) << "source " << p.get_str("source") << " holds no test windows";   // …test_data_layer.cpp:121
+  CHECK_GE(dataset_->win_k, 1) << "source " << p.get_str("source") << " holds no test windows";   // …test_data_layer.cpp:113
+  // …:98-106: the first record sets the sizes, include_positives / include_negatives: false drop the group
+  positive_size_ = p.get_bool("include_positives") ? dataset_->win_pos : 0;
+  negative_size_ = p.get_bool("include_negatives") ? dataset_->win_neg : 0;
+  LOG(INFO) << "Pos-size: " << positive_size_ << "Neg-size: " << negative_size_;
+  if (positive_size_ > 0)
+    for (size_t w = 0; w < dataset_->win_pos_ids.size(); ++w)
+      CHECK_EQ(dataset_->win_pos_ids[w], positive_size_) << "positive_shot_id count of test window " << w;   // …:191
   batch_size_ = (int)p.get_int("batch_size");
   CHECK_GE(batch_size_, 1);
-  (*top)[0]->Reshape(batch_size_, dataset_->win_k, dataset_->F, 1);                              // …:123-126
+  (*top)[0]->Reshape(batch_size_, channels(), dataset_->F, 1);                                    // …:117-121
   LOG(INFO) << "output data size: " << (*top)[0]->num() << "," << (*top)[0]->channels() << "," << (*top)[0]->height()
             << "," << (*top)[0]->width();
   if (top->size() > 1) (*top)[1]->Reshape(batch_size_, 1, 1, 1);
 }
 template <typename Dtype>
 void VideoShotWindowTestDataLayer<Dtype>::NextBatch(vector<int32_t>* rows, vector<int32_t>* video_ids) {
-  const int k = dataset_->win_k;
+  const int k = dataset_->win_k, stride = k + dataset_->win_pos + dataset_->win_neg, ch = channels();
   const size_t nw = dataset_->win_video_id.size();
-  rows->resize((size_t)batch_size_ * k); video_ids->resize(batch_size_);
+  rows->resize((size_t)batch_size_ * ch); video_ids->resize(batch_size_);
   for (int i = 0; i < batch_size_; ++i) {                          // cursor wraps (…:250-262)
-    for (int j = 0; j < k; ++j) (*rows)[(size_t)i * k + j] = dataset_->win_rows[cursor_ * k + j];
+    const int32_t* src = &dataset_->win_rows[cursor_ * stride];
+    int32_t* dst = &(*rows)[(size_t)i * ch];
+    for (int j = 0; j < k; ++j) *dst++ = src[j];                                   // …:207-214 context
+    for (int j = 0; j < positive_size_; ++j) *dst++ = src[k + j];                  // …:217-222 positives
+    for (int j = 0; j < negative_size_; ++j) *dst++ = src[k + dataset_->win_pos + j];   // …:225-232 negatives
     (*video_ids)[i] = dataset_->win_video_id[cursor_];
     cursor_ = (cursor_ + 1) % nw;
   }

@@ -272,6 +272,10 @@ void Net<Dtype>::MatchVideovecTrainGraph() {
       } else bad("Eltwise MAX is not part of the graph");
     } else if (type == "NORMALIZATION") {
       if (in(0).k == K_CTXMEAN) sym[ti[0]].k = K_CTXNORM;
+      else if (in(0).k == K_EMB && in(0).a == 1 && P.C == 2) {     // one context frame (PAIRWISE): nothing to average
+        P.ctx_coeff.assign(1, 1.f);
+        sym[ti[0]].k = K_CTXNORM;
+      }
       else if (in(0).k == K_PN) sym[ti[0]].k = K_PNNORM;
       else bad("unexpected NORMALIZATION input");
     } else if (type == "SUM" && in(0).k == K_LABEL) {

@@ -48,14 +48,22 @@ int main(int argc, char** argv) {
     shared_ptr<VideoDataset> ds = VideoDataset::Open(argv[2], win ? VideoDataset::kTestWindows : VideoDataset::kShots, "LMDB");
     FILE* o = fopen(argv[4], "w");
     double sum = 0; for (float f : ds->features) sum += f;
-    fprintf(o, "rows %lld F %d videos %zu windows %zu k %d sum %.6f\n", (long long)ds->n_rows, ds->F, ds->video_id.size(),
-            ds->win_video_id.size(), ds->win_k, sum);
+    fprintf(o, "rows %lld F %d videos %zu windows %zu k %d pos %d neg %d sum %.6f\n", (long long)ds->n_rows, ds->F, ds->video_id.size(),
+            ds->win_video_id.size(), ds->win_k, ds->win_pos, ds->win_neg, sum);
     for (size_t v = 0; v < ds->video_id.size(); ++v) {
       fprintf(o, "video %d n %d base %lld ids", ds->video_id[v], ds->n_shots[v], (long long)ds->row_base[v]);
       for (int j = 0; j < ds->n_shots[v]; ++j) fprintf(o, " %d", ds->shot_ids[ds->row_base[v] + j]);
       fprintf(o, "\n");
     }
-    for (size_t w = 0; w < ds->win_video_id.size(); ++w) fprintf(o, "window %d row0 %d\n", ds->win_video_id[w], ds->win_rows[w * ds->win_k]);
+    const size_t stride = (size_t)ds->win_k + ds->win_pos + ds->win_neg;
+    for (size_t w = 0; w < ds->win_video_id.size(); ++w) {
+      fprintf(o, "window %d row0 %d", ds->win_video_id[w], ds->win_rows[w * stride]);
+      if (stride > (size_t)ds->win_k) {           // first feature of every row, in channel order
+        fprintf(o, " first");
+        for (size_t j = 0; j < stride; ++j) fprintf(o, " %g", ds->features[(size_t)ds->win_rows[w * stride + j] * ds->F]);
+      }
+      fprintf(o, "\n");
+    }
     fclose(o);
   } else return 2;
   return 0;

@@ -268,16 +268,30 @@ typedef struct {
   int32_t context_type;            /* VV_CONTEXT_* (VideoSampledShotsDataParameter.ContextType) */
   int32_t initial_cursor;          /* records skipped before anything else (rand_skip, ...data_layer.cpp:156-180): the DB
                                       cursor starts at this record (modulo the record count) */
+  int32_t output_shot_distance;    /* PAIRWISE only (...data_layer.cpp:71, 407-418): label = frame distance, not video id */
+  float   max_shot_distance;       /* ... clamped to this bound (caffe.proto:674, default 5) */
 } vv_sampler_param;
 /* WINDOW (...data_layer.cpp:425-507): target = the middle of C sorted random frames.  PAST (:510-596): target = the
  * last of C sorted random frames.  PAST_CONTINUOUS (:599-674): C equally spaced frames, random stride and start,
  * target = the last.  PAST_CONTINUOUS_FIXED (:677-757): the same with the largest stride minus one, ending at the
- * video's end.  All fill the same (B, C+Nn) layout.  PAIRWISE (:396-422) feeds a different graph and is not built. */
-enum { VV_CONTEXT_WINDOW = 0, VV_CONTEXT_PAST = 1, VV_CONTEXT_PAST_CONTINUOUS = 2, VV_CONTEXT_PAST_CONTINUOUS_FIXED = 3 };
+ * video's end.  PAIRWISE (:396-422): two distinct random frames in draw order (target, then the one context frame),
+ * context_size forced to 2 (:200-201), records with one shot skipped; with output_shot_distance the label is their
+ * distance.  All fill the same (B, C+Nn) layout. */
+enum { VV_CONTEXT_WINDOW = 0, VV_CONTEXT_PAST = 1, VV_CONTEXT_PAST_CONTINUOUS = 2, VV_CONTEXT_PAST_CONTINUOUS_FIXED = 3,
+       VV_CONTEXT_PAIRWISE = 4 };
 void vv_sampler_param_default(vv_sampler_param* p);
 int vv_sampler_create(const vv_sampler_param* p, int32_t n_videos, const int32_t* video_id,
                       const int32_t* n_shots, const int64_t* row_base, const int32_t* shot_ids,
                       vv_sampler** out);
+/* The same with VideoSampledShotsDataParameter.negative_dataset (...data_layer.cpp:105-151, 253-286, 325-341): the
+ * negative buffer starts as EVERY shot of the negative dataset's records taken in order (no rand() draw, the main
+ * cursor stays at initial_cursor) and must come out exactly full -- the reference tests the fill level only after a
+ * whole record and overruns its buffer otherwise, so anything but an exact fit is VV_ERR_ARG.  neg_row_base index
+ * the same feature table as row_base.  neg_videos == 0 is vv_sampler_create. */
+int vv_sampler_create_neg(const vv_sampler_param* p, int32_t n_videos, const int32_t* video_id,
+                          const int32_t* n_shots, const int64_t* row_base, const int32_t* shot_ids,
+                          int32_t neg_videos, const int32_t* neg_video_id, const int32_t* neg_n_shots,
+                          const int64_t* neg_row_base, const int32_t* neg_shot_ids, vv_sampler** out);
 /* One prefetch batch.  idx / last_src: int32 [batch_size][context_size + num_negative_samples]
  * (last_src: the row whose LAST feature the slot holds -- differs from idx only for same-video
  * negatives, which the reference copies without their last element, ...data_layer.cpp:492; -1 =

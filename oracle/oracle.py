@@ -35,10 +35,11 @@ class _SamplerParam(C.Structure):
     _fields_ = [("batch_size", C.c_int32), ("context_size", C.c_int32),
                 ("num_negative_samples", C.c_int32), ("max_buffer_size", C.c_int32),
                 ("negative_swap_percentage", C.c_int32), ("max_same_video_negs", C.c_int32),
-                ("max_tries_for_negs", C.c_int32), ("context_type", C.c_int32), ("initial_cursor", C.c_int32)]
+                ("max_tries_for_negs", C.c_int32), ("context_type", C.c_int32), ("initial_cursor", C.c_int32),
+                ("output_shot_distance", C.c_int32), ("max_shot_distance", C.c_float)]
 
 
-CONTEXT_TYPES = {"WINDOW": 0, "PAST": 1, "PAST_CONTINUOUS": 2, "PAST_CONTINUOUS_FIXED": 3}
+CONTEXT_TYPES = {"WINDOW": 0, "PAST": 1, "PAST_CONTINUOUS": 2, "PAST_CONTINUOUS_FIXED": 3, "PAIRWISE": 4}
 
 
 class _StepCfg(C.Structure):
@@ -67,6 +68,8 @@ def lib():
         L.orc_rand.restype = C.c_int32
         L.orc_sampler_create.restype = C.c_void_p
         L.orc_sampler_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+        L.orc_sampler_create_neg.restype = C.c_void_p
+        L.orc_sampler_create_neg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint]
         L.orc_sampler_destroy.argtypes = [C.c_void_p]
         L.orc_sampler_next.argtypes = [C.c_void_p] * 4
         L.orc_sampler_buffer_rows.restype = C.c_void_p
@@ -155,11 +158,22 @@ def stdlib_pin(*args):
 
 # ------------------------------------------------------------------------------- sampler -----
 class Sampler:
-    """VideoSampledShotsDataLayer restated (context_type WINDOW / PAST / PAST_CONTINUOUS / PAST_CONTINUOUS_FIXED)."""
+    """VideoSampledShotsDataLayer restated (context_type WINDOW / PAST / PAST_CONTINUOUS / PAST_CONTINUOUS_FIXED /
+    PAIRWISE).  negatives = (video_id, n_shots, row_base[, shot_ids]) of a `negative_dataset`."""
+
+    @staticmethod
+    def _dataset(video_id, n_shots, row_base, shot_ids=None):
+        vid = np.ascontiguousarray(video_id, dtype=np.int32)
+        ns = np.ascontiguousarray(n_shots, dtype=np.int32)
+        rb = np.ascontiguousarray(row_base, dtype=np.int64)
+        sid = None if shot_ids is None else np.ascontiguousarray(shot_ids, dtype=np.int32)
+        soff = None if sid is None else np.concatenate([[0], np.cumsum(ns[:-1])]).astype(np.int64)
+        return _Dataset(len(vid), _p(vid), _p(ns), _p(rb), _p(sid), _p(soff)), (vid, ns, rb, sid, soff)
 
     def __init__(self, video_id, n_shots, row_base, *, batch_size, context_size,
                  num_negative_samples, max_buffer_size, negative_swap_percentage,
-                 max_same_video_negs=0, max_tries_for_negs=100, shot_ids=None, seed=1, context_type="WINDOW", initial_cursor=0):
+                 max_same_video_negs=0, max_tries_for_negs=100, shot_ids=None, seed=1, context_type="WINDOW", initial_cursor=0,
+                 output_shot_distance=False, max_shot_distance=5.0, negatives=None):
         self._vid = np.ascontiguousarray(video_id, dtype=np.int32)
         self._ns = np.ascontiguousarray(n_shots, dtype=np.int32)
         self._rb = np.ascontiguousarray(row_base, dtype=np.int64)
@@ -171,10 +185,17 @@ class Sampler:
                            _p(self._sid), _p(self._soff))
         self.p = _SamplerParam(batch_size, context_size, num_negative_samples, max_buffer_size,
                                negative_swap_percentage, max_same_video_negs, max_tries_for_negs,
-                               CONTEXT_TYPES[context_type], initial_cursor)
-        self.h = lib().orc_sampler_create(C.byref(self.ds), C.byref(self.p), seed)
+                               CONTEXT_TYPES[context_type], initial_cursor, int(output_shot_distance),
+                               max_shot_distance)
+        if negatives is None:
+            self.h = lib().orc_sampler_create(C.byref(self.ds), C.byref(self.p), seed)
+        else:
+            self.neg, self._neg_keep = self._dataset(*negatives)
+            self.h = lib().orc_sampler_create_neg(C.byref(self.ds), C.byref(self.neg), C.byref(self.p), seed)
         if not self.h:
             raise ValueError("reference would CHECK-fail for these sampler parameters")
+        if context_type == "PAIRWISE":
+            context_size = 2
         self.B, self.CN = batch_size, context_size + num_negative_samples
         self.max_buffer = max_buffer_size if num_negative_samples > 0 else 0
 

@@ -133,8 +133,16 @@ void orc_sampler_destroy(orc_sampler* s) {
 
 /* video_sampled_shots_data_layer.cpp:64-369 (DataLayerSetUp) */
 orc_sampler* orc_sampler_create(const orc_dataset* ds, const orc_sampler_param* p, unsigned seed) {
+  return orc_sampler_create_neg(ds, NULL, p, seed);
+}
+orc_sampler* orc_sampler_create_neg(const orc_dataset* ds, const orc_dataset* neg, const orc_sampler_param* p_in,
+                                    unsigned seed) {
+  orc_sampler_param pp = *p_in;
+  if (pp.context_type == ORC_CONTEXT_PAIRWISE) pp.context_size = 2;                  /* :200-201 */
+  const orc_sampler_param* p = &pp;
   if (p->context_size < 2 || p->batch_size < 1 || ds->n_videos < 1) return NULL;   /* :207,:209 */
-  if (p->context_type < ORC_CONTEXT_WINDOW || p->context_type > ORC_CONTEXT_PAST_CONTINUOUS_FIXED) return NULL;  /* :760 */
+  if (p->context_type < ORC_CONTEXT_WINDOW || p->context_type > ORC_CONTEXT_PAIRWISE) return NULL;  /* :760 */
+  if (neg && neg->n_videos < 1) return NULL;
   if (p->num_negative_samples > 0 &&
       (p->negative_swap_percentage < 0 || p->negative_swap_percentage > 99)) return NULL; /* :79-80 */
   /* :484-502 write same-video negatives at channel C + added without comparing added with num_negative_samples: more of
@@ -165,7 +173,26 @@ orc_sampler* orc_sampler_create(const orc_dataset* ds, const orc_sampler_param* 
 
   /* :240-344 -- one rand()%num_shots per visited record until the buffer holds max_buffer_size
    * unique keys; the cursor advances on every visit and is NOT rewound afterwards. */
-  if (mb > 0) {
+  if (mb > 0 && neg) {
+    /* :253-286 the negative dataset's own cursor, :325-341 every shot whose key is new.  The reference tests for a
+     * full buffer only after a whole record (:343) and writes past negatives_ when a record overshoots; only the
+     * exact fit passes its CHECK_EQ (:348), anything else is refused here. */
+    int added = 0, cur = 0;
+    const int64_t tries = (int64_t)p->max_tries_for_negs * mb;
+    for (int64_t nid = 0; nid < tries && added < mb; ++nid) {
+      const int v = cur;
+      cur = (cur + 1) % neg->n_videos;
+      for (int j = 0; j < neg->n_shots[v]; ++j) {
+        const uint64_t k = make_key(neg->video_id[v], shot_id_of(neg, v, j));
+        if (key_find(s, k)) continue;
+        if (added >= mb) { orc_sampler_destroy(s); return NULL; }
+        s->buf_row[added] = (int32_t)(neg->row_base[v] + j);
+        key_insert(s, added, k);
+        ++added;
+      }
+    }
+    if (added != mb) { orc_sampler_destroy(s); return NULL; }
+  } else if (mb > 0) {
     int added = 0;
     const int64_t tries = (int64_t)p->max_tries_for_negs * mb;
     for (int64_t nid = 0; nid < tries; ++nid) {
@@ -283,6 +310,31 @@ static int add_samples_past(orc_sampler* s, int v, int item, int* added_negs) {
   return 1;
 }
 
+/* video_sampled_shots_data_layer.cpp:396-422 (CONTEXT_PAIRWISE): two distinct random frames in draw order; the label
+ * is the video id, or with output_shot_distance their distance clamped to max_shot_distance (the reference
+ * holds it in an int: the float bound is truncated, :412-415). */
+static int add_samples_pairwise(orc_sampler* s, int v, int item, int32_t* label) {
+  const orc_sampler_param* p = &s->p;
+  const int CN = 2 + p->num_negative_samples;
+  const int n = s->ds.n_shots[v];
+  const int64_t base = s->ds.row_base[v];
+  if (n < 2) return 0;                                                                 /* :387 */
+  int32_t* perm = s->perm;
+  for (int i = 0; i < n; ++i) perm[i] = i;                                             /* :391 */
+  s_random_unique(s, perm, n, 2);                                                      /* :397 */
+  int32_t* row = s->slot_row + (size_t)item * CN;
+  int32_t* last = s->slot_last + (size_t)item * CN;
+  row[0] = last[0] = (int32_t)(base + perm[0]);                                        /* :400-405 */
+  row[1] = last[1] = (int32_t)(base + perm[1]);
+  if (p->output_shot_distance) {
+    const int d = abs(perm[0] - perm[1]);
+    *label = (float)d >= p->max_shot_distance ? (int32_t)p->max_shot_distance : d;
+  } else {
+    *label = s->ds.video_id[v];
+  }
+  return 1;
+}
+
 /* video_sampled_shots_data_layer.cpp:768-909 (InternalThreadEntry) */
 void orc_sampler_next(orc_sampler* s, int32_t* idx, int32_t* last_src, int32_t* label) {
   const orc_sampler_param* p = &s->p;
@@ -291,8 +343,10 @@ void orc_sampler_next(orc_sampler* s, int32_t* idx, int32_t* last_src, int32_t* 
   while (item < p->batch_size) {
     const int v = s->cursor;
     int added = 0;
+    int32_t lab = s->ds.video_id[v];
     const int ok = p->context_type == ORC_CONTEXT_WINDOW ? add_samples_window(s, v, item, &added)   /* :820 */
-                                                         : add_samples_past(s, v, item, &added);
+                 : p->context_type == ORC_CONTEXT_PAIRWISE ? add_samples_pairwise(s, v, item, &lab)
+                                                           : add_samples_past(s, v, item, &added);
     s->cursor = (s->cursor + 1) % s->ds.n_videos;                                      /* :826-846 */
     if (!ok) continue;                                                                 /* :848 */
     if (Nn > 0) {
@@ -303,7 +357,7 @@ void orc_sampler_next(orc_sampler* s, int32_t* idx, int32_t* last_src, int32_t* 
         s->slot_last[(size_t)item * CN + c] = s->buf_row[neg];
       }
     }
-    if (label) label[item] = s->ds.video_id[v];                                        /* :879 */
+    if (label) label[item] = lab;                                                      /* :879 */
     ++item;
     if (Nn > 0 && p->negative_swap_percentage > 0) {                                   /* :888-906 */
       const int n = s->ds.n_shots[v];

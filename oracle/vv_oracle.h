@@ -56,15 +56,24 @@ typedef struct {
   int32_t batch_size, context_size, num_negative_samples;
   int32_t max_buffer_size, negative_swap_percentage, max_same_video_negs;
   int32_t max_tries_for_negs;   /* gflag, default 100 (…data_layer.cpp:20) */
-  int32_t context_type;         /* VideoSampledShotsDataParameter.ContextType; PAIRWISE feeds a different graph */
+  int32_t context_type;         /* VideoSampledShotsDataParameter.ContextType */
   int32_t initial_cursor;       /* rand_skip (…data_layer.cpp:156-180): records skipped before the buffer is filled */
+  int32_t output_shot_distance; /* PAIRWISE only (…data_layer.cpp:71, 407-418): the label is the frame distance */
+  float   max_shot_distance;    /* ... clamped to this (caffe.proto:674, default 5) */
 } orc_sampler_param;
-enum { ORC_CONTEXT_WINDOW = 0, ORC_CONTEXT_PAST = 1, ORC_CONTEXT_PAST_CONTINUOUS = 2, ORC_CONTEXT_PAST_CONTINUOUS_FIXED = 3 };
+/* PAIRWISE (…data_layer.cpp:396-422): two random frames of the record, context_size forced to 2 (:200-201) */
+enum { ORC_CONTEXT_WINDOW = 0, ORC_CONTEXT_PAST = 1, ORC_CONTEXT_PAST_CONTINUOUS = 2, ORC_CONTEXT_PAST_CONTINUOUS_FIXED = 3,
+       ORC_CONTEXT_PAIRWISE = 4 };
 
 typedef struct orc_sampler orc_sampler;
 /* DataLayerSetUp (…data_layer.cpp:64-369): fills the negative buffer from the cursor position.
  * Returns NULL if the reference would CHECK-fail (…:344, :207, :434). */
 orc_sampler* orc_sampler_create(const orc_dataset* ds, const orc_sampler_param* p, unsigned seed);
+/* The same with `negative_dataset` set (…data_layer.cpp:105-151, 253-286, 325-341): the buffer is filled with EVERY
+ * shot of the negative dataset's records taken in order (no rand(), the main cursor stays where it is) and must
+ * come out exactly full (:344).  neg's row_base index the same row table as ds's. */
+orc_sampler* orc_sampler_create_neg(const orc_dataset* ds, const orc_dataset* neg, const orc_sampler_param* p,
+                                    unsigned seed);
 void         orc_sampler_destroy(orc_sampler* s);
 /* InternalThreadEntry (…data_layer.cpp:768-909): one batch.
  *   idx      [B][C+Nn]  table row held by each prefetch slot (channel 0 target, 1..C-1 context in

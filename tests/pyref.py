@@ -17,9 +17,13 @@ _libc = ctypes.CDLL("libc.so.6")
 
 class PySampler:
     def __init__(self, video_id, n_shots, row_base, B, C, Nn, max_buffer, swap, max_same=0,
-                 max_tries=100, context_type="WINDOW", initial_cursor=0):
+                 max_tries=100, context_type="WINDOW", initial_cursor=0, output_shot_distance=False,
+                 max_shot_distance=5.0, negatives=None):
         _libc.srand(1)            # identical to never having called srand
         self.context_type = context_type
+        self.out_dist, self.max_dist = output_shot_distance, max_shot_distance
+        if context_type == "PAIRWISE":
+            C = 2                  # …data_layer.cpp:200-201
         self.calls = 0
         self.vid, self.ns, self.rb = list(video_id), list(n_shots), list(row_base)
         self.B, self.C, self.Nn, self.mb, self.swap, self.max_same = B, C, Nn, max_buffer, swap, max_same
@@ -29,7 +33,22 @@ class PySampler:
         CN = C + Nn
         self.slot_row = [[-1] * CN for _ in range(B)]
         self.slot_last = [[-1] * CN for _ in range(B)]
-        if Nn > 0:
+        if Nn > 0 and negatives is not None:
+            # …data_layer.cpp:253-286, 325-341: every new shot of the negative dataset's records, in order
+            nvid, nns, nrb = negatives
+            cur = 0
+            for _ in range(max_tries * max_buffer):
+                v, cur = cur, (cur + 1) % len(nvid)
+                for j in range(nns[v]):
+                    key = (nvid[v], j)
+                    if key not in self.keys:
+                        self.keys.add(key)
+                        self.buf_key.append(key)
+                        self.buf_row.append(nrb[v] + j)
+                if len(self.buf_row) >= max_buffer:
+                    break
+            assert len(self.buf_row) == max_buffer
+        elif Nn > 0:
             for _ in range(max_tries * max_buffer):
                 v = self.cursor
                 self.cursor = (self.cursor + 1) % len(self.vid)
@@ -62,7 +81,18 @@ class PySampler:
             v = self.cursor
             n = self.ns[v]
             added, ok = 0, False
-            if self.context_type != "WINDOW" and n >= 2 and n >= C:
+            lab = self.vid[v]
+            if self.context_type == "PAIRWISE":
+                if n >= 2:           # …data_layer.cpp:387, 396-422
+                    perm = list(range(n))
+                    self.random_unique(perm, 0, 2)
+                    for c in (0, 1):
+                        self.slot_row[item][c] = self.slot_last[item][c] = self.rb[v] + perm[c]
+                    if self.out_dist:
+                        d = abs(perm[0] - perm[1])
+                        lab = int(self.max_dist) if d >= self.max_dist else d
+                    ok = True
+            elif self.context_type != "WINDOW" and n >= 2 and n >= C:
                 # …data_layer.cpp:510-757: target = the last of the C frames, context = the C-1 before it
                 perm = list(range(n))
                 if self.context_type == "PAST":
@@ -133,7 +163,7 @@ class PySampler:
                     r = self.buf_row[self.buffer_ids[c - C - added]]
                     self.slot_row[item][c] = r
                     self.slot_last[item][c] = r
-            labels[item] = self.vid[v]
+            labels[item] = lab
             item += 1
             if Nn > 0 and self.swap > 0:
                 for j in range(n):

@@ -139,9 +139,45 @@ def test_test_window_records_decode(tool, pb, tmp_path):
     subprocess.check_call([tool, "dbload", str(tmp_path / "test_db"), "windows", str(out)], stderr=subprocess.DEVNULL)
     lines = out.read_text().splitlines()
     head = lines[0].split()
-    assert head[:10] == ["rows", "228", "F", "64", "videos", "0", "windows", "57", "k", "4"]
+    assert head[:14] == ["rows", "228", "F", "64", "videos", "0", "windows", "57", "k", "4", "pos", "0", "neg", "0"]
     assert abs(float(head[-1]) - total) < 1e-3
     assert lines[1:] == want
+
+
+def make_windows_db(pb, path, n_windows=23, k=4, npos=2, nneg=3, F=32, seed=5):
+    """TestVideoShotWindows records WITH positive and negative shot words, serialised in field order (positives,
+    context, negatives).  Returns [(video_id, ctx [k,F], pos [npos,F], neg [nneg,F])]."""
+    rng = np.random.default_rng(seed)
+    items, out = [], []
+    for w in range(n_windows):
+        m = pb["TestVideoShotWindows"]()
+        m.video_id = int(rng.integers(0, 9))
+        groups = []
+        for field, n in ((m.context_shot_words, k), (m.positive_shot_words, npos), (m.negative_shot_words, nneg)):
+            f = (rng.integers(0, 32, (n, F)) / 8).astype(np.float32)
+            for j in range(n):
+                field.add().float_data.extend(f[j].tolist())
+            groups.append(f)
+        m.positive_shot_id.extend(range(100, 100 + npos))
+        m.negative_shot_id.extend(range(200, 200 + nneg))
+        items.append((b"%08d" % w, m.SerializeToString()))
+        out.append((m.video_id,) + tuple(groups))
+    write_lmdb(path, items)
+    return out
+
+
+def test_test_windows_with_positives_and_negatives_decode_in_channel_order(tool, pb, tmp_path):
+    # video_shot_window_test_data_layer.cpp:207-232: context words, then positives, then negatives -- the wire order
+    # of the record is positives (field 4), context (5), negatives (6)
+    wins = make_windows_db(pb, str(tmp_path / "test_db"))
+    out = tmp_path / "ds.txt"
+    subprocess.check_call([tool, "dbload", str(tmp_path / "test_db"), "windows", str(out)], stderr=subprocess.DEVNULL)
+    lines = out.read_text().splitlines()
+    head = lines[0].split()
+    assert head[:14] == ["rows", str(23 * 9), "F", "32", "videos", "0", "windows", "23", "k", "4", "pos", "2", "neg", "3"]
+    for w, (vid, ctx, pos, neg) in enumerate(wins):
+        first = " ".join("%g" % x for x in np.concatenate([ctx[:, 0], pos[:, 0], neg[:, 0]]))
+        assert lines[1 + w] == "window %d row0 %d first %s" % (vid, 9 * w, first)
 
 
 def test_large_records_spanning_hundreds_of_overflow_pages(tool, pb, tmp_path):

@@ -54,7 +54,7 @@ def assert_grad(analytic, numeric, kink=None):
     assert not bad.any(), (analytic[bad][:5], numeric[bad][:5])
 
 
-def test_relu_and_leaky_relu(eng):
+def test_relu_and_leaky_relu(eng, oracle):
     rng = np.random.default_rng(0)
     x = rng.standard_normal((6, 50)).astype(np.float32)
     for slope in (0.0, 0.01):
@@ -62,14 +62,16 @@ def test_relu_and_leaky_relu(eng):
         eng.op("relu", x.size, X, Y, slope)
         y = Y.get()
         assert np.array_equal(y, np.where(x > 0, x, x * np.float32(slope)))        # test_neuron_layer.cpp: TestReLU / WithNegativeSlope
+        assert np.array_equal(y, oracle.relu_fwd(x, slope))
         dy = rng.standard_normal(x.shape).astype(np.float32)
         DY, DX = eng.dev(dy), eng.dev(x.shape)
         eng.op("relu_bwd", x.size, X, DY, DX, slope)
+        assert np.array_equal(DX.get(), oracle.relu_bwd(x, dy, slope))
         num = numeric_grad(lambda v: np.where(v > 0, v, v * slope), x, dy)
         assert_grad(DX.get().astype(np.float64), num, kink=np.abs(x) < STEP)
 
 
-def test_dropout_train_statistics_and_backward(eng):
+def test_dropout_train_statistics_and_backward(eng, oracle):
     n, ratio = 200000, 0.6
     x = np.ones(n, np.float32)
     X, Y, M = eng.dev(x), eng.dev((n,)), eng.dev(np.zeros(n, np.uint8))
@@ -80,13 +82,15 @@ def test_dropout_train_statistics_and_backward(eng):
     kept = (y != 0).mean()
     assert abs(kept - (1 - ratio)) <= 1.96 * np.sqrt(ratio * (1 - ratio) / n) * 2  # the reference's 1.96 sigma check, doubled
     assert np.array_equal(m != 0, y != 0)
+    assert np.array_equal(y, oracle.dropout_fwd(x, m != 0, ratio))                # same mask -> the oracle's values
     dy = np.random.default_rng(1).standard_normal(n).astype(np.float32)
     DY, DX = eng.dev(dy), eng.dev((n,))
     eng.op("dropout", n, DY, DX, M, ratio, 0, 0)                                  # backward = the same mask on the diff
     assert np.allclose(DX.get(), dy * m * np.float32(scale))
+    assert np.allclose(DX.get(), oracle.dropout_bwd(dy, m != 0, ratio), rtol=1e-6, atol=0)
 
 
-def test_eltwise_sum_coeff_and_prod(eng):
+def test_eltwise_sum_coeff_and_prod(eng, oracle):
     rng = np.random.default_rng(2)
     a, b, c3 = [rng.standard_normal((4, 30)).astype(np.float32) for _ in range(3)]
     A, B, C3, Y = eng.dev(a), eng.dev(b), eng.dev(c3), eng.dev(a.shape)
@@ -95,16 +99,18 @@ def test_eltwise_sum_coeff_and_prod(eng):
     eng.op("axpby", a.size, -0.5, B, 1.0, Y)
     eng.op("axpby", a.size, 2.0, C3, 1.0, Y)
     assert np.allclose(Y.get(), a - 0.5 * b + 2 * c3, rtol=1e-6, atol=1e-6)
+    assert np.allclose(Y.get(), oracle.eltwise_fwd("SUM", [a, b, c3], [1, -0.5, 2]), rtol=1e-6, atol=1e-7)  # fma contraction
     # PROD of two bottoms (TestProd) and its stable backward: dA = B * dY
     eng.op("mul", a.size, A, B, Y, 0)
-    assert np.allclose(Y.get(), a * b, rtol=1e-6)
+    assert np.array_equal(Y.get(), oracle.eltwise_fwd("PROD", [a, b]))
     dy = rng.standard_normal(a.shape).astype(np.float32)
     DY, DA = eng.dev(dy), eng.dev(a.shape)
     eng.op("mul", a.size, B, DY, DA, 0)
+    assert np.array_equal(DA.get(), oracle.eltwise_bwd("PROD", [a, b], dy, 0))
     assert_grad(DA.get().astype(np.float64), numeric_grad(lambda v: v * b, a, dy))
 
 
-def test_slice_concat_split_copies(eng):
+def test_slice_concat_split_copies(eng, oracle):
     rng = np.random.default_rng(3)
     x = rng.standard_normal((5, 7, 6)).astype(np.float32)                          # (num, channels, dim)
     X = eng.dev(x)
@@ -115,18 +121,21 @@ def test_slice_concat_split_copies(eng):
     off = ctypes.c_void_p(X.ptr.value + 3 * 6 * 4)
     eng.op("copy2d", off, 7 * 6, T1, 4 * 6, 5, 4 * 6, 0)
     assert np.array_equal(T0.get(), x[:, :3]) and np.array_equal(T1.get(), x[:, 3:])
+    o0, o1 = oracle.slice_fwd(x, 1, [3, 4])
+    assert np.array_equal(T0.get(), o0[..., 0]) and np.array_equal(T1.get(), o1[..., 0])
     # CONCAT dim 1 puts them back (test_concat_layer.cpp); SLICE backward is the same copy
     Z = eng.dev(x.shape)
     eng.op("copy2d", T0, 3 * 6, Z, 7 * 6, 5, 3 * 6, 0)
     eng.op("copy2d", T1, 4 * 6, ctypes.c_void_p(Z.ptr.value + 3 * 6 * 4), 7 * 6, 5, 4 * 6, 0)
     assert np.array_equal(Z.get(), x)
+    assert np.array_equal(Z.get(), oracle.concat_fwd([o0, o1], 1)[..., 0])
     # SPLIT backward (split_layer.cu:18-33): bottom diff = sum of the top diffs
     d0, d1, d2 = [rng.standard_normal(x.shape).astype(np.float32) for _ in range(3)]
     D0, D1, D2, S = eng.dev(d0), eng.dev(d1), eng.dev(d2), eng.dev(x.shape)
     eng.op("copy2d", D0, x.size, S, x.size, 1, x.size, 0)
     eng.op("copy2d", D1, x.size, S, x.size, 1, x.size, 1)
     eng.op("copy2d", D2, x.size, S, x.size, 1, x.size, 1)
-    assert np.allclose(S.get(), d0 + d1 + d2, rtol=1e-6, atol=1e-6)
+    assert np.array_equal(S.get(), oracle.split_bwd([d0, d1, d2]))
 
 
 @pytest.mark.parametrize("num_output", [1, 10])

@@ -163,3 +163,49 @@ def test_setup_check_fails_like_reference(oracle):
     with pytest.raises(ValueError):                             # :79-80 swap percentage range
         _mk(oracle, ds, batch_size=2, context_size=3, num_negative_samples=2, max_buffer_size=4,
             negative_swap_percentage=100)
+
+
+@pytest.mark.parametrize("dist", [False, True])
+@pytest.mark.parametrize("B,Nn,mb,swap", [(16, 10, 200, 50), (8, 0, 0, 0), (8, 3, 40, 99)])
+def test_pairwise_equals_python_restatement_on_real_glibc(oracle, dist, B, Nn, mb, swap):
+    # …data_layer.cpp:396-422, 200-201: two random frames per record, context_size forced to 2
+    rng = np.random.default_rng(11)
+    ns = rng.integers(1, 14, 60)
+    vid = np.arange(100, 160)
+    rb = np.concatenate([[0], np.cumsum(ns[:-1])])
+    py = PySampler(vid, ns, rb, B, 7, Nn, mb, swap, context_type="PAIRWISE", output_shot_distance=dist,
+                   max_shot_distance=4.5)
+    oc = oracle.Sampler(vid, ns, rb, batch_size=B, context_size=7, num_negative_samples=Nn, max_buffer_size=mb,
+                        negative_swap_percentage=swap, context_type="PAIRWISE", output_shot_distance=dist,
+                        max_shot_distance=4.5)
+    for _ in range(6):
+        a, b = py.next(), oc.next()
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+        idx, _, label = b
+        assert idx.shape[1] == 2 + Nn
+        assert np.all(idx[:, 0] != idx[:, 1])
+        if dist:
+            d = np.abs(idx[:, 0] - idx[:, 1])
+            assert np.array_equal(label, np.where(d >= 4.5, 4, d))
+    assert py.calls == oc.rand_calls()
+
+
+def test_negative_dataset_fills_the_buffer_in_order(oracle):
+    # …data_layer.cpp:253-286, 325-341: no rand(), the main cursor untouched, every shot of the first records
+    ns = np.full(30, 8); vid = np.arange(30); rb = np.arange(30) * 8
+    nns = np.array([5, 7, 4, 9]); nvid = np.arange(1000, 1004); nrb = 240 + np.concatenate([[0], np.cumsum(nns[:-1])])
+    kw = dict(batch_size=4, context_size=3, num_negative_samples=2, max_buffer_size=16, negative_swap_percentage=50)
+    oc = oracle.Sampler(vid, ns, rb, negatives=(nvid, nns, nrb), **kw)
+    assert oc.rand_calls() == 0 and oc.cursor() == 0
+    assert np.array_equal(oc.buffer_rows(), 240 + np.arange(16))
+    py = PySampler(vid, ns, rb, 4, 3, 2, 16, 50, negatives=(nvid, nns, nrb))
+    for _ in range(5):
+        for x, y in zip(py.next(), oc.next()):
+            assert np.array_equal(x, y)
+    # a record that overshoots the buffer is the reference's out-of-bounds write (:325-343) -> refused
+    with pytest.raises(ValueError):
+        oracle.Sampler(vid, ns, rb, negatives=(nvid, nns, nrb), **dict(kw, max_buffer_size=15))
+    # never full: CHECK_EQ fails (:348)
+    with pytest.raises(ValueError):
+        oracle.Sampler(vid, ns, rb, negatives=(nvid, nns, nrb), **dict(kw, max_buffer_size=26))

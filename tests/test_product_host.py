@@ -217,3 +217,60 @@ def test_one_sampler_per_node_through_shared_memory(oracle):
             assert np.array_equal(got[c][0][k], ref_i[c * b:(c + 1) * b])
             assert np.array_equal(got[c][1][k], ref_y[c * b:(c + 1) * b])
     a.close()
+
+
+@pytest.mark.parametrize("threads", [0, 1, 3])
+@pytest.mark.parametrize("dist", [False, True])
+def test_pairwise_context_bit_exact_vs_oracle(oracle, threads, dist):
+    """CONTEXT_PAIRWISE (...data_layer.cpp:396-422): two random frames per record in draw order, context_size forced to 2,
+    one-shot records skipped; with output_shot_distance the label is the clamped frame distance.  Serial, one prefetch
+    thread and the three-stage pipeline give the oracle's stream."""
+    ds = SyntheticVideos(seed=3, n_videos=200, lo=1, span=40)
+    kw = dict(batch_size=32, context_size=9, num_negative_samples=10, max_buffer_size=300, negative_swap_percentage=50,
+              context_type="PAIRWISE", output_shot_distance=dist, max_shot_distance=6.5)
+    a = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, **kw)
+    o = oracle.Sampler(ds.video_id, ds.n_shots, ds.row_base, **kw)
+    assert a.CN == 12 and a.stat(1) == 1
+    if threads:
+        a.prefetch_start(depth=3, threads=threads)
+    for _ in range(30):
+        i1, l1, y1 = a.next(want_last=True, want_label=True)
+        i2, l2, y2 = o.next()
+        assert np.array_equal(i1, i2) and np.array_equal(l1, l2) and np.array_equal(y1, y2)
+    if dist:
+        assert y1.max() <= 6 and np.array_equal(y1, np.minimum(np.abs(i1[:, 0] - i1[:, 1]), 6))
+    a.close()
+    # no negatives at all: the pair only
+    kw.update(num_negative_samples=0, max_buffer_size=0)
+    a = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, **kw)
+    o = oracle.Sampler(ds.video_id, ds.n_shots, ds.row_base, **kw)
+    for _ in range(5):
+        assert np.array_equal(a.next(), o.next()[0])
+    a.close()
+
+
+def test_negative_dataset_bit_exact_vs_oracle(oracle):
+    """negative_dataset (...data_layer.cpp:105-151, 253-286, 325-341): the buffer starts as every shot of the negative
+    dataset's first records (no draw, main cursor untouched); swap-ins then bring the main dataset's shots in.  Same
+    video ids in both datasets share keys, as the reference's "vid:shot" strings do."""
+    ds = SyntheticVideos(seed=9, n_videos=80, lo=3, span=20)
+    total = int(ds.n_shots.sum())
+    nns = np.array([6, 9, 5, 12, 8, 10]); nvid = np.array([3, 1000, 1001, 7, 1002, 1003])
+    nrb = total + np.concatenate([[0], np.cumsum(nns[:-1])])
+    kw = dict(batch_size=16, context_size=5, num_negative_samples=6, max_buffer_size=int(nns[:5].sum()),
+              negative_swap_percentage=60)
+    a = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, negatives=(nvid, nns, nrb), **kw)
+    o = oracle.Sampler(ds.video_id, ds.n_shots, ds.row_base, negatives=(nvid, nns, nrb), **kw)
+    assert a.stat(1) == 0                        # keys are not rows any more: the general path
+    for k in range(25):
+        i1, l1, y1 = a.next(want_last=True, want_label=True)
+        i2, l2, y2 = o.next()
+        assert np.array_equal(i1, i2) and np.array_equal(l1, l2) and np.array_equal(y1, y2)
+        if k == 0:
+            assert i1[0, 5:].min() >= total      # before any swap-in the negatives are the negative dataset's rows
+    a.close()
+    for mb in (int(nns[:5].sum()) - 1, int(nns.sum()) + 1):       # overshoot / never full
+        with pytest.raises(vv.VVError):
+            vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, negatives=(nvid, nns, nrb), **dict(kw, max_buffer_size=mb))
+        with pytest.raises(ValueError):
+            oracle.Sampler(ds.video_id, ds.n_shots, ds.row_base, negatives=(nvid, nns, nrb), **dict(kw, max_buffer_size=mb))

@@ -301,6 +301,11 @@ struct vv_sampler {
 
   static uint64_t key(int32_t vid, int32_t shot) { return ((uint64_t)(uint32_t)vid << 32) | (uint32_t)shot; }
   int32_t shot_id(int v, int j) const { return has_ids ? shot_ids[shot_off[v] + j] : j; }
+  // …data_layer.cpp:412-415: the frame distance, or max_shot_distance (a float bound held in an int) from there on
+  int32_t pair_label(int f0, int f1) const {
+    const int d = f0 > f1 ? f0 - f1 : f1 - f0;
+    return (float)d >= p.max_shot_distance ? (int32_t)p.max_shot_distance : d;
+  }
 
   // include/caffe/util/rng.hpp:43-54
   void random_unique(std::vector<int32_t>& a, int n) {
@@ -482,7 +487,14 @@ void vv_sampler::frames_item(const uint32_t* rec, int32_t* out, int32_t* label) 
   const int64_t base = row_base[v];
   const uint32_t* x = rec + 4;
   if (label) *label = video_id[v];                                                   // :879
-  if (p.context_type == VV_CONTEXT_WINDOW || p.context_type == VV_CONTEXT_PAST) {
+  if (p.context_type == VV_CONTEXT_PAIRWISE) {
+    // :397 random_unique(perm, 2) on the identity permutation: perm[0] = j0, then perm[1] <-> perm[j1]
+    const int j0 = fm.mod((int32_t)(x[0] >> 1), n);
+    const int j1 = 1 + fm.mod((int32_t)(x[1] >> 1), n - 1);
+    const int f0 = j0, f1 = j1 == j0 ? 0 : j1;
+    out[0] = (int32_t)(base + f0); out[1] = (int32_t)(base + f1);                    // :400-405, draw order, not sorted
+    if (label && p.output_shot_distance) *label = pair_label(f0, f1);               // :407-415
+  } else if (p.context_type == VV_CONTEXT_WINDOW || p.context_type == VV_CONTEXT_PAST) {
     // random_unique(perm, C) on the identity permutation of 0..n-1, kept sparse: only the touched entries
     int32_t oi[64], ov[64]; int no = 0;
     int32_t fr[32];
@@ -533,7 +545,16 @@ int vv_sampler::next_general(int32_t* idx, int32_t* last_src, int32_t* label) {
     int added = 0;
     const int max_same = std::min(p.max_same_video_negs, Nn);                        // never past the item's Nn slots
     const bool ok = n >= 2 && n >= C;                                              // :387,:427,:512,:601,:679
-    if (ok && p.context_type != VV_CONTEXT_WINDOW) {
+    int32_t lab = s->video_id[v];
+    if (ok && p.context_type == VV_CONTEXT_PAIRWISE) {                             // :396-422
+      std::vector<int32_t>& perm = s->perm;
+      perm.resize(n);
+      for (int i = 0; i < n; ++i) perm[i] = i;
+      s->random_unique(perm, 2);                                                   // :397
+      sl[0].row = sl[0].last = (int32_t)(base + perm[0]);
+      sl[1].row = sl[1].last = (int32_t)(base + perm[1]);
+      if (p.output_shot_distance) lab = s->pair_label(perm[0], perm[1]);
+    } else if (ok && p.context_type != VV_CONTEXT_WINDOW) {
       // :510-757 -- target = the last of the C frames, context = the C-1 before it, in time order
       std::vector<int32_t>& perm = s->perm;
       perm.resize(n);
@@ -610,7 +631,7 @@ int vv_sampler::next_general(int32_t* idx, int32_t* last_src, int32_t* label) {
         sl[C + added + first].row = sl[C + added + first].last = brow[t];
       }
     }
-    if (label) label[item] = s->video_id[v];                                       // :879
+    if (label) label[item] = lab;                                                  // :879
     ++item;
     if (Nn > 0 && p.negative_swap_percentage > 0 && s->dense_keys) {               // :888-906, bitmap key set
       uint8_t* inb = s->row_in_buf.data() - s->row_min;      // indexed by table row
@@ -771,14 +792,26 @@ void vv_sampler_param_default(vv_sampler_param* p) {
   p->batch_size = 128; p->context_size = 5; p->num_negative_samples = 10;   // shipped prototxt :13-23
   p->max_buffer_size = 5000; p->negative_swap_percentage = 50; p->max_same_video_negs = 0;
   p->max_tries_for_negs = 100;
+  p->max_shot_distance = 5.f;                                                      // caffe.proto:674
 }
 
 int vv_sampler_create(const vv_sampler_param* p, int32_t n_videos, const int32_t* video_id,
                       const int32_t* n_shots, const int64_t* row_base, const int32_t* shot_ids,
                       vv_sampler** out) {
-  if (!p || !video_id || !n_shots || !row_base || !out || n_videos < 1) return VV_ERR_ARG;
+  return vv_sampler_create_neg(p, n_videos, video_id, n_shots, row_base, shot_ids, 0, nullptr, nullptr, nullptr, nullptr, out);
+}
+
+int vv_sampler_create_neg(const vv_sampler_param* p_in, int32_t n_videos, const int32_t* video_id,
+                          const int32_t* n_shots, const int64_t* row_base, const int32_t* shot_ids,
+                          int32_t neg_videos, const int32_t* neg_video_id, const int32_t* neg_n_shots,
+                          const int64_t* neg_row_base, const int32_t* neg_shot_ids, vv_sampler** out) {
+  if (!p_in || !video_id || !n_shots || !row_base || !out || n_videos < 1) return VV_ERR_ARG;
+  if (neg_videos < 0 || (neg_videos > 0 && (!neg_video_id || !neg_n_shots || !neg_row_base))) return VV_ERR_ARG;
+  vv_sampler_param pp = *p_in;
+  if (pp.context_type == VV_CONTEXT_PAIRWISE) pp.context_size = 2;                // :200-201
+  const vv_sampler_param* p = &pp;
   if (p->batch_size < 1 || p->context_size < 2) return VV_ERR_ARG;                // :207,:209
-  if (p->context_type < VV_CONTEXT_WINDOW || p->context_type > VV_CONTEXT_PAST_CONTINUOUS_FIXED) return VV_ERR_ARG;   // :760
+  if (p->context_type < VV_CONTEXT_WINDOW || p->context_type > VV_CONTEXT_PAIRWISE) return VV_ERR_ARG;   // :760
   if (p->context_type == VV_CONTEXT_WINDOW && p->context_size % 2 != 1) return VV_ERR_ARG;   // :434
   const int Nn = p->num_negative_samples;
   if (Nn < 0) return VV_ERR_ARG;
@@ -825,7 +858,7 @@ int vv_sampler_create(const vv_sampler_param* p, int32_t n_videos, const int32_t
       std::sort(ranges.begin(), ranges.end());
       for (size_t i = 1; i < ranges.size() && ok; ++i) ok = ranges[i].first >= ranges[i - 1].second;
     }
-    if (ok && lo >= 0 && hi < (1ll << 31) - 1) {
+    if (ok && neg_videos == 0 && lo >= 0 && hi < (1ll << 31) - 1) {     // a negative dataset brings keys that are not rows of this one
       s->dense_keys = true; s->row_min = lo;
       s->row_in_buf.assign((size_t)(hi - lo) + 64, 0);                            // 64 bytes of slack: the swap-in reads whole vectors
     }
@@ -834,7 +867,7 @@ int vv_sampler_create(const vv_sampler_param* p, int32_t n_videos, const int32_t
   s->cursor = p->initial_cursor % n_videos;                                       // rand_skip, :156-180
   const int C = p->context_size, CN = C + Nn;
   s->fast = s->dense_keys && p->max_same_video_negs <= 0;
-  s->CA = (p->context_type == VV_CONTEXT_WINDOW || p->context_type == VV_CONTEXT_PAST) ? C
+  s->CA = (p->context_type == VV_CONTEXT_WINDOW || p->context_type == VV_CONTEXT_PAST || p->context_type == VV_CONTEXT_PAIRWISE) ? C
           : (p->context_type == VV_CONTEXT_PAST_CONTINUOUS ? 2 : 0);
   s->rec_words = 4 + s->CA + Nn;
   s->rec1.assign((size_t)s->rec_words, 0u);
@@ -850,7 +883,28 @@ int vv_sampler_create(const vv_sampler_param* p, int32_t n_videos, const int32_t
   for (int i = 0; i < mb; ++i) s->buffer_ids[i] = i;
   s->buf_row.reserve(mb); s->buf_key.reserve(mb);
   // fill the negative buffer: one random shot of each visited record until full (:240-344)
-  if (mb > 0) {
+  if (mb > 0 && neg_videos > 0) {
+    // negative_dataset (:105-151 opens it, :253-286 its own cursor from the first record, :325-341 EVERY shot whose
+    // key is new; no rand(), the main cursor stays).  The reference tests for a full buffer only after a whole record
+    // (:343) and writes past negatives_ when the last record overshoots: only an exact fit passes its CHECK_EQ (:348).
+    const int64_t tries = (int64_t)p->max_tries_for_negs * mb;
+    int64_t off = 0; int cur = 0;
+    std::vector<int64_t> neg_off(neg_videos);
+    for (int v = 0; v < neg_videos; ++v) { if (neg_n_shots[v] < 1) { delete s; return VV_ERR_ARG; } neg_off[v] = off; off += neg_n_shots[v]; }
+    for (int64_t t = 0; t < tries && (int)s->buf_row.size() < mb; ++t) {
+      const int v = cur;
+      cur = (cur + 1) % neg_videos;
+      for (int j = 0; j < neg_n_shots[v]; ++j) {
+        const uint64_t k = vv_sampler::key(neg_video_id[v], neg_shot_ids ? neg_shot_ids[neg_off[v] + j] : j);
+        if (s->keys.count(k)) continue;
+        if ((int)s->buf_row.size() >= mb) { delete s; return VV_ERR_ARG; }
+        s->keys.insert(k);
+        s->buf_row.push_back((int32_t)(neg_row_base[v] + j));
+        s->buf_key.push_back(k);
+      }
+    }
+    if ((int)s->buf_row.size() != mb) { delete s; return VV_ERR_ARG; }
+  } else if (mb > 0) {
     const int64_t tries = (int64_t)p->max_tries_for_negs * mb;
     for (int64_t t = 0; t < tries && (int)s->buf_row.size() < mb; ++t) {
       const int v = s->cursor;

@@ -383,19 +383,26 @@ class _SamplerParam(C.Structure):
     _fields_ = [("batch_size", C.c_int32), ("context_size", C.c_int32),
                 ("num_negative_samples", C.c_int32), ("max_buffer_size", C.c_int32),
                 ("negative_swap_percentage", C.c_int32), ("max_same_video_negs", C.c_int32),
-                ("max_tries_for_negs", C.c_int32), ("context_type", C.c_int32), ("initial_cursor", C.c_int32)]
+                ("max_tries_for_negs", C.c_int32), ("context_type", C.c_int32), ("initial_cursor", C.c_int32),
+                ("output_shot_distance", C.c_int32), ("max_shot_distance", C.c_float)]
+
+
+CONTEXT_TYPES = {"WINDOW": 0, "PAST": 1, "PAST_CONTINUOUS": 2, "PAST_CONTINUOUS_FIXED": 3, "PAIRWISE": 4}
 
 
 class Sampler:
     """Host-side triplet sampler of the product library (vv_sampler_*): the reference's
-    VideoSampledShotsDataLayer with row indices instead of feature copies (WINDOW context)."""
+    VideoSampledShotsDataLayer with row indices instead of feature copies.  negatives = (video_id, n_shots,
+    row_base[, shot_ids]) of a `negative_dataset` whose rows live in the same feature table."""
 
     def __init__(self, video_id, n_shots, row_base, *, batch_size, context_size,
                  num_negative_samples, max_buffer_size=5000, negative_swap_percentage=50,
-                 max_same_video_negs=0, max_tries_for_negs=100, shot_ids=None, context_type="WINDOW", initial_cursor=0):
+                 max_same_video_negs=0, max_tries_for_negs=100, shot_ids=None, context_type="WINDOW", initial_cursor=0,
+                 output_shot_distance=False, max_shot_distance=5.0, negatives=None):
         L = load_library()
-        L.vv_sampler_create.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
-                                        C.c_void_p, C.POINTER(C.c_void_p)]
+        L.vv_sampler_create_neg.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.POINTER(C.c_void_p)]
         L.vv_sampler_next.argtypes = [C.c_void_p] * 4
         L.vv_sampler_destroy.argtypes = [C.c_void_p]
         L.vv_sampler_prefetch_start.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int32]
@@ -408,14 +415,22 @@ class Sampler:
         sid = None if shot_ids is None else np.ascontiguousarray(shot_ids, dtype=np.int32)
         p = _SamplerParam(batch_size, context_size, num_negative_samples, max_buffer_size,
                           negative_swap_percentage, max_same_video_negs, max_tries_for_negs,
-                          {"WINDOW": 0, "PAST": 1, "PAST_CONTINUOUS": 2, "PAST_CONTINUOUS_FIXED": 3}[context_type],
-                          initial_cursor)
+                          CONTEXT_TYPES[context_type], initial_cursor, int(output_shot_distance), max_shot_distance)
         self.h = C.c_void_p()
-        rc = L.vv_sampler_create(C.byref(p), len(vid), _ptr(vid), _ptr(ns), _ptr(rb), _ptr(sid),
-                                 C.byref(self.h))
+        nvid = nns = nrb = nsid = None
+        if negatives is not None:
+            nvid = np.ascontiguousarray(negatives[0], dtype=np.int32)
+            nns = np.ascontiguousarray(negatives[1], dtype=np.int32)
+            nrb = np.ascontiguousarray(negatives[2], dtype=np.int64)
+            nsid = np.ascontiguousarray(negatives[3], dtype=np.int32) if len(negatives) > 3 and negatives[3] is not None else None
+        rc = L.vv_sampler_create_neg(C.byref(p), len(vid), _ptr(vid), _ptr(ns), _ptr(rb), _ptr(sid),
+                                     0 if nvid is None else len(nvid), _ptr(nvid), _ptr(nns), _ptr(nrb), _ptr(nsid),
+                                     C.byref(self.h))
         if rc != 0:
             raise VVError("vv_sampler_create failed (%d): the reference would CHECK-fail on these "
                           "parameters" % rc)
+        if context_type == "PAIRWISE":
+            context_size = 2
         self.B, self.CN = batch_size, context_size + num_negative_samples
 
     def next(self, want_last=False, want_label=False):

@@ -28,7 +28,8 @@ def _test_branch_front(a, test_source, test_batch, frames):
 def train_net(source, B, C, Nn, D, *, max_buffer=5000, swap=50, max_same=0, dropout=0.0, margin=2.0,
               norm="L2", name="videovec_train", w_std=0.001, test_source=None, test_batch=673, test_frames=4,
               id_to_class_file=None, id_to_weight_file=None, use_direct_weight=False, ip_regularization=0.0,
-              context_type="WINDOW", rand_skip=0):
+              context_type="WINDOW", rand_skip=0, negative_dataset=None, output_shot_distance=False,
+              max_shot_distance=None):
     """test_source: also emit the TEST branch of the shipped file (window data -> average_for_test ->
     [shared fc7 / fc7_relu] -> test_norm -> retrieval_stats).
     id_to_weight_file / use_direct_weight: the weighted loss -- the data layer's video ids, replicated to (B, Nn)
@@ -45,7 +46,12 @@ def train_net(source, B, C, Nn, D, *, max_buffer=5000, swap=50, max_same=0, drop
       '    num_negative_samples: %d\n    max_buffer_size: %d\n    negative_swap_percentage: %d\n'
       '    max_same_video_negs: %d\n    context_type: %s\n    context_size: %d\n%s  }\n'
       '  include: { phase: TRAIN }\n}' % (source, B, Nn, max_buffer, swap, max_same, context_type, C,
-                                          '    rand_skip: %d\n' % rand_skip if rand_skip else ''))
+                                          ('    rand_skip: %d\n' % rand_skip if rand_skip else '') +
+                                          ('    negative_dataset: "%s"\n' % negative_dataset if negative_dataset else '') +
+                                          ('    output_shot_distance: true\n' if output_shot_distance else '') +
+                                          ('    max_shot_distance: %g\n' % max_shot_distance if max_shot_distance is not None else '')))
+    if context_type == "PAIRWISE":
+        C = 2                    # video_sampled_shots_data_layer.cpp:200-201
     datums = ["target_datum"] + ["context_datum_%d" % j for j in range(1, C)] + \
              ["negative_datum_%d" % k for k in range(1, Nn + 1)]
     a('layers {\n  name: "slice_input_data"\n  type: SLICE\n  bottom: "data"\n%s\n  include: { phase: TRAIN }\n}'
@@ -68,12 +74,14 @@ def train_net(source, B, C, Nn, D, *, max_buffer=5000, swap=50, max_same=0, drop
            ["negative_emb_%d_nonorm" % k for k in range(1, Nn + 1)]
     a('layers {\n  name: "slice_emb"\n  type: SLICE\n  bottom: "ip2"\n%s\n  slice_param { slice_dim: 0 }\n'
       '  include: { phase: TRAIN }\n}' % "\n".join('  top: "%s"' % e for e in embs))
-    a('layers {\n  name: "context_average"\n  type: ELTWISE\n%s\n  top: "context_feature_nonorm"\n'
-      '  eltwise_param {\n    operation: SUM\n%s\n  }\n  include: { phase: TRAIN }\n}'
-      % ("\n".join('  bottom: "%s"' % e for e in embs[1:C]),
-         "\n".join("    coeff: %.10g" % (1.0 / (C - 1)) for _ in range(C - 1))))
-    a('layers {\n  name: "word_embedding_norm"\n  type: NORMALIZATION\n  bottom: "context_feature_nonorm"\n'
-      '  top: "context_feature"\n  include: { phase: TRAIN }\n}')
+    if C > 2:
+        a('layers {\n  name: "context_average"\n  type: ELTWISE\n%s\n  top: "context_feature_nonorm"\n'
+          '  eltwise_param {\n    operation: SUM\n%s\n  }\n  include: { phase: TRAIN }\n}'
+          % ("\n".join('  bottom: "%s"' % e for e in embs[1:C]),
+             "\n".join("    coeff: %.10g" % (1.0 / (C - 1)) for _ in range(C - 1))))
+    # one context frame: ELTWISE needs two bottoms (eltwise_layer.cpp:17), the embedding is normalised as it is
+    a('layers {\n  name: "word_embedding_norm"\n  type: NORMALIZATION\n  bottom: "%s"\n'
+      '  top: "context_feature"\n  include: { phase: TRAIN }\n}' % ("context_feature_nonorm" if C > 2 else embs[1]))
     pn = [embs[0]] + embs[C:]
     a('layers {\n  name: "concat_pos_neg_nonorm"\n  type: CONCAT\n  top: "pos_neg_nonorm"\n%s\n'
       '  concat_param { concat_dim: 0 }\n  include: { phase: TRAIN }\n}'
