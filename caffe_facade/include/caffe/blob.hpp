@@ -25,6 +25,8 @@ class SyncedMemory {            // syncedmem.hpp:40-68
  private:
   void to_cpu();
   void to_gpu();
+  vv_ctx* ctx();                   // the context the device copy lives under (the current one when it is allocated)
+  vv_ctx* owner_ = nullptr;
   std::vector<char> host_;
   void* dev_ = nullptr;
   size_t size_;

@@ -76,6 +76,11 @@ class Caffe {
   static bool has_ctx();
   // what ctx() returns while set (a TEST net's own context during its layer-by-layer pass); returns the previous one
   static vv_ctx* set_current_ctx(vv_ctx* c);
+  // A net with a context of its own (TEST / extraction nets) registers it for the context's lifetime: device memory
+  // keeps using the context (hence the stream) it was allocated under for as long as that context lives.
+  static void register_ctx(vv_ctx* c);
+  static void unregister_ctx(vv_ctx* c);
+  static bool is_live(vv_ctx* c);
   static void Reset();                                     // destroy the context (tests)
  private:
   Caffe();
@@ -88,6 +93,7 @@ class Caffe {
   unsigned int seed_ = 1701;
   vv_ctx* ctx_ = nullptr;
   vv_ctx* current_ = nullptr;
+  std::vector<vv_ctx*> live_;
 };
 
 }  // namespace caffe

@@ -20,7 +20,7 @@ class Net {
  public:
   explicit Net(const NetParameter& param) { Init(param); }
   explicit Net(const string& param_file, Caffe::Phase phase = Caffe::TRAIN);
-  virtual ~Net() { if (own_ctx_ && ctx_) vv_destroy(ctx_); }
+  virtual ~Net();
   void Init(const NetParameter& param);
 
   // net.hpp:78-83: forward + backward of one prefetched batch; returns the weighted loss

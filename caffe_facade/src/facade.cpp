@@ -89,6 +89,16 @@ vv_ctx* Caffe::ctx() {
   return c.ctx_;
 }
 bool Caffe::has_ctx() { return Get().ctx_ != nullptr; }
+void Caffe::register_ctx(vv_ctx* c) { Get().live_.push_back(c); }
+void Caffe::unregister_ctx(vv_ctx* c) {
+  vector<vv_ctx*>& l = Get().live_;
+  l.erase(std::remove(l.begin(), l.end(), c), l.end());
+}
+bool Caffe::is_live(vv_ctx* c) {
+  if (!c) return false;
+  const Caffe& g = Get();
+  return c == g.ctx_ || std::find(g.live_.begin(), g.live_.end(), c) != g.live_.end();
+}
 void Caffe::Reset() {
   Caffe& c = Get();
   if (c.ctx_) vv_destroy(c.ctx_);
@@ -98,24 +108,32 @@ void Caffe::Reset() {
 // ------------------------------------------------------------------------------- SyncedMemory --
 // syncedmem.cpp:10-109 with HIP memory of the process context in place of cudaMalloc / cudaMemcpy
 SyncedMemory::~SyncedMemory() {
-  if (dev_ && Caffe::has_ctx()) vv_dev_free(Caffe::ctx(), dev_);
+  if (!dev_) return;
+  if (Caffe::is_live(owner_)) vv_dev_free(owner_, dev_);
+  else if (Caffe::has_ctx()) vv_dev_free(Caffe::ctx(), dev_);
+}
+// Transfers run on the stream of the context the device copy was allocated under (a TEST net has its own): reading a
+// blob after Net::Forward returned -- outside any net's pass -- must still be ordered after that net's kernels.
+vv_ctx* SyncedMemory::ctx() {
+  if (dev_ && Caffe::is_live(owner_)) return owner_;
+  return owner_ = Caffe::ctx();
 }
 void SyncedMemory::to_cpu() {
   switch (head_) {
     case UNINITIALIZED: host_.assign(size_, 0); head_ = HEAD_AT_CPU; break;
     case HEAD_AT_GPU:
       if (host_.size() != size_) host_.assign(size_, 0);
-      VV_CHECK(vv_dev_download(Caffe::ctx(), host_.data(), dev_, size_));
+      VV_CHECK(vv_dev_download(ctx(), host_.data(), dev_, size_));
       head_ = SYNCED; break;
     case HEAD_AT_CPU: case SYNCED: break;
   }
 }
 void SyncedMemory::to_gpu() {
   switch (head_) {
-    case UNINITIALIZED: VV_CHECK(vv_dev_alloc(Caffe::ctx(), size_, &dev_)); head_ = HEAD_AT_GPU; break;   // zero-filled
+    case UNINITIALIZED: VV_CHECK(vv_dev_alloc(ctx(), size_, &dev_)); head_ = HEAD_AT_GPU; break;   // zero-filled
     case HEAD_AT_CPU:
-      if (!dev_) VV_CHECK(vv_dev_alloc(Caffe::ctx(), size_, &dev_));
-      VV_CHECK(vv_dev_upload(Caffe::ctx(), dev_, host_.data(), size_));
+      if (!dev_) VV_CHECK(vv_dev_alloc(ctx(), size_, &dev_));
+      VV_CHECK(vv_dev_upload(ctx(), dev_, host_.data(), size_));
       head_ = SYNCED; break;
     case HEAD_AT_GPU: case SYNCED: break;
   }

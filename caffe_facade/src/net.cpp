@@ -148,6 +148,7 @@ void Net<Dtype>::Init(const NetParameter& in_param) {
     // a TEST / extraction net has its own feature table, hence its own context on the same device
     VV_CHECK(vv_create(Caffe::device(), getenv("VV_PREC") && !strcmp(getenv("VV_PREC"), "bf16") ? VV_PREC_BF16 : VV_PREC_F16, &ctx_));
     own_ctx_ = true;
+    Caffe::register_ctx(ctx_);
     static_cast<VideoShotWindowTestDataLayer<Dtype>*>(layers_[plan_.data_layer].get())->dataset()->UploadTable(ctx_);
   } else {
     ctx_ = Caffe::ctx();
@@ -413,6 +414,19 @@ void Net<Dtype>::BackwardFromTo(int start, int end) {
     }
     layers_[li]->set_accumulate_bottom(acc);
     layers_[li]->Backward(top_vecs_[li], bottom_need_backward_[li], &bottom_vecs_[li]);
+  }
+}
+
+// The net's blobs and layers free their device memory through the context they were allocated under: release them
+// while a net-owned context still exists.
+template <typename Dtype>
+Net<Dtype>::~Net() {
+  if (own_ctx_ && ctx_) {
+    net_output_blobs_.clear();
+    bottom_vecs_.clear(); top_vecs_.clear();
+    blobs_.clear(); params_.clear(); layers_.clear();
+    Caffe::unregister_ctx(ctx_);
+    vv_destroy(ctx_);
   }
 }
 
