@@ -12,6 +12,7 @@
 #include <map>
 #include <unordered_map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "vv_ctx.h"
@@ -86,6 +87,8 @@ void vv_step_cfg_default(vv_step_cfg* cfg) {
   cfg->solver_type = VV_SOLVER_SGD; cfg->delta = 1e-8f; cfg->ip_regularization = 0.f;
 }
 
+static int create_init(vv_ctx* c);
+
 int vv_create(int device, int prec, vv_ctx** out) {
   if (!out) return fail(VV_ERR_ARG, "vv_create: out is NULL");
   if (prec != VV_PREC_F16 && prec != VV_PREC_BF16) return fail(VV_ERR_ARG, "vv_create: bad prec %d", prec);
@@ -101,6 +104,14 @@ int vv_create(int device, int prec, vv_ctx** out) {
                 prop.gcnArchName);
   vv_ctx* c = new vv_ctx();
   c->device = device; c->prec = prec;
+  const int rc = create_init(c);
+  if (rc != VV_OK) { vv_destroy(c); return rc; }        // the message of the failing call stays in vv_last_error()
+  *out = c;
+  return VV_OK;
+}
+
+// everything vv_create allocates; a failure half way leaves a context vv_destroy can release
+static int create_init(vv_ctx* c) {
   HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
 
@@ -137,7 +148,6 @@ int vv_create(int device, int prec, vv_ctx** out) {
   HIPCHK(hipHostMalloc((void**)&c->seq_host, sizeof(int32_t), hipHostMallocMapped));
   *c->seq_host = 0;
   HIPCHK(hipHostGetDevicePointer((void**)&c->seq_host_dev, c->seq_host, 0));
-  *out = c;
   return VV_OK;
 }
 
@@ -179,7 +189,7 @@ static void free_batch(vv_ctx* c) {
 int vv_destroy(vv_ctx* c) {
   if (!c) return VV_OK;
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
   vv_ops_release(c);
   free_batch(c);
   dfree(c->table); dfree(c->patch_desc); dfree(c->W); dfree(c->b); dfree(c->hW); dfree(c->hb); dfree(c->Wh);
@@ -258,10 +268,31 @@ int vv_table_set(vv_ctx* c, const float* rows, int64_t n_rows, int32_t F) {
   if (rc) return rc;
   // range guard for f16: keep max|x|*sx inside [2^-8, 2^14]; otherwise move it to ~2^8
   float mx = 0.f;
-  for (int64_t i = 0; i < n_rows * F; ++i) {
-    const float v = fabsf(rows[i]);
-    if (!(v <= 3.0e38f)) return fail(VV_ERR_ARG, "vv_table_set: non-finite feature at %lld", (long long)i);
-    if (v > mx) mx = v;
+  {
+    // one pass over the host table for max|x| and the first non-finite value; split over a few threads (the scan of a
+    // 100 GB table on one core is the longest part of set-up)
+    const int64_t total = n_rows * F;
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(16, std::thread::hardware_concurrency()), total >> 22));
+    std::vector<float> part_mx(nt, 0.f);
+    std::vector<int64_t> part_bad(nt, -1);
+    auto scan = [&](int t) {
+      const int64_t lo = total * t / nt, hi = total * (t + 1) / nt;
+      float m = 0.f; int64_t bad = -1;
+      for (int64_t i = lo; i < hi; ++i) {
+        const float v = fabsf(rows[i]);
+        if (!(v <= 3.0e38f)) { bad = i; break; }
+        if (v > m) m = v;
+      }
+      part_mx[t] = m; part_bad[t] = bad;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(scan, t);
+    scan(0);
+    for (auto& x : th) x.join();
+    for (int t = 0; t < nt; ++t) {
+      if (part_bad[t] >= 0) return fail(VV_ERR_ARG, "vv_table_set: non-finite feature at %lld", (long long)part_bad[t]);
+      mx = std::max(mx, part_mx[t]);
+    }
   }
   float sx = 1.f;
   if (c->prec == VV_PREC_F16 && mx > 0.f && (mx > 16384.f || mx < 1.f / 256.f)) {
@@ -269,16 +300,14 @@ int vv_table_set(vv_ctx* c, const float* rows, int64_t n_rows, int32_t F) {
   }
   if ((rc = set_sx(c, sx))) return rc;
   const int64_t chunk_rows = std::max<int64_t>(1, (64ll << 20) / ((int64_t)F * 4));
-  float* stage = nullptr;
-  HIPCHK(hipMalloc(&stage, (size_t)chunk_rows * F * sizeof(float)));
+  DevTmp<float> stage;
+  HIPCHK(stage.alloc((size_t)chunk_rows * F));
   for (int64_t r0 = 0; r0 < n_rows; r0 += chunk_rows) {
     const int64_t nr = std::min(chunk_rows, n_rows - r0);
-    hipError_t e = hipMemcpyAsync(stage, rows + r0 * F, (size_t)nr * F * sizeof(float), hipMemcpyHostToDevice, c->stream);
-    if (e != hipSuccess) { dfree(stage); return fail(VV_ERR_HIP, "table upload: %s", hipGetErrorString(e)); }
+    HIPCHK(hipMemcpyAsync(stage, rows + r0 * F, (size_t)nr * F * sizeof(float), hipMemcpyHostToDevice, c->stream));
     launch_table_convert(c->prec, stage, c->table + r0 * c->Fp, nr, F, c->Fp, sx, c->stream);
-    (void)hipStreamSynchronize(c->stream);
+    HIPCHK(hipStreamSynchronize(c->stream));
   }
-  dfree(stage);
   HIPCHK(hipGetLastError());
   return VV_OK;
 }
@@ -298,18 +327,17 @@ int vv_table_get(vv_ctx* c, const int32_t* rows, int64_t n, float* out) {
   if (!c || !out || n <= 0) return fail(VV_ERR_ARG, "vv_table_get: bad argument");
   if (!c->table) return fail(VV_ERR_STATE, "vv_table_get: no table");
   HIPCHK(hipSetDevice(c->device));
-  int32_t* drows = nullptr; float* dout = nullptr;
+  DevTmp<int32_t> drows; DevTmp<float> dout;
   if (rows) {
     for (int64_t i = 0; i < n; ++i)
       if (rows[i] < 0 || rows[i] >= c->n_rows) return fail(VV_ERR_ARG, "vv_table_get: row %d out of range", rows[i]);
-    HIPCHK(hipMalloc(&drows, n * sizeof(int32_t)));
+    HIPCHK(drows.alloc((size_t)n));
     HIPCHK(hipMemcpy(drows, rows, n * sizeof(int32_t), hipMemcpyHostToDevice));
   } else if (n > c->n_rows) return fail(VV_ERR_ARG, "vv_table_get: n > n_rows");
-  HIPCHK(hipMalloc(&dout, (size_t)n * c->F * sizeof(float)));
+  HIPCHK(dout.alloc((size_t)n * c->F));
   launch_table_read(c->prec, c->table, drows, n, c->F, c->Fp, 1.f / c->sx, dout, c->stream);
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipMemcpy(out, dout, (size_t)n * c->F * sizeof(float), hipMemcpyDeviceToHost));
-  dfree(drows); dfree(dout);
   return VV_OK;
 }
 
@@ -777,12 +805,11 @@ int vv_blobs_get(vv_ctx* c, float* ip2, float* target_score, float* negative_sco
   if (ip2) {
     std::vector<float> tmp(n);
     if (c->last_dedup) {               // expand the per-slot rows back to one row per instance
-      float* d = nullptr;
-      HIPCHK(hipMalloc(&d, n * 4));
+      DevTmp<float> d;
+      HIPCHK(d.alloc(n));
       launch_gather_rows_f32(c->H, c->dd_map, c->R, D, d, c->stream);
       HIPCHK(hipStreamSynchronize(c->stream));
       HIPCHK(hipMemcpy(tmp.data(), d, n * 4, hipMemcpyDeviceToHost));
-      dfree(d);
     } else {
       HIPCHK(hipMemcpy(tmp.data(), c->H, n * 4, hipMemcpyDeviceToHost));
     }
@@ -795,23 +822,21 @@ int vv_blobs_get(vv_ctx* c, float* ip2, float* target_score, float* negative_sco
   }
   if (negative_scores) HIPCHK(hipMemcpy(negative_scores, c->s_bogus, (size_t)B * Nn * 4, hipMemcpyDeviceToHost));
   if (ip1_diff) {
-    float* d = nullptr;
-    HIPCHK(hipMalloc(&d, n * 4));
-    uint16_t* ungrouped = nullptr;
+    DevTmp<float> d;
+    HIPCHK(d.alloc(n));
+    DevTmp<uint16_t> ungrouped;
     if (c->last_dedup) {
-      HIPCHK(hipMalloc(&ungrouped, (size_t)c->R * c->Dp * 2));
+      HIPCHK(ungrouped.alloc((size_t)c->R * c->Dp));
       DedupArgs da;
       memset(&da, 0, sizeof(da));
       da.map = c->dd_map; da.ord = c->dd_ord; da.seg_start = c->dd_seg; da.pos = c->dd_pos; da.R = c->R;
       launch_dedup_pos(da, c->stream);
       launch_gather_rows_u16(c->dYh, c->dd_pos, c->R, c->Dp, ungrouped, c->stream);
     }
-    launch_dyh_to_float(c->prec, ungrouped ? ungrouped : c->dYh, c->R, D, c->Dp, 1.f / c->sg, d, c->stream);
+    launch_dyh_to_float(c->prec, ungrouped.p ? ungrouped.p : c->dYh, c->R, D, c->Dp, 1.f / c->sg, d, c->stream);
     HIPCHK(hipStreamSynchronize(c->stream));
-    dfree(ungrouped);
     std::vector<float> tmp(n);
     HIPCHK(hipMemcpy(tmp.data(), d, n * 4, hipMemcpyDeviceToHost));
-    dfree(d);
     reorder(tmp, ip1_diff);
   }
   return VV_OK;
@@ -831,9 +856,9 @@ int vv_embed(vv_ctx* c, const int32_t* rows, int64_t n, int relu, int l2norm, fl
     if (r < 0 || r >= c->n_rows) return fail(VV_ERR_ARG, "vv_embed: row %lld out of range", (long long)r);
     h[i] = (int32_t)r;
   }
-  int32_t* drows = nullptr; float* dout = nullptr;
-  HIPCHK(hipMalloc(&drows, (size_t)Rp * 4));
-  HIPCHK(hipMalloc(&dout, (size_t)n * D * 4));
+  DevTmp<int32_t> drows; DevTmp<float> dout;
+  HIPCHK(drows.alloc((size_t)Rp));
+  HIPCHK(dout.alloc((size_t)n * D));
   HIPCHK(hipMemcpyAsync(drows, h.data(), (size_t)Rp * 4, hipMemcpyHostToDevice, c->stream));
   FwdArgs fa;
   fa.table = c->table; fa.rows = drows; fa.Wh = c->Wh; fa.bias = c->b; fa.scales = c->scales;
@@ -844,7 +869,6 @@ int vv_embed(vv_ctx* c, const int32_t* rows, int64_t n, int relu, int l2norm, fl
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipMemcpy(out, dout, (size_t)n * D * 4, hipMemcpyDeviceToHost));
-  dfree(drows); dfree(dout);
   return VV_OK;
 }
 
@@ -864,9 +888,9 @@ int vv_embed_mean(vv_ctx* c, const int32_t* rows, int64_t n, int32_t k, const fl
   const int Rp = (int)round_up(n, R_ALIGN);
   std::vector<int32_t> h(Rp, (int32_t)c->n_rows);
   for (int64_t i = 0; i < n; ++i) h[i] = (int32_t)(c->n_rows + 1 + i);
-  int32_t *drows_in = nullptr, *drows = nullptr; float *dcoeff = nullptr, *dout = nullptr;
-  HIPCHK(hipMalloc(&drows_in, (size_t)n * k * 4)); HIPCHK(hipMalloc(&drows, (size_t)Rp * 4));
-  HIPCHK(hipMalloc(&dcoeff, (size_t)k * 4)); HIPCHK(hipMalloc(&dout, (size_t)n * D * 4));
+  DevTmp<int32_t> drows_in, drows; DevTmp<float> dcoeff, dout;
+  HIPCHK(drows_in.alloc((size_t)n * k)); HIPCHK(drows.alloc((size_t)Rp));
+  HIPCHK(dcoeff.alloc((size_t)k)); HIPCHK(dout.alloc((size_t)n * D));
   HIPCHK(hipMemcpyAsync(drows_in, rows, (size_t)n * k * 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(drows, h.data(), (size_t)Rp * 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(dcoeff, hc.data(), (size_t)k * 4, hipMemcpyHostToDevice, c->stream));
@@ -880,7 +904,6 @@ int vv_embed_mean(vv_ctx* c, const int32_t* rows, int64_t n, int32_t k, const fl
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipMemcpy(out, dout, (size_t)n * D * 4, hipMemcpyDeviceToHost));
-  dfree(drows_in); dfree(drows); dfree(dcoeff); dfree(dout);
   return VV_OK;
 }
 
@@ -891,14 +914,13 @@ int vv_retrieval_stats(vv_ctx* c, const float* feat, int32_t n, int32_t dim, con
     return fail(VV_ERR_ARG, "vv_retrieval_stats: bad argument");
   if (n_map < 1) return fail(VV_ERR_ARG, "need atleast one entry in id-to-class map!");   // retrieval_stats_layer.cpp:49
   HIPCHK(hipSetDevice(c->device));
-  float *dx = nullptr, *dd = nullptr;
-  HIPCHK(hipMalloc(&dx, (size_t)n * dim * 4)); HIPCHK(hipMalloc(&dd, (size_t)n * n * 4));
+  DevTmp<float> dx, dd;
+  HIPCHK(dx.alloc((size_t)n * dim)); HIPCHK(dd.alloc((size_t)n * n));
   HIPCHK(hipMemcpyAsync(dx, feat, (size_t)n * dim * 4, hipMemcpyHostToDevice, c->stream));
   launch_gram(dx, n, dim, -2.0f, dd, c->stream);                                           // :208-209
   std::vector<float> dist((size_t)n * n);
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipMemcpy(dist.data(), dd, dist.size() * 4, hipMemcpyDeviceToHost));
-  dfree(dx); dfree(dd);
   std::unordered_map<int, int> cls;
   for (int i = 0; i < n_map; ++i) cls[map_ids[i]] = map_cls[i];
   auto cls_of = [&](int id) { auto it = cls.find(id); return it == cls.end() ? 0 : it->second; };

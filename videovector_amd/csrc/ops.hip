@@ -317,15 +317,11 @@ int vv_op_gather_rows(vv_ctx* c, const int32_t* idx, int64_t n, float* out) {
     if (h[i] < -1 || h[i] >= c->n_rows) return vv_fail(VV_ERR_ARG, "vv_op_gather_rows: idx[%lld] = %d out of range", (long long)i, h[i]);
     if (h[i] < 0) h[i] = (int32_t)c->n_rows;                       // the all-zero row
   }
-  int32_t* d = nullptr;
-  HIPCHK(hipMalloc(&d, (size_t)n * 4));
-  hipError_t e = hipMemcpyAsync(d, h.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess) {
-    launch_table_read(c->prec, c->table, d, n, c->F, c->Fp, 1.f / c->sx, out, c->stream);
-    e = hipStreamSynchronize(c->stream);
-  }
-  (void)hipFree(d);
-  if (e != hipSuccess) return vv_fail(VV_ERR_HIP, "vv_op_gather_rows: %s", hipGetErrorString(e));
+  DevTmp<int32_t> d;
+  HIPCHK(d.alloc((size_t)n));
+  HIPCHK(hipMemcpyAsync(d, h.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+  launch_table_read(c->prec, c->table, d, n, c->F, c->Fp, 1.f / c->sx, out, c->stream);
+  HIPCHK(hipStreamSynchronize(c->stream));
   return VV_OK;
 }
 

@@ -22,6 +22,19 @@ int vv_fail(int code, const char* fmt, ...);
                      __LINE__);                                                                \
   } while (0)
 
+// A device allocation that lives for one API call: released on every return path, the early error returns of HIPCHK
+// included.
+template <typename T>
+struct DevTmp {
+  T* p = nullptr;
+  DevTmp() = default;
+  DevTmp(const DevTmp&) = delete;
+  DevTmp& operator=(const DevTmp&) = delete;
+  ~DevTmp() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t count) { return hipMalloc((void**)&p, count * sizeof(T)); }
+  operator T*() const { return p; }
+};
+
 struct ProfEntry { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; };
 
 struct vv_ctx {
