@@ -17,7 +17,7 @@
 
 #include "vv_ctx.h"
 
-namespace vv { void set_wgrad_tr(bool on); void set_gemm_variant(int v); void set_ablate(int v); void set_fwd_mi(int v); void set_score_reg(int v); void set_wgrad_sched(int v); void set_ph_mq(int v); int wgrad_max_ksteps_per_split(); int gemm_variant(); bool ablate_on(); }
+namespace vv { void set_wgrad_tr(bool on); void set_gemm_variant(int v); void set_ablate(int v); void set_fwd_mi(int v); void set_score_reg(int v); void set_score_waves(int v); void set_wgrad_sched(int v); void set_ph_mq(int v); int wgrad_max_ksteps_per_split(); int gemm_variant(); bool ablate_on(); }
 using namespace vv;
 
 thread_local char vv_g_err[512] = "";
@@ -132,12 +132,16 @@ static int create_init(vv_ctx* c) {
   set_fwd_mi(fm ? atoi(fm) : 0);
   const char* sr = getenv("VV_SCORE_REG");
   set_score_reg(sr ? atoi(sr) : 1);
+  const char* sw = getenv("VV_SCORE_WAVES");
+  set_score_waves(sw ? atoi(sw) : 8);
   const char* pq = getenv("VV_PH_MQ");
   set_ph_mq(pq ? atoi(pq) : 0);
   const char* ws = getenv("VV_WGRAD_SCHED");
   set_wgrad_sched(ws ? atoi(ws) : 0);
   const char* th = getenv("VV_TRACE_HOST");
   g_trace_host_ms = th ? atof(th) : -1.0;
+  const char* sb = getenv("VV_SEG_BWD");
+  if (sb) c->seg_bwd = atoi(sb) != 0;
   const char* dd = getenv("VV_DEDUP");
   if (dd) c->dedup = atoi(dd) != 0;
   HIPCHK(hipMalloc(&c->dd_info, 4 * sizeof(int32_t)));
@@ -178,6 +182,8 @@ static void free_batch(vv_ctx* c) {
   dfree(c->coeff); dfree(c->slabs); dfree(c->item_w); c->item_w = nullptr;
   dfree(c->dd_agg); dfree(c->dd_slot_of); dfree(c->dd_uniq); dfree(c->dd_map); dfree(c->dd_ord); dfree(c->dd_cnt);
   dfree(c->dd_seg); dfree(c->dd_pos); dfree(c->dYu);
+  dfree(c->segV); dfree(c->seg_rec); dfree(c->seg_dbp);
+  c->segV = nullptr; c->seg_rec = nullptr; c->seg_dbp = nullptr;
   c->dd_agg = nullptr; c->dd_slot_of = c->dd_uniq = c->dd_map = c->dd_ord = c->dd_cnt = c->dd_seg = c->dd_pos = nullptr;
   c->dYu = nullptr;
   c->idx_dev = c->rows = nullptr; c->H = nullptr; c->dYh = nullptr; c->dbp = nullptr;
@@ -440,6 +446,9 @@ static int ensure_batch(vv_ctx* c, int B, int C, int Nn) {
   HIPCHK(hipMalloc(&c->dd_pos, (size_t)c->Rp * 4));
   HIPCHK(hipMalloc(&c->dYu, (size_t)(c->Rp + BK) * c->Dp * 2));
   HIPCHK(hipMemset(c->dYu, 0, (size_t)(c->Rp + BK) * c->Dp * 2));
+  HIPCHK(hipMalloc(&c->segV, (size_t)2 * B * D * 4));
+  HIPCHK(hipMalloc(&c->seg_rec, (size_t)c->Rp * sizeof(SegRec)));
+  HIPCHK(hipMalloc(&c->seg_dbp, (size_t)SEGB_BLOCKS * D * 4));
   *c->U_host = 0;
   return VV_OK;
 }
@@ -590,9 +599,21 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   sa.map = dd ? c->dd_map : nullptr; sa.seg_start = dd ? c->dd_seg : nullptr; sa.ord = dd ? c->dd_ord : nullptr;
   sa.item_w = cfg->item_weight ? c->item_w : nullptr;
 
-  PROFILED(c, "score_loss", launch_score_loss(c->prec, sa, s));
+  // de-duplicated batches of the supported shape: the backward stays factored per instance and is summed per distinct
+  // row (k_score_fwd + k_seg_bwd); otherwise per-instance 16-bit gradient rows (+ k_segsum when de-duplicated)
+  const bool seg = dd && c->seg_bwd && score_fwd_supported(sa);
+  c->last_seg_bwd = seg; c->last_score = sa;
+  if (seg) {
+    sa.V = c->segV; sa.rec = c->seg_rec;
+    PROFILED(c, "score_loss", launch_score_fwd(sa, s));
+    SegBwdArgs ba;
+    ba.H = c->H; ba.V = c->segV; ba.rec = c->seg_rec; ba.seg_start = c->dd_seg; ba.info = c->dd_info; ba.dYu = c->dYu;
+    ba.dbp = c->seg_dbp; ba.Rp = c->Rp; ba.D = D; ba.Dp = c->Dp; ba.inv_sg = 1.f / c->sg;
+    ba.overflow_host = c->U_host_dev + 1;
+    PROFILED(c, "segsum", launch_seg_bwd(c->prec, ba, s));
+  } else PROFILED(c, "score_loss", launch_score_loss(c->prec, sa, s));
 
-  if (dd) {
+  if (dd && !seg) {
     SegsumArgs ga;
     ga.dYh = c->dYh; ga.seg_start = c->dd_seg; ga.info = c->dd_info; ga.dYu = c->dYu; ga.Rp = c->Rp; ga.Dp = c->Dp;
     ga.overflow_host = c->U_host_dev + 1;
@@ -603,7 +624,8 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   wa.Rp = c->Rp; wa.Dp = c->Dp; wa.Fp = c->Fp; wa.S = c->S; wa.ksteps_per_split = c->kps;
   wa.n_dev = dd ? c->dd_info : nullptr; wa.zero_row = (int32_t)c->n_rows;
   ReduceArgs ra;
-  ra.slabs = c->slabs; ra.S = c->S; ra.Dp = c->Dp; ra.Fp = c->Fp; ra.dbp = c->dbp; ra.B = B;
+  ra.slabs = c->slabs; ra.S = c->S; ra.Dp = c->Dp; ra.Fp = c->Fp; ra.dbp = seg ? c->seg_dbp : c->dbp; ra.B = B;
+  ra.db_rows = seg ? SEGB_BLOCKS : 0;
   ra.scales = c->scales; ra.sg = c->sg; ra.grads = c->grads; ra.D = D; ra.F = c->F;
   ra.ip_scale = cfg->ip_regularization > 0.f ? 1.f + cfg->ip_regularization * 0.5f : 1.f;     // inner_product_layer.cpp:80-90
   ra.loss_part = c->loss_part; ra.viol_part = c->viol_part; ra.loss_scale = cfg->loss_weight / (float)count; ra.loss_out = c->loss2;
@@ -825,6 +847,11 @@ int vv_blobs_get(vv_ctx* c, float* ip2, float* target_score, float* negative_sco
     DevTmp<float> d;
     HIPCHK(d.alloc(n));
     DevTmp<uint16_t> ungrouped;
+    if (c->last_seg_bwd) {
+      // the step kept its backward factored: produce the per-instance rows now (same forward values; the loss partials
+      // it rewrites are the ones already there, its bias partials go to the buffer the step did not use)
+      launch_score_loss(c->prec, c->last_score, c->stream);
+    }
     if (c->last_dedup) {
       HIPCHK(ungrouped.alloc((size_t)c->R * c->Dp));
       DedupArgs da;

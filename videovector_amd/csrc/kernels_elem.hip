@@ -227,40 +227,60 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
 // VGPRs between the forward reductions and the backward pass, so every row of ip2 is read from HBM
 // exactly once (the streaming kernel above re-reads them, and at ~8 workgroups per CU the 110 KB per
 // item do not survive in L2).  RPW = rows per wave, DV = float4 chunks per lane (D = 256*DV).
-// three block-wide sums at once (256 threads; red must hold >= 12 floats)
-__device__ __forceinline__ void block_sum3(float& x, float& y, float& z, float* red) {
+// block-wide sums over NW waves; red must hold >= 3 * NW floats; results broadcast to all threads
+template <int NW>
+__device__ __forceinline__ float block_sum_w(float v, float* red) {
+  v = wave_sum63(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) s += red[w];
+  return s;
+}
+template <int NW>
+__device__ __forceinline__ void block_sum3_w(float& x, float& y, float& z, float* red) {
   x = wave_sum63(x); y = wave_sum63(y); z = wave_sum63(z);
   __syncthreads();
-  if ((threadIdx.x & 63) == 63) { const int w = threadIdx.x >> 6; red[w] = x; red[4 + w] = y; red[8 + w] = z; }
+  if ((threadIdx.x & 63) == 63) { const int w = threadIdx.x >> 6; red[w] = x; red[NW + w] = y; red[2 * NW + w] = z; }
   __syncthreads();
-  x = red[0] + red[1] + red[2] + red[3];
-  y = red[4] + red[5] + red[6] + red[7];
-  z = red[8] + red[9] + red[10] + red[11];
+  x = y = z = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) { x += red[w]; y += red[NW + w]; z += red[2 * NW + w]; }
 }
 
-template <typename T, int RPW, int DV>
-__global__ __launch_bounds__(SL_THREADS) void k_score_loss_reg(ScoreArgs a) {
+// NW waves per item, RPW target/negative rows per wave (row qi lives in wave qi % NW), DV float4 chunks per lane
+// (D = 256 * DV); the context rows and the per-column tail are owned column-wise, CV = D / (64 NW) columns per thread.
+// Eight waves with two rows each keep the register footprint small enough for every workgroup of a 1024-item batch to
+// be resident at once (the four-wave form held 13 row slots per wave: ~200 VGPRs, two rounds of workgroups, and the
+// block-wide sums of each phase were exposed latency).
+template <typename T, int NW, int RPW, int DV>
+__global__ __launch_bounds__(64 * NW) void k_score_loss_reg(ScoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int THREADS = 64 * NW;
+  constexpr int CV = 256 * DV / THREADS;
+  static_assert(CV >= 1 && CV * THREADS == 256 * DV, "D must be a multiple of the thread count");
   constexpr int CXM = 6;       // context rows kept in registers (C - 1 <= CXM on this path)
   const int D = a.D, C = a.C, Nn = a.Nn, CN = C + Nn;
   float* A = sm;               // [D]
   float* Ah = A + D;           // [D]
-  float* acc0 = Ah + D;        // [4][D] per-wave partial dAh
-  float* acc1 = acc0 + 4 * D;  // [4][D] per-wave partial db
-  float* n2 = acc1 + 4 * D;    // [CN]
+  float* acc0 = Ah + D;        // [NW][D] per-wave partial dAh
+  float* acc1 = acc0 + NW * D; // [NW][D] per-wave partial db
+  float* n2 = acc1 + NW * D;   // [CN]
   float* tq = n2 + CN;         // [CN]
   float* cq = tq + CN;         // [CN]
-  float* red = cq + CN;        // [12]
-  int* ooff = (int*)(red + 12);// [CN] row of dYh receiving channel ch's gradient
+  float* red = cq + CN;        // [3 NW]
+  int* ooff = (int*)(red + 3 * NW);   // [CN] row of dYh receiving channel ch's gradient
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float eps = 1e-10f;
 
   // Every global read of ip2 is issued up front: the target / negative rows of this wave
-  // (qi = wave, wave+4, ...) and the context rows (thread tid owns columns tid + 256 v).
+  // (qi = wave, wave+NW, ...) and the context rows (thread tid owns columns tid + THREADS v).
   float4 x[RPW][DV];
 #pragma unroll
   for (int k = 0; k < RPW; ++k) {
-    const int qi = wave + 4 * k;
+    const int qi = wave + NW * k;
     const int ch = qi == 0 ? 0 : C + qi - 1;
     const int r = b * CN + (qi <= Nn ? ch : 0);
     const int hr = a.map ? a.map[r] : r;
@@ -268,18 +288,18 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss_reg(ScoreArgs a) {
     for (int v = 0; v < DV; ++v)
       x[k][v] = qi <= Nn ? *(const float4*)(a.H + (int64_t)hr * D + lane * 4 + v * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  float cx[CXM][DV];
+  float cx[CXM][CV];
 #pragma unroll
   for (int j = 0; j < CXM; ++j) {
     const int r = b * CN + (j + 1 < C ? j + 1 : 0);
     const int hr = a.map ? a.map[r] : r;
 #pragma unroll
-    for (int v = 0; v < DV; ++v) cx[j][v] = j + 1 < C ? a.H[(int64_t)hr * D + tid + v * 256] : 0.f;
+    for (int v = 0; v < CV; ++v) cx[j][v] = j + 1 < C ? a.H[(int64_t)hr * D + tid + v * THREADS] : 0.f;
   }
   float cf[CXM];
 #pragma unroll
   for (int j = 0; j < CXM; ++j) cf[j] = j + 1 < C ? a.coeff[j] : 0.f;
-  for (int ch = tid; ch < CN; ch += SL_THREADS) {
+  for (int ch = tid; ch < CN; ch += THREADS) {
     const int r = b * CN + ch;
     ooff[ch] = a.map ? a.seg_start[a.map[r]] + a.ord[r] : r;
   }
@@ -287,17 +307,17 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss_reg(ScoreArgs a) {
   // ---- phase 1: context mean and its norm
   float ssq = 0.f;
 #pragma unroll
-  for (int v = 0; v < DV; ++v) {
+  for (int v = 0; v < CV; ++v) {
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < CXM; ++j) s += cf[j] * cx[j][v];
-    A[tid + v * 256] = s;
+    A[tid + v * THREADS] = s;
     ssq += s * s;
   }
-  const float sA = block_sum(ssq, red);
+  const float sA = block_sum_w<NW>(ssq, red);
   const float nA = sqrtf(sA) + eps;
 #pragma unroll
-  for (int v = 0; v < DV; ++v) Ah[tid + v * 256] = A[tid + v * 256] / nA;
+  for (int v = 0; v < CV; ++v) Ah[tid + v * THREADS] = A[tid + v * THREADS] / nA;
   __syncthreads();
 
   // ---- phase 2: norms and dots from registers
@@ -306,7 +326,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss_reg(ScoreArgs a) {
   for (int v = 0; v < DV; ++v) y[v] = *(const float4*)(Ah + lane * 4 + v * 256);
 #pragma unroll
   for (int k = 0; k < RPW; ++k) {
-    const int qi = wave + 4 * k;
+    const int qi = wave + NW * k;
     float s = 0.f, t = 0.f;
 #pragma unroll
     for (int v = 0; v < DV; ++v) {
@@ -323,7 +343,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss_reg(ScoreArgs a) {
   const float sp = tq[0] / (sqrtf(n2[0]) + eps);
   const float wb = a.item_w ? a.item_w[b] : 1.f;
   float lsum = 0.f, vsum = 0.f, gsum = 0.f;
-  for (int k = tid; k < Nn; k += SL_THREADS) {
+  for (int k = tid; k < Nn; k += THREADS) {
     const int ch = C + k;
     const float sn = tq[ch] / (sqrtf(n2[ch]) + eps);
     const float d = sp - sn;
@@ -336,7 +356,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss_reg(ScoreArgs a) {
     cq[ch] = g;
     if (a.s_bogus) a.s_bogus[(int64_t)b * Nn + k] = sn;
   }
-  block_sum3(lsum, vsum, gsum, red);
+  block_sum3_w<NW>(lsum, vsum, gsum, red);
   if (tid == 0) {
     cq[0] = -gsum;
     a.loss_part[b] = lsum;
@@ -345,17 +365,16 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss_reg(ScoreArgs a) {
   }
   __syncthreads();
 
-  // ---- phase 4: backward of this wave's rows from registers; one coalesced 512-B store per chunk.
-  // The kernel is VALU-bound (no row loads and no gradient stores: 39 of its 49 us remain), so the per-element work
-  // is kept to the minimum: per row three scalars k1 = c n^2/den, k2 = c t/den (both times drop_scale * sg) and
-  // k3 = c/(n+eps); per element g*sg = k1*Ah - k2*x (masked), dAh += k3*x, db*sg += g*sg.  sg is a power of two,
-  // so carrying it through the sums and dividing at the end changes no bit.
+  // ---- phase 4: backward of this wave's rows from registers; one coalesced 512-B store per chunk.  Per row three
+  // scalars k1 = c n^2/den, k2 = c t/den (both times drop_scale * sg) and k3 = c/(n+eps); per element
+  // g*sg = k1*Ah - k2*x (masked), dAh += k3*x, db*sg += g*sg.  sg is a power of two, so carrying it through the sums
+  // and dividing at the end changes no bit.
   float4 pa[DV], pb[DV];
 #pragma unroll
   for (int v = 0; v < DV; ++v) { pa[v] = make_float4(0.f, 0.f, 0.f, 0.f); pb[v] = pa[v]; }
 #pragma unroll
   for (int k = 0; k < RPW; ++k) {
-    const int qi = wave + 4 * k;
+    const int qi = wave + NW * k;
     if (qi > Nn) continue;                         // wave-uniform
     const int ch = qi == 0 ? 0 : C + qi - 1;
     const float c = cq[ch], s = n2[ch], t = tq[ch];
@@ -391,20 +410,25 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss_reg(ScoreArgs a) {
 
   // ---- phase 5: backward of the context normalisation and mean (context rows still in registers)
   float dot = 0.f;
-  float u[DV];
+  float u[CV];
 #pragma unroll
-  for (int v = 0; v < DV; ++v) {
-    const int d = tid + v * 256;
-    u[v] = acc0[d] + acc0[D + d] + acc0[2 * D + d] + acc0[3 * D + d];
-    dot += A[d] * u[v];
+  for (int v = 0; v < CV; ++v) {
+    const int d = tid + v * THREADS;
+    float us = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) us += acc0[w * D + d];
+    u[v] = us;
+    dot += A[d] * us;
   }
-  dot = block_sum(dot, red);
+  dot = block_sum_w<NW>(dot, red);
   const float inv_denA = 1.f / (sA * sqrtf(sA) + eps);
 #pragma unroll
-  for (int v = 0; v < DV; ++v) {
-    const int d = tid + v * 256;
+  for (int v = 0; v < CV; ++v) {
+    const int d = tid + v * THREADS;
     const float dA = (sA * u[v] - A[d] * dot) * inv_denA;
-    float dbv = acc1[d] + acc1[D + d] + acc1[2 * D + d] + acc1[3 * D + d];
+    float dbv = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) dbv += acc1[w * D + d];
 #pragma unroll
     for (int j = 0; j < CXM; ++j) {
       if (j + 1 < C) {
@@ -419,13 +443,281 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss_reg(ScoreArgs a) {
 }
 #undef HROW
 
+static int g_score_waves = 8;
+void set_score_waves(int v) { g_score_waves = v == 4 ? 4 : 8; }
+
 template <typename T>
 static bool launch_score_loss_reg(const ScoreArgs& a, hipStream_t s) {
-  // fast path: D == 512, at most 52 target/negative rows (13 per wave) and at most 6 context rows
-  if (a.D != 512 || 1 + a.Nn > 52 || a.C - 1 > 6) return false;
-  const size_t lds = sizeof(float) * ((size_t)10 * a.D + 4 * (a.C + a.Nn) + 12);
-  VV_LAUNCH((k_score_loss_reg<T, 13, 2>), dim3(a.B), dim3(SL_THREADS), lds, s, a);
+  // fast path: D == 512, at most 6 context rows, at most 56 target/negative rows (52 with four waves)
+  if (a.D != 512 || a.C - 1 > 6) return false;
+  const int rows = 1 + a.Nn;
+  const int nw = g_score_waves;
+  const size_t lds = sizeof(float) * ((size_t)(2 + 2 * nw) * a.D + 4 * (a.C + a.Nn) + 3 * nw);
+#define VV_SLR(NW, RPW)                                                                                   \
+  do {                                                                                                    \
+    (void)hipFuncSetAttribute((const void*)k_score_loss_reg<T, NW, RPW, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    VV_LAUNCH((k_score_loss_reg<T, NW, RPW, 2>), dim3(a.B), dim3(64 * NW), lds, s, a);                    \
+  } while (0)
+  if (nw == 4) { if (rows > 52) return false; VV_SLR(4, 13); return true; }
+  if (rows <= 16) VV_SLR(8, 2);
+  else if (rows <= 32) VV_SLR(8, 4);
+  else if (rows <= 56) VV_SLR(8, 7);
+  else return false;
+#undef VV_SLR
   return true;
+}
+
+// ---- segment-wise backward, pass 1: k_score_loss_reg without the per-instance gradient rows.  Forward as there; the
+// backward stops at the factored form (vv_internal.h: SegRec): one record per instance, Ah_b and dA_b per item.
+template <int NW, int RPW, int DV>
+__global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int THREADS = 64 * NW;
+  constexpr int CV = 256 * DV / THREADS;
+  static_assert(CV >= 1 && CV * THREADS == 256 * DV, "D must be a multiple of the thread count");
+  constexpr int CXM = 6;
+  const int D = a.D, C = a.C, Nn = a.Nn, CN = C + Nn;
+  float* A = sm;               // [D]
+  float* Ah = A + D;           // [D]
+  float* acc0 = Ah + D;        // [NW][D] per-wave partial dAh
+  float* n2 = acc0 + NW * D;   // [CN]
+  float* tq = n2 + CN;         // [CN]
+  float* cq = tq + CN;         // [CN]
+  float* red = cq + CN;        // [3 NW]
+  int* ooff = (int*)(red + 3 * NW);   // [CN] grouped position of channel ch's instance
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float eps = 1e-10f;
+
+  float4 x[RPW][DV];
+#pragma unroll
+  for (int k = 0; k < RPW; ++k) {
+    const int qi = wave + NW * k;
+    const int ch = qi == 0 ? 0 : C + qi - 1;
+    const int r = b * CN + (qi <= Nn ? ch : 0);
+    const int hr = a.map[r];
+#pragma unroll
+    for (int v = 0; v < DV; ++v)
+      x[k][v] = qi <= Nn ? *(const float4*)(a.H + (int64_t)hr * D + lane * 4 + v * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float cx[CXM][CV];
+#pragma unroll
+  for (int j = 0; j < CXM; ++j) {
+    const int r = b * CN + (j + 1 < C ? j + 1 : 0);
+    const int hr = a.map[r];
+#pragma unroll
+    for (int v = 0; v < CV; ++v) cx[j][v] = j + 1 < C ? a.H[(int64_t)hr * D + tid + v * THREADS] : 0.f;
+  }
+  float cf[CXM];
+#pragma unroll
+  for (int j = 0; j < CXM; ++j) cf[j] = j + 1 < C ? a.coeff[j] : 0.f;
+  for (int ch = tid; ch < CN; ch += THREADS) {
+    const int r = b * CN + ch;
+    ooff[ch] = a.seg_start[a.map[r]] + a.ord[r];
+  }
+
+  // ---- context mean and its norm
+  float ssq = 0.f;
+#pragma unroll
+  for (int v = 0; v < CV; ++v) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < CXM; ++j) s += cf[j] * cx[j][v];
+    A[tid + v * THREADS] = s;
+    ssq += s * s;
+  }
+  const float sA = block_sum_w<NW>(ssq, red);
+  const float nA = sqrtf(sA) + eps;
+  float* Vb = a.V + (int64_t)2 * b * D;
+#pragma unroll
+  for (int v = 0; v < CV; ++v) {
+    const float ah = A[tid + v * THREADS] / nA;
+    Ah[tid + v * THREADS] = ah;
+    Vb[tid + v * THREADS] = ah;
+  }
+  __syncthreads();
+
+  // ---- norms and dots from registers
+  float4 y[DV];
+#pragma unroll
+  for (int v = 0; v < DV; ++v) y[v] = *(const float4*)(Ah + lane * 4 + v * 256);
+#pragma unroll
+  for (int k = 0; k < RPW; ++k) {
+    const int qi = wave + NW * k;
+    float s = 0.f, t = 0.f;
+#pragma unroll
+    for (int v = 0; v < DV; ++v) {
+      const float4 xx = x[k][v];
+      s += xx.x * xx.x + xx.y * xx.y + xx.z * xx.z + xx.w * xx.w;
+      t += xx.x * y[v].x + xx.y * y[v].y + xx.z * y[v].z + xx.w * y[v].w;
+    }
+    s = wave_sum63(s); t = wave_sum63(t);
+    if (lane == 63 && qi <= Nn) { const int ch = qi == 0 ? 0 : C + qi - 1; n2[ch] = s; tq[ch] = t; }
+  }
+  __syncthreads();
+
+  // ---- scores, hinge, loss, coefficients
+  const float sp = tq[0] / (sqrtf(n2[0]) + eps);
+  const float wb = a.item_w ? a.item_w[b] : 1.f;
+  float lsum = 0.f, vsum = 0.f, gsum = 0.f;
+  for (int k = tid; k < Nn; k += THREADS) {
+    const int ch = C + k;
+    const float sn = tq[ch] / (sqrtf(n2[ch]) + eps);
+    const float d = sp - sn;
+    const float h = fmaxf(0.f, a.margin - d);
+    float g;
+    if (a.norm == 2) { lsum += wb * h * h; g = 2.f * wb * h * a.grad_scale; }
+    else { lsum += wb * fabsf(h); g = h > 0.f ? wb * a.grad_scale : 0.f; }
+    vsum += d < 0.f ? 1.f : 0.f;
+    gsum += g;
+    cq[ch] = g;
+    if (a.s_bogus) a.s_bogus[(int64_t)b * Nn + k] = sn;
+  }
+  block_sum3_w<NW>(lsum, vsum, gsum, red);
+  if (tid == 0) {
+    cq[0] = -gsum;
+    a.loss_part[b] = lsum;
+    a.viol_part[b] = vsum;
+    if (a.s_true) a.s_true[b] = sp;
+  }
+  __syncthreads();
+
+  // ---- dAh = sum_q k3_q x_q from registers; the record of every target / negative instance
+  float4 pa[DV];
+#pragma unroll
+  for (int v = 0; v < DV; ++v) pa[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < RPW; ++k) {
+    const int qi = wave + NW * k;
+    if (qi > Nn) continue;                         // wave-uniform
+    const int ch = qi == 0 ? 0 : C + qi - 1;
+    const float c = cq[ch], s = n2[ch], t = tq[ch];
+    const float rs = sqrtf(s);
+    const float k3 = c * __builtin_amdgcn_rcpf(rs + eps);
+    const float cd = c * __builtin_amdgcn_rcpf(s * rs + eps) * a.drop_scale * a.sg;
+    if (lane == 0) { SegRec rc; rc.alpha = cd * s; rc.beta = cd * t; rc.vec = 2 * b; rc.pad = 0; a.rec[ooff[ch]] = rc; }
+#pragma unroll
+    for (int v = 0; v < DV; ++v) {
+      pa[v].x += k3 * x[k][v].x; pa[v].y += k3 * x[k][v].y; pa[v].z += k3 * x[k][v].z; pa[v].w += k3 * x[k][v].w;
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < DV; ++v) *(float4*)(acc0 + wave * D + lane * 4 + v * 256) = pa[v];
+  if (tid < C - 1) {
+    SegRec rc; rc.alpha = a.coeff[tid] * a.drop_scale * a.sg; rc.beta = 0.f; rc.vec = 2 * b + 1; rc.pad = 0;
+    a.rec[ooff[tid + 1]] = rc;
+  }
+  __syncthreads();
+
+  // ---- backward of the context normalisation: dA_b
+  float dot = 0.f;
+  float u[CV];
+#pragma unroll
+  for (int v = 0; v < CV; ++v) {
+    const int d = tid + v * THREADS;
+    float us = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) us += acc0[w * D + d];
+    u[v] = us;
+    dot += A[d] * us;
+  }
+  dot = block_sum_w<NW>(dot, red);
+  const float inv_denA = 1.f / (sA * sqrtf(sA) + eps);
+#pragma unroll
+  for (int v = 0; v < CV; ++v) {
+    const int d = tid + v * THREADS;
+    Vb[D + d] = (sA * u[v] - A[d] * dot) * inv_denA;
+  }
+}
+
+bool score_fwd_supported(const ScoreArgs& a) { return a.D == 512 && a.C - 1 <= 6 && 1 + a.Nn <= 56; }
+
+void launch_score_fwd(const ScoreArgs& a, hipStream_t s) {
+  const int rows = 1 + a.Nn;
+  const size_t lds = sizeof(float) * ((size_t)(2 + 8) * a.D + 4 * (a.C + a.Nn) + 3 * 8);
+#define VV_SF(RPW)                                                                                        \
+  do {                                                                                                    \
+    (void)hipFuncSetAttribute((const void*)k_score_fwd<8, RPW, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    VV_LAUNCH((k_score_fwd<8, RPW, 2>), dim3(a.B), dim3(512), lds, s, a);                                  \
+  } while (0)
+  if (rows <= 16) VV_SF(2);
+  else if (rows <= 32) VV_SF(4);
+  else VV_SF(7);
+#undef VV_SF
+}
+
+// ---- segment-wise backward, pass 2: one wave per distinct row, a lane owns 8 consecutive columns (D = 512).
+// Persistent grid: wave w of block g takes rows 4 g + w, + 4 SEGB_BLOCKS, ...; the column sums of the rows it produced
+// (the bias gradient) leave as one partial row per block.
+template <typename T>
+__global__ __launch_bounds__(256) void k_seg_bwd(SegBwdArgs a) {
+  __shared__ float cs[4][512];
+  const int U = a.info[0];
+  const int Uk = min((U + BK - 1) / BK * BK, a.Rp);   // the wgrad K loop reads whole BK-row steps
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = lane * 8, D = a.D;
+  float col[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) col[j] = 0.f;
+  int saturated = 0;
+  for (int u = blockIdx.x * 4 + wave; u < Uk; u += 4 * SEGB_BLOCKS) {
+    uint32_t o[4] = {0u, 0u, 0u, 0u};
+    if (u < U) {
+      const int b = a.seg_start[u], e = a.seg_start[u + 1];
+      const float4 x0 = *(const float4*)(a.H + (int64_t)u * D + c0), x1 = *(const float4*)(a.H + (int64_t)u * D + c0 + 4);
+      float acc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+      float bs = 0.f;
+      int i = b;
+      for (; i + 3 < e; i += 4) {                     // four instances in flight
+        SegRec r[4]; float4 v0[4], v1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = a.rec[i + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float* vp = a.V + (int64_t)r[k].vec * D + c0;
+          v0[k] = *(const float4*)vp; v1[k] = *(const float4*)(vp + 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float al = r[k].alpha;
+          acc[0] += al * v0[k].x; acc[1] += al * v0[k].y; acc[2] += al * v0[k].z; acc[3] += al * v0[k].w;
+          acc[4] += al * v1[k].x; acc[5] += al * v1[k].y; acc[6] += al * v1[k].z; acc[7] += al * v1[k].w;
+          bs += r[k].beta;
+        }
+      }
+      for (; i < e; ++i) {
+        const SegRec r = a.rec[i];
+        const float* vp = a.V + (int64_t)r.vec * D + c0;
+        const float4 v0 = *(const float4*)vp, v1 = *(const float4*)(vp + 4);
+        acc[0] += r.alpha * v0.x; acc[1] += r.alpha * v0.y; acc[2] += r.alpha * v0.z; acc[3] += r.alpha * v0.w;
+        acc[4] += r.alpha * v1.x; acc[5] += r.alpha * v1.y; acc[6] += r.alpha * v1.z; acc[7] += r.alpha * v1.w;
+        bs += r.beta;
+      }
+      const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+      float g[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        g[j] = xv[j] > 0.f ? acc[j] - bs * xv[j] : 0.f;
+        col[j] += g[j];
+        if (T::id == 0) saturated |= fabsf(g[j]) > 65504.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = T::from_float(g[2 * j]) | ((uint32_t)T::from_float(g[2 * j + 1]) << 16);
+    }
+    *(uint4*)(a.dYu + (int64_t)u * a.Dp + c0) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cs[wave][c0 + j] = col[j];
+  __syncthreads();
+  for (int d = threadIdx.x; d < 512; d += 256)
+    a.dbp[(int64_t)blockIdx.x * D + d] = (cs[0][d] + cs[1][d] + cs[2][d] + cs[3][d]) * a.inv_sg;
+  if (T::id == 0 && saturated && a.overflow_host) __hip_atomic_fetch_add(a.overflow_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+void launch_seg_bwd(int prec, const SegBwdArgs& a, hipStream_t s) {
+  if (prec == 0) VV_LAUNCH(k_seg_bwd<F16>, dim3(SEGB_BLOCKS), dim3(256), 0, s, a);
+  else VV_LAUNCH(k_seg_bwd<BF16>, dim3(SEGB_BLOCKS), dim3(256), 0, s, a);
 }
 
 static int g_score_reg = 1;
@@ -475,15 +767,16 @@ __device__ __forceinline__ void reduce_db(const ReduceArgs& a, int blk) {
   float s = 0.f;
   if (d < a.D) {
     const float* p = a.dbp + d;
+    const int nb = a.db_rows > 0 ? a.db_rows : a.B;
     int b = ty;
-    for (; b + 112 < a.B; b += 128) {
+    for (; b + 112 < nb; b += 128) {
       float v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(b + 16 * u) * a.D];
 #pragma unroll
       for (int u = 0; u < 8; ++u) s += v[u];
     }
-    for (; b < a.B; b += 16) s += p[(int64_t)b * a.D];
+    for (; b < nb; b += 16) s += p[(int64_t)b * a.D];
   }
   part[ty][tx] = s;
   __syncthreads();

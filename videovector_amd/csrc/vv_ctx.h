@@ -73,6 +73,11 @@ struct vv_ctx {
   int32_t *dd_slot_of = nullptr, *dd_uniq = nullptr, *dd_map = nullptr, *dd_ord = nullptr, *dd_cnt = nullptr,
           *dd_seg = nullptr, *dd_pos = nullptr, *dd_info = nullptr;
   uint16_t* dYu = nullptr;
+  // segment-wise backward (vv_internal.h: SegRec)
+  float* segV = nullptr; vv::SegRec* seg_rec = nullptr; float* seg_dbp = nullptr;
+  bool seg_bwd = true;             // env VV_SEG_BWD=0: the per-instance gradient rows + k_segsum instead
+  bool last_seg_bwd = false;
+  vv::ScoreArgs last_score;            // to rebuild the per-instance gradient rows for vv_blobs_get(ip1_diff)
   int32_t* U_host = nullptr;        // pinned + mapped: k_dd_leaders stores U here every step, the launcher reads it late
   int32_t* U_host_dev = nullptr;    // device alias of U_host
   uint32_t dd_epoch = 0;

@@ -59,6 +59,16 @@ struct FwdArgs {
   int abl = 0;                 // timing studies only (VV_ABLATE): selects an ablated instantiation of the phase-staggered kernel
 };
 
+// Segment-wise backward (de-duplicated batches): the score kernel keeps the gradient of an instance in factored form
+// -- dY[r] = [x_u > 0] (alpha_r V[vec_r] - beta_r x_u), where V holds the item's normalised context mean Ah_b (row 2b:
+// target / negative instances, alpha = c n^2/den, beta = c t/den) and the gradient of its context mean dA_b (row 2b+1:
+// context instances, alpha = c_j, beta = 0) -- and writes one 16-byte record per instance at its grouped position.
+// k_seg_bwd then produces, per distinct row u, dYu[u] = [x_u > 0] (sum_r alpha_r V[vec_r] - (sum_r beta_r) x_u) from
+// the records of its instances: the per-instance 16-bit gradient rows ((C+Nn) B D values written and read back) are
+// never materialised.
+struct SegRec { float alpha, beta; int32_t vec; int32_t pad; };
+constexpr int SEGB_BLOCKS = 1024;     // persistent grid of k_seg_bwd = rows of its bias partials
+
 struct ScoreArgs {
   const float* H;          // [R][D] item-major rows (b*CN + ch)
   uint16_t* dYh;           // [Rp][Dp] scaled half gradient of ip1_nonorm
@@ -79,6 +89,9 @@ struct ScoreArgs {
   const int32_t* map = nullptr;      // [R]
   const int32_t* seg_start = nullptr;  // [U + 1]   pos[r] = seg_start[map[r]] + ord[r]
   const int32_t* ord = nullptr;      // [R]
+  // segment-wise backward (launch_score_fwd): outputs instead of dYh / dbp
+  float* V = nullptr;                // [2B][D]
+  SegRec* rec = nullptr;             // [R]
 };
 
 // Row de-duplication of one batch (kernels_dedup.hip).  The sampler draws the negatives of every item
@@ -102,6 +115,19 @@ struct DedupArgs {
   int32_t* tickets;              // device [2]: arrival counters of the two single-pass scans
   int32_t* u_host;               // host-mapped copy of U (read one or more steps late by the launcher)
   int R, Rp; int32_t zero_row; int32_t row_limit; uint32_t epoch;
+};
+
+struct SegBwdArgs {
+  const float* H;                // [U][D] projection of the distinct rows (x_u)
+  const float* V;                // [2B][D]
+  const SegRec* rec;             // [R] grouped by slot: records of slot u are rec[seg_start[u] .. seg_start[u+1])
+  const int32_t* seg_start;      // [U + 1]
+  const int32_t* info;           // {U}
+  uint16_t* dYu;                 // [Rp][Dp] (zero rows up to the next multiple of BK)
+  float* dbp;                    // [SEGB_BLOCKS][D] column sums of the unrounded rows, unscaled
+  int Rp, D, Dp;
+  float inv_sg;
+  int32_t* overflow_host = nullptr;
 };
 
 struct SegsumArgs {
@@ -131,6 +157,7 @@ struct WgradArgs {
 struct ReduceArgs {
   const float* slabs; int S, Dp, Fp;
   const float* dbp; int B;
+  int db_rows = 0;         // rows of dbp (0 = B, one per item; the segment-wise backward writes SEGB_BLOCKS partials)
   const Scales* scales;
   float sg;
   float* grads;            // [D*F + D]
@@ -182,6 +209,9 @@ void launch_dedup(const DedupArgs& a, hipStream_t s);
 void launch_dedup_groups(const DedupArgs& a, hipStream_t s);
 void launch_dedup_pos(const DedupArgs& a, hipStream_t s);   // pos[] for the debug accessors only
 void launch_segsum(int prec, const SegsumArgs& a, hipStream_t s);
+bool score_fwd_supported(const ScoreArgs& a);               // shapes the segment-wise pair is built for
+void launch_score_fwd(const ScoreArgs& a, hipStream_t s);   // forward + factored backward records (dedup mode)
+void launch_seg_bwd(int prec, const SegBwdArgs& a, hipStream_t s);
 void launch_gather_rows_f32(const float* src, const int32_t* map, int R, int D, float* dst, hipStream_t s);
 void launch_gather_rows_u16(const uint16_t* src, const int32_t* pos, int R, int Dp, uint16_t* dst, hipStream_t s);
 void launch_reduce(const ReduceArgs& a, hipStream_t s);
