@@ -43,10 +43,19 @@ def test_random_shapes_dedup_dense_oracle(vv, oracle, seed):
         outs[mode] = (eng.loss(), bl, dW.copy(), db.copy(), eng.dedup_stats())
     (l0, b0, dW0, db0, _), (l1, b1, dW1, db1, st) = outs[False], outs[True]
     assert st == (B * (C + Nn), len(np.unique(np.where(idx < 0, -1, idx))))
-    assert l0 == l1
-    for k in ("ip2", "target_score", "negative_scores", "ip1_diff"):
-        assert np.array_equal(b0[k], b1[k]), (k, B, C, Nn, F, D)
-    assert np.array_equal(db0, db1)
+    if D == 512 and C - 1 <= 6 and 1 + Nn <= 56:
+        # the shape of the segment-wise backward (tests/test_gpu_segbwd.py): another kernel computes the scores (last-bit
+        # differences) and the bias gradient is summed per distinct row instead of per item
+        assert abs(l0[0] - l1[0]) <= 1e-6 * abs(l0[0]) and l0[1] == l1[1]
+        assert np.array_equal(b0["ip2"], b1["ip2"])
+        for k in ("target_score", "negative_scores"):
+            assert np.abs(b0[k] - b1[k]).max() <= 2.5e-7, (k, B, C, Nn, F, D)
+        assert rel_fro(b1["ip1_diff"], b0["ip1_diff"]) <= 1e-6 and rel_fro(db1, db0) <= 1e-5
+    else:
+        assert l0 == l1
+        for k in ("ip2", "target_score", "negative_scores", "ip1_diff"):
+            assert np.array_equal(b0[k], b1[k]), (k, B, C, Nn, F, D)
+        assert np.array_equal(db0, db1)
     scale = max(np.abs(dW0).max(), 1e-30)
     assert np.abs(dW1 - dW0).max() <= 2e-3 * scale, (B, C, Nn, F, D)
     if seed % 3 == 0:

@@ -117,3 +117,19 @@ def test_segment_wise_backward_sgd_trajectory(vv):
     assert all(abs(x - y) <= 1e-4 * y for x, y in zip(res[0][0], res[1][0]))
     print("SEGBWD trajectory step diff %.3e" % rel_fro(res[1][1] - W0, res[0][1] - W0))
     assert rel_fro(res[1][1] - W0, res[0][1] - W0) <= 1e-2      # free-running: the two roundings of dYu drift apart slowly
+
+
+def test_segment_wise_backward_is_bit_reproducible(vv):
+    """The records of a distinct row arrive in a different order in every run (an atomic counter hands out the
+    positions); the sums must not depend on it: segments up to 64 instances are summed in instance order, longer ones
+    with order-independent (exact) sums."""
+    B, C, Nn, F = 128, 5, 50, 256
+    ds, table, idx, W, b = make_case(11, 8, B, C, Nn, F, D, wstd=0.02)      # ~300 rows: segments of ~20 instances
+    idx[:, C + 7] = 5                                                       # one row 128+ times: a long segment
+    idx[:40, C + 9] = 6                                                     # and one of 40+
+    outs = [run(vv, "f16", table, idx, W, b, C, Nn, seg=True) for _ in range(4)]
+    for o in outs[1:]:
+        assert np.array_equal(o["dW"], outs[0]["dW"]) and np.array_equal(o["db"], outs[0]["db"])
+        assert o["loss"] == outs[0]["loss"]
+    d = run(vv, "f16", table, idx, W, b, C, Nn, seg=True, dedup=False)
+    assert rel_fro(outs[0]["dW"], d["dW"]) <= 5e-4 and rel_fro(outs[0]["db"], d["db"]) <= 1e-5

@@ -594,7 +594,7 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
     const float rs = sqrtf(s);
     const float k3 = c * __builtin_amdgcn_rcpf(rs + eps);
     const float cd = c * __builtin_amdgcn_rcpf(s * rs + eps) * a.drop_scale * a.sg;
-    if (lane == 0) { SegRec rc; rc.alpha = cd * s; rc.beta = cd * t; rc.vec = 2 * b; rc.pad = 0; a.rec[ooff[ch]] = rc; }
+    if (lane == 0) { SegRec rc; rc.alpha = cd * s; rc.beta = cd * t; rc.vec = 2 * b; rc.pad = b * CN + ch; a.rec[ooff[ch]] = rc; }
 #pragma unroll
     for (int v = 0; v < DV; ++v) {
       pa[v].x += k3 * x[k][v].x; pa[v].y += k3 * x[k][v].y; pa[v].z += k3 * x[k][v].z; pa[v].w += k3 * x[k][v].w;
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
 #pragma unroll
   for (int v = 0; v < DV; ++v) *(float4*)(acc0 + wave * D + lane * 4 + v * 256) = pa[v];
   if (tid < C - 1) {
-    SegRec rc; rc.alpha = a.coeff[tid] * a.drop_scale * a.sg; rc.beta = 0.f; rc.vec = 2 * b + 1; rc.pad = 0;
+    SegRec rc; rc.alpha = a.coeff[tid] * a.drop_scale * a.sg; rc.beta = 0.f; rc.vec = 2 * b + 1; rc.pad = b * CN + tid + 1;
     a.rec[ooff[tid + 1]] = rc;
   }
   __syncthreads();
@@ -648,9 +648,16 @@ void launch_score_fwd(const ScoreArgs& a, hipStream_t s) {
 // ---- segment-wise backward, pass 2: one wave per distinct row, a lane owns 8 consecutive columns (D = 512).
 // Persistent grid: wave w of block g takes rows 4 g + w, + 4 SEGB_BLOCKS, ...; the column sums of the rows it produced
 // (the bias gradient) leave as one partial row per block.
+// The records of a row sit in ARRIVAL order (k_dd_map's atomic counter), which differs from run to run; the sums must
+// not.  A segment of up to 64 records is put in instance order first (each lane holds one record, counts the smaller
+// instance indices, and files its record at that rank in a wave-private LDS strip); longer segments -- a row repeated
+// more than 64 times in one batch -- are summed in an order-independent way instead: every product is rounded to a
+// multiple of 2^-36 in f64 ((p + M) - M, M = 1.5 * 2^16; exact for |p| < 2^15 in the gradient's scaled units), and
+// sums of such multiples are exact in f64 up to 2^17, whatever the order.
 template <typename T>
 __global__ __launch_bounds__(256) void k_seg_bwd(SegBwdArgs a) {
   __shared__ float cs[4][512];
+  __shared__ SegRec strip[4][64];
   const int U = a.info[0];
   const int Uk = min((U + BK - 1) / BK * BK, a.Rp);   // the wgrad K loop reads whole BK-row steps
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -662,37 +669,68 @@ __global__ __launch_bounds__(256) void k_seg_bwd(SegBwdArgs a) {
   for (int u = blockIdx.x * 4 + wave; u < Uk; u += 4 * SEGB_BLOCKS) {
     uint32_t o[4] = {0u, 0u, 0u, 0u};
     if (u < U) {
-      const int b = a.seg_start[u], e = a.seg_start[u + 1];
+      const int b = a.seg_start[u], e = a.seg_start[u + 1], n = e - b;
       const float4 x0 = *(const float4*)(a.H + (int64_t)u * D + c0), x1 = *(const float4*)(a.H + (int64_t)u * D + c0 + 4);
       float acc[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = 0.f;
       float bs = 0.f;
-      int i = b;
-      for (; i + 3 < e; i += 4) {                     // four instances in flight
-        SegRec r[4]; float4 v0[4], v1[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) r[k] = a.rec[i + k];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float* vp = a.V + (int64_t)r[k].vec * D + c0;
-          v0[k] = *(const float4*)vp; v1[k] = *(const float4*)(vp + 4);
+      if (n <= 64) {
+        const SegRec* rs = a.rec + b;
+        if (n > 1) {                                  // instance order
+          SegRec mine; mine.alpha = 0.f; mine.beta = 0.f; mine.vec = 0; mine.pad = 0x7fffffff;
+          if (lane < n) mine = a.rec[b + lane];
+          int rank = 0;
+          for (int j = 0; j < n; ++j) rank += __builtin_amdgcn_readlane(mine.pad, j) < mine.pad;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the previous row's reads of the strip are done
+          if (lane < n) strip[wave][rank] = mine;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          rs = strip[wave];
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float al = r[k].alpha;
-          acc[0] += al * v0[k].x; acc[1] += al * v0[k].y; acc[2] += al * v0[k].z; acc[3] += al * v0[k].w;
-          acc[4] += al * v1[k].x; acc[5] += al * v1[k].y; acc[6] += al * v1[k].z; acc[7] += al * v1[k].w;
-          bs += r[k].beta;
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        int i = 0;
+        for (; i + 3 < n; i += 4) {                   // four instances in flight
+          SegRec r[4]; float4 v0[4], v1[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) r[k] = rs[i + k];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float* vp = a.V + (int64_t)r[k].vec * D + c0;
+            v0[k] = *(const float4*)vp; v1[k] = *(const float4*)(vp + 4);
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float al = r[k].alpha;
+            acc[0] += al * v0[k].x; acc[1] += al * v0[k].y; acc[2] += al * v0[k].z; acc[3] += al * v0[k].w;
+            acc[4] += al * v1[k].x; acc[5] += al * v1[k].y; acc[6] += al * v1[k].z; acc[7] += al * v1[k].w;
+            bs += r[k].beta;
+          }
         }
-      }
-      for (; i < e; ++i) {
-        const SegRec r = a.rec[i];
-        const float* vp = a.V + (int64_t)r.vec * D + c0;
-        const float4 v0 = *(const float4*)vp, v1 = *(const float4*)(vp + 4);
-        acc[0] += r.alpha * v0.x; acc[1] += r.alpha * v0.y; acc[2] += r.alpha * v0.z; acc[3] += r.alpha * v0.w;
-        acc[4] += r.alpha * v1.x; acc[5] += r.alpha * v1.y; acc[6] += r.alpha * v1.z; acc[7] += r.alpha * v1.w;
-        bs += r.beta;
+        for (; i < n; ++i) {
+          const SegRec r = rs[i];
+          const float* vp = a.V + (int64_t)r.vec * D + c0;
+          const float4 v0 = *(const float4*)vp, v1 = *(const float4*)(vp + 4);
+          acc[0] += r.alpha * v0.x; acc[1] += r.alpha * v0.y; acc[2] += r.alpha * v0.z; acc[3] += r.alpha * v0.w;
+          acc[4] += r.alpha * v1.x; acc[5] += r.alpha * v1.y; acc[6] += r.alpha * v1.z; acc[7] += r.alpha * v1.w;
+          bs += r.beta;
+        }
+      } else {                                        // order-independent sums
+        const double M = 98304.0;
+        double dacc[8], dbs = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dacc[j] = 0.0;
+        for (int i = b; i < e; ++i) {
+          const SegRec r = a.rec[i];
+          const float* vp = a.V + (int64_t)r.vec * D + c0;
+          const float4 v0 = *(const float4*)vp, v1 = *(const float4*)(vp + 4);
+          const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+          const double al = (double)r.alpha;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dacc[j] += (al * (double)vv[j] + M) - M;
+          dbs += ((double)r.beta + M) - M;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = (float)dacc[j];
+        bs = (float)dbs;
       }
       const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
       float g[8];

@@ -66,7 +66,7 @@ struct FwdArgs {
 // k_seg_bwd then produces, per distinct row u, dYu[u] = [x_u > 0] (sum_r alpha_r V[vec_r] - (sum_r beta_r) x_u) from
 // the records of its instances: the per-instance 16-bit gradient rows ((C+Nn) B D values written and read back) are
 // never materialised.
-struct SegRec { float alpha, beta; int32_t vec; int32_t pad; };
+struct SegRec { float alpha, beta; int32_t vec; int32_t pad; };   // pad: the instance index b (C+Nn) + ch (sets the summation order)
 constexpr int SEGB_BLOCKS = 1024;     // persistent grid of k_seg_bwd = rows of its bias partials
 
 struct ScoreArgs {
