@@ -541,7 +541,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
     // row goes through the GEMMs separately -- the dense path has no multiplicity factor
     c->dedup = 0; c->dedup_overflowed = true;
   }
-  const bool dd = c->dedup && cfg->dropout_ratio == 0.f && (gemm_variant() == 0 || gemm_variant() == 3 || gemm_variant() == 4 || (gemm_variant() >= 5 && gemm_variant() <= 7)) && !ablate_on();
+  const bool dd = c->dedup && cfg->dropout_ratio == 0.f && (gemm_variant() == 0 || gemm_variant() == 3 || gemm_variant() == 4 || (gemm_variant() >= 5 && gemm_variant() <= 8)) && !ablate_on();
   c->last_dedup = dd;
   if (!dd) launch_map_rows(didx, c->rows, c->R, c->Rp, (int32_t)c->n_rows, (int32_t)row_limit, s);
   if (dd) {
@@ -636,7 +636,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   // the last block.  Needs the phase-staggered weight-gradient kernel (it can run a subset of the M tiles).
   const int tilesM = c->Dp / BM;
   const bool chunked = c->comm && c->comm_overlap && tilesM > 1 &&
-                       (gemm_variant() == 5 || gemm_variant() == 6) && !ablate_on();
+                       (gemm_variant() == 5 || gemm_variant() == 6 || gemm_variant() == 8) && !ablate_on();
   if (!chunked) {
     PROFILED(c, "wgrad_gemm", launch_wgrad_gemm(c->prec, wa, s));
     PROFILED(c, "reduce", launch_reduce(ra, s));

@@ -721,7 +721,7 @@ static void launch_fwd_p(const FwdArgs& a, hipStream_t s) {
 
 void launch_fwd_gemm_ph(int prec, const FwdArgs& a, hipStream_t s);
 void launch_fwd_gemm(int prec, const FwdArgs& a, hipStream_t s) {
-  if (g_gemm_variant == 5 || g_gemm_variant == 7) { FwdArgs b = a; b.abl = g_ablate; launch_fwd_gemm_ph(prec, b, s); return; }   // 5: both new, 6: new wgrad only, 7: new fwd only
+  if (g_gemm_variant == 5 || g_gemm_variant == 7 || g_gemm_variant == 8) { FwdArgs b = a; b.abl = g_ablate; launch_fwd_gemm_ph(prec, b, s); return; }   // 5: both new, 6: new wgrad only, 7: new fwd only
   if (prec == 0) launch_fwd_p<F16>(a, s); else launch_fwd_p<BF16>(a, s);
 }
 
@@ -744,7 +744,9 @@ static void launch_wgrad_ring_t(const WgradArgs& a, hipStream_t s) {
 }
 
 void launch_wgrad_gemm_ph(int prec, const WgradArgs& a, hipStream_t s);
+void launch_wgrad_gemm_w4(int prec, const WgradArgs& a, hipStream_t s);
 void launch_wgrad_gemm(int prec, const WgradArgs& a, hipStream_t s) {
+  if (g_gemm_variant == 8 && g_wgrad_tr) { launch_wgrad_gemm_w4(prec, a, s); return; }     // 8: phase-staggered forward + four-wave weight gradient
   if ((g_gemm_variant == 5 || g_gemm_variant == 6) && g_wgrad_tr) { WgradArgs b = a; b.abl = g_ablate; launch_wgrad_gemm_ph(prec, b, s); return; }
   if (g_ablate && prec == 0) {
     const dim3 grid((a.Dp / BM) * (a.Fp / BN) * a.S), block(GEMM_THREADS);

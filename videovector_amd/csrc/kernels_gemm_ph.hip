@@ -33,15 +33,24 @@ namespace vv {
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
+// LDS-DMA issue as inline assembly.  Through __builtin_amdgcn_global_load_lds the compiler knows the instruction
+// writes LDS and, unable to tell the ring's slots apart, puts `s_waitcnt vmcnt(0)` in front of every later ds_read: the
+// whole stream was drained once per phase and the counted waits below never had anything left to count (seen in the
+// disassembly of both kernels; the lookahead the schedule is built on did not exist).  As assembly the instruction is
+// opaque: ordering against the fragment reads is exactly what the schedule states -- this wave's counted vmcnt wait,
+// then a workgroup barrier, before any wave reads a slot; a slot restaged only after its readers have passed a barrier
+// with their reads complete.  M0 carries the wave-uniform LDS base (the builtin sets it the same way).
 __device__ __forceinline__ void ph_glds16(const void* gsrc, void* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc), LDS_PTR(lds_wave_base), 16, 0, 0);
+  const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(lds_wave_base));
+  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(m0v), "v"(gsrc) : "m0", "memory");
 }
 // the same with the source 256 bytes further on (the upper 128-column half of a k-major operand): an immediate
 // offset of the instruction instead of a second address register pair.  The hardware adds the instruction offset to
 // the LDS address as well as to the global one (LDS_ADDR = M0 base + inst_offset + lane * size), so the LDS base is
 // handed over 256 bytes low.  Only used for slots >= 2: the adjusted base never falls below the start of the LDS.
 __device__ __forceinline__ void ph_glds16_hi(const void* gsrc, unsigned char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc), LDS_PTR(lds_wave_base - 256), 16, 256, 0);
+  const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(lds_wave_base - 256));
+  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off offset:256" :: "s"(m0v), "v"(gsrc) : "m0", "memory");
 }
 __device__ __forceinline__ int ph_xcd_remap(int bid, int nblk) {
   const int x = bid & 7, q = nblk >> 3, rem = nblk & 7;
@@ -393,6 +402,168 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
           *(float4*)(slab + (int64_t)m * a.Fp + n) = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
+}
+
+// ------------------------------------------------------------------------------- weight gradient, four waves ----
+// k_wgrad_gemm_w4: the same product and the same 256 x 256 tile as k_wgrad_gemm_ph with FOUR waves, one per SIMD, each
+// owning a 128 x 128 quadrant (64 accumulator tiles = 256 registers; the fragments live in the other half of the
+// 512-register file a lone wave may use).  Why: the eight-wave kernel reads 28 operand fragments per wave and K-tile
+// (224 KiB of LDS reads per CU and K-tile) for 64 MFMAs each; its ablation (profiles/r02_ph_gemm_ablation.txt) shows
+// the LDS-DMA writes and the fragment reads serialising on the LDS (staging alone 0.145 ms + reads alone 0.111 ms =
+// 0.237 ms with the MFMAs removed, 0.26 ms with them).  A 128 x 128 wave tile needs 16 fragments per 32-deep step for
+// 64 MFMAs: 128 KiB of reads per K-tile.
+//   * stage = one 32-deep K step: four sub-slots of 8 KiB (X_lo, X_hi, Y_lo, Y_hi: 32 k-rows x 128 columns, the image
+//     of k_wgrad_gemm_ph's half-tiles) in a ring of 4 stages (128 KiB); wave (wx, wy) reads X half wx and Y half wy;
+//   * every wave stages 2 of the 8 1-KiB pieces of each sub-slot; stage s+4 is issued right after the barrier that
+//     opens stage s (its sub-slots are the ones stage s's fragments were read from, now in registers everywhere), so three
+//     stages (96 KiB per CU) are in flight across every barrier; one counted wait (vmcnt(16)) and ONE barrier per stage;
+//   * fragments are double-buffered in registers: the reads of stage s+1 are issued between the MFMAs of stage s.
+template <typename T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_wgrad_gemm_w4(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int SUB = 8192;                              // one sub-slot: 32 k-rows x 128 halves
+  int32_t* ids = (int32_t*)(smem + PH_LDS_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wx = wave & 1, wy = wave >> 1;
+  const int tilesM = a.Dp / BM, tilesN = a.Fp / BN;
+  const int L = ph_xcd_remap(blockIdx.x, gridDim.x);
+  const int tmc = a.tm_count > 0 ? a.tm_count : tilesM;
+  const int tm = a.tm_begin + L % tmc, tn = (L / tmc) % tilesN, sp = L / (tmc * tilesN);
+  const int m0 = tm * BM, n0 = tn * BN;
+  int total_steps = a.Rp / BK, kps = a.ksteps_per_split;
+  if (a.n_dev) {
+    total_steps = (*a.n_dev + BK - 1) / BK;
+    kps = (total_steps + a.S - 1) / a.S;
+  }
+  const int k_begin = sp * kps;
+  int k_end = k_begin + kps;
+  if (k_end > total_steps) k_end = total_steps;
+  const int nk_all = k_end > k_begin ? k_end - k_begin : 0;
+
+  f32x4 acc[8][8];                     // [X tile][Y tile]
+#pragma unroll
+  for (int ni = 0; ni < 8; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // staging: piece p = i*4 + wave (i = 0, 1) of a sub-slot = k-rows 4p .. 4p+3; lane -> (row, 16-byte chunk)
+  const int srow0 = wave * 4 + (lane >> 4), srow1 = srow0 + 16;
+  const int scol0 = ((lane & 15) ^ (ph_h(srow0) << 1)) * 8;
+  const int scol1 = ((lane & 15) ^ (ph_h(srow1) << 1)) * 8;
+  const uint16_t* tb0 = a.table + n0 + scol0;
+  const uint16_t* tb1 = a.table + n0 + scol1;
+  const int g = lane >> 4, li = lane & 15, q4 = li >> 2, pp = li & 3;
+  const int hx = ph_h(8 * g + q4) << 1;
+  const int rd = (8 * g + q4) * 256 + (pp & 1) * 8;
+  int fa[8];                           // fragment tile ti of a sub-slot (both operands share the image)
+#pragma unroll
+  for (int ti = 0; ti < 8; ++ti) fa[ti] = rd + (((ti * 2 + (pp >> 1)) ^ hx) << 4);
+  const unsigned char* xbase = smem + wx * SUB;
+  const unsigned char* ybase = smem + (2 + wy) * SUB;
+
+  for (int c0 = 0; c0 < nk_all; c0 += PH_WG_IDS / BK) {
+    const int nk_c = nk_all - c0 < PH_WG_IDS / BK ? nk_all - c0 : PH_WG_IDS / BK;
+    const int nk = (nk_c + 1) & ~1;                           // even number of K-tiles: the stage count is a multiple of 4
+    const int ns = nk * 2;
+    const int64_t kg0 = (int64_t)(k_begin + c0) * BK;
+    const int live = nk_c * BK;
+    __syncthreads();
+    for (int i = tid; i < nk * BK; i += 256) ids[i] = i < live ? a.rows[kg0 + i] : a.zero_row;
+    __syncthreads();
+    const uint16_t* pa0 = a.dYh + (kg0 + srow0) * a.Dp + m0 + scol0;
+    const uint16_t* pa1 = a.dYh + (kg0 + srow1) * a.Dp + m0 + scol1;
+    const int64_t a_step = (int64_t)32 * a.Dp;
+    // stage st into ring position q: X_lo, X_hi, Y_lo, Y_hi (2 pieces each)
+    auto issue = [&](int st, int q, int id0, int id1) {
+      unsigned char* dst = smem + q * 4 * SUB + wave * 1024;
+      const int64_t r0 = (int64_t)id0 * a.Fp, r1 = (int64_t)id1 * a.Fp;
+      ph_glds16(tb0 + r0, dst);                   ph_glds16(tb1 + r1, dst + 4096);
+      ph_glds16_hi(tb0 + r0, dst + SUB);          ph_glds16_hi(tb1 + r1, dst + SUB + 4096);
+      const uint16_t* y0 = pa0 + st * a_step; const uint16_t* y1 = pa1 + st * a_step;
+      ph_glds16(y0, dst + 2 * SUB);               ph_glds16(y1, dst + 2 * SUB + 4096);
+      ph_glds16_hi(y0, dst + 3 * SUB);            ph_glds16_hi(y1, dst + 3 * SUB + 4096);
+    };
+    // X fragments are single-buffered (tile ni is dead after its eight MFMAs and is reloaded for the next stage right
+    // behind them), Y fragments double-buffered: 32 + 64 registers instead of 128
+    i16x8 xf[8], yf[2][8];
+#define W4_FRAG(dst, base, q, ti)                                                                      \
+    { const unsigned char* p_ = (base) + (q) * 4 * SUB + fa[ti];                                       \
+      const i16x4 lo_ = ph_tr(p_), hi_ = ph_tr(p_ + 1024);                                             \
+      dst = i16x8{lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1], hi_[2], hi_[3]}; }
+#define W4_RELOAD(q, ti) W4_FRAG(xf[ti], xbase, ((q) + 1) & 3, ti) W4_FRAG(yf[((q) + 1) & 1][ti], ybase, ((q) + 1) & 3, ti)
+#define W4_GROUP(q, ni, nxt)                                                                           \
+    if ((ni) > 0 && (nxt)) { W4_RELOAD(q, (ni) > 0 ? (ni) - 1 : 0) }                                   \
+    _Pragma("unroll") for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = T::mfma(xf[ni], yf[(q) & 1][mi], acc[ni][mi]); \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                 \
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                               \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                               \
+    }                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);
+    // stage s (ring position q, Y fragments in buffer q & 1): wait for stage s+1, open with the barrier, restage the
+    // ring position with stage s+4, reload the fragments for stage s+1 between the MFMAs of stage s
+#define W4_STAGE(q, s, WAITN, more)                                                                    \
+    PH_WAIT(WAITN);                                                                                    \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
+    __builtin_amdgcn_s_barrier();                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    if (more) {                                                                                        \
+      issue((s) + 4, q, idn0, idn1);                                                                   \
+      if ((s) + 5 < ns) { idn0 = ids[((s) + 5) * 32 + srow0]; idn1 = ids[((s) + 5) * 32 + srow1]; }    \
+    }                                                                                                  \
+    { const bool nxt_ = (s) + 1 < ns;                                                                  \
+      W4_GROUP(q, 0, nxt_) W4_GROUP(q, 1, nxt_) W4_GROUP(q, 2, nxt_) W4_GROUP(q, 3, nxt_)              \
+      W4_GROUP(q, 4, nxt_) W4_GROUP(q, 5, nxt_) W4_GROUP(q, 6, nxt_) W4_GROUP(q, 7, nxt_)              \
+      if (nxt_) { W4_RELOAD(q, 7) } }                                                                  \
+    __builtin_amdgcn_sched_barrier(0);
+    // prologue: stages 0..3 in flight, stage 0's fragments in buffer 0
+#pragma unroll
+    for (int st = 0; st < 4; ++st) issue(st, st, ids[st * 32 + srow0], ids[st * 32 + srow1]);
+    int idn0 = ns > 4 ? ids[4 * 32 + srow0] : a.zero_row, idn1 = ns > 4 ? ids[4 * 32 + srow1] : a.zero_row;
+    PH_WAIT(24);
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int ti = 0; ti < 8; ++ti) { W4_FRAG(xf[ti], xbase, 0, ti) W4_FRAG(yf[0][ti], ybase, 0, ti) }
+    int s = 0;
+    for (; s + 4 < ns; s += 4) {
+      W4_STAGE(0, s, 16, true)
+      W4_STAGE(1, s + 1, 16, true)
+      W4_STAGE(2, s + 2, 16, true)
+      W4_STAGE(3, s + 3, 16, true)
+    }
+    W4_STAGE(0, s, 16, false)
+    W4_STAGE(1, s + 1, 8, false)
+    W4_STAGE(2, s + 2, 0, false)
+    W4_STAGE(3, s + 3, 0, false)
+#undef W4_FRAG
+#undef W4_RELOAD
+#undef W4_GROUP
+#undef W4_STAGE
+  }
+
+  float* slab = a.slabs + (int64_t)sp * a.Dp * a.Fp;
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+    const int m = m0 + wy * 128 + mi * 16 + li;
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni) {
+      const int n = n0 + wx * 128 + ni * 16 + g * 4;
+      const f32x4 v = acc[ni][mi];
+      *(float4*)(slab + (int64_t)m * a.Fp + n) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+template <typename T>
+static void launch_wgrad_w4_t(const WgradArgs& a, hipStream_t s) {
+  static bool once = ((void)hipFuncSetAttribute((const void*)k_wgrad_gemm_w4<T>,
+                      hipFuncAttributeMaxDynamicSharedMemorySize, PH_WG_LDS_BYTES), true);
+  (void)once;
+  const dim3 grid((a.tm_count > 0 ? a.tm_count : a.Dp / BM) * (a.Fp / BN) * a.S), block(256);
+  VV_LAUNCH((k_wgrad_gemm_w4<T>), grid, block, PH_WG_LDS_BYTES, s, a);
+}
+void launch_wgrad_gemm_w4(int prec, const WgradArgs& a, hipStream_t s) {
+  if (prec == 0) launch_wgrad_w4_t<F16>(a, s); else launch_wgrad_w4_t<BF16>(a, s);
 }
 
 // ------------------------------------------------------------------------------- launchers ----
