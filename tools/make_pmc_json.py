@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/gpu_final.sh) -> profiles/pmc_latest.json.
+"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/sessions/*_final.sh) -> profiles/pmc_latest.json.
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) KiB: /opt/skills/guides/MI355X_MICROARCH.md says FETCH_SIZE
 reports half of the bytes of wide coalesced reads on gfx950 (64-B tally of 128-B requests); unit KiB."""
 import csv
@@ -10,8 +10,8 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
-NAMES = {"k_fwd_gemm": "fwd_gemm", "k_wgrad_gemm": "wgrad_gemm", "k_score_loss": "score_loss", "k_reduce": "reduce",
-         "k_sgd": "sgd", "k_segsum": "segsum", "k_dd_claim": "dd_claim", "k_dd_leaders": "dd_leaders",
+NAMES = {"k_fwd_gemm": "fwd_gemm", "k_wgrad_gemm": "wgrad_gemm", "k_score_loss": "score_loss", "k_score_fwd": "score_loss",
+         "k_reduce": "reduce", "k_sgd": "sgd", "k_segsum": "segsum", "k_seg_bwd": "segsum", "k_dd_claim": "dd_claim", "k_dd_leaders": "dd_leaders",
          "k_dd_map": "dd_map", "k_dd_segstart": "dd_segstart", "k_dd_pos": "dd_pos"}
 
 
@@ -23,7 +23,7 @@ def short(n):
     return None
 
 
-out = {"_source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of bench.py (tools/gpu_final.sh); "
+out = {"_source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of bench.py (tools/sessions/*_final.sh); "
                   "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) KiB, FETCH_SIZE doubled as "
                   "/opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950"}
 for mode in ("on", "off"):
