@@ -67,6 +67,16 @@ def cpu_baseline(ds, idx, W, b, items, iters, threads=0):
         orc.sgd_update(bo, r["db"], hb, 1e-3, 2.0, 0.9, 5e-4, 0.0)
         return time.perf_counter() - t0
     blas = orc.find_blas()
+    # Thread count: every hardware thread is not the fastest choice on a two-socket SMT host (128 threads ran this step
+    # 2x slower than 64 on the 2 x EPYC 9575F box); like the BLAS, it is picked on one warm-up iteration each.
+    tried = {}
+    if threads == 0:
+        all_t = orc.get_threads()
+        one()                                    # first touch of the buffer pool
+        for t_ in sorted({all_t, max(1, all_t // 2), max(1, all_t // 4)}, reverse=True):
+            orc.set_threads(t_)
+            tried[t_] = one()
+        orc.set_threads(min(tried, key=tried.get))
     t_own = one()
     t_ext = None
     if blas and orc.set_blas(blas):
@@ -85,6 +95,8 @@ def cpu_baseline(ds, idx, W, b, items, iters, threads=0):
            "sample": "%d of %d batch items (%d rows) of the same 4096->%d, C5, Nn%d step, "
                      "%d timed iterations after warm-up, %.2f s each" % (items, B_PER_GPU, items * (C + NN), D, NN, iters, t),
            "iteration_gflops": 4.0 * items * (C + NN) * F * D / t / 1e9}
+    if tried:
+        out["threads_tried_s_per_iteration"] = {str(k): round(v, 3) for k, v in tried.items()}
     if gemm is not None:
         out["fc7_gemm_gflops"] = gemm
     return out

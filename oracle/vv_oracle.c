@@ -4,9 +4,11 @@
  * reference file:line (relative to /root/reference) it restates.  Written from the reference's
  * behaviour; no reference source text is reproduced here.
  */
+#define _POSIX_C_SOURCE 200809L
 #include "vv_oracle.h"
 
 #include <dlfcn.h>
+#include <time.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -496,10 +498,72 @@ static void gemm_blocked(int M, int N, int K, float alpha, const float* A, int a
 #pragma omp parallel for num_threads(nt)
     for (int i = 0; i < M; ++i) for (int j = 0; j < N; ++j) C[(size_t)i * N + j] *= beta;
   }
+  const int mblocks = (M + GK_MC - 1) / GK_MC;
+  if (mblocks * 2 <= nt) {
+    /* Few row blocks (the weight gradient: M = D): the packed slab of A (all M rows x KC) is packed once per K block
+     * and shared; every thread packs column panels of B for itself and runs them against all of A.  Same products,
+     * same K order per element of C as the general arrangement below. */
+    const int mpan = (M + MR - 1) / MR, npan_all = (N + NR - 1) / NR;
+    float* Ash = (float*)aligned_alloc(64, sizeof(float) * (size_t)GK_KC * mpan * MR + 64);
+#pragma omp parallel num_threads(nt)
+    {
+      float* Bq = (float*)aligned_alloc(64, sizeof(float) * (size_t)GK_KC * NR + 64);
+      float tile[8 * 32];
+      for (int pc = 0; pc < K; pc += GK_KC) {
+        const int kc = K - pc < GK_KC ? K - pc : GK_KC;
+#pragma omp for schedule(static)
+        for (int ip = 0; ip < mpan; ++ip) {
+          float* dst = Ash + (size_t)ip * GK_KC * MR;
+          const int r0 = ip * MR, mr = M - r0 < MR ? M - r0 : MR;
+          if (!a_trans) {
+            for (int i = 0; i < mr; ++i) {
+              const float* src = A + (size_t)(r0 + i) * K + pc;
+              for (int k = 0; k < kc; ++k) dst[(size_t)k * MR + i] = alpha * src[k];
+            }
+            for (int i = mr; i < MR; ++i) for (int k = 0; k < kc; ++k) dst[(size_t)k * MR + i] = 0.f;
+          } else {
+            for (int k = 0; k < kc; ++k) {
+              const float* src = A + (size_t)(pc + k) * M + r0;
+              for (int i = 0; i < mr; ++i) dst[(size_t)k * MR + i] = alpha * src[i];
+              for (int i = mr; i < MR; ++i) dst[(size_t)k * MR + i] = 0.f;
+            }
+          }
+        }                                                         /* implicit barrier */
+#pragma omp for schedule(dynamic, 1)
+        for (int jp = 0; jp < npan_all; ++jp) {
+          const int j0 = jp * NR, nr = N - j0 < NR ? N - j0 : NR;
+          if (!b_trans) {
+            for (int k = 0; k < kc; ++k) {
+              const float* src = B + (size_t)(pc + k) * N + j0;
+              for (int j = 0; j < nr; ++j) Bq[(size_t)k * NR + j] = src[j];
+              for (int j = nr; j < NR; ++j) Bq[(size_t)k * NR + j] = 0.f;
+            }
+          } else {
+            for (int j = 0; j < nr; ++j) {
+              const float* src = B + (size_t)(j0 + j) * K + pc;
+              for (int k = 0; k < kc; ++k) Bq[(size_t)k * NR + j] = src[k];
+            }
+            for (int j = nr; j < NR; ++j) for (int k = 0; k < kc; ++k) Bq[(size_t)k * NR + j] = 0.f;
+          }
+          for (int ip = 0; ip < mpan; ++ip) {
+            const int r0 = ip * MR, mr = M - r0 < MR ? M - r0 : MR;
+            const float* ap = Ash + (size_t)ip * GK_KC * MR;
+            if (mr == MR && nr == NR) ukr(kc, ap, Bq, C + (size_t)r0 * N + j0, N, 0);
+            else {
+              ukr(kc, ap, Bq, tile, NR, 1);
+              for (int i = 0; i < mr; ++i) for (int j = 0; j < nr; ++j) C[(size_t)(r0 + i) * N + j0 + j] += tile[i * NR + j];
+            }
+          }
+        }                                                         /* implicit barrier: Ash is repacked next */
+      }
+      free(Bq);
+    }
+    free(Ash);
+    return;
+  }
   const int nc_max = N < GK_NC ? N : GK_NC;
   const int npan_max = (nc_max + NR - 1) / NR;
   float* Bp = (float*)aligned_alloc(64, sizeof(float) * (size_t)GK_KC * npan_max * NR + 64);
-  const int mblocks = (M + GK_MC - 1) / GK_MC;
 #pragma omp parallel num_threads(nt)
   {
     float* Ap = (float*)aligned_alloc(64, sizeof(float) * (size_t)GK_KC * (GK_MC + 8) + 64);
@@ -669,6 +733,7 @@ void orc_max_margin_bwd(int count, const float* s_true, const float* s_bogus, co
 
 /* sum_layer.cpp:31-54 */
 void orc_sum_fwd(int num, int dim, int num_output, const float* x, float* y) {
+#pragma omp parallel for num_threads(threads_for((double)num * dim))
   for (int i = 0; i < num; ++i) {
     float s = 0.f;
     for (int j = 0; j < dim; ++j) s += x[(size_t)i * dim + j];
@@ -677,6 +742,7 @@ void orc_sum_fwd(int num, int dim, int num_output, const float* x, float* y) {
 }
 /* sum_layer.cpp:56-82 */
 void orc_sum_bwd(int num, int dim, int num_output, const float* dy, float* dx) {
+#pragma omp parallel for num_threads(threads_for((double)num * dim))
   for (int i = 0; i < num; ++i) {
     float s = 0.f;
     for (int o = 0; o < num_output; ++o) s += dy[(size_t)i * num_output + o];
@@ -865,6 +931,41 @@ static float* falloc(size_t n) {
   if (!p) { fprintf(stderr, "vv_oracle: out of memory (%zu floats)\n", n); abort(); }
   return p;
 }
+/* The big per-iteration arrays (the reference's blobs live for the whole run: Blob::Reshape allocates once,
+ * blob.cpp:14-27) come from a small pool of blocks that survive between calls, so that a timed iteration does not pay
+ * for page faults on a gigabyte of fresh memory.  Contents are NOT zeroed.  Calls are serialised (one step at a time). */
+#define ORC_POOL 32
+static struct { float* p; size_t n; int used; } g_pool[ORC_POOL];
+static float* palloc(size_t n) {
+  int best = -1;
+  for (int i = 0; i < ORC_POOL; ++i)
+    if (!g_pool[i].used && g_pool[i].p && g_pool[i].n >= n && (best < 0 || g_pool[i].n < g_pool[best].n)) best = i;
+  if (best >= 0 && g_pool[best].n <= 2 * n + 1024) { g_pool[best].used = 1; return g_pool[best].p; }
+  for (int i = 0; i < ORC_POOL; ++i)
+    if (!g_pool[i].used && !g_pool[i].p) {
+      g_pool[i].p = (float*)aligned_alloc(64, ((n ? n : 1) * sizeof(float) + 63) / 64 * 64);
+      if (!g_pool[i].p) { fprintf(stderr, "vv_oracle: out of memory (%zu floats)\n", n); abort(); }
+      g_pool[i].n = n; g_pool[i].used = 1;
+      return g_pool[i].p;
+    }
+  for (int i = 0; i < ORC_POOL; ++i)                     /* every slot holds a block of another size: replace a free one */
+    if (!g_pool[i].used) {
+      free(g_pool[i].p);
+      g_pool[i].p = (float*)aligned_alloc(64, ((n ? n : 1) * sizeof(float) + 63) / 64 * 64);
+      if (!g_pool[i].p) { fprintf(stderr, "vv_oracle: out of memory (%zu floats)\n", n); abort(); }
+      g_pool[i].n = n; g_pool[i].used = 1;
+      return g_pool[i].p;
+    }
+  fprintf(stderr, "vv_oracle: buffer pool exhausted\n"); abort();
+}
+static void pfree(float* p) {
+  for (int i = 0; i < ORC_POOL; ++i) if (g_pool[i].p == p) { g_pool[i].used = 0; return; }
+  free(p);
+}
+
+/* ORC_TIMING=1: wall time of the phases of orc_forward_backward on stderr (where a CPU run of the step spends its time) */
+static double orc_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
+#define ORC_PHASE(name) do { if (timing) { const double t_ = orc_now(); fprintf(stderr, "[orc] %-28s %8.1f ms\n", name, (t_ - tph) * 1e3); tph = t_; } } while (0)
 
 /* Net::ForwardBackward over mednet_embedding_train.prototxt (TRAIN phase), layer by layer. */
 void orc_forward_backward(const orc_step_cfg* cfg, const float* table, const int32_t* idx,
@@ -873,18 +974,21 @@ void orc_forward_backward(const orc_step_cfg* cfg, const float* table, const int
   const int B = cfg->B, C = cfg->C, Nn = cfg->Nn, F = cfg->F, D = cfg->D;
   const int CN = C + Nn, R = CN * B, Q = 1 + Nn;
   const int nt = threads_for((double)R * (F > D ? F : D));
+  const int timing = getenv("ORC_TIMING") != NULL;
+  double tph = orc_now();
 
   /* --- data layer copy (…data_layer.cpp:439-452,856-875) then SLICE dim 1 + CONCAT dim 0
    * (prototxt :48-131; slice_layer.cpp:79-105, concat_layer.cpp:45-83) + FLATTEN (a reshape): X row = ch*B+b */
-  float* data = falloc((size_t)B * CN * F);
+  float* data = palloc((size_t)B * CN * F);
 #pragma omp parallel for num_threads(nt)
   for (int i = 0; i < B * CN; ++i) {
     float* dst = data + (size_t)i * F;
     if (idx[i] >= 0) memcpy(dst, table + (size_t)idx[i] * F, sizeof(float) * F);
+    else memset(dst, 0, sizeof(float) * F);
     if (last_src && last_src[i] != idx[i])
       dst[F - 1] = last_src[i] >= 0 ? table[(size_t)last_src[i] * F + F - 1] : 0.f;
   }
-  float* X = falloc((size_t)R * F);
+  float* X = palloc((size_t)R * F);
   int32_t* ones = (int32_t*)malloc(sizeof(int32_t) * (size_t)(CN > Q ? CN : Q));
   for (int k = 0; k < (CN > Q ? CN : Q); ++k) ones[k] = 1;
 #pragma omp parallel for num_threads(nt)
@@ -896,13 +1000,15 @@ void orc_forward_backward(const orc_step_cfg* cfg, const float* table, const int
     orc_split_pieces(b1 - b0, F, CN, ones, data + (size_t)b0 * CN * F, piece);
     free(piece);
   }
-  free(data);
+  pfree(data);
 
+  ORC_PHASE("data + slice/concat");
   /* --- fc7 INNER_PRODUCT (inner_product_layer.cpp:61-74): Y = X W^T + 1 b^T */
-  float* Y = falloc((size_t)R * D);
+  float* Y = palloc((size_t)R * D);
   orc_inner_product_fwd(R, D, F, X, W, b, Y);
+  ORC_PHASE("fc7 forward");
   /* --- RELU (relu_layer.cpp:10-20), DROPOUT in place on ip2 (dropout_layer.cpp:34-50) */
-  float* H = falloc((size_t)R * D);
+  float* H = palloc((size_t)R * D);
   const float slope = cfg->relu_negative_slope;
   const int64_t RD = (int64_t)R * D, BD = (int64_t)B * D;
 #pragma omp parallel for num_threads(nt)
@@ -924,11 +1030,12 @@ void orc_forward_backward(const orc_step_cfg* cfg, const float* table, const int
       free(E);
     }
   }
+  ORC_PHASE("relu/dropout + context sum");
   /* --- NORMALIZATION of the context mean (prototxt :281-288) */
   float* Ahat = falloc((size_t)B * D);
   orc_normalize_fwd(B, D, A, Ahat);
   /* --- CONCAT dim 0 of target + negatives, NORMALIZATION, SLICE (prototxt :290-342) */
-  float* PN = falloc((size_t)Q * B * D);
+  float* PN = palloc((size_t)Q * B * D);
   {
     const float** piece = (const float**)malloc(sizeof(float*) * (size_t)Q);
     piece[0] = H;
@@ -937,8 +1044,9 @@ void orc_forward_backward(const orc_step_cfg* cfg, const float* table, const int
     orc_join_pieces(1, D, Q, ones, piece, PN);
     free(piece);
   }
-  float* Phat = falloc((size_t)Q * B * D);
+  float* Phat = palloc((size_t)Q * B * D);
   orc_normalize_fwd(Q * B, D, PN, Phat);
+  ORC_PHASE("normalisations + concat");
   /* --- ELTWISE PROD + SUM (prototxt :354-629): s+ replicated Nn times, s-[b][k] */
   float* s_true = falloc((size_t)B * (Nn > 0 ? Nn : 1));
   float* s_bogus = falloc((size_t)B * (Nn > 0 ? Nn : 1));
@@ -958,6 +1066,7 @@ void orc_forward_backward(const orc_step_cfg* cfg, const float* table, const int
       for (int bb = 0; bb < B; ++bb) s_bogus[(size_t)bb * Nn + (q - 1)] = col[bb];    /* concat dim 1 */
     }
   }
+  ORC_PHASE("prod + sum forward");
   /* --- MAX_MARGIN_LOSS (prototxt :655-671) */
   const int count = B * Nn;
   float* wrep = NULL;                 /* the 3rd bottom: item weight replicated over the Nn terms (a SUM layer) */
@@ -980,10 +1089,11 @@ void orc_forward_backward(const orc_step_cfg* cfg, const float* table, const int
     const float f = (float)count / (float)cfg->global_count;
     for (int i = 0; i < count; ++i) { d_true[i] *= f; d_bogus[i] *= f; }
   }
+  ORC_PHASE("loss fwd + bwd");
   /* SUM / PROD backward per q; the Q copies of context_feature are tops of a SPLIT (split_layer.cpp:36-51) */
   float* dAhat = falloc((size_t)B * D);
-  float* dPhat = falloc((size_t)Q * B * D);
-  float* dAq = falloc((size_t)Q * B * D);
+  float* dPhat = palloc((size_t)Q * B * D);
+  float* dAq = palloc((size_t)Q * B * D);
   float* dprod = falloc((size_t)B * D);
   for (int q = 0; q < Q; ++q) {
     if (q == 0) orc_sum_bwd(B, D, Nn, d_true, dprod);                                 /* sum :56-82 */
@@ -1008,15 +1118,16 @@ void orc_forward_backward(const orc_step_cfg* cfg, const float* table, const int
     orc_split_bwd(n, Q, tops, dAhat + o);
     free(tops);
   }
-  free(dAq);
-  float* dPN = falloc((size_t)Q * B * D);
+  pfree(dAq);
+  ORC_PHASE("sum/prod/split backward");
+  float* dPN = palloc((size_t)Q * B * D);
   orc_normalize_bwd(Q * B, D, PN, dPhat, dPN);
   float* dA = falloc((size_t)B * D);
   orc_normalize_bwd(B, D, A, dAhat, dA);
   /* diffs back to the rows of dH: CONCAT backward (concat_layer.cpp:86-100) hands the target and negative rows
    * their pieces of dPN, the ELTWISE SUM backward (:132-138) writes c_j dA into the context rows; the SLICE dim 0
    * backward (slice_layer.cpp:107-120) is then the identity on this layout. */
-  float* dH = falloc((size_t)R * D);
+  float* dH = palloc((size_t)R * D);
   {
     float** piece = (float**)malloc(sizeof(float*) * (size_t)Q);
     piece[0] = dH;
@@ -1032,14 +1143,16 @@ void orc_forward_backward(const orc_step_cfg* cfg, const float* table, const int
         orc_eltwise_bwd(1, n, C - 1, NULL, cfg->ctx_coeff, NULL, dA + o, j - 1, 1, dH + (size_t)j * BD + o);
     }
   }
+  ORC_PHASE("normalisation/concat/eltwise bwd");
   /* DROPOUT backward (dropout_layer.cpp:52-68), RELU backward (relu_layer.cpp:23-37) */
-  float* dY = falloc((size_t)R * D);
+  float* dY = palloc((size_t)R * D);
 #pragma omp parallel for num_threads(nt)
   for (int p = 0; p < nt; ++p) {
     const int64_t o = RD * p / nt, n = RD * (p + 1) / nt - o;
     if (cfg->dropout_ratio > 0.f) orc_dropout_bwd(n, dH + o, cfg->dropout_mask + o, cfg->dropout_ratio, 1, dH + o);
     orc_relu_bwd(n, Y + o, dH + o, slope, dY + o);
   }
+  ORC_PHASE("dropout/relu backward");
   /* INNER_PRODUCT backward (inner_product_layer.cpp:76-106): dW = dY^T X, db = dY^T 1 */
   orc_inner_product_bwd(R, D, F, X, W, dY, out->dW, out->db, NULL);
   if (out->dW && cfg->ip_regularization > 0.f) {
@@ -1047,6 +1160,7 @@ void orc_forward_backward(const orc_step_cfg* cfg, const float* table, const int
     for (size_t i = 0; i < (size_t)D * F; ++i) out->dW[i] *= f;
   }
 
+  ORC_PHASE("fc7 backward");
   if (out->Y) memcpy(out->Y, Y, sizeof(float) * (size_t)R * D);
   if (out->H) memcpy(out->H, H, sizeof(float) * (size_t)R * D);
   if (out->ctx) memcpy(out->ctx, Ahat, sizeof(float) * (size_t)B * D);
@@ -1055,9 +1169,9 @@ void orc_forward_backward(const orc_step_cfg* cfg, const float* table, const int
   if (out->s_bogus) memcpy(out->s_bogus, s_bogus, sizeof(float) * (size_t)B * Nn);
   if (out->dY) memcpy(out->dY, dY, sizeof(float) * (size_t)R * D);
 
-  free(X); free(Y); free(H); free(A); free(Ahat); free(PN); free(Phat); free(s_true);
-  free(s_bogus); free(prod); free(col); free(d_true); free(d_bogus); free(dAhat); free(dPhat);
-  free(dprod); free(dPN); free(dA); free(dH); free(dY); free(ones);
+  pfree(X); pfree(Y); pfree(H); free(A); free(Ahat); pfree(PN); pfree(Phat); free(s_true);
+  free(s_bogus); free(prod); free(col); free(d_true); free(d_bogus); free(dAhat); pfree(dPhat);
+  free(dprod); pfree(dPN); free(dA); pfree(dH); pfree(dY); free(ones);
 }
 
 /* videovec_extraction.prototxt:179-205 (fc7 INNER_PRODUCT + RELU), optional NORMALIZATION as in

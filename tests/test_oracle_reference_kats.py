@@ -240,8 +240,12 @@ def test_blocked_sgemm_edges_and_both_kernels(oracle, force_avx2):
     block, the cache blocks or the thread count, alpha / beta, on the AVX-512 kernel (when the CPU has it) and the AVX2 one."""
     try:
         oracle.sgemm_isa(force_avx2=force_avx2)
+        oracle.set_threads(8)
         rng = np.random.default_rng(5)
-        for (M, N, K) in [(1, 1, 1), (7, 33, 5), (97, 50, 401), (200, 4100, 37), (13, 17, 800), (64, 64, 64)]:
+        # (100, 700, 900) and (200, 4100, 37): few row blocks and enough work for several threads -- the arrangement
+        # with one shared packed slab of A (the weight gradient's shape); (1000, 64, 500): many row blocks
+        for (M, N, K) in [(1, 1, 1), (7, 33, 5), (97, 50, 401), (200, 4100, 37), (13, 17, 800), (64, 64, 64),
+                          (100, 700, 900), (1000, 64, 500)]:
             for ta in (False, True):
                 for tb in (False, True):
                     A = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
@@ -255,6 +259,7 @@ def test_blocked_sgemm_edges_and_both_kernels(oracle, force_avx2):
                     assert np.abs(out0 - ref0).max() <= 2e-5 * max(1.0, np.abs(ref0).max())
     finally:
         oracle.sgemm_isa(force_avx2=False)
+        oracle.set_threads(0)
 
 
 # ---------------------------------------------------------------- the plain layers -----------

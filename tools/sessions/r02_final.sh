@@ -48,8 +48,10 @@ for mode in ("on", "off"):
     for k, cs in acc.items():
         print(k, " ".join("%s=%.4g" % (c, sum(v) / len(v)) for c, v in sorted(cs.items())))
         if "SQ_VALU_MFMA_BUSY_CYCLES" in cs and "SQ_BUSY_CYCLES" in cs:
-            print("   MFMA busy / SQ busy = %.3f" % (sum(cs["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(cs["SQ_VALU_MFMA_BUSY_CYCLES"]) /
-                                                   (sum(cs["SQ_BUSY_CYCLES"]) / len(cs["SQ_BUSY_CYCLES"]))))
+            # SQ_BUSY_CYCLES sums the 32 shader engines' busy cycles (8 XCDs x 4), SQ_VALU_MFMA_BUSY_CYCLES the 1024 SIMDs'
+            mf = sum(cs["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(cs["SQ_VALU_MFMA_BUSY_CYCLES"])
+            bz = sum(cs["SQ_BUSY_CYCLES"]) / len(cs["SQ_BUSY_CYCLES"])
+            print("   kernel cycles %.0f, matrix pipe busy per SIMD = %.3f" % (bz / 32, mf / (bz / 32 * 1024)))
 PY
 python3 tools/samp_time.py > $O/${TAG}_sampler_rates.txt 2>&1
 bash tools/facade_rate.sh > $O/${TAG}_facade_rate.txt 2>&1
