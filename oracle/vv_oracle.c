@@ -1048,15 +1048,18 @@ void orc_forward_backward(const orc_step_cfg* cfg, const float* table, const int
   orc_normalize_fwd(Q * B, D, PN, Phat);
   ORC_PHASE("normalisations + concat");
   /* --- ELTWISE PROD + SUM (prototxt :354-629): s+ replicated Nn times, s-[b][k] */
+  /* the per-q layers work on B x D values each: teams of the size the stand-alone layer functions pick for that much
+   * work (alternating between team sizes from one parallel region to the next costs more than the regions do) */
+  const int ntq = threads_for((double)BD);
   float* s_true = falloc((size_t)B * (Nn > 0 ? Nn : 1));
   float* s_bogus = falloc((size_t)B * (Nn > 0 ? Nn : 1));
   float* prod = falloc((size_t)B * D);
   float* col = falloc((size_t)B);
   for (int q = 0; q < Q; ++q) {
     const float* P = Phat + (size_t)q * B * D;
-#pragma omp parallel for num_threads(nt)
-    for (int p = 0; p < nt; ++p) {                                                    /* eltwise :61-65 */
-      const int64_t o = BD * p / nt, n = BD * (p + 1) / nt - o;
+#pragma omp parallel for num_threads(ntq)
+    for (int p = 0; p < ntq; ++p) {                                                   /* eltwise :61-65 */
+      const int64_t o = BD * p / ntq, n = BD * (p + 1) / ntq - o;
       const float* two[2] = { Ahat + o, P + o };
       orc_eltwise_fwd(0, n, 2, two, NULL, prod + o);
     }
@@ -1102,9 +1105,9 @@ void orc_forward_backward(const orc_step_cfg* cfg, const float* table, const int
       orc_sum_bwd(B, D, 1, col, dprod);
     }
     const float* P = Phat + (size_t)q * B * D;
-#pragma omp parallel for num_threads(nt)
-    for (int p = 0; p < nt; ++p) {                                                    /* eltwise :116-131 */
-      const int64_t o = BD * p / nt, n = BD * (p + 1) / nt - o;
+#pragma omp parallel for num_threads(ntq)
+    for (int p = 0; p < ntq; ++p) {                                                   /* eltwise :116-131 */
+      const int64_t o = BD * p / ntq, n = BD * (p + 1) / ntq - o;
       const float* two[2] = { Ahat + o, P + o };
       orc_eltwise_bwd(0, n, 2, two, NULL, NULL, dprod + o, 1, 1, dPhat + (size_t)q * BD + o);
       orc_eltwise_bwd(0, n, 2, two, NULL, NULL, dprod + o, 0, 1, dAq + (size_t)q * BD + o);
