@@ -144,8 +144,17 @@ static int create_init(vv_ctx* c) {
   if (sb) c->seg_bwd = atoi(sb) != 0;
   const char* dd = getenv("VV_DEDUP");
   if (dd) c->dedup = atoi(dd) != 0;
-  HIPCHK(hipMalloc(&c->dd_info, 4 * sizeof(int32_t)));
-  HIPCHK(hipMemset(c->dd_info, 0, 4 * sizeof(int32_t)));
+  HIPCHK(hipMalloc(&c->dd_info_all, vv_ctx::kDdSets * 4 * sizeof(int32_t)));
+  HIPCHK(hipMemset(c->dd_info_all, 0, vv_ctx::kDdSets * 4 * sizeof(int32_t)));
+  HIPCHK(hipStreamCreateWithFlags(&c->dd_stream, hipStreamNonBlocking));
+  for (int i = 0; i < vv_ctx::kDdSets; ++i) {
+    c->dd_set[i].info = c->dd_info_all + 4 * i;
+    HIPCHK(hipEventCreateWithFlags(&c->dd_set[i].done, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->dd_set[i].used, hipEventDisableTiming));
+  }
+  c->dd_info = c->dd_set[0].info;
+  const char* da = getenv("VV_DEDUP_ASYNC");
+  if (da) c->dd_async = atoi(da) != 0;
   HIPCHK(hipHostMalloc((void**)&c->U_host, 2 * sizeof(int32_t), hipHostMallocMapped));   // {U, saturated f16 gradient sums}
   c->U_host[0] = c->U_host[1] = 0;
   HIPCHK(hipHostGetDevicePointer((void**)&c->U_host_dev, c->U_host, 0));
@@ -180,8 +189,14 @@ static void free_batch(vv_ctx* c) {
   dfree(c->idx_dev); dfree(c->rows); dfree(c->H); dfree(c->dYh); dfree(c->dbp);
   dfree(c->loss_part); dfree(c->viol_part); dfree(c->s_true); dfree(c->s_bogus);
   dfree(c->coeff); dfree(c->slabs); dfree(c->item_w); c->item_w = nullptr;
-  dfree(c->dd_agg); dfree(c->dd_slot_of); dfree(c->dd_uniq); dfree(c->dd_map); dfree(c->dd_ord); dfree(c->dd_cnt);
-  dfree(c->dd_seg); dfree(c->dd_pos); dfree(c->dYu);
+  if (c->dd_stream) (void)hipStreamSynchronize(c->dd_stream);
+  dfree(c->dd_agg); dfree(c->dd_pos); dfree(c->dYu);
+  for (int i = 0; i < vv_ctx::kDdSets; ++i) {
+    vv_ctx::DdSet& d = c->dd_set[i];
+    dfree(d.rows); dfree(d.slot_of); dfree(d.uniq); dfree(d.map); dfree(d.ord); dfree(d.cnt); dfree(d.seg);
+    d.rows = d.slot_of = d.uniq = d.map = d.ord = d.cnt = d.seg = nullptr; d.used_recorded = false;
+  }
+  c->dd_rows = nullptr;
   dfree(c->segV); dfree(c->seg_rec); dfree(c->seg_dbp);
   c->segV = nullptr; c->seg_rec = nullptr; c->seg_dbp = nullptr;
   c->dd_agg = nullptr; c->dd_slot_of = c->dd_uniq = c->dd_map = c->dd_ord = c->dd_cnt = c->dd_seg = c->dd_pos = nullptr;
@@ -200,7 +215,12 @@ int vv_destroy(vv_ctx* c) {
   free_batch(c);
   dfree(c->table); dfree(c->patch_desc); dfree(c->W); dfree(c->b); dfree(c->hW); dfree(c->hb); dfree(c->Wh);
   dfree(c->scales); dfree(c->wmax_blocks); dfree(c->grads_own); dfree(c->mask); dfree(c->loss2);
-  dfree(c->dd_key); dfree(c->dd_info);
+  dfree(c->dd_key); dfree(c->dd_info_all);
+  for (int i = 0; i < vv_ctx::kDdSets; ++i) {
+    if (c->dd_set[i].done) (void)hipEventDestroy(c->dd_set[i].done);
+    if (c->dd_set[i].used) (void)hipEventDestroy(c->dd_set[i].used);
+  }
+  if (c->dd_stream) (void)hipStreamDestroy(c->dd_stream);
   if (c->comm) vv::comm_destroy(c->comm);
   if (c->ev_chunk) (void)hipEventDestroy(c->ev_chunk);
   if (c->U_host) (void)hipHostFree(c->U_host);
@@ -437,12 +457,16 @@ static int ensure_batch(vv_ctx* c, int B, int C, int Nn) {
   c->dd_agg_stride = c->R / 1024 + 2;
   HIPCHK(hipMalloc(&c->dd_agg, (size_t)2 * c->dd_agg_stride * sizeof(unsigned long long)));
   HIPCHK(hipMemset(c->dd_agg, 0, (size_t)2 * c->dd_agg_stride * sizeof(unsigned long long)));
-  HIPCHK(hipMalloc(&c->dd_slot_of, (size_t)c->Rp * 4));
-  HIPCHK(hipMalloc(&c->dd_uniq, (size_t)c->Rp * 4));
-  HIPCHK(hipMalloc(&c->dd_map, (size_t)c->Rp * 4));
-  HIPCHK(hipMalloc(&c->dd_ord, (size_t)c->Rp * 4));
-  HIPCHK(hipMalloc(&c->dd_cnt, (size_t)c->Rp * 4));
-  HIPCHK(hipMalloc(&c->dd_seg, (size_t)(c->Rp + 1) * 4));
+  for (int i = 0; i < vv_ctx::kDdSets; ++i) {
+    vv_ctx::DdSet& d = c->dd_set[i];
+    HIPCHK(hipMalloc(&d.rows, (size_t)c->Rp * 4));
+    HIPCHK(hipMalloc(&d.slot_of, (size_t)c->Rp * 4));
+    HIPCHK(hipMalloc(&d.uniq, (size_t)c->Rp * 4));
+    HIPCHK(hipMalloc(&d.map, (size_t)c->Rp * 4));
+    HIPCHK(hipMalloc(&d.ord, (size_t)c->Rp * 4));
+    HIPCHK(hipMalloc(&d.cnt, (size_t)c->Rp * 4));
+    HIPCHK(hipMalloc(&d.seg, (size_t)(c->Rp + 1) * 4));
+  }
   HIPCHK(hipMalloc(&c->dd_pos, (size_t)c->Rp * 4));
   HIPCHK(hipMalloc(&c->dYu, (size_t)(c->Rp + BK) * c->Dp * 2));
   HIPCHK(hipMemset(c->dYu, 0, (size_t)(c->Rp + BK) * c->Dp * 2));
@@ -545,27 +569,39 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   c->last_dedup = dd;
   if (!dd) launch_map_rows(didx, c->rows, c->R, c->Rp, (int32_t)c->n_rows, (int32_t)row_limit, s);
   if (dd) {
+    // The grouping kernels need only the indices: they run on the context's second stream, so that when the host is a
+    // step ahead (the normal case: nothing in the loop waits for the GPU) the grouping of step k+1 executes beside the
+    // kernels of step k and the step's own stream merely waits for an event that has long been signalled.  Three sets of
+    // output arrays rotate; a set is rewritten only after the step that read it has issued its last reader.
+    hipStream_t ds = c->dd_async ? c->dd_stream : s;
     const int64_t need = c->n_rows + 1 + c->patch_cap;
     if (need > c->dd_key_cap) {
       HIPCHK(hipStreamSynchronize(s));
+      HIPCHK(hipStreamSynchronize(c->dd_stream));
       dfree(c->dd_key); c->dd_key = nullptr;
       HIPCHK(hipMalloc(&c->dd_key, (size_t)need * sizeof(unsigned long long)));
-      HIPCHK(hipMemsetAsync(c->dd_key, 0, (size_t)need * sizeof(unsigned long long), s));
+      HIPCHK(hipMemsetAsync(c->dd_key, 0, (size_t)need * sizeof(unsigned long long), ds));
       c->dd_key_cap = need;
     }
     if (++c->dd_epoch == 0) {        // epoch tags wrapped: start over with clean tag words
-      HIPCHK(hipMemsetAsync(c->dd_key, 0, (size_t)c->dd_key_cap * sizeof(unsigned long long), s));
-      HIPCHK(hipMemsetAsync(c->dd_agg, 0, (size_t)2 * c->dd_agg_stride * sizeof(unsigned long long), s));
+      HIPCHK(hipMemsetAsync(c->dd_key, 0, (size_t)c->dd_key_cap * sizeof(unsigned long long), ds));
+      HIPCHK(hipMemsetAsync(c->dd_agg, 0, (size_t)2 * c->dd_agg_stride * sizeof(unsigned long long), ds));
       c->dd_epoch = 1;
     }
+    vv_ctx::DdSet& set = c->dd_set[c->dd_step++ % vv_ctx::kDdSets];
+    c->dd_rows = set.rows; c->dd_slot_of = set.slot_of; c->dd_uniq = set.uniq; c->dd_map = set.map; c->dd_ord = set.ord;
+    c->dd_cnt = set.cnt; c->dd_seg = set.seg; c->dd_info = set.info;
+    if (c->dd_async && set.used_recorded) HIPCHK(hipStreamWaitEvent(ds, set.used, 0));
     DedupArgs da;
-    da.idx = didx; da.rows = c->rows; da.u_host = c->U_host_dev; da.key = c->dd_key; da.agg = c->dd_agg; da.agg_stride = c->dd_agg_stride;
+    da.idx = didx; da.rows = c->dd_rows; da.u_host = c->U_host_dev; da.key = c->dd_key; da.agg = c->dd_agg; da.agg_stride = c->dd_agg_stride;
     da.slot_of = c->dd_slot_of; da.uniq_rows = c->dd_uniq; da.map = c->dd_map; da.ord = c->dd_ord; da.cnt = c->dd_cnt;
     da.seg_start = c->dd_seg; da.pos = c->dd_pos; da.info = c->dd_info; da.tickets = c->dd_info + 2;
     da.R = c->R; da.Rp = c->Rp; da.zero_row = (int32_t)c->n_rows; da.row_limit = (int32_t)row_limit; da.epoch = c->dd_epoch;
-    // (Running the grouping kernels on a second stream beside the forward GEMM was measured: the two
-    // cross-stream event waits cost more than the ~15 us they hide -- 0.405 vs 0.394 ms per step.)
-    PROFILED(c, "dedup", (launch_dedup(da, s), launch_dedup_groups(da, s)));
+    PROFILED(c, "dedup", (launch_dedup(da, ds), launch_dedup_groups(da, ds)));
+    if (c->dd_async) {
+      HIPCHK(hipEventRecord(set.done, ds));
+      HIPCHK(hipStreamWaitEvent(s, set.done, 0));
+    }
   }
 
   FwdArgs fa;
@@ -654,6 +690,11 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
       const size_t off = (size_t)d0 * c->F, n = (size_t)dn * c->F + (last ? (size_t)D : 0);
       if (vv::comm_allreduce(c->comm, c->grads, off, n, c->ev_chunk)) return fail(VV_ERR_HIP, "all-reduce: %s", vv::comm_error(c->comm));
     }
+  }
+  if (dd && c->dd_async) {
+    vv_ctx::DdSet& set = c->dd_set[(c->dd_step - 1) % vv_ctx::kDdSets];
+    HIPCHK(hipEventRecord(set.used, s));
+    set.used_recorded = true;
   }
   c->grads_pending = c->comm != nullptr;       // (a one-rank communicator still runs its collective: same code path)
   c->grads_chunked = chunked;

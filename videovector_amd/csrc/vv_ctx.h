@@ -81,6 +81,20 @@ struct vv_ctx {
   int32_t* U_host = nullptr;        // pinned + mapped: k_dd_leaders stores U here every step, the launcher reads it late
   int32_t* U_host_dev = nullptr;    // device alias of U_host
   uint32_t dd_epoch = 0;
+  // The grouping kernels of step k+1 run on a stream of their own while step k is still executing (they need only the
+  // indices): three sets of their output arrays rotate (dd_* above point at the set of the step being issued), an event
+  // per set says when the step that used it has issued its last reader, another when its grouping is done.
+  static constexpr int kDdSets = 3;
+  struct DdSet {
+    int32_t *rows = nullptr, *slot_of = nullptr, *uniq = nullptr, *map = nullptr, *ord = nullptr, *cnt = nullptr, *seg = nullptr,
+            *info = nullptr;
+    hipEvent_t done = nullptr, used = nullptr; bool used_recorded = false;
+  } dd_set[kDdSets];
+  int32_t* dd_info_all = nullptr;
+  int32_t* dd_rows = nullptr;      // instance -> table row of the current set (k_dd_claim's output)
+  hipStream_t dd_stream = nullptr;
+  uint64_t dd_step = 0;
+  bool dd_async = true;            // env VV_DEDUP_ASYNC=0: the grouping kernels in the step's own stream
   int32_t step_seq = 0;
   // staging of index batches taken from a sampler's prefetch ring (vv_forward_backward_ring)
   static constexpr int kStage = 8;
