@@ -40,7 +40,10 @@ def test_cfg5_dedup_equals_dense_at_full_size(setup):
     n_unique = len(np.unique(idx))
     assert st0 == (B * (C + Nn), B * (C + Nn)) and st1 == (B * (C + Nn), n_unique)
     print("CFG5 rows %d distinct %d (factor %.1f) loss %.6f violations %.0f" % (st1 + (st1[0] / st1[1],) + l1))
-    assert l0 == l1 and np.array_equal(db0, db1)                  # same forward, same per-instance gradients
+    # same forward; the segment-wise backward's score kernel may differ in the last bit of the loss, and db is summed
+    # per distinct row instead of per item
+    assert abs(l0[0] - l1[0]) <= 1e-6 * l0[0] and l0[1] == l1[1]
+    assert np.linalg.norm(db1 - db0) <= 1e-5 * np.linalg.norm(db0)
     rel = np.linalg.norm(dW1 - dW0) / np.linalg.norm(dW0)
     assert rel <= 4e-3, rel                                       # bf16 rounding of the per-row gradient sums
     assert np.isfinite(l1[0]) and 0 < l1[0] < 16 and 0 <= l1[1] <= B * Nn

@@ -43,7 +43,7 @@ def test_random_shapes_dedup_dense_oracle(vv, oracle, seed):
         outs[mode] = (eng.loss(), bl, dW.copy(), db.copy(), eng.dedup_stats())
     (l0, b0, dW0, db0, _), (l1, b1, dW1, db1, st) = outs[False], outs[True]
     assert st == (B * (C + Nn), len(np.unique(np.where(idx < 0, -1, idx))))
-    if D == 512 and C - 1 <= 6 and 1 + Nn <= 56:
+    if D in (512, 1024):
         # the shape of the segment-wise backward (tests/test_gpu_segbwd.py): another kernel computes the scores (last-bit
         # differences) and the bias gradient is summed per distinct row instead of per item
         assert abs(l0[0] - l1[0]) <= 1e-6 * abs(l0[0]) and l0[1] == l1[1]

@@ -15,6 +15,10 @@ D = 512
 
 
 def run(vv, prec, table, idx, W, b, C, Nn, seg, dedup=True, **kw):
+    return run_d(vv, prec, table, idx, W, b, C, Nn, seg, dedup, **kw)
+
+
+def run_d(vv, prec, table, idx, W, b, C, Nn, seg, dedup=True, **kw):
     os.environ["VV_SEG_BWD"] = "1" if seg else "0"
     try:
         eng = vv.Engine(0, prec)
@@ -133,3 +137,31 @@ def test_segment_wise_backward_is_bit_reproducible(vv):
         assert o["loss"] == outs[0]["loss"]
     d = run(vv, "f16", table, idx, W, b, C, Nn, seg=True, dedup=False)
     assert rel_fro(outs[0]["dW"], d["dW"]) <= 5e-4 and rel_fro(outs[0]["db"], d["db"]) <= 1e-5
+
+
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+@pytest.mark.parametrize("Dx,C,Nn", [(1024, 5, 20), (1024, 4, 200), (512, 5, 70), (512, 9, 10)])
+def test_segment_wise_backward_streaming_forward_shapes(vv, oracle, prec, Dx, C, Nn):
+    """Shapes the register-resident forward does not hold (D = 1024; more than 56 target / negative rows; more than 6
+    context rows) take the streaming kernel's segment-wise form and the two-chunk k_seg_bwd: the per-GPU shape of
+    BASELINE configs[4] is one of them."""
+    B, F = 48, 256
+    ds, table, idx, W, b = make_case(31, 8, B, C, Nn, F, Dx, wstd=0.02)
+    idx[5, 1] = -1
+    a = run_d(vv, prec, table, idx, W, b, C, Nn, seg=False)
+    s = run_d(vv, prec, table, idx, W, b, C, Nn, seg=True)
+    d = run_d(vv, prec, table, idx, W, b, C, Nn, seg=True, dedup=False)
+    assert np.array_equal(a["ip2"], s["ip2"])
+    for k in ("target_score", "negative_scores"):
+        assert np.abs(a[k] - s[k]).max() <= 2.5e-7, k
+    assert abs(a["loss"][0] - s["loss"][0]) <= 1e-6 * a["loss"][0] and a["loss"][1] == s["loss"][1]
+    tol = 5e-4 if prec == "f16" else 4e-3
+    assert rel_fro(s["dW"], d["dW"]) <= tol and rel_fro(s["db"], d["db"]) <= 1e-5
+    s2 = run_d(vv, prec, table, idx, W, b, C, Nn, seg=True)
+    assert np.array_equal(s["dW"], s2["dW"]) and np.array_equal(s["db"], s2["db"])        # bit-reproducible
+    print("SEGBWD streaming %s D=%d C=%d Nn=%d: dW vs dense %.3e (rows path %.3e)" % (prec, Dx, C, Nn, rel_fro(s["dW"], d["dW"]),
+                                                                                     rel_fro(a["dW"], d["dW"])))
+    if prec == "f16":
+        eng, cfg, got, ref = run_both(vv, oracle, prec, table, idx, W, b, C, Nn)
+        check(got, ref, TOL[prec], "segbwd-streaming-D%d-C%d-Nn%d" % (Dx, C, Nn))
+        eng.close()

@@ -61,7 +61,9 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 //   dAh = sum_q c_q H[q]/(n_q+eps);   dH[q] = c_q (n_q^2 Ah - H[q] t_q)/(n_q^3 + eps)
 //   dA  = (sA dAh - A (A.dAh))/(sA^1.5 + eps), dH[j] = c_j dA
 //   dY  = dH * drop_scale * [H > 0]
-template <typename T, bool VEC>
+// SEG: the segment-wise form of the backward (vv_internal.h: SegRec) for shapes the register-resident k_score_fwd does
+// not hold: no per-instance gradient rows, one record per instance, Ah / dA per item.
+template <typename T, bool VEC, bool SEG = false>
 __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int D = a.D, C = a.C, Nn = a.Nn, CN = C + Nn;
@@ -99,7 +101,10 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
   }
   const float sA = block_sum(ssq, red);
   const float nA = sqrtf(sA) + eps;
-  for (int d = tid; d < D; d += SL_THREADS) Ah[d] = A[d] / nA;
+  for (int d = tid; d < D; d += SL_THREADS) {
+    Ah[d] = A[d] / nA;
+    if (SEG) a.V[(int64_t)2 * b * D + d] = Ah[d];
+  }
   __syncthreads();
 
   // ---- phase 2: norms and dots of target / negative rows (one row per wave at a time)
@@ -155,7 +160,13 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
     const float c = cq[ch], s = n2[ch], rs = sqrtf(s);
     const float cd = c * __builtin_amdgcn_rcpf(s * rs + eps) * a.drop_scale * a.sg;
     k1[ch] = cd * s; k2[ch] = cd * tq[ch]; k3[ch] = c * __builtin_amdgcn_rcpf(rs + eps);
+    if (SEG) { SegRec rc; rc.alpha = cd * s; rc.beta = cd * tq[ch]; rc.vec = 2 * b; rc.pad = b * CN + ch; a.rec[ooff[ch]] = rc; }
   }
+  if (SEG)
+    for (int j = 1 + tid; j < C; j += SL_THREADS) {
+      SegRec rc; rc.alpha = a.coeff[j - 1] * a.drop_scale * a.sg; rc.beta = 0.f; rc.vec = 2 * b + 1; rc.pad = b * CN + j;
+      a.rec[ooff[j]] = rc;
+    }
   __syncthreads();
 
   // ---- phase 4: backward of the normalised target / negative rows, column-parallel: a thread
@@ -176,10 +187,15 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
         const int ch = qi == 0 ? 0 : C + qi - 1;
         const float r1 = k1[ch], r2 = k2[ch], r3 = k3[ch];
         const float* h = HROW(ch) + d;
-        uint16_t* dy = a.dYh + (int64_t)ooff[ch] * a.Dp + d;
         float xv[W];
         if (VEC) { const float4 x = *(const float4*)h; xv[0] = x.x; xv[1 % W] = x.y; xv[2 % W] = x.z; xv[3 % W] = x.w; }
         else xv[0] = h[0];
+        if (SEG) {
+#pragma unroll
+          for (int e = 0; e < W; ++e) pa[e] += r3 * xv[e];
+          continue;
+        }
+        uint16_t* dy = a.dYh + (int64_t)ooff[ch] * a.Dp + d;
         uint16_t o[W];
 #pragma unroll
         for (int e = 0; e < W; ++e) {
@@ -210,6 +226,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
   const float inv_denA = 1.f / (sA * sqrtf(sA) + eps);
   for (int d = tid; d < D; d += SL_THREADS) {
     const float dA = (sA * acc0[d] - A[d] * dot) * inv_denA;
+    if (SEG) { a.V[(int64_t)(2 * b + 1) * D + d] = dA; continue; }
     float dbv = 0.f;
     for (int gI = 0; gI < G; ++gI) dbv += acc1[gI * D + d];
     for (int j = 1; j < C; ++j) {
@@ -629,10 +646,18 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
   }
 }
 
-bool score_fwd_supported(const ScoreArgs& a) { return a.D == 512 && a.C - 1 <= 6 && 1 + a.Nn <= 56; }
+// the segment-wise pair: k_seg_bwd holds a row of D = 512 or 1024 columns; the forward is the register-resident
+// k_score_fwd where an item fits (D = 512, up to 56 target / negative rows, 6 context rows), else the streaming kernel
+bool score_fwd_supported(const ScoreArgs& a) { return a.D == 512 || a.D == 1024; }
 
 void launch_score_fwd(const ScoreArgs& a, hipStream_t s) {
   const int rows = 1 + a.Nn;
+  if (!(a.D == 512 && a.C - 1 <= 6 && rows <= 56)) {
+    const size_t lds = sizeof(float) * ((size_t)2 * a.D + 2 * (a.D > 1024 ? a.D : 1024) + 8 * (a.C + a.Nn) + 8);
+    (void)hipFuncSetAttribute((const void*)k_score_loss<F16, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    VV_LAUNCH((k_score_loss<F16, true, true>), dim3(a.B), dim3(SL_THREADS), lds, s, a);
+    return;
+  }
   const size_t lds = sizeof(float) * ((size_t)(2 + 8) * a.D + 4 * (a.C + a.Nn) + 3 * 8);
 #define VV_SF(RPW)                                                                                        \
   do {                                                                                                    \
@@ -654,108 +679,140 @@ void launch_score_fwd(const ScoreArgs& a, hipStream_t s) {
 // more than 64 times in one batch -- are summed in an order-independent way instead: every product is rounded to a
 // multiple of 2^-36 in f64 ((p + M) - M, M = 1.5 * 2^16; exact for |p| < 2^15 in the gradient's scaled units), and
 // sums of such multiples are exact in f64 up to 2^17, whatever the order.
-template <typename T>
+template <typename T, int CH>
 __global__ __launch_bounds__(256) void k_seg_bwd(SegBwdArgs a) {
-  __shared__ float cs[4][512];
+  __shared__ float cs[4][512 * CH];
   __shared__ SegRec strip[4][64];
   const int U = a.info[0];
   const int Uk = min((U + BK - 1) / BK * BK, a.Rp);   // the wgrad K loop reads whole BK-row steps
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c0 = lane * 8, D = a.D;
-  float col[8];
+  const int c0 = lane * 8, D = a.D;                   // D = 512 CH; chunk c covers columns 512 c + c0 .. + 7
+  float col[CH][8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) col[j] = 0.f;
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) col[c][j] = 0.f;
   int saturated = 0;
   for (int u = blockIdx.x * 4 + wave; u < Uk; u += 4 * SEGB_BLOCKS) {
-    uint32_t o[4] = {0u, 0u, 0u, 0u};
-    if (u < U) {
-      const int b = a.seg_start[u], e = a.seg_start[u + 1], n = e - b;
-      const float4 x0 = *(const float4*)(a.H + (int64_t)u * D + c0), x1 = *(const float4*)(a.H + (int64_t)u * D + c0 + 4);
-      float acc[8];
-      float bs = 0.f;
-      if (n <= 64) {
-        const SegRec* rs = a.rec + b;
-        if (n > 1) {                                  // instance order
-          SegRec mine; mine.alpha = 0.f; mine.beta = 0.f; mine.vec = 0; mine.pad = 0x7fffffff;
-          if (lane < n) mine = a.rec[b + lane];
-          int rank = 0;
-          for (int j = 0; j < n; ++j) rank += __builtin_amdgcn_readlane(mine.pad, j) < mine.pad;
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the previous row's reads of the strip are done
-          if (lane < n) strip[wave][rank] = mine;
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          rs = strip[wave];
-        }
+    if (u >= U) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-        int i = 0;
-        for (; i + 3 < n; i += 4) {                   // four instances in flight
-          SegRec r[4]; float4 v0[4], v1[4];
+      for (int c = 0; c < CH; ++c) *(uint4*)(a.dYu + (int64_t)u * a.Dp + 512 * c + c0) = make_uint4(0u, 0u, 0u, 0u);
+      continue;
+    }
+    const int b = a.seg_start[u], e = a.seg_start[u + 1], n = e - b;
+    float acc[CH][8];
+    float bs = 0.f;
+    if (n <= 64) {
+      const SegRec* rs = a.rec + b;
+      if (n > 1) {                                    // instance order
+        SegRec mine; mine.alpha = 0.f; mine.beta = 0.f; mine.vec = 0; mine.pad = 0x7fffffff;
+        if (lane < n) mine = a.rec[b + lane];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += __builtin_amdgcn_readlane(mine.pad, j) < mine.pad;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the previous row's reads of the strip are done
+        if (lane < n) strip[wave][rank] = mine;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        rs = strip[wave];
+      }
 #pragma unroll
-          for (int k = 0; k < 4; ++k) r[k] = rs[i + k];
+      for (int c = 0; c < CH; ++c)
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float* vp = a.V + (int64_t)r[k].vec * D + c0;
-            v0[k] = *(const float4*)vp; v1[k] = *(const float4*)(vp + 4);
+        for (int j = 0; j < 8; ++j) acc[c][j] = 0.f;
+      constexpr int UN = CH == 1 ? 4 : 2;             // instances in flight
+      int i = 0;
+      for (; i + UN - 1 < n; i += UN) {
+        SegRec r[UN]; float4 v0[UN][CH], v1[UN][CH];
+#pragma unroll
+        for (int k = 0; k < UN; ++k) r[k] = rs[i + k];
+#pragma unroll
+        for (int k = 0; k < UN; ++k)
+#pragma unroll
+          for (int c = 0; c < CH; ++c) {
+            const float* vp = a.V + (int64_t)r[k].vec * D + 512 * c + c0;
+            v0[k][c] = *(const float4*)vp; v1[k][c] = *(const float4*)(vp + 4);
           }
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float al = r[k].alpha;
-            acc[0] += al * v0[k].x; acc[1] += al * v0[k].y; acc[2] += al * v0[k].z; acc[3] += al * v0[k].w;
-            acc[4] += al * v1[k].x; acc[5] += al * v1[k].y; acc[6] += al * v1[k].z; acc[7] += al * v1[k].w;
-            bs += r[k].beta;
+        for (int k = 0; k < UN; ++k) {
+          const float al = r[k].alpha;
+#pragma unroll
+          for (int c = 0; c < CH; ++c) {
+            acc[c][0] += al * v0[k][c].x; acc[c][1] += al * v0[k][c].y; acc[c][2] += al * v0[k][c].z; acc[c][3] += al * v0[k][c].w;
+            acc[c][4] += al * v1[k][c].x; acc[c][5] += al * v1[k][c].y; acc[c][6] += al * v1[k][c].z; acc[c][7] += al * v1[k][c].w;
           }
+          bs += r[k].beta;
         }
-        for (; i < n; ++i) {
-          const SegRec r = rs[i];
-          const float* vp = a.V + (int64_t)r.vec * D + c0;
+      }
+      for (; i < n; ++i) {
+        const SegRec r = rs[i];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const float* vp = a.V + (int64_t)r.vec * D + 512 * c + c0;
           const float4 v0 = *(const float4*)vp, v1 = *(const float4*)(vp + 4);
-          acc[0] += r.alpha * v0.x; acc[1] += r.alpha * v0.y; acc[2] += r.alpha * v0.z; acc[3] += r.alpha * v0.w;
-          acc[4] += r.alpha * v1.x; acc[5] += r.alpha * v1.y; acc[6] += r.alpha * v1.z; acc[7] += r.alpha * v1.w;
-          bs += r.beta;
+          acc[c][0] += r.alpha * v0.x; acc[c][1] += r.alpha * v0.y; acc[c][2] += r.alpha * v0.z; acc[c][3] += r.alpha * v0.w;
+          acc[c][4] += r.alpha * v1.x; acc[c][5] += r.alpha * v1.y; acc[c][6] += r.alpha * v1.z; acc[c][7] += r.alpha * v1.w;
         }
-      } else {                                        // order-independent sums
-        const double M = 98304.0;
-        double dacc[8], dbs = 0.0;
+        bs += r.beta;
+      }
+    } else {                                          // order-independent sums
+      const double M = 98304.0;
+      double dacc[CH][8], dbs = 0.0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dacc[j] = 0.0;
-        for (int i = b; i < e; ++i) {
-          const SegRec r = a.rec[i];
-          const float* vp = a.V + (int64_t)r.vec * D + c0;
+      for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dacc[c][j] = 0.0;
+      for (int i = b; i < e; ++i) {
+        const SegRec r = a.rec[i];
+        const double al = (double)r.alpha;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const float* vp = a.V + (int64_t)r.vec * D + 512 * c + c0;
           const float4 v0 = *(const float4*)vp, v1 = *(const float4*)(vp + 4);
           const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-          const double al = (double)r.alpha;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) dacc[j] += (al * (double)vv[j] + M) - M;
-          dbs += ((double)r.beta + M) - M;
+          for (int j = 0; j < 8; ++j) dacc[c][j] += (al * (double)vv[j] + M) - M;
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = (float)dacc[j];
-        bs = (float)dbs;
+        dbs += ((double)r.beta + M) - M;
       }
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[c][j] = (float)dacc[c][j];
+      bs = (float)dbs;
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const float* xp = a.H + (int64_t)u * D + 512 * c + c0;
+      const float4 x0 = *(const float4*)xp, x1 = *(const float4*)(xp + 4);
       const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
       float g[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        g[j] = xv[j] > 0.f ? acc[j] - bs * xv[j] : 0.f;
-        col[j] += g[j];
+        g[j] = xv[j] > 0.f ? acc[c][j] - bs * xv[j] : 0.f;
+        col[c][j] += g[j];
         if (T::id == 0) saturated |= fabsf(g[j]) > 65504.f;
       }
+      uint32_t o[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = T::from_float(g[2 * j]) | ((uint32_t)T::from_float(g[2 * j + 1]) << 16);
+      *(uint4*)(a.dYu + (int64_t)u * a.Dp + 512 * c + c0) = make_uint4(o[0], o[1], o[2], o[3]);
     }
-    *(uint4*)(a.dYu + (int64_t)u * a.Dp + c0) = make_uint4(o[0], o[1], o[2], o[3]);
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) cs[wave][c0 + j] = col[j];
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cs[wave][512 * c + c0 + j] = col[c][j];
   __syncthreads();
-  for (int d = threadIdx.x; d < 512; d += 256)
+  for (int d = threadIdx.x; d < 512 * CH; d += 256)
     a.dbp[(int64_t)blockIdx.x * D + d] = (cs[0][d] + cs[1][d] + cs[2][d] + cs[3][d]) * a.inv_sg;
   if (T::id == 0 && saturated && a.overflow_host) __hip_atomic_fetch_add(a.overflow_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 void launch_seg_bwd(int prec, const SegBwdArgs& a, hipStream_t s) {
-  if (prec == 0) VV_LAUNCH(k_seg_bwd<F16>, dim3(SEGB_BLOCKS), dim3(256), 0, s, a);
-  else VV_LAUNCH(k_seg_bwd<BF16>, dim3(SEGB_BLOCKS), dim3(256), 0, s, a);
+  const int ch = a.D / 512;
+#define VV_SB(T, CH) VV_LAUNCH((k_seg_bwd<T, CH>), dim3(SEGB_BLOCKS), dim3(256), 0, s, a)
+  if (prec == 0) { if (ch == 1) VV_SB(F16, 1); else VV_SB(F16, 2); }
+  else { if (ch == 1) VV_SB(BF16, 1); else VV_SB(BF16, 2); }
+#undef VV_SB
 }
 
 static int g_score_reg = 1;
