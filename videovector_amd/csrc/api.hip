@@ -17,7 +17,7 @@
 
 #include "vv_ctx.h"
 
-namespace vv { void set_wgrad_tr(bool on); void set_gemm_variant(int v); void set_ablate(int v); void set_fwd_mi(int v); void set_score_reg(int v); void set_score_waves(int v); void set_wgrad_sched(int v); void set_ph_mq(int v); int wgrad_max_ksteps_per_split(); int gemm_variant(); bool ablate_on(); }
+namespace vv { void set_wgrad_tr(bool on); void set_gemm_variant(int v); void set_ablate(int v); void set_score_reg(int v); void set_score_waves(int v); void set_ph_mq(int v); int gemm_variant(); bool ablate_on(); }
 using namespace vv;
 
 thread_local char vv_g_err[512] = "";
@@ -128,16 +128,12 @@ static int create_init(vv_ctx* c) {
   if (gv) set_gemm_variant(atoi(gv));
   const char* ab = getenv("VV_ABLATE");
   set_ablate(ab ? atoi(ab) : 0);
-  const char* fm = getenv("VV_FWD_MI");
-  set_fwd_mi(fm ? atoi(fm) : 0);
   const char* sr = getenv("VV_SCORE_REG");
   set_score_reg(sr ? atoi(sr) : 1);
   const char* sw = getenv("VV_SCORE_WAVES");
   set_score_waves(sw ? atoi(sw) : 8);
   const char* pq = getenv("VV_PH_MQ");
   set_ph_mq(pq ? atoi(pq) : 0);
-  const char* ws = getenv("VV_WGRAD_SCHED");
-  set_wgrad_sched(ws ? atoi(ws) : 0);
   const char* th = getenv("VV_TRACE_HOST");
   g_trace_host_ms = th ? atof(th) : -1.0;
   const char* sb = getenv("VV_SEG_BWD");
@@ -448,8 +444,6 @@ static int ensure_batch(vv_ctx* c, int B, int C, int Nn) {
   int S = (256 + tiles - 1) / tiles;
   if (S > total_steps) S = total_steps;
   if (S < 1) S = 1;
-  // the ring kernel keeps the split's row ids in LDS: bound the K range of one split
-  while ((total_steps + S - 1) / S > wgrad_max_ksteps_per_split() && S < total_steps) ++S;
   c->S = S; c->kps = (total_steps + S - 1) / S;
   c->slab_bytes = (size_t)S * c->Dp * c->Fp * 4;
   HIPCHK(hipMalloc(&c->slabs, c->slab_bytes));
@@ -565,7 +559,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
     // row goes through the GEMMs separately -- the dense path has no multiplicity factor
     c->dedup = 0; c->dedup_overflowed = true;
   }
-  const bool dd = c->dedup && cfg->dropout_ratio == 0.f && (gemm_variant() == 0 || gemm_variant() == 3 || gemm_variant() == 4 || (gemm_variant() >= 5 && gemm_variant() <= 8)) && !ablate_on();
+  const bool dd = c->dedup && cfg->dropout_ratio == 0.f && (gemm_variant() == 0 || (gemm_variant() >= 5 && gemm_variant() <= 8)) && !ablate_on();
   c->last_dedup = dd;
   if (!dd) launch_map_rows(didx, c->rows, c->R, c->Rp, (int32_t)c->n_rows, (int32_t)row_limit, s);
   if (dd) {

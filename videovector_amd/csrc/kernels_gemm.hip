@@ -1,4 +1,7 @@
-// kernels_gemm.hip -- the two MFMA kernels of the videovec training step (gfx950 only).
+// kernels_gemm.hip -- the round-1 forms of the two MFMA kernels of the videovec training step (gfx950 only) and the
+// launch dispatch.  The default kernels are the phase-staggered ones of kernels_gemm_ph.hip (VV_GEMM_VARIANT=5); these
+// are kept as the measured baseline (variant 0: forward 0.111 ms, weight gradient 0.109 ms at the de-duplicated size
+// against 0.081 / 0.071) and for the staging-transpose form of the weight gradient (VV_WGRAD_TR=0).
 //
 //   k_fwd_gemm   : ip2 = ReLU(X W^T + b) with X gathered row-by-row from the HBM-resident feature
 //                  table through the triplet index.  Replaces the data layer's batch copy +
@@ -384,331 +387,51 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm(WgradArgs a) {
   }
 }
 
-// =============================================================================================
-// Ring variants: the same tiles with K advanced 32 at a time through a 4-slot LDS ring and counted
-// waits, so that 2-3 units (64-96 KiB per CU) of LDS-DMA stay in flight ACROSS the barriers instead
-// of draining to zero every K-step.  (The 2-buffer kernels above are latency-bound: at most 64 KiB
-// in flight per CU against ~2 us of loaded HBM latency.)
-//   iteration u:  issue unit u+3 -> slot (u+3)&3   (last read in iteration u-1, released by its barrier)
-//                 ds_read + 32 MFMA on slot u&3
-//                 s_waitcnt vmcnt(8)   (own loads of unit u+1 landed; units u+2, u+3 stay in flight)
-//                 s_barrier            (everyone's unit u+1 landed, everyone done reading slot u&3)
-// =============================================================================================
-constexpr int RING = 4;
-constexpr int UNIT_K = 32;
-constexpr int UNIT_OP_BYTES = 256 * UNIT_K * 2;        // one operand, one unit: 16 KiB
-constexpr int UNIT_BYTES = 2 * UNIT_OP_BYTES;          // A + B: 32 KiB
-constexpr int RING_LDS_BYTES = RING * UNIT_BYTES;      // 128 KiB
-
-#define VV_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-
-__device__ __forceinline__ void ring_wait_and_barrier(int u, int nu) {
-  // loads still allowed in flight: 4 per unit issued after unit u+1
-  if (u + 3 < nu) VV_WAIT_VMCNT(8);
-  else if (u + 2 < nu) VV_WAIT_VMCNT(4);
-  else VV_WAIT_VMCNT(0);
-  __builtin_amdgcn_s_barrier();
-}
-
-// forward: LDS unit image per operand [256 rows][32 halves] = 64-B rows of 4 chunks,
-// chunk' = chunk ^ ((-(row>>2)) & 3)  (conflict-free ds_read_b128: tools/lds_banks.py)
-__device__ __forceinline__ int fw_f(int row) { return (-(row >> 2)) & 3; }
-
-template <typename T, bool DROP, bool VEC, int ABL = 0>
-__global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ring(FwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const int Dp = (int)round_up(a.D, D_ALIGN);
-  const int tilesN = Dp / BN;
-  const int R = a.n_dev ? *a.n_dev : a.R;
-  const int nact = a.n_dev ? ((R + BM - 1) / BM) * tilesN : (int)gridDim.x;
-  if (a.seq_host && blockIdx.x == 0 && tid == 0) __hip_atomic_store(a.seq_host, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  if ((int)blockIdx.x >= nact) return;
-  const int L = xcd_remap(blockIdx.x, nact);
-  const int m0 = (L / tilesN) * BM, n0 = (L % tilesN) * BN;
-  const int Fp = a.Fp;
-
-  const uint16_t* a_src[2];
-  const uint16_t* b_src[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int c = (i * 8 + wave) * 64 + lane;
-    const int row = c >> 2, lc = (c & 3) ^ fw_f(row);
-    a_src[i] = a.table + (int64_t)(m0 + row < R ? a.rows[m0 + row] : a.zero_row) * Fp + lc * 8;
-    b_src[i] = a.Wh + (int64_t)(n0 + row) * Fp + lc * 8;
-  }
-
-  f32x4 acc[8][4];
-#pragma unroll
-  for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  auto stage = [&](int u) {
-    unsigned char* As = smem + (u & (RING - 1)) * UNIT_BYTES;
-    unsigned char* Bs = As + UNIT_OP_BYTES;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      glds16(a_src[i] + u * UNIT_K, As + (i * 8 + wave) * 1024);
-      glds16(b_src[i] + u * UNIT_K, Bs + (i * 8 + wave) * 1024);
-    }
-  };
-
-  const int nu = Fp / UNIT_K;
-  stage(0);
-  if (nu > 1) stage(1);
-  if (nu > 2) stage(2);
-  if (nu > 2) VV_WAIT_VMCNT(8); else if (nu > 1) VV_WAIT_VMCNT(4); else VV_WAIT_VMCNT(0);
-  __builtin_amdgcn_s_barrier();
-
-  const int frow = lane & 15, fq = lane >> 4;
-  const int aoff = (wm * 128 + frow) * 64 + ((fq ^ fw_f(frow)) << 4);   // fw_f(row) depends on row&15 only
-  const int boff = (wn * 64 + frow) * 64 + ((fq ^ fw_f(frow)) << 4);
-  for (int u = 0; u < nu; ++u) {
-    if constexpr (!(ABL & 1)) { if (u + 3 < nu) stage(u + 3); }
-    const unsigned char* As = smem + (u & (RING - 1)) * UNIT_BYTES;
-    const unsigned char* Bs = As + UNIT_OP_BYTES;
-    i16x8 af[8], bf[4];
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
-      af[mi] = (ABL & 4) ? i16x8{1, 2, 3, 4, 5, 6, 7, (short)mi} : *(const i16x8*)(As + aoff + mi * 16 * 64);
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-      bf[ni] = (ABL & 4) ? i16x8{1, 2, 3, 4, 5, 6, 7, (short)ni} : *(const i16x8*)(Bs + boff + ni * 16 * 64);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma_abl<T, ABL>(bf[ni], af[mi], acc[mi][ni]);
-    __builtin_amdgcn_s_setprio(0);
-    ring_wait_and_barrier(u, nu);
-  }
-
-  const float descale = 1.0f / (a.scales->sx * a.scales->sw_cur);
-  const float dscale = DROP ? 1.0f / (1.0f - a.drop_ratio) : 1.0f;
-  const float lo = a.relu ? 0.f : -INFINITY;
-#pragma unroll
-  for (int mi = 0; mi < 8; ++mi) {
-    const int m = m0 + wm * 128 + mi * 16 + frow;
-    if (m >= R) continue;
-    int64_t ref_row = 0;
-    if (DROP) {
-      const int bb = m / a.CN, ch = m - bb * a.CN;
-      ref_row = (int64_t)ch * a.B + bb;
-    }
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int n = n0 + wn * 64 + ni * 16 + fq * 4;
-      if (n >= a.D) continue;
-      float v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float bj = (n + j < a.D) ? a.bias[n + j] : 0.f;
-        v[j] = fmaxf(acc[mi][ni][j] * descale + bj, lo);
-        if (DROP) {
-          const uint64_t e = (uint64_t)(ref_row * a.D + n + j);
-          bool keep;
-          if (a.mask) keep = (n + j < a.D) && a.mask[e] != 0;
-          else keep = (float)(mix64(a.drop_seed, e) >> 40) * (1.0f / 16777216.0f) >= a.drop_ratio;
-          v[j] = keep ? v[j] * dscale : 0.f;
-        }
-      }
-      float* dst = a.H + (int64_t)m * a.D + n;
-      if (VEC) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
-      else
-        for (int j = 0; j < 4; ++j) if (n + j < a.D) dst[j] = v[j];
-    }
-  }
-}
-
-// weight gradient: unit image per operand [32 k-rows][256 halves] (512-B rows), same swizzle and
-// transposed reads as k_wgrad_gemm.  The table-row ids of the split's whole K range are copied to
-// LDS once (the last 32 KiB of the 160 KiB), so the loop issues no ordinary global loads: hipcc
-// would otherwise wait vmcnt(0) on them and drain the ring.
-constexpr int WG_IDS_MAX = 8192;
-constexpr int WG_RING_LDS_BYTES = RING_LDS_BYTES + WG_IDS_MAX * 4;   // 160 KiB
-
-template <typename T, int ABL = 0>
-__global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ring(WgradArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  int32_t* ids = (int32_t*)(smem + RING_LDS_BYTES);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const int tilesM = a.Dp / BM, tilesN = a.Fp / BN;
-  const int L = xcd_remap(blockIdx.x, gridDim.x);
-  const int tm = L % tilesM, tn = (L / tilesM) % tilesN, sp = L / (tilesM * tilesN);
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int total_units = a.Rp / UNIT_K;
-  const int u_begin = sp * a.ksteps_per_split * (BK / UNIT_K);
-  int u_end = u_begin + a.ksteps_per_split * (BK / UNIT_K);
-  if (u_end > total_units) u_end = total_units;
-  const int nu = u_end > u_begin ? u_end - u_begin : 0;
-
-  for (int i = tid; i < nu * UNIT_K; i += GEMM_THREADS) ids[i] = a.rows[(int64_t)u_begin * UNIT_K + i];
-  __syncthreads();
-
-  int srow[2], slc[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int c = (i * 8 + wave) * 64 + lane;
-    srow[i] = c >> 5;
-    slc[i] = (c & 31) ^ (wg_h(srow[i]) << 1);
-  }
-
-  f32x4 acc[8][4];
-#pragma unroll
-  for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  auto stage = [&](int u) {
-    unsigned char* As = smem + (u & (RING - 1)) * UNIT_BYTES;
-    unsigned char* Bs = As + UNIT_OP_BYTES;
-    const int64_t kg = (int64_t)(u_begin + u) * UNIT_K;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int32_t rid = ids[u * UNIT_K + srow[i]];
-      glds16(a.dYh + (kg + srow[i]) * a.Dp + m0 + slc[i] * 8, As + (i * 8 + wave) * 1024);
-      glds16(a.table + (int64_t)rid * a.Fp + n0 + slc[i] * 8, Bs + (i * 8 + wave) * 1024);
-    }
-  };
-
-  if (nu > 0) {
-    stage(0);
-    if (nu > 1) stage(1);
-    if (nu > 2) stage(2);
-    if (nu > 2) VV_WAIT_VMCNT(8); else if (nu > 1) VV_WAIT_VMCNT(4); else VV_WAIT_VMCNT(0);
-    __builtin_amdgcn_s_barrier();
-  }
-
-  const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
-  const int row1 = 8 * g + q;
-  const int hx = wg_h(row1) << 1;
-  const int rbase = row1 * 512 + (pp & 1) * 8;
-  for (int u = 0; u < nu; ++u) {
-    if constexpr (!(ABL & 1)) { if (u + 3 < nu) stage(u + 3); }
-    const unsigned char* As = smem + (u & (RING - 1)) * UNIT_BYTES;
-    const unsigned char* Bs = As + UNIT_OP_BYTES;
-    i16x8 af[8], bf[4];
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
-      const int off = rbase + (((wm * 16 + mi * 2 + (pp >> 1)) ^ hx) << 4);
-      const i16x4 lo = tr_read<ABL>(As + off);
-      const i16x4 hi = tr_read<ABL>(As + off + 4 * 512);
-      af[mi] = i16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    }
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int off = rbase + (((wn * 8 + ni * 2 + (pp >> 1)) ^ hx) << 4);
-      const i16x4 lo = tr_read<ABL>(Bs + off);
-      const i16x4 hi = tr_read<ABL>(Bs + off + 4 * 512);
-      bf[ni] = i16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    }
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma_abl<T, ABL>(bf[ni], af[mi], acc[mi][ni]);
-    __builtin_amdgcn_s_setprio(0);
-    ring_wait_and_barrier(u, nu);
-  }
-
-  float* slab = a.slabs + (int64_t)sp * a.Dp * a.Fp;
-#pragma unroll
-  for (int mi = 0; mi < 8; ++mi) {
-    const int m = m0 + wm * 128 + mi * 16 + li;
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int n = n0 + wn * 64 + ni * 16 + g * 4;
-      *(float4*)(slab + (int64_t)m * a.Fp + n) =
-          make_float4(acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]);
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------- launchers ----
+// VV_GEMM_VARIANT: 5 (default) = the phase-staggered kernels of kernels_gemm_ph.hip; 6 / 7 = only the weight-gradient /
+// only the forward one of them; 8 = phase-staggered forward + four-wave weight gradient; 0 = the round-1 kernels of this
+// file (two-buffer K = 64 steps, full drain per step), kept as the measured baseline and for VV_WGRAD_TR=0 (operands
+// transposed while staging instead of transposed LDS reads).  VV_ABLATE applies to the phase-staggered kernels.
 static bool g_wgrad_tr = true;
-static int g_wgrad_sched = 0;       // VV_WGRAD_SCHED: bit0 interleaved staging, bit1 setprio (experiments)
-void set_wgrad_sched(int v) { g_wgrad_sched = v; }
-static int g_fwd_mi = 0;            // VV_FWD_MI: force the forward tile height (0 = automatic)
-void set_fwd_mi(int v) { g_fwd_mi = v; }
 static int g_ablate = 0;
 void set_ablate(int v) { g_ablate = v; }
-static int g_gemm_variant = 5;     // 5 = phase-staggered kernels (kernels_gemm_ph.hip, default); 6 / 7 = only the weight-gradient / forward one;
-                                   // 0 = two-buffer K=64 kernels (round 1), 1 / 4 = 4-slot ring K=32 kernels, 3 = 0 with burst staging
+static int g_gemm_variant = 5;
 void set_wgrad_tr(bool on) { g_wgrad_tr = on; }
 void set_gemm_variant(int v) { g_gemm_variant = v; }
 int gemm_variant() { return g_gemm_variant; }
 bool ablate_on() { return g_ablate != 0; }
-int wgrad_max_ksteps_per_split() { return g_gemm_variant == 1 ? WG_IDS_MAX / BK : (1 << 30); }
 
 template <typename T, bool DROP, bool VEC>
 static void launch_fwd_t(const FwdArgs& a, hipStream_t s) {
+  const int Rp = (int)round_up(a.R, R_ALIGN), Dp = (int)round_up(a.D, D_ALIGN);
+  const dim3 block(GEMM_THREADS);
+  if constexpr (!DROP && VEC) {
+    // balanced M tiling: the tile height 32*MI that needs the least (rounds of 256 WGs) x (tile height).  Dedup mode sizes
+    // the tiles for the expected row count (R_hint, a few steps old: 3 % + 64 rows of slack) while the grid covers the
+    // worst case R; surplus workgroups exit at once.
+    const int Rh = a.n_dev && a.R_hint > 0 ? (int)std::min<long>(a.R, a.R_hint + a.R_hint / 32 + 64) : a.R;
+    int best = 8; long best_cost = -1;
+    for (int mi = 8; mi >= (a.n_dev ? 4 : 7); --mi) {
+      const long tiles = ((Rh + 32 * mi - 1) / (32 * mi)) * (long)(Dp / BN);
+      const long cost = ((tiles + 255) / 256) * mi;
+      if (best_cost < 0 || cost < best_cost) { best = mi; best_cost = cost; }
+    }
+#define VV_FWD_MI(M)                                                                                          \
+    if (best == M) {                                                                                         \
+      static bool o = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm<T, DROP, VEC, 0, M, 1>,             \
+                       hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES), true);                   \
+      (void)o;                                                                                               \
+      const dim3 g2(((a.R + 32 * M - 1) / (32 * M)) * (Dp / BN));                                            \
+      VV_LAUNCH((k_fwd_gemm<T, DROP, VEC, 0, M, 1>), g2, block, GEMM_LDS_BYTES, s, a);                       \
+      return;                                                                                                \
+    }
+    VV_FWD_MI(8) VV_FWD_MI(7) VV_FWD_MI(6) VV_FWD_MI(5) VV_FWD_MI(4)
+#undef VV_FWD_MI
+  }
   static bool once = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm<T, DROP, VEC>,
                       hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES), true);
   (void)once;
-  const int Rp = (int)round_up(a.R, R_ALIGN), Dp = (int)round_up(a.D, D_ALIGN);
-  const dim3 grid((Rp / BM) * (Dp / BN)), block(GEMM_THREADS);
-  if constexpr (T::id == 0 && !DROP && VEC) {
-    if (g_ablate) {
-#define VV_ABL_FWD(N)                                                                              \
-      if (g_ablate == N) {                                                                         \
-        if (g_gemm_variant == 1) {                                                                 \
-          (void)hipFuncSetAttribute((const void*)k_fwd_gemm_ring<T, DROP, VEC, N>,                 \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES);   \
-          VV_LAUNCH((k_fwd_gemm_ring<T, DROP, VEC, N>), grid, block, RING_LDS_BYTES, s, a); \
-        } else {                                                                                   \
-          (void)hipFuncSetAttribute((const void*)k_fwd_gemm<T, DROP, VEC, N>,                      \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);   \
-          VV_LAUNCH((k_fwd_gemm<T, DROP, VEC, N>), grid, block, GEMM_LDS_BYTES, s, a);    \
-        }                                                                                          \
-        return;                                                                                    \
-      }
-      VV_ABL_FWD(1) VV_ABL_FWD(2) VV_ABL_FWD(3) VV_ABL_FWD(6) VV_ABL_FWD(7)
-#undef VV_ABL_FWD
-    }
-  }
-  if constexpr (!DROP && VEC) {
-    // balanced M tiling: the tile height 32*MI that needs the least (rounds of 256 WGs) x (tile height).
-    // Dedup mode sizes the tiles for the expected row count (R_hint, the previous step's) while the grid
-    // covers the worst case R; surplus workgroups exit at once.
-    if (g_gemm_variant != 1) {
-      // the hint is a few steps old: leave 3 % + 64 rows of slack so that a slightly larger batch does not
-      // spill into one more round of workgroups
-      const int Rh = a.n_dev && a.R_hint > 0 ? (int)std::min<long>(a.R, a.R_hint + a.R_hint / 32 + 64) : a.R;
-      int best = 8; long best_cost = -1;
-      for (int mi = 8; mi >= (a.n_dev ? 4 : 7); --mi) {
-        const long tiles = ((Rh + 32 * mi - 1) / (32 * mi)) * (long)(Dp / BN);
-        const long cost = ((tiles + 255) / 256) * mi;
-        if (best_cost < 0 || cost < best_cost) { best = mi; best_cost = cost; }
-      }
-      if (g_fwd_mi) best = g_fwd_mi;
-      if (getenv("VV_DEBUG_MI")) fprintf(stderr, "fwd tile: hint %d R %d -> MI %d\n", a.R_hint, a.R, best);
-      const int sched = g_gemm_variant != 3;     // default: interleaved staging + setprio (variant 3 = burst staging, for A/B)
-#define VV_FWD_MI(M, SC)                                                                                      \
-      if (best == M && sched == SC) {                                                                        \
-        static bool o = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm<T, DROP, VEC, 0, M, SC>,          \
-                         hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES), true);                 \
-        (void)o;                                                                                             \
-        const dim3 g2(((a.R + 32 * M - 1) / (32 * M)) * (Dp / BN));                                          \
-        VV_LAUNCH((k_fwd_gemm<T, DROP, VEC, 0, M, SC>), g2, block, GEMM_LDS_BYTES, s, a);           \
-        return;                                                                                              \
-      }
-      VV_FWD_MI(8, 1) VV_FWD_MI(7, 1) VV_FWD_MI(6, 1) VV_FWD_MI(5, 1) VV_FWD_MI(4, 1)
-      VV_FWD_MI(7, 0) VV_FWD_MI(6, 0)
-#undef VV_FWD_MI
-    }
-  }
-  if (g_gemm_variant == 1 || g_gemm_variant == 4) {
-    static bool once2 = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ring<T, DROP, VEC>,
-                         hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES), true);
-    (void)once2;
-    VV_LAUNCH((k_fwd_gemm_ring<T, DROP, VEC>), grid, block, RING_LDS_BYTES, s, a);
-    return;
-  }
+  const dim3 grid((Rp / BM) * (Dp / BN));
   VV_LAUNCH((k_fwd_gemm<T, DROP, VEC>), grid, block, GEMM_LDS_BYTES, s, a);
 }
 
@@ -721,7 +444,7 @@ static void launch_fwd_p(const FwdArgs& a, hipStream_t s) {
 
 void launch_fwd_gemm_ph(int prec, const FwdArgs& a, hipStream_t s);
 void launch_fwd_gemm(int prec, const FwdArgs& a, hipStream_t s) {
-  if (g_gemm_variant == 5 || g_gemm_variant == 7 || g_gemm_variant == 8) { FwdArgs b = a; b.abl = g_ablate; launch_fwd_gemm_ph(prec, b, s); return; }   // 5: both new, 6: new wgrad only, 7: new fwd only
+  if (g_gemm_variant == 5 || g_gemm_variant == 7 || g_gemm_variant == 8) { FwdArgs b = a; b.abl = g_ablate; launch_fwd_gemm_ph(prec, b, s); return; }
   if (prec == 0) launch_fwd_p<F16>(a, s); else launch_fwd_p<BF16>(a, s);
 }
 
@@ -734,53 +457,11 @@ static void launch_wgrad_t(const WgradArgs& a, hipStream_t s) {
   VV_LAUNCH((k_wgrad_gemm<T, TR>), grid, block, GEMM_LDS_BYTES, s, a);
 }
 
-template <typename T>
-static void launch_wgrad_ring_t(const WgradArgs& a, hipStream_t s) {
-  static bool once = ((void)hipFuncSetAttribute((const void*)k_wgrad_gemm_ring<T>,
-                      hipFuncAttributeMaxDynamicSharedMemorySize, WG_RING_LDS_BYTES), true);
-  (void)once;
-  const dim3 grid((a.Dp / BM) * (a.Fp / BN) * a.S), block(GEMM_THREADS);
-  VV_LAUNCH((k_wgrad_gemm_ring<T>), grid, block, WG_RING_LDS_BYTES, s, a);
-}
-
 void launch_wgrad_gemm_ph(int prec, const WgradArgs& a, hipStream_t s);
 void launch_wgrad_gemm_w4(int prec, const WgradArgs& a, hipStream_t s);
 void launch_wgrad_gemm(int prec, const WgradArgs& a, hipStream_t s) {
-  if (g_gemm_variant == 8 && g_wgrad_tr) { launch_wgrad_gemm_w4(prec, a, s); return; }     // 8: phase-staggered forward + four-wave weight gradient
+  if (g_gemm_variant == 8 && g_wgrad_tr) { launch_wgrad_gemm_w4(prec, a, s); return; }
   if ((g_gemm_variant == 5 || g_gemm_variant == 6) && g_wgrad_tr) { WgradArgs b = a; b.abl = g_ablate; launch_wgrad_gemm_ph(prec, b, s); return; }
-  if (g_ablate && prec == 0) {
-    const dim3 grid((a.Dp / BM) * (a.Fp / BN) * a.S), block(GEMM_THREADS);
-#define VV_ABL_WG(N)                                                                               \
-    if (g_ablate == N) {                                                                           \
-      if (g_gemm_variant == 1) {                                                                   \
-        (void)hipFuncSetAttribute((const void*)k_wgrad_gemm_ring<F16, N>,                          \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, WG_RING_LDS_BYTES);  \
-        VV_LAUNCH((k_wgrad_gemm_ring<F16, N>), grid, block, WG_RING_LDS_BYTES, s, a);     \
-      } else {                                                                                     \
-        (void)hipFuncSetAttribute((const void*)k_wgrad_gemm<F16, true, N>,                         \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);     \
-        VV_LAUNCH((k_wgrad_gemm<F16, true, N>), grid, block, GEMM_LDS_BYTES, s, a);       \
-      }                                                                                            \
-      return;                                                                                      \
-    }
-    VV_ABL_WG(1) VV_ABL_WG(2) VV_ABL_WG(3) VV_ABL_WG(6) VV_ABL_WG(7)
-#undef VV_ABL_WG
-  }
-  if (g_wgrad_sched && g_wgrad_tr && prec == 0 && g_gemm_variant != 1) {    // experimental schedules (f16 only)
-    const dim3 grid((a.Dp / BM) * (a.Fp / BN) * a.S), block(GEMM_THREADS);
-#define VV_WG_SCHED(N)                                                                                         \
-    if (g_wgrad_sched == N) {                                                                                  \
-      (void)hipFuncSetAttribute((const void*)k_wgrad_gemm<F16, true, 0, N>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES); \
-      VV_LAUNCH((k_wgrad_gemm<F16, true, 0, N>), grid, block, GEMM_LDS_BYTES, s, a);                    \
-      return;                                                                                                  \
-    }
-    VV_WG_SCHED(1) VV_WG_SCHED(2) VV_WG_SCHED(3)
-#undef VV_WG_SCHED
-  }
-  if (g_gemm_variant == 1 && g_wgrad_tr && a.ksteps_per_split * BK <= WG_IDS_MAX) {
-    if (prec == 0) launch_wgrad_ring_t<F16>(a, s); else launch_wgrad_ring_t<BF16>(a, s);
-    return;
-  }
   if (prec == 0) { if (g_wgrad_tr) launch_wgrad_t<F16, true>(a, s); else launch_wgrad_t<F16, false>(a, s); }
   else { if (g_wgrad_tr) launch_wgrad_t<BF16, true>(a, s); else launch_wgrad_t<BF16, false>(a, s); }
 }
