@@ -226,6 +226,7 @@ def main():
     class Run:
         """One engine + its step function; source = 'ring' (end to end) or 'resident'."""
         n_comm = 0
+        comm_kind = None                          # "torch" once a run had to fall back from the library's communicator
 
         def __init__(self, prec, dedup):
             self.prec = prec
@@ -249,8 +250,23 @@ def main():
                 if rank == 0 and os.path.exists(comm_id_path + "_%d" % Run.n_comm):
                     os.unlink(comm_id_path + "_%d" % Run.n_comm)
                 dist.barrier()
-                self.eng.comm_init(world, rank, comm_id_path + "_%d" % Run.n_comm, comm_transport)
-                self.eng.comm_overlap(mode == "overlap")
+                ok = 1
+                try:
+                    self.eng.comm_init(world, rank, comm_id_path + "_%d" % Run.n_comm, comm_transport)
+                    self.eng.comm_overlap(mode == "overlap")
+                except vv.VVError as e:
+                    ok = 0
+                    print("rank %d: library communicator failed (%s)" % (rank, e), file=sys.stderr)
+                flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:
+                    # some rank could not bring the library's communicator up: every rank falls back to the collective
+                    # of torch.distributed (same RCCL, same exact synchronous schedule) and the line says so
+                    if ok:
+                        self.eng.comm_destroy()
+                    Run.comm_kind = "torch"
+                    self.grads = torch.zeros(D * F + D, dtype=torch.float32, device=dev)
+                    self.eng.grads_bind(self.grads.data_ptr())
             self.it = 0
 
         def reset(self, dedup):
@@ -271,7 +287,7 @@ def main():
                     if diag: host_ms.append((time.perf_counter() - th0) * 1e3)
                 else:
                     eng.forward_backward(cfg, idx_dev_ptr=idx_dev.data_ptr() + i * stride)
-                if comm == "torch":
+                if comm == "torch" or Run.comm_kind == "torch":
                     dist.all_reduce(self.grads)
                 elif comm == "lib":
                     eng.allreduce_grads()          # (vv_apply_update would call it too; explicit for the reader)
@@ -418,7 +434,8 @@ def main():
                                   % (args.sampler_threads, args.prefetch_depth, ", POSIX shared-memory ring" if world > 1 else ""),
                        "comm": {"none": "none", "lib": "the library's RCCL communicator on its own communication stream (vv_comm_*)"
                                 if comm_transport == "rccl" else "the library's shared-memory test transport (one-device hook)",
-                                "torch": "torch.distributed.all_reduce"}[comm],
+                                "torch": "torch.distributed.all_reduce"}[Run.comm_kind or comm]
+                               + (" (fallback: the library's communicator did not come up)" if Run.comm_kind == "torch" and comm == "lib" else ""),
                        "allreduce": {"none": "none (1 GPU)", "sync": "synchronous (exact SGD), exposed",
                                      "overlap": "exact SGD, chunked all-reduce overlapped with the weight-gradient kernel",
                                      "stale": "overlapped with the next iteration's forward/backward "
