@@ -177,10 +177,35 @@ def main():
         sampler.prefetch_start(depth=args.prefetch_depth, threads=args.sampler_threads,
                                shm_name=ring_name if world > 1 else None, consumers=world)
         ring = sampler.ring()
+    ring_consumer = rank
+    sampler_note = ""
     if dist:
         dist.barrier()
-    if rank != 0:
-        ring = vv.BatchRing.attach(ring_name, timeout_s=120.0)
+        ok = 1
+        if rank != 0:
+            try:
+                if os.environ.get("VV_BENCH_PRIVATE_SAMPLERS") == "1":
+                    raise vv.VVError("forced by VV_BENCH_PRIVATE_SAMPLERS")
+                ring = vv.BatchRing.attach(ring_name, timeout_s=120.0)
+            except vv.VVError as e:
+                ok = 0
+                print("rank %d: cannot attach the node's batch ring (%s)" % (rank, e), file=sys.stderr)
+        flag = torch.tensor([ok], dtype=torch.int32)
+        flag_dev = flag.to(torch.device("cuda", local_rank))
+        dist.all_reduce(flag_dev, op=dist.ReduceOp.MIN)
+        if int(flag_dev.item()) == 0:
+            # the shared-memory ring is not usable on this node: every rank runs the identical sampler of the global
+            # batch for itself (the same indices; N samplers' worth of host work) and the line says so
+            if rank == 0:
+                sampler.prefetch_stop()
+                sampler.close()
+            elif ok:
+                ring.close()
+            sampler = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, **skw)
+            sampler.prefetch_start(depth=args.prefetch_depth, threads=args.sampler_threads, shm_name=None, consumers=1)
+            ring = sampler.ring()
+            ring_consumer = 0
+            sampler_note = " (fallback: one identical sampler per rank, the shared-memory ring could not be attached)"
 
     # batches for the resident-indices legs come from a second, identical sampler (rank-local slice of the global batch)
     n_res = 0 if args.no_extra_legs else Wm + K
@@ -283,7 +308,7 @@ def main():
             else:
                 if source == "ring":
                     th0 = time.perf_counter()
-                    eng.forward_backward_ring(cfg, ring, consumer=rank, item_begin=rank * B_PER_GPU)
+                    eng.forward_backward_ring(cfg, ring, consumer=ring_consumer, item_begin=rank * B_PER_GPU)
                     if diag: host_ms.append((time.perf_counter() - th0) * 1e3)
                 else:
                     eng.forward_backward(cfg, idx_dev_ptr=idx_dev.data_ptr() + i * stride)
@@ -431,7 +456,7 @@ def main():
                        "global_batch": Bg, "triplets_per_step": Bg * NN,
                        "parallelism": "dp%d" % world, "items_per_s": value / NN, "dedup": args.dedup,
                        "sampler": "one per node (rank 0), %d stage thread(s), prefetch depth %d%s"
-                                  % (args.sampler_threads, args.prefetch_depth, ", POSIX shared-memory ring" if world > 1 else ""),
+                                  % (args.sampler_threads, args.prefetch_depth, ", POSIX shared-memory ring" if world > 1 else "") + sampler_note,
                        "comm": {"none": "none", "lib": "the library's RCCL communicator on its own communication stream (vv_comm_*)"
                                 if comm_transport == "rccl" else "the library's shared-memory test transport (one-device hook)",
                                 "torch": "torch.distributed.all_reduce"}[Run.comm_kind or comm]

@@ -36,3 +36,20 @@ def test_bench_two_ranks_on_one_device(mode):
         assert ("torch" in d["config"]["comm"]) == (mode == "torch-sync")
     else:
         assert d["gpu_path_only"]["value"] > 0 and d["step_ms_stats"]["n"] == 4
+
+
+def test_bench_fallbacks_keep_the_run_alive():
+    """If a rank cannot attach the node's batch ring, every rank runs the identical global sampler for itself (same
+    indices, hence the same loss as the shared ring gives), and the JSON line says so."""
+    losses = {}
+    for tag, extra_env in (("ring", {}), ("private", {"VV_BENCH_PRIVATE_SAMPLERS": "1"})):
+        env = dict(os.environ, VV_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                            "--master-addr", "127.0.0.1", "--master-port", "29531" if tag == "ring" else "29533",
+                            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
+                            "--no-extra-legs"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+        assert ("fallback" in d["config"]["sampler"]) == (tag == "private")
+        losses[tag] = d["final_loss"]
+    assert losses["ring"] == losses["private"]
