@@ -233,7 +233,7 @@ int vv_destroy(vv_ctx* c) {
 int vv_set_dedup(vv_ctx* c, int on) {
   if (!c) return fail(VV_ERR_ARG, "vv_set_dedup: ctx is NULL");
   c->dedup = on != 0;
-  if (on && c->U_host) { c->U_host[1] = 0; c->dedup_overflowed = false; }   // a fresh start for the overflow guard
+  if (c->U_host) { c->U_host[1] = 0; c->sg_shift = 0; c->sg_clean_steps = 0; }   // a fresh start for the gradient scale
   return VV_OK;
 }
 
@@ -554,11 +554,6 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
 
   // De-duplicate the batch rows when dropout is off (with dropout every instance has its own mask on
   // top of the shared projection; that path stays dense).  Needs the default two-buffer GEMM kernels.
-  if (c->dedup && *(volatile int32_t*)(c->U_host + 1) > 0) {
-    // an earlier step's per-row gradient sums left the f16 range (k_segsum saturated them): from here on every sampled
-    // row goes through the GEMMs separately -- the dense path has no multiplicity factor
-    c->dedup = 0; c->dedup_overflowed = true;
-  }
   const bool dd = c->dedup && cfg->dropout_ratio == 0.f && (gemm_variant() == 0 || (gemm_variant() >= 5 && gemm_variant() <= 8)) && !ablate_on();
   c->last_dedup = dd;
   if (!dd) launch_map_rows(didx, c->rows, c->R, c->Rp, (int32_t)c->n_rows, (int32_t)row_limit, s);
@@ -615,7 +610,19 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   const int64_t gcount = cfg->global_count > 0 ? cfg->global_count : count;
   // half-precision gradient scale: a power of two near the loss count keeps dY*sg around 1
   int e; frexpf((float)gcount, &e);
-  c->sg = c->prec == VV_PREC_F16 ? ldexpf(1.f, e) : 1.f;
+  // ... and follows the data like the loss scale of any half-precision trainer: when an earlier step reported 16-bit
+  // gradient values past f16's 65504 (they were stored saturated -- never inf / NaN -- and counted in host-visible
+  // memory: a row whose embedding norm is tiny has gradients ~ 1 / norm, times its multiplicity in the batch), the scale
+  // drops by 2^4 for the following steps; after 2000 clean steps it climbs back one power of two.  A power of two
+  // either way: exact to undo.
+  if (c->prec == VV_PREC_F16) {
+    if (*(volatile int32_t*)(c->U_host + 1) > 0) {
+      *(volatile int32_t*)(c->U_host + 1) = 0;
+      c->sg_shift = std::min(c->sg_shift + 4, 48);
+      c->sg_clean_steps = 0; ++c->sg_overflows;
+    } else if (c->sg_shift > 0 && ++c->sg_clean_steps >= 2000) { --c->sg_shift; c->sg_clean_steps = 0; }
+  }
+  c->sg = c->prec == VV_PREC_F16 ? ldexpf(1.f, e - c->sg_shift) : 1.f;
   c->last_loss_weight = cfg->loss_weight;
 
   ScoreArgs sa;
@@ -628,6 +635,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   sa.sg = c->sg;
   sa.map = dd ? c->dd_map : nullptr; sa.seg_start = dd ? c->dd_seg : nullptr; sa.ord = dd ? c->dd_ord : nullptr;
   sa.item_w = cfg->item_weight ? c->item_w : nullptr;
+  sa.overflow_host = c->U_host_dev + 1;
 
   // de-duplicated batches of the supported shape: the backward stays factored per instance and is summed per distinct
   // row (k_score_fwd + k_seg_bwd); otherwise per-instance 16-bit gradient rows (+ k_segsum when de-duplicated)

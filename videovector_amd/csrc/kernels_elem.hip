@@ -172,6 +172,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
   // ---- phase 4: backward of the normalised target / negative rows, column-parallel: a thread
   // owns one group of W consecutive columns (16-B loads) and walks the rows of its row group,
   // keeping its dAh / db partial sums in registers (deterministic order, no atomics).
+  int sat = 0;                                // f16: gradient values past 65504 (stored saturated, reported to the host)
   constexpr int W = VEC ? 4 : 1;
   const int Dv = D / W;                       // column groups
   const int Dvp = Dv < SL_THREADS ? Dv : SL_THREADS;
@@ -203,6 +204,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
           float g = r1 * ya[e] - r2 * xv[e];            // already times sg (a power of two: exact)
           g = xv[e] > 0.f ? g : 0.f;
           pb[e] += g;
+          if (T::id == 0) sat |= fabsf(g) > 65504.f;
           o[e] = T::from_float(g);
         }
         if (VEC) *(uint2*)dy = make_uint2(o[0] | ((uint32_t)o[1 % W] << 16), o[2 % W] | ((uint32_t)o[3 % W] << 16));
@@ -234,10 +236,12 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
       float g = a.coeff[j - 1] * dA * a.drop_scale;
       g = x > 0.f ? g : 0.f;
       dbv += g;
+      if (T::id == 0) sat |= fabsf(g * a.sg) > 65504.f;
       a.dYh[(int64_t)ooff[j] * a.Dp + d] = T::from_float(g * a.sg);
     }
     a.dbp[(int64_t)b * D + d] = dbv;
   }
+  if (T::id == 0 && sat && a.overflow_host) __hip_atomic_fetch_add(a.overflow_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Register-resident variant for small (1+Nn) x D: each wave keeps its target / negative rows in
@@ -386,6 +390,7 @@ __global__ __launch_bounds__(64 * NW) void k_score_loss_reg(ScoreArgs a) {
   // scalars k1 = c n^2/den, k2 = c t/den (both times drop_scale * sg) and k3 = c/(n+eps); per element
   // g*sg = k1*Ah - k2*x (masked), dAh += k3*x, db*sg += g*sg.  sg is a power of two, so carrying it through the sums
   // and dividing at the end changes no bit.
+  int sat = 0;
   float4 pa[DV], pb[DV];
 #pragma unroll
   for (int v = 0; v < DV; ++v) { pa[v] = make_float4(0.f, 0.f, 0.f, 0.f); pb[v] = pa[v]; }
@@ -409,6 +414,7 @@ __global__ __launch_bounds__(64 * NW) void k_score_loss_reg(ScoreArgs a) {
       for (int e = 0; e < 4; ++e) {
         g[e] = k1 * yv[e] - k2 * xv[e];
         g[e] = xv[e] > 0.f ? g[e] : 0.f;
+        if (T::id == 0) sat |= fabsf(g[e]) > 65504.f;
       }
       pa[v].x += k3 * xv[0]; pa[v].y += k3 * xv[1]; pa[v].z += k3 * xv[2]; pa[v].w += k3 * xv[3];
       pb[v].x += g[0]; pb[v].y += g[1]; pb[v].z += g[2]; pb[v].w += g[3];
@@ -452,11 +458,13 @@ __global__ __launch_bounds__(64 * NW) void k_score_loss_reg(ScoreArgs a) {
         float g = cf[j] * dA * a.drop_scale;
         g = cx[j][v] > 0.f ? g : 0.f;
         dbv += g;
+        if (T::id == 0) sat |= fabsf(g * a.sg) > 65504.f;
         a.dYh[(int64_t)ooff[j + 1] * a.Dp + d] = T::from_float(g * a.sg);
       }
     }
     a.dbp[(int64_t)b * D + d] = dbv;
   }
+  if (T::id == 0 && sat && a.overflow_host) __hip_atomic_fetch_add(a.overflow_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 #undef HROW
 

@@ -67,7 +67,8 @@ struct vv_ctx {
   // row de-duplication (kernels_dedup.hip)
   int dedup = 1;                    // 1 = on whenever dropout is off (VV_DEDUP / vv_set_dedup)
   bool last_dedup = false;          // what the last forward/backward pass used
-  bool dedup_overflowed = false;    // de-duplication was switched off because f16 gradient sums saturated
+  int sg_shift = 0;                 // powers of two taken off the f16 gradient scale after saturated values were reported
+  int sg_clean_steps = 0; int64_t sg_overflows = 0;
   unsigned long long* dd_key = nullptr; int64_t dd_key_cap = 0;
   unsigned long long* dd_agg = nullptr; int dd_agg_stride = 0;
   int32_t *dd_slot_of = nullptr, *dd_uniq = nullptr, *dd_map = nullptr, *dd_ord = nullptr, *dd_cnt = nullptr,

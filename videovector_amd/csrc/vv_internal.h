@@ -89,6 +89,7 @@ struct ScoreArgs {
   const int32_t* map = nullptr;      // [R]
   const int32_t* seg_start = nullptr;  // [U + 1]   pos[r] = seg_start[map[r]] + ord[r]
   const int32_t* ord = nullptr;      // [R]
+  int32_t* overflow_host = nullptr;  // host-mapped counter of f16 gradient values that had to be saturated
   // segment-wise backward (launch_score_fwd): outputs instead of dYh / dbp
   float* V = nullptr;                // [2B][D]
   SegRec* rec = nullptr;             // [R]
