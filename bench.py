@@ -363,6 +363,8 @@ def main():
     host_ms = []
     t_setup_done = time.perf_counter()
     main_source = "resident" if mode == "stale" else "ring"
+    if os.environ.get("VV_BENCH_SOURCE") == "resident":       # debugging aid: the main leg on resident indices (needs the extra legs' batches)
+        main_source = "resident"
     run = Run(args.prec, args.dedup == "on")
     elapsed, kern, diag_ms = run.timed(main_source, per_step_events=diag)
     if diag and rank == 0:

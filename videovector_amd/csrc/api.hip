@@ -146,7 +146,6 @@ static int create_init(vv_ctx* c) {
   for (int i = 0; i < vv_ctx::kDdSets; ++i) {
     c->dd_set[i].info = c->dd_info_all + 4 * i;
     HIPCHK(hipEventCreateWithFlags(&c->dd_set[i].done, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c->dd_set[i].used, hipEventDisableTiming));
   }
   c->dd_info = c->dd_set[0].info;
   const char* da = getenv("VV_DEDUP_ASYNC");
@@ -190,7 +189,7 @@ static void free_batch(vv_ctx* c) {
   for (int i = 0; i < vv_ctx::kDdSets; ++i) {
     vv_ctx::DdSet& d = c->dd_set[i];
     dfree(d.rows); dfree(d.slot_of); dfree(d.uniq); dfree(d.map); dfree(d.ord); dfree(d.cnt); dfree(d.seg);
-    d.rows = d.slot_of = d.uniq = d.map = d.ord = d.cnt = d.seg = nullptr; d.used_recorded = false;
+    d.rows = d.slot_of = d.uniq = d.map = d.ord = d.cnt = d.seg = nullptr; d.used_seq = 0;
   }
   c->dd_rows = nullptr;
   dfree(c->segV); dfree(c->seg_rec); dfree(c->seg_dbp);
@@ -214,7 +213,6 @@ int vv_destroy(vv_ctx* c) {
   dfree(c->dd_key); dfree(c->dd_info_all);
   for (int i = 0; i < vv_ctx::kDdSets; ++i) {
     if (c->dd_set[i].done) (void)hipEventDestroy(c->dd_set[i].done);
-    if (c->dd_set[i].used) (void)hipEventDestroy(c->dd_set[i].used);
   }
   if (c->dd_stream) (void)hipStreamDestroy(c->dd_stream);
   if (c->comm) vv::comm_destroy(c->comm);
@@ -532,6 +530,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
     c->stage_seq[sl] = seq;
     didx = c->stage_dev[sl];
   }
+  if (!seq) seq = ++c->step_seq;          // every step has a sequence number; its forward GEMM stamps it into host-visible memory
 
   // eltwise coefficients (cached on the device until they change)
   std::vector<float> coeff(C - 1);
@@ -580,7 +579,17 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
     vv_ctx::DdSet& set = c->dd_set[c->dd_step++ % vv_ctx::kDdSets];
     c->dd_rows = set.rows; c->dd_slot_of = set.slot_of; c->dd_uniq = set.uniq; c->dd_map = set.map; c->dd_ord = set.ord;
     c->dd_cnt = set.cnt; c->dd_seg = set.seg; c->dd_info = set.info;
-    if (c->dd_async && set.used_recorded) HIPCHK(hipStreamWaitEvent(ds, set.used, 0));
+    if (c->dd_async && set.used_seq) {
+      // The set was last read by the step with sequence number used_seq.  The step's stream runs its kernels in order, so
+      // once the forward GEMM of ANY later step has stamped its number, every kernel of that step has finished.  The host
+      // waits for that stamp (normally long there: it bounds how far the host runs ahead to kDdSets - 1 steps) -- an event
+      // recorded per step for the same purpose cost ~6 us of stream time each (a queue barrier packet between two kernels).
+      for (unsigned spins = 0; (int32_t)(__atomic_load_n(c->seq_host, __ATOMIC_ACQUIRE) - set.used_seq) <= 0; ++spins) {
+        if (spins > 4096) { timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
+        if (hipStreamQuery(s) == hipSuccess) break;             // nothing queued any more: every earlier step is done
+      }
+    }
+    set.used_seq = seq;
     DedupArgs da;
     da.idx = didx; da.rows = c->dd_rows; da.u_host = c->U_host_dev; da.key = c->dd_key; da.agg = c->dd_agg; da.agg_stride = c->dd_agg_stride;
     da.slot_of = c->dd_slot_of; da.uniq_rows = c->dd_uniq; da.map = c->dd_map; da.ord = c->dd_ord; da.cnt = c->dd_cnt;
@@ -598,7 +607,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   fa.H = c->H; fa.R = c->R; fa.D = D; fa.Fp = c->Fp; fa.relu = 1; fa.zero_row = (int32_t)c->n_rows;
   fa.n_dev = dd ? c->dd_info : nullptr;
   fa.R_hint = dd ? *(volatile int32_t*)c->U_host : 0;
-  fa.seq_host = seq ? c->seq_host_dev : nullptr; fa.seq = seq;
+  fa.seq_host = c->seq_host_dev; fa.seq = seq;
 
   fa.drop_ratio = cfg->dropout_ratio;
   fa.mask = (cfg->dropout_ratio > 0.f && cfg->dropout_mask) ? c->mask : nullptr;
@@ -692,11 +701,6 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
       const size_t off = (size_t)d0 * c->F, n = (size_t)dn * c->F + (last ? (size_t)D : 0);
       if (vv::comm_allreduce(c->comm, c->grads, off, n, c->ev_chunk)) return fail(VV_ERR_HIP, "all-reduce: %s", vv::comm_error(c->comm));
     }
-  }
-  if (dd && c->dd_async) {
-    vv_ctx::DdSet& set = c->dd_set[(c->dd_step - 1) % vv_ctx::kDdSets];
-    HIPCHK(hipEventRecord(set.used, s));
-    set.used_recorded = true;
   }
   c->grads_pending = c->comm != nullptr;       // (a one-rank communicator still runs its collective: same code path)
   c->grads_chunked = chunked;

@@ -83,13 +83,13 @@ struct vv_ctx {
   int32_t* U_host_dev = nullptr;    // device alias of U_host
   uint32_t dd_epoch = 0;
   // The grouping kernels of step k+1 run on a stream of their own while step k is still executing (they need only the
-  // indices): three sets of their output arrays rotate (dd_* above point at the set of the step being issued), an event
-  // per set says when the step that used it has issued its last reader, another when its grouping is done.
-  static constexpr int kDdSets = 3;
+  // indices): four sets of their output arrays rotate (dd_* above point at the set of the step being issued), the forward
+  // GEMM's sequence stamp says when the step that read a set is over, an event per set when its grouping is done.
+  static constexpr int kDdSets = 4;
   struct DdSet {
     int32_t *rows = nullptr, *slot_of = nullptr, *uniq = nullptr, *map = nullptr, *ord = nullptr, *cnt = nullptr, *seg = nullptr,
             *info = nullptr;
-    hipEvent_t done = nullptr, used = nullptr; bool used_recorded = false;
+    hipEvent_t done = nullptr; int32_t used_seq = 0;      // sequence number of the step that last read the set
   } dd_set[kDdSets];
   int32_t* dd_info_all = nullptr;
   int32_t* dd_rows = nullptr;      // instance -> table row of the current set (k_dd_claim's output)
