@@ -95,6 +95,7 @@ struct vv_ctx {
   int32_t* dd_rows = nullptr;      // instance -> table row of the current set (k_dd_claim's output)
   hipStream_t dd_stream = nullptr;
   uint64_t dd_step = 0;
+  double dd_spin_us = 60.0;        // how long the host watches the grouping's event before queueing a stream wait (VV_DEDUP_SPIN_US)
   bool dd_async = true;            // env VV_DEDUP_ASYNC=0: the grouping kernels in the step's own stream
   int32_t step_seq = 0;
   // staging of index batches taken from a sampler's prefetch ring (vv_forward_backward_ring)
