@@ -155,8 +155,8 @@ static int create_init(vv_ctx* c) {
   HIPCHK(hipHostMalloc((void**)&c->U_host, 2 * sizeof(int32_t), hipHostMallocMapped));   // {U, saturated f16 gradient sums}
   c->U_host[0] = c->U_host[1] = 0;
   HIPCHK(hipHostGetDevicePointer((void**)&c->U_host_dev, c->U_host, 0));
-  HIPCHK(hipHostMalloc((void**)&c->seq_host, sizeof(int32_t), hipHostMallocMapped));
-  *c->seq_host = 0;
+  HIPCHK(hipHostMalloc((void**)&c->seq_host, 2 * sizeof(int32_t), hipHostMallocMapped));
+  c->seq_host[0] = c->seq_host[1] = 0;
   HIPCHK(hipHostGetDevicePointer((void**)&c->seq_host_dev, c->seq_host, 0));
   return VV_OK;
 }
@@ -389,7 +389,8 @@ int vv_params_set(vv_ctx* c, int32_t D, const float* W, const float* b, const fl
   if (b) HIPCHK(hipMemcpy(c->b, b, D * 4, hipMemcpyHostToDevice)); else HIPCHK(hipMemset(c->b, 0, D * 4));
   if (hW) HIPCHK(hipMemcpy(c->hW, hW, nW * 4, hipMemcpyHostToDevice)); else HIPCHK(hipMemset(c->hW, 0, nW * 4));
   if (hb) HIPCHK(hipMemcpy(c->hb, hb, D * 4, hipMemcpyHostToDevice)); else HIPCHK(hipMemset(c->hb, 0, D * 4));
-  // scale for the half copy from max|W|, then convert
+  // scale for the half copy from max|W|, then convert (a scale update still pending from an earlier SGD step is void)
+  c->scale_pending = false;
   HIPCHK(hipMemsetAsync(&c->scales->wmax_bits, 0, sizeof(unsigned), c->stream));
   launch_absmax(c->W, (int64_t)nW, &c->scales->wmax_bits, c->stream);
   launch_scale_update(c->prec, c->scales, nullptr, c->stream);
@@ -510,6 +511,12 @@ static int stage_acquire(vv_ctx* c, size_t bytes, int* slot) {
   return VV_OK;
 }
 
+static void flush_scale_update(vv_ctx* c) {
+  if (!c->scale_pending) return;
+  launch_scale_update(c->prec, c->scales, c->wmax_blocks, c->stream);
+  c->scale_pending = false;
+}
+
 static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int idx_on_device, int64_t row_limit, int32_t seq = 0) {
   int rc = check_cfg(c, cfg);
   if (rc) return rc;
@@ -583,10 +590,21 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
     c->dd_cnt = set.cnt; c->dd_seg = set.seg; c->dd_info = set.info;
     if (c->dd_async && set.used_seq) {
       // The set was last read by the step with sequence number used_seq.  The step's stream runs its kernels in order, so
-      // once the forward GEMM of ANY later step has stamped its number, every kernel of that step has finished.  The host
-      // waits for that stamp (normally long there: it bounds how far the host runs ahead to kDdSets - 1 steps) -- an event
+      // once a kernel of ANY later step has stamped its number, every kernel of that step has finished.  The host waits
+      // for that stamp (normally long there: it bounds how far the host runs ahead to kDdSets - 1 steps) -- an event
       // recorded per step for the same purpose cost ~6 us of stream time each (a queue barrier packet between two kernels).
-      for (unsigned spins = 0; (int32_t)(__atomic_load_n(c->seq_host, __ATOMIC_ACQUIRE) - set.used_seq) <= 0; ++spins) {
+      // In steady state this wait is what paces the host, so the grouping it queues next starts right at the stamp and
+      // shares the chip with the kernel that wrote it.  Two stamps exist: the forward GEMM's (word 0, written as it starts)
+      // and the score kernel's (word 1, i.e. "the forward GEMM has finished").  A/B on one box, 4 x 4000 steps each
+      // (profiles/r02_step_ablations.txt): released by the forward GEMM the grouping costs that GEMM 5-6 us (0.085 against
+      // 0.080 ms alone: one persistent workgroup per CU, and a CU that also hosts grouping workgroups finishes late) and the
+      // step takes 0.2305 ms; released by the score kernel it costs the score and segment kernels 4.5 + 2 us and the step
+      // takes 0.2337 ms.  Released after the segment kernel or later it runs into the weight-gradient GEMM, is starved there
+      // (80 us instead of 33) and the next step waits for it (0.239-0.253 ms).  Default: the forward GEMM's stamp -- the
+      // faster step, at the price of a forward-GEMM duration (and roofline fraction) that includes the co-running kernels.
+      // VV_DEDUP_GATE=1 selects the other.
+      static const int gate_word = getenv("VV_DEDUP_GATE") ? (atoi(getenv("VV_DEDUP_GATE")) != 0) : 0;
+      for (unsigned spins = 0; (int32_t)(__atomic_load_n(c->seq_host + gate_word, __ATOMIC_ACQUIRE) - set.used_seq) <= 0; ++spins) {
         if (spins > 4096) { timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
         if (hipStreamQuery(s) == hipSuccess) break;             // nothing queued any more: every earlier step is done
       }
@@ -656,6 +674,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   sa.map = dd ? c->dd_map : nullptr; sa.seg_start = dd ? c->dd_seg : nullptr; sa.ord = dd ? c->dd_ord : nullptr;
   sa.item_w = cfg->item_weight ? c->item_w : nullptr;
   sa.overflow_host = c->U_host_dev + 1;
+  sa.gate_host = c->seq_host_dev + 1; sa.gate_seq = seq;
 
   // de-duplicated batches of the supported shape: the backward stays factored per instance and is summed per distinct
   // row (k_score_fwd + k_seg_bwd); otherwise per-instance 16-bit gradient rows (+ k_segsum when de-duplicated)
@@ -695,6 +714,8 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   const int tilesM = c->Dp / BM;
   const bool chunked = c->comm && c->comm_overlap && tilesM > 1 &&
                        (gemm_variant() == 5 || gemm_variant() == 6 || gemm_variant() == 8) && !ablate_on();
+  // the W -> half scale update the previous vv_apply_update left pending rides in this step's (first) reduction launch
+  if (c->scale_pending) { ra.scale_sc = c->scales; ra.scale_wmax = c->wmax_blocks; ra.scale_prec = c->prec; c->scale_pending = false; }
   if (!chunked) {
     PROFILED(c, "wgrad_gemm", launch_wgrad_gemm(c->prec, wa, s));
     PROFILED(c, "reduce", launch_reduce(ra, s));
@@ -708,6 +729,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
       ra.d_begin = d0; ra.d_count = dn; ra.parts = last ? 3 : 1;
       if (tm == 0) { PROFILED(c, "wgrad_gemm", launch_wgrad_gemm(c->prec, wa, s)); PROFILED(c, "reduce", launch_reduce(ra, s)); }
       else { launch_wgrad_gemm(c->prec, wa, s); launch_reduce(ra, s); }
+      ra.scale_sc = nullptr;
       HIPCHK(hipEventRecord(c->ev_chunk, s));
       const size_t off = (size_t)d0 * c->F, n = (size_t)dn * c->F + (last ? (size_t)D : 0);
       if (vv::comm_allreduce(c->comm, c->grads, off, n, c->ev_chunk)) return fail(VV_ERR_HIP, "all-reduce: %s", vv::comm_error(c->comm));
@@ -816,8 +838,12 @@ int vv_apply_update(vv_ctx* c, const vv_step_cfg* cfg) {
   a.lr_mult_w = cfg->lr_mult[0]; a.lr_mult_b = cfg->lr_mult[1];
   a.decay_mult_w = cfg->decay_mult[0]; a.decay_mult_b = cfg->decay_mult[1];
   a.reg = cfg->reg; a.solver_type = cfg->solver_type; a.delta = cfg->delta;
+  flush_scale_update(c);               // two updates in a row without a step between them
   PROFILED(c, "sgd", launch_sgd(c->prec, a, c->stream));
-  launch_scale_update(c->prec, c->scales, c->wmax_blocks, c->stream);
+  // The next W -> half scale (k_scale_update: folds this kernel's per-block max |w|) is needed by the NEXT k_sgd only.  It
+  // is left pending and performed by one extra workgroup of the next step's k_reduce; anything else that touches the
+  // scales or the parameters first flushes it as its own launch.
+  c->scale_pending = true;
   HIPCHK(hipGetLastError());
   c->iter++;
   c->prof_calls++;

@@ -152,6 +152,9 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
     a.loss_part[b] = lsum;
     a.viol_part[b] = vsum;
     if (a.s_true) a.s_true[b] = sp;
+    // workgroup 0 is in the kernel's first round: "this step's forward GEMM has finished" (placed here, where few values
+    // are live: at the kernel's head it cost the RPW 7 form six registers and, at 133, an occupancy step)
+    if (a.gate_host && b == 0) __hip_atomic_store(a.gate_host, a.gate_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __syncthreads();
   // per-row constants, once per row instead of once per (row, column group): g*sg = k1*Ah - k2*x, dAh += k3*x
@@ -383,6 +386,9 @@ __global__ __launch_bounds__(64 * NW) void k_score_loss_reg(ScoreArgs a) {
     a.loss_part[b] = lsum;
     a.viol_part[b] = vsum;
     if (a.s_true) a.s_true[b] = sp;
+    // workgroup 0 is in the kernel's first round: "this step's forward GEMM has finished" (placed here, where few values
+    // are live: at the kernel's head it cost the RPW 7 form six registers and, at 133, an occupancy step)
+    if (a.gate_host && b == 0) __hip_atomic_store(a.gate_host, a.gate_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __syncthreads();
 
@@ -603,6 +609,9 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
     a.loss_part[b] = lsum;
     a.viol_part[b] = vsum;
     if (a.s_true) a.s_true[b] = sp;
+    // workgroup 0 is in the kernel's first round: "this step's forward GEMM has finished" (placed here, where few values
+    // are live: at the kernel's head it cost the RPW 7 form six registers and, at 133, an occupancy step)
+    if (a.gate_host && b == 0) __hip_atomic_store(a.gate_host, a.gate_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __syncthreads();
 
@@ -901,13 +910,40 @@ __device__ __forceinline__ void reduce_loss(const ReduceArgs& a) {
   if (threadIdx.x == 0) { a.loss_out[0] = l * a.loss_scale; a.loss_out[1] = v; }
 }
 
+// next W->half scale from the running max: f16 keeps max|W|*sw in [2^11, 2^12); bf16 needs none.  One 256-thread workgroup.
+__device__ __forceinline__ void scale_update_body(Scales* sc, const float* wmax_blocks, int nblocks, int prec) {
+  __shared__ float red[8];
+  float mm = 0.f;
+  if (wmax_blocks)
+    for (int i = threadIdx.x; i < nblocks; i += 256) mm = fmaxf(mm, wmax_blocks[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mm;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  mm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float m = fmaxf(mm, __uint_as_float(sc->wmax_bits));
+  float sw = 1.f;
+  if (prec == 0 && m > 0.f && isfinite(m)) {
+    int e;
+    frexpf(m, &e);                 // m = f * 2^e, f in [0.5, 1)
+    sw = ldexpf(1.f, 12 - e);      // m * sw in [2^11, 2^12)
+  }
+  sc->sw_next = sw;
+  sc->wmax_bits = 0u;
+}
+
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
   int bid = blockIdx.x;
+  // a pending W -> half scale update of the PREVIOUS step's SGD kernel rides as the last workgroup (its own one-workgroup
+  // launch cost ~5 us of stream time a step: the kernel plus two dependent-launch gaps); this step's k_sgd reads the result
+  const int G = (int)gridDim.x - (a.scale_sc ? 1 : 0);
+  if (bid == G) { scale_update_body(a.scale_sc, a.scale_wmax, SGD_BLOCKS, a.scale_prec); return; }
   if (a.parts & 2) {
-    if (bid == (int)gridDim.x - 1) { reduce_loss(a); return; }
+    if (bid == G - 1) { reduce_loss(a); return; }
     const int ndb = (a.D + 15) / 16;
-    if (bid >= (int)gridDim.x - 1 - ndb) { reduce_db(a, bid - ((int)gridDim.x - 1 - ndb)); return; }
+    if (bid >= G - 1 - ndb) { reduce_db(a, bid - (G - 1 - ndb)); return; }
   }
   if (!(a.parts & 1)) return;
   const float inv = a.ip_scale / (a.sg * a.scales->sx);
@@ -947,7 +983,7 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
   }
 }
 void launch_reduce(const ReduceArgs& a, hipStream_t s) {
-  const dim3 grid(((a.parts & 1) ? RED_DW_BLOCKS : 0) + ((a.parts & 2) ? (a.D + 15) / 16 + 1 : 0));   // dW blocks, db blocks, the loss block
+  const dim3 grid(((a.parts & 1) ? RED_DW_BLOCKS : 0) + ((a.parts & 2) ? (a.D + 15) / 16 + 1 : 0) + (a.scale_sc ? 1 : 0));   // dW blocks, db blocks, the loss block, the scale block
   if (a.F % 4 == 0) VV_LAUNCH(k_reduce<true>, grid, dim3(256), 0, s, a);
   else VV_LAUNCH(k_reduce<false>, grid, dim3(256), 0, s, a);
 }
@@ -1027,28 +1063,7 @@ void launch_sgd(int prec, const SgdArgs& a, hipStream_t s) {
   else { if (vec) VV_LAUNCH((k_sgd<BF16, true>), grid, block, 0, s, a); else VV_LAUNCH((k_sgd<BF16, false>), grid, block, 0, s, a); }
 }
 
-// next W->half scale from the running max: f16 keeps max|W|*sw in [2^11, 2^12); bf16 needs none.
-__global__ void k_scale_update(Scales* sc, const float* wmax_blocks, int nblocks, int prec) {
-  __shared__ float red[8];
-  float mm = 0.f;
-  if (wmax_blocks)
-    for (int i = threadIdx.x; i < nblocks; i += 256) mm = fmaxf(mm, wmax_blocks[i]);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o, 64));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mm;
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-  mm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  const float m = fmaxf(mm, __uint_as_float(sc->wmax_bits));
-  float sw = 1.f;
-  if (prec == 0 && m > 0.f && isfinite(m)) {
-    int e;
-    frexpf(m, &e);                 // m = f * 2^e, f in [0.5, 1)
-    sw = ldexpf(1.f, 12 - e);      // m * sw in [2^11, 2^12)
-  }
-  sc->sw_next = sw;
-  sc->wmax_bits = 0u;
-}
+__global__ void k_scale_update(Scales* sc, const float* wmax_blocks, int nblocks, int prec) { scale_update_body(sc, wmax_blocks, nblocks, prec); }
 void launch_scale_update(int prec, Scales* sc, const float* wmax_blocks, hipStream_t s) {
   hipLaunchKernelGGL(k_scale_update, dim3(1), dim3(256), 0, s, sc, wmax_blocks, SGD_BLOCKS, prec);
 }

@@ -49,6 +49,7 @@ struct vv_ctx {
   int D = 0, Dp = 0;
   float *W = nullptr, *b = nullptr, *hW = nullptr, *hb = nullptr;
   uint16_t* Wh = nullptr; vv::Scales* scales = nullptr; float* wmax_blocks = nullptr;
+  bool scale_pending = false;               // k_sgd ran, its scale update has not (it rides in the next k_reduce)
   float* grads = nullptr;           // [D*F + D] (own buffer, or the bound external one)
   float* grads_own = nullptr;
   // per-batch buffers
@@ -104,8 +105,10 @@ struct vv_ctx {
   int32_t* stage_dev[kStage] = {};          // the device's alias of the same memory
   int32_t stage_seq[kStage] = {};           // sequence number of the step that last read the slot
   size_t stage_bytes = 0; int32_t stage_next = 0;
-  int32_t* seq_host = nullptr;              // pinned + mapped: the forward GEMM stores the step's sequence number here,
-  int32_t* seq_host_dev = nullptr;          //   i.e. "the kernels that read this step's index batch have finished"
+  int32_t* seq_host = nullptr;              // pinned + mapped, two words.  [0]: the forward GEMM stores the step's sequence
+  int32_t* seq_host_dev = nullptr;          //   number here when it starts, i.e. "the kernels that read this step's index
+                                            //   batch have finished"; [1]: the score kernel does when IT starts, i.e. "this
+                                            //   step's forward GEMM has finished" (the gate of the asynchronous grouping)
   // data-parallel gradient exchange (comm.hip)
   vv::Comm* comm = nullptr;
   bool comm_overlap = false;        // all-reduce row blocks of dW while the weight-gradient kernel produces the next

@@ -90,6 +90,8 @@ struct ScoreArgs {
   const int32_t* seg_start = nullptr;  // [U + 1]   pos[r] = seg_start[map[r]] + ord[r]
   const int32_t* ord = nullptr;      // [R]
   int32_t* overflow_host = nullptr;  // host-mapped counter of f16 gradient values that had to be saturated
+  int32_t* gate_host = nullptr;      // host-mapped word that receives gate_seq when the kernel starts ("the forward GEMM
+  int32_t gate_seq = 0;              //   of this step has finished": releases the host to queue a later step's grouping)
   // segment-wise backward (launch_score_fwd): outputs instead of dYh / dbp
   float* V = nullptr;                // [2B][D]
   SegRec* rec = nullptr;             // [R]
@@ -168,6 +170,9 @@ struct ReduceArgs {
   const float* loss_part; const float* viol_part; float loss_scale; float* loss_out;
   int d_begin = 0, d_count = 0;      // rows of dW this launch reduces (d_count 0 = all D)
   int parts = 3;                     // bit 0: the dW rows, bit 1: db and the loss scalars
+  Scales* scale_sc = nullptr;        // non-null: one more workgroup performs the W -> half scale update left pending by the
+  const float* scale_wmax = nullptr; //   previous step's k_sgd (its per-block max |w| slots)
+  int scale_prec = 0;
 };
 
 struct SgdArgs {
