@@ -131,6 +131,10 @@ def main():
                          "torch.distributed.all_reduce on the tensor the gradients are bound to (cross-check; no overlap mode)")
     ap.add_argument("--sampler-threads", type=int, default=int(os.environ.get("VV_SAMPLER_THREADS", "3")))
     ap.add_argument("--prefetch-depth", type=int, default=8)
+    ap.add_argument("--settle-ms", type=float, default=50.0,
+                    help="untimed steps of the same workload, this many ms of them, in front of the W warm-up steps of every "
+                         "leg: the device needs ~25 ms of continuous work after an idle spell (set-up, a host-side leg) before "
+                         "its step time is steady (profiles/r02_step_ablations.txt, 3.).  0 = none: W warm-up steps only")
     args = ap.parse_args()
 
     global B_PER_GPU, NN, D
@@ -164,6 +168,8 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     K, Wm = args.steps, args.warmup
+    # settle steps: a fixed count per workload (every rank must run the same number), ~args.settle_ms of GPU work
+    S = int(np.ceil(args.settle_ms / (2.3 if args.workload == "cfg5" else 0.25))) if args.settle_ms > 0 else 0
     Bg = B_PER_GPU * world
     ds = SyntheticVideos(seed=SEED, n_videos=N_VIDEOS)
     skw = dict(batch_size=Bg, context_size=C, num_negative_samples=NN, max_buffer_size=5000, negative_swap_percentage=50)
@@ -208,7 +214,7 @@ def main():
             sampler_note = " (fallback: one identical sampler per rank, the shared-memory ring could not be attached)"
 
     # batches for the resident-indices legs come from a second, identical sampler (rank-local slice of the global batch)
-    n_res = 0 if args.no_extra_legs else Wm + K
+    n_res = 0 if args.no_extra_legs else S + Wm + K
     batches = None
     if n_res:
         smp2 = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, **skw)
@@ -247,6 +253,7 @@ def main():
         return 1e-3 * (1.0 + 1e-3 * it) ** -0.75
 
     KERNELS = ("dedup", "fwd_gemm", "score_loss", "segsum", "wgrad_gemm", "reduce", "sgd")
+    GEMMS = ("fwd_gemm", "wgrad_gemm")
 
     class Run:
         """One engine + its step function; source = 'ring' (end to end) or 'resident'."""
@@ -320,9 +327,13 @@ def main():
             self.it += 1
 
         def timed(self, source, per_step_events=False, profile=True):
-            """W warm-up steps, then exactly K steps between barrier + synchronize; max over ranks."""
+            """S settle steps, W warm-up steps, then exactly K steps between barrier + synchronize; max over ranks."""
             eng = self.eng
-            for i in range(Wm):
+            cold = [torch.cuda.Event(enable_timing=True) for _ in range(min(S, 24) + 1)] if S else []
+            for i in range(S):
+                if i < len(cold): cold[i].record(work_stream)
+                self.step(source, i)
+            for i in range(S, S + Wm):
                 self.step(source, i)
             if self.trainer is not None:
                 self.trainer.flush()
@@ -332,13 +343,14 @@ def main():
             # prof_every-th step (a timed dispatch cannot be pipelined behind its predecessor, ~5 us each).
             prof_every = int(os.environ.get("VV_BENCH_PROF_EVERY", "0")) or max(4, K // 8)
             if profile:
+                eng.profile_select(GEMMS if profile == "gemm" else None)
                 eng.profile_enable(prof_every)
             evs = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)] if per_step_events else None
             t0 = time.perf_counter()
             if evs: evs[0].record(work_stream)
-            for i in range(Wm, Wm + K):
+            for i in range(S + Wm, S + Wm + K):
                 self.step(source, i)
-                if evs: evs[i - Wm + 1].record(work_stream)
+                if evs: evs[i - S - Wm + 1].record(work_stream)
             if self.trainer is not None:
                 self.trainer.flush()
             torch.cuda.synchronize()
@@ -351,7 +363,10 @@ def main():
             kern = {k: eng.profile_get(k) for k in KERNELS} if profile else {}
             if profile:
                 eng.profile_enable(False)
-            steps_ms = [evs[j].elapsed_time(evs[j + 1]) for j in range(K)] if evs else None
+            # (with kernel timing on, the steps that carried timed dispatches are left out of the per-step series)
+            steps_ms = [evs[j].elapsed_time(evs[j + 1]) for j in range(K)
+                        if not (profile and j % prof_every == prof_every - 1)] if evs else None
+            self.cold_ms = [cold[j].elapsed_time(cold[j + 1]) for j in range(len(cold) - 1)]
             return el, kern, steps_ms
 
     def stats(ms):
@@ -366,7 +381,11 @@ def main():
     if os.environ.get("VV_BENCH_SOURCE") == "resident":       # debugging aid: the main leg on resident indices (needs the extra legs' batches)
         main_source = "resident"
     run = Run(args.prec, args.dedup == "on")
-    elapsed, kern, diag_ms = run.timed(main_source, per_step_events=diag)
+    # The timed leg times the two GEMMs only when the other kernels' durations come from the per-step leg below (cfg 2: a GEMM
+    # is the dominant kernel by 3x; a timed dispatch costs ~5 us of stream time, 7 of them on every 4th of 20 steps 4 %).
+    main_prof = "gemm" if (not args.no_extra_legs and args.workload == "cfg2") else "all"
+    elapsed, kern, diag_ms = run.timed(main_source, per_step_events=diag, profile=main_prof)
+    main_cold_ms = run.cold_ms
     if diag and rank == 0:
         print("main-leg step ms: " + " ".join("%.3f" % x for x in diag_ms), file=sys.stderr)
         print("host ms in forward_backward_ring (warm-up included): " + " ".join("%.3f" % x for x in host_ms), file=sys.stderr)
@@ -379,8 +398,13 @@ def main():
         extra["gpu_path_only"] = {"value": Bg * NN * K / g_el, "unit": "triplets/s", "ms_per_step": g_el / K * 1e3,
                                   "note": "index batches resident in HBM before the timed region: sampler, ring and H2D excluded"}
         run.reset(args.dedup == "on")
-        _, _, steps_ms = run.timed(main_source, per_step_events=True, profile=False)
-        extra["step_ms_stats"] = dict(stats(steps_ms), note="end-to-end steps, one HIP event per step (a separate run of the same K steps)")
+        _, s_kern, steps_ms = run.timed(main_source, per_step_events=True, profile="all")
+        extra["step_ms_stats"] = dict(stats(steps_ms), note="end-to-end steps, one HIP event per step (a separate run of the same K "
+                                                             "steps; the steps whose kernels were individually timed left out)")
+        if main_prof == "gemm":
+            for k, v in s_kern.items():
+                if k not in GEMMS:
+                    kern[k] = v
         if args.dedup == "on":
             run.reset(False)
             d_el, d_kern, _ = run.timed("resident")
@@ -406,7 +430,7 @@ def main():
         # rows the GEMMs really processed: distinct table rows per timed batch of this rank (host recount on the identical
         # stream of the second sampler; the ring's batches are the same batches)
         if args.dedup == "on" and batches is not None:
-            U = float(np.mean([len(np.unique(batches[i])) for i in range(Wm, Wm + K)]))
+            U = float(np.mean([len(np.unique(batches[i])) for i in range(S + Wm, S + Wm + K)]))
         elif args.dedup == "on":
             U = float(run.eng.dedup_stats()[1])
         else:
@@ -448,6 +472,11 @@ def main():
             "dtype": args.prec,
             "dtype_note": args.prec + " MFMA operands with fp32 accumulation; fp32 master weights, activations, loss and update",
             "data": "synthetic",
+            "settle": {"steps": S, "cold_start_step_ms": [round(x, 4) for x in main_cold_ms],
+                       "note": "untimed steps of the same workload in front of the W warm-up steps of every leg (--settle-ms, "
+                               "default 50 ms of them; 0 = none).  After an idle spell the device's step time takes ~100 steps "
+                               "(~25 ms) to become steady -- cold_start_step_ms are the first of them, one HIP event per step; "
+                               "the timed region is exactly `steps` full training steps either way"},
             "value_scope": ("end to end: bit-exact reference sampler on %d prefetch thread(s) inside the timed region, "
                             "225 KB index batch per step through pinned staging + async H2D, full training iteration"
                             % args.sampler_threads) if main_source == "ring" else "resident indices (stale-gradient schedule)",
@@ -469,8 +498,10 @@ def main():
                                               "(one-update delayed gradients: NOT the reference's algorithm)"}[mode]},
             "roofline": roof,
             "kernels_ms": {k: round(v, 4) for k, v in live.items()},
-            "kernel_timing": "HIP events on the kernels' dispatch packets, every %d-th of the %d timed steps (%d samples per kernel)"
-                             % (max(4, K // 8), K, max([v[1] for v in kern.values()] or [0])),
+            "kernel_timing": ("HIP events on the kernels' dispatch packets, every %d-th of the %d timed steps (%d samples per kernel)"
+                              % (max(4, K // 8), K, max([v[1] for v in kern.values()] or [0])))
+                             + ("; the two GEMMs (the roofline's kernel among them) inside the timed region itself, the other kernels "
+                                "on the same steps of the per-step leg (step_ms_stats)" if main_prof == "gemm" else ""),
             "dedup": {"mode": args.dedup, "rows_per_step": R, "distinct_rows_per_step": U, "factor": R / U,
                       "note": "the reference sampler draws all negatives of a batch from one shared 5000-frame "
                               "buffer, so sampled rows repeat; each distinct row is projected once and its "

@@ -340,9 +340,12 @@ int vv_forward_backward_ring(vv_ctx* ctx, const vv_step_cfg* cfg, vv_batch_ring*
  * "score_loss", "wgrad_gemm", "reduce", "sgd") over the launches since the last reset, measured
  * with hipEvents on the context's stream (only while enabled; enabling adds two event records
  * per launch). */
-/* on: 0 = off, 1 = every step, N > 1 = every N-th step (a step ends with vv_apply_update).  The events ride on the
+/* on: 0 = off, 1 = every step, N > 1 = the N-th, 2N-th, ... step after the call (a step ends with vv_apply_update).  The events ride on the
  * kernels' own dispatch packets (hipExtLaunchKernelGGL); no extra packets are queued. */
 int vv_profile_enable(vv_ctx* ctx, int on);
+/* Restrict the timing to a comma-separated list of kernel names (NULL or "" = all).  A timed dispatch cannot be pipelined
+ * behind its predecessor (~5 us each): the benchmark's timed leg times the two GEMMs only. */
+int vv_profile_select(vv_ctx* ctx, const char* kernels);
 int vv_profile_get(vv_ctx* ctx, const char* kernel, double* avg_ms, int64_t* launches);
 
 #ifdef __cplusplus

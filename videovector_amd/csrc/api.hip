@@ -37,7 +37,8 @@ namespace vv { thread_local ProfPair g_prof; }
 // hipExtLaunchKernelGGL, which stamps them from the dispatch packet itself (vv_internal.h: VV_LAUNCH).
 static void prof_begin(vv_ctx* c, const char* name, hipEvent_t* e0, hipEvent_t* e1) {
   *e0 = *e1 = nullptr;
-  if (!c->prof || (c->prof_calls % (uint64_t)c->prof_every) != 0) return;
+  if (!c->prof || (c->prof_calls % (uint64_t)c->prof_every) != (uint64_t)c->prof_every - 1) return;   // the N-th, 2N-th, ... step
+  if (!c->prof_only.empty() && c->prof_only.find(std::string(",") + name + ",") == std::string::npos) return;
   auto& pe = c->prof_map[name];
   if (pe.ev.size() >= 8192) return;
   while (c->ev_pool.size() < c->ev_used + 2) {
@@ -1116,6 +1117,12 @@ int vv_profile_enable(vv_ctx* c, int on) {
   c->prof = on != 0;
   c->prof_every = on > 1 ? on : 1;
   c->prof_calls = 0;
+  return VV_OK;
+}
+
+int vv_profile_select(vv_ctx* c, const char* kernels) {
+  if (!c) return fail(VV_ERR_ARG, "vv_profile_select: ctx is NULL");
+  c->prof_only = (kernels && *kernels) ? "," + std::string(kernels) + "," : std::string();
   return VV_OK;
 }
 

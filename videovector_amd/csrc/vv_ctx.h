@@ -120,6 +120,7 @@ struct vv_ctx {
   int prof_every = 1;               // record every prof_every-th forward/backward + update (vv_profile_enable's argument)
   uint64_t prof_calls = 0;
   std::map<std::string, ProfEntry> prof_map;
+  std::string prof_only;            // vv_profile_select: ",name,name," -- only these kernels are timed (empty = all)
   std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;    // events are reused across profiling sessions
 };
 

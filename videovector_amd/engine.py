@@ -93,6 +93,7 @@ def load_library():
         "vv_embed_mean": [vp, vp, i64, i32, vp, C.c_int, C.c_int, vp],
         "vv_retrieval_stats": [vp, vp, i32, i32, vp, vp, vp, i32, C.c_int, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32)],
         "vv_profile_enable": [vp, C.c_int],
+        "vv_profile_select": [vp, C.c_char_p],
         "vv_profile_get": [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)],
     }
     for name, args in sigs.items():
@@ -331,6 +332,10 @@ class Engine:
     # ---- profiling
     def profile_enable(self, on=True):
         self._chk(self.L.vv_profile_enable(self.h, int(on)))
+
+    def profile_select(self, kernels=None):
+        """Time only these kernels (iterable of names); None = all."""
+        self._chk(self.L.vv_profile_select(self.h, ",".join(kernels).encode() if kernels else None))
 
     def profile_get(self, kernel):
         ms, n = C.c_double(), C.c_int64()
