@@ -129,6 +129,12 @@ def main():
                     help="N>1: who runs the gradient all-reduce.  'lib' (default): the product library's own RCCL "
                          "communicator on its communication stream (vv_comm_init / vv_allreduce_grads).  'torch': "
                          "torch.distributed.all_reduce on the tensor the gradients are bound to (cross-check; no overlap mode)")
+    ap.add_argument("--sampler", default="auto", choices=["auto", "node", "rank"],
+                    help="N>1: who draws the batches.  'rank' (auto for N>1): every rank runs the reference's sampler for its own "
+                         "batch of 1024 (its own draw stream: srand(1 + rank), and its own starting record) -- the global batch is "
+                         "N independent reference batches.  'node': ONE logical sampler draws the global batch of N*1024 exactly as "
+                         "a single reference process with that batch size would (SURVEY 8e; the parity-tested form) and every rank "
+                         "takes its slice out of a shared-memory ring -- bound by the sampler's serial walk (DESIGN.md 8)")
     ap.add_argument("--sampler-threads", type=int, default=int(os.environ.get("VV_SAMPLER_THREADS", "3")))
     ap.add_argument("--prefetch-depth", type=int, default=8)
     ap.add_argument("--settle-ms", type=float, default=50.0,
@@ -174,51 +180,82 @@ def main():
     ds = SyntheticVideos(seed=SEED, n_videos=N_VIDEOS)
     skw = dict(batch_size=Bg, context_size=C, num_negative_samples=NN, max_buffer_size=5000, negative_swap_percentage=50)
 
-    # ---- the node's ONE sampler: rank 0 draws global batches ahead on prefetch threads and publishes them through a
-    # ring (POSIX shared memory when there are other ranks); every rank takes items [rank*B, (rank+1)*B) of each batch.
+    smode = args.sampler if args.sampler != "auto" else ("rank" if world > 1 else "node")
+    if world == 1:
+        smode = "node"                                  # one rank: the two are the same sampler
     ring_name = "vv_bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", str(os.getppid())))
     sampler = None
-    if rank == 0:
-        sampler = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, **skw)
-        sampler.prefetch_start(depth=args.prefetch_depth, threads=args.sampler_threads,
-                               shm_name=ring_name if world > 1 else None, consumers=world)
-        ring = sampler.ring()
-    ring_consumer = rank
     sampler_note = ""
-    if dist:
-        dist.barrier()
-        ok = 1
-        if rank != 0:
-            try:
-                if os.environ.get("VV_BENCH_PRIVATE_SAMPLERS") == "1":
-                    raise vv.VVError("forced by VV_BENCH_PRIVATE_SAMPLERS")
-                ring = vv.BatchRing.attach(ring_name, timeout_s=120.0)
-            except vv.VVError as e:
-                ok = 0
-                print("rank %d: cannot attach the node's batch ring (%s)" % (rank, e), file=sys.stderr)
-        flag = torch.tensor([ok], dtype=torch.int32)
-        flag_dev = flag.to(torch.device("cuda", local_rank))
-        dist.all_reduce(flag_dev, op=dist.ReduceOp.MIN)
-        if int(flag_dev.item()) == 0:
-            # the shared-memory ring is not usable on this node: every rank runs the identical sampler of the global
-            # batch for itself (the same indices; N samplers' worth of host work) and the line says so
-            if rank == 0:
-                sampler.prefetch_stop()
-                sampler.close()
-            elif ok:
-                ring.close()
+    one_logical = None
+    ring_attached = False
+    if smode == "rank":
+        # ---- per-rank samplers: the reference's sampler, one instance per rank, batch B_PER_GPU, its own rand() stream and
+        # starting record.  Beside it rank 0 measures what ONE logical sampler of the global batch delivers (the bound of 'node').
+        if rank == 0:
+            sn = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, **skw)
+            sn.prefetch_start(depth=args.prefetch_depth, threads=args.sampler_threads, shm_name=None, consumers=1)
+            for _ in range(3): sn.next()
+            nb = max(4, 32 // world)
+            t0 = time.perf_counter()
+            for _ in range(nb): sn.next()
+            ms_g = (time.perf_counter() - t0) / nb * 1e3
+            sn.prefetch_stop(); sn.close()
+            one_logical = {"ms_per_global_batch": ms_g, "bound_triplets_per_s": Bg * NN / (ms_g * 1e-3),
+                           "note": "--sampler node: one logical sampler of the global batch (%d stage thread(s)), measured here "
+                                   "without the GPUs: the node's rate in that mode cannot exceed it" % args.sampler_threads}
+        skw = dict(skw, batch_size=B_PER_GPU, rand_seed=1 + rank, initial_cursor=(rank * N_VIDEOS) // world)
+        sampler = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, **skw)
+        sampler.prefetch_start(depth=args.prefetch_depth, threads=args.sampler_threads, shm_name=None, consumers=1)
+        ring = sampler.ring()
+        ring_consumer = 0
+        item_begin = 0
+        if dist: dist.barrier()
+    else:
+        # ---- the node's ONE sampler: rank 0 draws global batches ahead on prefetch threads and publishes them through a
+        # ring (POSIX shared memory when there are other ranks); every rank takes items [rank*B, (rank+1)*B) of each batch.
+        item_begin = rank * B_PER_GPU
+        if rank == 0:
             sampler = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, **skw)
-            sampler.prefetch_start(depth=args.prefetch_depth, threads=args.sampler_threads, shm_name=None, consumers=1)
+            sampler.prefetch_start(depth=args.prefetch_depth, threads=args.sampler_threads,
+                                   shm_name=ring_name if world > 1 else None, consumers=world)
             ring = sampler.ring()
-            ring_consumer = 0
-            sampler_note = " (fallback: one identical sampler per rank, the shared-memory ring could not be attached)"
+        ring_consumer = rank
+        if dist:
+            dist.barrier()
+            ok = 1
+            if rank != 0:
+                try:
+                    if os.environ.get("VV_BENCH_PRIVATE_SAMPLERS") == "1":
+                        raise vv.VVError("forced by VV_BENCH_PRIVATE_SAMPLERS")
+                    ring = vv.BatchRing.attach(ring_name, timeout_s=120.0)
+                    ring_attached = True
+                except vv.VVError as e:
+                    ok = 0
+                    print("rank %d: cannot attach the node's batch ring (%s)" % (rank, e), file=sys.stderr)
+            flag = torch.tensor([ok], dtype=torch.int32)
+            flag_dev = flag.to(torch.device("cuda", local_rank))
+            dist.all_reduce(flag_dev, op=dist.ReduceOp.MIN)
+            if int(flag_dev.item()) == 0:
+                # the shared-memory ring is not usable on this node: every rank runs the identical sampler of the global
+                # batch for itself (the same indices; N samplers' worth of host work) and the line says so
+                if rank == 0:
+                    sampler.prefetch_stop()
+                    sampler.close()
+                elif ok:
+                    ring.close()
+                    ring_attached = False
+                sampler = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, **skw)
+                sampler.prefetch_start(depth=args.prefetch_depth, threads=args.sampler_threads, shm_name=None, consumers=1)
+                ring = sampler.ring()
+                ring_consumer = 0
+                sampler_note = " (fallback: one identical sampler per rank, the shared-memory ring could not be attached)"
 
     # batches for the resident-indices legs come from a second, identical sampler (rank-local slice of the global batch)
     n_res = 0 if args.no_extra_legs else S + Wm + K
     batches = None
     if n_res:
         smp2 = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, **skw)
-        batches = np.stack([smp2.next()[rank * B_PER_GPU:(rank + 1) * B_PER_GPU] for _ in range(n_res)])
+        batches = np.stack([smp2.next()[item_begin:item_begin + B_PER_GPU] for _ in range(n_res)])
         smp2.close()
     # raw rate of the sampler by itself (calling thread, no pipeline), for the record
     smp3 = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, **skw)
@@ -315,7 +352,7 @@ def main():
             else:
                 if source == "ring":
                     th0 = time.perf_counter()
-                    eng.forward_backward_ring(cfg, ring, consumer=ring_consumer, item_begin=rank * B_PER_GPU)
+                    eng.forward_backward_ring(cfg, ring, consumer=ring_consumer, item_begin=item_begin)
                     if diag: host_ms.append((time.perf_counter() - th0) * 1e3)
                 else:
                     eng.forward_backward(cfg, idx_dev_ptr=idx_dev.data_ptr() + i * stride)
@@ -329,7 +366,7 @@ def main():
         def timed(self, source, per_step_events=False, profile=True):
             """S settle steps, W warm-up steps, then exactly K steps between barrier + synchronize; max over ranks."""
             eng = self.eng
-            cold = [torch.cuda.Event(enable_timing=True) for _ in range(min(S, 24) + 1)] if S else []
+            cold = [torch.cuda.Event(enable_timing=True) for _ in range(min(S, 25))]
             for i in range(S):
                 if i < len(cold): cold[i].record(work_stream)
                 self.step(source, i)
@@ -486,8 +523,11 @@ def main():
                                    % (1 if args.workload == "cfg2" else 4, D, B_PER_GPU, Bg, NN),
                        "global_batch": Bg, "triplets_per_step": Bg * NN,
                        "parallelism": "dp%d" % world, "items_per_s": value / NN, "dedup": args.dedup,
-                       "sampler": "one per node (rank 0), %d stage thread(s), prefetch depth %d%s"
-                                  % (args.sampler_threads, args.prefetch_depth, ", POSIX shared-memory ring" if world > 1 else "") + sampler_note,
+                       "sampler": ("one per rank: the reference's sampler at batch %d with srand(1 + rank) and its own starting record, "
+                                   "%d stage thread(s), prefetch depth %d" % (B_PER_GPU, args.sampler_threads, args.prefetch_depth))
+                                  if smode == "rank" else
+                                  ("one per node (rank 0), %d stage thread(s), prefetch depth %d%s"
+                                   % (args.sampler_threads, args.prefetch_depth, ", POSIX shared-memory ring" if world > 1 else "") + sampler_note),
                        "comm": {"none": "none", "lib": "the library's RCCL communicator on its own communication stream (vv_comm_*)"
                                 if comm_transport == "rccl" else "the library's shared-memory test transport (one-device hook)",
                                 "torch": "torch.distributed.all_reduce"}[Run.comm_kind or comm]
@@ -509,10 +549,13 @@ def main():
             "step_tflops_executed": 2 * gemm_flop / (ms * 1e-3) / 1e12,
             "step_tflops_dense_equivalent": 2 * dense_flop / (ms * 1e-3) / 1e12,
             "gather_GBs": 2.0 * R * F * 2 / (ms * 1e-3) / 1e9,
-            "sampler_ms_per_global_batch_one_thread": sampler_serial_ms,
+            "sampler_ms_per_global_batch_one_thread": sampler_serial_ms if smode == "node" else None,
+            "sampler_ms_per_rank_batch_one_thread": sampler_serial_ms if smode == "rank" else None,
             "final_loss": loss, "final_violations": viol,
         }
         out.update(extra)
+        if one_logical is not None:
+            out["one_logical_sampler"] = one_logical
         # where the wall-clock time of this process goes besides the K timed steps (for whoever times the whole command)
         out["wall_s"] = {"imports_setup_presampling_table": round(t_setup_done - t_process_start, 3),
                          "warmup_plus_timed_steps": round(t_main_done - t_setup_done, 3),
@@ -529,7 +572,7 @@ def main():
         print(json.dumps(out))
     if dist:
         dist.barrier()
-    if rank != 0:
+    if ring_attached:
         ring.close()
     if sampler is not None:
         sampler.close()

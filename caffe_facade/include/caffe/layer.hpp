@@ -154,7 +154,8 @@ class VideoSampledShotsDataLayer : public Layer<Dtype> {
   bool prefetching_ = false;
   int rand_skip_ = 0;
   vector<int32_t> fw_idx_, fw_last_, fw_label_;
-  vv_sampler* sampler_ = nullptr;          // rank 0 only in a data-parallel job
+  bool per_rank_ = false;                  // data-parallel: every rank runs its own sampler (VV_SAMPLER_MODE, facade.cpp)
+  vv_sampler* sampler_ = nullptr;          // data-parallel with ONE logical sampler (VV_SAMPLER_MODE=node): rank 0 only
   vv_batch_ring* ring_ = nullptr;          // the prefetch ring (rank 0: the sampler's own; other ranks: attached by name)
   int batch_size_ = 0, context_size_ = 0, num_negative_samples_ = 0, feature_size_ = 0;
 };

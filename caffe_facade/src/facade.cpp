@@ -470,7 +470,8 @@ void VideoSampledShotsDataLayer<Dtype>::CreatePrefetchThread() {
   // takes its batch_size items of it
   const string ring_name = "vv_caffe_" + Caffe::job_id() + "_" + this->layer_param_.get_str("name");
   if (sampler_) {
-    CHECK_EQ(vv_sampler_prefetch_start(sampler_, kPrefetchDepth, threads < 1 ? 1 : threads, world > 1 ? ring_name.c_str() : nullptr, world), 0);
+    const bool shared = world > 1 && !per_rank_;
+    CHECK_EQ(vv_sampler_prefetch_start(sampler_, kPrefetchDepth, threads < 1 ? 1 : threads, shared ? ring_name.c_str() : nullptr, shared ? world : 1), 0);
     CHECK_EQ(vv_sampler_ring(sampler_, &ring_), 0);
   } else {
     CHECK_EQ(vv_batch_ring_attach(ring_name.c_str(), 300.0, &ring_), 0) << "rank " << Caffe::rank() << ": no batch ring " << ring_name
@@ -520,11 +521,28 @@ void VideoSampledShotsDataLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>&, 
   sp.max_shot_distance = (float)p.get_num("max_shot_distance");
   CHECK_LE(sp.max_same_video_negs, sp.num_negative_samples)
       << "max_same_video_negs exceeds num_negative_samples: the reference writes past the item's channels (…data_layer.cpp:484-502)";
+  // Data-parallel jobs.  Default: every rank runs this layer as the reference wrote it, for its own batch_size
+  // items, with its own draw stream (srand(1 + rank); rank 0 keeps the reference's never-seeded stream) and its own starting
+  // record (rand_skip + rank * records / world): N independent reference samplers, no serial section shared by the ranks.
+  // VV_SAMPLER_MODE=node: ONE logical sampler (rank 0) draws the global batch of world * batch_size items exactly as a
+  // single process with that batch size would and every rank takes its slice (bit-identical to the
+  // one-process run, bound by the sampler's serial walk: ~0.17 ms per 1024 items).
   if (Caffe::world() > 1) {
-    CHECK_LE(sp.max_same_video_negs, 0) << "data-parallel runs need max_same_video_negs: 0";
-    sp.batch_size = batch_size_ * Caffe::world();      // the prototxt's batch_size is per GPU; the sampler draws the global batch
+    const char* sm = getenv("VV_SAMPLER_MODE");
+    per_rank_ = !(sm && string(sm) == "node");
+    CHECK(!sm || string(sm) == "node" || string(sm) == "rank") << "VV_SAMPLER_MODE: node or rank";
+    if (per_rank_) {
+      const int nrec = (int)dataset_->video_id.size();
+      sp.rand_seed = 1 + Caffe::rank();
+      sp.initial_cursor = (int)(((int64_t)rand_skip_ + (int64_t)Caffe::rank() * nrec / Caffe::world()) % nrec);
+      LOG(INFO) << "Data-parallel rank " << Caffe::rank() << ": own sampler, srand(" << sp.rand_seed << "), first record " << sp.initial_cursor;
+    } else {
+      CHECK_LE(sp.max_same_video_negs, 0) << "VV_SAMPLER_MODE=node needs max_same_video_negs: 0";
+      sp.batch_size = batch_size_ * Caffe::world();    // the prototxt's batch_size is per GPU; the sampler draws the global batch
+      LOG(INFO) << "Data-parallel rank " << Caffe::rank() << ": one logical sampler of the global batch on rank 0";
+    }
   }
-  if (Caffe::rank() == 0) {
+  if (Caffe::rank() == 0 || per_rank_) {
     const int rc = vv_sampler_create_neg(&sp, (int)dataset_->video_id.size(), dataset_->video_id.data(), dataset_->n_shots.data(),
                                          dataset_->row_base.data(), dataset_->shot_ids.data(), (int)dataset_->neg_video_id.size(),
                                          dataset_->neg_video_id.data(), dataset_->neg_n_shots.data(), dataset_->neg_row_base.data(),
@@ -542,7 +560,7 @@ void VideoSampledShotsDataLayer<Dtype>::NextBatch(vector<int32_t>* idx, vector<i
   JoinPrefetchThread();                                            // base_data_layer.cpp:81-95: join, hand over, respawn
   const size_t n = (size_t)batch_size_ * (context_size_ + num_negative_samples_);
   idx->resize(n); last_src->resize(n); label->resize(batch_size_);
-  if (Caffe::world() == 1) {
+  if (Caffe::world() == 1 || per_rank_) {
     CHECK_EQ(vv_sampler_next(sampler_, idx->data(), last_src->data(), label->data()), 0);
   } else {                                                         // this rank's items of the global batch
     CHECK_EQ(vv_batch_ring_next(ring_, Caffe::rank(), Caffe::rank() * batch_size_, batch_size_, idx->data(), label->data(), 600.0), 0)

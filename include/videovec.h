@@ -270,6 +270,9 @@ typedef struct {
                                       cursor starts at this record (modulo the record count) */
   int32_t output_shot_distance;    /* PAIRWISE only (...data_layer.cpp:71, 407-418): label = frame distance, not video id */
   float   max_shot_distance;       /* ... clamped to this bound (caffe.proto:674, default 5) */
+  int32_t rand_seed;               /* srand() argument of the draw stream.  0 or 1 = the reference's (it never seeds: glibc's seed
+                                      1).  Other values (< 2^31 - 1) give each data-parallel rank its own stream (per-rank
+                                      samplers); the stream is still glibc's rand() after srand(rand_seed) */
 } vv_sampler_param;
 /* WINDOW (...data_layer.cpp:425-507): target = the middle of C sorted random frames.  PAST (:510-596): target = the
  * last of C sorted random frames.  PAST_CONTINUOUS (:599-674): C equally spaced frames, random stride and start,

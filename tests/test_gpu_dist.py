@@ -22,7 +22,7 @@ def test_bench_two_ranks_on_one_device(mode):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"),
                         "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
-                        "--allreduce", ar] + extra + (["--no-extra-legs"] if mode != "stale" else []), capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+                        "--allreduce", ar, "--sampler", "node", "--settle-ms", "2"] + extra + (["--no-extra-legs"] if mode != "stale" else []), capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                    # rank 0 only
@@ -47,9 +47,28 @@ def test_bench_fallbacks_keep_the_run_alive():
         r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                             "--master-addr", "127.0.0.1", "--master-port", "29531" if tag == "ring" else "29533",
                             os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
-                            "--no-extra-legs"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+                            "--no-extra-legs", "--sampler", "node", "--settle-ms", "2"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
         assert r.returncode == 0, r.stderr[-3000:]
         d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
         assert ("fallback" in d["config"]["sampler"]) == (tag == "private")
         losses[tag] = d["final_loss"]
     assert losses["ring"] == losses["private"]
+
+
+def test_bench_per_rank_samplers_is_the_default_for_two_ranks():
+    """N > 1 default: every rank runs the reference's sampler for its own batch (own draw stream and starting record);
+    the line names the mode and carries the measured bound of the one-logical-sampler form beside it."""
+    env = dict(os.environ, VV_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29535", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--settle-ms", "2"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2048 and d["scaling"] == "weak"
+    assert d["config"]["sampler"].startswith("one per rank") and "srand(1 + rank)" in d["config"]["sampler"]
+    assert d["one_logical_sampler"]["ms_per_global_batch"] > 0 and d["one_logical_sampler"]["bound_triplets_per_s"] > 0
+    assert d["value"] > 0 and 0 < d["final_loss"] < 16 and d["settle"]["steps"] == 8
+    assert d["gpu_path_only"]["value"] > 0 and d["dense_execution"]["value"] > 0

@@ -499,7 +499,7 @@ def test_caffe_train_data_parallel_two_ranks(tool, pb, tmp_path, overlap):
     procs = []
     for r in range(2):
         env = dict(os.environ, WORLD_SIZE="2", RANK=str(r), LOCAL_RANK="0", VV_COMM="shm", VV_COMM_OVERLAP=overlap,
-                   VV_JOB_ID="t%d_%s" % (os.getpid(), overlap))
+                   VV_JOB_ID="t%d_%s" % (os.getpid(), overlap), VV_SAMPLER_MODE="node")
         procs.append(subprocess.Popen([CAFFE, "train", "--solver=%s" % two, "--weights=%s" % (tmp_path / "init.caffemodel"),
                                        "--gpu=0", "--log_file=%s" % (tmp_path / "two.log")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
@@ -521,3 +521,42 @@ def test_caffe_train_data_parallel_two_ranks(tool, pb, tmp_path, overlap):
     l1 = [float(x) for x in re.findall(r"Iteration \d+, loss = ([0-9.eE+-]+)", log1)]
     lg = [float(x) for x in re.findall(r"Iteration \d+, loss = ([0-9.eE+-]+)", open(tmp_path / "one.log").read())]
     assert abs(0.5 * (l0[0] + l1[0]) - lg[0]) <= 1e-4 * lg[0]
+
+
+def test_caffe_train_data_parallel_per_rank_samplers(tool, pb, oracle, tmp_path):
+    """The default data-parallel form: every rank runs the reference's sampler for its own batch (srand(1 + rank), first
+    record rank * records / world).  Checked against the oracle driven the same way: each rank's logged loss of iterations
+    0 and 1 (iteration 1 sees the update made from the SUM of both ranks' gradients under the global loss count)."""
+    B, C, Nn, F, D, V, IT = 32, 5, 6, 256, 64, 80, 2
+    W0, b0 = init_weights(3, D, F, std=0.02)
+    write_caffemodel(pb, str(tmp_path / "init.caffemodel"), W0, b0)
+    src = "synthetic://videos=%d;seed=1701;features=%d" % (V, F)
+    net_p, sol_p = tmp_path / "net.prototxt", tmp_path / "solver.prototxt"
+    net_p.write_text(train_net(src, B, C, Nn, D, max_buffer=500, w_std=0.02))
+    sol_p.write_text(solver(str(net_p), base_lr=0.01, max_iter=IT, display=1, snapshot=0, snapshot_prefix=str(tmp_path / "snap")))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, WORLD_SIZE="2", RANK=str(r), LOCAL_RANK="0", VV_COMM="shm", VV_JOB_ID="pr%d" % os.getpid(), VV_DEDUP="0")
+        procs.append(subprocess.Popen([CAFFE, "train", "--solver=%s" % sol_p, "--weights=%s" % (tmp_path / "init.caffemodel"),
+                                       "--gpu=0", "--log_file=%s" % (tmp_path / "dp.log")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[1][-3000:]
+    logs = [open(tmp_path / "dp.log").read(), open(str(tmp_path / "dp.log") + ".rank1").read()]
+    assert "own sampler, srand(1), first record 0" in logs[0] and "own sampler, srand(2), first record %d" % (V // 2) in logs[1]
+    got = [[float(x) for x in re.findall(r"Iteration \d+, loss = ([0-9.eE+-]+)", l)] for l in logs]
+
+    ds = SyntheticVideos(seed=1701, n_videos=V)
+    table = ds.table(F)
+    smp = [oracle.Sampler(ds.video_id, ds.n_shots, ds.row_base, batch_size=B, context_size=C, num_negative_samples=Nn,
+                          max_buffer_size=500, negative_swap_percentage=50, seed=1 + r, initial_cursor=(r * V) // 2) for r in range(2)]
+    Wq, bq = W0.copy(), b0.copy()
+    hW, hb = np.zeros_like(W0), np.zeros_like(b0)
+    for it in range(IT):
+        res = [oracle.forward_backward(table, smp[r].next()[0], round_operand(Wq, "f16"), bq, C_=C, Nn=Nn, want=("dW", "db")) for r in range(2)]
+        for r in range(2):
+            assert abs(got[r][it] - res[r]["loss"]) <= 1e-3 * res[r]["loss"], (it, r, got[r][it], res[r]["loss"])
+        lr = oracle.learning_rate("inv", 0.01, 1e-3, 0.75, 0, it)
+        oracle.sgd_update(Wq, 0.5 * (res[0]["dW"] + res[1]["dW"]), hW, lr, 1.0, 0.9, 5e-4, 1.0)
+        oracle.sgd_update(bq, 0.5 * (res[0]["db"] + res[1]["db"]), hb, lr, 2.0, 0.9, 5e-4, 0.0)

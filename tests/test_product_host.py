@@ -84,6 +84,33 @@ def test_sampler_initial_cursor_bit_exact_vs_oracle(oracle):
             assert np.array_equal(i1, i2) and np.array_equal(l1, l2) and np.array_equal(y1, y2)
 
 
+def test_sampler_rand_seed_bit_exact_vs_oracle(oracle):
+    """Per-rank samplers: rand_seed = srand() argument of the draw stream (the oracle's stream is pinned against the
+    real libc's srand / rand for other seeds in test_oracle_rng.py); cursor offset as a rank would use it."""
+    ds = SyntheticVideos(seed=7, n_videos=160, lo=2, span=40)
+    for seed, skip, same in [(2, 0, 0), (5, 40, 0), (123456789, 77, 3), (2147483646, 3, 0)]:
+        kw = dict(batch_size=32, context_size=5, num_negative_samples=10, max_buffer_size=300, negative_swap_percentage=50,
+                  max_same_video_negs=same, initial_cursor=skip)
+        a = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, rand_seed=seed, **kw)
+        b = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, rand_seed=seed, **kw)
+        b.prefetch_start(depth=4, threads=3)
+        o = oracle.Sampler(ds.video_id, ds.n_shots, ds.row_base, seed=seed, **kw)
+        for _ in range(6):
+            i1, l1, y1 = a.next(want_last=True, want_label=True)
+            i2, l2, y2 = o.next()
+            assert np.array_equal(i1, i2) and np.array_equal(l1, l2) and np.array_equal(y1, y2)
+            assert np.array_equal(b.next(), i2)
+        b.prefetch_stop()
+    # seed 0 and seed 1 are the reference's never-seeded stream
+    kw = dict(batch_size=8, context_size=5, num_negative_samples=4, max_buffer_size=64, negative_swap_percentage=50)
+    ref = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, **kw).next()
+    for seed in (0, 1):
+        assert np.array_equal(vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, rand_seed=seed, **kw).next(), ref)
+    assert not np.array_equal(vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, rand_seed=2, **kw).next(), ref)
+    with pytest.raises(vv.VVError):
+        vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, rand_seed=-3, **kw)
+
+
 def test_sampler_with_explicit_shot_ids_and_errors(oracle):
     ds = SyntheticVideos(seed=9, n_videos=30)
     sid = np.concatenate([np.arange(n)[::-1] * 3 for n in ds.n_shots]).astype(np.int32)

@@ -51,10 +51,11 @@ namespace {
 // word >> 1; the first 310 outputs are discarded by srandom.  (glibc 2.35 stdlib/random_r.c)
 class LibcRand {
  public:
-  void init(int block, int swap_pct) {
+  void init(int block, int swap_pct, uint32_t seed = 1) {
     uint32_t st[31];
-    int64_t w = 1;
-    st[0] = 1;
+    if (seed == 0) seed = 1;             // srandom_r: seed 0 is seed 1 (the never-seeded stream)
+    int64_t w = seed;
+    st[0] = seed;
     for (int i = 1; i < 31; ++i) {
       w = (16807 * w) % 2147483647;     // exact in 64 bits; equals glibc's overflow-free form
       st[i] = (uint32_t)w;
@@ -863,7 +864,7 @@ int vv_sampler_create_neg(const vv_sampler_param* p_in, int32_t n_videos, const 
       s->row_in_buf.assign((size_t)(hi - lo) + 64, 0);                            // 64 bytes of slack: the swap-in reads whole vectors
     }
   }
-  if (p->initial_cursor < 0) { delete s; return VV_ERR_ARG; }
+  if (p->initial_cursor < 0 || p->rand_seed < 0 || p->rand_seed == 2147483647) { delete s; return VV_ERR_ARG; }
   s->cursor = p->initial_cursor % n_videos;                                       // rand_skip, :156-180
   const int C = p->context_size, CN = C + Nn;
   s->fast = s->dense_keys && p->max_same_video_negs <= 0;
@@ -875,7 +876,7 @@ int vv_sampler_create_neg(const vv_sampler_param* p_in, int32_t n_videos, const 
     const int64_t per_item = (int64_t)C + Nn + 3ll * max_n + 32;
     const int64_t block = std::max<int64_t>(16384, 4 * per_item);
     if (block > (1ll << 28)) { delete s; return VV_ERR_ARG; }
-    s->rng.init((int)block, Nn > 0 ? p->negative_swap_percentage : 0);
+    s->rng.init((int)block, Nn > 0 ? p->negative_swap_percentage : 0, (uint32_t)p->rand_seed);
   }
   if (!s->fast) s->slots.assign((size_t)p->batch_size * CN, Slot());
   const int mb = Nn > 0 ? p->max_buffer_size : 0;

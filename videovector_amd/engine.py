@@ -389,7 +389,7 @@ class _SamplerParam(C.Structure):
                 ("num_negative_samples", C.c_int32), ("max_buffer_size", C.c_int32),
                 ("negative_swap_percentage", C.c_int32), ("max_same_video_negs", C.c_int32),
                 ("max_tries_for_negs", C.c_int32), ("context_type", C.c_int32), ("initial_cursor", C.c_int32),
-                ("output_shot_distance", C.c_int32), ("max_shot_distance", C.c_float)]
+                ("output_shot_distance", C.c_int32), ("max_shot_distance", C.c_float), ("rand_seed", C.c_int32)]
 
 
 CONTEXT_TYPES = {"WINDOW": 0, "PAST": 1, "PAST_CONTINUOUS": 2, "PAST_CONTINUOUS_FIXED": 3, "PAIRWISE": 4}
@@ -403,7 +403,7 @@ class Sampler:
     def __init__(self, video_id, n_shots, row_base, *, batch_size, context_size,
                  num_negative_samples, max_buffer_size=5000, negative_swap_percentage=50,
                  max_same_video_negs=0, max_tries_for_negs=100, shot_ids=None, context_type="WINDOW", initial_cursor=0,
-                 output_shot_distance=False, max_shot_distance=5.0, negatives=None):
+                 output_shot_distance=False, max_shot_distance=5.0, negatives=None, rand_seed=1):
         L = load_library()
         L.vv_sampler_create_neg.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -420,7 +420,7 @@ class Sampler:
         sid = None if shot_ids is None else np.ascontiguousarray(shot_ids, dtype=np.int32)
         p = _SamplerParam(batch_size, context_size, num_negative_samples, max_buffer_size,
                           negative_swap_percentage, max_same_video_negs, max_tries_for_negs,
-                          CONTEXT_TYPES[context_type], initial_cursor, int(output_shot_distance), max_shot_distance)
+                          CONTEXT_TYPES[context_type], initial_cursor, int(output_shot_distance), max_shot_distance, rand_seed)
         self.h = C.c_void_p()
         nvid = nns = nrb = nsid = None
         if negatives is not None:
