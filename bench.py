@@ -135,6 +135,8 @@ def main():
                          "N independent reference batches.  'node': ONE logical sampler draws the global batch of N*1024 exactly as "
                          "a single reference process with that batch size would (SURVEY 8e; the parity-tested form) and every rank "
                          "takes its slice out of a shared-memory ring -- bound by the sampler's serial walk (DESIGN.md 8)")
+    ap.add_argument("--cpu-bind", default="auto", choices=["auto", "off"],
+                    help="N>1: give every rank its own block of physical cores on its GPU's NUMA node (videovector_amd/hostbind.py)")
     ap.add_argument("--sampler-threads", type=int, default=int(os.environ.get("VV_SAMPLER_THREADS", "3")))
     ap.add_argument("--prefetch-depth", type=int, default=8)
     ap.add_argument("--settle-ms", type=float, default=50.0,
@@ -157,6 +159,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     dist = None
+    cpu_bind = "none (one rank)"
+    if world > 1 and args.cpu_bind == "auto":
+        # before the sampler's threads and the collective library's helper threads exist: they inherit the mask
+        from videovector_amd import hostbind
+        ndev = max(1, torch.cuda.device_count())
+        n_local = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        pci = []
+        for r in range(n_local):
+            pr = torch.cuda.get_device_properties(r % ndev)
+            pci.append((pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id))
+        cpu_bind = hostbind.bind(local_rank, pci)
+    elif world > 1:
+        cpu_bind = "off"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -523,6 +538,7 @@ def main():
                                    % (1 if args.workload == "cfg2" else 4, D, B_PER_GPU, Bg, NN),
                        "global_batch": Bg, "triplets_per_step": Bg * NN,
                        "parallelism": "dp%d" % world, "items_per_s": value / NN, "dedup": args.dedup,
+                       "cpu_binding_rank0": cpu_bind,
                        "sampler": ("one per rank: the reference's sampler at batch %d with srand(1 + rank) and its own starting record, "
                                    "%d stage thread(s), prefetch depth %d" % (B_PER_GPU, args.sampler_threads, args.prefetch_depth))
                                   if smode == "rank" else

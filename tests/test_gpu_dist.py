@@ -72,3 +72,4 @@ def test_bench_per_rank_samplers_is_the_default_for_two_ranks():
     assert d["one_logical_sampler"]["ms_per_global_batch"] > 0 and d["one_logical_sampler"]["bound_triplets_per_s"] > 0
     assert d["value"] > 0 and 0 < d["final_loss"] < 16 and d["settle"]["steps"] == 8
     assert d["gpu_path_only"]["value"] > 0 and d["dense_execution"]["value"] > 0
+    assert "logical CPUs" in d["config"]["cpu_binding_rank0"] or d["config"]["cpu_binding_rank0"].startswith("not bound")
