@@ -9,15 +9,16 @@ mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -q > $O/${TAG}_pytest.log 2>&1; echo "pytest exit $?" >> $O/${TAG}_pytest.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/${TAG}_smoke.log 2>&1; echo "smoke exit $?" >> $O/${TAG}_smoke.log
 timeout 900 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; echo "bench exit $?" >> $O/${TAG}_bench.err
+timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_driver_args.json 2>> $O/${TAG}_bench.err
 timeout 600 python bench.py --dedup off --no-cpu-baseline --no-extra-legs > $O/${TAG}_bench_dense.json 2>> $O/${TAG}_bench.err
 timeout 600 python bench.py --prec bf16 --no-cpu-baseline --no-extra-legs > $O/${TAG}_bench_bf16.json 2>> $O/${TAG}_bench.err
 timeout 600 python bench.py --workload cfg5 --no-cpu-baseline --no-extra-legs --steps 40 --warmup 5 > $O/${TAG}_bench_cfg5.json 2>> $O/${TAG}_bench.err
 rm -rf $O/prof_${TAG} && mkdir -p $O/prof_${TAG}
 for mode in on off; do
   P=$O/prof_${TAG}/dedup_${mode}
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -o kt -- python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extra-legs --dedup $mode > $O/${TAG}_prof_trace_${mode}.log 2>&1
-  timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $P/pmc_fetch -o pf -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra-legs --dedup $mode > $O/${TAG}_prof_fetch_${mode}.log 2>&1
-  timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $P/pmc_write -o pw -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra-legs --dedup $mode > $O/${TAG}_prof_write_${mode}.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -o kt -- python3 bench.py --steps 400 --warmup 5 --no-cpu-baseline --no-extra-legs --dedup $mode > $O/${TAG}_prof_trace_${mode}.log 2>&1
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $P/pmc_fetch -o pf -- python3 bench.py --steps 6 --warmup 2 --settle-ms 0 --no-cpu-baseline --no-extra-legs --dedup $mode > $O/${TAG}_prof_fetch_${mode}.log 2>&1
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $P/pmc_write -o pw -- python3 bench.py --steps 6 --warmup 2 --settle-ms 0 --no-cpu-baseline --no-extra-legs --dedup $mode > $O/${TAG}_prof_write_${mode}.log 2>&1
   python3 tools/summarize_prof.py $P > $O/${TAG}_kernel_trace_and_pmc_summary_dedup_${mode}.txt 2>&1
   cp $(find $P/trace -name "*kernel_stats.csv" | head -1) $O/${TAG}_kernel_stats_dedup_${mode}.csv
 done
@@ -30,7 +31,7 @@ for mode in on off; do
              "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS"; do
     i=$((i+1))
     P=$O/prof_${TAG}/sq_${mode}_$i
-    timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $P -o sq -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra-legs --dedup $mode > $O/${TAG}_sq_${mode}_$i.log 2>&1
+    timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $P -o sq -- python3 bench.py --steps 6 --warmup 2 --settle-ms 0 --no-cpu-baseline --no-extra-legs --dedup $mode > $O/${TAG}_sq_${mode}_$i.log 2>&1
   done
 done
 python3 - > $O/${TAG}_sq_counters_summary.txt <<'PY'
