@@ -17,7 +17,7 @@
 
 #include "vv_ctx.h"
 
-namespace vv { void set_wgrad_tr(bool on); void set_gemm_variant(int v); void set_ablate(int v); void set_score_reg(int v); void set_score_waves(int v); void set_ph_mq(int v); int gemm_variant(); bool ablate_on(); }
+namespace vv { void set_wgrad_tr(bool on); void set_gemm_variant(int v); void set_ablate(int v); void set_score_reg(int v); void set_score_waves(int v); void set_ph_mq(int v); void set_score_stream(int v); int gemm_variant(); bool ablate_on(); }
 using namespace vv;
 
 thread_local char vv_g_err[512] = "";
@@ -133,6 +133,8 @@ static int create_init(vv_ctx* c) {
   set_score_reg(sr ? atoi(sr) : 1);
   const char* sw = getenv("VV_SCORE_WAVES");
   set_score_waves(sw ? atoi(sw) : 8);
+  const char* sst = getenv("VV_SCORE_STREAM");
+  set_score_stream(sst ? atoi(sst) : 0);
   const char* pq = getenv("VV_PH_MQ");
   set_ph_mq(pq ? atoi(pq) : 0);
   const char* th = getenv("VV_TRACE_HOST");

@@ -61,9 +61,7 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 //   dAh = sum_q c_q H[q]/(n_q+eps);   dH[q] = c_q (n_q^2 Ah - H[q] t_q)/(n_q^3 + eps)
 //   dA  = (sA dAh - A (A.dAh))/(sA^1.5 + eps), dH[j] = c_j dA
 //   dY  = dH * drop_scale * [H > 0]
-// SEG: the segment-wise form of the backward (vv_internal.h: SegRec) for shapes the register-resident k_score_fwd does
-// not hold: no per-instance gradient rows, one record per instance, Ah / dA per item.
-template <typename T, bool VEC, bool SEG = false>
+template <typename T, bool VEC>
 __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int D = a.D, C = a.C, Nn = a.Nn, CN = C + Nn;
@@ -103,7 +101,6 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
   const float nA = sqrtf(sA) + eps;
   for (int d = tid; d < D; d += SL_THREADS) {
     Ah[d] = A[d] / nA;
-    if (SEG) a.V[(int64_t)2 * b * D + d] = Ah[d];
   }
   __syncthreads();
 
@@ -163,13 +160,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
     const float c = cq[ch], s = n2[ch], rs = sqrtf(s);
     const float cd = c * __builtin_amdgcn_rcpf(s * rs + eps) * a.drop_scale * a.sg;
     k1[ch] = cd * s; k2[ch] = cd * tq[ch]; k3[ch] = c * __builtin_amdgcn_rcpf(rs + eps);
-    if (SEG) { SegRec rc; rc.alpha = cd * s; rc.beta = cd * tq[ch]; rc.vec = 2 * b; rc.pad = b * CN + ch; a.rec[ooff[ch]] = rc; }
   }
-  if (SEG)
-    for (int j = 1 + tid; j < C; j += SL_THREADS) {
-      SegRec rc; rc.alpha = a.coeff[j - 1] * a.drop_scale * a.sg; rc.beta = 0.f; rc.vec = 2 * b + 1; rc.pad = b * CN + j;
-      a.rec[ooff[j]] = rc;
-    }
   __syncthreads();
 
   // ---- phase 4: backward of the normalised target / negative rows, column-parallel: a thread
@@ -194,11 +185,6 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
         float xv[W];
         if (VEC) { const float4 x = *(const float4*)h; xv[0] = x.x; xv[1 % W] = x.y; xv[2 % W] = x.z; xv[3 % W] = x.w; }
         else xv[0] = h[0];
-        if (SEG) {
-#pragma unroll
-          for (int e = 0; e < W; ++e) pa[e] += r3 * xv[e];
-          continue;
-        }
         uint16_t* dy = a.dYh + (int64_t)ooff[ch] * a.Dp + d;
         uint16_t o[W];
 #pragma unroll
@@ -231,7 +217,6 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
   const float inv_denA = 1.f / (sA * sqrtf(sA) + eps);
   for (int d = tid; d < D; d += SL_THREADS) {
     const float dA = (sA * acc0[d] - A[d] * dot) * inv_denA;
-    if (SEG) { a.V[(int64_t)(2 * b + 1) * D + d] = dA; continue; }
     float dbv = 0.f;
     for (int gI = 0; gI < G; ++gI) dbv += acc1[gI * D + d];
     for (int j = 1; j < C; ++j) {
@@ -663,16 +648,189 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
   }
 }
 
+// ---- the same pass for items that do not fit in registers (D = 1024, hundreds of negatives: the per-GPU shape of BASELINE
+// configs[4]): ONE sweep over the item's rows.  A wave takes negatives wave, wave + NW, ...; a row is in registers (DV float4
+// per lane) while its norm and its dot with Ah are reduced inside the wave, and because every wave has computed the TARGET's
+// score for itself first, the row's hinge coefficient g_k is known right there: its record is written and k3 x_k is added to
+// the wave's partial dAh before the row is dropped.  Only the target's own coefficient (-sum of all g_k) has to wait for the
+// block-wide sum; wave 0 adds that row at the end.  (A segment-wise form of the streaming k_score_loss read every row twice: 0.92 ms of the
+// 2.26 ms cfg-5 step; this kernel 0.47 ms.)  Sums in a fixed order: a wave's rows in sequence, then the waves in sequence.
+template <int NW, int DV>
+__global__ __launch_bounds__(64 * NW) void k_score_stream(ScoreArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int THREADS = 64 * NW;
+  constexpr int CV = 256 * DV / THREADS;
+  static_assert(CV >= 1 && CV * THREADS == 256 * DV, "D must be a multiple of the thread count");
+  const int D = 256 * DV, C = a.C, Nn = a.Nn, CN = C + Nn;
+  float* A = sm;               // [D]
+  float* Ah = A + D;           // [D]
+  float* acc0 = Ah + D;        // [NW][D] per-wave partial dAh
+  float* red = acc0 + NW * D;  // [3 NW]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float eps = 1e-10f;
+  const int32_t* map = a.map + (int64_t)b * CN;
+  const int32_t* ord = a.ord + (int64_t)b * CN;
+
+  // ---- context mean and its norm (column-parallel: a thread owns CV columns)
+  float ssq = 0.f;
+#pragma unroll
+  for (int v = 0; v < CV; ++v) {
+    const int d = tid + v * THREADS;
+    float sx = 0.f;
+    for (int j = 1; j < C; ++j) sx += a.coeff[j - 1] * a.H[(int64_t)map[j] * D + d];
+    A[d] = sx;
+    ssq += sx * sx;
+  }
+  const float sA = block_sum_w<NW>(ssq, red);
+  const float nA = sqrtf(sA) + eps;
+  float* Vb = a.V + (int64_t)2 * b * D;
+#pragma unroll
+  for (int v = 0; v < CV; ++v) {
+    const int d = tid + v * THREADS;
+    const float ah = A[d] / nA;
+    Ah[d] = ah;
+    Vb[d] = ah;
+  }
+  __syncthreads();
+  float4 y[DV];
+#pragma unroll
+  for (int v = 0; v < DV; ++v) y[v] = *(const float4*)(Ah + lane * 4 + v * 256);
+
+  auto load_row = [&](int ch, float4* x) {
+    const float* h = a.H + (int64_t)map[ch] * D + lane * 4;
+#pragma unroll
+    for (int v = 0; v < DV; ++v) x[v] = *(const float4*)(h + v * 256);
+  };
+  // norm^2 and dot with Ah of a row held in registers; both totals in every lane
+  auto norm_dot = [&](const float4* x, float& s, float& t) {
+    float ps = 0.f, pt = 0.f;
+#pragma unroll
+    for (int v = 0; v < DV; ++v) {
+      ps += x[v].x * x[v].x + x[v].y * x[v].y + x[v].z * x[v].z + x[v].w * x[v].w;
+      pt += x[v].x * y[v].x + x[v].y * y[v].y + x[v].z * y[v].z + x[v].w * y[v].w;
+    }
+    ps = wave_sum63(ps); pt = wave_sum63(pt);
+    s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ps), 63));
+    t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pt), 63));
+  };
+
+  // ---- the target's score, by every wave for itself
+  float4 x0[DV];
+  load_row(0, x0);
+  float s0, t0;
+  norm_dot(x0, s0, t0);
+  const float sp = t0 / (sqrtf(s0) + eps);
+  const float wb = a.item_w ? a.item_w[b] : 1.f;
+
+  // ---- the wave's negatives: one sweep, the next row's loads issued before this row's reductions
+  float4 pa[DV];
+#pragma unroll
+  for (int v = 0; v < DV; ++v) pa[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float lsum = 0.f, vsum = 0.f, gsum = 0.f;
+  float4 xc[DV], xn[DV];
+  int k = wave;
+  if (k < Nn) load_row(C + k, xc);
+  for (; k < Nn; k += NW) {
+    const int ch = C + k;
+    const bool more = k + NW < Nn;               // wave-uniform
+    if (more) load_row(ch + NW, xn);
+    float sq, tq;
+    norm_dot(xc, sq, tq);
+    const float rs = sqrtf(sq);
+    const float sn = tq / (rs + eps);
+    const float d = sp - sn;
+    const float h = fmaxf(0.f, a.margin - d);
+    float g;     // max_margin_loss_layer.cpp:82-97, 152-186 (as k_score_fwd)
+    if (a.norm == 2) { lsum += wb * h * h; g = 2.f * wb * h * a.grad_scale; }
+    else { lsum += wb * fabsf(h); g = h > 0.f ? wb * a.grad_scale : 0.f; }
+    vsum += d < 0.f ? 1.f : 0.f;
+    gsum += g;
+    const float k3 = g * __builtin_amdgcn_rcpf(rs + eps);
+    const float cd = g * __builtin_amdgcn_rcpf(sq * rs + eps) * a.drop_scale * a.sg;
+    if (lane == 0) {
+      SegRec rc; rc.alpha = cd * sq; rc.beta = cd * tq; rc.vec = 2 * b; rc.pad = b * CN + ch;
+      a.rec[a.seg_start[map[ch]] + ord[ch]] = rc;
+      if (a.s_bogus) a.s_bogus[(int64_t)b * Nn + k] = sn;
+    }
+#pragma unroll
+    for (int v = 0; v < DV; ++v) {
+      pa[v].x += k3 * xc[v].x; pa[v].y += k3 * xc[v].y; pa[v].z += k3 * xc[v].z; pa[v].w += k3 * xc[v].w;
+    }
+    if (more) {
+#pragma unroll
+      for (int v = 0; v < DV; ++v) xc[v] = xn[v];
+    }
+  }
+  // ---- block-wide loss / violations / sum of the coefficients (every lane of a wave holds the wave's values)
+  __syncthreads();
+  if (lane == 0) { red[wave] = lsum; red[NW + wave] = vsum; red[2 * NW + wave] = gsum; }
+  __syncthreads();
+  lsum = vsum = gsum = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) { lsum += red[w]; vsum += red[NW + w]; gsum += red[2 * NW + w]; }
+  if (tid == 0) {
+    a.loss_part[b] = lsum;
+    a.viol_part[b] = vsum;
+    if (a.s_true) a.s_true[b] = sp;
+    if (a.gate_host && b == 0) __hip_atomic_store(a.gate_host, a.gate_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  // ---- the target row: coefficient -sum_k g_k (wave 0 adds it to its partial)
+  if (wave == 0) {
+    const float c = -gsum, rs = sqrtf(s0);
+    const float k3 = c * __builtin_amdgcn_rcpf(rs + eps);
+    const float cd = c * __builtin_amdgcn_rcpf(s0 * rs + eps) * a.drop_scale * a.sg;
+    if (lane == 0) { SegRec rc; rc.alpha = cd * s0; rc.beta = cd * t0; rc.vec = 2 * b; rc.pad = b * CN; a.rec[a.seg_start[map[0]] + ord[0]] = rc; }
+#pragma unroll
+    for (int v = 0; v < DV; ++v) {
+      pa[v].x += k3 * x0[v].x; pa[v].y += k3 * x0[v].y; pa[v].z += k3 * x0[v].z; pa[v].w += k3 * x0[v].w;
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < DV; ++v) *(float4*)(acc0 + wave * D + lane * 4 + v * 256) = pa[v];
+  for (int j = 1 + tid; j < C; j += THREADS) {
+    SegRec rc; rc.alpha = a.coeff[j - 1] * a.drop_scale * a.sg; rc.beta = 0.f; rc.vec = 2 * b + 1; rc.pad = b * CN + j;
+    a.rec[a.seg_start[map[j]] + ord[j]] = rc;
+  }
+  __syncthreads();
+
+  // ---- backward of the context normalisation: dA_b
+  float dot = 0.f;
+  float u[CV];
+#pragma unroll
+  for (int v = 0; v < CV; ++v) {
+    const int d = tid + v * THREADS;
+    float us = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) us += acc0[w * D + d];
+    u[v] = us;
+    dot += A[d] * us;
+  }
+  dot = block_sum_w<NW>(dot, red);
+  const float inv_denA = 1.f / (sA * sqrtf(sA) + eps);
+#pragma unroll
+  for (int v = 0; v < CV; ++v) {
+    const int d = tid + v * THREADS;
+    Vb[D + d] = (sA * u[v] - A[d] * dot) * inv_denA;
+  }
+}
+
 // the segment-wise pair: k_seg_bwd holds a row of D = 512 or 1024 columns; the forward is the register-resident
 // k_score_fwd where an item fits (D = 512, up to 56 target / negative rows, 6 context rows), else the streaming kernel
 bool score_fwd_supported(const ScoreArgs& a) { return a.D == 512 || a.D == 1024; }
 
+static int g_score_stream = 0;            // VV_SCORE_STREAM=1: the one-sweep streaming kernel for every shape (A/B against k_score_fwd)
+void set_score_stream(int v) { g_score_stream = v; }
 void launch_score_fwd(const ScoreArgs& a, hipStream_t s) {
   const int rows = 1 + a.Nn;
-  if (!(a.D == 512 && a.C - 1 <= 6 && rows <= 56)) {
-    const size_t lds = sizeof(float) * ((size_t)2 * a.D + 2 * (a.D > 1024 ? a.D : 1024) + 8 * (a.C + a.Nn) + 8);
-    (void)hipFuncSetAttribute((const void*)k_score_loss<F16, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    VV_LAUNCH((k_score_loss<F16, true, true>), dim3(a.B), dim3(SL_THREADS), lds, s, a);
+  if (!(a.D == 512 && a.C - 1 <= 6 && rows <= 56) || g_score_stream == 1) {
+    const size_t lds = sizeof(float) * ((size_t)(2 + 8) * a.D + 3 * 8);
+    if (a.D == 512) {
+      (void)hipFuncSetAttribute((const void*)k_score_stream<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      VV_LAUNCH((k_score_stream<8, 2>), dim3(a.B), dim3(512), lds, s, a);
+    } else {
+      (void)hipFuncSetAttribute((const void*)k_score_stream<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      VV_LAUNCH((k_score_stream<8, 4>), dim3(a.B), dim3(512), lds, s, a);
+    }
     return;
   }
   const size_t lds = sizeof(float) * ((size_t)(2 + 8) * a.D + 4 * (a.C + a.Nn) + 3 * 8);
