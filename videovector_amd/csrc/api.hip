@@ -146,6 +146,7 @@ static int create_init(vv_ctx* c) {
   HIPCHK(hipMalloc(&c->dd_info_all, vv_ctx::kDdSets * 4 * sizeof(int32_t)));
   HIPCHK(hipMemset(c->dd_info_all, 0, vv_ctx::kDdSets * 4 * sizeof(int32_t)));
   HIPCHK(hipStreamCreateWithFlags(&c->dd_stream, hipStreamNonBlocking));
+  { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && ncu > 0) c->n_cu = ncu; }
   for (int i = 0; i < vv_ctx::kDdSets; ++i) {
     c->dd_set[i].info = c->dd_info_all + 4 * i;
     HIPCHK(hipEventCreateWithFlags(&c->dd_set[i].done, hipEventDisableTiming));
@@ -617,6 +618,14 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
     da.idx = didx; da.rows = c->dd_rows; da.u_host = c->U_host_dev; da.key = c->dd_key; da.agg = c->dd_agg; da.agg_stride = c->dd_agg_stride;
     da.slot_of = c->dd_slot_of; da.uniq_rows = c->dd_uniq; da.map = c->dd_map; da.ord = c->dd_ord; da.cnt = c->dd_cnt;
     da.seg_start = c->dd_seg; da.pos = c->dd_pos; da.info = c->dd_info; da.tickets = c->dd_info + 2;
+    {
+      // placement of the grouping workgroups beside the forward GEMM (kernels_dedup.hip): only when that GEMM -- sized for
+      // the previous step's distinct-row count, as launch_fwd_gemm will size it -- leaves at least 24 CUs idle
+      static const int lds_kb = getenv("VV_DEDUP_LDS_KB") ? atoi(getenv("VV_DEDUP_LDS_KB")) : -1;
+      const int hint = *(volatile int32_t*)c->U_host;
+      const long tiles = fwd_gemm_plan(c->R, hint, D, nullptr);
+      da.lds_bytes = lds_kb >= 0 ? lds_kb * 1024 : (c->dd_async && gemm_variant() == 5 && hint > 0 && tiles <= c->n_cu - 24 ? 36 * 1024 : 0);
+    }
     da.R = c->R; da.Rp = c->Rp; da.zero_row = (int32_t)c->n_rows; da.row_limit = (int32_t)row_limit; da.epoch = c->dd_epoch;
     PROFILED(c, "dedup", (launch_dedup(da, ds), launch_dedup_groups(da, ds)));
     if (c->dd_async) {

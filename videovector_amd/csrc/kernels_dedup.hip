@@ -152,17 +152,26 @@ __global__ __launch_bounds__(256) void k_dd_pos(DedupArgs a) {
 // measured: 26.9 us against 24.7 us for the four launches; with release / acquire fences at agent scope instead of
 // atomics 120 us.  A barrier across 55 workgroups costs about what a dependent launch does on this part.)
 
+// DedupArgs.lds_bytes: the grouping kernels of a later step run on the context's second stream BESIDE the forward GEMM
+// (api.hip, the async block).  That GEMM is one persistent 512-thread workgroup per CU holding 128 of the CU's 160 KiB of
+// LDS, on 216 of the 256 CUs at cfg 2; a grouping workgroup placed on one of those CUs slows that CU's GEMM workgroup and
+// the whole GEMM waits for it (0.085-0.088 ms against 0.080 alone).  Asking for 36 KiB of dynamic LDS they never touch
+// makes the grouping workgroups too big for the 32 KiB a GEMM workgroup leaves free: the dispatcher can place them only on
+// the CUs the GEMM does not use.  Forward GEMM 0.083 ms, step 3-5 us shorter (profiles/r02_step_ablations.txt, 4.).  The
+// caller asks for it only when the GEMM leaves CUs idle: beside a GEMM of more than one round of workgroups (cfg 5) a
+// grouping workgroup that cannot share a CU takes a whole CU away from the GEMM for its lifetime (forward 0.47 -> 0.50 ms).
+
 // part 1: what the forward GEMM needs (distinct rows and their count)
 void launch_dedup(const DedupArgs& a, hipStream_t s) {
   const int g256 = (a.Rp + 255) / 256;
-  VV_LAUNCH_FIRST(k_dd_claim, dim3(g256), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_dd_leaders, dim3((a.R + DD_BLOCK - 1) / DD_BLOCK), dim3(DD_BLOCK), 0, s, a);
+  VV_LAUNCH_FIRST(k_dd_claim, dim3(g256), dim3(256), a.lds_bytes, s, a);
+  hipLaunchKernelGGL(k_dd_leaders, dim3((a.R + DD_BLOCK - 1) / DD_BLOCK), dim3(DD_BLOCK), a.lds_bytes, s, a);
 }
 // part 2: what the score kernel needs (instance -> slot / grouped gradient row); independent of the
 // forward GEMM, so the caller may run it on a second stream beside it
 void launch_dedup_groups(const DedupArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_dd_map, dim3((a.R + 255) / 256), dim3(256), 0, s, a);
-  VV_LAUNCH_LAST(k_dd_segstart, dim3(a.R / DD_BLOCK + 1), dim3(DD_BLOCK), 0, s, a);
+  hipLaunchKernelGGL(k_dd_map, dim3((a.R + 255) / 256), dim3(256), a.lds_bytes, s, a);
+  VV_LAUNCH_LAST(k_dd_segstart, dim3(a.R / DD_BLOCK + 1), dim3(DD_BLOCK), a.lds_bytes, s, a);
 }
 // instance -> grouped gradient row as an array; the score kernel computes the same value inline, only the
 // debug accessor (vv_blobs_get ip1_diff) needs it materialised

@@ -580,12 +580,13 @@ static void launch_fwd_ph_q(const FwdArgs& a, hipStream_t s) {
 static int g_ph_mq = 0;                   // VV_PH_MQ: force the tile height (2, 3, 4); 0 = automatic
 void set_ph_mq(int v) { g_ph_mq = v; }
 
-template <typename T, bool DROP, bool VEC>
-static void launch_fwd_ph_t(const FwdArgs& a, hipStream_t s) {
-  const int Dp = (int)round_up(a.D, D_ALIGN);
-  // tile height 64*MQ with the least (rounds of 256 workgroups) x (cost of one K-tile of that height); the cost of a
-  // K-tile is not proportional to MQ: the LDS-DMA stream and the barriers do not shrink with the tile
-  const int Rh = a.n_dev && a.R_hint > 0 ? (int)std::min<long>(a.R, a.R_hint + a.R_hint / 32 + 64) : a.R;
+// Tile height 64*MQ of the forward GEMM for R rows (R_hint > 0: the distinct-row count of the previous step, the rows
+// the workgroups will really find) and the number of workgroups that get a tile: the least (rounds of 256 workgroups) x
+// (cost of one K-tile of that height); the cost of a K-tile is not proportional to MQ: the LDS-DMA stream and the
+// barriers do not shrink with the tile.
+long fwd_gemm_plan(int R, int R_hint, int D, int* mq_out) {
+  const int Dp = (int)round_up(D, D_ALIGN);
+  const int Rh = R_hint > 0 ? (int)std::min<long>(R, R_hint + R_hint / 32 + 64) : R;
   static const int kCost[5] = {0, 0, 70, 85, 100};
   int best = 4; long best_cost = -1;
   for (int mq = 4; mq >= 2; --mq) {
@@ -594,6 +595,15 @@ static void launch_fwd_ph_t(const FwdArgs& a, hipStream_t s) {
     if (best_cost < 0 || cost < best_cost) { best = mq; best_cost = cost; }
   }
   if (g_ph_mq >= 2 && g_ph_mq <= 4) best = g_ph_mq;
+  if (mq_out) *mq_out = best;
+  return ((Rh + 64 * best - 1) / (64 * best)) * (long)(Dp / BN);
+}
+
+template <typename T, bool DROP, bool VEC>
+static void launch_fwd_ph_t(const FwdArgs& a, hipStream_t s) {
+  const int Dp = (int)round_up(a.D, D_ALIGN);
+  int best;
+  (void)fwd_gemm_plan(a.R, a.n_dev ? a.R_hint : 0, a.D, &best);
   if constexpr (T::id == 0 && !DROP && VEC) {
     if (a.abl) {
       const dim3 grid(((a.R + 255) / 256) * (Dp / BN)), block(GEMM_THREADS);

@@ -49,6 +49,7 @@ struct vv_ctx {
   int D = 0, Dp = 0;
   float *W = nullptr, *b = nullptr, *hW = nullptr, *hb = nullptr;
   uint16_t* Wh = nullptr; vv::Scales* scales = nullptr; float* wmax_blocks = nullptr;
+  int n_cu = 256;                           // compute units of the device
   bool scale_pending = false;               // k_sgd ran, its scale update has not (it rides in the next k_reduce)
   float* grads = nullptr;           // [D*F + D] (own buffer, or the bound external one)
   float* grads_own = nullptr;

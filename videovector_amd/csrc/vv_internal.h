@@ -102,6 +102,7 @@ struct ScoreArgs {
 // the projection is computed once per unique row and the gradient rows of its instances are summed
 // before the weight-gradient GEMM.
 struct DedupArgs {
+  int lds_bytes = 0;             // dynamic LDS the kernels ask for and never touch (placement, kernels_dedup.hip)
   const int32_t* idx;            // [R] batch indices as sampled (-1 = empty slot)
   int32_t* rows;                 // [Rp] instance -> table row, written by k_dd_claim (what k_map_rows writes)
   unsigned long long* key;       // [table rows + scratch] epoch-tagged leader election
@@ -209,6 +210,7 @@ extern thread_local ProfPair g_prof;
 
 // kernel launchers (defined in the .hip files); prec: 0 = f16, 1 = bf16
 void launch_fwd_gemm(int prec, const FwdArgs& a, hipStream_t s);
+long fwd_gemm_plan(int R, int R_hint, int D, int* mq_out);   // workgroups of the default forward GEMM that get a tile
 void launch_wgrad_gemm(int prec, const WgradArgs& a, hipStream_t s);
 void launch_score_loss(int prec, const ScoreArgs& a, hipStream_t s);
 void launch_dedup(const DedupArgs& a, hipStream_t s);
