@@ -27,6 +27,7 @@ update.  What is timed, and reported as what:
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -138,7 +139,9 @@ def main():
     ap.add_argument("--cpu-bind", default="auto", choices=["auto", "off"],
                     help="N>1: give every rank its own block of physical cores on its GPU's NUMA node (videovector_amd/hostbind.py)")
     ap.add_argument("--sampler-threads", type=int, default=int(os.environ.get("VV_SAMPLER_THREADS", "3")))
-    ap.add_argument("--prefetch-depth", type=int, default=8)
+    ap.add_argument("--prefetch-depth", type=int, default=32,
+                    help="batches the sampler keeps ahead of the consumer (the reference: 1).  32 covers the stretches of a few dozen steps in "
+                         "which the sampler -- 0.175 ms per batch on average against a 0.225 ms step -- falls behind (profiles/r02_long_run.txt)")
     ap.add_argument("--settle-ms", type=float, default=50.0,
                     help="untimed steps of the same workload, this many ms of them, in front of the W warm-up steps of every "
                          "leg: the device needs ~25 ms of continuous work after an idle spell (set-up, a host-side leg) before "
@@ -398,6 +401,8 @@ def main():
                 eng.profile_select(GEMMS if profile == "gemm" else None)
                 eng.profile_enable(prof_every)
             evs = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)] if per_step_events else None
+            gc.collect()
+            gc.disable()             # (as timeit does: a collector pause of the Python driver loop is not the path's time)
             t0 = time.perf_counter()
             if evs: evs[0].record(work_stream)
             for i in range(S + Wm, S + Wm + K):
@@ -408,6 +413,7 @@ def main():
             torch.cuda.synchronize()
             if dist: dist.barrier()
             el = time.perf_counter() - t0
+            gc.enable()
             if dist:
                 t = torch.tensor([el], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
