@@ -1103,6 +1103,10 @@ int vv_allreduce_grads(vv_ctx* c) {
   if (!c->grads_pending) return VV_OK;                         // already summed
   HIPCHK(hipSetDevice(c->device));
   if (!c->grads_chunked) {                                     // the whole buffer, after everything queued on the compute stream
+    // synchronous schedule over RCCL: the collective goes straight into the compute stream (nothing would run beside it)
+    const int rc = vv::comm_allreduce_inline(c->comm, c->grads, (size_t)c->D * c->F + c->D, c->stream);
+    if (rc < 0) return fail(VV_ERR_HIP, "all-reduce: %s", vv::comm_error(c->comm));
+    if (rc == 0) { c->grads_pending = false; return VV_OK; }
     HIPCHK(hipEventRecord(c->ev_chunk, c->stream));
     if (vv::comm_allreduce(c->comm, c->grads, 0, (size_t)c->D * c->F + c->D, c->ev_chunk))
       return fail(VV_ERR_HIP, "all-reduce: %s", vv::comm_error(c->comm));

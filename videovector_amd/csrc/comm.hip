@@ -192,6 +192,16 @@ Comm* comm_create(int world, int rank, const char* id_path, int transport, size_
 
 // all-reduce(sum) of buf[0 .. n) in place.  `after`: the collective starts once this event (recorded on the compute
 // stream) has completed; on return ev_done (comm_done_event) marks its end on the communication stream.
+// The collective queued directly on the caller's stream (RCCL only): no second stream, no events.  For the synchronous
+// schedule, where nothing runs beside the all-reduce anyway, this saves the two stream joins (~6 us of stream time each).
+// Returns 1 when the transport cannot do that (the caller then uses comm_allreduce), 0 on success, -1 on error.
+int comm_allreduce_inline(Comm* c, float* buf, size_t n, hipStream_t stream) {
+  if (c->transport != VV_COMM_RCCL) return 1;
+  const int rc = c->AllReduce(buf, buf, n, kNcclFloat32, kNcclSum, c->nccl, stream);
+  if (rc != 0) { c->err = std::string("ncclAllReduce: ") + (c->ErrStr ? c->ErrStr(rc) : "error"); return -1; }
+  return 0;
+}
+
 int comm_allreduce(Comm* c, float* buf, size_t off, size_t n, hipEvent_t after) {
   if (after && hipStreamWaitEvent(c->stream, after, 0) != hipSuccess) { c->err = "hipStreamWaitEvent failed"; return -1; }
   if (c->transport == VV_COMM_RCCL) {

@@ -14,6 +14,7 @@ void comm_destroy(Comm* c);
 // all-reduce(sum) of buf[off .. off+n) in place on the communication stream, started after `after` (an event of the
 // compute stream, or null); comm_done_event marks its completion
 int comm_allreduce(Comm* c, float* buf, size_t off, size_t n, hipEvent_t after);
+int comm_allreduce_inline(Comm* c, float* buf, size_t n, hipStream_t stream);   // on the caller's stream (RCCL); 1 = not available
 hipEvent_t comm_done_event(Comm* c);
 const char* comm_error(Comm* c);
 int comm_world(Comm* c);
