@@ -384,6 +384,12 @@ def main():
         def timed(self, source, per_step_events=False, profile=True):
             """S settle steps, W warm-up steps, then exactly K steps between barrier + synchronize; max over ranks."""
             eng = self.eng
+            # Everything that takes host time happens HERE, before the settle steps: between the synchronisation that ends the
+            # warm-up and the first timed step the device must not sit idle (tens of ms of idling -- a collector run, thousands of
+            # event objects -- and it is back at the bottom of its clock ramp: a 20-step region then measures 0.26 ms, not 0.23).
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)] if per_step_events else None
+            gc.collect()
+            gc.disable()             # (as timeit does: a collector pause of the Python driver loop is not the path's time)
             cold = [torch.cuda.Event(enable_timing=True) for _ in range(min(S, 25))]
             for i in range(S):
                 if i < len(cold): cold[i].record(work_stream)
@@ -400,9 +406,6 @@ def main():
             if profile:
                 eng.profile_select(GEMMS if profile == "gemm" else None)
                 eng.profile_enable(prof_every)
-            evs = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)] if per_step_events else None
-            gc.collect()
-            gc.disable()             # (as timeit does: a collector pause of the Python driver loop is not the path's time)
             t0 = time.perf_counter()
             if evs: evs[0].record(work_stream)
             for i in range(S + Wm, S + Wm + K):

@@ -635,7 +635,9 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
       // stream at all (a wait packet in front of the forward GEMM costs ~6 us of stream time even when already satisfied);
       // otherwise the stream waits as usual.
       bool fired = false;
-      if (c->dd_spin_us > 0) {
+      // (an idle step stream -- the first step after a synchronisation -- means the grouping just queued cannot have run yet:
+      // watching it would hold the host for its whole 40 us while the GPU then waits for the step's launches; queue the wait)
+      if (c->dd_spin_us > 0 && hipStreamQuery(s) != hipSuccess) {
         const double t0 = host_now_ms();
         do { fired = hipEventQuery(set.done) == hipSuccess; } while (!fired && (host_now_ms() - t0) * 1e3 < c->dd_spin_us);
       }
