@@ -148,7 +148,7 @@ class VideoSampledShotsDataLayer : public Layer<Dtype> {
   shared_ptr<VideoDataset> dataset_;
   // prefetch: the sampler's background threads keep kPrefetchDepth index batches ahead of the solver
   // (BasePrefetchingDataLayer, base_data_layer.cpp:52-95; InternalThread, internal_thread.cpp:14-37)
-  static constexpr int kPrefetchDepth = 32;   // covers the stretches in which the sampler falls behind the GPU step
+  static constexpr int kPrefetchDepth = 128;   // covers the stretches in which the sampler falls behind the GPU step
   void CreatePrefetchThread();     // starts the prefetch threads (first call)
   void JoinPrefetchThread();       // the wait happens inside vv_sampler_next
   bool prefetching_ = false;
