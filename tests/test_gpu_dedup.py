@@ -190,3 +190,60 @@ def test_f16_gradient_scale_adapts_after_saturation(dedup):
     assert errs[0] > 1e-2, "the first step was expected to saturate"
     assert errs[-1] <= 2e-3
     ref.close(); eng.close()
+
+
+def test_kernel_timing_hook_samples_the_nth_steps_and_honours_the_selection(vv):
+    """vv_profile_enable(N): the N-th, 2N-th, ... step after the call carry timing events; vv_profile_select restricts
+    them to the named kernels (bench.py times the two GEMMs inside its timed region)."""
+    B, C, Nn, F, D = 64, 5, 10, 256, 512
+    ds, table, idx, W, b = make_case(5, 30, B, C, Nn, F, D, wstd=0.02)
+    eng = vv.Engine(0, "f16")
+    eng.table_set(table)
+    eng.params_set(W, b)
+    cfg = vv.StepConfig(B, C, Nn)
+    for _ in range(3):
+        eng.step(cfg, idx)
+    eng.profile_select(("fwd_gemm", "wgrad_gemm"))
+    eng.profile_enable(4)
+    for _ in range(10):
+        eng.step(cfg, idx)
+    got = {k: eng.profile_get(k) for k in ("dedup", "fwd_gemm", "score_loss", "segsum", "wgrad_gemm", "reduce", "sgd")}
+    assert got["fwd_gemm"][1] == 2 and got["wgrad_gemm"][1] == 2          # steps 4 and 8 of the 10
+    assert got["fwd_gemm"][0] > 0 and got["wgrad_gemm"][0] > 0
+    assert all(got[k][1] == 0 for k in ("dedup", "score_loss", "segsum", "reduce", "sgd"))
+    eng.profile_select(None)
+    eng.profile_enable(1)
+    eng.step(cfg, idx)
+    assert all(eng.profile_get(k)[1] == 1 for k in ("dedup", "fwd_gemm", "score_loss", "segsum", "wgrad_gemm", "reduce", "sgd"))
+    eng.profile_enable(False)
+    eng.close()
+
+
+def test_pending_scale_update_is_flushed_by_whatever_comes_next(vv):
+    """The W -> half scale update of an SGD step rides in the NEXT step's slab reduction; two updates in a row, a
+    parameter read-back or new parameters in between must give the same weights as the plain sequence."""
+    B, C, Nn, F, D = 64, 5, 10, 256, 512
+    ds, table, idx, W, b = make_case(6, 30, B, C, Nn, F, D, wstd=0.02)
+    cfg = vv.StepConfig(B, C, Nn, lr=0.5)                      # large steps: max |W| moves, the f16 scale with it
+
+    def run(variant):
+        eng = vv.Engine(0, "f16")
+        eng.table_set(table)
+        eng.params_set(W, b)
+        for it in range(6):
+            eng.forward_backward(cfg, idx)
+            eng.apply_update(cfg)
+            if variant == "double" and it == 2:
+                eng.apply_update(cfg)                          # same gradients applied twice: the pending update is flushed first
+            if variant == "readback" and it == 2:
+                eng.params_get()
+        out = eng.params_get()
+        emb = eng.embed(idx[:8, 0].copy())
+        eng.close()
+        return out, emb
+
+    (Wa, ba, _, _), ea = run("plain")
+    (Wr, br, _, _), er = run("readback")
+    assert np.array_equal(Wa, Wr) and np.array_equal(ba, br) and np.array_equal(ea, er)
+    (Wd, bd, _, _), ed = run("double")
+    assert np.isfinite(Wd).all() and np.isfinite(ed).all() and not np.array_equal(Wd, Wa)
