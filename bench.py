@@ -14,9 +14,10 @@ update.  What is timed, and reported as what:
   value            END TO END, sustainable: the triplet sampler (the reference's sequential libc-rand() sampler,
                    bit-exact) runs on prefetch threads INSIDE the timed region, as BasePrefetchingDataLayer's thread does
                    in the reference (base_data_layer.cpp:69-95); every step takes its batch out of the prefetch ring,
-                   sends the 225 KB of indices to the GPU (pinned staging, async H2D) and runs the iteration.  For N > 1
-                   ONE sampler per node (rank 0) draws the global batch and publishes it in POSIX shared memory; every
-                   rank takes its 1024 items.
+                   hands the 225 KB of indices to the GPU (pinned, device-mapped staging) and runs the iteration.  For N > 1
+                   every rank runs the reference's sampler for its own 1024 items (--sampler rank, the default: srand(1 + rank),
+                   its own starting record); --sampler node: ONE sampler per node (rank 0) draws the global batch and
+                   publishes it in POSIX shared memory, every rank takes its 1024 items (sampler-bound).
   gpu_path_only    the same K steps with the index batches already resident in HBM (sampler excluded) -- the kernel path
                    alone, what round 1 reported as `value`.
   dense_execution  gpu_path_only with row de-duplication off: every sampled row projected separately, as the reference does.
@@ -24,6 +25,10 @@ update.  What is timed, and reported as what:
                    and only f16 meets the 1e-3 embedding tolerance).
   step_ms_stats    min / median / p95 / max of the individual step times of a further run of the K steps with one HIP event
                    per step.
+  settle           every leg runs --settle-ms (50) ms of untimed steps in front of its W warm-up steps: after an idle spell the
+                   device needs ~25 ms of continuous work to reach a steady step time; the timed region is exactly K steps.
+Kernel durations (kernels_ms, roofline): HIP events on the kernels' own dispatch packets, on every max(4, K/8)-th step; inside the
+timed region only the two GEMMs carry them, the other kernels are timed on the same steps of the step_ms_stats leg.
 Prints ONE JSON line on rank 0.
 """
 import argparse
