@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- triplets/sec of the videovec_embedding training step on N MI355X (one process per GPU).
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W       (N > 1 without a launcher: starts its own N ranks, one per GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Workload = BASELINE.json configs[1] per GPU: synthetic fc7 features 4096-d -> 512-d embedding, batch 1024 per GPU
@@ -153,6 +153,12 @@ def main():
                          "its step time is steady (profiles/r02_step_ablations.txt, 3.).  0 = none: W warm-up steps only")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process -- which has not imported torch or touched HIP, and
+        # never exec()s -- becomes the launcher of N ranks of itself (videovector_amd/launch.py) and relays rank 0's line.
+        from videovector_amd.launch import launch_ranks
+        sys.exit(launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+
     global B_PER_GPU, NN, D
     if args.workload == "cfg5":
         B_PER_GPU, NN, D = 4096, 200, 1024
@@ -164,8 +170,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one process per GPU, or none: a bare "
+                         "`python bench.py --gpus N` starts its own ranks)" % (args.gpus, world))
     dist = None
     cpu_bind = "none (one rank)"
     if world > 1 and args.cpu_bind == "auto":
@@ -193,6 +199,10 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+        if os.environ.get("VV_BENCH_TEST_FAIL_RANK") == str(rank):
+            # test hook: this rank dies while the others wait for it in a collective (tests/test_gpu_dist.py)
+            print("rank %d: exiting on VV_BENCH_TEST_FAIL_RANK" % rank, file=sys.stderr)
+            os._exit(7)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 

@@ -73,3 +73,33 @@ def test_bench_per_rank_samplers_is_the_default_for_two_ranks():
     assert d["value"] > 0 and 0 < d["final_loss"] < 16 and d["settle"]["steps"] == 8
     assert d["gpu_path_only"]["value"] > 0 and d["dense_execution"]["value"] > 0
     assert "logical CPUs" in d["config"]["cpu_binding_rank0"] or d["config"]["cpu_binding_rank0"].startswith("not bound")
+
+
+def test_bench_bare_command_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: the process starts its two ranks itself
+    (videovector_amd/launch.py) and rank 0's ONE line comes out of its stdout -- the form the driver's 1-GPU command has."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(VV_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+                        "--no-cpu-baseline", "--settle-ms", "2"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 2048 and d["config"]["parallelism"] == "dp2"
+    assert d["config"]["allreduce"] and d["config"]["sampler"] and d["config"]["comm"]
+    assert d["roofline"]["frac"] > 0 and d["roofline"]["kernel"]
+    assert d["gpu_path_only"]["value"] > 0
+    assert d["value"] > 0 and abs(d["value"] - 2048 * 50 * 6 / (d["ms_per_step"] * 6e-3)) <= 1e-6 * d["value"]
+
+
+def test_bench_bare_command_a_dead_rank_fails_the_job():
+    """rank 1 dies right after the rendezvous while rank 0 waits for it: rc != 0 and a message, not a hang."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(VV_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", VV_BENCH_TEST_FAIL_RANK="1", VV_LAUNCH_GRACE="5")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-extra-legs", "--settle-ms", "2"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 7, (r.returncode, r.stderr[-2000:])
+    assert "rank 1 exited with code 7" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
