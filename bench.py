@@ -322,7 +322,7 @@ def main():
     def lr_at(it):     # shipped solver: inv policy, base 1e-3, gamma 1e-3, power .75
         return 1e-3 * (1.0 + 1e-3 * it) ** -0.75
 
-    KERNELS = ("dedup", "fwd_gemm", "score_loss", "segsum", "wgrad_gemm", "reduce", "sgd")
+    KERNELS = ("dedup", "fwd_gemm", "score_loss", "segsum", "guard", "wgrad_gemm", "reduce", "sgd")
     GEMMS = ("fwd_gemm", "wgrad_gemm")
 
     class Run:
@@ -388,7 +388,7 @@ def main():
                     eng.forward_backward_ring(cfg, ring, consumer=ring_consumer, item_begin=item_begin)
                     if diag: host_ms.append((time.perf_counter() - th0) * 1e3)
                 else:
-                    eng.forward_backward(cfg, idx_dev_ptr=idx_dev.data_ptr() + i * stride)
+                    eng.forward_backward(cfg, idx_dev_ptr=idx_dev.data_ptr() + i * stride, idx_ready=True)   # uploaded and synchronised at set-up
                 if comm == "torch" or Run.comm_kind == "torch":
                     dist.all_reduce(self.grads)
                 elif comm == "lib":

@@ -230,7 +230,10 @@ template <typename Dtype>
 void DropoutLayer<Dtype>::Backward_gpu(const vector<Blob<Dtype>*>& top, const vector<bool>& propagate_down, vector<Blob<Dtype>*>* bottom) {
   if (!propagate_down[0]) return;
   const int n = top[0]->count();
-  CHECK(Caffe::phase() == Caffe::TRAIN) << "DROPOUT backward is a TRAIN-phase operation";  // dropout_layer.cu:59-70
+  if (Caffe::phase() != Caffe::TRAIN) {      // dropout_layer.cu:68-70: outside TRAIN the diff passes through unchanged
+    VV_CHECK(vv_op_axpby(X(), n, 1.f, top[0]->gpu_diff(), 0.f, (*bottom)[0]->mutable_gpu_diff()));
+    return;
+  }
   const float ratio = (float)this->layer_param_.get_msg("dropout_param").get_num("dropout_ratio");
   VV_CHECK(vv_op_dropout(X(), n, top[0]->gpu_diff(), (*bottom)[0]->mutable_gpu_diff(), (uint8_t*)mask_, ratio, 0, 0));
 }

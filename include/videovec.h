@@ -56,6 +56,12 @@ int vv_synchronize(vv_ctx* ctx);
  * the last forward/backward pass and how many were distinct (rows == unique_rows on the dense path). */
 int vv_set_dedup(vv_ctx* ctx, int on);
 int vv_dedup_stats(vv_ctx* ctx, int64_t* rows, int64_t* unique_rows);
+/* f16 operands: the 16-bit gradient operand of the weight-gradient product (InnerProductLayer::Backward,
+ * inner_product_layer.cpp:80-97) carries one power-of-two scale per step.  A gradient value outside f16's range is never
+ * applied clipped: the kernels that round gradients record their maxima, and a step whose values did not fit produces
+ * them again at a smaller scale before the product runs (exact: powers of two).  `repeats` = steps so far that needed
+ * that (as reported by the device, four steps late); `scale` = the scale the next step starts with. */
+int vv_grad_scale_stats(vv_ctx* ctx, int64_t* repeats, float* scale);
 
 /* ---- feature table: stands for the rows the data layer copies out of the VideoShots DB
  * (VideoSampledShotsDataLayer::AddSamplesToTop, src/caffe/layers/video_sampled_shots_data_layer.cpp:
@@ -128,7 +134,10 @@ void vv_step_cfg_default(vv_step_cfg* cfg);
  * max-margin loss, and its backward down to the fc7 parameter gradients.
  * idx: int32 [B][C+Nn] table rows exactly as the data layer lays out its top blob
  * (video_sampled_shots_data_layer.cpp:214-220: channel 0 target, 1..C-1 context, C.. negatives),
- * -1 = all-zero row; idx_on_device != 0 means idx is a device pointer. */
+ * -1 = all-zero row.  idx_on_device: 0 = host array; 1 = device pointer whose contents were produced on the context's
+ * stream (vv_set_stream): every kernel of the step, the index grouping on the library's second stream included, is
+ * ordered after the work already queued there; 2 = device pointer whose contents are complete when the call is made
+ * (no ordering is added: static, pre-synchronised batches). */
 int vv_forward_backward(vv_ctx* ctx, const vv_step_cfg* cfg, const int32_t* idx, int idx_on_device);
 /* The same with the reference's quirk Q1 honoured: a same-video negative (max_same_video_negs > 0)
  * is copied WITHOUT its last feature (video_sampled_shots_data_layer.cpp:492), so that element of

@@ -89,6 +89,7 @@ void vv_step_cfg_default(vv_step_cfg* cfg) {
 }
 
 static int create_init(vv_ctx* c);
+static int comm_join(vv_ctx* c);
 
 int vv_create(int device, int prec, vv_ctx** out) {
   if (!out) return fail(VV_ERR_ARG, "vv_create: out is NULL");
@@ -159,6 +160,11 @@ static int create_init(vv_ctx* c) {
   HIPCHK(hipHostMalloc((void**)&c->U_host, 2 * sizeof(int32_t), hipHostMallocMapped));   // {U, saturated f16 gradient sums}
   c->U_host[0] = c->U_host[1] = 0;
   HIPCHK(hipHostGetDevicePointer((void**)&c->U_host_dev, c->U_host, 0));
+  HIPCHK(hipMalloc(&c->gg, sizeof(GradGuard)));
+  { GradGuard g0; memset(&g0, 0, sizeof(g0)); g0.mul = 1.f; HIPCHK(hipMemcpy(c->gg, &g0, sizeof(g0), hipMemcpyHostToDevice)); }
+  HIPCHK(hipHostMalloc((void**)&c->gmax_host, 32 * sizeof(unsigned long long), hipHostMallocMapped));
+  memset(c->gmax_host, 0, 32 * sizeof(unsigned long long));
+  HIPCHK(hipHostGetDevicePointer((void**)&c->gmax_host_dev, c->gmax_host, 0));
   HIPCHK(hipHostMalloc((void**)&c->seq_host, 2 * sizeof(int32_t), hipHostMallocMapped));
   c->seq_host[0] = c->seq_host[1] = 0;
   HIPCHK(hipHostGetDevicePointer((void**)&c->seq_host_dev, c->seq_host, 0));
@@ -198,8 +204,9 @@ static void free_batch(vv_ctx* c) {
     d.rows = d.slot_of = d.uniq = d.map = d.ord = d.cnt = d.seg = nullptr; d.used_seq = 0;
   }
   c->dd_rows = nullptr;
-  dfree(c->segV); dfree(c->seg_rec); dfree(c->seg_dbp);
-  c->segV = nullptr; c->seg_rec = nullptr; c->seg_dbp = nullptr;
+  dfree(c->segV); dfree(c->seg_rec); dfree(c->seg_dbp); dfree(c->gg_slots);
+  c->segV = nullptr; c->seg_rec = nullptr; c->seg_dbp = nullptr; c->gg_slots = nullptr; c->gg_nslot = 0;
+  c->sg_adj = 0; c->gg_seq0 = 0;
   c->dd_agg = nullptr; c->dd_slot_of = c->dd_uniq = c->dd_map = c->dd_ord = c->dd_cnt = c->dd_seg = c->dd_pos = nullptr;
   c->dYu = nullptr;
   c->idx_dev = c->rows = nullptr; c->H = nullptr; c->dYh = nullptr; c->dbp = nullptr;
@@ -212,17 +219,19 @@ int vv_destroy(vv_ctx* c) {
   if (!c) return VV_OK;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->comm) { vv::comm_destroy(c->comm); c->comm = nullptr; }    // drains the communication stream: before any buffer it uses goes
   vv_ops_release(c);
   free_batch(c);
   dfree(c->table); dfree(c->patch_desc); dfree(c->W); dfree(c->b); dfree(c->hW); dfree(c->hb); dfree(c->Wh);
   dfree(c->scales); dfree(c->wmax_blocks); dfree(c->grads_own); dfree(c->mask); dfree(c->loss2);
-  dfree(c->dd_key); dfree(c->dd_info_all);
+  dfree(c->dd_key); dfree(c->dd_info_all); dfree(c->gg);
+  if (c->gmax_host) (void)hipHostFree(c->gmax_host);
   for (int i = 0; i < vv_ctx::kDdSets; ++i) {
     if (c->dd_set[i].done) (void)hipEventDestroy(c->dd_set[i].done);
   }
   if (c->dd_stream) (void)hipStreamDestroy(c->dd_stream);
-  if (c->comm) vv::comm_destroy(c->comm);
   if (c->ev_chunk) (void)hipEventDestroy(c->ev_chunk);
+  if (c->ev_idx) (void)hipEventDestroy(c->ev_idx);
   if (c->U_host) (void)hipHostFree(c->U_host);
   for (int i = 0; i < vv_ctx::kStage; ++i)
     if (c->stage_host[i]) (void)hipHostFree(c->stage_host[i]);
@@ -237,7 +246,7 @@ int vv_destroy(vv_ctx* c) {
 int vv_set_dedup(vv_ctx* c, int on) {
   if (!c) return fail(VV_ERR_ARG, "vv_set_dedup: ctx is NULL");
   c->dedup = on != 0;
-  if (c->U_host) { c->U_host[1] = 0; c->sg_shift = 0; c->sg_clean_steps = 0; }   // a fresh start for the gradient scale
+  c->sg_adj = 0; c->gg_seq0 = 0;                                                  // a fresh start for the gradient scale
   return VV_OK;
 }
 
@@ -250,6 +259,13 @@ int vv_dedup_stats(vv_ctx* c, int64_t* rows, int64_t* unique_rows) {
   if (c->last_dedup) HIPCHK(hipMemcpy(&U, c->dd_info, sizeof(U), hipMemcpyDeviceToHost));
   if (rows) *rows = c->R;
   if (unique_rows) *unique_rows = U;
+  return VV_OK;
+}
+
+int vv_grad_scale_stats(vv_ctx* c, int64_t* repeats, float* scale) {
+  if (!c) return fail(VV_ERR_ARG, "vv_grad_scale_stats: ctx is NULL");
+  if (repeats) *repeats = c->gg_repeats;
+  if (scale) *scale = c->sg;
   return VV_OK;
 }
 
@@ -373,9 +389,11 @@ int vv_params_set(vv_ctx* c, int32_t D, const float* W, const float* b, const fl
   if (!c || !W || D <= 0) return fail(VV_ERR_ARG, "vv_params_set: bad argument");
   if (!c->table) return fail(VV_ERR_STATE, "vv_params_set: set the feature table first (defines F)");
   HIPCHK(hipSetDevice(c->device));
+  { const int rcj = comm_join(c); if (rcj) return rcj; }
   HIPCHK(hipStreamSynchronize(c->stream));
   const int F = c->F;
   const size_t nW = (size_t)D * F;
+  if (D != c->D && c->comm) return fail(VV_ERR_STATE, "vv_params_set: the communicator was sized for D = %d (vv_comm_destroy first)", c->D);
   if (D != c->D) {
     dfree(c->W); dfree(c->b); dfree(c->hW); dfree(c->hb); dfree(c->Wh); dfree(c->grads_own);
     c->W = c->b = c->hW = c->hb = nullptr; c->Wh = nullptr; c->grads = c->grads_own = nullptr;
@@ -472,6 +490,9 @@ static int ensure_batch(vv_ctx* c, int B, int C, int Nn) {
   HIPCHK(hipMalloc(&c->segV, (size_t)2 * B * D * 4));
   HIPCHK(hipMalloc(&c->seg_rec, (size_t)c->Rp * sizeof(SegRec)));
   HIPCHK(hipMalloc(&c->seg_dbp, (size_t)SEGB_BLOCKS * D * 4));
+  c->gg_nslot = std::max(std::max(B, SEGB_BLOCKS), (c->Rp + 3) / 4);
+  HIPCHK(hipMalloc(&c->gg_slots, (size_t)3 * 2 * c->gg_nslot * 4));
+  HIPCHK(hipMemset(c->gg_slots, 0, (size_t)3 * 2 * c->gg_nslot * 4));
   *c->U_host = 0;
   return VV_OK;
 }
@@ -521,11 +542,25 @@ static void flush_scale_update(vv_ctx* c) {
   c->scale_pending = false;
 }
 
+// Joins the communication stream: after this, everything the library queued there (block-wise all-reduces of the
+// overlapped schedule) has completed.  Callers that read or free the gradient buffer, or start a new backward pass into
+// it, go through here first.
+static int comm_join(vv_ctx* c) {
+  if (c->comm && c->grads_pending && c->grads_chunked) {
+    HIPCHK(hipStreamWaitEvent(c->stream, vv::comm_done_event(c->comm), 0));
+    c->grads_pending = false; c->grads_chunked = false;
+  }
+  return VV_OK;
+}
+
+// idx_on_device: 0 host indices; 1 device indices produced on the context's stream (ordered after everything queued
+// there); 2 device indices that are complete already (no ordering needed: the ring's staging slots, static batches)
 static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int idx_on_device, int64_t row_limit, int32_t seq = 0) {
   int rc = check_cfg(c, cfg);
   if (rc) return rc;
   if (!idx) return fail(VV_ERR_ARG, "vv_forward_backward: idx is NULL");
   HIPCHK(hipSetDevice(c->device));
+  if ((rc = comm_join(c))) return rc;        // an overlapped all-reduce of the previous backward pass still owns the gradient buffer
   if ((rc = ensure_batch(c, cfg->B, cfg->C, cfg->Nn))) return rc;
   const int B = c->B, C = c->C, Nn = c->Nn, CN = C + Nn, D = c->D;
   hipStream_t s = c->stream;
@@ -575,6 +610,12 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
     // kernels of step k and the step's own stream merely waits for an event that has long been signalled.  Three sets of
     // output arrays rotate; a set is rewritten only after the step that read it has issued its last reader.
     hipStream_t ds = c->dd_async ? c->dd_stream : s;
+    if (c->dd_async && idx_on_device == 1) {
+      // the caller's indices may still be in the making on the context's stream: the grouping stream waits for it
+      if (!c->ev_idx) HIPCHK(hipEventCreateWithFlags(&c->ev_idx, hipEventDisableTiming));
+      HIPCHK(hipEventRecord(c->ev_idx, s));
+      HIPCHK(hipStreamWaitEvent(ds, c->ev_idx, 0));
+    }
     const int64_t need = c->n_rows + 1 + c->patch_cap;
     if (need > c->dd_key_cap) {
       HIPCHK(hipStreamSynchronize(s));
@@ -662,19 +703,35 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   const int64_t gcount = cfg->global_count > 0 ? cfg->global_count : count;
   // half-precision gradient scale: a power of two near the loss count keeps dY*sg around 1
   int e; frexpf((float)gcount, &e);
-  // ... and follows the data like the loss scale of any half-precision trainer: when an earlier step reported 16-bit
-  // gradient values past f16's 65504 (they were stored saturated -- never inf / NaN -- and counted in host-visible
-  // memory: a row whose embedding norm is tiny has gradients ~ 1 / norm, times its multiplicity in the batch), the scale
-  // drops by 2^4 for the following steps; after 2000 clean steps it climbs back one power of two.  A power of two
-  // either way: exact to undo.
+  // ... and follows the data: every step reports its largest |dY| (k_reduce, a host-visible ring); when the max of step
+  // seq - 4 -- a FIXED lag, so that the scale sequence does not depend on host timing and runs stay bit-reproducible --
+  // lies outside [2^5, 2^13) in the current scaled units, the scale moves so that it lies in [2^9, 2^10).  This only
+  // keeps the guard's repeats rare: a value past f16's range never reaches the weight-gradient GEMM (GradGuard).
   if (c->prec == VV_PREC_F16) {
-    if (*(volatile int32_t*)(c->U_host + 1) > 0) {
-      *(volatile int32_t*)(c->U_host + 1) = 0;
-      c->sg_shift = std::min(c->sg_shift + 4, 48);
-      c->sg_clean_steps = 0; ++c->sg_overflows;
-    } else if (c->sg_shift > 0 && ++c->sg_clean_steps >= 2000) { --c->sg_shift; c->sg_clean_steps = 0; }
+    constexpr int kLag = 4;
+    if (c->gg_seq0 == 0) c->gg_seq0 = seq;
+    if (seq - c->gg_seq0 >= kLag) {
+      const int32_t want = seq - kLag;
+      volatile unsigned long long* en = c->gmax_host + 2 * (want & 15);
+      bool have = false;
+      for (unsigned spins = 0; !(have = (int32_t)(uint32_t)__atomic_load_n(en, __ATOMIC_ACQUIRE) == want); ++spins) {
+        if (spins > 4096) { timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
+        if (hipStreamQuery(s) == hipSuccess) { have = (int32_t)(uint32_t)__atomic_load_n(en, __ATOMIC_ACQUIRE) == want; break; }
+      }
+      if (have) {
+        const uint32_t bits = (uint32_t)(en[0] >> 32);
+        float gmax; memcpy(&gmax, &bits, 4);
+        if ((int32_t)(uint32_t)en[1] > 0) ++c->gg_repeats;
+        if (gmax > 0.f && std::isfinite(gmax)) {
+          int eu; (void)frexpf(gmax, &eu);
+          const int ex = eu + e + c->sg_adj;            // exponent of the max in the current scaled units
+          if (ex > 13 || ex < 5) c->sg_adj += 10 - ex;
+        }
+      }
+    }
+    c->sg_adj = std::max(-100 - e, std::min(100 - e, c->sg_adj));
   }
-  c->sg = c->prec == VV_PREC_F16 ? ldexpf(1.f, e - c->sg_shift) : 1.f;
+  c->sg = c->prec == VV_PREC_F16 ? ldexpf(1.f, e + c->sg_adj) : 1.f;
   c->last_loss_weight = cfg->loss_weight;
 
   ScoreArgs sa;
@@ -687,28 +744,48 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   sa.sg = c->sg;
   sa.map = dd ? c->dd_map : nullptr; sa.seg_start = dd ? c->dd_seg : nullptr; sa.ord = dd ? c->dd_ord : nullptr;
   sa.item_w = cfg->item_weight ? c->item_w : nullptr;
-  sa.overflow_host = c->U_host_dev + 1;
   sa.gate_host = c->seq_host_dev + 1; sa.gate_seq = seq;
 
   // de-duplicated batches of the supported shape: the backward stays factored per instance and is summed per distinct
   // row (k_score_fwd + k_seg_bwd); otherwise per-instance 16-bit gradient rows (+ k_segsum when de-duplicated)
   const bool seg = dd && c->seg_bwd && score_fwd_supported(sa);
   c->last_seg_bwd = seg; c->last_score = sa;
+  // f16 gradient-scale guard (vv_internal.h: GradGuard): the kernels that round gradients to 16 bits are launched once as
+  // usual (round 0) and once more per guard round as conditional repeats -- near-empty launches unless the round before
+  // reported a value past f16's range.  Rounds: 1 where one kernel rounds (per-instance rows, or the segment sums); 2 for
+  // rows + their sums (k_segsum): sums of clipped rows say nothing about the true sums, which the second round sees.
+  GuardArgs gd;
+  if (c->prec == VV_PREC_F16) { gd.gg = c->gg; gd.slots = c->gg_slots; gd.nslot = c->gg_nslot; gd.seq = seq; }
+  const int n_rounds = c->prec != VV_PREC_F16 ? 0 : (dd && !seg ? 2 : 1);
+  gd.n_of[0] = seg ? 0 : B;
+  gd.n_of[1] = seg ? SEGB_BLOCKS : (dd ? (c->Rp + 3) / 4 : 0);
+  SegBwdArgs ba;
+  SegsumArgs ga;
   if (seg) {
     sa.V = c->segV; sa.rec = c->seg_rec;
-    PROFILED(c, "score_loss", launch_score_fwd(sa, s));
-    SegBwdArgs ba;
     ba.H = c->H; ba.V = c->segV; ba.rec = c->seg_rec; ba.seg_start = c->dd_seg; ba.info = c->dd_info; ba.dYu = c->dYu;
     ba.dbp = c->seg_dbp; ba.Rp = c->Rp; ba.D = D; ba.Dp = c->Dp; ba.inv_sg = 1.f / c->sg;
-    ba.overflow_host = c->U_host_dev + 1;
-    PROFILED(c, "segsum", launch_seg_bwd(c->prec, ba, s));
-  } else PROFILED(c, "score_loss", launch_score_loss(c->prec, sa, s));
-
-  if (dd && !seg) {
-    SegsumArgs ga;
+  } else if (dd) {
     ga.dYh = c->dYh; ga.seg_start = c->dd_seg; ga.info = c->dd_info; ga.dYu = c->dYu; ga.Rp = c->Rp; ga.Dp = c->Dp;
-    ga.overflow_host = c->U_host_dev + 1;
-    PROFILED(c, "segsum", launch_segsum(c->prec, ga, s));
+  }
+  for (int round = 0; round <= n_rounds; ++round) {
+    gd.round = round; gd.final_round = round == n_rounds;
+    if (seg) {
+      if (round == 0) PROFILED(c, "score_loss", launch_score_fwd(sa, s));
+      ba.guard = gd; ba.guard.producer = 1; ba.guard.last = 1;
+      if (round == 0) PROFILED(c, "segsum", launch_seg_bwd(c->prec, ba, s));
+      else PROFILED(c, "guard", launch_seg_bwd(c->prec, ba, s));
+    } else {
+      sa.guard = gd; sa.guard.producer = 0; sa.guard.last = dd ? 0 : 1;
+      if (round == 0) PROFILED(c, "score_loss", launch_score_loss(c->prec, sa, s));
+      else if (!dd) PROFILED(c, "guard", launch_score_loss(c->prec, sa, s));
+      else launch_score_loss(c->prec, sa, s);
+      if (dd) {
+        ga.guard = gd; ga.guard.producer = 1; ga.guard.last = 1;
+        if (round == 0) PROFILED(c, "segsum", launch_segsum(c->prec, ga, s));
+        else PROFILED(c, "guard", launch_segsum(c->prec, ga, s));
+      }
+    }
   }
   WgradArgs wa;
   wa.dYh = dd ? c->dYu : c->dYh; wa.table = c->table; wa.rows = dd ? c->dd_uniq : c->rows; wa.slabs = c->slabs;
@@ -718,6 +795,10 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   ra.slabs = c->slabs; ra.S = c->S; ra.Dp = c->Dp; ra.Fp = c->Fp; ra.dbp = seg ? c->seg_dbp : c->dbp; ra.B = B;
   ra.db_rows = seg ? SEGB_BLOCKS : 0;
   ra.scales = c->scales; ra.sg = c->sg; ra.grads = c->grads; ra.D = D; ra.F = c->F;
+  if (gd.gg) {
+    ra.gg = c->gg; ra.gmax_slots = c->gg_slots; ra.gmax_n0 = gd.n_of[0]; ra.gmax_n1 = gd.n_of[1]; ra.gmax_stride = c->gg_nslot;
+    ra.gmax_host = c->gmax_host_dev; ra.seq = seq;
+  }
   ra.ip_scale = cfg->ip_regularization > 0.f ? 1.f + cfg->ip_regularization * 0.5f : 1.f;     // inner_product_layer.cpp:80-90
   ra.loss_part = c->loss_part; ra.viol_part = c->viol_part; ra.loss_scale = cfg->loss_weight / (float)count; ra.loss_out = c->loss2;
 
@@ -758,6 +839,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
 }
 
 int vv_forward_backward(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int idx_on_device) {
+  if (idx_on_device < 0 || idx_on_device > 2) return fail(VV_ERR_ARG, "vv_forward_backward: idx_on_device must be 0, 1 or 2");
   return fb_impl(c, cfg, idx, idx_on_device, c ? c->n_rows : 0);
 }
 
@@ -793,7 +875,7 @@ int vv_forward_backward_ring(vv_ctx* c, const vv_step_cfg* cfg, vv_batch_ring* r
   }
   const int32_t seq = ++c->step_seq;
   c->stage_seq[sl] = seq;
-  return fb_impl(c, cfg, c->stage_dev[sl], 1, c->n_rows, seq);
+  return fb_impl(c, cfg, c->stage_dev[sl], 2, c->n_rows, seq);
 }
 
 // Quirk Q1 (video_sampled_shots_data_layer.cpp:492): a same-video negative is copied WITHOUT its
@@ -903,6 +985,7 @@ int vv_grads_get(vv_ctx* c, float* dW, float* db) {
   if (!c) return fail(VV_ERR_ARG, "vv_grads_get: ctx is NULL");
   if (!c->have_fwd) return fail(VV_ERR_STATE, "vv_grads_get: no backward pass yet");
   HIPCHK(hipSetDevice(c->device));
+  { const int rcj = comm_join(c); if (rcj) return rcj; }       // block-wise all-reduces in flight: the buffer is read whole
   HIPCHK(hipStreamSynchronize(c->stream));
   const size_t nW = (size_t)c->D * c->F;
   if (dW) HIPCHK(hipMemcpy(dW, c->grads, nW * 4, hipMemcpyDeviceToHost));
@@ -914,6 +997,7 @@ int vv_blobs_get(vv_ctx* c, float* ip2, float* target_score, float* negative_sco
   if (!c) return fail(VV_ERR_ARG, "vv_blobs_get: ctx is NULL");
   if (!c->have_fwd) return fail(VV_ERR_STATE, "vv_blobs_get: no forward pass yet");
   HIPCHK(hipSetDevice(c->device));
+  { const int rcj = comm_join(c); if (rcj) return rcj; }
   HIPCHK(hipStreamSynchronize(c->stream));
   const int B = c->B, CN = c->C + c->Nn, D = c->D, Nn = c->Nn;
   const size_t n = (size_t)c->R * D;
@@ -945,10 +1029,19 @@ int vv_blobs_get(vv_ctx* c, float* ip2, float* target_score, float* negative_sco
     DevTmp<float> d;
     HIPCHK(d.alloc(n));
     DevTmp<uint16_t> ungrouped;
+    // the scale the step's 16-bit gradients really carry: the host's sg times what the guard's repeats took off
+    float sgf = c->sg;
+    if (c->prec == VV_PREC_F16) {
+      GradGuard gh;
+      HIPCHK(hipMemcpy(&gh, c->gg, sizeof(gh), hipMemcpyDeviceToHost));
+      sgf *= gh.mul;
+    }
     if (c->last_seg_bwd) {
       // the step kept its backward factored: produce the per-instance rows now (same forward values; the loss partials
       // it rewrites are the ones already there, its bias partials go to the buffer the step did not use)
-      launch_score_loss(c->prec, c->last_score, c->stream);
+      ScoreArgs la = c->last_score;
+      la.sg = sgf; la.guard = GuardArgs();
+      launch_score_loss(c->prec, la, c->stream);
     }
     if (c->last_dedup) {
       HIPCHK(ungrouped.alloc((size_t)c->R * c->Dp));
@@ -958,7 +1051,7 @@ int vv_blobs_get(vv_ctx* c, float* ip2, float* target_score, float* negative_sco
       launch_dedup_pos(da, c->stream);
       launch_gather_rows_u16(c->dYh, c->dd_pos, c->R, c->Dp, ungrouped, c->stream);
     }
-    launch_dyh_to_float(c->prec, ungrouped.p ? ungrouped.p : c->dYh, c->R, D, c->Dp, 1.f / c->sg, d, c->stream);
+    launch_dyh_to_float(c->prec, ungrouped.p ? ungrouped.p : c->dYh, c->R, D, c->Dp, 1.f / sgf, d, c->stream);
     HIPCHK(hipStreamSynchronize(c->stream));
     std::vector<float> tmp(n);
     HIPCHK(hipMemcpy(tmp.data(), d, n * 4, hipMemcpyDeviceToHost));

@@ -44,9 +44,45 @@ typedef int (*fn_CommDestroy)(NcclComm);
 typedef const char* (*fn_GetErrorString)(int);
 enum { kNcclFloat32 = 7, kNcclSum = 0 };
 
+// Who wrote a rendezvous object: the writer's pid and its start time (field 22 of /proc/<pid>/stat).  Rank 0 stays
+// inside comm_create until every rank has joined, so a reader accepts an id file / a shared-memory header only while
+// its writer is ALIVE: what a crashed or finished earlier run left behind under the same name is ignored (its writer
+// is gone, or the pid now belongs to a process with another start time).  All ranks of a communicator share one node
+// (one /proc); where /proc cannot be read the check degrades to "accept".
+static uint64_t proc_starttime(int pid) {
+  char path[64];
+  snprintf(path, sizeof(path), "/proc/%d/stat", pid);
+  FILE* f = fopen(path, "r");
+  if (!f) return 0;
+  char buf[1024];
+  const size_t n = fread(buf, 1, sizeof(buf) - 1, f);
+  fclose(f);
+  buf[n] = 0;
+  const char* p = strrchr(buf, ')');           // the command name may hold spaces and parentheses
+  if (!p) return 0;
+  int field = 2;
+  for (++p; *p; ++p)
+    if (*p == ' ' && ++field == 22) return strtoull(p + 1, nullptr, 10);
+  return 0;
+}
+static bool proc_readable() { return proc_starttime((int)getpid()) != 0; }
+static bool writer_alive(int pid, uint64_t start) {
+  if (!proc_readable()) return true;
+  return pid > 0 && start != 0 && proc_starttime(pid) == start;
+}
+
+struct IdFile {
+  uint64_t magic;                               // "VVRCID01"
+  int32_t pid; int32_t pad_;
+  uint64_t start;
+  char id[128];
+};
+static constexpr uint64_t kIdMagic = 0x5656524349443031ull;
+
 struct ShmHdr {
   uint64_t magic;
-  int32_t world; int32_t pad_;
+  int32_t world; int32_t pid;                   // pid, start: the creating rank 0 (see proc_starttime)
+  uint64_t start;
   uint64_t n_floats;
   alignas(64) std::atomic<int64_t> arrive;     // monotonic arrival counter (barrier generations of `world` arrivals)
 };
@@ -114,7 +150,7 @@ Comm* comm_create(int world, int rank, const char* id_path, int transport, size_
   if (transport == VV_COMM_RCCL) {
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", nullptr};
     for (int i = 0; names[i] && !c->dl; ++i) c->dl = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
-    if (!c->dl) return fail(std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?"));
+    if (!c->dl) { const char* e = dlerror(); return fail(std::string("cannot load librccl: ") + (e ? e : "?")); }
     auto GetUniqueId = (fn_GetUniqueId)dlsym(c->dl, "ncclGetUniqueId");
     auto CommInitRank = (fn_CommInitRank)dlsym(c->dl, "ncclCommInitRank");
     c->AllReduce = (fn_AllReduce)dlsym(c->dl, "ncclAllReduce");
@@ -127,23 +163,35 @@ Comm* comm_create(int world, int rank, const char* id_path, int transport, size_
       const int rc = GetUniqueId(&id);
       if (rc != 0) return fail(std::string("ncclGetUniqueId: ") + (c->ErrStr ? c->ErrStr(rc) : "error"));
       if (world > 1) {
+        IdFile rec;
+        memset(&rec, 0, sizeof(rec));
+        rec.magic = kIdMagic; rec.pid = (int32_t)getpid(); rec.start = proc_starttime(rec.pid);
+        memcpy(rec.id, &id, sizeof(id));
+        (void)unlink(id_path);                   // whatever an earlier run left under this name
         const std::string tmp = std::string(id_path) + ".tmp";
         FILE* f = fopen(tmp.c_str(), "wb");
-        if (!f || fwrite(&id, sizeof(id), 1, f) != 1) { if (f) fclose(f); return fail("cannot write " + tmp); }
+        if (!f || fwrite(&rec, sizeof(rec), 1, f) != 1) { if (f) fclose(f); return fail("cannot write " + tmp); }
         fclose(f);
         if (rename(tmp.c_str(), id_path) != 0) return fail(std::string("cannot rename to ") + id_path);
       }
     } else {
       const auto t0 = std::chrono::steady_clock::now();
       for (;;) {
+        IdFile rec;
         FILE* f = fopen(id_path, "rb");
-        if (f) { const size_t n = fread(&id, sizeof(id), 1, f); fclose(f); if (n == 1) break; }
+        if (f) {
+          const size_t n = fread(&rec, sizeof(rec), 1, f);
+          fclose(f);
+          // a file whose writer is not alive is a leftover: keep waiting for this launch's rank 0 to replace it
+          if (n == 1 && rec.magic == kIdMagic && writer_alive(rec.pid, rec.start)) { memcpy(&id, rec.id, sizeof(id)); break; }
+        }
         if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
           return fail(std::string("timed out waiting for the communicator id file ") + id_path);
         std::this_thread::sleep_for(std::chrono::milliseconds(5));
       }
     }
     const int rc = CommInitRank(&c->nccl, world, id, rank);
+    if (rank == 0 && world > 1) (void)unlink(id_path);      // every rank has joined (or the attempt failed): the file has done its job
     if (rc != 0) return fail(std::string("ncclCommInitRank: ") + (c->ErrStr ? c->ErrStr(rc) : "error"));
   } else if (transport == VV_COMM_SHM) {
     c->shm_name = shm_name_of(id_path);
@@ -170,20 +218,41 @@ Comm* comm_create(int world, int rank, const char* id_path, int transport, size_
     c->shm = (ShmHdr*)mem;
     if (rank == 0) {
       c->shm->world = world; c->shm->n_floats = n_floats; c->shm->arrive.store(0);
+      c->shm->pid = (int32_t)getpid(); c->shm->start = proc_starttime((int)getpid());
       std::atomic_thread_fence(std::memory_order_release);
       c->shm->magic = kShmMagic;
     } else {
+      // accept the object only once its header is complete AND its creator is alive; an object of an earlier run (opened
+      // before this launch's rank 0 unlinked and re-created the name) is dropped and the name opened again
       const auto t0 = std::chrono::steady_clock::now();
-      while (((volatile ShmHdr*)c->shm)->magic != kShmMagic) {
+      for (;;) {
+        volatile ShmHdr* h = (volatile ShmHdr*)c->shm;
+        if (h->magic == kShmMagic) {
+          std::atomic_thread_fence(std::memory_order_acquire);
+          if (writer_alive(h->pid, h->start)) break;
+          munmap((void*)c->shm, c->shm_bytes); c->shm = nullptr;
+          for (;;) {
+            const int fd2 = shm_open(c->shm_name.c_str(), O_RDWR, 0600);
+            struct stat st;
+            if (fd2 >= 0 && fstat(fd2, &st) == 0 && (size_t)st.st_size >= c->shm_bytes) {
+              void* m2 = mmap(nullptr, c->shm_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd2, 0);
+              close(fd2);
+              if (m2 != MAP_FAILED) { c->shm = (ShmHdr*)m2; break; }
+            } else if (fd2 >= 0) close(fd2);
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return fail("timed out waiting for " + c->shm_name);
+            std::this_thread::sleep_for(std::chrono::milliseconds(5));
+          }
+          continue;
+        }
         if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return fail("shared-memory object never initialised");
         std::this_thread::sleep_for(std::chrono::milliseconds(1));
       }
-      std::atomic_thread_fence(std::memory_order_acquire);
       if (c->shm->world != world || c->shm->n_floats != n_floats) return fail("shared-memory object belongs to a different job shape");
     }
     c->stage_floats = n_floats;
     if (hipHostMalloc((void**)&c->stage, n_floats * sizeof(float), hipHostMallocDefault) != hipSuccess) return fail("hipHostMalloc failed");
     if (!shm_barrier(c, timeout_s)) return fail("ranks did not all arrive");
+    if (rank == 0) shm_unlink(c->shm_name.c_str());     // every rank holds its mapping: the name has done its job (nothing is left behind, crash or not)
   } else {
     return fail("unknown transport");
   }

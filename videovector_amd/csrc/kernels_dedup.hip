@@ -182,18 +182,21 @@ void launch_dedup_pos(const DedupArgs& a, hipStream_t s) {
 // One wave per slot; a lane owns 8 consecutive columns (16-B loads) of every 512-column chunk.
 template <typename T>
 __global__ __launch_bounds__(256) void k_segsum(SegsumArgs a) {
+  // f16: the sum of a row repeated thousands of times, with gradients far above their usual scaled size, could pass
+  // 65504: the f16 gradient-scale guard (vv_internal.h: GradGuard) sees the sums before they are rounded.  A repeat finds
+  // the instance rows already rewritten at the reduced scale by the score kernel's repeat and simply sums them again.
+  __shared__ float ggs[16];
+  float sgm;
+  if (!gg_begin(a.guard, ggs, sgm)) return;
   const int U = a.info[0];
   const int Uk = (U + BK - 1) / BK * BK;             // the wgrad K loop reads whole BK-row steps
   const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (u >= Uk || u >= a.Rp) return;
-  // f16: the sum of a row repeated thousands of times, with gradients far above their usual O(1) scaled size, could pass
-  // 65504.  T::from_float saturates (no inf, no NaN downstream); every saturated value is counted in host-visible
-  // memory and the host switches the context to the dense path, which has no multiplicity factor (api.hip: fb_impl).
-  int saturated = 0;
+  const bool live = u < Uk && u < a.Rp;
+  double gmx = 0.0;
   int b = 0, e = 0;
   if (u < U) { b = a.seg_start[u]; e = a.seg_start[u + 1]; }
-  for (int c0 = lane * 8; c0 < a.Dp; c0 += 512) {
+  for (int c0 = lane * 8; live && c0 < a.Dp; c0 += 512) {
     double acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.0;
@@ -210,13 +213,11 @@ __global__ __launch_bounds__(256) void k_segsum(SegsumArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       o[j] = T::from_float((float)acc[2 * j]) | ((uint32_t)T::from_float((float)acc[2 * j + 1]) << 16);
-    if (T::id == 0) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) saturated |= fabs(acc[j]) > 65504.0;
-    }
+    for (int j = 0; j < 8; ++j) gmx = fmax(gmx, fabs(acc[j]));
     *(uint4*)(a.dYu + (int64_t)u * a.Dp + c0) = make_uint4(o[0], o[1], o[2], o[3]);
   }
-  if (T::id == 0 && saturated && a.overflow_host) __hip_atomic_fetch_add(a.overflow_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (a.guard.gg) gg_end(a.guard, gg_block_max((float)fmin(gmx, 3.0e38), ggs));
 }
 
 void launch_segsum(int prec, const SegsumArgs& a, hipStream_t s) {

@@ -81,6 +81,10 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
   float* k3 = k2 + CN;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float eps = 1e-10f;
+  __shared__ float ggs[16];
+  float sgm;
+  if (!gg_begin(a.guard, ggs, sgm)) return;
+  const float sg = a.sg * sgm;
   for (int ch = tid; ch < CN; ch += SL_THREADS) {
     const int r = b * CN + ch;
     hoff[ch] = a.map ? a.map[r] : r;
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
   for (int qi = tid; qi < 1 + Nn; qi += SL_THREADS) {
     const int ch = qi == 0 ? 0 : C + qi - 1;
     const float c = cq[ch], s = n2[ch], rs = sqrtf(s);
-    const float cd = c * __builtin_amdgcn_rcpf(s * rs + eps) * a.drop_scale * a.sg;
+    const float cd = c * __builtin_amdgcn_rcpf(s * rs + eps) * a.drop_scale * sg;
     k1[ch] = cd * s; k2[ch] = cd * tq[ch]; k3[ch] = c * __builtin_amdgcn_rcpf(rs + eps);
   }
   __syncthreads();
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
   // ---- phase 4: backward of the normalised target / negative rows, column-parallel: a thread
   // owns one group of W consecutive columns (16-B loads) and walks the rows of its row group,
   // keeping its dAh / db partial sums in registers (deterministic order, no atomics).
-  int sat = 0;                                // f16: gradient values past 65504 (stored saturated, reported to the host)
+  float gmx = 0.f;                            // max |g| in scaled units before rounding (f16 gradient-scale guard)
   constexpr int W = VEC ? 4 : 1;
   const int Dv = D / W;                       // column groups
   const int Dvp = Dv < SL_THREADS ? Dv : SL_THREADS;
@@ -193,14 +197,14 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
           float g = r1 * ya[e] - r2 * xv[e];            // already times sg (a power of two: exact)
           g = xv[e] > 0.f ? g : 0.f;
           pb[e] += g;
-          if (T::id == 0) sat |= fabsf(g) > 65504.f;
+          gmx = fmaxf(gmx, fabsf(g));
           o[e] = T::from_float(g);
         }
         if (VEC) *(uint2*)dy = make_uint2(o[0] | ((uint32_t)o[1 % W] << 16), o[2 % W] | ((uint32_t)o[3 % W] << 16));
         else dy[0] = o[0];
       }
 #pragma unroll
-      for (int e = 0; e < W; ++e) { acc0[rg * D + d + e] = pa[e]; acc1[rg * D + d + e] = pb[e] * (1.f / a.sg); }
+      for (int e = 0; e < W; ++e) { acc0[rg * D + d + e] = pa[e]; acc1[rg * D + d + e] = pb[e] * (1.f / sg); }
     }
   }
   __syncthreads();
@@ -224,12 +228,12 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
       float g = a.coeff[j - 1] * dA * a.drop_scale;
       g = x > 0.f ? g : 0.f;
       dbv += g;
-      if (T::id == 0) sat |= fabsf(g * a.sg) > 65504.f;
-      a.dYh[(int64_t)ooff[j] * a.Dp + d] = T::from_float(g * a.sg);
+      gmx = fmaxf(gmx, fabsf(g * sg));
+      a.dYh[(int64_t)ooff[j] * a.Dp + d] = T::from_float(g * sg);
     }
     a.dbp[(int64_t)b * D + d] = dbv;
   }
-  if (T::id == 0 && sat && a.overflow_host) __hip_atomic_fetch_add(a.overflow_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (a.guard.gg) gg_end(a.guard, gg_block_max(gmx, ggs));
 }
 
 // Register-resident variant for small (1+Nn) x D: each wave keeps its target / negative rows in
@@ -283,6 +287,10 @@ __global__ __launch_bounds__(64 * NW) void k_score_loss_reg(ScoreArgs a) {
   int* ooff = (int*)(red + 3 * NW);   // [CN] row of dYh receiving channel ch's gradient
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float eps = 1e-10f;
+  __shared__ float ggs[16];
+  float sgm;
+  if (!gg_begin(a.guard, ggs, sgm)) return;
+  const float sg = a.sg * sgm;
 
   // Every global read of ip2 is issued up front: the target / negative rows of this wave
   // (qi = wave, wave+NW, ...) and the context rows (thread tid owns columns tid + THREADS v).
@@ -381,7 +389,7 @@ __global__ __launch_bounds__(64 * NW) void k_score_loss_reg(ScoreArgs a) {
   // scalars k1 = c n^2/den, k2 = c t/den (both times drop_scale * sg) and k3 = c/(n+eps); per element
   // g*sg = k1*Ah - k2*x (masked), dAh += k3*x, db*sg += g*sg.  sg is a power of two, so carrying it through the sums
   // and dividing at the end changes no bit.
-  int sat = 0;
+  float gmx = 0.f;
   float4 pa[DV], pb[DV];
 #pragma unroll
   for (int v = 0; v < DV; ++v) { pa[v] = make_float4(0.f, 0.f, 0.f, 0.f); pb[v] = pa[v]; }
@@ -393,7 +401,7 @@ __global__ __launch_bounds__(64 * NW) void k_score_loss_reg(ScoreArgs a) {
     const float c = cq[ch], s = n2[ch], t = tq[ch];
     const float rs = sqrtf(s);
     const float k3 = c * __builtin_amdgcn_rcpf(rs + eps);
-    const float cd = c * __builtin_amdgcn_rcpf(s * rs + eps) * a.drop_scale * a.sg;
+    const float cd = c * __builtin_amdgcn_rcpf(s * rs + eps) * a.drop_scale * sg;
     const float k1 = cd * s, k2 = cd * t;
     uint16_t* dy = a.dYh + (int64_t)ooff[ch] * a.Dp;
 #pragma unroll
@@ -405,7 +413,7 @@ __global__ __launch_bounds__(64 * NW) void k_score_loss_reg(ScoreArgs a) {
       for (int e = 0; e < 4; ++e) {
         g[e] = k1 * yv[e] - k2 * xv[e];
         g[e] = xv[e] > 0.f ? g[e] : 0.f;
-        if (T::id == 0) sat |= fabsf(g[e]) > 65504.f;
+        gmx = fmaxf(gmx, fabsf(g[e]));
       }
       pa[v].x += k3 * xv[0]; pa[v].y += k3 * xv[1]; pa[v].z += k3 * xv[2]; pa[v].w += k3 * xv[3];
       pb[v].x += g[0]; pb[v].y += g[1]; pb[v].z += g[2]; pb[v].w += g[3];
@@ -414,7 +422,7 @@ __global__ __launch_bounds__(64 * NW) void k_score_loss_reg(ScoreArgs a) {
       *(uint2*)(dy + lane * 4 + v * 256) = make_uint2(lo, hi);
     }
   }
-  const float inv_sg = 1.f / a.sg;
+  const float inv_sg = 1.f / sg;
 #pragma unroll
   for (int v = 0; v < DV; ++v) {
     *(float4*)(acc0 + wave * D + lane * 4 + v * 256) = pa[v];
@@ -449,13 +457,13 @@ __global__ __launch_bounds__(64 * NW) void k_score_loss_reg(ScoreArgs a) {
         float g = cf[j] * dA * a.drop_scale;
         g = cx[j][v] > 0.f ? g : 0.f;
         dbv += g;
-        if (T::id == 0) sat |= fabsf(g * a.sg) > 65504.f;
-        a.dYh[(int64_t)ooff[j + 1] * a.Dp + d] = T::from_float(g * a.sg);
+        gmx = fmaxf(gmx, fabsf(g * sg));
+        a.dYh[(int64_t)ooff[j + 1] * a.Dp + d] = T::from_float(g * sg);
       }
     }
     a.dbp[(int64_t)b * D + d] = dbv;
   }
-  if (T::id == 0 && sat && a.overflow_host) __hip_atomic_fetch_add(a.overflow_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (a.guard.gg) gg_end(a.guard, gg_block_max(gmx, ggs));
 }
 #undef HROW
 
@@ -858,6 +866,9 @@ template <typename T, int CH>
 __global__ __launch_bounds__(256) void k_seg_bwd(SegBwdArgs a) {
   __shared__ float cs[4][512 * CH];
   __shared__ SegRec strip[4][64];
+  float sgm;                                          // a repeat (guard round 1) scales the sums by a further 2^-k
+  if (!gg_begin(a.guard, &cs[0][0], sgm)) return;
+  const bool first = a.guard.round == 0;              // the bias partials come out of the unrounded values: once
   const int U = a.info[0];
   const int Uk = min((U + BK - 1) / BK * BK, a.Rp);   // the wgrad K loop reads whole BK-row steps
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -867,8 +878,8 @@ __global__ __launch_bounds__(256) void k_seg_bwd(SegBwdArgs a) {
   for (int c = 0; c < CH; ++c)
 #pragma unroll
     for (int j = 0; j < 8; ++j) col[c][j] = 0.f;
-  int saturated = 0;
-  for (int u = blockIdx.x * 4 + wave; u < Uk; u += 4 * SEGB_BLOCKS) {
+  float gmx = 0.f;
+  for (int u = blockIdx.x * 4 + wave; u < Uk; u += 4 * (int)gridDim.x) {
     if (u >= U) {
 #pragma unroll
       for (int c = 0; c < CH; ++c) *(uint4*)(a.dYu + (int64_t)u * a.Dp + 512 * c + c0) = make_uint4(0u, 0u, 0u, 0u);
@@ -962,9 +973,9 @@ __global__ __launch_bounds__(256) void k_seg_bwd(SegBwdArgs a) {
       float g[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        g[j] = xv[j] > 0.f ? acc[c][j] - bs * xv[j] : 0.f;
+        g[j] = xv[j] > 0.f ? (acc[c][j] - bs * xv[j]) * sgm : 0.f;
         col[c][j] += g[j];
-        if (T::id == 0) saturated |= fabsf(g[j]) > 65504.f;
+        gmx = fmaxf(gmx, fabsf(g[j]));
       }
       uint32_t o[4];
 #pragma unroll
@@ -977,14 +988,20 @@ __global__ __launch_bounds__(256) void k_seg_bwd(SegBwdArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) cs[wave][512 * c + c0 + j] = col[c][j];
   __syncthreads();
-  for (int d = threadIdx.x; d < 512 * CH; d += 256)
-    a.dbp[(int64_t)blockIdx.x * D + d] = (cs[0][d] + cs[1][d] + cs[2][d] + cs[3][d]) * a.inv_sg;
-  if (T::id == 0 && saturated && a.overflow_host) __hip_atomic_fetch_add(a.overflow_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (first)
+    for (int d = threadIdx.x; d < 512 * CH; d += 256)
+      a.dbp[(int64_t)blockIdx.x * D + d] = (cs[0][d] + cs[1][d] + cs[2][d] + cs[3][d]) * a.inv_sg;
+  if (a.guard.gg) {
+    __syncthreads();
+    gg_end(a.guard, gg_block_max(gmx, &cs[0][0]));
+  }
 }
 
 void launch_seg_bwd(int prec, const SegBwdArgs& a, hipStream_t s) {
   const int ch = a.D / 512;
-#define VV_SB(T, CH) VV_LAUNCH((k_seg_bwd<T, CH>), dim3(SEGB_BLOCKS), dim3(256), 0, s, a)
+  // (a conditional repeat of the gradient-scale guard normally returns at once: a quarter of the grid starts faster)
+  const int nb = a.guard.round == 0 ? SEGB_BLOCKS : SEGB_BLOCKS / 4;
+#define VV_SB(T, CH) VV_LAUNCH((k_seg_bwd<T, CH>), dim3(nb), dim3(256), 0, s, a)
   if (prec == 0) { if (ch == 1) VV_SB(F16, 1); else VV_SB(F16, 2); }
   else { if (ch == 1) VV_SB(BF16, 1); else VV_SB(BF16, 2); }
 #undef VV_SB
@@ -1066,6 +1083,21 @@ __device__ __forceinline__ void reduce_loss(const ReduceArgs& a) {
   l = block_sum(l, red);
   v = block_sum(v, red + 4);
   if (threadIdx.x == 0) { a.loss_out[0] = l * a.loss_scale; a.loss_out[1] = v; }
+  if (a.gmax_host) {
+    // f16 gradient-scale guard: the step's largest |dY| (unscaled: the normal pass's per-block maxima over the host's sg)
+    // and the shift the repeats applied go to a host-visible ring; the host reads entry seq - 4 when it issues step seq
+    __shared__ float gsm[16];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < a.gmax_n0; i += 256) m = fmaxf(m, a.gmax_slots[i]);
+    for (int i = threadIdx.x; i < a.gmax_n1; i += 256) m = fmaxf(m, a.gmax_slots[(size_t)a.gmax_stride + i]);
+    m = gg_block_max(m, gsm);
+    if (threadIdx.x == 0) {
+      const int sh = a.gg ? a.gg->shift[3] : 0;
+      unsigned long long* e = a.gmax_host + 2 * (a.seq & 15);
+      __hip_atomic_store(e + 1, (unsigned long long)(unsigned)sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(e, ((unsigned long long)__float_as_uint(m / a.sg) << 32) | (unsigned)a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 // next W->half scale from the running max: f16 keeps max|W|*sw in [2^11, 2^12); bf16 needs none.  One 256-thread workgroup.
@@ -1104,7 +1136,8 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
     if (bid >= G - 1 - ndb) { reduce_db(a, bid - (G - 1 - ndb)); return; }
   }
   if (!(a.parts & 1)) return;
-  const float inv = a.ip_scale / (a.sg * a.scales->sx);
+  const float sgf = a.sg_dev ? *a.sg_dev : (a.gg ? a.sg * a.gg->mul : a.sg);   // the scale the 16-bit gradients really carry
+  const float inv = a.ip_scale / (sgf * a.scales->sx);
   const int64_t slab_sz = (int64_t)a.Dp * a.Fp;
   const int d0 = a.d_begin, dn = a.d_count > 0 ? a.d_count : a.D;
   if (VEC) {

@@ -15,6 +15,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <map>
+#include <mutex>
 
 #include "vv_ctx.h"
 
@@ -144,8 +146,17 @@ __global__ __launch_bounds__(EB) void k_max_margin_bwd(int count, const float* s
   }
 }
 // fp32 rows -> scaled 16-bit rows [R][Dp] (the weight-gradient kernel's dY operand)
+// the scale of those rows, on the device: max |dY| (k_absmax's float bits) placed in [2^11, 2^12) for f16 -- nothing can
+// leave f16's range, whatever the caller's gradients are; 1 for bf16
+__global__ void k_pick_scale(const unsigned* max_bits, int prec, float* sg_out) {
+  const float m = __uint_as_float(*max_bits);
+  float sg = 1.f;
+  if (prec == 0 && m > 0.f && isfinite(m)) { int e; (void)frexpf(m, &e); sg = ldexpf(1.f, 12 - e); }
+  *sg_out = sg;
+}
 template <typename T>
-__global__ __launch_bounds__(EB) void k_to_half_rows(const float* src, uint16_t* dst, int64_t rows, int cols, int cols_p, float scale) {
+__global__ __launch_bounds__(EB) void k_to_half_rows(const float* src, uint16_t* dst, int64_t rows, int cols, int cols_p, const float* scale_dev) {
+  const float scale = *scale_dev;
   const int64_t n = rows * cols_p;
   for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < n; i += (int64_t)gridDim.x * EB) {
     const int64_t r = i / cols_p; const int c = (int)(i - r * cols_p);
@@ -172,21 +183,33 @@ struct OpScratch {                 // per-context buffers of the INNER_PRODUCT o
   int32_t* ident = nullptr;
   uint16_t* dy16 = nullptr; float* slabs = nullptr; size_t slab_bytes = 0;
   float* loss2 = nullptr;
+  float* sgs = nullptr;                              // {max |dY| bits, scale} of the last backward call
+  int Fp = 0, Dp = 0;                                // the padded widths x16 / dy16 were sized for
 };
 
 }  // namespace
 
-static std::map<vv_ctx*, OpScratch>& scratch_map() { static std::map<vv_ctx*, OpScratch> m; return m; }
+// one entry per context; the map itself is shared by every context of the process (one lock around look-ups: contexts
+// may live on different host threads; an entry is only ever used by its own context's caller)
+static std::mutex g_scratch_mu;
+static std::map<vv_ctx*, OpScratch>& scratch_map_unlocked() { static std::map<vv_ctx*, OpScratch> m; return m; }
+static OpScratch& scratch_of(vv_ctx* c) {
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  return scratch_map_unlocked()[c];              // (std::map: references stay valid across other insertions)
+}
 void vv_ops_release(vv_ctx* c) {
-  auto it = scratch_map().find(c);
-  if (it == scratch_map().end()) return;
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  auto& scratch = scratch_map_unlocked();
+  auto it = scratch.find(c);
+  if (it == scratch.end()) return;
   OpScratch& s = it->second;
   if (s.x16) (void)hipFree(s.x16);
   if (s.ident) (void)hipFree(s.ident);
   if (s.dy16) (void)hipFree(s.dy16);
   if (s.slabs) (void)hipFree(s.slabs);
   if (s.loss2) (void)hipFree(s.loss2);
-  scratch_map().erase(it);
+  if (s.sgs) (void)hipFree(s.sgs);
+  scratch.erase(it);
 }
 
 #define NEED(c) do { if (!(c)) return vv_fail(VV_ERR_ARG, "%s: ctx is NULL", __func__); HIPCHK(hipSetDevice((c)->device)); } while (0)
@@ -289,7 +312,7 @@ int vv_op_max_margin(vv_ctx* c, int32_t count, const float* s_true, const float*
                      int32_t norm, float* loss, float* violations) {
   NEED(c);
   if (count < 1 || (norm != VV_NORM_L1 && norm != VV_NORM_L2)) return vv_fail(VV_ERR_ARG, "vv_op_max_margin: bad count / Unknown Norm");
-  OpScratch& s = scratch_map()[c];
+  OpScratch& s = scratch_of(c);
   if (!s.loss2) HIPCHK(hipMalloc(&s.loss2, 2 * sizeof(float)));
   hipLaunchKernelGGL(k_max_margin, dim3(1), dim3(EB), 0, c->stream, count, s_true, s_bogus, weight, margin, norm, s.loss2);
   float h[2];
@@ -332,9 +355,9 @@ int vv_op_inner_product(vv_ctx* c, const float* X, int64_t R, float* Y) {
   NEED(c);
   if (!c->W || !c->table) return vv_fail(VV_ERR_STATE, "vv_op_inner_product: table (it defines F) and parameters must be set first");
   if (!X || !Y || R <= 0 || R > (1ll << 30)) return vv_fail(VV_ERR_ARG, "vv_op_inner_product: bad argument");
-  OpScratch& s = scratch_map()[c];
+  OpScratch& s = scratch_of(c);
   const int64_t Rp = round_up(R, R_ALIGN);
-  if (Rp > s.x_rows) {
+  if (Rp > s.x_rows || s.Fp != c->Fp || s.Dp != c->Dp) {     // (new parameters / a new table on the same context: other widths)
     HIPCHK(hipStreamSynchronize(c->stream));
     if (s.x16) (void)hipFree(s.x16);
     if (s.ident) (void)hipFree(s.ident);
@@ -343,7 +366,7 @@ int vv_op_inner_product(vv_ctx* c, const float* X, int64_t R, float* Y) {
     HIPCHK(hipMalloc(&s.x16, (size_t)(Rp + 1) * c->Fp * 2));
     HIPCHK(hipMalloc(&s.ident, (size_t)Rp * 4));
     HIPCHK(hipMalloc(&s.dy16, (size_t)(Rp + BK) * c->Dp * 2));
-    s.x_rows = Rp;
+    s.x_rows = Rp; s.Fp = c->Fp; s.Dp = c->Dp;
   }
   HIPCHK(hipMemsetAsync(s.x16, 0, (size_t)(Rp + 1) * c->Fp * 2, c->stream));
   launch_table_convert(c->prec, X, s.x16, R, c->F, c->Fp, c->sx, c->stream);
@@ -363,17 +386,19 @@ int vv_op_inner_product(vv_ctx* c, const float* X, int64_t R, float* Y) {
 // Propagation to the bottom (dX = dY W, :51-57) is not built: the fc layer of this path sits on the data layer.
 int vv_op_inner_product_bwd(vv_ctx* c, const float* dY, int64_t R, float ip_regularization) {
   NEED(c);
-  OpScratch& s = scratch_map()[c];
+  OpScratch& s = scratch_of(c);
   const int64_t Rp = round_up(R, R_ALIGN);
-  if (!dY || R <= 0 || !s.x16 || Rp > s.x_rows) return vv_fail(VV_ERR_STATE, "vv_op_inner_product_bwd: call vv_op_inner_product on the same rows first");
+  if (!dY || R <= 0 || !s.x16 || Rp > s.x_rows || s.Fp != c->Fp || s.Dp != c->Dp) return vv_fail(VV_ERR_STATE, "vv_op_inner_product_bwd: call vv_op_inner_product on the same rows first");
   const int D = c->D, Dp = c->Dp;
-  // half-precision gradient scale as in the fused path: a power of two near the row count (loss gradients scale with
-  // 1 / count), exact to undo
-  int e2; frexpf((float)R, &e2);
-  const float sg = c->prec == VV_PREC_F16 ? ldexpf(1.f, e2) : 1.f;
+  // half-precision gradient scale: a power of two picked on the device from max |dY| itself (the caller's gradients are
+  // arbitrary: no value may reach the product clipped), exact to undo
+  if (!s.sgs) HIPCHK(hipMalloc(&s.sgs, 2 * sizeof(float)));
+  HIPCHK(hipMemsetAsync(s.sgs, 0, sizeof(float), c->stream));
+  launch_absmax(dY, R * D, (unsigned*)s.sgs, c->stream);
+  hipLaunchKernelGGL(k_pick_scale, dim3(1), dim3(1), 0, c->stream, (const unsigned*)s.sgs, c->prec, s.sgs + 1);
   HIPCHK(hipMemsetAsync(s.dy16, 0, (size_t)(Rp + BK) * Dp * 2, c->stream));
-  if (c->prec == 0) hipLaunchKernelGGL(k_to_half_rows<F16>, egrid(R * Dp), dim3(EB), 0, c->stream, dY, s.dy16, R, D, Dp, sg);
-  else hipLaunchKernelGGL(k_to_half_rows<BF16>, egrid(R * Dp), dim3(EB), 0, c->stream, dY, s.dy16, R, D, Dp, sg);
+  if (c->prec == 0) hipLaunchKernelGGL(k_to_half_rows<F16>, egrid(R * Dp), dim3(EB), 0, c->stream, dY, s.dy16, R, D, Dp, (const float*)(s.sgs + 1));
+  else hipLaunchKernelGGL(k_to_half_rows<BF16>, egrid(R * Dp), dim3(EB), 0, c->stream, dY, s.dy16, R, D, Dp, (const float*)(s.sgs + 1));
   const int tiles = (Dp / BM) * (c->Fp / BN);
   const int total_steps = (int)(Rp / BK);
   int S = std::max(1, std::min((256 + tiles - 1) / tiles, total_steps));
@@ -392,7 +417,7 @@ int vv_op_inner_product_bwd(vv_ctx* c, const float* dY, int64_t R, float ip_regu
   launch_wgrad_gemm(c->prec, wa, c->stream);
   ReduceArgs ra;
   ra.slabs = s.slabs; ra.S = S; ra.Dp = Dp; ra.Fp = c->Fp; ra.dbp = nullptr; ra.B = 0;
-  ra.scales = c->scales; ra.sg = sg; ra.grads = c->grads; ra.D = D; ra.F = c->F;
+  ra.scales = c->scales; ra.sg = 1.f; ra.sg_dev = s.sgs + 1; ra.grads = c->grads; ra.D = D; ra.F = c->F;
   ra.ip_scale = ip_regularization > 0.f ? 1.f + ip_regularization * 0.5f : 1.f;
   ra.loss_part = nullptr; ra.viol_part = nullptr; ra.loss_scale = 0.f; ra.loss_out = nullptr;
   ra.parts = 1;

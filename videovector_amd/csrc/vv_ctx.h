@@ -69,8 +69,14 @@ struct vv_ctx {
   // row de-duplication (kernels_dedup.hip)
   int dedup = 1;                    // 1 = on whenever dropout is off (VV_DEDUP / vv_set_dedup)
   bool last_dedup = false;          // what the last forward/backward pass used
-  int sg_shift = 0;                 // powers of two taken off the f16 gradient scale after saturated values were reported
-  int sg_clean_steps = 0; int64_t sg_overflows = 0;
+  // f16 gradient-scale guard (vv_internal.h: GradGuard)
+  vv::GradGuard* gg = nullptr; float* gg_slots = nullptr; int gg_nslot = 0;
+  unsigned long long* gmax_host = nullptr;     // pinned + mapped: 16 entries of {seq | bits(max |dY|) << 32, final shift}
+  unsigned long long* gmax_host_dev = nullptr;
+  int sg_adj = 0;                   // powers of two on top of the count-based default scale (follows the reported maxima)
+  int32_t gg_seq0 = 0;              // first step since the guard's state was reset (no reports older than that)
+  int64_t gg_repeats = 0;           // steps whose gradients had to be produced again at a smaller scale
+  float gg_last_mul = 1.f;          // (debug accessors) final scale multiplier of the last step, read back on demand
   unsigned long long* dd_key = nullptr; int64_t dd_key_cap = 0;
   unsigned long long* dd_agg = nullptr; int dd_agg_stride = 0;
   int32_t *dd_slot_of = nullptr, *dd_uniq = nullptr, *dd_map = nullptr, *dd_ord = nullptr, *dd_cnt = nullptr,
@@ -116,6 +122,7 @@ struct vv_ctx {
   bool grads_pending = false;       // a backward pass has produced gradients that have not been all-reduced / joined yet
   bool grads_chunked = false;       // ... and their all-reduce is already in flight on the communication stream
   hipEvent_t ev_chunk = nullptr;
+  hipEvent_t ev_idx = nullptr;      // orders the grouping stream behind caller-produced device indices (idx_on_device = 1)
   // profiling
   bool prof = false;
   int prof_every = 1;               // record every prof_every-th forward/backward + update (vv_profile_enable's argument)

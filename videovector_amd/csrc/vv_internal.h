@@ -37,6 +37,33 @@ struct Scales {
   unsigned wmax_bits;  // running max |W| (float bits) collected by the SGD kernel
 };
 
+// f16 gradient-scale guard.  The 16-bit gradient operand of the weight-gradient GEMM carries ONE power-of-two scale per
+// step (the host's sg).  A value past f16's range must never reach the GEMM clipped, so every kernel that rounds
+// gradients to 16 bits ("producer": k_score_loss / k_score_loss_reg, k_segsum, k_seg_bwd) records its per-block max |g|
+// (before rounding) and raises flag[round] when one passes GG_LIMIT; the host then launches the same producers once
+// more per guard round as conditional REPEATS: a repeat whose previous round raised no flag returns at once (the normal
+// case: one near-empty launch), otherwise it folds the recorded maxima, takes the excess powers of two off the scale
+// (max placed at 2^12) and produces its output again.  k_reduce undoes sg * mul.  Exact: powers of two only.
+struct GradGuard {
+  int32_t flag[4];           // flag[r] == seq: round r of step seq produced a value past GG_LIMIT
+  int32_t shift[4];          // shift[r], r = 1, 2: powers of two taken off the host's scale from round r on (cumulative);
+                             // shift[3]: the step's final shift
+  float mul;                 // 2^-shift of the step's last round
+  int32_t pad[3];
+};
+constexpr float GG_LIMIT = 32768.f;
+struct GuardArgs {
+  GradGuard* gg = nullptr;   // null: no guard (bf16 operands: fp32's exponent range)
+  float* slots = nullptr;    // [3 rounds][2 producers][nslot] per-block max |g| in the units of that round's scale
+  int nslot = 0;
+  int producer = 0;          // which producer of the round this launch is (0, 1)
+  int n_of[2] = {0, 0};      // blocks of producer 0 / 1 (0: that producer does not exist)
+  int round = 0;             // 0: the step's normal pass; r >= 1: the r-th conditional repeat
+  int last = 0;              // this launch closes the round (writes shift[round]) ...
+  int final_round = 0;       // ... and the round is the step's last (publishes mul)
+  int32_t seq = 0;
+};
+
 struct FwdArgs {
   const uint16_t* table;   // [n_rows + 1][Fp], last row all zero
   const int32_t* rows;     // [Rp] table row per batch row (already mapped, padding -> zero row)
@@ -89,7 +116,7 @@ struct ScoreArgs {
   const int32_t* map = nullptr;      // [R]
   const int32_t* seg_start = nullptr;  // [U + 1]   pos[r] = seg_start[map[r]] + ord[r]
   const int32_t* ord = nullptr;      // [R]
-  int32_t* overflow_host = nullptr;  // host-mapped counter of f16 gradient values that had to be saturated
+  GuardArgs guard;                   // f16 gradient-scale guard (kernels that write dYh)
   int32_t* gate_host = nullptr;      // host-mapped word that receives gate_seq when the kernel starts ("the forward GEMM
   int32_t gate_seq = 0;              //   of this step has finished": releases the host to queue a later step's grouping)
   // segment-wise backward (launch_score_fwd): outputs instead of dYh / dbp
@@ -131,7 +158,7 @@ struct SegBwdArgs {
   float* dbp;                    // [SEGB_BLOCKS][D] column sums of the unrounded rows, unscaled
   int Rp, D, Dp;
   float inv_sg;
-  int32_t* overflow_host = nullptr;
+  GuardArgs guard;
 };
 
 struct SegsumArgs {
@@ -140,7 +167,7 @@ struct SegsumArgs {
   const int32_t* info;           // {U}
   uint16_t* dYu;                 // [Rp][Dp] per-slot sums (zero rows up to the next multiple of BK)
   int Rp, Dp;
-  int32_t* overflow_host = nullptr;   // host-mapped counter of f16 sums that saturated
+  GuardArgs guard;
 };
 
 struct WgradArgs {
@@ -164,6 +191,11 @@ struct ReduceArgs {
   int db_rows = 0;         // rows of dbp (0 = B, one per item; the segment-wise backward writes SEGB_BLOCKS partials)
   const Scales* scales;
   float sg;
+  const GradGuard* gg = nullptr;   // f16: the step's final scale is sg * gg->mul
+  const float* sg_dev = nullptr;   // per-layer operator: the scale chosen on the device (overrides sg)
+  // the loss workgroup also reports the step's max |dY| (unscaled) and final shift to the host: ring of 16 entries
+  const float* gmax_slots = nullptr; int gmax_n0 = 0, gmax_n1 = 0, gmax_stride = 0;
+  unsigned long long* gmax_host = nullptr; int32_t seq = 0;
   float* grads;            // [D*F + D]
   int D, F;
   float ip_scale;          // 1 + regularization/2 (inner_product_layer.cpp:80-90), normally 1
@@ -284,6 +316,54 @@ struct BF16 {
     return __builtin_bit_cast(float, (uint32_t)v << 16);
   }
 };
+
+#ifdef __HIPCC__
+// ---- f16 gradient-scale guard, device side (GradGuard above).  Every thread of the block calls these.
+// max over the block, valid in every thread; smem: >= 16 floats of LDS not otherwise in use around the call
+__device__ __forceinline__ float gg_block_max(float v, float* smem) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float m = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, smem[w]);
+  return m;
+}
+// Start of a producer launch.  false: a repeat whose previous round raised no flag -- nothing to do, the caller returns
+// (all threads alike).  sg_mul: the power of two to put on top of the host's scale in this round.
+__device__ __forceinline__ bool gg_begin(const GuardArgs& g, float* smem, float& sg_mul) {
+  sg_mul = 1.f;
+  if (!g.gg || g.round == 0) return true;
+  const int prev = g.round > 1 ? g.gg->shift[g.round - 1] : 0;
+  int shift = prev;
+  const bool active = g.gg->flag[g.round - 1] == g.seq;
+  if (active) {
+    float m = 0.f;
+    const float* sl = g.slots + (size_t)(g.round - 1) * 2 * g.nslot;
+    for (int p = 0; p < 2; ++p)
+      for (int i = threadIdx.x; i < g.n_of[p]; i += blockDim.x) m = fmaxf(m, sl[(size_t)p * g.nslot + i]);
+    m = gg_block_max(m, smem);
+    int e = 0;
+    (void)frexpf(m, &e);                       // m = f 2^e, f in [0.5, 1): afterwards the largest value lies in [2^11, 2^12)
+    shift = prev + (e - 12 > 1 ? e - 12 : 1);
+    __syncthreads();                           // smem may be reused by the caller
+  }
+  if (g.last && blockIdx.x == 0 && threadIdx.x == 0) {
+    g.gg->shift[g.round] = shift;
+    if (g.final_round) { g.gg->mul = ldexpf(1.f, -shift); g.gg->shift[3] = shift; }     // [3]: the step's final shift
+  }
+  sg_mul = ldexpf(1.f, -shift);
+  return active;
+}
+// End of a producer launch: block_max = this block's max |g| in the round's scaled units, before rounding (thread 0's
+// value is used).
+__device__ __forceinline__ void gg_end(const GuardArgs& g, float block_max) {
+  if (!g.gg || threadIdx.x != 0) return;
+  g.slots[((size_t)g.round * 2 + g.producer) * g.nslot + blockIdx.x] = block_max;
+  if (block_max > GG_LIMIT) __hip_atomic_store(&g.gg->flag[g.round], g.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif
 
 // splitmix64 finaliser, identical to videovector_amd/synth.py:mix64
 __host__ __device__ inline uint64_t mix64(uint64_t seed, uint64_t x) {

@@ -62,6 +62,7 @@ def load_library():
         "vv_destroy": [vp], "vv_set_stream": [vp, vp], "vv_synchronize": [vp],
         "vv_device_query": [C.c_int, C.c_char_p, C.c_size_t],
         "vv_set_dedup": [vp, C.c_int], "vv_dedup_stats": [vp, C.POINTER(i64), C.POINTER(i64)],
+        "vv_grad_scale_stats": [vp, C.POINTER(i64), C.POINTER(C.c_float)],
         "vv_table_set": [vp, vp, i64, i32], "vv_table_synth": [vp, C.c_uint64, i64, i32],
         "vv_table_get": [vp, vp, i64, vp],
         "vv_params_set": [vp, i32, vp, vp, vp, vp], "vv_params_get": [vp, vp, vp, vp, vp],
@@ -190,6 +191,12 @@ class Engine:
         self._chk(self.L.vv_dedup_stats(self.h, C.byref(r), C.byref(u)))
         return r.value, u.value
 
+    def grad_scale_stats(self):
+        """(steps whose 16-bit gradients had to be produced again at a smaller scale, current scale); videovec.h."""
+        r, sc = C.c_int64(0), C.c_float(0)
+        self._chk(self.L.vv_grad_scale_stats(self.h, C.byref(r), C.byref(sc)))
+        return r.value, sc.value
+
     def table_set(self, rows):
         rows = np.ascontiguousarray(rows, dtype=np.float32)
         self.n_rows, self.F = rows.shape
@@ -221,9 +228,11 @@ class Engine:
         return W, b, hW, hb
 
     # ---- iteration
-    def forward_backward(self, cfg, idx=None, idx_dev_ptr=None):
+    def forward_backward(self, cfg, idx=None, idx_dev_ptr=None, idx_ready=False):
+        """idx: host array [B][C+Nn]; or idx_dev_ptr: device indices produced on the context's stream (ordered behind it),
+        idx_ready=True when they are complete already (static batches: no ordering added)."""
         if idx_dev_ptr is not None:
-            self._chk(self.L.vv_forward_backward(self.h, C.byref(cfg.c), C.c_void_p(int(idx_dev_ptr)), 1))
+            self._chk(self.L.vv_forward_backward(self.h, C.byref(cfg.c), C.c_void_p(int(idx_dev_ptr)), 2 if idx_ready else 1))
         else:
             idx = np.ascontiguousarray(idx, dtype=np.int32)
             assert idx.shape == (cfg.c.B, cfg.c.C + cfg.c.Nn)
