@@ -121,10 +121,12 @@ def main():
                          "sums); 'off' executes the reference-equivalent dense work")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="only the end-to-end leg (skips gpu_path_only, dense_execution, bf16_execution, step_ms_stats)")
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg5"],
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg5", "shipped"],
                     help="cfg2 (default, the metric's configuration): batch 1024/GPU, 50 negatives, 4096->512.  cfg5: the "
-                         "per-GPU work of BASELINE configs[4] (batch 4096, 200 negatives, 4096->1024, quoted for bf16) -- "
-                         "informational, not the contract's bench line")
+                         "per-GPU work of BASELINE configs[4] (batch 4096, 200 negatives, 4096->1024, quoted for bf16).  shipped: "
+                         "the reference's own project files (mednet_embedding_train.prototxt:13-23,200,226: batch 128, window 5, "
+                         "10 negatives of which up to 6 from the same video -- quirk Q1 --, 4096->4096, dropout 0.9).  The last two "
+                         "are informational, not the contract's bench line")
     ap.add_argument("--allreduce", default="auto", choices=["auto", "sync", "overlap", "stale"],
                     help="N>1.  'sync' (default): exact synchronous SGD, the all-reduce of [dW|db] between backward and "
                          "update.  'overlap': the same exact update, the gradient all-reduced in F-chunks on a second "
@@ -162,6 +164,14 @@ def main():
     global B_PER_GPU, NN, D
     if args.workload == "cfg5":
         B_PER_GPU, NN, D = 4096, 200, 1024
+    shipped = args.workload == "shipped"
+    if shipped:
+        B_PER_GPU, NN, D = 128, 10, 4096
+        if args.gpus != 1:
+            raise SystemExit("--workload shipped is a one-GPU informational run")
+        args.no_extra_legs = True
+    DROPOUT = 0.9 if shipped else 0.0        # mednet_embedding_train.prototxt:226
+    MAX_SAME = 6 if shipped else 0           # :19 (same-video negatives: quirk Q1)
     import torch
     import videovector_amd as vv
     from videovector_amd.synth import SyntheticVideos, init_weights
@@ -211,7 +221,8 @@ def main():
     S = int(np.ceil(args.settle_ms / (2.3 if args.workload == "cfg5" else 0.25))) if args.settle_ms > 0 else 0
     Bg = B_PER_GPU * world
     ds = SyntheticVideos(seed=SEED, n_videos=N_VIDEOS)
-    skw = dict(batch_size=Bg, context_size=C, num_negative_samples=NN, max_buffer_size=5000, negative_swap_percentage=50)
+    skw = dict(batch_size=Bg, context_size=C, num_negative_samples=NN, max_buffer_size=5000, negative_swap_percentage=50,
+               max_same_video_negs=MAX_SAME)
 
     smode = args.sampler if args.sampler != "auto" else ("rank" if world > 1 else "node")
     if world == 1:
@@ -221,7 +232,12 @@ def main():
     sampler_note = ""
     one_logical = None
     ring_attached = False
-    if smode == "rank":
+    if shipped:
+        # quirk-Q1 batches carry a second index array (which row each slot's LAST feature comes from): drawn on the calling
+        # thread, step by step, as the facade does for such batches (caffe_facade/src/net.cpp:505-517)
+        sampler = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, **skw)
+        ring = None; ring_consumer = 0; item_begin = 0
+    elif smode == "rank":
         # ---- per-rank samplers: the reference's sampler, one instance per rank, batch B_PER_GPU, its own rand() stream and
         # starting record.  Beside it rank 0 measures what ONE logical sampler of the global batch delivers (the bound of 'node').
         if rank == 0:
@@ -284,7 +300,7 @@ def main():
                 sampler_note = " (fallback: one identical sampler per rank, the shared-memory ring could not be attached)"
 
     # batches for the resident-indices legs come from a second, identical sampler (rank-local slice of the global batch)
-    n_res = 0 if args.no_extra_legs else S + Wm + K
+    n_res = 0 if (args.no_extra_legs or shipped) else S + Wm + K
     batches = None
     if n_res:
         smp2 = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, **skw)
@@ -338,6 +354,8 @@ def main():
             self.eng.params_set(W0, b0)
             self.eng.set_dedup(dedup)
             self.cfg = vv.StepConfig(B_PER_GPU, C, NN, global_count=Bg * NN)
+            if DROPOUT > 0:
+                self.cfg.set("dropout_ratio", DROPOUT); self.cfg.set("dropout_seed", 1701)
             self.grads = None
             self.trainer = None
             if mode == "stale":
@@ -383,7 +401,10 @@ def main():
                 assert source == "resident", "--allreduce stale runs on resident indices"
                 self.trainer.step(lr_at(self.it), global_batch=Bg, idx_dev_ptr=idx_dev.data_ptr() + i * stride)
             else:
-                if source == "ring":
+                if source == "q1":
+                    idx_h, last_h, _ = sampler.next(want_last=True)
+                    eng.forward_backward_q1(cfg, idx_h, last_h)
+                elif source == "ring":
                     th0 = time.perf_counter()
                     eng.forward_backward_ring(cfg, ring, consumer=ring_consumer, item_begin=item_begin)
                     if diag: host_ms.append((time.perf_counter() - th0) * 1e3)
@@ -453,13 +474,15 @@ def main():
     diag = os.environ.get("VV_BENCH_DIAG") == "1"
     host_ms = []
     t_setup_done = time.perf_counter()
-    main_source = "resident" if mode == "stale" else "ring"
+    main_source = "resident" if mode == "stale" else ("q1" if shipped else "ring")
     if os.environ.get("VV_BENCH_SOURCE") == "resident":       # debugging aid: the main leg on resident indices (needs the extra legs' batches)
         main_source = "resident"
     run = Run(args.prec, args.dedup == "on")
     # The timed leg times the two GEMMs only when the other kernels' durations come from the per-step leg below (cfg 2: a GEMM
     # is the dominant kernel by 3x; a timed dispatch costs ~5 us of stream time, 7 of them on every 4th of 20 steps 4 %).
     main_prof = "gemm" if (not args.no_extra_legs and args.workload == "cfg2") else "all"
+    if shipped:
+        S = max(1, int(args.settle_ms / 0.5))
     elapsed, kern, diag_ms = run.timed(main_source, per_step_events=diag, profile=main_prof)
     main_cold_ms = run.cold_ms
     if diag and rank == 0:
@@ -487,6 +510,17 @@ def main():
             extra["dense_execution"] = {"value": Bg * NN * K / d_el, "unit": "triplets/s", "ms_per_step": d_el / K * 1e3,
                                         "source": "resident indices",
                                         "kernels_ms": {k: round(v[0], 4) for k, v in d_kern.items() if v[1] > 0}}
+        if args.workload == "cfg2":
+            # "a dropout-0.9 number reported separately" -- the same steps with the shipped dropout ratio
+            # (mask from a counter-based generator in the forward GEMM's epilogue; every instance has its own mask, so the
+            # rows are not de-duplicated: the dense kernels + 16-bit per-instance gradient rows)
+            run.reset(False)
+            run.cfg.set("dropout_ratio", 0.9); run.cfg.set("dropout_seed", 1701)
+            p_el, p_kern, _ = run.timed("resident")
+            run.cfg.set("dropout_ratio", 0.0)
+            extra["dropout_execution"] = {"value": Bg * NN * K / p_el, "unit": "triplets/s", "ms_per_step": p_el / K * 1e3,
+                                          "dropout_ratio": 0.9, "source": "resident indices; dense execution (no de-duplication under dropout)",
+                                          "kernels_ms": {k: round(v[0], 4) for k, v in p_kern.items() if v[1] > 0}}
         run.eng.close()
         other = "bf16" if args.prec == "f16" else "f16"
         if mode != "stale":
@@ -505,7 +539,9 @@ def main():
         dense_flop = 2.0 * R * F * D         # per launch of either GEMM kernel, every sampled row (SURVEY 8d figure)
         # rows the GEMMs really processed: distinct table rows per timed batch of this rank (host recount on the identical
         # stream of the second sampler; the ring's batches are the same batches)
-        if args.dedup == "on" and batches is not None:
+        if DROPOUT > 0:
+            U = float(R)                      # dropout: every instance has its own mask, nothing is shared
+        elif args.dedup == "on" and batches is not None:
             U = float(np.mean([len(np.unique(batches[i])) for i in range(S + Wm, S + Wm + K)]))
         elif args.dedup == "on":
             U = float(run.eng.dedup_stats()[1])
@@ -531,7 +567,7 @@ def main():
         roof["dedup_factor"] = R / U
         pmc, pmc_src = None, None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc_path):
+        if os.path.exists(pmc_path) and args.workload == "cfg2":      # (the committed PMC passes are of the cfg-2 kernels)
             try:
                 pj = json.load(open(pmc_path))
                 pmc = pj.get("dedup_" + args.dedup, {}).get(dom, {}).get("hbm_bytes_per_launch")
@@ -555,13 +591,21 @@ def main():
                                "the timed region is exactly `steps` full training steps either way"},
             "value_scope": ("end to end: bit-exact reference sampler on %d prefetch thread(s) inside the timed region, "
                             "225 KB index batch per step through pinned staging + async H2D, full training iteration"
-                            % args.sampler_threads) if main_source == "ring" else "resident indices (stale-gradient schedule)",
-            "config": {"workload": "BASELINE configs[%d] per GPU: synthetic fc7 4096-d -> %d-d, batch "
+                            % args.sampler_threads) if main_source == "ring" else
+                           ("end to end: bit-exact reference sampler on the calling thread (quirk-Q1 batches: index + last-feature "
+                            "arrays), composite rows patched on the device, full training iteration" if main_source == "q1"
+                            else "resident indices (stale-gradient schedule)"),
+            "config": {"workload": ("the reference's shipped project files (mednet_embedding_train.prototxt:13-23,200,226; INFORMATIONAL, not "
+                                    "BASELINE's metric configuration): synthetic fc7 4096-d -> %d-d, batch %d, context_size 5, %d negatives "
+                                    "(max_same_video_negs 6: quirk Q1), dropout 0.9, max_buffer 5000, swap 50%%, margin 2 L2, SGD momentum .9 "
+                                    "wd 5e-4 inv lr" % (D, B_PER_GPU, NN)) if shipped else
+                                   "BASELINE configs[%d] per GPU: synthetic fc7 4096-d -> %d-d, batch "
                                    "%d/GPU (global %d), context_size 5 (window +-2), %d negatives, "
                                    "max_buffer 5000, swap 50%%, margin 2 L2, SGD momentum .9 wd 5e-4 inv lr"
                                    % (1 if args.workload == "cfg2" else 4, D, B_PER_GPU, Bg, NN),
                        "global_batch": Bg, "triplets_per_step": Bg * NN,
-                       "parallelism": "dp%d" % world, "items_per_s": value / NN, "dedup": args.dedup,
+                       "parallelism": "dp%d" % world, "items_per_s": value / NN,
+                       "dedup": args.dedup if DROPOUT == 0 else "off (dropout: every instance has its own mask; dense kernels)",
                        "cpu_binding_rank0": cpu_bind,
                        "sampler": ("one per rank: the reference's sampler at batch %d with srand(1 + rank) and its own starting record, "
                                    "%d stage thread(s), prefetch depth %d" % (B_PER_GPU, args.sampler_threads, args.prefetch_depth))
@@ -588,7 +632,10 @@ def main():
                               "instances' gradient rows are summed before the weight-gradient GEMM"},
             "step_tflops_executed": 2 * gemm_flop / (ms * 1e-3) / 1e12,
             "step_tflops_dense_equivalent": 2 * dense_flop / (ms * 1e-3) / 1e12,
-            "gather_GBs": 2.0 * R * F * 2 / (ms * 1e-3) / 1e9,
+            "gather_GBs_dense_equivalent": 2.0 * R * F * 2 / (ms * 1e-3) / 1e9,
+            "gather_GBs_executed": 2.0 * U * F * 2 / (ms * 1e-3) / 1e9,
+            "gather_note": "feature rows read by the two GEMMs per second: dense-equivalent = every sampled row (2 R F 2 B per step, "
+                           "SURVEY 8d's reference-equivalent figure); executed = the distinct rows the kernels really gathered (2 U F 2 B)",
             "sampler_ms_per_global_batch_one_thread": sampler_serial_ms if smode == "node" else None,
             "sampler_ms_per_rank_batch_one_thread": sampler_serial_ms if smode == "rank" else None,
             "final_loss": loss, "final_violations": viol,
@@ -600,7 +647,7 @@ def main():
         out["wall_s"] = {"imports_setup_presampling_table": round(t_setup_done - t_process_start, 3),
                          "warmup_plus_timed_steps": round(t_main_done - t_setup_done, 3),
                          "extra_legs": round(t_legs_done - t_main_done, 3)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not shipped:
             b0_idx = batches[0] if batches is not None else None
             if b0_idx is None:
                 s4 = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, **skw); b0_idx = s4.next(); s4.close()
