@@ -145,7 +145,7 @@ def main():
                          "takes its slice out of a shared-memory ring -- bound by the sampler's serial walk (DESIGN.md 8)")
     ap.add_argument("--cpu-bind", default="auto", choices=["auto", "off"],
                     help="N>1: give every rank its own block of physical cores on its GPU's NUMA node (videovector_amd/hostbind.py)")
-    ap.add_argument("--sampler-threads", type=int, default=int(os.environ.get("VV_SAMPLER_THREADS", "3")))
+    ap.add_argument("--sampler-threads", type=int, default=int(os.environ.get("VV_SAMPLER_THREADS", "4")))
     ap.add_argument("--prefetch-depth", type=int, default=128,
                     help="batches the sampler keeps ahead of the consumer (the reference: 1).  128 (29 MB of index batches) covers the stretches of up to several hundred steps in "
                          "which the sampler -- 0.175 ms per batch on average against a 0.225 ms step -- falls behind (profiles/r02_long_run.txt)")

@@ -464,7 +464,7 @@ VideoSampledShotsDataLayer<Dtype>::~VideoSampledShotsDataLayer() {
 template <typename Dtype>
 void VideoSampledShotsDataLayer<Dtype>::CreatePrefetchThread() {
   if (prefetching_) return;
-  const int threads = getenv("VV_SAMPLER_THREADS") ? atoi(getenv("VV_SAMPLER_THREADS")) : 3;
+  const int threads = getenv("VV_SAMPLER_THREADS") ? atoi(getenv("VV_SAMPLER_THREADS")) : 4;
   const int world = Caffe::world();
   // data-parallel: ONE sampler per node (rank 0) draws the global batch and publishes it in shared memory; every rank
   // takes its batch_size items of it

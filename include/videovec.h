@@ -316,9 +316,10 @@ int vv_sampler_destroy(vv_sampler* s);
  * reference starts one thread per batch that fills prefetch_data_ while the solver consumes the previous one.
  * Here background threads run `depth` batches ahead of the consumer; afterwards vv_sampler_next pops finished
  * batches in order (the index stream is exactly the one vv_sampler_next would have produced by itself).
- *   threads   1 = whole batches on one thread; 2 or 3 = the item's three chains (stream walk + buffer swap-in /
- *             negative-slot draw / frame draw) as a pipeline of threads (same indices; only for samplers without
- *             same-video negatives whose (video_id, shot_id) keys name distinct rows, else 1 is used).
+ *   threads   1 = whole batches on one thread; 2, 3 or 4 = the item's three chains (stream walk + buffer swap-in /
+ *             negative-slot draw / frame draw) as a pipeline of threads, the fourth generating the rand() stream a
+ *             block ahead of the walk (same indices; only for samplers without same-video negatives whose
+ *             (video_id, shot_id) keys name distinct rows, else 1 is used).
  *   shm_name  NULL = a private ring.  A name = the ring lives in a POSIX shared-memory object of that name, so that
  *             ONE sampler per node serves `consumers` processes (the data-parallel ranks: every rank takes its
  *             items of the same global batch) -- see vv_batch_ring_attach.
@@ -326,7 +327,9 @@ int vv_sampler_destroy(vv_sampler* s);
 int vv_sampler_prefetch_start(vv_sampler* s, int32_t depth, int32_t threads, const char* shm_name, int32_t consumers);
 int vv_sampler_prefetch_stop(vv_sampler* s);
 /* Counters for tests and tuning: which = 0 swap-in walks that had to restart (a swap-in evicted a later shot of the same
- * video), 1 = the staged fast path is in use (0/1), 2 = producer threads of the running prefetch.  -1 = unknown. */
+ * video), 1 = the staged fast path is in use (0/1), 2 = producer threads of the running prefetch, 3 = time-stamp-counter
+ * ticks since the pipeline started, 4 / 5 / 6 = ticks of them the walk / negative-slot / frame stage spent waiting.
+ * -1 = unknown. */
 int64_t vv_sampler_stat(vv_sampler* s, int32_t which);
 
 /* A reader's view of a sampler's batch ring.  vv_sampler_ring: the producer process's own handle (owned by the

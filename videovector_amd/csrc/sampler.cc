@@ -74,29 +74,64 @@ class LibcRand {
     uint32_t* h = h_.data();
     for (int i = 0; i < 31; ++i) h[kHist - 31 + i] = st[(f + i) % 31];
     for (int i = kHist - 32; i >= 0; --i) h[i] = h[i + 31] - h[i + 28];     // run the recurrence backwards for the extra history
-    generate(0);
-    pos_ = 0;
+    generate(h_.data() + kHist, 0);
+    base_ = h_.data() + kHist; pos_ = 0; avail_ = n_;
   }
+  ~LibcRand() { if (helper_on_) { helper_stop_.store(1); if (helper_.joinable()) helper_.join(); } }
   int capacity() const { return n_; }
   // make the next k values addressable as peek(0..k-1) (k <= capacity())
   void ensure(int k) {
-    if (pos_ + k <= n_) return;
+    if (pos_ + k <= avail_) return;
+    if (helper_on_) { switch_block(); return; }
     const int m = n_ - pos_;                       // unconsumed values
     memmove(h_.data(), h_.data() + pos_, (size_t)(kHist + m) * sizeof(uint32_t));
-    generate(m);
+    generate(h_.data() + kHist, m);
     pos_ = 0;
   }
-  const uint32_t* peek() const { return h_.data() + kHist + pos_; }     // raw words: rand() = word >> 1
+  const uint32_t* peek() const { return base_ + pos_; }     // raw words: rand() = word >> 1
   void skip(int k) { pos_ += k; }
-  int32_t next() { ensure(1); return (int32_t)(h_[kHist + pos_++] >> 1); }
+  int32_t next() { ensure(1); return (int32_t)(base_[pos_++] >> 1); }
   void discard(int64_t k) {
     while (k > 0) { const int step = (int)std::min<int64_t>(k, n_ / 2); ensure(step); pos_ += step; k -= step; }
   }
 
+  // ---- generation off the consumer's thread.  The stream is a pure function of the seed, so the NEXT block can be
+  // produced while the current one is consumed: two block buffers, each [n_ words of front slack][kHist][n_ values]; a
+  // helper thread fills the idle one with the continuation of the other (its history = the other's last kHist values).
+  // When the consumer runs out it copies its unconsumed tail (with the history in front of it) into the slack right in
+  // front of the next block's values -- the run stays contiguous for peek() -- and hands the exhausted buffer back to the
+  // helper.  Only the consumer's thread touches pos_ / base_ / avail_; the buffers change hands through fill_ / ready_.
+  void start_helper() {
+    if (helper_on_) return;
+    for (int b = 0; b < 2; ++b) blk_[b].assign((size_t)n_ + kHist + n_ + 8, 0u);
+    // the single buffer's state becomes block 0's: history + values at the same offsets, the cursor where it was
+    memcpy(blk_[0].data() + n_, h_.data(), (size_t)(kHist + n_) * sizeof(uint32_t));
+    cur_ = 0; base_ = blk_[0].data() + n_ + kHist; avail_ = n_;        // (pos_ unchanged)
+    ready_[0].store(1); ready_[1].store(0);
+    helper_stop_.store(0);
+    fill_.store(1, std::memory_order_release);                        // fill block 1 as the continuation of block 0
+    helper_on_ = true;
+    helper_ = std::thread([this]() { helper_loop(); });
+  }
+  void stop_helper() {
+    if (!helper_on_) return;
+    helper_stop_.store(1);
+    if (helper_.joinable()) helper_.join();
+    helper_on_ = false;
+    // back to the single buffer: the unconsumed run (with its history) to the front, the rest generated here
+    const int m = avail_ - pos_;
+    const int keep = std::min(m, n_);
+    memcpy(h_.data(), base_ + pos_ - kHist, (size_t)(kHist + keep) * sizeof(uint32_t));
+    generate(h_.data() + kHist, keep);
+    base_ = h_.data() + kHist; pos_ = 0; avail_ = n_;
+    // (m > n_ cannot happen: a switch leaves at most n_ - 1 + n_ values and the next ensure() only runs it down)
+    blk_[0].clear(); blk_[0].shrink_to_fit(); blk_[1].clear(); blk_[1].shrink_to_fit();
+  }
+  void pin_helper_like_caller(const cpu_set_t* set) { helper_set_ = set ? *set : cpu_set_t(); helper_pin_ = set != nullptr; }
+
  private:
   static constexpr int kHist = 40;               // words kept in front of the first unconsumed value (>= 37)
-  void generate(int from) {
-    uint32_t* __restrict h = h_.data() + kHist;
+  void generate(uint32_t* __restrict h, int from) {       // h = the values' start, kHist words of history in front of it
     const int n = n_;
     int i = from;
     for (; i + 8 <= n; i += 8) {                 // every operand of a block lies in front of the block
@@ -106,9 +141,47 @@ class LibcRand {
     }
     for (; i < n; ++i) h[i] = h[i - 31] + h[i - 3];
   }
+  void helper_loop() {
+    if (helper_pin_) (void)sched_setaffinity(0, sizeof(helper_set_), &helper_set_);
+    unsigned spins = 0;
+    while (!helper_stop_.load(std::memory_order_relaxed)) {
+      const int b = fill_.load(std::memory_order_acquire);
+      if (b < 0) {
+        if (++spins < 2000) __builtin_ia32_pause(); else if (spins < 4000) sched_yield(); else std::this_thread::sleep_for(std::chrono::microseconds(20));
+        continue;
+      }
+      spins = 0;
+      uint32_t* dst = blk_[b].data() + n_ + kHist;                     // values of block b
+      const uint32_t* src = blk_[1 - b].data() + n_ + kHist + n_ - kHist;   // the other block's last kHist values
+      memcpy(dst - kHist, src, (size_t)kHist * sizeof(uint32_t));
+      generate(dst, 0);
+      fill_.store(-1, std::memory_order_relaxed);
+      ready_[b].store(1, std::memory_order_release);
+    }
+  }
+  void switch_block() {
+    const int nb = 1 - cur_;
+    unsigned spins = 0;
+    while (!ready_[nb].load(std::memory_order_acquire)) { if (++spins < 100000) __builtin_ia32_pause(); else sched_yield(); }
+    const int m = avail_ - pos_;                                       // unconsumed values of the current run
+    uint32_t* nv = blk_[nb].data() + n_ + kHist;
+    memcpy(nv - m - kHist, base_ + pos_ - kHist, (size_t)(kHist + m) * sizeof(uint32_t));   // (the copy's end rewrites the block's own history with the same words)
+    base_ = nv - m; pos_ = 0; avail_ = m + n_;
+    ready_[cur_].store(0, std::memory_order_relaxed);
+    fill_.store(cur_, std::memory_order_release);                      // the exhausted block: continuation of block nb
+    cur_ = nb;
+  }
   std::vector<uint32_t> h_;
-  int n_ = 0, pos_ = 0;
+  const uint32_t* base_ = nullptr;
+  int n_ = 0, pos_ = 0, avail_ = 0;
   uint32_t swap_ = 0;
+  // helper mode
+  std::vector<uint32_t> blk_[2];
+  std::thread helper_;
+  bool helper_on_ = false; int cur_ = 0;
+  std::atomic<int> fill_{-1}, helper_stop_{0};
+  std::atomic<int> ready_[2];
+  cpu_set_t helper_set_; bool helper_pin_ = false;
 };
 
 struct Slot { int32_t row = -1, last = -1; };
@@ -179,9 +252,16 @@ void pin_self(const cpu_set_t* set) {
   if (set) (void)sched_setaffinity(0, sizeof(*set), set);
 }
 
+// Waiting for another stage / the consumer / the producer.  A sleep costs its quantum PLUS the timer slack and the wake-up
+// (50 us asked = 100-130 us observed), a yield a trip through the scheduler: a stage that is a few items ahead of its
+// producer, or a consumer whose batch is 20 us from complete, must not pay that -- the light frame stage oversleeping at
+// a batch's end held every batch back by a sleep quantum (0.257 ms per 1024-item batch with three stage threads against
+// 0.174 ms with two, profiles/r02_sampler_rates.txt; both figures also carried the CONSUMER's own oversleep).  So: spin on
+// `pause` for ~100 us (these are dedicated threads on cores of their own, stage_cpu_set), then yield for a few ms, and
+// only a wait longer than that (a full ring in front of a GPU-bound consumer, an idle pipeline) sleeps.
 void backoff(unsigned& spins) {
-  if (++spins < 64) { __builtin_ia32_pause(); return; }
-  if (spins < 256) { sched_yield(); return; }
+  if (++spins < 6000) { __builtin_ia32_pause(); return; }
+  if (spins < 12000) { sched_yield(); return; }
   std::this_thread::sleep_for(std::chrono::microseconds(50));
 }
 
@@ -338,6 +418,11 @@ struct vv_sampler {
   std::vector<Event> events; uint64_t ev_mask = 0;
   alignas(64) std::atomic<int64_t> walked{0};
   alignas(64) std::atomic<uint64_t> ev_tail{0};
+  // time-stamp-counter ticks each stage spent waiting (for its producer, its consumers, ring space); vv_sampler_stat 3..6
+  alignas(64) std::atomic<uint64_t> wait_walk{0};
+  alignas(64) std::atomic<uint64_t> wait_negs{0};
+  alignas(64) std::atomic<uint64_t> wait_frames{0};
+  uint64_t tsc_start = 0;
   void run_batches();
   void run_walk();
   void run_negs(bool also_frames);
@@ -692,13 +777,16 @@ void vv_sampler::run_walk() {
     unsigned spins = 0;
     // the record slot must have been consumed by both later stages, its batch buffer released by every consumer,
     // and the event ring must have room for one more video
+    uint64_t tw = 0;
     for (;;) {
       const int64_t done = std::min(ring->hdr->done_negs.load(std::memory_order_acquire), ring->hdr->done_frames.load(std::memory_order_acquire));
       if (it - done < ring_items && ev_head + (uint64_t)max_n <= ev_tail.load(std::memory_order_acquire) + ev_cap) break;
       if (published < it) { walked.store(it, std::memory_order_release); published = it; }
       if (stop.load(std::memory_order_relaxed)) return;
+      if (!tw) tw = __rdtsc();
       backoff(spins);
     }
+    if (tw) wait_walk.store(wait_walk.load(std::memory_order_relaxed) + (__rdtsc() - tw), std::memory_order_relaxed);
     uint32_t* rec = recs.data() + (size_t)(it % ring_items) * rec_words;
     select_item(rec);
     swap_item<true>(rec, buf_row.data(), events.data(), ev_mask, &ev_head);
@@ -714,18 +802,21 @@ void vv_sampler::run_negs(bool also_frames) {
   int32_t* brow = buf_row_negs.data();
   while (!stop.load(std::memory_order_relaxed)) {
     unsigned spins = 0;
+    uint64_t tw = 0;
     while (it >= avail) {
       avail = walked.load(std::memory_order_acquire);
       if (it < avail) break;
       if (published < it) { ring->hdr->done_negs.store(it, std::memory_order_release); if (also_frames) ring->hdr->done_frames.store(it, std::memory_order_release); published = it; }
       if (stop.load(std::memory_order_relaxed)) return;
+      if (!tw) tw = __rdtsc();
       backoff(spins);
     }
     const int64_t k = it / B;
     if (it % B == 0) {
       spins = 0;
-      while (k - ring->min_released() >= h->depth) { if (stop.load(std::memory_order_relaxed)) return; backoff(spins); }
+      while (k - ring->min_released() >= h->depth) { if (stop.load(std::memory_order_relaxed)) return; if (!tw) tw = __rdtsc(); backoff(spins); }
     }
+    if (tw) wait_negs.store(wait_negs.load(std::memory_order_relaxed) + (__rdtsc() - tw), std::memory_order_relaxed);
     const uint32_t* rec = recs.data() + (size_t)(it % ring_items) * rec_words;
     int32_t* out = ring->idx_of(k) + (size_t)(it % B) * CN;
     negs_item(rec, out + C, brow);
@@ -749,18 +840,21 @@ void vv_sampler::run_frames() {
   int64_t it = 0, published = 0, avail = 0;
   while (!stop.load(std::memory_order_relaxed)) {
     unsigned spins = 0;
+    uint64_t tw = 0;
     while (it >= avail) {
       avail = walked.load(std::memory_order_acquire);
       if (it < avail) break;
       if (published < it) { ring->hdr->done_frames.store(it, std::memory_order_release); published = it; }
       if (stop.load(std::memory_order_relaxed)) return;
+      if (!tw) tw = __rdtsc();
       backoff(spins);
     }
     const int64_t k = it / B;
     if (it % B == 0) {
       spins = 0;
-      while (k - ring->min_released() >= h->depth) { if (stop.load(std::memory_order_relaxed)) return; backoff(spins); }
+      while (k - ring->min_released() >= h->depth) { if (stop.load(std::memory_order_relaxed)) return; if (!tw) tw = __rdtsc(); backoff(spins); }
     }
+    if (tw) wait_frames.store(wait_frames.load(std::memory_order_relaxed) + (__rdtsc() - tw), std::memory_order_relaxed);
     const uint32_t* rec = recs.data() + (size_t)(it % ring_items) * rec_words;
     frames_item(rec, ring->idx_of(k) + (size_t)(it % B) * CN, ring->label_of(k) + (it % B));
     ++it;
@@ -972,9 +1066,14 @@ int vv_sampler_prefetch_start(vv_sampler* s, int32_t depth, int32_t threads, con
   s->events.assign(cap, vv_sampler::Event{0, 0}); s->ev_mask = cap - 1;
   s->buf_row_negs = s->buf_row;
   s->walked.store(0); s->ev_tail.store(0);
+  s->wait_walk.store(0); s->wait_negs.store(0); s->wait_frames.store(0); s->tsc_start = __rdtsc();
   const bool three = threads >= 3;
-  s->n_stage_threads = three ? 3 : 2;
+  s->n_stage_threads = threads >= 4 ? 4 : (three ? 3 : 2);
   cpu_set_t set; const bool pin = stage_cpu_set(&set);
+  if (threads >= 4) {            // the fourth thread generates the rand() stream a block ahead of the walk (LibcRand::start_helper)
+    s->rng.pin_helper_like_caller(pin ? &set : nullptr);
+    s->rng.start_helper();
+  }
   s->threads.emplace_back([s, set, pin]() { pin_self(pin ? &set : nullptr); s->run_walk(); });
   s->threads.emplace_back([s, three, set, pin]() { pin_self(pin ? &set : nullptr); s->run_negs(!three); });
   if (three) s->threads.emplace_back([s, set, pin]() { pin_self(pin ? &set : nullptr); s->run_frames(); });
@@ -987,6 +1086,7 @@ int vv_sampler_prefetch_stop(vv_sampler* s) {
   s->stop.store(1);
   for (auto& t : s->threads) if (t.joinable()) t.join();
   s->threads.clear();
+  s->rng.stop_helper();
   ring_free(s->ring);
   s->ring = nullptr;
   s->n_stage_threads = 0;
@@ -1005,6 +1105,10 @@ int64_t vv_sampler_stat(vv_sampler* s, int32_t which) {
     case 0: return s->stat_restarts;             // swap-in walks restarted because a later shot of the video was evicted
     case 1: return s->fast ? 1 : 0;              // staged fast path in use
     case 2: return s->n_stage_threads;           // producer threads of the running prefetch (0 = none)
+    case 3: return (int64_t)(__rdtsc() - s->tsc_start);                  // ticks since the prefetch pipeline started
+    case 4: return (int64_t)s->wait_walk.load(std::memory_order_relaxed);     // ... of which the walk stage spent waiting
+    case 5: return (int64_t)s->wait_negs.load(std::memory_order_relaxed);     // ... the negative-slot stage
+    case 6: return (int64_t)s->wait_frames.load(std::memory_order_relaxed);   // ... the frame stage
     default: return -1;
   }
 }

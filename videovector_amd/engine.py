@@ -458,7 +458,7 @@ class Sampler:
             return idx, last, label
         return idx
 
-    def prefetch_start(self, depth=4, threads=3, shm_name=None, consumers=1):
+    def prefetch_start(self, depth=4, threads=4, shm_name=None, consumers=1):
         """Background threads keep `depth` batches ahead (BasePrefetchingDataLayer, base_data_layer.cpp:52-95); next()
         then pops finished batches.  shm_name: publish the ring in POSIX shared memory for `consumers` processes
         (BatchRing.attach)."""
