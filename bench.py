@@ -128,11 +128,13 @@ def main():
                          "10 negatives of which up to 6 from the same video -- quirk Q1 --, 4096->4096, dropout 0.9).  The last two "
                          "are informational, not the contract's bench line")
     ap.add_argument("--allreduce", default="auto", choices=["auto", "sync", "overlap", "stale"],
-                    help="N>1.  'sync' (default): exact synchronous SGD, the all-reduce of [dW|db] between backward and "
-                         "update.  'overlap': the same exact update, the gradient all-reduced in F-chunks on a second "
-                         "stream while the weight-gradient kernel is still producing the next chunk.  'stale': the "
-                         "all-reduce of iteration t overlaps iteration t+1 and gradients are applied one update late "
-                         "(NOT the reference's algorithm; opt-in, labelled)")
+                    help="N>1.  'overlap' (auto with --comm lib): exact synchronous SGD with the exchange hidden behind the NEXT "
+                         "step's forward GEMM -- the update runs F-chunk by F-chunk on the library's communication stream "
+                         "(all-reduce of the chunk, SGD on its columns, publish) while the forward GEMM already runs and "
+                         "waits per chunk inside the kernel.  'sync': the same update, the whole all-reduce of [dW|db] "
+                         "between backward and update, exposed.  'stale': the all-reduce of iteration t overlaps "
+                         "iteration t+1 and gradients are applied one update late (NOT the reference's algorithm; opt-in, "
+                         "labelled)")
     ap.add_argument("--comm", default="lib", choices=["lib", "torch"],
                     help="N>1: who runs the gradient all-reduce.  'lib' (default): the product library's own RCCL "
                          "communicator on its communication stream (vv_comm_init / vv_allreduce_grads).  'torch': "
@@ -325,7 +327,7 @@ def main():
     assert work_stream.cuda_stream != 0
     stride = B_PER_GPU * (C + NN) * 4
     idx_dev = torch.from_numpy(batches).to(dev) if batches is not None else None
-    mode = args.allreduce if args.allreduce != "auto" else ("sync" if world > 1 else "none")
+    mode = args.allreduce if args.allreduce != "auto" else (("overlap" if args.comm == "lib" else "sync") if world > 1 else "none")
     if world == 1 and mode in ("sync", "overlap"):
         mode = "none"
     comm = args.comm if mode in ("sync", "overlap") else "none"
@@ -617,7 +619,8 @@ def main():
                                 "torch": "torch.distributed.all_reduce"}[Run.comm_kind or comm]
                                + (" (fallback: the library's communicator did not come up)" if Run.comm_kind == "torch" and comm == "lib" else ""),
                        "allreduce": {"none": "none (1 GPU)", "sync": "synchronous (exact SGD), exposed",
-                                     "overlap": "exact SGD, chunked all-reduce overlapped with the weight-gradient kernel",
+                                     "overlap": "exact SGD; the update (all-reduce, SGD, publish) runs F-chunk by F-chunk on the communication "
+                                                "stream while the next step's forward GEMM runs and waits per chunk inside the kernel",
                                      "stale": "overlapped with the next iteration's forward/backward "
                                               "(one-update delayed gradients: NOT the reference's algorithm)"}[mode]},
             "roofline": roof,

@@ -157,11 +157,12 @@ void Net<Dtype>::Init(const NetParameter& in_param) {
   PushParamsToDevice();
   if (!is_test && Caffe::world() > 1) {
     // data-parallel TRAIN net: the gradient buffer is summed over the ranks before every update (vv_apply_update joins
-    // the all-reduce); VV_COMM=shm selects the one-device test transport, VV_COMM_OVERLAP=1 the block-wise overlap
+    // the all-reduce); VV_COMM=shm selects the one-device test transport; the update overlaps the next forward GEMM
+    // (vv_comm_overlap: F-chunks on the communication stream, gated forward) unless VV_COMM_OVERLAP=0
     const string id_path = "/tmp/vv_caffe_comm_" + Caffe::job_id();
     const bool shm = getenv("VV_COMM") && !strcmp(getenv("VV_COMM"), "shm");
     VV_CHECK(vv_comm_init(ctx_, Caffe::world(), Caffe::rank(), id_path.c_str(), shm ? VV_COMM_SHM : VV_COMM_RCCL));
-    VV_CHECK(vv_comm_overlap(ctx_, getenv("VV_COMM_OVERLAP") && atoi(getenv("VV_COMM_OVERLAP")) != 0));
+    VV_CHECK(vv_comm_overlap(ctx_, !(getenv("VV_COMM_OVERLAP") && atoi(getenv("VV_COMM_OVERLAP")) == 0)));
     cfg_.global_count = (int64_t)Caffe::world() * plan_.B * plan_.Nn;
     LOG(INFO) << "Data-parallel rank " << Caffe::rank() << " of " << Caffe::world() << ": per-GPU batch " << plan_.B
               << ", global batch " << Caffe::world() * plan_.B << ", gradients all-reduced over "

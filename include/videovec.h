@@ -173,8 +173,14 @@ int vv_grads_bind(vv_ctx* ctx, void* dev_ptr);
  *                     global B * Nn, and give every rank its items of the same global batch (vv_batch_ring_next).
  *   vv_allreduce_grads  sums [dW | db] over the ranks on the context's communication stream and makes the compute stream
  *                     wait for it (the host does not block with RCCL).  vv_apply_update calls it when the caller has not.
- *   vv_comm_overlap   on: vv_forward_backward produces dW one 256-row block at a time and all-reduces each finished
- *                     block while the next one is computed (same sums, same update: exact synchronous SGD). */
+ *   vv_comm_overlap   on: exact synchronous SGD with the exchange hidden behind the NEXT step's forward pass.  The gradient
+ *                     buffer is laid out chunk-major (four column blocks of dW, each one contiguous message; vv_grads_get
+ *                     still returns the blob's row-major D x F); vv_apply_update queues, per chunk, all-reduce -> SGD on the
+ *                     chunk's columns -> publish on the communication stream and returns; the next vv_forward_backward starts
+ *                     its forward GEMM at once, and the kernel waits for each chunk of W where its K loop reaches it
+ *                     (InnerProductLayer::Forward reads every column of W: inner_product_layer.cpp:60-69).  Same sums,
+ *                     same update as without overlap; every other entry point that touches the parameters first orders
+ *                     itself behind the update in flight.  vv_allreduce_grads is a no-op in this mode. */
 enum { VV_COMM_RCCL = 0, VV_COMM_SHM = 1 };
 int vv_comm_init(vv_ctx* ctx, int32_t world, int32_t rank, const char* id_path, int32_t transport);
 int vv_comm_overlap(vv_ctx* ctx, int on);

@@ -89,7 +89,7 @@ void vv_step_cfg_default(vv_step_cfg* cfg) {
 }
 
 static int create_init(vv_ctx* c);
-static int comm_join(vv_ctx* c);
+static inline int comm_join(vv_ctx* c) { return vv_comm_join(c); }
 
 int vv_create(int device, int prec, vv_ctx** out) {
   if (!out) return fail(VV_ERR_ARG, "vv_create: out is NULL");
@@ -160,6 +160,13 @@ static int create_init(vv_ctx* c) {
   HIPCHK(hipHostMalloc((void**)&c->U_host, 2 * sizeof(int32_t), hipHostMallocMapped));   // {U, saturated f16 gradient sums}
   c->U_host[0] = c->U_host[1] = 0;
   HIPCHK(hipHostGetDevicePointer((void**)&c->U_host_dev, c->U_host, 0));
+  HIPCHK(hipMalloc(&c->w_gate, (W_CHUNKS + 1) * W_GATE_STRIDE * sizeof(int32_t)));
+  HIPCHK(hipMemset(c->w_gate, 0, (W_CHUNKS + 1) * W_GATE_STRIDE * sizeof(int32_t)));
+  c->pub_count = c->w_gate + W_CHUNKS * W_GATE_STRIDE;          // the arrival counter of the publishing kernels: a line of its own
+  HIPCHK(hipEventCreateWithFlags(&c->ev_chunk0, hipEventDisableTiming));
+  HIPCHK(hipHostMalloc((void**)&c->gate_err, sizeof(int32_t), hipHostMallocMapped));
+  *c->gate_err = 0;
+  HIPCHK(hipHostGetDevicePointer((void**)&c->gate_err_dev, c->gate_err, 0));
   HIPCHK(hipMalloc(&c->gg, sizeof(GradGuard)));
   { GradGuard g0; memset(&g0, 0, sizeof(g0)); g0.mul = 1.f; HIPCHK(hipMemcpy(c->gg, &g0, sizeof(g0), hipMemcpyHostToDevice)); }
   HIPCHK(hipHostMalloc((void**)&c->gmax_host, 32 * sizeof(unsigned long long), hipHostMallocMapped));
@@ -224,7 +231,8 @@ int vv_destroy(vv_ctx* c) {
   free_batch(c);
   dfree(c->table); dfree(c->patch_desc); dfree(c->W); dfree(c->b); dfree(c->hW); dfree(c->hb); dfree(c->Wh);
   dfree(c->scales); dfree(c->wmax_blocks); dfree(c->grads_own); dfree(c->mask); dfree(c->loss2);
-  dfree(c->dd_key); dfree(c->dd_info_all); dfree(c->gg);
+  dfree(c->dd_key); dfree(c->dd_info_all); dfree(c->gg); dfree(c->w_gate);
+  if (c->gate_err) (void)hipHostFree(c->gate_err);
   if (c->gmax_host) (void)hipHostFree(c->gmax_host);
   for (int i = 0; i < vv_ctx::kDdSets; ++i) {
     if (c->dd_set[i].done) (void)hipEventDestroy(c->dd_set[i].done);
@@ -232,6 +240,7 @@ int vv_destroy(vv_ctx* c) {
   if (c->dd_stream) (void)hipStreamDestroy(c->dd_stream);
   if (c->ev_chunk) (void)hipEventDestroy(c->ev_chunk);
   if (c->ev_idx) (void)hipEventDestroy(c->ev_idx);
+  if (c->ev_chunk0) (void)hipEventDestroy(c->ev_chunk0);
   if (c->U_host) (void)hipHostFree(c->U_host);
   for (int i = 0; i < vv_ctx::kStage; ++i)
     if (c->stage_host[i]) (void)hipHostFree(c->stage_host[i]);
@@ -271,6 +280,7 @@ int vv_grad_scale_stats(vv_ctx* c, int64_t* repeats, float* scale) {
 
 int vv_set_stream(vv_ctx* c, void* s) {
   if (!c) return fail(VV_ERR_ARG, "vv_set_stream: ctx is NULL");
+  { const int rcj = comm_join(c); if (rcj) return rcj; }
   HIPCHK(hipStreamSynchronize(c->stream));
   c->stream = s ? (hipStream_t)s : c->own_stream;
   return VV_OK;
@@ -278,6 +288,7 @@ int vv_set_stream(vv_ctx* c, void* s) {
 
 int vv_synchronize(vv_ctx* c) {
   if (!c) return fail(VV_ERR_ARG, "vv_synchronize: ctx is NULL");
+  { const int rcj = comm_join(c); if (rcj) return rcj; }
   HIPCHK(hipStreamSynchronize(c->stream));
   return VV_OK;
 }
@@ -429,6 +440,7 @@ int vv_params_get(vv_ctx* c, float* W, float* b, float* hW, float* hb) {
   if (!c) return fail(VV_ERR_ARG, "vv_params_get: ctx is NULL");
   if (!c->W) return fail(VV_ERR_STATE, "vv_params_get: no parameters");
   HIPCHK(hipSetDevice(c->device));
+  { const int rcj = comm_join(c); if (rcj) return rcj; }
   HIPCHK(hipStreamSynchronize(c->stream));
   const size_t nW = (size_t)c->D * c->F;
   if (W) HIPCHK(hipMemcpy(W, c->W, nW * 4, hipMemcpyDeviceToHost));
@@ -542,13 +554,18 @@ static void flush_scale_update(vv_ctx* c) {
   c->scale_pending = false;
 }
 
-// Joins the communication stream: after this, everything the library queued there (block-wise all-reduces of the
-// overlapped schedule) has completed.  Callers that read or free the gradient buffer, or start a new backward pass into
-// it, go through here first.
-static int comm_join(vv_ctx* c) {
-  if (c->comm && c->grads_pending && c->grads_chunked) {
+// Joins the communication stream: after this, everything the library queued there -- the F-chunks of an overlapped
+// update: all-reduce, SGD, publish -- is ordered before whatever the compute stream is given next.  Every entry point
+// that reads or writes the parameters, their half copy, the momentum or the gradient buffer goes through here first;
+// the one reader that does not is the next step's forward GEMM, which waits chunk by chunk inside the kernel instead.
+extern "C++" int vv_comm_join(vv_ctx* c) {
+  if (c->comm && c->upd_inflight) {
     HIPCHK(hipStreamWaitEvent(c->stream, vv::comm_done_event(c->comm), 0));
-    c->grads_pending = false; c->grads_chunked = false;
+    c->upd_inflight = false;
+  }
+  if (c->gate_err && *(volatile int32_t*)c->gate_err) {
+    *c->gate_err = 0;
+    return fail(VV_ERR_STATE, "a forward pass gave up waiting for the overlapped parameter update (a rank failed, or the communication stream stalled)");
   }
   return VV_OK;
 }
@@ -560,7 +577,8 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   if (rc) return rc;
   if (!idx) return fail(VV_ERR_ARG, "vv_forward_backward: idx is NULL");
   HIPCHK(hipSetDevice(c->device));
-  if ((rc = comm_join(c))) return rc;        // an overlapped all-reduce of the previous backward pass still owns the gradient buffer
+  // (an overlapped update of the previous step may still be arriving: see the forward GEMM below)
+  if (c->upd_inflight && (cfg->B != c->B || cfg->C != c->C || cfg->Nn != c->Nn || !c->H) && (rc = comm_join(c))) return rc;
   if ((rc = ensure_batch(c, cfg->B, cfg->C, cfg->Nn))) return rc;
   const int B = c->B, C = c->C, Nn = c->Nn, CN = C + Nn, D = c->D;
   hipStream_t s = c->stream;
@@ -697,6 +715,18 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   fa.mask = (cfg->dropout_ratio > 0.f && cfg->dropout_mask) ? c->mask : nullptr;
   fa.drop_seed = cfg->dropout_seed * 0x9E3779B97F4A7C15ull + c->iter;
   fa.B = B; fa.CN = CN;
+  if (c->upd_inflight) {
+    // Data-parallel overlap: the previous step's update is still arriving on the communication stream, F-chunk by
+    // F-chunk.  The forward GEMM starts anyway and waits per chunk inside the kernel -- provided its persistent
+    // workgroups leave compute units free for the update's own kernels (all-reduce, SGD: they must be able to run
+    // BESIDE the waiting GEMM, or nothing would ever release it); otherwise the stream joins here, as without overlap.
+    const long tiles = fwd_gemm_plan(c->R, dd ? fa.R_hint : 0, D, nullptr);
+    static const bool no_gate = getenv("VV_COMM_GATE") && atoi(getenv("VV_COMM_GATE")) == 0;
+    if (!no_gate && gemm_variant() == 5 && !ablate_on() && fwd_gemm_can_gate(fa) && (!dd || fa.R_hint > 0) && tiles <= c->n_cu - 24) {
+      fa.gate = c->w_gate; fa.gate_seq = c->upd_seq; fa.gate_err = c->gate_err_dev;
+      c->upd_inflight = false;              // whatever follows the forward GEMM on this stream follows the whole update
+    } else if ((rc = comm_join(c))) return rc;
+  }
   PROFILED(c, "fwd_gemm", launch_fwd_gemm(c->prec, fa, s));
 
   const int64_t count = (int64_t)B * Nn;
@@ -802,33 +832,27 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   ra.ip_scale = cfg->ip_regularization > 0.f ? 1.f + cfg->ip_regularization * 0.5f : 1.f;     // inner_product_layer.cpp:80-90
   ra.loss_part = c->loss_part; ra.viol_part = c->viol_part; ra.loss_scale = cfg->loss_weight / (float)count; ra.loss_out = c->loss2;
 
-  // Data-parallel overlap (exact synchronous SGD): the weight gradient is produced one 256-row block of dW at a time
-  // (wgrad + slab reduction of that block); while the next block is being computed, the finished one -- a contiguous
-  // piece of the flat gradient buffer -- is all-reduced on the communication stream.  db and the loss scalars ride with
-  // the last block.  Needs the phase-staggered weight-gradient kernel (it can run a subset of the M tiles).
-  const int tilesM = c->Dp / BM;
-  const bool chunked = c->comm && c->comm_overlap && tilesM > 1 &&
-                       (gemm_variant() == 5 || gemm_variant() == 6 || gemm_variant() == 8) && !ablate_on();
-  // the W -> half scale update the previous vv_apply_update left pending rides in this step's (first) reduction launch
+  // Data-parallel overlap: the gradient buffer is laid out chunk-major (W_CHUNKS column blocks, each one contiguous
+  // all-reduce message) and vv_apply_update runs the update chunk by chunk on the communication stream.
+  const bool chunked = c->comm && c->comm_overlap && c->F % 4 == 0 && c->grads == c->grads_own;
+  if (chunked) ra.chunk_cols = c->Fp / W_CHUNKS;
+  // the W -> half scale update the previous vv_apply_update left pending rides in this step's reduction launch
   if (c->scale_pending) { ra.scale_sc = c->scales; ra.scale_wmax = c->wmax_blocks; ra.scale_prec = c->prec; c->scale_pending = false; }
-  if (!chunked) {
-    PROFILED(c, "wgrad_gemm", launch_wgrad_gemm(c->prec, wa, s));
-    PROFILED(c, "reduce", launch_reduce(ra, s));
+  PROFILED(c, "wgrad_gemm", launch_wgrad_gemm(c->prec, wa, s));
+  if (chunked && c->Fp / W_CHUNKS < c->F) {
+    // the first F-chunk is reduced by a launch of its own and an event marks it: the communication stream starts on
+    // chunk 0 (all-reduce, SGD) while the other chunks, db and the loss are still being reduced here
+    ReduceArgs r0 = ra;
+    r0.f_begin = 0; r0.f_count = c->Fp / W_CHUNKS; r0.parts = 1; r0.gmax_host = nullptr;
+    PROFILED(c, "reduce", launch_reduce(r0, s));
+    HIPCHK(hipEventRecord(c->ev_chunk0, s));
+    ra.scale_sc = nullptr;
+    ra.f_begin = c->Fp / W_CHUNKS; ra.f_count = c->F - ra.f_begin;
+    launch_reduce(ra, s);
+    c->chunk0_event = true;
   } else {
-    for (int tm = 0; tm < tilesM; ++tm) {
-      const int d0 = tm * BM;
-      if (d0 >= D) break;
-      const int dn = std::min(BM, D - d0);
-      const bool last = d0 + dn >= D;
-      wa.tm_begin = tm; wa.tm_count = 1;
-      ra.d_begin = d0; ra.d_count = dn; ra.parts = last ? 3 : 1;
-      if (tm == 0) { PROFILED(c, "wgrad_gemm", launch_wgrad_gemm(c->prec, wa, s)); PROFILED(c, "reduce", launch_reduce(ra, s)); }
-      else { launch_wgrad_gemm(c->prec, wa, s); launch_reduce(ra, s); }
-      ra.scale_sc = nullptr;
-      HIPCHK(hipEventRecord(c->ev_chunk, s));
-      const size_t off = (size_t)d0 * c->F, n = (size_t)dn * c->F + (last ? (size_t)D : 0);
-      if (vv::comm_allreduce(c->comm, c->grads, off, n, c->ev_chunk)) return fail(VV_ERR_HIP, "all-reduce: %s", vv::comm_error(c->comm));
-    }
+    PROFILED(c, "reduce", launch_reduce(ra, s));
+    c->chunk0_event = false;
   }
   c->grads_pending = c->comm != nullptr;       // (a one-rank communicator still runs its collective: same code path)
   c->grads_chunked = chunked;
@@ -926,7 +950,9 @@ int vv_apply_update(vv_ctx* c, const vv_step_cfg* cfg) {
   if (rc) return rc;
   if (!c->have_fwd) return fail(VV_ERR_STATE, "vv_apply_update: no gradients (call vv_forward_backward)");
   HIPCHK(hipSetDevice(c->device));
-  if (c->grads_pending && (rc = vv_allreduce_grads(c))) return rc;     // data-parallel: the update consumes the SUM over the ranks
+  if ((rc = comm_join(c))) return rc;                                  // two updates in a row: the first one completes first
+  const bool overlapped = c->comm && c->grads_pending && c->grads_chunked;
+  if (!overlapped && c->grads_pending && (rc = vv_allreduce_grads(c))) return rc;     // data-parallel: the update consumes the SUM over the ranks
   SgdArgs a;
   a.W = c->W; a.b = c->b; a.hW = c->hW; a.hb = c->hb; a.grads = c->grads; a.Wh = c->Wh; a.scales = c->scales; a.wmax_blocks = c->wmax_blocks;
   a.D = c->D; a.F = c->F; a.Dp = c->Dp; a.Fp = c->Fp;
@@ -935,6 +961,35 @@ int vv_apply_update(vv_ctx* c, const vv_step_cfg* cfg) {
   a.decay_mult_w = cfg->decay_mult[0]; a.decay_mult_b = cfg->decay_mult[1];
   a.reg = cfg->reg; a.solver_type = cfg->solver_type; a.delta = cfg->delta;
   flush_scale_update(c);               // two updates in a row without a step between them
+  if (overlapped) {
+    // Exact synchronous SGD with the exchange hidden behind the NEXT step's forward GEMM: behind one event of the compute
+    // stream, the communication stream runs per F-chunk  all-reduce -> SGD on the chunk's columns -> publish w_gate[chunk];
+    // the next forward GEMM (fb_impl) starts right away and waits for each chunk where its K loop reaches it.  db rides
+    // with the last chunk; the bias is updated there.
+    hipStream_t cs = vv::comm_stream(c->comm);
+    HIPCHK(hipEventRecord(c->ev_chunk, c->stream));
+    const int32_t useq = ++c->upd_seq;
+    const int cc = c->Fp / W_CHUNKS;
+    a.pub_count = c->pub_count; a.pub_seq = useq;
+    for (int k = 0; k < W_CHUNKS; ++k) {
+      // chunk 0 may start as soon as ITS reduction is done (ev_chunk0, fb_impl); the others follow the whole backward pass
+      hipEvent_t after = k == 0 ? (c->chunk0_event ? c->ev_chunk0 : c->ev_chunk) : (k == 1 && c->chunk0_event ? c->ev_chunk : nullptr);
+      const int c0 = std::min(c->F, k * cc), c1 = std::min(c->F, (k + 1) * cc);
+      const bool last = k == W_CHUNKS - 1;
+      const size_t off = (size_t)c->D * c0, n = (size_t)c->D * (c1 - c0) + (last ? (size_t)c->D : 0);
+      static const int delay_us = getenv("VV_COMM_TEST_DELAY_US") ? atoi(getenv("VV_COMM_TEST_DELAY_US")) : 0;
+      if (after) HIPCHK(hipStreamWaitEvent(cs, after, 0));
+      if (delay_us > 0) launch_delay(delay_us, cs);      // test hook: a slow exchange, so that the next forward GEMM really waits at its gates
+      static const bool skip_ar1 = getenv("VV_COMM_SKIP_AR1") && atoi(getenv("VV_COMM_SKIP_AR1")) != 0;   // diagnosis: no collective call at world 1
+      if (!(skip_ar1 && vv::comm_world(c->comm) == 1) && n > 0 && vv::comm_allreduce(c->comm, c->grads, off, n, nullptr))
+        return fail(VV_ERR_HIP, "all-reduce: %s", vv::comm_error(c->comm));
+      a.chunked = 1; a.f_begin = c0; a.f_count = c1 - c0; a.blk_off = k * (SGD_BLOCKS / W_CHUNKS); a.do_bias = last; a.set_scale = k == 0;
+      a.pub_flag = c->w_gate + k * W_GATE_STRIDE;          // the kernel's last workgroup publishes the chunk (SgdArgs::pub_flag)
+      if (k == 0) PROFILED(c, "sgd", launch_sgd(c->prec, a, cs)); else launch_sgd(c->prec, a, cs);     // (an empty chunk: its wmax slots become 0, the bias if it is the last)
+    }
+    if (vv::comm_record_done(c->comm)) return fail(VV_ERR_HIP, "all-reduce: %s", vv::comm_error(c->comm));
+    c->grads_pending = false; c->upd_inflight = true;
+  } else
   PROFILED(c, "sgd", launch_sgd(c->prec, a, c->stream));
   // The next W -> half scale (k_scale_update: folds this kernel's per-block max |w|) is needed by the NEXT k_sgd only.  It
   // is left pending and performed by one extra workgroup of the next step's k_reduce; anything else that touches the
@@ -956,6 +1011,7 @@ int vv_loss_get(vv_ctx* c, float* loss, float* violations) {
   if (!c) return fail(VV_ERR_ARG, "vv_loss_get: ctx is NULL");
   if (!c->have_fwd) return fail(VV_ERR_STATE, "vv_loss_get: no forward pass yet");
   HIPCHK(hipSetDevice(c->device));
+  if (c->gate_err && *(volatile int32_t*)c->gate_err) { const int rcj = comm_join(c); if (rcj) return rcj; }
   float h[2];
   HIPCHK(hipMemcpyAsync(h, c->loss2, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -988,7 +1044,17 @@ int vv_grads_get(vv_ctx* c, float* dW, float* db) {
   { const int rcj = comm_join(c); if (rcj) return rcj; }       // block-wise all-reduces in flight: the buffer is read whole
   HIPCHK(hipStreamSynchronize(c->stream));
   const size_t nW = (size_t)c->D * c->F;
-  if (dW) HIPCHK(hipMemcpy(dW, c->grads, nW * 4, hipMemcpyDeviceToHost));
+  if (dW && !c->grads_chunked) HIPCHK(hipMemcpy(dW, c->grads, nW * 4, hipMemcpyDeviceToHost));
+  if (dW && c->grads_chunked) {        // chunk-major buffer (ReduceArgs::chunk_cols) -> the blob's row-major D x F
+    std::vector<float> tmp(nW);
+    HIPCHK(hipMemcpy(tmp.data(), c->grads, nW * 4, hipMemcpyDeviceToHost));
+    const int cc = c->Fp / W_CHUNKS;
+    for (int k = 0; k < W_CHUNKS; ++k) {
+      const int c0 = std::min(c->F, k * cc), c1 = std::min(c->F, (k + 1) * cc);
+      for (int d = 0; d < c->D && c1 > c0; ++d)
+        memcpy(dW + (size_t)d * c->F + c0, tmp.data() + (size_t)c->D * c0 + (size_t)d * (c1 - c0), (size_t)(c1 - c0) * 4);
+    }
+  }
   if (db) HIPCHK(hipMemcpy(db, c->grads + nW, c->D * 4, hipMemcpyDeviceToHost));
   return VV_OK;
 }
@@ -1066,6 +1132,7 @@ int vv_embed(vv_ctx* c, const int32_t* rows, int64_t n, int relu, int l2norm, fl
   if (!c->table || !c->W) return fail(VV_ERR_STATE, "vv_embed: table and parameters must be set first");
   if (n > (1ll << 30)) return fail(VV_ERR_ARG, "vv_embed: n too large");
   HIPCHK(hipSetDevice(c->device));
+  { const int rcj = comm_join(c); if (rcj) return rcj; }
   const int D = c->D;
   const int Rp = (int)round_up(n, R_ALIGN);
   std::vector<int32_t> h(Rp, (int32_t)c->n_rows);
@@ -1096,6 +1163,7 @@ int vv_embed_mean(vv_ctx* c, const int32_t* rows, int64_t n, int32_t k, const fl
   if (!c->table || !c->W) return fail(VV_ERR_STATE, "vv_embed_mean: table and parameters must be set first");
   if (n > (1ll << 24)) return fail(VV_ERR_ARG, "vv_embed_mean: n too large");
   HIPCHK(hipSetDevice(c->device));
+  { const int rcj = comm_join(c); if (rcj) return rcj; }
   for (int64_t i = 0; i < n * k; ++i)
     if (rows[i] < 0 || rows[i] >= c->n_rows) return fail(VV_ERR_ARG, "vv_embed_mean: row %d out of range", rows[i]);
   int rc = ensure_scratch_rows(c, n);
@@ -1196,25 +1264,24 @@ int vv_allreduce_grads(vv_ctx* c) {
   if (!c->comm) { c->grads_pending = false; return VV_OK; }
   if (!c->have_fwd) return fail(VV_ERR_STATE, "vv_allreduce_grads: no gradients (call vv_forward_backward)");
   if (!c->grads_pending) return VV_OK;                         // already summed
+  if (c->grads_chunked) return VV_OK;                          // overlapped schedule: vv_apply_update exchanges chunk by chunk
   HIPCHK(hipSetDevice(c->device));
-  if (!c->grads_chunked) {                                     // the whole buffer, after everything queued on the compute stream
-    // synchronous schedule over RCCL: the collective goes straight into the compute stream (nothing would run beside it)
-    const int rc = vv::comm_allreduce_inline(c->comm, c->grads, (size_t)c->D * c->F + c->D, c->stream);
-    if (rc < 0) return fail(VV_ERR_HIP, "all-reduce: %s", vv::comm_error(c->comm));
-    if (rc == 0) { c->grads_pending = false; return VV_OK; }
-    HIPCHK(hipEventRecord(c->ev_chunk, c->stream));
-    if (vv::comm_allreduce(c->comm, c->grads, 0, (size_t)c->D * c->F + c->D, c->ev_chunk))
-      return fail(VV_ERR_HIP, "all-reduce: %s", vv::comm_error(c->comm));
-  }
+  // synchronous schedule over RCCL: the collective goes straight into the compute stream (nothing would run beside it)
+  const int rc = vv::comm_allreduce_inline(c->comm, c->grads, (size_t)c->D * c->F + c->D, c->stream);
+  if (rc < 0) return fail(VV_ERR_HIP, "all-reduce: %s", vv::comm_error(c->comm));
+  if (rc == 0) { c->grads_pending = false; return VV_OK; }
+  HIPCHK(hipEventRecord(c->ev_chunk, c->stream));
+  if (vv::comm_allreduce(c->comm, c->grads, 0, (size_t)c->D * c->F + c->D, c->ev_chunk))
+    return fail(VV_ERR_HIP, "all-reduce: %s", vv::comm_error(c->comm));
   HIPCHK(hipStreamWaitEvent(c->stream, vv::comm_done_event(c->comm), 0));   // the update waits for the sum; the host does not
-  c->grads_pending = false; c->grads_chunked = false;
+  c->grads_pending = false;
   return VV_OK;
 }
 
 int vv_comm_destroy(vv_ctx* c) {
   if (!c) return VV_OK;
-  if (c->comm) { (void)hipStreamSynchronize(c->stream); vv::comm_destroy(c->comm); c->comm = nullptr; }
-  c->grads_pending = c->grads_chunked = false;
+  if (c->comm) { (void)comm_join(c); (void)hipStreamSynchronize(c->stream); vv::comm_destroy(c->comm); c->comm = nullptr; }
+  c->grads_pending = c->grads_chunked = c->upd_inflight = false;
   return VV_OK;
 }
 

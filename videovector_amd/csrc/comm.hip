@@ -143,7 +143,11 @@ Comm* comm_create(int world, int rank, const char* id_path, int transport, size_
   Comm* c = new Comm();
   c->world = world; c->rank = rank; c->transport = transport;
   auto fail = [&](const std::string& m) { if (err) *err = m; comm_destroy(c); return (Comm*)nullptr; };
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
+  // the communication stream gets the highest priority: its short kernels (the chunks of the overlapped update) run beside
+  // the compute stream's large ones and must not queue behind them
+  int prio_lo = 0, prio_hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) != hipSuccess) return fail("hipStreamCreate failed");
   if (hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
   const double timeout_s = getenv("VV_COMM_TIMEOUT") ? atof(getenv("VV_COMM_TIMEOUT")) : 120.0;
@@ -298,5 +302,10 @@ int comm_allreduce(Comm* c, float* buf, size_t off, size_t n, hipEvent_t after) 
 }
 
 hipEvent_t comm_done_event(Comm* c) { return c->ev_done; }
+hipStream_t comm_stream(Comm* c) { return c->stream; }
+int comm_record_done(Comm* c) {
+  if (hipEventRecord(c->ev_done, c->stream) != hipSuccess) { c->err = "hipEventRecord failed"; return -1; }
+  return 0;
+}
 
 }  // namespace vv

@@ -13,6 +13,7 @@
 //   k_sgd        : SGDSolver::ComputeUpdateValue + Blob::Update in one pass
 //                  (solver.cpp:502-531, blob.cpp:112-136), also refreshes the half copy of W.
 //   table / conversion helpers.
+#include <algorithm>
 #include "vv_internal.h"
 
 namespace vv {
@@ -1141,10 +1142,12 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
   const int64_t slab_sz = (int64_t)a.Dp * a.Fp;
   const int d0 = a.d_begin, dn = a.d_count > 0 ? a.d_count : a.D;
   if (VEC) {
-    const int f4 = a.F / 4;
+    const int fb = a.f_count > 0 ? a.f_begin : 0, fn = a.f_count > 0 ? a.f_count : a.F;
+    const int f4 = fn / 4;
+    const int nblk = (int)gridDim.x - (a.scale_sc ? 1 : 0) - ((a.parts & 2) ? (a.D + 15) / 16 + 1 : 0);      // this launch's dW blocks
     for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < (int64_t)dn * f4;
-         i += (int64_t)RED_DW_BLOCKS * 256) {
-      const int d = d0 + (int)(i / f4), f = (int)(i % f4) * 4;
+         i += (int64_t)nblk * 256) {
+      const int d = d0 + (int)(i / f4), f = fb + (int)(i % f4) * 4;
       const float* p = a.slabs + (int64_t)d * a.Fp + f;
       float4 s = *(const float4*)p;
       int k = 1;
@@ -1160,8 +1163,12 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
         const float4 t = *(const float4*)(p + k * slab_sz);
         s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
       }
-      *(float4*)(a.grads + (int64_t)d * a.F + f) =
-          make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+      int64_t o = (int64_t)d * a.F + f;
+      if (a.chunk_cols > 0) {          // chunk-major (vv_internal.h: ReduceArgs::chunk_cols); chunk_cols % 4 == 0
+        const int cc = f / a.chunk_cols, c0 = min(a.F, cc * a.chunk_cols), c1 = min(a.F, (cc + 1) * a.chunk_cols);
+        o = (int64_t)a.D * c0 + (int64_t)d * (c1 - c0) + (f - c0);
+      }
+      *(float4*)(a.grads + o) = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
     }
   } else {
     const int64_t nW = (int64_t)dn * a.F;
@@ -1174,7 +1181,9 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
   }
 }
 void launch_reduce(const ReduceArgs& a, hipStream_t s) {
-  const dim3 grid(((a.parts & 1) ? RED_DW_BLOCKS : 0) + ((a.parts & 2) ? (a.D + 15) / 16 + 1 : 0) + (a.scale_sc ? 1 : 0));   // dW blocks, db blocks, the loss block, the scale block
+  // dW blocks (fewer for a launch that reduces a column range only), db blocks, the loss block, the scale block
+  const int dwb = !(a.parts & 1) ? 0 : (a.f_count > 0 && a.F % 4 == 0 ? std::max(64, (int)((int64_t)RED_DW_BLOCKS * a.f_count / a.F)) : RED_DW_BLOCKS);
+  const dim3 grid(dwb + ((a.parts & 2) ? (a.D + 15) / 16 + 1 : 0) + (a.scale_sc ? 1 : 0));
   if (a.F % 4 == 0) VV_LAUNCH(k_reduce<true>, grid, dim3(256), 0, s, a);
   else VV_LAUNCH(k_reduce<false>, grid, dim3(256), 0, s, a);
 }
@@ -1204,19 +1213,22 @@ __global__ __launch_bounds__(256) void k_sgd(SgdArgs a) {
     return w;
   };
   if (VEC) {       // F % 4 == 0: 16-B accesses, one row segment per thread
-    const int f4 = a.F / 4;
+    const int fc = a.chunked ? a.f_count : a.F;              // this launch's columns: one F-chunk, or all
+    const int f4 = fc / 4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)a.D * f4;
          i += (int64_t)gridDim.x * 256) {
-      const int d = (int)(i / f4), f = (int)(i % f4) * 4;
+      const int d = (int)(i / f4), fl = (int)(i % f4) * 4, f = a.f_begin + fl;
       const int64_t o = (int64_t)d * a.F + f;
+      const int64_t og = a.chunked ? (int64_t)a.D * a.f_begin + (int64_t)d * fc + fl : o;     // chunk-major gradient buffer
       float4 w = *(const float4*)(a.W + o), h = *(const float4*)(a.hW + o);
-      const float4 g = *(const float4*)(a.grads + o);
+      const float4 g = *(const float4*)(a.grads + og);
       w.x = upd(w.x, g.x, h.x); w.y = upd(w.y, g.y, h.y); w.z = upd(w.z, g.z, h.z); w.w = upd(w.w, g.w, h.w);
       *(float4*)(a.W + o) = w;
       *(float4*)(a.hW + o) = h;
       const uint32_t lo = T::from_float(w.x * sw) | ((uint32_t)T::from_float(w.y * sw) << 16);
       const uint32_t hi = T::from_float(w.z * sw) | ((uint32_t)T::from_float(w.w * sw) << 16);
-      *(uint2*)(a.Wh + (int64_t)d * a.Fp + f) = make_uint2(lo, hi);
+      if (a.pub_flag) __hip_atomic_store((unsigned long long*)(a.Wh + (int64_t)d * a.Fp + f), ((unsigned long long)hi << 32) | lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else *(uint2*)(a.Wh + (int64_t)d * a.Fp + f) = make_uint2(lo, hi);
     }
   } else {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nW; i += (int64_t)gridDim.x * 256) {
@@ -1229,9 +1241,10 @@ __global__ __launch_bounds__(256) void k_sgd(SgdArgs a) {
     }
   }
   const float lr_b = a.rate * a.lr_mult_b, dc_b = a.weight_decay * a.decay_mult_b;
-  for (int d = blockIdx.x * 256 + threadIdx.x; d < a.D; d += gridDim.x * 256) {
+  for (int d = blockIdx.x * 256 + threadIdx.x; a.do_bias && d < a.D; d += gridDim.x * 256) {
     float h = a.hb[d];
-    a.b[d] = rule(a.b[d], a.grads[nW + d], h, lr_b, dc_b);
+    const float bn = rule(a.b[d], a.grads[nW + d], h, lr_b, dc_b);
+    if (a.pub_flag) __hip_atomic_store(a.b + d, bn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else a.b[d] = bn;
     a.hb[d] = h;
   }
   // per-block max |w| -> one slot per block (no atomics: thousands of adds on one address
@@ -1243,13 +1256,34 @@ __global__ __launch_bounds__(256) void k_sgd(SgdArgs a) {
   if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = wmax;
   __syncthreads();
   if (threadIdx.x == 0) {
-    a.wmax_blocks[blockIdx.x] = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
-    if (blockIdx.x == 0) a.scales->sw_cur = sw;
+    a.wmax_blocks[a.blk_off + blockIdx.x] = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    if (blockIdx.x == 0 && a.set_scale) {
+      if (a.pub_flag) __hip_atomic_store(&a.scales->sw_cur, sw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else a.scales->sw_cur = sw;
+    }
+  }
+  if (a.pub_flag) {                    // SgdArgs::pub_flag: every wave's stores have landed before the workgroup counts itself in
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int old = __hip_atomic_fetch_add(a.pub_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old == (int)gridDim.x - 1) {
+        __hip_atomic_store(a.pub_count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.pub_flag, a.pub_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
 }
+__global__ void k_publish(int32_t* flag, int32_t seq) { __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// test hook (VV_COMM_TEST_DELAY_US): holds a stream for `us` microseconds, so that the gated forward GEMM really waits
+__global__ void k_delay(int us) {
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
+  while (__builtin_amdgcn_s_memrealtime() - t0 < (uint64_t)us * 100) __builtin_amdgcn_s_sleep(16);
+}
+void launch_delay(int us, hipStream_t s) { hipLaunchKernelGGL(k_delay, dim3(1), dim3(1), 0, s, us); }
+void launch_publish(int32_t* flag, int32_t seq, hipStream_t s) { hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, s, flag, seq); }
 void launch_sgd(int prec, const SgdArgs& a, hipStream_t s) {
   const bool vec = a.F % 4 == 0;
-  const dim3 grid(SGD_BLOCKS), block(256);
+  const dim3 grid(a.chunked ? SGD_BLOCKS / W_CHUNKS : SGD_BLOCKS), block(256);
   if (prec == 0) { if (vec) VV_LAUNCH((k_sgd<F16, true>), grid, block, 0, s, a); else VV_LAUNCH((k_sgd<F16, false>), grid, block, 0, s, a); }
   else { if (vec) VV_LAUNCH((k_sgd<BF16, true>), grid, block, 0, s, a); else VV_LAUNCH((k_sgd<BF16, false>), grid, block, 0, s, a); }
 }

@@ -65,7 +65,17 @@ constexpr int PH_LDS_BYTES = 8 * PH_SLOT;      // ring of 8 slots = 128 KiB
 // Half-tile LDS image: [128 rows][64 halves] = 128-B rows of 8 16-B chunks, chunk' = chunk ^ (row & 7)
 // (conflict-free ds_read_b128 fragment reads, as in k_fwd_gemm).  One LDS-DMA wave-instruction = 8 rows.
 // MQ = 16-row MFMA tiles per wave and A half: the tile is (64*MQ) x 256 (MQ 4: 256 rows, 3: 192, 2: 128).
-template <typename T, bool DROP, bool VEC, int MQ, int ABL = 0>
+// GATE: the W operand may still be arriving chunk by chunk (FwdArgs::gate).  Every wave checks all chunk flags once at
+// its start -- nothing of its stream is in flight yet, the check costs one round trip -- and when all are set (one GPU,
+// or an all-reduce that finished early: the usual case) the loop runs exactly as without gating.  Otherwise the
+// workgroup waits in front of its first B_lo issue of each chunk (B_lo(kt) is the first W access of K-tile kt: phase 3 of
+// K-tile kt - 2): WAVE 0 polls the chunk's flag (agent scope, s_sleep between polls: one poller per workgroup -- every
+// wave of 216 workgroups polling one line slowed the very kernels that were to set it) and runs the agent-scope acquire
+// (this CU's L1 may not serve the chunk from before the update); a workgroup barrier then releases the other waves.  The
+// barrier is one more in every wave's sequence: waves 4-7, one barrier behind, pass it one segment later, still behind
+// wave 0's poll.  The poll is a vector load: it drains wave 0's own stream once per chunk (three times per kernel, and
+// only while an update is really still in flight).
+template <typename T, bool DROP, bool VEC, int MQ, int ABL = 0, bool GATE = false>
 __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int HROWS = 32 * MQ;               // live rows of an A half-tile
@@ -116,6 +126,43 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) ph_glds16(src[i] + kt * BK, dst + (i * 8 + wave) * 1024);
   };
+
+  // chunk gates (GATE only)
+  const int kpc = nk / W_CHUNKS;               // K-tiles per W chunk
+  bool gated = false;
+  auto gate_wait = [&](int chunk) {
+    if (wave == 0) {
+      unsigned spins = 0;
+      while ((int32_t)(__hip_atomic_load(a.gate + chunk * W_GATE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.gate_seq) < 0) {
+        __builtin_amdgcn_s_sleep(64);
+        if (++spins > 2000000u) {              // ~seconds: the update never came (a failed rank, a bug): flag it and go on
+          if (lane == 0) __hip_atomic_store(a.gate_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          break;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __builtin_amdgcn_s_barrier();
+  };
+  if (GATE) {
+    // (every wave reads the flags itself here: `gated` must be the same in all eight, and a flag only ever grows --
+    // a wave that sees all set while another does not is excluded by re-reading after a barrier)
+    __shared__ int s_behind;
+    if (tid == 0) {
+      int behind = 0;
+#pragma unroll
+      for (int cch = 0; cch < W_CHUNKS; ++cch)
+        behind |= (int32_t)(__hip_atomic_load(a.gate + cch * W_GATE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.gate_seq) < 0;
+      s_behind = behind;
+    }
+    __syncthreads();
+    gated = s_behind != 0;
+    if (gated) {
+      if (kpc >= 4) gate_wait(0);
+      else for (int cch = 0; cch < W_CHUNKS; ++cch) gate_wait(cch);     // tiny K: the prologue already spans chunks
+      if (kpc < 4) gated = false;
+    } else if (wave == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the flags were read after the kernel began: order the W loads behind them
+  }
 
   // prologue: half-tiles 0 .. 5
   issue(0, 0, 0); issue(0, 1, 1); issue(0, 2, 2); issue(0, 3, 3); issue(1, 0, 4); issue(1, 1, 5);
@@ -168,6 +215,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
     PH_LOAD_A(0) PH_LOAD_B(b0, 1) PH_STREAM(0, t, 0, true) PH_MFMA(0, 0, b0)
     PH_LOAD_B(b1, 2) PH_STREAM(0, t, 1, true) PH_MFMA(0, 1, b1)
     PH_LOAD_A(3) PH_STREAM(0, t, 2, false) PH_MFMA(1, 1, b1)
+    if (GATE && gated && (t + 2) % kpc == 0 && t + 2 < nk) gate_wait((t + 2) / kpc);     // B_lo(t + 2) opens a chunk
     PH_STREAM(0, t, 3, true) PH_MFMA(1, 0, b0)
     // ---- K-tile t + 1 (odd): slots 4..7
     PH_LOAD_A(4) PH_LOAD_B(b0, 5) PH_STREAM(1, t + 1, 0, true) PH_MFMA(0, 0, b0)
@@ -183,7 +231,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
 
   // Epilogue: descale, bias, ReLU, dropout.  The MFMA was issued with the operands swapped (D' = W_tile X_tile^T):
   // the lane's column is the batch row m and its 4 registers are 4 consecutive outputs n -> one 16-B store.
-  const float descale = 1.0f / (a.scales->sx * a.scales->sw_cur);
+  // (gated: the scale of the half copy was rewritten while this kernel ran -- an agent-scope load, not the scalar cache's copy)
+  const float sw_now = GATE ? __hip_atomic_load(&a.scales->sw_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.scales->sw_cur;
+  const float descale = 1.0f / (a.scales->sx * sw_now);
   const float dscale = DROP ? 1.0f / (1.0f - a.drop_ratio) : 1.0f;
   const float lo = a.relu ? 0.f : -INFINITY;
 #pragma unroll
@@ -574,8 +624,19 @@ static void launch_fwd_ph_q(const FwdArgs& a, hipStream_t s) {
   (void)once;
   const int Dp = (int)round_up(a.D, D_ALIGN);
   const dim3 grid(((a.R + 64 * MQ - 1) / (64 * MQ)) * (Dp / BN)), block(GEMM_THREADS);
+  if constexpr (!DROP && VEC) {
+    if (a.gate) {
+      static bool once_g = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, PH_LDS_BYTES), true);
+      (void)once_g;
+      VV_LAUNCH((k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, true>), grid, block, PH_LDS_BYTES, s, a);
+      return;
+    }
+  }
   VV_LAUNCH((k_fwd_gemm_ph<T, DROP, VEC, MQ>), grid, block, PH_LDS_BYTES, s, a);
 }
+// the gated instantiation exists for the plain forward (no dropout, D % 4 == 0): the caller gates only then
+bool fwd_gemm_can_gate(const FwdArgs& a) { return a.drop_ratio == 0.f && a.D % 4 == 0; }
 
 static int g_ph_mq = 0;                   // VV_PH_MQ: force the tile height (2, 3, 4); 0 = automatic
 void set_ph_mq(int v) { g_ph_mq = v; }

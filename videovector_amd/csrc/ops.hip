@@ -355,6 +355,7 @@ int vv_op_inner_product(vv_ctx* c, const float* X, int64_t R, float* Y) {
   NEED(c);
   if (!c->W || !c->table) return vv_fail(VV_ERR_STATE, "vv_op_inner_product: table (it defines F) and parameters must be set first");
   if (!X || !Y || R <= 0 || R > (1ll << 30)) return vv_fail(VV_ERR_ARG, "vv_op_inner_product: bad argument");
+  { const int rcj = vv_comm_join(c); if (rcj) return rcj; }
   OpScratch& s = scratch_of(c);
   const int64_t Rp = round_up(R, R_ALIGN);
   if (Rp > s.x_rows || s.Fp != c->Fp || s.Dp != c->Dp) {     // (new parameters / a new table on the same context: other widths)

@@ -16,6 +16,8 @@ void comm_destroy(Comm* c);
 int comm_allreduce(Comm* c, float* buf, size_t off, size_t n, hipEvent_t after);
 int comm_allreduce_inline(Comm* c, float* buf, size_t n, hipStream_t stream);   // on the caller's stream (RCCL); 1 = not available
 hipEvent_t comm_done_event(Comm* c);
+hipStream_t comm_stream(Comm* c);          // the communication stream (the overlapped update queues its kernels there)
+int comm_record_done(Comm* c);             // records comm_done_event behind everything queued on the communication stream
 const char* comm_error(Comm* c);
 int comm_world(Comm* c);
 int comm_rank(Comm* c);

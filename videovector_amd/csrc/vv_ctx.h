@@ -118,9 +118,16 @@ struct vv_ctx {
                                             //   step's forward GEMM has finished" (the gate of the asynchronous grouping)
   // data-parallel gradient exchange (comm.hip)
   vv::Comm* comm = nullptr;
-  bool comm_overlap = false;        // all-reduce row blocks of dW while the weight-gradient kernel produces the next
-  bool grads_pending = false;       // a backward pass has produced gradients that have not been all-reduced / joined yet
-  bool grads_chunked = false;       // ... and their all-reduce is already in flight on the communication stream
+  bool comm_overlap = false;        // the update runs F-chunk by F-chunk on the communication stream (all-reduce, SGD, publish) and
+                                    // the NEXT step's forward GEMM waits per chunk inside the kernel (FwdArgs::gate)
+  bool grads_pending = false;       // a backward pass has produced gradients that have not been all-reduced yet
+  bool grads_chunked = false;       // the gradient buffer of the last backward pass is laid out chunk-major (ReduceArgs::chunk_cols)
+  bool upd_inflight = false;        // an overlapped update is on the communication stream and the compute stream has not joined it
+  int32_t upd_seq = 0;              // sequence number of the last overlapped update (what w_gate[c] reaches when chunk c is done)
+  int32_t* w_gate = nullptr;        // device [W_CHUNKS * W_GATE_STRIDE]: one flag per 128-B line
+  int32_t* pub_count = nullptr;     // device: arrival counter of the publishing SGD kernels (behind the flags)
+  hipEvent_t ev_chunk0 = nullptr; bool chunk0_event = false;     // the first F-chunk's reduction is done (recorded by fb_impl)
+  int32_t* gate_err = nullptr; int32_t* gate_err_dev = nullptr;     // pinned + mapped: a gated forward gave up waiting
   hipEvent_t ev_chunk = nullptr;
   hipEvent_t ev_idx = nullptr;      // orders the grouping stream behind caller-produced device indices (idx_on_device = 1)
   // profiling
@@ -135,3 +142,5 @@ struct vv_ctx {
 
 // ops.hip keeps per-context scratch for the per-layer INNER_PRODUCT operators; vv_destroy releases it
 void vv_ops_release(vv_ctx* c);
+// api.hip: orders the compute stream behind an overlapped parameter update still on the communication stream
+int vv_comm_join(vv_ctx* c);

@@ -84,7 +84,17 @@ struct FwdArgs {
   int32_t* seq_host = nullptr; // host-mapped word that receives `seq` (the step's index batch has been consumed), or null
   int32_t seq = 0;
   int abl = 0;                 // timing studies only (VV_ABLATE): selects an ablated instantiation of the phase-staggered kernel
+  // Data-parallel overlap (api.hip: vv_apply_update): the parameter update of the PREVIOUS step may still be arriving --
+  // F-chunk by F-chunk, each chunk all-reduced and applied on the communication stream -- while this kernel runs.
+  // gate[c * W_GATE_STRIDE] holds the sequence number of the last update whose chunk c (K-tiles [c nk/4, (c+1) nk/4) of W)
+  // is complete; a workgroup waits for it to reach gate_seq before it issues its first load of a W tile of chunk c.
+  // null = no gating.
+  const int32_t* gate = nullptr;
+  int32_t gate_seq = 0;
+  int32_t* gate_err = nullptr; // host-mapped: set when a wait gave up (bounded: a lost update must not hang the device)
 };
+constexpr int W_CHUNKS = 4;    // F-chunks of the overlapped update (chunk-major gradient buffer, api.hip)
+constexpr int W_GATE_STRIDE = 32;   // ints between two chunk flags: a 128-B line each (the waiting workgroups poll them)
 
 // Segment-wise backward (de-duplicated batches): the score kernel keeps the gradient of an instance in factored form
 // -- dY[r] = [x_u > 0] (alpha_r V[vec_r] - beta_r x_u), where V holds the item's normalised context mean Ah_b (row 2b:
@@ -202,6 +212,10 @@ struct ReduceArgs {
   // the loss reduction rides in one extra workgroup: loss = loss_scale * sum(loss_part), violations = sum(viol_part)
   const float* loss_part; const float* viol_part; float loss_scale; float* loss_out;
   int d_begin = 0, d_count = 0;      // rows of dW this launch reduces (d_count 0 = all D)
+  int f_begin = 0, f_count = 0;      // columns of dW this launch reduces (f_count 0 = all F); multiples of 4
+  int chunk_cols = 0;                // > 0: dW is stored CHUNK-MAJOR -- W_CHUNKS column blocks of chunk_cols (padded) columns,
+                                     //   block c = all D rows of columns [c0, c1) = [min(F, c cc), min(F, (c+1) cc)) at float offset
+                                     //   D c0, row stride c1 - c0 -- so that every F-chunk is one contiguous all-reduce buffer
   int parts = 3;                     // bit 0: the dW rows, bit 1: db and the loss scalars
   Scales* scale_sc = nullptr;        // non-null: one more workgroup performs the W -> half scale update left pending by the
   const float* scale_wmax = nullptr; //   previous step's k_sgd (its per-block max |w| slots)
@@ -219,6 +233,19 @@ struct SgdArgs {
   int reg;
   int solver_type;         // 0 SGD, 1 Nesterov, 2 AdaGrad
   float delta;             // AdaGrad stability constant
+  // one F-chunk of the update (data-parallel overlap): columns [f_begin, f_begin + f_count) of every row, read from the
+  // chunk-major gradient buffer (ReduceArgs::chunk_cols; f_count may be 0: nothing but, possibly, the bias);
+  // chunked = 0: the whole matrix from the row-major buffer
+  int chunked = 0, f_begin = 0, f_count = 0;
+  int blk_off = 0;         // first slot of wmax_blocks this launch writes (its grid is SGD_BLOCKS / W_CHUNKS)
+  int do_bias = 1;         // this launch also updates b (the last chunk: db is all-reduced with it)
+  int set_scale = 1;       // this launch publishes the scale of the new half copy (the first chunk)
+  // Publication from inside the kernel (chunked launches of the overlapped update; null = none): what the NEXT forward
+  // GEMM reads while this very stream is still working -- the half copy, its scale, the bias -- is stored write-through
+  // at agent scope (sc1); every wave drains its stores, the workgroup meets at a barrier and adds itself to pub_count;
+  // the workgroup whose add is the last sets *pub_flag = pub_seq (and clears the counter for the next chunk).  The
+  // consumer polls the flag and runs an agent-scope acquire (FwdArgs::gate).  No separate launch, no L2 write-back.
+  int32_t* pub_flag = nullptr; int32_t* pub_count = nullptr; int32_t pub_seq = 0;
 };
 
 // Kernel timing without extra queue packets: when the ABI layer has armed a pair of events (vv_profile_enable),
@@ -242,6 +269,7 @@ extern thread_local ProfPair g_prof;
 
 // kernel launchers (defined in the .hip files); prec: 0 = f16, 1 = bf16
 void launch_fwd_gemm(int prec, const FwdArgs& a, hipStream_t s);
+bool fwd_gemm_can_gate(const FwdArgs& a);                     // the forward kernel has a gated form for these arguments (FwdArgs::gate)
 long fwd_gemm_plan(int R, int R_hint, int D, int* mq_out);   // workgroups of the default forward GEMM that get a tile
 void launch_wgrad_gemm(int prec, const WgradArgs& a, hipStream_t s);
 void launch_score_loss(int prec, const ScoreArgs& a, hipStream_t s);
@@ -256,6 +284,8 @@ void launch_gather_rows_f32(const float* src, const int32_t* map, int R, int D, 
 void launch_gather_rows_u16(const uint16_t* src, const int32_t* pos, int R, int Dp, uint16_t* dst, hipStream_t s);
 void launch_reduce(const ReduceArgs& a, hipStream_t s);
 void launch_sgd(int prec, const SgdArgs& a, hipStream_t s);
+void launch_publish(int32_t* flag, int32_t seq, hipStream_t s);
+void launch_delay(int us, hipStream_t s);                             // test hook: occupies s for `us` microseconds       // flag <- seq (agent scope), behind everything queued on s
 void launch_scale_update(int prec, Scales* sc, const float* wmax_blocks, hipStream_t s);
 void launch_table_convert(int prec, const float* src, uint16_t* dst, int64_t n_rows, int F, int Fp,
                           float sx, hipStream_t s);
