@@ -683,7 +683,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
       static const int lds_kb = getenv("VV_DEDUP_LDS_KB") ? atoi(getenv("VV_DEDUP_LDS_KB")) : -1;
       const int hint = *(volatile int32_t*)c->U_host;
       const long tiles = fwd_gemm_plan(c->R, hint, D, nullptr);
-      da.lds_bytes = lds_kb >= 0 ? lds_kb * 1024 : (c->dd_async && gemm_variant() == 5 && hint > 0 && tiles <= c->n_cu - 24 ? 36 * 1024 : 0);
+      da.lds_bytes = lds_kb >= 0 ? lds_kb * 1024 : (c->dd_async && gemm_variant() == 5 && hint > 0 && tiles <= c->n_cu - 16 ? 36 * 1024 : 0);
     }
     da.R = c->R; da.Rp = c->Rp; da.zero_row = (int32_t)c->n_rows; da.row_limit = (int32_t)row_limit; da.epoch = c->dd_epoch;
     PROFILED(c, "dedup", (launch_dedup(da, ds), launch_dedup_groups(da, ds)));
@@ -722,7 +722,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
     // BESIDE the waiting GEMM, or nothing would ever release it); otherwise the stream joins here, as without overlap.
     const long tiles = fwd_gemm_plan(c->R, dd ? fa.R_hint : 0, D, nullptr);
     static const bool no_gate = getenv("VV_COMM_GATE") && atoi(getenv("VV_COMM_GATE")) == 0;
-    if (!no_gate && gemm_variant() == 5 && !ablate_on() && fwd_gemm_can_gate(fa) && (!dd || fa.R_hint > 0) && tiles <= c->n_cu - 24) {
+    if (!no_gate && gemm_variant() == 5 && !ablate_on() && fwd_gemm_can_gate(fa) && (!dd || fa.R_hint > 0) && tiles <= c->n_cu - 16) {
       fa.gate = c->w_gate; fa.gate_seq = c->upd_seq; fa.gate_err = c->gate_err_dev;
       c->upd_inflight = false;              // whatever follows the forward GEMM on this stream follows the whole update
     } else if ((rc = comm_join(c))) return rc;

@@ -75,11 +75,16 @@ constexpr int PH_LDS_BYTES = 8 * PH_SLOT;      // ring of 8 slots = 128 KiB
 // barrier is one more in every wave's sequence: waves 4-7, one barrier behind, pass it one segment later, still behind
 // wave 0's poll.  The poll is a vector load: it drains wave 0's own stream once per chunk (three times per kernel, and
 // only while an update is really still in flight).
-template <typename T, bool DROP, bool VEC, int MQ, int ABL = 0, bool GATE = false>
+// DEAD (0 / 1): the LAST 16-row MFMA tile of the upper A half (waves 4-7's) is left out -- the tile covers 64 MQ - 16 rows.
+// With MQ = 3 that is 176 rows: 236 instead of 216 workgroups for the benchmark's ~20 650 distinct rows, on 256 CUs.
+// (Rows of the 128-row half-tile image that no wave reads are still staged, from the L2-hot zero row: dropping those
+// LDS-DMA instructions -- the second one of waves 4-7 at 96 live rows -- with per-wave counted waits was measured and made
+// the 192-row kernel 4.6 us SLOWER, profiles/r03_step_ablations.txt.)
+template <typename T, bool DROP, bool VEC, int MQ, int ABL = 0, bool GATE = false, int DEAD = 0>
 __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int HROWS = 32 * MQ;               // live rows of an A half-tile
-  constexpr int BMT = 2 * HROWS;               // rows of the output tile
+  constexpr int HROWS = 32 * MQ;               // rows of the lower A half-tile (upper: HROWS - 16 DEAD)
+  constexpr int BMT = 2 * HROWS - 16 * DEAD;   // rows of the output tile
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
     for (int i = 0; i < 2; ++i) {
       const int row = (i * 8 + wave) * 8 + (lane >> 3), lc = (lane & 7) ^ (row & 7);
       const int grow = m0 + hf * HROWS + row;
-      const int trow = (row < HROWS && grow < R && !(ABL & 8)) ? a.rows[grow] : a.zero_row;
+      const int trow = (row < HROWS - 16 * DEAD * hf && grow < R && !(ABL & 8)) ? a.rows[grow] : a.zero_row;
       srcA[hf][i] = a.table + (int64_t)trow * Fp + lc * 8;
       srcB[hf][i] = a.Wh + (int64_t)(n0 + hf * 128 + row) * Fp + lc * 8;
     }
@@ -126,6 +131,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) ph_glds16(src[i] + kt * BK, dst + (i * 8 + wave) * 1024);
   };
+#define PH_WAITQ() PH_WAIT(8)                  /* everything but the four youngest half-tiles has landed */
 
   // chunk gates (GATE only)
   const int kpc = nk / W_CHUNKS;               // K-tiles per W chunk
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
 
   // prologue: half-tiles 0 .. 5
   issue(0, 0, 0); issue(0, 1, 1); issue(0, 2, 2); issue(0, 3, 3); issue(1, 0, 4); issue(1, 1, 5);
-  PH_WAIT(8);                                  // half-tiles 0, 1 (A_lo, B_lo of K-tile 0) have landed
+  PH_WAITQ();                                  // half-tiles 0, 1 (A_lo, B_lo of K-tile 0) have landed
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one segment behind
   if (wm == 1) __builtin_amdgcn_s_setprio(1);  // the younger half loses VALU arbitration otherwise
@@ -178,8 +184,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
   i16x8 af[MQ][2], b0[2][2], b1[2][2];
 
   // one phase: LOAD segment (reads + stream + wait), barrier, MFMA segment, barrier
+  const bool dead_hi = DEAD && wm == 1;        // this wave's last tile of the upper A half does not exist
 #define PH_LOAD_A(slot)                                                                              \
   if (!abl_rd) _Pragma("unroll") for (int mi = 0; mi < MQ; ++mi) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) \
+    if (!(DEAD && ((slot) & 3) == 3 && mi == MQ - 1 && dead_hi))                                     \
     af[mi][kk] = *(const i16x8*)(smem + (slot) * PH_SLOT + a_off + mi * 2048 + (((kk * 4 + fq) ^ sw) << 4));
 #define PH_LOAD_B(dst, slot)                                                                         \
   if (!abl_rd) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)  \
@@ -188,6 +196,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
   __builtin_amdgcn_s_barrier();                                                                      \
   __builtin_amdgcn_sched_barrier(0);                                                                 \
   if (!abl_mm) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int mi = 0; mi < MQ; ++mi) \
+    if (!(DEAD && (mh) == 1 && mi == MQ - 1 && dead_hi))                                             \
     _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                 \
       acc[mh][mi][nh][ni] = T::mfma(bfr[ni][kk], af[mi][kk], acc[mh][mi][nh][ni]);                   \
   __builtin_amdgcn_sched_barrier(0);                                                                 \
@@ -197,7 +206,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
 #define PH_STREAM(tpar, t, p, wait)                                                                  \
   {                                                                                                  \
     const int h = 4 * (t) + (p) + 6;                                                                 \
-    if (h < H && !abl_st) { issue(h >> 2, ((p) + 2) & 3, 4 * (((tpar) + (((p) + 6) >> 2)) & 1) + (((p) + 2) & 3)); if (wait) PH_WAIT(8); } \
+    if (h < H && !abl_st) { issue(h >> 2, ((p) + 2) & 3, 4 * (((tpar) + (((p) + 6) >> 2)) & 1) + (((p) + 2) & 3)); if (wait) PH_WAITQ(); } \
     else if (wait) PH_WAIT(0);                                                                       \
   }
   // ABL: timing studies only (VV_ABLATE, results wrong): 1 no LDS-DMA stream in the loop, 2 no MFMA, 4 no fragment
@@ -228,6 +237,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
 #undef PH_LOAD_B
 #undef PH_MFMA
 #undef PH_STREAM
+#undef PH_WAITQ
 
   // Epilogue: descale, bias, ReLU, dropout.  The MFMA was issued with the operands swapped (D' = W_tile X_tile^T):
   // the lane's column is the batch row m and its 4 registers are 4 consecutive outputs n -> one 16-B store.
@@ -240,6 +250,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
   for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
     for (int mi = 0; mi < MQ; ++mi) {
+      if (DEAD && mh == 1 && mi == MQ - 1 && dead_hi) continue;
       const int m = m0 + mh * HROWS + wm * 16 * MQ + mi * 16 + frow;
       if (m >= R) continue;
       int64_t ref_row = 0;
@@ -617,54 +628,65 @@ void launch_wgrad_gemm_w4(int prec, const WgradArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------- launchers ----
-template <typename T, bool DROP, bool VEC, int MQ>
+template <typename T, bool DROP, bool VEC, int MQ, int DEAD = 0>
 static void launch_fwd_ph_q(const FwdArgs& a, hipStream_t s) {
-  static bool once = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, MQ>,
+  static bool once = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, false, DEAD>,
                       hipFuncAttributeMaxDynamicSharedMemorySize, PH_LDS_BYTES), true);
   (void)once;
   const int Dp = (int)round_up(a.D, D_ALIGN);
-  const dim3 grid(((a.R + 64 * MQ - 1) / (64 * MQ)) * (Dp / BN)), block(GEMM_THREADS);
+  constexpr int BMT = 64 * MQ - 16 * DEAD;
+  const dim3 grid(((a.R + BMT - 1) / BMT) * (Dp / BN)), block(GEMM_THREADS);
   if constexpr (!DROP && VEC) {
     if (a.gate) {
-      static bool once_g = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, true>,
+      static bool once_g = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, true, DEAD>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, PH_LDS_BYTES), true);
       (void)once_g;
-      VV_LAUNCH((k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, true>), grid, block, PH_LDS_BYTES, s, a);
+      VV_LAUNCH((k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, true, DEAD>), grid, block, PH_LDS_BYTES, s, a);
       return;
     }
   }
-  VV_LAUNCH((k_fwd_gemm_ph<T, DROP, VEC, MQ>), grid, block, PH_LDS_BYTES, s, a);
+  VV_LAUNCH((k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, false, DEAD>), grid, block, PH_LDS_BYTES, s, a);
 }
 // the gated instantiation exists for the plain forward (no dropout, D % 4 == 0): the caller gates only then
 bool fwd_gemm_can_gate(const FwdArgs& a) { return a.drop_ratio == 0.f && a.D % 4 == 0; }
 
-static int g_ph_mq = 0;                   // VV_PH_MQ: force the tile height (2, 3, 4); 0 = automatic
+static int g_ph_mq = 0;                   // VV_PH_MQ: force the tile (2, 3, 4 = 128 / 192 / 256 rows, 31 = 176 rows); 0 = automatic
 void set_ph_mq(int v) { g_ph_mq = v; }
 
-// Tile height 64*MQ of the forward GEMM for R rows (R_hint > 0: the distinct-row count of the previous step, the rows
-// the workgroups will really find) and the number of workgroups that get a tile: the least (rounds of 256 workgroups) x
-// (cost of one K-tile of that height); the cost of a K-tile is not proportional to MQ: the LDS-DMA stream and the
-// barriers do not shrink with the tile.
-long fwd_gemm_plan(int R, int R_hint, int D, int* mq_out) {
+// Tile of the forward GEMM for R rows (R_hint > 0: the distinct-row count of the previous step, the rows the workgroups
+// will really find) and the number of workgroups that get a tile: the least (rounds of 256 workgroups) x (cost of one
+// K-tile of that height); the cost of a K-tile is not proportional to the tile height: the B half-tiles, the barriers and
+// the phase structure do not shrink with it.  Tiles: 256, 192 and 128 rows; 176 (192 without its last 16-row MFMA tile:
+// 236 instead of 216 workgroups on the 256 CUs at the benchmark's ~20 650 distinct rows) only on request (VV_PH_MQ=31):
+// measured on one box, 400 steps each, the 176-row launch took 85.9 us against 84.4 us -- every workgroup of the single
+// round still stages and waits for the same half-tiles, so fewer rows per workgroup shorten nothing, and the 20 extra
+// workgroups take the CUs the grouping kernels of the next step were running on (profiles/r03_step_ablations.txt).
+static const int kTileRows[4] = {256, 192, 176, 128};
+static const int kTileCost[4] = {100, 85, 1000000, 70};
+static int fwd_pick_tile(int R, int R_hint, int D, long* tiles_out) {
   const int Dp = (int)round_up(D, D_ALIGN);
   const int Rh = R_hint > 0 ? (int)std::min<long>(R, R_hint + R_hint / 32 + 64) : R;
-  static const int kCost[5] = {0, 0, 70, 85, 100};
-  int best = 4; long best_cost = -1;
-  for (int mq = 4; mq >= 2; --mq) {
-    const long tiles = ((Rh + 64 * mq - 1) / (64 * mq)) * (long)(Dp / BN);
-    const long cost = ((tiles + 255) / 256) * kCost[mq];
-    if (best_cost < 0 || cost < best_cost) { best = mq; best_cost = cost; }
+  int best = 0; long best_cost = -1;
+  for (int t = 0; t < 4; ++t) {
+    const long tiles = ((Rh + kTileRows[t] - 1) / kTileRows[t]) * (long)(Dp / BN);
+    const long cost = ((tiles + 255) / 256) * kTileCost[t];
+    if (best_cost < 0 || cost < best_cost) { best = t; best_cost = cost; }
   }
-  if (g_ph_mq >= 2 && g_ph_mq <= 4) best = g_ph_mq;
-  if (mq_out) *mq_out = best;
-  return ((Rh + 64 * best - 1) / (64 * best)) * (long)(Dp / BN);
+  if (g_ph_mq == 4) best = 0; else if (g_ph_mq == 3) best = 1; else if (g_ph_mq == 31) best = 2; else if (g_ph_mq == 2) best = 3;
+  if (tiles_out) *tiles_out = ((Rh + kTileRows[best] - 1) / kTileRows[best]) * (long)(Dp / BN);
+  return best;
+}
+long fwd_gemm_plan(int R, int R_hint, int D, int* mq_out) {
+  long tiles = 0;
+  const int t = fwd_pick_tile(R, R_hint, D, &tiles);
+  if (mq_out) *mq_out = t == 0 ? 4 : t == 3 ? 2 : 3;
+  return tiles;
 }
 
 template <typename T, bool DROP, bool VEC>
 static void launch_fwd_ph_t(const FwdArgs& a, hipStream_t s) {
   const int Dp = (int)round_up(a.D, D_ALIGN);
-  int best;
-  (void)fwd_gemm_plan(a.R, a.n_dev ? a.R_hint : 0, a.D, &best);
+  const int best = fwd_pick_tile(a.R, a.n_dev ? a.R_hint : 0, a.D, nullptr);
   if constexpr (T::id == 0 && !DROP && VEC) {
     if (a.abl) {
       const dim3 grid(((a.R + 255) / 256) * (Dp / BN)), block(GEMM_THREADS);
@@ -678,8 +700,9 @@ static void launch_fwd_ph_t(const FwdArgs& a, hipStream_t s) {
 #undef VV_ABL_FWP
     }
   }
-  if (best == 4) launch_fwd_ph_q<T, DROP, VEC, 4>(a, s);
-  else if (best == 3) launch_fwd_ph_q<T, DROP, VEC, 3>(a, s);
+  if (best == 0) launch_fwd_ph_q<T, DROP, VEC, 4>(a, s);
+  else if (best == 1) launch_fwd_ph_q<T, DROP, VEC, 3>(a, s);
+  else if (best == 2) launch_fwd_ph_q<T, DROP, VEC, 3, 1>(a, s);
   else launch_fwd_ph_q<T, DROP, VEC, 2>(a, s);
 }
 
