@@ -133,7 +133,7 @@ def test_caffe_train_with_negative_dataset(tool, pb, lmdb_pb, oracle, tmp_path):
     Wg, bg, _ = read_caffemodel(pb, str(tmp_path / "snap_iter_6.caffemodel"))
     print("NEGDS: W %.3e b %.3e dW %.3e" % (rel_fro(Wg, Wq), rel_fro(bg, bq), rel_fro(Wg - W0, Wq - W0)))
     # free-running iterations of a small case amplify the rounding differences of the first step (hinge terms switch
-    # on and off; tools/sessions/r2_d2_negds_debug.py measures 2e-5 -> 9e-4 over six iterations with per-iteration
+    # on and off; tools/lab/trajectory_sensitivity.py measures how fast trajectories separate (2e-5 -> 9e-4 over six iterations here) with per-iteration
     # gradients agreeing to 4e-4): every per-iteration loss is held to 1e-3 above, the weights to a looser bound
     assert rel_fro(Wg, Wq) <= 5e-3 and rel_fro(Wg - W0, Wq - W0) <= 2e-2
     # one shot fewer in the buffer: the reference overruns negatives_ (…:325-343) -- refused with its message
