@@ -573,7 +573,7 @@ def main():
             try:
                 pj = json.load(open(pmc_path))
                 pmc = pj.get("dedup_" + args.dedup, {}).get(dom, {}).get("hbm_bytes_per_launch")
-                pmc_src = pj.get("source", "profiles/pmc_latest.json")
+                pmc_src = "profiles/pmc_latest.json (" + pj.get("_source", pj.get("source", "rocprofv3 PMC passes")) + ")"
             except Exception:
                 pmc = None
         roof["traffic"] = pmc
