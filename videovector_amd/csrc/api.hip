@@ -570,6 +570,81 @@ extern "C++" int vv_comm_join(vv_ctx* c) {
   return VV_OK;
 }
 
+// The grouping of one batch (k_dd_claim .. k_dd_segstart) into the next of the rotating output sets, on the grouping
+// stream; *set_out = the set.  The step that consumes the set binds it and orders its stream behind set.done (fb_impl).
+static int dd_issue(vv_ctx* c, const int32_t* didx, int idx_on_device, int64_t row_limit, int32_t seq, int* set_out) {
+  hipStream_t s = c->stream;
+  const int D = c->D;
+  {
+    // The grouping kernels need only the indices: they run on the context's second stream, so that when the host is a
+    // step ahead (the normal case: nothing in the loop waits for the GPU) the grouping of step k+1 executes beside the
+    // kernels of step k and the step's own stream merely waits for an event that has long been signalled.  Three sets of
+    // output arrays rotate; a set is rewritten only after the step that read it has issued its last reader.
+    hipStream_t ds = c->dd_async ? c->dd_stream : s;
+    if (c->dd_async && idx_on_device == 1) {
+      // the caller's indices may still be in the making on the context's stream: the grouping stream waits for it
+      if (!c->ev_idx) HIPCHK(hipEventCreateWithFlags(&c->ev_idx, hipEventDisableTiming));
+      HIPCHK(hipEventRecord(c->ev_idx, s));
+      HIPCHK(hipStreamWaitEvent(ds, c->ev_idx, 0));
+    }
+    const int64_t need = c->n_rows + 1 + c->patch_cap;
+    if (need > c->dd_key_cap) {
+      HIPCHK(hipStreamSynchronize(s));
+      HIPCHK(hipStreamSynchronize(c->dd_stream));
+      dfree(c->dd_key); c->dd_key = nullptr;
+      HIPCHK(hipMalloc(&c->dd_key, (size_t)need * sizeof(unsigned long long)));
+      HIPCHK(hipMemsetAsync(c->dd_key, 0, (size_t)need * sizeof(unsigned long long), ds));
+      c->dd_key_cap = need;
+    }
+    if (++c->dd_epoch == 0) {        // epoch tags wrapped: start over with clean tag words
+      HIPCHK(hipMemsetAsync(c->dd_key, 0, (size_t)c->dd_key_cap * sizeof(unsigned long long), ds));
+      HIPCHK(hipMemsetAsync(c->dd_agg, 0, (size_t)2 * c->dd_agg_stride * sizeof(unsigned long long), ds));
+      c->dd_epoch = 1;
+    }
+    const int si = (int)(c->dd_step++ % vv_ctx::kDdSets);
+    vv_ctx::DdSet& set = c->dd_set[si];
+    *set_out = si;
+    if (c->dd_async && set.used_seq) {
+      // The set was last read by the step with sequence number used_seq.  The step's stream runs its kernels in order, so
+      // once a kernel of ANY later step has stamped its number, every kernel of that step has finished.  The host waits
+      // for that stamp (normally long there: it bounds how far the host runs ahead to kDdSets - 1 steps) -- an event
+      // recorded per step for the same purpose cost ~6 us of stream time each (a queue barrier packet between two kernels).
+      // In steady state this wait is what paces the host, so the grouping it queues next starts right at the stamp and
+      // shares the chip with the kernel that wrote it.  Two stamps exist: the forward GEMM's (word 0, written as it starts)
+      // and the score kernel's (word 1, i.e. "the forward GEMM has finished").  A/B on one box, 4 x 4000 steps each
+      // (profiles/r02_step_ablations.txt): released by the forward GEMM the grouping costs that GEMM 5-6 us (0.085 against
+      // 0.080 ms alone: one persistent workgroup per CU, and a CU that also hosts grouping workgroups finishes late) and the
+      // step takes 0.2305 ms; released by the score kernel it costs the score and segment kernels 4.5 + 2 us and the step
+      // takes 0.2337 ms.  Released after the segment kernel or later it runs into the weight-gradient GEMM, is starved there
+      // (80 us instead of 33) and the next step waits for it (0.239-0.253 ms).  Default: the forward GEMM's stamp -- the
+      // faster step, at the price of a forward-GEMM duration (and roofline fraction) that includes the co-running kernels.
+      // VV_DEDUP_GATE=1 selects the other.
+      static const int gate_word = getenv("VV_DEDUP_GATE") ? (atoi(getenv("VV_DEDUP_GATE")) != 0) : 0;
+      for (unsigned spins = 0; (int32_t)(__atomic_load_n(c->seq_host + gate_word, __ATOMIC_ACQUIRE) - set.used_seq) <= 0; ++spins) {
+        if (spins > 4096) { timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
+        if (hipStreamQuery(s) == hipSuccess) break;             // nothing queued any more: every earlier step is done
+      }
+    }
+    set.used_seq = seq;
+    DedupArgs da;
+    da.idx = didx; da.rows = set.rows; da.u_host = c->U_host_dev; da.key = c->dd_key; da.agg = c->dd_agg; da.agg_stride = c->dd_agg_stride;
+    da.slot_of = set.slot_of; da.uniq_rows = set.uniq; da.map = set.map; da.ord = set.ord; da.cnt = set.cnt;
+    da.seg_start = set.seg; da.pos = c->dd_pos; da.info = set.info; da.tickets = set.info + 2;
+    {
+      // placement of the grouping workgroups beside the forward GEMM (kernels_dedup.hip): only when that GEMM -- sized for
+      // the previous step's distinct-row count, as launch_fwd_gemm will size it -- leaves at least 24 CUs idle
+      static const int lds_kb = getenv("VV_DEDUP_LDS_KB") ? atoi(getenv("VV_DEDUP_LDS_KB")) : -1;
+      const int hint = *(volatile int32_t*)c->U_host;
+      const long tiles = fwd_gemm_plan(c->R, hint, D, nullptr);
+      da.lds_bytes = lds_kb >= 0 ? lds_kb * 1024 : (c->dd_async && gemm_variant() == 5 && hint > 0 && tiles <= c->n_cu - 16 ? 36 * 1024 : 0);
+    }
+    da.R = c->R; da.Rp = c->Rp; da.zero_row = (int32_t)c->n_rows; da.row_limit = (int32_t)row_limit; da.epoch = c->dd_epoch;
+    PROFILED(c, "dedup", (launch_dedup(da, ds), launch_dedup_groups(da, ds)));
+    if (c->dd_async) HIPCHK(hipEventRecord(set.done, ds));
+  }
+  return VV_OK;
+}
+
 // idx_on_device: 0 host indices; 1 device indices produced on the context's stream (ordered after everything queued
 // there); 2 device indices that are complete already (no ordering needed: the ring's staging slots, static batches)
 static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int idx_on_device, int64_t row_limit, int32_t seq = 0) {
@@ -623,80 +698,21 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   c->last_dedup = dd;
   if (!dd) launch_map_rows(didx, c->rows, c->R, c->Rp, (int32_t)c->n_rows, (int32_t)row_limit, s);
   if (dd) {
-    // The grouping kernels need only the indices: they run on the context's second stream, so that when the host is a
-    // step ahead (the normal case: nothing in the loop waits for the GPU) the grouping of step k+1 executes beside the
-    // kernels of step k and the step's own stream merely waits for an event that has long been signalled.  Three sets of
-    // output arrays rotate; a set is rewritten only after the step that read it has issued its last reader.
-    hipStream_t ds = c->dd_async ? c->dd_stream : s;
-    if (c->dd_async && idx_on_device == 1) {
-      // the caller's indices may still be in the making on the context's stream: the grouping stream waits for it
-      if (!c->ev_idx) HIPCHK(hipEventCreateWithFlags(&c->ev_idx, hipEventDisableTiming));
-      HIPCHK(hipEventRecord(c->ev_idx, s));
-      HIPCHK(hipStreamWaitEvent(ds, c->ev_idx, 0));
-    }
-    const int64_t need = c->n_rows + 1 + c->patch_cap;
-    if (need > c->dd_key_cap) {
-      HIPCHK(hipStreamSynchronize(s));
-      HIPCHK(hipStreamSynchronize(c->dd_stream));
-      dfree(c->dd_key); c->dd_key = nullptr;
-      HIPCHK(hipMalloc(&c->dd_key, (size_t)need * sizeof(unsigned long long)));
-      HIPCHK(hipMemsetAsync(c->dd_key, 0, (size_t)need * sizeof(unsigned long long), ds));
-      c->dd_key_cap = need;
-    }
-    if (++c->dd_epoch == 0) {        // epoch tags wrapped: start over with clean tag words
-      HIPCHK(hipMemsetAsync(c->dd_key, 0, (size_t)c->dd_key_cap * sizeof(unsigned long long), ds));
-      HIPCHK(hipMemsetAsync(c->dd_agg, 0, (size_t)2 * c->dd_agg_stride * sizeof(unsigned long long), ds));
-      c->dd_epoch = 1;
-    }
-    vv_ctx::DdSet& set = c->dd_set[c->dd_step++ % vv_ctx::kDdSets];
+    int si = 0;
+    if ((rc = dd_issue(c, didx, idx_on_device, row_limit, seq, &si))) return rc;
+    vv_ctx::DdSet& set = c->dd_set[si];
+    set.used_seq = seq;
     c->dd_rows = set.rows; c->dd_slot_of = set.slot_of; c->dd_uniq = set.uniq; c->dd_map = set.map; c->dd_ord = set.ord;
     c->dd_cnt = set.cnt; c->dd_seg = set.seg; c->dd_info = set.info;
-    if (c->dd_async && set.used_seq) {
-      // The set was last read by the step with sequence number used_seq.  The step's stream runs its kernels in order, so
-      // once a kernel of ANY later step has stamped its number, every kernel of that step has finished.  The host waits
-      // for that stamp (normally long there: it bounds how far the host runs ahead to kDdSets - 1 steps) -- an event
-      // recorded per step for the same purpose cost ~6 us of stream time each (a queue barrier packet between two kernels).
-      // In steady state this wait is what paces the host, so the grouping it queues next starts right at the stamp and
-      // shares the chip with the kernel that wrote it.  Two stamps exist: the forward GEMM's (word 0, written as it starts)
-      // and the score kernel's (word 1, i.e. "the forward GEMM has finished").  A/B on one box, 4 x 4000 steps each
-      // (profiles/r02_step_ablations.txt): released by the forward GEMM the grouping costs that GEMM 5-6 us (0.085 against
-      // 0.080 ms alone: one persistent workgroup per CU, and a CU that also hosts grouping workgroups finishes late) and the
-      // step takes 0.2305 ms; released by the score kernel it costs the score and segment kernels 4.5 + 2 us and the step
-      // takes 0.2337 ms.  Released after the segment kernel or later it runs into the weight-gradient GEMM, is starved there
-      // (80 us instead of 33) and the next step waits for it (0.239-0.253 ms).  Default: the forward GEMM's stamp -- the
-      // faster step, at the price of a forward-GEMM duration (and roofline fraction) that includes the co-running kernels.
-      // VV_DEDUP_GATE=1 selects the other.
-      static const int gate_word = getenv("VV_DEDUP_GATE") ? (atoi(getenv("VV_DEDUP_GATE")) != 0) : 0;
-      for (unsigned spins = 0; (int32_t)(__atomic_load_n(c->seq_host + gate_word, __ATOMIC_ACQUIRE) - set.used_seq) <= 0; ++spins) {
-        if (spins > 4096) { timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
-        if (hipStreamQuery(s) == hipSuccess) break;             // nothing queued any more: every earlier step is done
-      }
-    }
-    set.used_seq = seq;
-    DedupArgs da;
-    da.idx = didx; da.rows = c->dd_rows; da.u_host = c->U_host_dev; da.key = c->dd_key; da.agg = c->dd_agg; da.agg_stride = c->dd_agg_stride;
-    da.slot_of = c->dd_slot_of; da.uniq_rows = c->dd_uniq; da.map = c->dd_map; da.ord = c->dd_ord; da.cnt = c->dd_cnt;
-    da.seg_start = c->dd_seg; da.pos = c->dd_pos; da.info = c->dd_info; da.tickets = c->dd_info + 2;
-    {
-      // placement of the grouping workgroups beside the forward GEMM (kernels_dedup.hip): only when that GEMM -- sized for
-      // the previous step's distinct-row count, as launch_fwd_gemm will size it -- leaves at least 24 CUs idle
-      static const int lds_kb = getenv("VV_DEDUP_LDS_KB") ? atoi(getenv("VV_DEDUP_LDS_KB")) : -1;
-      const int hint = *(volatile int32_t*)c->U_host;
-      const long tiles = fwd_gemm_plan(c->R, hint, D, nullptr);
-      da.lds_bytes = lds_kb >= 0 ? lds_kb * 1024 : (c->dd_async && gemm_variant() == 5 && hint > 0 && tiles <= c->n_cu - 16 ? 36 * 1024 : 0);
-    }
-    da.R = c->R; da.Rp = c->Rp; da.zero_row = (int32_t)c->n_rows; da.row_limit = (int32_t)row_limit; da.epoch = c->dd_epoch;
-    PROFILED(c, "dedup", (launch_dedup(da, ds), launch_dedup_groups(da, ds)));
     if (c->dd_async) {
-      HIPCHK(hipEventRecord(set.done, ds));
       // The grouping takes ~30 us on an idle second stream and the host is normally several steps ahead of the GPU: it
       // can afford to watch the event for a moment.  Once the event has fired nothing needs to be put into the step's
       // stream at all (a wait packet in front of the forward GEMM costs ~6 us of stream time even when already satisfied);
       // otherwise the stream waits as usual.
-      bool fired = false;
-      // (an idle step stream -- the first step after a synchronisation -- means the grouping just queued cannot have run yet:
+      bool fired = hipEventQuery(set.done) == hipSuccess;
+      // (an idle step stream -- the first step after a synchronisation -- means a grouping just queued cannot have run yet:
       // watching it would hold the host for its whole 40 us while the GPU then waits for the step's launches; queue the wait)
-      if (c->dd_spin_us > 0 && hipStreamQuery(s) != hipSuccess) {
+      if (!fired && c->dd_spin_us > 0 && hipStreamQuery(s) != hipSuccess) {
         const double t0 = host_now_ms();
         do { fired = hipEventQuery(set.done) == hipSuccess; } while (!fired && (host_now_ms() - t0) * 1e3 < c->dd_spin_us);
       }
@@ -886,8 +902,8 @@ int vv_forward_backward_ring(vv_ctx* c, const vv_step_cfg* cfg, vv_batch_ring* r
                 rb, rcn, item_begin, item_begin + cfg->B, cfg->C + cfg->Nn);
   HIPCHK(hipSetDevice(c->device));
   const size_t bytes = (size_t)cfg->B * rcn * sizeof(int32_t);
-  const double t0 = g_trace_host_ms >= 0 ? host_now_ms() : 0.0;
   int sl = 0;
+  const double t0 = g_trace_host_ms >= 0 ? host_now_ms() : 0.0;
   if ((rc = stage_acquire(c, bytes, &sl))) return rc;
   const double t1 = g_trace_host_ms >= 0 ? host_now_ms() : 0.0;
   if (vv_batch_ring_next(ring, consumer, item_begin, cfg->B, c->stage_host[sl], label_out, timeout_s))
@@ -899,6 +915,9 @@ int vv_forward_backward_ring(vv_ctx* c, const vv_step_cfg* cfg, vv_batch_ring* r
   }
   const int32_t seq = ++c->step_seq;
   c->stage_seq[sl] = seq;
+  // (Issuing the grouping of the NEXT batch from here, a whole step ahead, was built and measured: 0.2345 against 0.2334 ms
+  // per step over 20-step timed regions, two runs each -- the host is ahead of the GPU anyway, and the first step after a
+  // synchronisation does not wait for its grouping in any noticeable way.  Taken out again.)
   return fb_impl(c, cfg, c->stage_dev[sl], 2, c->n_rows, seq);
 }
 
