@@ -143,11 +143,6 @@ int vv_forward_backward(vv_ctx* ctx, const vv_step_cfg* cfg, const int32_t* idx,
  * is copied WITHOUT its last feature (video_sampled_shots_data_layer.cpp:492), so that element of
  * the slot keeps what the previous batch left there.  last_src: int32 [B][C+Nn] = the table row
  * whose LAST feature each slot holds (-1 = zero), as vv_sampler_next reports it; both host arrays. */
-/* vv_forward_backward_ring (declared with the sampler's prefetch ring below) takes the next batch out of a ring; with
- * look-ahead (default on; VV_LOOKAHEAD=0) it also takes the batch AFTER that one when it is already complete, stages it
- * and issues its index grouping a step ahead -- that batch is then what the next call runs on.  Indices, order and results
- * are unchanged; only a caller that changes ring, slice or batch shape between two calls must switch it off first. */
-int vv_set_lookahead(vv_ctx* ctx, int on);
 int vv_forward_backward_q1(vv_ctx* ctx, const vv_step_cfg* cfg, const int32_t* idx,
                            const int32_t* last_src);
 /* SGDSolver::ComputeUpdateValue + Net::Update (solver.cpp:485-531, net.cpp:803-839,
@@ -354,8 +349,6 @@ int vv_batch_ring_attach(const char* shm_name, double timeout_s, vv_batch_ring**
 int vv_batch_ring_info(vv_batch_ring* r, int32_t* batch_size, int32_t* slots_per_item, int32_t* consumers, int32_t* depth);
 int vv_batch_ring_next(vv_batch_ring* r, int32_t consumer, int32_t item_begin, int32_t item_count, int32_t* idx,
                        int32_t* label, double timeout_s);
-/* 1 when the consumer's next batch is complete (vv_batch_ring_next would not wait), else 0. */
-int vv_batch_ring_ready(vv_batch_ring* ring, int32_t consumer);
 int vv_batch_ring_detach(vv_batch_ring* r);
 /* BasePrefetchingDataLayer::Forward_gpu (src/caffe/layers/base_data_layer.cu:7-21: join the prefetch thread, copy the
  * batch to the device) + Net::ForwardBackward: take this consumer's next batch out of the ring -- items

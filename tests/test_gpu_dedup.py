@@ -321,45 +321,3 @@ def test_guard_long_run_on_the_benchmark_stream():
         " ".join("%.1e" % e for e in errs), repeats, sorted(scales)))
     assert repeats == 0 and max(errs) <= 2e-3
     smp.close(); eng.close(); dense.close()
-
-
-def test_ring_lookahead_changes_nothing_but_the_timing():
-    """vv_forward_backward_ring takes the NEXT batch out of the ring as soon as it is complete, stages it and issues its
-    index grouping a step ahead (videovec.h: vv_set_lookahead).  Same batches in the same order, the same parameters bit
-    for bit -- also with loss read-backs, steps on explicit indices and parameter read-backs between ring steps (the held
-    batch keeps its staging slot and its grouping set)."""
-    import videovector_amd as vv
-    from videovector_amd.synth import SyntheticVideos, init_weights
-    B, C, Nn, F, D = 256, 5, 20, 512, 512
-    ds = SyntheticVideos(seed=31, n_videos=400)
-    kw = dict(batch_size=B, context_size=C, num_negative_samples=Nn, max_buffer_size=2000, negative_swap_percentage=50)
-    W, b = init_weights(31, D, F, std=0.02)
-    extra = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, **dict(kw, rand_seed=7)).next()       # a batch from elsewhere
-    outs = []
-    for la in (True, False):
-        smp = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, **kw)
-        smp.prefetch_start(depth=8, threads=4)
-        ring = smp.ring()
-        eng = vv.Engine(0, "f16")
-        eng.set_lookahead(la)
-        eng.table_synth(ds.seed, ds.n_rows, F); eng.params_set(W, b)
-        cfg = vv.StepConfig(B, C, Nn, lr=0.02)
-        losses, labels = [], []
-        lab = np.zeros(B, np.int32)
-        for it in range(30):
-            eng.forward_backward_ring(cfg, ring, label_out=lab)
-            eng.apply_update(cfg)
-            labels.append(lab.copy())
-            if it % 7 == 3:
-                losses.append(eng.loss())                       # a synchronisation between two ring steps
-            if it % 11 == 5:
-                eng.step(cfg, extra)                            # a step on explicit indices in between (uses the other sets / slots)
-                losses.append(eng.loss())
-            if it == 20:
-                eng.params_get()
-        outs.append((eng.params_get(), losses, np.stack(labels), eng.dedup_stats()))
-        eng.close(); smp.close()
-    (pa, la_, ya, sa), (pb, lb, yb, sb) = outs
-    assert la_ == lb and np.array_equal(ya, yb) and sa == sb
-    for x, y in zip(pa, pb):
-        assert np.array_equal(x, y)

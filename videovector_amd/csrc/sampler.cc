@@ -1166,11 +1166,6 @@ int vv_batch_ring_next(vv_batch_ring* r, int32_t consumer, int32_t item_begin, i
   return pop_batch(r, consumer, item_begin, item_count, idx, nullptr, label, timeout_s);
 }
 
-int vv_batch_ring_ready(vv_batch_ring* r, int32_t consumer) {
-  if (!r || consumer < 0 || consumer >= r->hdr->consumers) return 0;
-  return r->ready(r->next_k[consumer]) ? 1 : 0;
-}
-
 int vv_batch_ring_detach(vv_batch_ring* r) {
   if (!r) return VV_OK;
   if (r->owner) return VV_ERR_ARG;            // the sampler owns its ring (vv_sampler_prefetch_stop)

@@ -116,12 +116,6 @@ struct vv_ctx {
   int32_t* seq_host_dev = nullptr;          //   number here when it starts, i.e. "the kernels that read this step's index
                                             //   batch have finished"; [1]: the score kernel does when IT starts, i.e. "this
                                             //   step's forward GEMM has finished" (the gate of the asynchronous grouping)
-  // look-ahead of vv_forward_backward_ring: the NEXT batch already staged and its grouping already issued
-  struct LookAhead {
-    bool valid = false; vv_batch_ring* ring = nullptr; int32_t consumer = 0, item_begin = 0, B = 0, CN = 0;
-    int slot = 0, set = 0; int32_t seq = 0; std::vector<int32_t> labels;
-  } la;
-  bool la_enabled = true;           // env VV_LOOKAHEAD=0: off
   // data-parallel gradient exchange (comm.hip)
   vv::Comm* comm = nullptr;
   bool comm_overlap = false;        // the update runs F-chunk by F-chunk on the communication stream (all-reduce, SGD, publish) and

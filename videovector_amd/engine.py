@@ -70,7 +70,7 @@ def load_library():
         "vv_forward_backward": [vp, vp, vp, C.c_int], "vv_apply_update": [vp, vp],
         "vv_forward_backward_q1": [vp, vp, vp, vp],
         "vv_step": [vp, vp, vp, C.c_int],
-        "vv_forward_backward_ring": [vp, vp, vp, i32, i32, vp, C.c_double], "vv_set_lookahead": [vp, C.c_int],
+        "vv_forward_backward_ring": [vp, vp, vp, i32, i32, vp, C.c_double],
         "vv_dev_alloc": [vp, C.c_size_t, C.POINTER(vp)], "vv_dev_free": [vp, vp],
         "vv_dev_upload": [vp, vp, vp, C.c_size_t], "vv_dev_download": [vp, vp, vp, C.c_size_t],
         "vv_dev_memset": [vp, vp, C.c_int, C.c_size_t],
@@ -248,10 +248,6 @@ class Engine:
         """Next batch of the sampler's prefetch ring -> pinned staging -> async H2D -> forward/backward."""
         self._chk(self.L.vv_forward_backward_ring(self.h, C.byref(cfg.c), ring.h, consumer, item_begin, _ptr(label_out),
                                                   float(timeout_s)))
-
-    def set_lookahead(self, on):
-        """forward_backward_ring also takes, stages and groups the batch AFTER the one it runs on (videovec.h)."""
-        self._chk(self.L.vv_set_lookahead(self.h, int(bool(on))))
 
     # ---- per-layer operators (vv_dev_* / vv_op_*): device buffers are DevBuf objects
     def dev(self, array_or_shape):
