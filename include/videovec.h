@@ -174,7 +174,7 @@ int vv_grads_bind(vv_ctx* ctx, void* dev_ptr);
  *   vv_allreduce_grads  sums [dW | db] over the ranks on the context's communication stream and makes the compute stream
  *                     wait for it (the host does not block with RCCL).  vv_apply_update calls it when the caller has not.
  *   vv_comm_overlap   on: exact synchronous SGD with the exchange hidden behind the NEXT step's forward pass.  The gradient
- *                     buffer is laid out chunk-major (four column blocks of dW, each one contiguous message; vv_grads_get
+ *                     buffer is laid out chunk-major (a few column blocks of dW, each one contiguous message; vv_grads_get
  *                     still returns the blob's row-major D x F); vv_apply_update queues, per chunk, all-reduce -> SGD on the
  *                     chunk's columns -> publish on the communication stream and returns; the next vv_forward_backward starts
  *                     its forward GEMM at once, and the kernel waits for each chunk of W where its K loop reaches it

@@ -44,5 +44,6 @@ if __name__ == "__main__":
     else:
         steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
         for rep in range(2):
-            for mode, env in (("none", {}), ("sync", {}), ("overlap", {}), ("overlap_skip_ar", {"VV_COMM_SKIP_AR1": "1"}), ("overlap", {"VV_COMM_TEST_DELAY_US": "20"}), ("overlap_nogate", {"VV_COMM_GATE": "0"})):
+            for mode, env in (("none", {}), ("sync", {}), ("overlap", {}), ("overlap_chunks2", {"VV_COMM_CHUNKS": "2"}), ("overlap_chunks4", {"VV_COMM_CHUNKS": "4"}),
+                              ("overlap", {"VV_COMM_TEST_DELAY_US": "20"}), ("overlap_chunks2", {"VV_COMM_CHUNKS": "2", "VV_COMM_TEST_DELAY_US": "30"}), ("overlap_nogate", {"VV_COMM_GATE": "0"})):
                 subprocess.run([sys.executable, os.path.abspath(__file__), mode, str(steps)], env=dict(os.environ, **env))

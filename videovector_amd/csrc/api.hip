@@ -160,9 +160,10 @@ static int create_init(vv_ctx* c) {
   HIPCHK(hipHostMalloc((void**)&c->U_host, 2 * sizeof(int32_t), hipHostMallocMapped));   // {U, saturated f16 gradient sums}
   c->U_host[0] = c->U_host[1] = 0;
   HIPCHK(hipHostGetDevicePointer((void**)&c->U_host_dev, c->U_host, 0));
-  HIPCHK(hipMalloc(&c->w_gate, (W_CHUNKS + 1) * W_GATE_STRIDE * sizeof(int32_t)));
-  HIPCHK(hipMemset(c->w_gate, 0, (W_CHUNKS + 1) * W_GATE_STRIDE * sizeof(int32_t)));
-  c->pub_count = c->w_gate + W_CHUNKS * W_GATE_STRIDE;          // the arrival counter of the publishing kernels: a line of its own
+  HIPCHK(hipMalloc(&c->w_gate, (W_CHUNKS_MAX + 1) * W_GATE_STRIDE * sizeof(int32_t)));
+  HIPCHK(hipMemset(c->w_gate, 0, (W_CHUNKS_MAX + 1) * W_GATE_STRIDE * sizeof(int32_t)));
+  c->pub_count = c->w_gate + W_CHUNKS_MAX * W_GATE_STRIDE;      // the arrival counter of the publishing kernels: a line of its own
+  { const char* nc = getenv("VV_COMM_CHUNKS"); if (nc) c->n_chunks = std::max(1, std::min(W_CHUNKS_MAX, atoi(nc))); }
   HIPCHK(hipEventCreateWithFlags(&c->ev_chunk0, hipEventDisableTiming));
   HIPCHK(hipHostMalloc((void**)&c->gate_err, sizeof(int32_t), hipHostMallocMapped));
   *c->gate_err = 0;
@@ -554,6 +555,32 @@ static void flush_scale_update(vv_ctx* c) {
   c->scale_pending = false;
 }
 
+// F-chunks of the overlapped update: n column blocks of W whose widths fall off geometrically (ratio 0.6: e.g. 51 / 31 / 18 %
+// of F for three).  The exchange is slower than the forward GEMM consumes W, so the GEMM always ends up waiting for the
+// LAST chunk and then still has that chunk's K-tiles to run: a small last chunk shortens that tail, a large first chunk
+// keeps the number of collectives (each with its launch latency) down.  Boundaries are even K-tiles (the gate sits in
+// front of phase 3 of an even K-tile), at least 4 apart; fills c->chunk_kt[0 .. n], returns n (1 when F is too short).
+static int chunk_plan(vv_ctx* c) {
+  const int nk = c->Fp / BK;
+  int n = std::max(1, std::min(c->n_chunks, nk / 8));
+  for (;;) {
+    double den = 0, r = 1;
+    for (int i = 0; i < n; ++i) { den += r; r *= 0.6; }
+    c->chunk_kt[0] = 0;
+    double acc = 0; r = 1;
+    bool ok = true;
+    for (int i = 1; i < n; ++i) {
+      acc += r; r *= 0.6;
+      int kt = (int)(nk * acc / den + 0.5) & ~1;
+      if (kt < c->chunk_kt[i - 1] + 4 || kt > nk - 4) ok = false;
+      c->chunk_kt[i] = kt;
+    }
+    c->chunk_kt[n] = nk;
+    if (ok || n == 1) return n;
+    --n;
+  }
+}
+
 // Joins the communication stream: after this, everything the library queued there -- the F-chunks of an overlapped
 // update: all-reduce, SGD, publish -- is ordered before whatever the compute stream is given next.  Every entry point
 // that reads or writes the parameters, their half copy, the momentum or the gradient buffer goes through here first;
@@ -740,6 +767,8 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
     static const bool no_gate = getenv("VV_COMM_GATE") && atoi(getenv("VV_COMM_GATE")) == 0;
     if (!no_gate && gemm_variant() == 5 && !ablate_on() && fwd_gemm_can_gate(fa) && (!dd || fa.R_hint > 0) && tiles <= c->n_cu - 16) {
       fa.gate = c->w_gate; fa.gate_seq = c->upd_seq; fa.gate_err = c->gate_err_dev;
+      fa.gate_n = chunk_plan(c);
+      for (int i = 0; i <= fa.gate_n; ++i) fa.gate_kt[i] = c->chunk_kt[i];
       c->upd_inflight = false;              // whatever follows the forward GEMM on this stream follows the whole update
     } else if ((rc = comm_join(c))) return rc;
   }
@@ -848,22 +877,25 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   ra.ip_scale = cfg->ip_regularization > 0.f ? 1.f + cfg->ip_regularization * 0.5f : 1.f;     // inner_product_layer.cpp:80-90
   ra.loss_part = c->loss_part; ra.viol_part = c->viol_part; ra.loss_scale = cfg->loss_weight / (float)count; ra.loss_out = c->loss2;
 
-  // Data-parallel overlap: the gradient buffer is laid out chunk-major (W_CHUNKS column blocks, each one contiguous
+  // Data-parallel overlap: the gradient buffer is laid out chunk-major (a few column blocks, each one contiguous
   // all-reduce message) and vv_apply_update runs the update chunk by chunk on the communication stream.
   const bool chunked = c->comm && c->comm_overlap && c->F % 4 == 0 && c->grads == c->grads_own;
-  if (chunked) ra.chunk_cols = c->Fp / W_CHUNKS;
+  if (chunked) {
+    ra.n_chunks = chunk_plan(c);
+    for (int i = 0; i <= ra.n_chunks; ++i) ra.chunk_c0[i] = std::min(c->F, c->chunk_kt[i] * BK);
+  }
   // the W -> half scale update the previous vv_apply_update left pending rides in this step's reduction launch
   if (c->scale_pending) { ra.scale_sc = c->scales; ra.scale_wmax = c->wmax_blocks; ra.scale_prec = c->prec; c->scale_pending = false; }
   PROFILED(c, "wgrad_gemm", launch_wgrad_gemm(c->prec, wa, s));
-  if (chunked && c->Fp / W_CHUNKS < c->F) {
+  if (chunked && ra.n_chunks > 1 && ra.chunk_c0[1] < c->F) {
     // the first F-chunk is reduced by a launch of its own and an event marks it: the communication stream starts on
     // chunk 0 (all-reduce, SGD) while the other chunks, db and the loss are still being reduced here
     ReduceArgs r0 = ra;
-    r0.f_begin = 0; r0.f_count = c->Fp / W_CHUNKS; r0.parts = 1; r0.gmax_host = nullptr;
+    r0.f_begin = 0; r0.f_count = ra.chunk_c0[1]; r0.parts = 1; r0.gmax_host = nullptr;
     PROFILED(c, "reduce", launch_reduce(r0, s));
     HIPCHK(hipEventRecord(c->ev_chunk0, s));
     ra.scale_sc = nullptr;
-    ra.f_begin = c->Fp / W_CHUNKS; ra.f_count = c->F - ra.f_begin;
+    ra.f_begin = ra.chunk_c0[1]; ra.f_count = c->F - ra.f_begin;
     launch_reduce(ra, s);
     c->chunk0_event = true;
   } else {
@@ -988,13 +1020,13 @@ int vv_apply_update(vv_ctx* c, const vv_step_cfg* cfg) {
     hipStream_t cs = vv::comm_stream(c->comm);
     HIPCHK(hipEventRecord(c->ev_chunk, c->stream));
     const int32_t useq = ++c->upd_seq;
-    const int cc = c->Fp / W_CHUNKS;
+    const int nch = chunk_plan(c);               // (the layout k_reduce wrote: same Fp, same plan)
     a.pub_count = c->pub_count; a.pub_seq = useq;
-    for (int k = 0; k < W_CHUNKS; ++k) {
+    for (int k = 0; k < nch; ++k) {
       // chunk 0 may start as soon as ITS reduction is done (ev_chunk0, fb_impl); the others follow the whole backward pass
       hipEvent_t after = k == 0 ? (c->chunk0_event ? c->ev_chunk0 : c->ev_chunk) : (k == 1 && c->chunk0_event ? c->ev_chunk : nullptr);
-      const int c0 = std::min(c->F, k * cc), c1 = std::min(c->F, (k + 1) * cc);
-      const bool last = k == W_CHUNKS - 1;
+      const int c0 = std::min(c->F, c->chunk_kt[k] * BK), c1 = std::min(c->F, c->chunk_kt[k + 1] * BK);
+      const bool last = k == nch - 1;
       const size_t off = (size_t)c->D * c0, n = (size_t)c->D * (c1 - c0) + (last ? (size_t)c->D : 0);
       static const int delay_us = getenv("VV_COMM_TEST_DELAY_US") ? atoi(getenv("VV_COMM_TEST_DELAY_US")) : 0;
       if (after) HIPCHK(hipStreamWaitEvent(cs, after, 0));
@@ -1002,7 +1034,8 @@ int vv_apply_update(vv_ctx* c, const vv_step_cfg* cfg) {
       static const bool skip_ar1 = getenv("VV_COMM_SKIP_AR1") && atoi(getenv("VV_COMM_SKIP_AR1")) != 0;   // diagnosis: no collective call at world 1
       if (!(skip_ar1 && vv::comm_world(c->comm) == 1) && n > 0 && vv::comm_allreduce(c->comm, c->grads, off, n, nullptr))
         return fail(VV_ERR_HIP, "all-reduce: %s", vv::comm_error(c->comm));
-      a.chunked = 1; a.f_begin = c0; a.f_count = c1 - c0; a.blk_off = k * (SGD_BLOCKS / W_CHUNKS); a.do_bias = last; a.set_scale = k == 0;
+      a.chunked = 1; a.f_begin = c0; a.f_count = c1 - c0; a.do_bias = last; a.set_scale = k == 0;
+      a.blk_off = k * (SGD_BLOCKS / nch); a.n_blk = last ? SGD_BLOCKS - a.blk_off : SGD_BLOCKS / nch;      // together: every slot of wmax_blocks
       a.pub_flag = c->w_gate + k * W_GATE_STRIDE;          // the kernel's last workgroup publishes the chunk (SgdArgs::pub_flag)
       if (k == 0) PROFILED(c, "sgd", launch_sgd(c->prec, a, cs)); else launch_sgd(c->prec, a, cs);     // (an empty chunk: its wmax slots become 0, the bias if it is the last)
     }
@@ -1064,12 +1097,12 @@ int vv_grads_get(vv_ctx* c, float* dW, float* db) {
   HIPCHK(hipStreamSynchronize(c->stream));
   const size_t nW = (size_t)c->D * c->F;
   if (dW && !c->grads_chunked) HIPCHK(hipMemcpy(dW, c->grads, nW * 4, hipMemcpyDeviceToHost));
-  if (dW && c->grads_chunked) {        // chunk-major buffer (ReduceArgs::chunk_cols) -> the blob's row-major D x F
+  if (dW && c->grads_chunked) {        // chunk-major buffer (ReduceArgs::n_chunks) -> the blob's row-major D x F
     std::vector<float> tmp(nW);
     HIPCHK(hipMemcpy(tmp.data(), c->grads, nW * 4, hipMemcpyDeviceToHost));
-    const int cc = c->Fp / W_CHUNKS;
-    for (int k = 0; k < W_CHUNKS; ++k) {
-      const int c0 = std::min(c->F, k * cc), c1 = std::min(c->F, (k + 1) * cc);
+    const int nch = chunk_plan(c);
+    for (int k = 0; k < nch; ++k) {
+      const int c0 = std::min(c->F, c->chunk_kt[k] * BK), c1 = std::min(c->F, c->chunk_kt[k + 1] * BK);
       for (int d = 0; d < c->D && c1 > c0; ++d)
         memcpy(dW + (size_t)d * c->F + c0, tmp.data() + (size_t)c->D * c0 + (size_t)d * (c1 - c0), (size_t)(c1 - c0) * 4);
     }

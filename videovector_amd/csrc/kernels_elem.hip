@@ -1164,8 +1164,10 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
         s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
       }
       int64_t o = (int64_t)d * a.F + f;
-      if (a.chunk_cols > 0) {          // chunk-major (vv_internal.h: ReduceArgs::chunk_cols); chunk_cols % 4 == 0
-        const int cc = f / a.chunk_cols, c0 = min(a.F, cc * a.chunk_cols), c1 = min(a.F, (cc + 1) * a.chunk_cols);
+      if (a.n_chunks > 0) {            // chunk-major (vv_internal.h: ReduceArgs::n_chunks)
+        int cc = 0;
+        while (cc + 1 < a.n_chunks && f >= a.chunk_c0[cc + 1]) ++cc;
+        const int c0 = a.chunk_c0[cc], c1 = a.chunk_c0[cc + 1];
         o = (int64_t)a.D * c0 + (int64_t)d * (c1 - c0) + (f - c0);
       }
       *(float4*)(a.grads + o) = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
@@ -1283,7 +1285,7 @@ void launch_delay(int us, hipStream_t s) { hipLaunchKernelGGL(k_delay, dim3(1), 
 void launch_publish(int32_t* flag, int32_t seq, hipStream_t s) { hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, s, flag, seq); }
 void launch_sgd(int prec, const SgdArgs& a, hipStream_t s) {
   const bool vec = a.F % 4 == 0;
-  const dim3 grid(a.chunked ? SGD_BLOCKS / W_CHUNKS : SGD_BLOCKS), block(256);
+  const dim3 grid(a.chunked ? a.n_blk : SGD_BLOCKS), block(256);
   if (prec == 0) { if (vec) VV_LAUNCH((k_sgd<F16, true>), grid, block, 0, s, a); else VV_LAUNCH((k_sgd<F16, false>), grid, block, 0, s, a); }
   else { if (vec) VV_LAUNCH((k_sgd<BF16, true>), grid, block, 0, s, a); else VV_LAUNCH((k_sgd<BF16, false>), grid, block, 0, s, a); }
 }

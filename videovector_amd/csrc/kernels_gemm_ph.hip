@@ -134,8 +134,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
 #define PH_WAITQ() PH_WAIT(8)                  /* everything but the four youngest half-tiles has landed */
 
   // chunk gates (GATE only)
-  const int kpc = nk / W_CHUNKS;               // K-tiles per W chunk
   bool gated = false;
+  int g_next = 1;                              // the next chunk whose gate lies inside the K loop
   auto gate_wait = [&](int chunk) {
     if (wave == 0) {
       unsigned spins = 0;
@@ -157,16 +157,17 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
     if (tid == 0) {
       int behind = 0;
 #pragma unroll
-      for (int cch = 0; cch < W_CHUNKS; ++cch)
-        behind |= (int32_t)(__hip_atomic_load(a.gate + cch * W_GATE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.gate_seq) < 0;
+      for (int cch = 0; cch < W_CHUNKS_MAX; ++cch)
+        if (cch < a.gate_n) behind |= (int32_t)(__hip_atomic_load(a.gate + cch * W_GATE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.gate_seq) < 0;
       s_behind = behind;
     }
     __syncthreads();
     gated = s_behind != 0;
     if (gated) {
-      if (kpc >= 4) gate_wait(0);
-      else for (int cch = 0; cch < W_CHUNKS; ++cch) gate_wait(cch);     // tiny K: the prologue already spans chunks
-      if (kpc < 4) gated = false;
+      // chunk 0 in front of the prologue; with it every chunk that starts before K-tile 4 (the prologue's loads reach K-tile 1)
+      gate_wait(0);
+      while (g_next < a.gate_n && a.gate_kt[g_next] < 4) { gate_wait(g_next); ++g_next; }
+      if (g_next >= a.gate_n) gated = false;
     } else if (wave == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the flags were read after the kernel began: order the W loads behind them
   }
 
@@ -224,7 +225,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
     PH_LOAD_A(0) PH_LOAD_B(b0, 1) PH_STREAM(0, t, 0, true) PH_MFMA(0, 0, b0)
     PH_LOAD_B(b1, 2) PH_STREAM(0, t, 1, true) PH_MFMA(0, 1, b1)
     PH_LOAD_A(3) PH_STREAM(0, t, 2, false) PH_MFMA(1, 1, b1)
-    if (GATE && gated && (t + 2) % kpc == 0 && t + 2 < nk) gate_wait((t + 2) / kpc);     // B_lo(t + 2) opens a chunk
+    if (GATE && gated && t + 2 == a.gate_kt[g_next]) {                   // B_lo(t + 2) opens a chunk
+      gate_wait(g_next);
+      if (++g_next >= a.gate_n) gated = false;
+    }
     PH_STREAM(0, t, 3, true) PH_MFMA(1, 0, b0)
     // ---- K-tile t + 1 (odd): slots 4..7
     PH_LOAD_A(4) PH_LOAD_B(b0, 5) PH_STREAM(1, t + 1, 0, true) PH_MFMA(0, 0, b0)

@@ -121,10 +121,12 @@ struct vv_ctx {
   bool comm_overlap = false;        // the update runs F-chunk by F-chunk on the communication stream (all-reduce, SGD, publish) and
                                     // the NEXT step's forward GEMM waits per chunk inside the kernel (FwdArgs::gate)
   bool grads_pending = false;       // a backward pass has produced gradients that have not been all-reduced yet
-  bool grads_chunked = false;       // the gradient buffer of the last backward pass is laid out chunk-major (ReduceArgs::chunk_cols)
+  bool grads_chunked = false;       // the gradient buffer of the last backward pass is laid out chunk-major (ReduceArgs::n_chunks)
   bool upd_inflight = false;        // an overlapped update is on the communication stream and the compute stream has not joined it
   int32_t upd_seq = 0;              // sequence number of the last overlapped update (what w_gate[c] reaches when chunk c is done)
-  int32_t* w_gate = nullptr;        // device [W_CHUNKS * W_GATE_STRIDE]: one flag per 128-B line
+  int32_t* w_gate = nullptr;        // device [W_CHUNKS_MAX * W_GATE_STRIDE]: one flag per 128-B line
+  int n_chunks = 3;                 // F-chunks of the overlapped update (env VV_COMM_CHUNKS, 1 .. 4)
+  int chunk_kt[5] = {0, 0, 0, 0, 0};    // first K-tile of each chunk for the current Fp (chunk_plan)
   int32_t* pub_count = nullptr;     // device: arrival counter of the publishing SGD kernels (behind the flags)
   hipEvent_t ev_chunk0 = nullptr; bool chunk0_event = false;     // the first F-chunk's reduction is done (recorded by fb_impl)
   int32_t* gate_err = nullptr; int32_t* gate_err_dev = nullptr;     // pinned + mapped: a gated forward gave up waiting

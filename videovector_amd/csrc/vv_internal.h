@@ -86,14 +86,16 @@ struct FwdArgs {
   int abl = 0;                 // timing studies only (VV_ABLATE): selects an ablated instantiation of the phase-staggered kernel
   // Data-parallel overlap (api.hip: vv_apply_update): the parameter update of the PREVIOUS step may still be arriving --
   // F-chunk by F-chunk, each chunk all-reduced and applied on the communication stream -- while this kernel runs.
-  // gate[c * W_GATE_STRIDE] holds the sequence number of the last update whose chunk c (K-tiles [c nk/4, (c+1) nk/4) of W)
-  // is complete; a workgroup waits for it to reach gate_seq before it issues its first load of a W tile of chunk c.
+  // gate[c * W_GATE_STRIDE] holds the sequence number of the last update whose chunk c (K-tiles [gate_kt[c], gate_kt[c+1])
+  // of W) is complete; a workgroup waits for it to reach gate_seq before it issues its first load of a W tile of chunk c.
   // null = no gating.
   const int32_t* gate = nullptr;
   int32_t gate_seq = 0;
+  int gate_n = 0;              // chunks (1 .. W_CHUNKS_MAX)
+  int gate_kt[5] = {0, 0, 0, 0, 0};   // first K-tile of each chunk (even; gate_kt[0] = 0, gate_kt[gate_n] = all K-tiles)
   int32_t* gate_err = nullptr; // host-mapped: set when a wait gave up (bounded: a lost update must not hang the device)
 };
-constexpr int W_CHUNKS = 4;    // F-chunks of the overlapped update (chunk-major gradient buffer, api.hip)
+constexpr int W_CHUNKS_MAX = 4; // F-chunks of the overlapped update at most (chunk-major gradient buffer, api.hip: chunk_plan)
 constexpr int W_GATE_STRIDE = 32;   // ints between two chunk flags: a 128-B line each (the waiting workgroups poll them)
 
 // Segment-wise backward (de-duplicated batches): the score kernel keeps the gradient of an instance in factored form
@@ -213,9 +215,9 @@ struct ReduceArgs {
   const float* loss_part; const float* viol_part; float loss_scale; float* loss_out;
   int d_begin = 0, d_count = 0;      // rows of dW this launch reduces (d_count 0 = all D)
   int f_begin = 0, f_count = 0;      // columns of dW this launch reduces (f_count 0 = all F); multiples of 4
-  int chunk_cols = 0;                // > 0: dW is stored CHUNK-MAJOR -- W_CHUNKS column blocks of chunk_cols (padded) columns,
-                                     //   block c = all D rows of columns [c0, c1) = [min(F, c cc), min(F, (c+1) cc)) at float offset
-                                     //   D c0, row stride c1 - c0 -- so that every F-chunk is one contiguous all-reduce buffer
+  int n_chunks = 0;                  // > 0: dW is stored CHUNK-MAJOR -- n_chunks column blocks, block c = all D rows of columns
+  int chunk_c0[5] = {0, 0, 0, 0, 0}; //   [chunk_c0[c], chunk_c0[c+1]) at float offset D chunk_c0[c], row stride = the block's width
+                                     //   (boundaries multiples of 4) -- so that every F-chunk is one contiguous all-reduce buffer
   int parts = 3;                     // bit 0: the dW rows, bit 1: db and the loss scalars
   Scales* scale_sc = nullptr;        // non-null: one more workgroup performs the W -> half scale update left pending by the
   const float* scale_wmax = nullptr; //   previous step's k_sgd (its per-block max |w| slots)
@@ -234,10 +236,10 @@ struct SgdArgs {
   int solver_type;         // 0 SGD, 1 Nesterov, 2 AdaGrad
   float delta;             // AdaGrad stability constant
   // one F-chunk of the update (data-parallel overlap): columns [f_begin, f_begin + f_count) of every row, read from the
-  // chunk-major gradient buffer (ReduceArgs::chunk_cols; f_count may be 0: nothing but, possibly, the bias);
+  // chunk-major gradient buffer (ReduceArgs::n_chunks; f_count may be 0: nothing but, possibly, the bias);
   // chunked = 0: the whole matrix from the row-major buffer
   int chunked = 0, f_begin = 0, f_count = 0;
-  int blk_off = 0;         // first slot of wmax_blocks this launch writes (its grid is SGD_BLOCKS / W_CHUNKS)
+  int blk_off = 0, n_blk = 0;   // slots of wmax_blocks this launch writes = its grid (the chunks of an update share SGD_BLOCKS)
   int do_bias = 1;         // this launch also updates b (the last chunk: db is all-reduced with it)
   int set_scale = 1;       // this launch publishes the scale of the new half copy (the first chunk)
   // Publication from inside the kernel (chunked launches of the overlapped update; null = none): what the NEXT forward
