@@ -1,5 +1,5 @@
 #!/bin/bash
-# The host sampler (videovector_amd/csrc/sampler.cc) under ThreadSanitizer and under AddressSanitizer + UBSan: serial, 1-3 thread
+# The host sampler (videovector_amd/csrc/sampler.cc) under ThreadSanitizer and under AddressSanitizer + UBSan: serial, 1-4 thread
 # pipelines and the shared-memory ring with two consumers against the same stream.  CPU only.
 set -e
 cd "$(dirname "$0")/.."

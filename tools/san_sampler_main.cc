@@ -28,7 +28,7 @@ int main() {
     std::vector<std::vector<int32_t>> want(40, std::vector<int32_t>(n));
     for (auto& w : want) vv_sampler_next(ref, w.data(), nullptr, nullptr);
     vv_sampler_destroy(ref);
-    for (int threads = 1; threads <= 3; ++threads) {
+    for (int threads = 1; threads <= 4; ++threads) {
       vv_sampler* s = nullptr;
       vv_sampler_create(&p, V, vid.data(), ns.data(), rb.data(), nullptr, &s);
       vv_sampler_prefetch_start(s, 3, threads, nullptr, 1);
@@ -41,7 +41,7 @@ int main() {
       char name[64]; snprintf(name, sizeof name, "vv_san_%d_%d_%d", (int)getpid(), ct, same);
       vv_sampler* s = nullptr;
       vv_sampler_create(&p, V, vid.data(), ns.data(), rb.data(), nullptr, &s);
-      vv_sampler_prefetch_start(s, 4, 3, name, 2);
+      vv_sampler_prefetch_start(s, 4, 4, name, 2);
       int bad[2] = {0, 0};
       auto consumer = [&](int c) {
         vv_batch_ring* r = nullptr;
