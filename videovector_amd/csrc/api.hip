@@ -17,7 +17,7 @@
 
 #include "vv_ctx.h"
 
-namespace vv { void set_wgrad_tr(bool on); void set_gemm_variant(int v); void set_ablate(int v); void set_score_reg(int v); void set_score_waves(int v); void set_ph_mq(int v); void set_score_stream(int v); int gemm_variant(); bool ablate_on(); }
+namespace vv { void set_fwd_ring10(bool on); void set_wgrad_tr(bool on); void set_gemm_variant(int v); void set_ablate(int v); void set_score_reg(int v); void set_score_waves(int v); void set_ph_mq(int v); void set_score_stream(int v); int gemm_variant(); bool ablate_on(); }
 using namespace vv;
 
 thread_local char vv_g_err[512] = "";
@@ -136,6 +136,7 @@ static int create_init(vv_ctx* c) {
   set_score_waves(sw ? atoi(sw) : 8);
   const char* sst = getenv("VV_SCORE_STREAM");
   set_score_stream(sst ? atoi(sst) : 0);
+  set_fwd_ring10(getenv("VV_FWD_RING10") && atoi(getenv("VV_FWD_RING10")) != 0);
   const char* pq = getenv("VV_PH_MQ");
   set_ph_mq(pq ? atoi(pq) : 0);
   const char* th = getenv("VV_TRACE_HOST");

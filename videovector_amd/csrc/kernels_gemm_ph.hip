@@ -289,6 +289,136 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------- forward, ten-slot ring (experiment) ----
+// The same kernel with the WHOLE LDS as its ring: ten slots of 16 KiB, half-tiles issued EIGHT ahead of their use (two full
+// K-tiles), counted wait vmcnt(12): six half-tiles (96 KiB per CU) stay in flight across every barrier instead of four.
+// The ablations say the kernel sits on its LDS-DMA stream; if that stream is latency-bound (bytes in flight / round trip),
+// half as many bytes again in flight should show.  Slots are runtime values here (half-tile h lives in slot h mod 10: the
+// pattern repeats every five K-tiles, the loop is unrolled by two).  VV_GEMM_VARIANT=10 selects it (plain forward only).
+template <typename T, int MQ>
+__global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph10(FwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NS = 10;
+  constexpr int HROWS = 32 * MQ, BMT = 2 * HROWS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int Dp = (int)round_up(a.D, D_ALIGN);
+  const int tilesN = Dp / BN;
+  const int R = a.n_dev ? *a.n_dev : a.R;
+  const int nact = a.n_dev ? ((R + BMT - 1) / BMT) * tilesN : (int)gridDim.x;
+  if (a.seq_host && blockIdx.x == 0 && tid == 0) __hip_atomic_store(a.seq_host, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if ((int)blockIdx.x >= nact) return;
+  const int L = ph_xcd_remap(blockIdx.x, nact);
+  const int m0 = (L / tilesN) * BMT, n0 = (L % tilesN) * BN;
+  const int Fp = a.Fp;
+  const uint16_t* srcA[2][2];
+  const uint16_t* srcB[2][2];
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = (i * 8 + wave) * 8 + (lane >> 3), lc = (lane & 7) ^ (row & 7);
+      const int grow = m0 + hf * HROWS + row;
+      const int trow = (row < HROWS && grow < R) ? a.rows[grow] : a.zero_row;
+      srcA[hf][i] = a.table + (int64_t)trow * Fp + lc * 8;
+      srcB[hf][i] = a.Wh + (int64_t)(n0 + hf * 128 + row) * Fp + lc * 8;
+    }
+  f32x4 acc[2][MQ][2][2];
+#pragma unroll
+  for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+    for (int mi = 0; mi < MQ; ++mi)
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mh][mi][nh][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nk = Fp / BK;
+  const int H = 4 * nk;
+  auto issue = [&](int kt, int q, int slot) {
+    const uint16_t* const* src = q == 0 ? srcA[0] : q == 1 ? srcB[0] : q == 2 ? srcB[1] : srcA[1];
+    unsigned char* dst = smem + slot * PH_SLOT;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ph_glds16(src[i] + kt * BK, dst + (i * 8 + wave) * 1024);
+  };
+  // prologue: half-tiles 0 .. 7 (K-tiles 0 and 1) into slots 0 .. 7
+#pragma unroll
+  for (int h = 0; h < 8; ++h) issue(h >> 2, h & 3, h);
+  PH_WAIT(12);                                 // half-tiles 0, 1 have landed
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_setprio(1);
+  const int frow = lane & 15, fq = lane >> 4;
+  const int a_off = (wm * 16 * MQ + frow) * 128;
+  const int b_off = (wn * 32 + frow) * 128;
+  const int sw = frow & 7;
+  i16x8 af[MQ][2], b0[2][2], b1[2][2];
+  int base = 0;                                // slot of half-tile 4 t
+  auto slot_of = [&](int j) { const int x = base + j; return x >= NS ? (x >= 2 * NS ? x - 2 * NS : x - NS) : x; };   // j < 16
+#define P10_LOAD_A(j)                                                                                \
+  { const unsigned char* sp_ = smem + slot_of(j) * PH_SLOT;                                          \
+    _Pragma("unroll") for (int mi = 0; mi < MQ; ++mi) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) \
+      af[mi][kk] = *(const i16x8*)(sp_ + a_off + mi * 2048 + (((kk * 4 + fq) ^ sw) << 4)); }
+#define P10_LOAD_B(dst, j)                                                                           \
+  { const unsigned char* sp_ = smem + slot_of(j) * PH_SLOT;                                          \
+    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)  \
+      dst[ni][kk] = *(const i16x8*)(sp_ + b_off + ni * 2048 + (((kk * 4 + fq) ^ sw) << 4)); }
+#define P10_MFMA(mh, nh, bfr)                                                                        \
+  __builtin_amdgcn_s_barrier();                                                                      \
+  __builtin_amdgcn_sched_barrier(0);                                                                 \
+  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int mi = 0; mi < MQ; ++mi) \
+    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                 \
+      acc[mh][mi][nh][ni] = T::mfma(bfr[ni][kk], af[mi][kk], acc[mh][mi][nh][ni]);                   \
+  __builtin_amdgcn_sched_barrier(0);                                                                 \
+  __builtin_amdgcn_s_barrier();                                                                      \
+  __builtin_amdgcn_sched_barrier(0);
+  // stream step of phase (t, p): half-tile 4 t + p + 8 = quadrant p of K-tile t + 2, into the slot of half-tile 4 t + p - 2
+#define P10_STREAM(t, j, p, wait)                                                                    \
+  {                                                                                                  \
+    const int h = 4 * (t) + (p) + 8;                                                                 \
+    if (h < H) { issue((t) + 2, (p), slot_of((j) + 8)); if (wait) PH_WAIT(12); }                     \
+    else if (wait) PH_WAIT(0);                                                                       \
+  }
+  for (int t = 0; t < nk; t += 2) {
+    // K-tile t: half-tiles base + 0 .. 3
+    P10_LOAD_A(0) P10_LOAD_B(b0, 1) P10_STREAM(t, 0, 0, true) P10_MFMA(0, 0, b0)
+    P10_LOAD_B(b1, 2) P10_STREAM(t, 1, 1, true) P10_MFMA(0, 1, b1)
+    P10_LOAD_A(3) P10_STREAM(t, 2, 2, false) P10_MFMA(1, 1, b1)
+    P10_STREAM(t, 3, 3, true) P10_MFMA(1, 0, b0)
+    // K-tile t + 1: half-tiles base + 4 .. 7
+    P10_LOAD_A(4) P10_LOAD_B(b0, 5) P10_STREAM(t + 1, 4, 0, true) P10_MFMA(0, 0, b0)
+    P10_LOAD_B(b1, 6) P10_STREAM(t + 1, 5, 1, true) P10_MFMA(0, 1, b1)
+    P10_LOAD_A(7) P10_STREAM(t + 1, 6, 2, false) P10_MFMA(1, 1, b1)
+    P10_STREAM(t + 1, 7, 3, true) P10_MFMA(1, 0, b0)
+    base += 8; if (base >= NS) base -= NS;
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();
+#undef P10_LOAD_A
+#undef P10_LOAD_B
+#undef P10_MFMA
+#undef P10_STREAM
+  const float descale = 1.0f / (a.scales->sx * a.scales->sw_cur);
+  const float lo = a.relu ? 0.f : -INFINITY;
+#pragma unroll
+  for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+    for (int mi = 0; mi < MQ; ++mi) {
+      const int m = m0 + mh * HROWS + wm * 16 * MQ + mi * 16 + frow;
+      if (m >= R) continue;
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int n = n0 + nh * 128 + wn * 32 + ni * 16 + fq * 4;
+          if (n >= a.D) continue;
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fmaxf(acc[mh][mi][nh][ni][j] * descale + a.bias[n + j], lo);
+          *(float4*)(a.H + (int64_t)m * a.D + n) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------- wgrad --------
 // dW = dY^T X, one split of K per workgroup.  Both operands are k-major in HBM (dY rows / gathered feature rows), so a
 // half-tile is 64 k-rows x 128 columns: 256-B LDS rows of 16 chunks, chunk' = chunk ^ (h(row) << 1) with
@@ -654,6 +784,8 @@ static void launch_fwd_ph_q(const FwdArgs& a, hipStream_t s) {
 // the gated instantiation exists for the plain forward (no dropout, D % 4 == 0): the caller gates only then
 bool fwd_gemm_can_gate(const FwdArgs& a) { return a.drop_ratio == 0.f && a.D % 4 == 0; }
 
+static bool g_fwd_ring10 = false;         // VV_FWD_RING10=1: the ten-slot forward kernel (experiment)
+void set_fwd_ring10(bool on) { g_fwd_ring10 = on; }
 static int g_ph_mq = 0;                   // VV_PH_MQ: force the tile (2, 3, 4 = 128 / 192 / 256 rows, 31 = 176 rows); 0 = automatic
 void set_ph_mq(int v) { g_ph_mq = v; }
 
@@ -702,6 +834,19 @@ static void launch_fwd_ph_t(const FwdArgs& a, hipStream_t s) {
       }
       VV_ABL_FWP(1) VV_ABL_FWP(2) VV_ABL_FWP(3) VV_ABL_FWP(4) VV_ABL_FWP(6) VV_ABL_FWP(7) VV_ABL_FWP(8) VV_ABL_FWP(9)
 #undef VV_ABL_FWP
+    }
+  }
+  if constexpr (!DROP && VEC) {
+    if (g_fwd_ring10 && !a.gate && a.D % 4 == 0 && a.bias && (best == 0 || best == 1)) {
+      const dim3 block(GEMM_THREADS);
+      if (best == 0) {
+        static bool o4 = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph10<T, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * PH_SLOT), true); (void)o4;
+        VV_LAUNCH((k_fwd_gemm_ph10<T, 4>), dim3(((a.R + 255) / 256) * (Dp / BN)), block, 10 * PH_SLOT, s, a);
+      } else {
+        static bool o3 = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph10<T, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * PH_SLOT), true); (void)o3;
+        VV_LAUNCH((k_fwd_gemm_ph10<T, 3>), dim3(((a.R + 191) / 192) * (Dp / BN)), block, 10 * PH_SLOT, s, a);
+      }
+      return;
     }
   }
   if (best == 0) launch_fwd_ph_q<T, DROP, VEC, 4>(a, s);
