@@ -196,7 +196,10 @@ def test_f16_gradient_never_applied_clipped(path, monkeypatch):
     repeats, scale = eng.grad_scale_stats()
     print("F16 GUARD %s: dW error per step %s; repeats reported %d, scale now %g" % (path, " ".join("%.1e" % e for e in errs), repeats, scale))
     assert max(errs) <= 2e-3 and max(errs_b) <= 2e-3, (errs, errs_b)      # the first step included
-    assert 1 <= repeats <= 6                 # the first steps repeated (reports arrive four steps late), then the scale had followed
+    if path == "seg":
+        assert repeats == 0                  # proactive: the score kernel bounds the gradients, k_seg_bwd settles the scale before it rounds
+    else:
+        assert 1 <= repeats <= 6             # the first steps repeated (reports arrive four steps late), then the scale had followed
     ip1 = eng.blobs(cfg, ip2=False, scores=False, ip1_diff=True)["ip1_diff"]
     ip1_ref = ref.blobs(cfg, ip2=False, scores=False, ip1_diff=True)["ip1_diff"]
     assert np.linalg.norm(ip1 - 3e5 * ip1_ref) <= 4e-3 * np.linalg.norm(3e5 * ip1_ref)
@@ -205,7 +208,8 @@ def test_f16_gradient_never_applied_clipped(path, monkeypatch):
 
 def test_f16_guard_tiny_gradients_are_scaled_up():
     """The other side of the range: gradients 1e-7 times their usual size would sink into f16's subnormals at the
-    count-based default scale; the reported maxima move the scale up within a few steps."""
+    count-based default scale; the segment-wise backward settles its scale on the device from a bound on the step's own
+    gradients, in both directions, before it rounds anything: the first step is already right."""
     import videovector_amd as vv
     from videovector_amd.synth import SyntheticVideos, init_weights
     B, C, Nn, F, D = 64, 5, 10, 256, 512
@@ -225,7 +229,7 @@ def test_f16_guard_tiny_gradients_are_scaled_up():
         dW, _ = eng.grads()
         errs.append(float(np.linalg.norm(dW - 1e-7 * dW1) / np.linalg.norm(1e-7 * dW1)))
     print("F16 GUARD tiny: dW error per step %s; scale now %g" % (" ".join("%.1e" % e for e in errs), eng.grad_scale_stats()[1]))
-    assert errs[-1] <= 2e-3 and eng.grad_scale_stats()[0] == 0
+    assert max(errs) <= 2e-3 and eng.grad_scale_stats()[0] == 0       # the first step included: the scale is settled on the device
     ref.close(); eng.close()
 
 

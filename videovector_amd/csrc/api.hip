@@ -169,6 +169,8 @@ static int create_init(vv_ctx* c) {
   HIPCHK(hipHostMalloc((void**)&c->gate_err, sizeof(int32_t), hipHostMallocMapped));
   *c->gate_err = 0;
   HIPCHK(hipHostGetDevicePointer((void**)&c->gate_err_dev, c->gate_err, 0));
+  HIPCHK(hipMalloc(&c->gg_bound, GG_BOUND_SLOTS * GG_BOUND_STRIDE * sizeof(unsigned long long)));
+  HIPCHK(hipMemset(c->gg_bound, 0, GG_BOUND_SLOTS * GG_BOUND_STRIDE * sizeof(unsigned long long)));
   HIPCHK(hipMalloc(&c->gg, sizeof(GradGuard)));
   { GradGuard g0; memset(&g0, 0, sizeof(g0)); g0.mul = 1.f; HIPCHK(hipMemcpy(c->gg, &g0, sizeof(g0), hipMemcpyHostToDevice)); }
   HIPCHK(hipHostMalloc((void**)&c->gmax_host, 32 * sizeof(unsigned long long), hipHostMallocMapped));
@@ -233,7 +235,7 @@ int vv_destroy(vv_ctx* c) {
   free_batch(c);
   dfree(c->table); dfree(c->patch_desc); dfree(c->W); dfree(c->b); dfree(c->hW); dfree(c->hb); dfree(c->Wh);
   dfree(c->scales); dfree(c->wmax_blocks); dfree(c->grads_own); dfree(c->mask); dfree(c->loss2);
-  dfree(c->dd_key); dfree(c->dd_info_all); dfree(c->gg); dfree(c->w_gate);
+  dfree(c->dd_key); dfree(c->dd_info_all); dfree(c->gg); dfree(c->gg_bound); dfree(c->w_gate);
   if (c->gate_err) (void)hipHostFree(c->gate_err);
   if (c->gmax_host) (void)hipHostFree(c->gmax_host);
   for (int i = 0; i < vv_ctx::kDdSets; ++i) {
@@ -779,10 +781,12 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   const int64_t gcount = cfg->global_count > 0 ? cfg->global_count : count;
   // half-precision gradient scale: a power of two near the loss count keeps dY*sg around 1
   int e; frexpf((float)gcount, &e);
-  // ... and follows the data: every step reports its largest |dY| (k_reduce, a host-visible ring); when the max of step
-  // seq - 4 -- a FIXED lag, so that the scale sequence does not depend on host timing and runs stay bit-reproducible --
-  // lies outside [2^5, 2^13) in the current scaled units, the scale moves so that it lies in [2^9, 2^10).  This only
-  // keeps the guard's repeats rare: a value past f16's range never reaches the weight-gradient GEMM (GradGuard).
+  // The segment-wise backward then settles the scale on the device, from a bound on the step's own gradients, before it
+  // rounds anything (GuardArgs::proactive).  On the other paths the host's scale follows the data: every step reports its
+  // largest |dY| (k_reduce, a host-visible ring); when the max of step seq - 4 -- a FIXED lag, so that the scale sequence
+  // does not depend on host timing and runs stay bit-reproducible -- lies outside [2^5, 2^13) in the current scaled units,
+  // the scale moves so that it lies in [2^9, 2^10).  That only keeps the guard's repeats rare: a value past f16's range never
+  // reaches the weight-gradient GEMM either way (GradGuard).
   if (c->prec == VV_PREC_F16) {
     constexpr int kLag = 4;
     if (c->gg_seq0 == 0) c->gg_seq0 = seq;
@@ -795,10 +799,15 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
         if (hipStreamQuery(s) == hipSuccess) { have = (int32_t)(uint32_t)__atomic_load_n(en, __ATOMIC_ACQUIRE) == want; break; }
       }
       if (have) {
-        const uint32_t bits = (uint32_t)(en[0] >> 32);
-        float gmax; memcpy(&gmax, &bits, 4);
-        if ((int32_t)(uint32_t)en[1] > 0) ++c->gg_repeats;
-        if (gmax > 0.f && std::isfinite(gmax)) {
+        const uint32_t bits = (uint32_t)(en[0] >> 32), gbits = (uint32_t)(en[1] >> 32);
+        float gmax, gbound; memcpy(&gmax, &bits, 4); memcpy(&gbound, &gbits, 4);
+        const uint32_t rep = (uint32_t)en[1];
+        if (rep & (1u << 30)) return fail(VV_ERR_STATE, "internal error: a 16-bit gradient value passed f16's range in step %d although the "
+                                                        "gradient-scale guard was active (GradGuard)", (int)want);
+        if (rep & (1u << 16)) ++c->gg_repeats;
+        if (gbound > 0.f) {
+          // segment-wise path: nothing to steer -- k_seg_bwd settles its scale on the device from the step's own bound
+        } else if (gmax > 0.f && std::isfinite(gmax)) {
           int eu; (void)frexpf(gmax, &eu);
           const int ex = eu + e + c->sg_adj;            // exponent of the max in the current scaled units
           if (ex > 13 || ex < 5) c->sg_adj += 10 - ex;
@@ -832,13 +841,18 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   // rows + their sums (k_segsum): sums of clipped rows say nothing about the true sums, which the second round sees.
   GuardArgs gd;
   if (c->prec == VV_PREC_F16) { gd.gg = c->gg; gd.slots = c->gg_slots; gd.nslot = c->gg_nslot; gd.seq = seq; }
-  const int n_rounds = c->prec != VV_PREC_F16 ? 0 : (dd && !seg ? 2 : 1);
+  // (the segment-wise backward needs no repeat at all: its score kernel bounds every instance's gradient and k_seg_bwd
+  // settles the scale before it rounds anything -- GuardArgs::proactive)
+  static const bool proactive_on = !(getenv("VV_GUARD_PROACTIVE") && atoi(getenv("VV_GUARD_PROACTIVE")) == 0);   // 0: the repeat form on this path too (A/B)
+  const bool proactive = seg && proactive_on;
+  const int n_rounds = c->prec != VV_PREC_F16 ? 0 : (proactive ? 0 : (dd && !seg ? 2 : 1));
   gd.n_of[0] = seg ? 0 : B;
   gd.n_of[1] = seg ? SEGB_BLOCKS : (dd ? (c->Rp + 3) / 4 : 0);
   SegBwdArgs ba;
   SegsumArgs ga;
   if (seg) {
     sa.V = c->segV; sa.rec = c->seg_rec;
+    if (gd.gg && proactive) { sa.bound_out = c->gg_bound; sa.bound_seq = seq; }
     ba.H = c->H; ba.V = c->segV; ba.rec = c->seg_rec; ba.seg_start = c->dd_seg; ba.info = c->dd_info; ba.dYu = c->dYu;
     ba.dbp = c->seg_dbp; ba.Rp = c->Rp; ba.D = D; ba.Dp = c->Dp; ba.inv_sg = 1.f / c->sg;
   } else if (dd) {
@@ -849,6 +863,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
     if (seg) {
       if (round == 0) PROFILED(c, "score_loss", launch_score_fwd(sa, s));
       ba.guard = gd; ba.guard.producer = 1; ba.guard.last = 1;
+      if (gd.gg && proactive) { ba.guard.proactive = 1; ba.guard.bound = c->gg_bound; ba.guard.cnt_max = c->dd_info + 1; }
       if (round == 0) PROFILED(c, "segsum", launch_seg_bwd(c->prec, ba, s));
       else PROFILED(c, "guard", launch_seg_bwd(c->prec, ba, s));
     } else {
@@ -873,7 +888,8 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   ra.scales = c->scales; ra.sg = c->sg; ra.grads = c->grads; ra.D = D; ra.F = c->F;
   if (gd.gg) {
     ra.gg = c->gg; ra.gmax_slots = c->gg_slots; ra.gmax_n0 = gd.n_of[0]; ra.gmax_n1 = gd.n_of[1]; ra.gmax_stride = c->gg_nslot;
-    ra.gmax_host = c->gmax_host_dev; ra.seq = seq;
+    ra.gmax_host = c->gmax_host_dev; ra.seq = seq; ra.guard_last_round = n_rounds;
+    if (proactive) { ra.gbound = c->gg_bound; ra.gcnt = c->dd_info + 1; }
   }
   ra.ip_scale = cfg->ip_regularization > 0.f ? 1.f + cfg->ip_regularization * 0.5f : 1.f;     // inner_product_layer.cpp:80-90
   ra.loss_part = c->loss_part; ra.viol_part = c->viol_part; ra.loss_scale = cfg->loss_weight / (float)count; ra.loss_out = c->loss2;

@@ -37,7 +37,7 @@ __device__ __forceinline__ void st_agent(unsigned long long* p, unsigned long lo
 
 __global__ __launch_bounds__(256) void k_dd_claim(DedupArgs a) {
   const int r = blockIdx.x * 256 + threadIdx.x;
-  if (r == 0) a.tickets[0] = 0;        // k_dd_leaders' ticket counter (kernel boundary orders the reset)
+  if (r == 0) { a.tickets[0] = 0; a.info[1] = 0; }   // k_dd_leaders' ticket counter, k_dd_segstart's max count (kernel boundaries order the resets)
   if (r >= a.Rp) return;
   int row = a.zero_row;
   if (r < a.R) { const int i = a.idx[r]; if (i >= 0 && i < a.row_limit) row = i; }   // as k_map_rows
@@ -133,6 +133,12 @@ __global__ __launch_bounds__(DD_BLOCK) void k_dd_segstart(DedupArgs a) {
   const int bid = take_ticket(a.tickets + 1, sm);
   const int u = bid * DD_BLOCK + threadIdx.x;
   const int v = u < U ? a.cnt[u] : 0;
+  {                                                  // info[1] = the largest instance count of a distinct row (GuardArgs::cnt_max)
+    int m = v;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(a.info + 1, m);
+  }
   int bt;
   const int lp = block_excl_scan(v, &bt, sm);
   unsigned long long* agg = a.agg + a.agg_stride;

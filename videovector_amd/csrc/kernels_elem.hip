@@ -610,6 +610,7 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
   __syncthreads();
 
   // ---- dAh = sum_q k3_q x_q from registers; the record of every target / negative instance
+  float bnd = 0.f;
   float4 pa[DV];
 #pragma unroll
   for (int v = 0; v < DV; ++v) pa[v] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -622,6 +623,7 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
     const float rs = sqrtf(s);
     const float k3 = c * __builtin_amdgcn_rcpf(rs + eps);
     const float cd = c * __builtin_amdgcn_rcpf(s * rs + eps) * a.drop_scale * a.sg;
+    bnd = fmaxf(bnd, fabsf(cd * s) + fabsf(cd * t) * rs);           // |alpha| + |beta| |x|: GuardArgs::bound
     if (lane == 0) { SegRec rc; rc.alpha = cd * s; rc.beta = cd * t; rc.vec = 2 * b; rc.pad = b * CN + ch; a.rec[ooff[ch]] = rc; }
 #pragma unroll
     for (int v = 0; v < DV; ++v) {
@@ -634,9 +636,15 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
     SegRec rc; rc.alpha = a.coeff[tid] * a.drop_scale * a.sg; rc.beta = 0.f; rc.vec = 2 * b + 1; rc.pad = b * CN + tid + 1;
     a.rec[ooff[tid + 1]] = rc;
   }
+  if (lane == 0) red[wave] = bnd;                   // (red is free here: block_sum3_w's readers are past the barrier above)
   __syncthreads();
 
   // ---- backward of the context normalisation: dA_b
+  float bnd_item = 0.f;
+  if (tid == 0) {
+#pragma unroll
+    for (int w = 0; w < NW; ++w) bnd_item = fmaxf(bnd_item, red[w]);
+  }
   float dot = 0.f;
   float u[CV];
 #pragma unroll
@@ -654,6 +662,14 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
   for (int v = 0; v < CV; ++v) {
     const int d = tid + v * THREADS;
     Vb[D + d] = (sA * u[v] - A[d] * dot) * inv_denA;
+  }
+  if (tid == 0 && a.bound_out) {
+    // context instances: |coeff_j ds sg| max_d |dA_d| <= |alpha_j| 4 sA gsum / (sA^1.5 + eps)   (|u_d| <= sum_q |c_q| = 2 gsum)
+    float am = 0.f;
+#pragma unroll
+    for (int j = 0; j < CXM; ++j) am = fmaxf(am, fabsf(cf[j]));      // (the coefficients are in registers since the kernel's start)
+    bnd_item = fmaxf(bnd_item, am * a.drop_scale * a.sg * 4.f * sA * gsum * inv_denA);
+    atomicMax(a.bound_out + (b & (GG_BOUND_SLOTS - 1)) * GG_BOUND_STRIDE, ((unsigned long long)(unsigned)a.bound_seq << 32) | __float_as_uint(bnd_item));
   }
 }
 
@@ -674,9 +690,11 @@ __global__ __launch_bounds__(64 * NW) void k_score_stream(ScoreArgs a) {
   float* A = sm;               // [D]
   float* Ah = A + D;           // [D]
   float* acc0 = Ah + D;        // [NW][D] per-wave partial dAh
-  float* red = acc0 + NW * D;  // [3 NW]
+  float* red = acc0 + NW * D;  // [4 NW]: three groups for the loss sums, one for the waves' gradient bounds
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float eps = 1e-10f;
+  float coeff_max = 0.f;       // max |coeff_j| (the context instances' gradient bound; loaded while the rows arrive)
+  for (int j = 0; j + 1 < C; ++j) coeff_max = fmaxf(coeff_max, fabsf(a.coeff[j]));
   const int32_t* map = a.map + (int64_t)b * CN;
   const int32_t* ord = a.ord + (int64_t)b * CN;
 
@@ -735,7 +753,7 @@ __global__ __launch_bounds__(64 * NW) void k_score_stream(ScoreArgs a) {
   float4 pa[DV];
 #pragma unroll
   for (int v = 0; v < DV; ++v) pa[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-  float lsum = 0.f, vsum = 0.f, gsum = 0.f;
+  float lsum = 0.f, vsum = 0.f, gsum = 0.f, bnd = 0.f;
   float4 xc[DV], xn[DV];
   int k = wave;
   if (k < Nn) load_row(C + k, xc);
@@ -756,6 +774,7 @@ __global__ __launch_bounds__(64 * NW) void k_score_stream(ScoreArgs a) {
     gsum += g;
     const float k3 = g * __builtin_amdgcn_rcpf(rs + eps);
     const float cd = g * __builtin_amdgcn_rcpf(sq * rs + eps) * a.drop_scale * a.sg;
+    bnd = fmaxf(bnd, fabsf(cd * sq) + fabsf(cd * tq) * rs);          // |alpha| + |beta| |x|: GuardArgs::bound
     if (lane == 0) {
       SegRec rc; rc.alpha = cd * sq; rc.beta = cd * tq; rc.vec = 2 * b; rc.pad = b * CN + ch;
       a.rec[a.seg_start[map[ch]] + ord[ch]] = rc;
@@ -788,6 +807,7 @@ __global__ __launch_bounds__(64 * NW) void k_score_stream(ScoreArgs a) {
     const float c = -gsum, rs = sqrtf(s0);
     const float k3 = c * __builtin_amdgcn_rcpf(rs + eps);
     const float cd = c * __builtin_amdgcn_rcpf(s0 * rs + eps) * a.drop_scale * a.sg;
+    bnd = fmaxf(bnd, fabsf(cd * s0) + fabsf(cd * t0) * rs);
     if (lane == 0) { SegRec rc; rc.alpha = cd * s0; rc.beta = cd * t0; rc.vec = 2 * b; rc.pad = b * CN; a.rec[a.seg_start[map[0]] + ord[0]] = rc; }
 #pragma unroll
     for (int v = 0; v < DV; ++v) {
@@ -800,9 +820,15 @@ __global__ __launch_bounds__(64 * NW) void k_score_stream(ScoreArgs a) {
     SegRec rc; rc.alpha = a.coeff[j - 1] * a.drop_scale * a.sg; rc.beta = 0.f; rc.vec = 2 * b + 1; rc.pad = b * CN + j;
     a.rec[a.seg_start[map[j]] + ord[j]] = rc;
   }
+  if (lane == 0) red[3 * NW + wave] = bnd;          // (a fourth group of NW words behind the three of the loss sums)
   __syncthreads();
 
   // ---- backward of the context normalisation: dA_b
+  float bnd_item = 0.f;
+  if (tid == 0) {
+#pragma unroll
+    for (int w = 0; w < NW; ++w) bnd_item = fmaxf(bnd_item, red[3 * NW + w]);
+  }
   float dot = 0.f;
   float u[CV];
 #pragma unroll
@@ -821,6 +847,10 @@ __global__ __launch_bounds__(64 * NW) void k_score_stream(ScoreArgs a) {
     const int d = tid + v * THREADS;
     Vb[D + d] = (sA * u[v] - A[d] * dot) * inv_denA;
   }
+  if (tid == 0 && a.bound_out) {                    // as k_score_fwd
+    bnd_item = fmaxf(bnd_item, coeff_max * a.drop_scale * a.sg * 4.f * sA * gsum * inv_denA);
+    atomicMax(a.bound_out + (b & (GG_BOUND_SLOTS - 1)) * GG_BOUND_STRIDE, ((unsigned long long)(unsigned)a.bound_seq << 32) | __float_as_uint(bnd_item));
+  }
 }
 
 // the segment-wise pair: k_seg_bwd holds a row of D = 512 or 1024 columns; the forward is the register-resident
@@ -832,7 +862,7 @@ void set_score_stream(int v) { g_score_stream = v; }
 void launch_score_fwd(const ScoreArgs& a, hipStream_t s) {
   const int rows = 1 + a.Nn;
   if (!(a.D == 512 && a.C - 1 <= 6 && rows <= 56) || g_score_stream == 1) {
-    const size_t lds = sizeof(float) * ((size_t)(2 + 8) * a.D + 3 * 8);
+    const size_t lds = sizeof(float) * ((size_t)(2 + 8) * a.D + 4 * 8);
     if (a.D == 512) {
       (void)hipFuncSetAttribute((const void*)k_score_stream<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       VV_LAUNCH((k_score_stream<8, 2>), dim3(a.B), dim3(512), lds, s, a);
@@ -870,6 +900,17 @@ __global__ __launch_bounds__(256) void k_seg_bwd(SegBwdArgs a) {
   float sgm;                                          // a repeat (guard round 1) scales the sums by a further 2^-k
   if (!gg_begin(a.guard, &cs[0][0], sgm)) return;
   const bool first = a.guard.round == 0;              // the bias partials come out of the unrounded values: once
+  if (a.guard.gg && a.guard.proactive) {              // GuardArgs::proactive: the scale is settled BEFORE anything is rounded
+    const float bm = gg_bound_fold(a.guard.bound, a.guard.seq);
+    const float G = bm * (float)(*a.guard.cnt_max) * 1.01f;          // no element of any row's sum can pass this
+    // ... and the scale is settled here outright, in both directions: the bound is put in [2^13, 2^14) (the true maximum
+    // then sits the bound's looseness -- tens to hundreds -- below: well inside f16's normal range), whatever the host's sg
+    int e = 14;
+    if (G > 0.f && G < 3.0e38f) (void)frexpf(G, &e);                 // G < 2^e  (zero gradient / inf / nan: no shift; gg_end's flag reports)
+    const int shift = e - 14 > 60 ? 60 : (e - 14 < -60 ? -60 : e - 14);
+    sgm = ldexpf(1.f, -shift);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { a.guard.gg->shift[3] = shift; a.guard.gg->mul = sgm; }
+  }
   const int U = a.info[0];
   const int Uk = min((U + BK - 1) / BK * BK, a.Rp);   // the wgrad K loop reads whole BK-row steps
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -991,7 +1032,7 @@ __global__ __launch_bounds__(256) void k_seg_bwd(SegBwdArgs a) {
   __syncthreads();
   if (first)
     for (int d = threadIdx.x; d < 512 * CH; d += 256)
-      a.dbp[(int64_t)blockIdx.x * D + d] = (cs[0][d] + cs[1][d] + cs[2][d] + cs[3][d]) * a.inv_sg;
+        a.dbp[(int64_t)blockIdx.x * D + d] = (cs[0][d] + cs[1][d] + cs[2][d] + cs[3][d]) * (a.inv_sg / sgm);   // (sgm: a power of two, exact)
   if (a.guard.gg) {
     __syncthreads();
     gg_end(a.guard, gg_block_max(gmx, &cs[0][0]));
@@ -1092,10 +1133,19 @@ __device__ __forceinline__ void reduce_loss(const ReduceArgs& a) {
     for (int i = threadIdx.x; i < a.gmax_n0; i += 256) m = fmaxf(m, a.gmax_slots[i]);
     for (int i = threadIdx.x; i < a.gmax_n1; i += 256) m = fmaxf(m, a.gmax_slots[(size_t)a.gmax_stride + i]);
     m = gg_block_max(m, gsm);
+    const float gbm = a.gbound ? gg_bound_fold(a.gbound, a.seq) : 0.f;
     if (threadIdx.x == 0) {
-      const int sh = a.gg ? a.gg->shift[3] : 0;
+      // word 1: bits 0-15 the shift taken off on the device, bit 16 a conditional repeat ran, bit 30 a value passed the limit
+      // in the step's FINAL round (cannot happen with the repeats / the proactive bound: the host treats it as an internal
+      // error); high half: the proactive bound cnt_max x bound over the host's sg (0 on the other paths)
+      unsigned fl = 0; float G = 0.f;
+      if (a.gg) {
+        fl = (unsigned)(a.gg->shift[3] & 0xFFFF) | (a.gg->repeat_seq == a.seq ? (1u << 16) : 0u) |
+             (a.gg->flag[a.guard_last_round] == a.seq ? (1u << 30) : 0u);
+        if (a.gbound) G = gbm * (float)(*a.gcnt) / a.sg;
+      }
       unsigned long long* e = a.gmax_host + 2 * (a.seq & 15);
-      __hip_atomic_store(e + 1, (unsigned long long)(unsigned)sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(e + 1, ((unsigned long long)__float_as_uint(G) << 32) | fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __hip_atomic_store(e, ((unsigned long long)__float_as_uint(m / a.sg) << 32) | (unsigned)a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }

@@ -71,6 +71,7 @@ struct vv_ctx {
   bool last_dedup = false;          // what the last forward/backward pass used
   // f16 gradient-scale guard (vv_internal.h: GradGuard)
   vv::GradGuard* gg = nullptr; float* gg_slots = nullptr; int gg_nslot = 0;
+  unsigned long long* gg_bound = nullptr;      // GuardArgs::bound: the score kernel's (seq, largest per-instance element bound)
   unsigned long long* gmax_host = nullptr;     // pinned + mapped: 16 entries of {seq | bits(max |dY|) << 32, final shift}
   unsigned long long* gmax_host_dev = nullptr;
   int sg_adj = 0;                   // powers of two on top of the count-based default scale (follows the reported maxima)

@@ -49,7 +49,8 @@ struct GradGuard {
   int32_t shift[4];          // shift[r], r = 1, 2: powers of two taken off the host's scale from round r on (cumulative);
                              // shift[3]: the step's final shift
   float mul;                 // 2^-shift of the step's last round
-  int32_t pad[3];
+  int32_t repeat_seq;        // the last step in which a conditional repeat really ran
+  int32_t pad[2];
 };
 constexpr float GG_LIMIT = 32768.f;
 struct GuardArgs {
@@ -62,7 +63,29 @@ struct GuardArgs {
   int last = 0;              // this launch closes the round (writes shift[round]) ...
   int final_round = 0;       // ... and the round is the step's last (publishes mul)
   int32_t seq = 0;
+  // PROACTIVE form (the segment-wise backward: k_score_fwd / k_score_stream + k_seg_bwd): no repeat launch.  The score kernel
+  // knows every instance's factored gradient (alpha, beta, the vector it multiplies) and bounds its largest element:
+  // |alpha| max|Ah_d| + |beta| max|x_d| <= |alpha| + |beta| |x| for a target / negative instance, |alpha| 4 sA gsum /
+  // (sA^1.5 + eps) for a context instance; it leaves the batch's maximum in *bound (tagged with the step's sequence number, so
+  // that nothing has to reset it).  A distinct row's sum is at most (its instance count) x that, the grouping kernels leave the
+  // largest instance count in *cnt_max: k_seg_bwd takes 2^-shift off the scale BEFORE it rounds anything whenever
+  // cnt_max x bound could pass 2^15.  Rigorous (a bound, not an estimate), and loose by design: a shift that was not
+  // needed costs nothing while the values stay normal f16 numbers.
+  int proactive = 0;
+  const unsigned long long* bound = nullptr;   // GG_BOUND_SLOTS words, one 128-B line each (an item adds to slot blockIdx % 64: a
+  const int32_t* cnt_max = nullptr;            //   thousand atomics on ONE word cost the score kernel 4 us of serialisation)
 };
+constexpr int GG_BOUND_SLOTS = 64, GG_BOUND_STRIDE = 16;     // (stride in 8-byte words)
+#ifdef __HIPCC__
+// the batch's largest per-instance element bound: max over the slots that carry this step's sequence number (every lane alike)
+__device__ __forceinline__ float gg_bound_fold(const unsigned long long* bound, int32_t seq) {
+  const unsigned long long w = bound[(threadIdx.x & (GG_BOUND_SLOTS - 1)) * GG_BOUND_STRIDE];
+  float m = (unsigned)(w >> 32) == (unsigned)seq ? __uint_as_float((unsigned)w) : 0.f;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  return m;
+}
+#endif
 
 struct FwdArgs {
   const uint16_t* table;   // [n_rows + 1][Fp], last row all zero
@@ -134,6 +157,8 @@ struct ScoreArgs {
   // segment-wise backward (launch_score_fwd): outputs instead of dYh / dbp
   float* V = nullptr;                // [2B][D]
   SegRec* rec = nullptr;             // [R]
+  unsigned long long* bound_out = nullptr;   // GuardArgs::bound: (seq << 32) | bits of the largest per-instance element bound
+  int32_t bound_seq = 0;
 };
 
 // Row de-duplication of one batch (kernels_dedup.hip).  The sampler draws the negatives of every item
@@ -208,6 +233,8 @@ struct ReduceArgs {
   // the loss workgroup also reports the step's max |dY| (unscaled) and final shift to the host: ring of 16 entries
   const float* gmax_slots = nullptr; int gmax_n0 = 0, gmax_n1 = 0, gmax_stride = 0;
   unsigned long long* gmax_host = nullptr; int32_t seq = 0;
+  int guard_last_round = 0;        // the step's final guard round (its flag must not be up)
+  const unsigned long long* gbound = nullptr; const int32_t* gcnt = nullptr;   // proactive path: GuardArgs::bound / cnt_max (reported too)
   float* grads;            // [D*F + D]
   int D, F;
   float ip_scale;          // 1 + regularization/2 (inner_product_layer.cpp:80-90), normally 1
@@ -382,6 +409,7 @@ __device__ __forceinline__ bool gg_begin(const GuardArgs& g, float* smem, float&
     __syncthreads();                           // smem may be reused by the caller
   }
   if (g.last && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (active) g.gg->repeat_seq = g.seq;
     g.gg->shift[g.round] = shift;
     if (g.final_round) { g.gg->mul = ldexpf(1.f, -shift); g.gg->shift[3] = shift; }     // [3]: the step's final shift
   }
