@@ -8,8 +8,10 @@ Workload = BASELINE.json configs[1] per GPU: synthetic fc7 features 4096-d -> 51
 (global batch N*1024, weak scaling), context window +-2 (context_size 5), 50 negatives.
 
 A step = one full training iteration on one batch: (row de-duplication,) gather-GEMM forward, fused score/loss
-forward+backward, (per-row gradient sums,) gather-GEMM^T weight gradient, (all-reduce of [dW|db] for N > 1), fused SGD
-update.  What is timed, and reported as what:
+forward+backward, (per-row gradient sums,) gather-GEMM^T weight gradient, fused SGD update; for N > 1 the exact exchange of
+[dW|db]: by default chunk by chunk on the library's communication stream while the next step's forward GEMM already runs and
+waits per chunk inside the kernel (--allreduce overlap), or the whole all-reduce between backward and update (sync).
+What is timed, and reported as what:
 
   value            END TO END, sustainable: the triplet sampler (the reference's sequential libc-rand() sampler,
                    bit-exact) runs on prefetch threads INSIDE the timed region, as BasePrefetchingDataLayer's thread does
@@ -21,6 +23,8 @@ update.  What is timed, and reported as what:
   gpu_path_only    the same K steps with the index batches already resident in HBM (sampler excluded) -- the kernel path
                    alone, what round 1 reported as `value`.
   dense_execution  gpu_path_only with row de-duplication off: every sampled row projected separately, as the reference does.
+  dropout_execution  the same with the shipped dropout ratio 0.9 ("a dropout-0.9 number reported separately"): dense
+                   kernels (every instance has its own mask), the mask from a counter-based generator in the forward epilogue.
   bf16_execution   end to end with bf16 MFMA operands (the north star's operand type; the default is f16: same MFMA rate,
                    and only f16 meets the 1e-3 embedding tolerance).
   step_ms_stats    min / median / p95 / max of the individual step times of a further run of the K steps with one HIP event
@@ -151,7 +155,7 @@ def main():
     ap.add_argument("--sampler-threads", type=int, default=int(os.environ.get("VV_SAMPLER_THREADS", "4")))
     ap.add_argument("--prefetch-depth", type=int, default=128,
                     help="batches the sampler keeps ahead of the consumer (the reference: 1).  128 (29 MB of index batches) covers the stretches of up to several hundred steps in "
-                         "which the sampler -- 0.175 ms per batch on average against a 0.225 ms step -- falls behind (profiles/r02_long_run.txt)")
+                         "which the sampler -- 0.13 ms per batch at the median against a 0.23 ms step, but with stretches of up to 0.27 ms -- falls behind (profiles/r02_long_run.txt, r03_sampler_rates.txt)")
     ap.add_argument("--settle-ms", type=float, default=50.0,
                     help="untimed steps of the same workload, this many ms of them, in front of the W warm-up steps of every "
                          "leg: the device needs ~25 ms of continuous work after an idle spell (set-up, a host-side leg) before "

@@ -197,6 +197,16 @@ Comm* comm_create(int world, int rank, const char* id_path, int transport, size_
     const int rc = CommInitRank(&c->nccl, world, id, rank);
     if (rank == 0 && world > 1) (void)unlink(id_path);      // every rank has joined (or the attempt failed): the file has done its job
     if (rc != 0) return fail(std::string("ncclCommInitRank: ") + (c->ErrStr ? c->ErrStr(rc) : "error"));
+    // One small collective now, waited for: the library sets up its channels and connections lazily at the first call, which
+    // can take seconds -- not something to happen under a forward GEMM that is waiting at its gates (api.hip, overlap).
+    {
+      float* warm = nullptr;
+      if (hipMalloc((void**)&warm, 4096) != hipSuccess || hipMemsetAsync(warm, 0, 4096, c->stream) != hipSuccess) return fail("hipMalloc failed");
+      const int rw = c->AllReduce(warm, warm, 1024, kNcclFloat32, kNcclSum, c->nccl, c->stream);
+      const hipError_t es = hipStreamSynchronize(c->stream);
+      (void)hipFree(warm);
+      if (rw != 0 || es != hipSuccess) return fail(std::string("the communicator's first all-reduce failed: ") + (rw != 0 && c->ErrStr ? c->ErrStr(rw) : hipGetErrorString(es)));
+    }
   } else if (transport == VV_COMM_SHM) {
     c->shm_name = shm_name_of(id_path);
     c->shm_bytes = shm_hdr_bytes() + (size_t)world * n_floats * sizeof(float);

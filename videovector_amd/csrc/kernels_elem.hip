@@ -900,6 +900,7 @@ __global__ __launch_bounds__(256) void k_seg_bwd(SegBwdArgs a) {
   float sgm;                                          // a repeat (guard round 1) scales the sums by a further 2^-k
   if (!gg_begin(a.guard, &cs[0][0], sgm)) return;
   const bool first = a.guard.round == 0;              // the bias partials come out of the unrounded values: once
+  int pro_shift = 0;
   if (a.guard.gg && a.guard.proactive) {              // GuardArgs::proactive: the scale is settled BEFORE anything is rounded
     const float bm = gg_bound_fold(a.guard.bound, a.guard.seq);
     const float G = bm * (float)(*a.guard.cnt_max) * 1.01f;          // no element of any row's sum can pass this
@@ -907,9 +908,8 @@ __global__ __launch_bounds__(256) void k_seg_bwd(SegBwdArgs a) {
     // then sits the bound's looseness -- tens to hundreds -- below: well inside f16's normal range), whatever the host's sg
     int e = 14;
     if (G > 0.f && G < 3.0e38f) (void)frexpf(G, &e);                 // G < 2^e  (zero gradient / inf / nan: no shift; gg_end's flag reports)
-    const int shift = e - 14 > 60 ? 60 : (e - 14 < -60 ? -60 : e - 14);
-    sgm = ldexpf(1.f, -shift);
-    if (blockIdx.x == 0 && threadIdx.x == 0) { a.guard.gg->shift[3] = shift; a.guard.gg->mul = sgm; }
+    pro_shift = e - 14 > 60 ? 60 : (e - 14 < -60 ? -60 : e - 14);
+    sgm = ldexpf(1.f, -pro_shift);                                   // (first needed where the first row is rounded: the two loads above fly meanwhile)
   }
   const int U = a.info[0];
   const int Uk = min((U + BK - 1) / BK * BK, a.Rp);   // the wgrad K loop reads whole BK-row steps
@@ -1034,6 +1034,7 @@ __global__ __launch_bounds__(256) void k_seg_bwd(SegBwdArgs a) {
     for (int d = threadIdx.x; d < 512 * CH; d += 256)
         a.dbp[(int64_t)blockIdx.x * D + d] = (cs[0][d] + cs[1][d] + cs[2][d] + cs[3][d]) * (a.inv_sg / sgm);   // (sgm: a power of two, exact)
   if (a.guard.gg) {
+    if (a.guard.proactive && blockIdx.x == 0 && threadIdx.x == 0) { a.guard.gg->shift[3] = pro_shift; a.guard.gg->mul = sgm; }   // for k_reduce
     __syncthreads();
     gg_end(a.guard, gg_block_max(gmx, &cs[0][0]));
   }

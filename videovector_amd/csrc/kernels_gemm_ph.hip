@@ -141,7 +141,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
       unsigned spins = 0;
       while ((int32_t)(__hip_atomic_load(a.gate + chunk * W_GATE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.gate_seq) < 0) {
         __builtin_amdgcn_s_sleep(64);
-        if (++spins > 2000000u) {              // ~seconds: the update never came (a failed rank, a bug): flag it and go on
+        if (++spins > 12000000u) {             // ~half a minute: the update never came (a failed rank, a bug): flag it and go on
           if (lane == 0) __hip_atomic_store(a.gate_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           break;
         }
