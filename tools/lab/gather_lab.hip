@@ -61,10 +61,10 @@ __global__ __launch_bounds__(512) void k_gather(const unsigned short* table, con
 }
 
 template <int DEPTH, int PIECE, int ROWS, bool ROT>
-double run(const unsigned short* table, const int* rows, int Fp, int ntiles, int grid, hipStream_t st, unsigned* sink) {
+double run(const unsigned short* table, const int* rows, int Fp, int ntiles, int grid, hipStream_t st, unsigned* sink, int kext = 0) {
   const int lds = DEPTH * ROWS * PIECE;
   CHK(hipFuncSetAttribute((const void*)k_gather<DEPTH, PIECE, ROWS, ROT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  const int nsteps = Fp * 2 / PIECE;
+  const int nsteps = (kext ? kext : Fp) * 2 / PIECE;
   const int tpw = ntiles / grid;
   hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
   for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((k_gather<DEPTH, PIECE, ROWS, ROT>), dim3(grid), dim3(512), lds, st, table, rows, Fp, nsteps, tpw, sink);
@@ -80,7 +80,7 @@ int main() {
   const int Fp = 4096, n_rows = 81914, ROWS = 256;
   const int ntiles = 512;    // 512 tiles x 256 rows = 131072 gathered rows (1.07 GB of row bytes)
   unsigned short* table; int* rows; unsigned* sink;
-  CHK(hipMalloc(&table, (size_t)n_rows * Fp * 2)); CHK(hipMemset(table, 1, (size_t)n_rows * Fp * 2));
+  CHK(hipMalloc(&table, (size_t)n_rows * (Fp + 256) * 2)); CHK(hipMemset(table, 1, (size_t)n_rows * (Fp + 256) * 2));
   CHK(hipMalloc(&sink, 64));
   std::vector<int> h(ntiles * ROWS);
   unsigned long long s = 88172645463325252ull;
@@ -99,5 +99,22 @@ int main() {
   RUN(2, 512, 64, false, 256) RUN(2, 512, 64, true, 256) RUN(4, 512, 64, true, 256)
   RUN(2, 128, 256, true, 128) RUN(4, 128, 256, true, 128)
   RUN(2, 128, 256, true, 512) RUN(4, 128, 256, false, 512)
+  // L2-hot operand (the W side of the forward GEMM): 512 rows shared by every workgroup, K extent 4096, row stride ld halves
+  {
+    const int nW = 512;
+    std::vector<int> hw(ntiles * ROWS);
+    for (size_t i = 0; i < hw.size(); ++i) hw[i] = (int)(i % nW);
+    CHK(hipMemcpy(rows, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+    printf("512 shared rows (L2), K extent 4096, by row stride\n");
+    for (int ld : {4096, 4096 + 32, 4096 + 64, 4096 + 128, 4096 + 192}) {
+#define RUNW(D, P, R, ROTB, G) { double ms = run<D, P, R, ROTB>(table, rows, ld, ntiles, G, st, sink, 4096); \
+    printf("stride %d B depth %d piece %4d rot %d grid %3d : %.3f ms  %.2f TB/s  %.1f GB/s/WG\n", ld * 2, D, P, (int)ROTB, G, ms, bytes / ms / 1e9, bytes / ms / 1e6 / G); }
+      RUNW(4, 128, 256, false, 256) RUNW(4, 128, 256, true, 256) RUNW(4, 128, 256, false, 216)
+    }
+    // random rows of the big table again, by stride
+    CHK(hipMemcpy(rows, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    printf("random rows of the 670 MB table, K extent 4096, by row stride\n");
+    for (int ld : {4096, 4096 + 64, 4096 + 128}) { RUNW(4, 128, 256, false, 256) RUNW(4, 128, 256, true, 256) }
+  }
   return 0;
 }

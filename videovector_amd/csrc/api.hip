@@ -59,6 +59,7 @@ static void prof_end(vv_ctx* c, const char* name, hipEvent_t e0, hipEvent_t e1) 
 // VV_TRACE_HOST=<ms>: report every launcher call that keeps the HOST longer than that (first use of a kernel variant,
 // a runtime pool growing, ...) -- the GPU queue runs dry behind such a call.
 static double g_trace_host_ms = -1.0;
+static double g_wait_ms[5] = {0, 0, 0, 0, 0}; static long g_wait_calls = 0;      // VV_TRACE_WAITS: where the host waits (ms, summed)
 static inline double host_now_ms() {
   timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
   return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
@@ -544,10 +545,12 @@ static int stage_acquire(vv_ctx* c, size_t bytes, int* slot) {
   }
   const int sl = c->stage_next;
   c->stage_next = (c->stage_next + 1) % vv_ctx::kStage;
+  const double tw0 = host_now_ms();
   for (unsigned spins = 0; (int32_t)(__atomic_load_n(c->seq_host, __ATOMIC_ACQUIRE) - c->stage_seq[sl]) < 0; ++spins) {
     if (spins > 4096) { timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
     if (hipStreamQuery(c->stream) == hipSuccess) break;     // nothing queued any more: every earlier step is done
   }
+  g_wait_ms[3] += host_now_ms() - tw0;
   *slot = sl;
   return VV_OK;
 }
@@ -650,10 +653,12 @@ static int dd_issue(vv_ctx* c, const int32_t* didx, int idx_on_device, int64_t r
       // faster step, at the price of a forward-GEMM duration (and roofline fraction) that includes the co-running kernels.
       // VV_DEDUP_GATE=1 selects the other.
       static const int gate_word = getenv("VV_DEDUP_GATE") ? (atoi(getenv("VV_DEDUP_GATE")) != 0) : 0;
+      const double tw0 = host_now_ms();
       for (unsigned spins = 0; (int32_t)(__atomic_load_n(c->seq_host + gate_word, __ATOMIC_ACQUIRE) - set.used_seq) <= 0; ++spins) {
         if (spins > 4096) { timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
         if (hipStreamQuery(s) == hipSuccess) break;             // nothing queued any more: every earlier step is done
       }
+      g_wait_ms[1] += host_now_ms() - tw0;
     }
     set.used_seq = seq;
     DedupArgs da;
@@ -745,6 +750,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
       if (!fired && c->dd_spin_us > 0 && hipStreamQuery(s) != hipSuccess) {
         const double t0 = host_now_ms();
         do { fired = hipEventQuery(set.done) == hipSuccess; } while (!fired && (host_now_ms() - t0) * 1e3 < c->dd_spin_us);
+        g_wait_ms[2] += host_now_ms() - t0;
       }
       if (!fired) HIPCHK(hipStreamWaitEvent(s, set.done, 0));
     }
@@ -794,9 +800,17 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
       const int32_t want = seq - kLag;
       volatile unsigned long long* en = c->gmax_host + 2 * (want & 15);
       bool have = false;
+      const double tw0 = host_now_ms();
       for (unsigned spins = 0; !(have = (int32_t)(uint32_t)__atomic_load_n(en, __ATOMIC_ACQUIRE) == want); ++spins) {
         if (spins > 4096) { timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
         if (hipStreamQuery(s) == hipSuccess) { have = (int32_t)(uint32_t)__atomic_load_n(en, __ATOMIC_ACQUIRE) == want; break; }
+      }
+      g_wait_ms[0] += host_now_ms() - tw0;
+      static const bool trace_waits = getenv("VV_TRACE_WAITS") != nullptr;
+      if (trace_waits && ++g_wait_calls % 100 == 0) {
+        fprintf(stderr, "[vv waits] per step over the last 100: gradient-scale report %.3f, grouping-set gate %.3f, grouping event %.3f, staging slot %.3f ms\n",
+                g_wait_ms[0] / 100, g_wait_ms[1] / 100, g_wait_ms[2] / 100, g_wait_ms[3] / 100);
+        g_wait_ms[0] = g_wait_ms[1] = g_wait_ms[2] = g_wait_ms[3] = 0;
       }
       if (have) {
         const uint32_t bits = (uint32_t)(en[0] >> 32), gbits = (uint32_t)(en[1] >> 32);

@@ -832,7 +832,7 @@ static void launch_fwd_ph_t(const FwdArgs& a, hipStream_t s) {
         VV_LAUNCH((k_fwd_gemm_ph<T, DROP, VEC, 4, N>), grid, block, PH_LDS_BYTES, s, a);                \
         return;                                                                                        \
       }
-      VV_ABL_FWP(1) VV_ABL_FWP(2) VV_ABL_FWP(3) VV_ABL_FWP(4) VV_ABL_FWP(6) VV_ABL_FWP(7) VV_ABL_FWP(8) VV_ABL_FWP(9)
+      VV_ABL_FWP(1) VV_ABL_FWP(2) VV_ABL_FWP(3) VV_ABL_FWP(4) VV_ABL_FWP(6) VV_ABL_FWP(7) VV_ABL_FWP(8) VV_ABL_FWP(9) VV_ABL_FWP(14)
 #undef VV_ABL_FWP
     }
   }
