@@ -17,7 +17,7 @@
 
 #include "vv_ctx.h"
 
-namespace vv { void set_fwd_ring10(bool on); void set_wgrad_tr(bool on); void set_gemm_variant(int v); void set_ablate(int v); void set_score_reg(int v); void set_score_waves(int v); void set_ph_mq(int v); void set_score_stream(int v); int gemm_variant(); bool ablate_on(); }
+namespace vv { void set_fwd_lead(int v); void set_fwd_ring10(bool on); void set_wgrad_tr(bool on); void set_gemm_variant(int v); void set_ablate(int v); void set_score_reg(int v); void set_score_waves(int v); void set_ph_mq(int v); void set_score_stream(int v); int gemm_variant(); bool ablate_on(); }
 using namespace vv;
 
 thread_local char vv_g_err[512] = "";
@@ -129,6 +129,7 @@ static int create_init(vv_ctx* c) {
   if (tr) set_wgrad_tr(atoi(tr) != 0);
   const char* gv = getenv("VV_GEMM_VARIANT");
   if (gv) set_gemm_variant(atoi(gv));
+  if (const char* fl = getenv("VV_FWD_LEAD")) set_fwd_lead(atoi(fl));
   const char* ab = getenv("VV_ABLATE");
   set_ablate(ab ? atoi(ab) : 0);
   const char* sr = getenv("VV_SCORE_REG");

@@ -24,6 +24,7 @@
 //   WAR  the half-tile issued in LOAD(t,p) replaces the one consumed in phase (t-1,p+2) / (t,p-2): at least two
 //        phases (four barriers) earlier.
 #include <algorithm>
+#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 #include "vv_internal.h"
@@ -42,6 +43,11 @@ namespace vv {
 // with their reads complete.  M0 carries the wave-uniform LDS base (the builtin sets it the same way).
 __device__ __forceinline__ void ph_glds16(const void* gsrc, void* lds_wave_base) {
   const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(lds_wave_base));
+  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(m0v), "v"(gsrc) : "m0", "memory");
+}
+// the same with the LDS address as a number (a wave-uniform byte offset into LDS: nothing to cast or null-check per use)
+__device__ __forceinline__ void ph_glds16_at(const void* gsrc, unsigned lds_addr) {
+  const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_addr);
   asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(m0v), "v"(gsrc) : "m0", "memory");
 }
 // the same with the source 256 bytes further on (the upper 128-column half of a k-major operand): an immediate
@@ -80,7 +86,15 @@ constexpr int PH_LDS_BYTES = 8 * PH_SLOT;      // ring of 8 slots = 128 KiB
 // (Rows of the 128-row half-tile image that no wave reads are still staged, from the L2-hot zero row: dropping those
 // LDS-DMA instructions -- the second one of waves 4-7 at 96 live rows -- with per-wave counted waits was measured and made
 // the 192-row kernel 4.6 us SLOWER, profiles/r03_step_ablations.txt.)
-template <typename T, bool DROP, bool VEC, int MQ, int ABL = 0, bool GATE = false, int DEAD = 0>
+// LEAD (0 / 1): the workgroups of one row tile (its column tiles: two at D = 512) ask for the same gathered lines at the
+// same time, so each line costs BOTH of them a miss -- the second request finds the first still in flight and waits for HBM
+// just as long (tools/lab/fwd_stream_lab.hip: the stream alone 104 us as issued today, 140 us when the siblings read
+// different rows, 74 us with every row L2-hot).  With LEAD the even column tiles ask for their A_lo half-tile ONE K-TILE
+// EARLY and the odd ones for their A_hi half-tile: every line's missing request comes from one sibling, and the other's,
+// a K-tile later, is an L2 hit (lab: 92 us; two or more K-tiles of lead are slower again).  The stream keeps its order and
+// its counts -- only the address of the leading half-tile's instructions moves a K-tile on -- so the counted waits hold
+// as they are; the leading half lives one K-tile longer and gets a ring of three slots (its two natural ones + a ninth).
+template <typename T, bool DROP, bool VEC, int MQ, int ABL = 0, bool GATE = false, int DEAD = 0, int LEAD = 0>
 __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int HROWS = 32 * MQ;               // rows of the lower A half-tile (upper: HROWS - 16 DEAD)
@@ -125,11 +139,23 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
   const int nk = Fp / BK;                      // K-tiles (Fp is a multiple of 256: nk % 4 == 0)
   const int H = 4 * nk;                        // half-tiles of this workgroup's stream
   // half-tile h = 4*kt + q, q: 0 A_lo, 1 B_lo, 2 B_hi, 3 A_hi; slot = h & 7
+  const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(smem)) + wave * 1024;   // this wave's first piece of slot 0
+  // LEAD: the leading A half (q = lead_q) of K-tile k lives in ring position k % 3 = slot lead_q, 4 + lead_q, 8
+  const int lead_q = LEAD ? (((L % tilesN) & 1) ? 3 : 0) : -1;
+  int ring_w = 0, ring_r = 0;                  // ring position the next leading half-tile goes to / K-tile t's is read from
+  auto ring_slot = [&](int r) { return r == 2 ? 8 : 4 * r + lead_q; };
   auto issue = [&](int kt, int q, int slot) {
-    const uint16_t* const* src = q == 0 ? srcA[0] : q == 1 ? srcB[0] : q == 2 ? srcB[1] : srcA[1];
-    unsigned char* dst = smem + slot * PH_SLOT;
+    int k = kt;
+    if (LEAD && q == lead_q) {                 // (the last K-tile's place in the stream re-stages K-tile nk - 1 into the free position: counts stay exact)
+      k = kt + 1 < nk ? kt + 1 : nk - 1;
+      slot = ring_slot(ring_w);
+      ring_w = ring_w == 2 ? 0 : ring_w + 1;
+    }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) ph_glds16(src[i] + kt * BK, dst + (i * 8 + wave) * 1024);
+    for (int i = 0; i < 2; ++i) {
+      const uint16_t* src = q == 0 ? srcA[0][i] : q == 1 ? srcB[0][i] : q == 2 ? srcB[1][i] : srcA[1][i];
+      ph_glds16_at(src + k * BK, lds_wave + slot * PH_SLOT + i * 8192);
+    }
   };
 #define PH_WAITQ() PH_WAIT(8)                  /* everything but the four youngest half-tiles has landed */
 
@@ -171,7 +197,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
     } else if (wave == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the flags were read after the kernel began: order the W loads behind them
   }
 
-  // prologue: half-tiles 0 .. 5
+  // prologue: half-tiles 0 .. 5 (LEAD: the leading half of K-tile 0 in front of them)
+  if (LEAD) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const uint64_t lo = (uint64_t)srcA[0][i], hi = (uint64_t)srcA[1][i];
+      ph_glds16_at((const uint16_t*)(lead_q == 0 ? lo : hi), lds_wave + ring_slot(0) * PH_SLOT + i * 8192);
+    }
+    ring_w = 1;
+  }
   issue(0, 0, 0); issue(0, 1, 1); issue(0, 2, 2); issue(0, 3, 3); issue(1, 0, 4); issue(1, 1, 5);
   PH_WAITQ();                                  // half-tiles 0, 1 (A_lo, B_lo of K-tile 0) have landed
   __builtin_amdgcn_s_barrier();
@@ -187,9 +221,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
   // one phase: LOAD segment (reads + stream + wait), barrier, MFMA segment, barrier
   const bool dead_hi = DEAD && wm == 1;        // this wave's last tile of the upper A half does not exist
 #define PH_LOAD_A(slot)                                                                              \
-  if (!abl_rd) _Pragma("unroll") for (int mi = 0; mi < MQ; ++mi) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) \
+  if (!abl_rd) {                                                                                     \
+    const int a_slot = (LEAD && ((slot) & 3) == lead_q) ? ring_slot(ring_r) : (slot);                \
+    _Pragma("unroll") for (int mi = 0; mi < MQ; ++mi) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) \
     if (!(DEAD && ((slot) & 3) == 3 && mi == MQ - 1 && dead_hi))                                     \
-    af[mi][kk] = *(const i16x8*)(smem + (slot) * PH_SLOT + a_off + mi * 2048 + (((kk * 4 + fq) ^ sw) << 4));
+    af[mi][kk] = *(const i16x8*)(smem + a_slot * PH_SLOT + a_off + mi * 2048 + (((kk * 4 + fq) ^ sw) << 4)); \
+  }
 #define PH_LOAD_B(dst, slot)                                                                         \
   if (!abl_rd) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)  \
     dst[ni][kk] = *(const i16x8*)(smem + (slot) * PH_SLOT + b_off + ni * 2048 + (((kk * 4 + fq) ^ sw) << 4));
@@ -207,7 +244,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
 #define PH_STREAM(tpar, t, p, wait)                                                                  \
   {                                                                                                  \
     const int h = 4 * (t) + (p) + 6;                                                                 \
-    if (h < H && !abl_st) { issue(h >> 2, ((p) + 2) & 3, 4 * (((tpar) + (((p) + 6) >> 2)) & 1) + (((p) + 2) & 3)); if (wait) PH_WAITQ(); } \
+    if ((!CHK || h < H) && !abl_st) { issue(h >> 2, ((p) + 2) & 3, 4 * (((tpar) + (((p) + 6) >> 2)) & 1) + (((p) + 2) & 3)); if (wait) PH_WAITQ(); } \
     else if (wait) PH_WAIT(0);                                                                       \
   }
   // ABL: timing studies only (VV_ABLATE, results wrong): 1 no LDS-DMA stream in the loop, 2 no MFMA, 4 no fragment
@@ -220,7 +257,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
     for (int ni = 0; ni < 2; ++ni) { b0[ni][0] = b0[ni][1] = b1[ni][0] = b1[ni][1] = i16x8{1, 2, 3, 4, 5, 6, 7, (short)ni}; }
   }
 
-  for (int t = 0; t < nk; t += 2) {
+  // two K-tiles; CHK: the stream may have run out (only the last pair of K-tiles can see that: its issues reach K-tile t + 3)
+  auto pair = [&](int t, auto chk) {
+    constexpr bool CHK = decltype(chk)::value;
     // ---- K-tile t (even): slots 0..3
     PH_LOAD_A(0) PH_LOAD_B(b0, 1) PH_STREAM(0, t, 0, true) PH_MFMA(0, 0, b0)
     PH_LOAD_B(b1, 2) PH_STREAM(0, t, 1, true) PH_MFMA(0, 1, b1)
@@ -230,12 +269,17 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
       if (++g_next >= a.gate_n) gated = false;
     }
     PH_STREAM(0, t, 3, true) PH_MFMA(1, 0, b0)
+    if (LEAD) ring_r = ring_r == 2 ? 0 : ring_r + 1;
     // ---- K-tile t + 1 (odd): slots 4..7
     PH_LOAD_A(4) PH_LOAD_B(b0, 5) PH_STREAM(1, t + 1, 0, true) PH_MFMA(0, 0, b0)
     PH_LOAD_B(b1, 6) PH_STREAM(1, t + 1, 1, true) PH_MFMA(0, 1, b1)
     PH_LOAD_A(7) PH_STREAM(1, t + 1, 2, false) PH_MFMA(1, 1, b1)
     PH_STREAM(1, t + 1, 3, true) PH_MFMA(1, 0, b0)
-  }
+    if (LEAD) ring_r = ring_r == 2 ? 0 : ring_r + 1;
+  };
+  int t_main = 0;
+  for (; t_main < nk - 2; t_main += 2) pair(t_main, std::false_type{});
+  pair(t_main, std::true_type{});
   if (wm == 0) __builtin_amdgcn_s_barrier();   // waves 0-3 catch the extra barrier of waves 4-7
 #undef PH_LOAD_A
 #undef PH_LOAD_B
@@ -762,6 +806,9 @@ void launch_wgrad_gemm_w4(int prec, const WgradArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------- launchers ----
+static int g_fwd_lead = 0;                // VV_FWD_LEAD=1: the LEAD instantiation (measured: no gain in the full kernel, profiles/r03_step_ablations.txt)
+void set_fwd_lead(int v) { g_fwd_lead = v; }
+
 template <typename T, bool DROP, bool VEC, int MQ, int DEAD = 0>
 static void launch_fwd_ph_q(const FwdArgs& a, hipStream_t s) {
   static bool once = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, false, DEAD>,
@@ -770,6 +817,23 @@ static void launch_fwd_ph_q(const FwdArgs& a, hipStream_t s) {
   const int Dp = (int)round_up(a.D, D_ALIGN);
   constexpr int BMT = 64 * MQ - 16 * DEAD;
   const dim3 grid(((a.R + BMT - 1) / BMT) * (Dp / BN)), block(GEMM_THREADS);
+  if constexpr (!DROP && VEC && DEAD == 0) {
+    if (g_fwd_lead && Dp / BN > 1) {
+      constexpr int LDS9 = 9 * PH_SLOT;
+      if (a.gate) {
+        static bool once_lg = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, true, DEAD, 1>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS9), true);
+        (void)once_lg;
+        VV_LAUNCH((k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, true, DEAD, 1>), grid, block, LDS9, s, a);
+      } else {
+        static bool once_l = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, false, DEAD, 1>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS9), true);
+        (void)once_l;
+        VV_LAUNCH((k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, false, DEAD, 1>), grid, block, LDS9, s, a);
+      }
+      return;
+    }
+  }
   if constexpr (!DROP && VEC) {
     if (a.gate) {
       static bool once_g = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, true, DEAD>,
@@ -834,6 +898,26 @@ static void launch_fwd_ph_t(const FwdArgs& a, hipStream_t s) {
       }
       VV_ABL_FWP(1) VV_ABL_FWP(2) VV_ABL_FWP(3) VV_ABL_FWP(4) VV_ABL_FWP(6) VV_ABL_FWP(7) VV_ABL_FWP(8) VV_ABL_FWP(9) VV_ABL_FWP(14)
 #undef VV_ABL_FWP
+    }
+  }
+  if constexpr (T::id == 0 && !DROP && VEC) {
+    // lab: ablations of the 192-row kernel at the de-duplicated size (VV_LAB_FWD_ABL; the step's results are wrong)
+    static const int lab_abl = getenv("VV_LAB_FWD_ABL") ? atoi(getenv("VV_LAB_FWD_ABL")) : 0;
+    if (lab_abl && best == 1 && !a.gate) {
+      const dim3 grid(((a.R + 191) / 192) * (Dp / BN)), block(GEMM_THREADS);
+#define VV_LAB_FWP(N)                                                                                  \
+      if (lab_abl == N) {                                                                              \
+        if (g_fwd_lead) {                                                                              \
+          (void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, 3, N, false, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * PH_SLOT); \
+          VV_LAUNCH((k_fwd_gemm_ph<T, DROP, VEC, 3, N, false, 0, 1>), grid, block, 9 * PH_SLOT, s, a);  \
+        } else {                                                                                       \
+          (void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, 3, N>, hipFuncAttributeMaxDynamicSharedMemorySize, PH_LDS_BYTES); \
+          VV_LAUNCH((k_fwd_gemm_ph<T, DROP, VEC, 3, N>), grid, block, PH_LDS_BYTES, s, a);              \
+        }                                                                                              \
+        return;                                                                                        \
+      }
+      VV_LAB_FWP(1) VV_LAB_FWP(2) VV_LAB_FWP(6) VV_LAB_FWP(8) VV_LAB_FWP(14)
+#undef VV_LAB_FWP
     }
   }
   if constexpr (!DROP && VEC) {
