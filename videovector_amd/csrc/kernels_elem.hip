@@ -680,8 +680,10 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
 // the wave's partial dAh before the row is dropped.  Only the target's own coefficient (-sum of all g_k) has to wait for the
 // block-wide sum; wave 0 adds that row at the end.  (A segment-wise form of the streaming k_score_loss read every row twice: 0.92 ms of the
 // 2.26 ms cfg-5 step; this kernel 0.47 ms.)  Sums in a fixed order: a wave's rows in sequence, then the waves in sequence.
+// (DV = 4 sits at the edge of 128 VGPRs: two workgroups per CU need 4 waves per SIMD -- the gradient bound's two registers
+// pushed it to 131 and one workgroup per CU, 0.47 -> 0.70 ms at cfg 5; the second launch bound holds it at 128)
 template <int NW, int DV>
-__global__ __launch_bounds__(64 * NW) void k_score_stream(ScoreArgs a) {
+__global__ __launch_bounds__(64 * NW, DV == 4 ? 4 : 1) void k_score_stream(ScoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int THREADS = 64 * NW;
   constexpr int CV = 256 * DV / THREADS;
@@ -693,8 +695,6 @@ __global__ __launch_bounds__(64 * NW) void k_score_stream(ScoreArgs a) {
   float* red = acc0 + NW * D;  // [4 NW]: three groups for the loss sums, one for the waves' gradient bounds
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float eps = 1e-10f;
-  float coeff_max = 0.f;       // max |coeff_j| (the context instances' gradient bound; loaded while the rows arrive)
-  for (int j = 0; j + 1 < C; ++j) coeff_max = fmaxf(coeff_max, fabsf(a.coeff[j]));
   const int32_t* map = a.map + (int64_t)b * CN;
   const int32_t* ord = a.ord + (int64_t)b * CN;
 
@@ -848,6 +848,8 @@ __global__ __launch_bounds__(64 * NW) void k_score_stream(ScoreArgs a) {
     Vb[D + d] = (sA * u[v] - A[d] * dot) * inv_denA;
   }
   if (tid == 0 && a.bound_out) {                    // as k_score_fwd
+    float coeff_max = 0.f;       // max |coeff_j|: the context instances' gradient bound
+    for (int j = 0; j + 1 < C; ++j) coeff_max = fmaxf(coeff_max, fabsf(a.coeff[j]));
     bnd_item = fmaxf(bnd_item, coeff_max * a.drop_scale * a.sg * 4.f * sA * gsum * inv_denA);
     atomicMax(a.bound_out + (b & (GG_BOUND_SLOTS - 1)) * GG_BOUND_STRIDE, ((unsigned long long)(unsigned)a.bound_seq << 32) | __float_as_uint(bnd_item));
   }
@@ -1177,7 +1179,11 @@ __device__ __forceinline__ void scale_update_body(Scales* sc, const float* wmax_
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
-  int bid = blockIdx.x;
+  // The few workgroups with serial work (bias columns: a loop over the per-block partials; loss; scale) are numbered last
+  // but DISPATCHED first: the 2048 dW workgroups fill every CU's block slots, and a workgroup that only starts when the
+  // first of them retires adds its own loop to the kernel's length (measured: 16.7 us with them last).
+  const int n_special = (a.scale_sc ? 1 : 0) + ((a.parts & 2) ? (a.D + 15) / 16 + 1 : 0);
+  int bid = (int)blockIdx.x < n_special ? (int)gridDim.x - n_special + (int)blockIdx.x : (int)blockIdx.x - n_special;
   // a pending W -> half scale update of the PREVIOUS step's SGD kernel rides as the last workgroup (its own one-workgroup
   // launch cost ~5 us of stream time a step: the kernel plus two dependent-launch gaps); this step's k_sgd reads the result
   const int G = (int)gridDim.x - (a.scale_sc ? 1 : 0);
@@ -1202,6 +1208,14 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
       const float* p = a.slabs + (int64_t)d * a.Fp + f;
       float4 s = *(const float4*)p;
       int k = 1;
+      if (a.S == 8) {                  // the usual split: all eight loads in flight at once, summed in slab order
+        float4 t[7];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) t[u] = *(const float4*)(p + (u + 1) * slab_sz);
+#pragma unroll
+        for (int u = 0; u < 7; ++u) { s.x += t[u].x; s.y += t[u].y; s.z += t[u].z; s.w += t[u].w; }
+        k = 8;
+      }
       for (; k + 3 < a.S; k += 4) {
         const float4 t0 = *(const float4*)(p + (k + 0) * slab_sz), t1 = *(const float4*)(p + (k + 1) * slab_sz);
         const float4 t2 = *(const float4*)(p + (k + 2) * slab_sz), t3 = *(const float4*)(p + (k + 3) * slab_sz);

@@ -461,7 +461,11 @@ void launch_wgrad_gemm_ph(int prec, const WgradArgs& a, hipStream_t s);
 void launch_wgrad_gemm_w4(int prec, const WgradArgs& a, hipStream_t s);
 void launch_wgrad_gemm(int prec, const WgradArgs& a, hipStream_t s) {
   if (g_gemm_variant == 8 && g_wgrad_tr) { launch_wgrad_gemm_w4(prec, a, s); return; }
-  if ((g_gemm_variant == 5 || g_gemm_variant == 6) && g_wgrad_tr) { WgradArgs b = a; b.abl = g_ablate; launch_wgrad_gemm_ph(prec, b, s); return; }
+  if ((g_gemm_variant == 5 || g_gemm_variant == 6) && g_wgrad_tr) {
+    // (lab: VV_LAB_WG_ABL ablates this kernel alone, at whatever size the step runs -- VV_ABLATE switches the de-duplication off)
+    static const int lab_abl = getenv("VV_LAB_WG_ABL") ? atoi(getenv("VV_LAB_WG_ABL")) : 0;
+    WgradArgs b = a; b.abl = g_ablate ? g_ablate : lab_abl; launch_wgrad_gemm_ph(prec, b, s); return;
+  }
   if (prec == 0) { if (g_wgrad_tr) launch_wgrad_t<F16, true>(a, s); else launch_wgrad_t<F16, false>(a, s); }
   else { if (g_wgrad_tr) launch_wgrad_t<BF16, true>(a, s); else launch_wgrad_t<BF16, false>(a, s); }
 }

@@ -326,6 +326,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
             }
           }
           float* dst = a.H + (int64_t)m * a.D + n;
+          if ((ABL & 64) && v[0] != 12345.f) continue;                    // (lab, ABL 64: no stores)
           if (VEC) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
           else
             for (int j = 0; j < 4; ++j) if (n + j < a.D) dst[j] = v[j];
@@ -638,7 +639,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
         for (int ni = 0; ni < 4; ++ni) {
           const int n = n0 + nh * 128 + wm * 64 + ni * 16 + g * 4;
           const f32x4 v = acc[nh][ni][mh][mi];
-          *(float4*)(slab + (int64_t)m * a.Fp + n) = make_float4(v[0], v[1], v[2], v[3]);
+          if (!(ABL & 64) || v[0] == 12345.f) *(float4*)(slab + (int64_t)m * a.Fp + n) = make_float4(v[0], v[1], v[2], v[3]);   // (lab, ABL 64: no stores)
         }
     }
 }
@@ -916,7 +917,7 @@ static void launch_fwd_ph_t(const FwdArgs& a, hipStream_t s) {
         }                                                                                              \
         return;                                                                                        \
       }
-      VV_LAB_FWP(1) VV_LAB_FWP(2) VV_LAB_FWP(6) VV_LAB_FWP(8) VV_LAB_FWP(14)
+      VV_LAB_FWP(1) VV_LAB_FWP(2) VV_LAB_FWP(3) VV_LAB_FWP(6) VV_LAB_FWP(8) VV_LAB_FWP(14) VV_LAB_FWP(64) VV_LAB_FWP(67)
 #undef VV_LAB_FWP
     }
   }
@@ -960,7 +961,7 @@ static void launch_wgrad_ph_t(const WgradArgs& a, hipStream_t s) {
         VV_LAUNCH((k_wgrad_gemm_ph<T, N>), grid, block, PH_WG_LDS_BYTES, s, a);                         \
         return;                                                                                        \
       }
-      VV_ABL_WGP(1) VV_ABL_WGP(2) VV_ABL_WGP(3) VV_ABL_WGP(4) VV_ABL_WGP(6) VV_ABL_WGP(7) VV_ABL_WGP(8) VV_ABL_WGP(9)
+      VV_ABL_WGP(1) VV_ABL_WGP(2) VV_ABL_WGP(3) VV_ABL_WGP(4) VV_ABL_WGP(6) VV_ABL_WGP(7) VV_ABL_WGP(8) VV_ABL_WGP(9) VV_ABL_WGP(64) VV_ABL_WGP(71)
 #undef VV_ABL_WGP
     }
   }
