@@ -565,8 +565,17 @@ def main():
                     "dense_equivalent_flop_per_launch": dense_flop,
                     "dense_equivalent_achieved": dense_flop / (dom_ms * 1e-3) / 1e12}
         else:
-            # score_loss: reads every instance's ip2 row (fp32) once, writes its 16-bit gradient row once
-            nbytes = R * D * 4.0 + R * D * 2.0
+            if args.dedup == "on" and DROPOUT == 0 and dom == "segsum":
+                # k_seg_bwd: reads every distinct row's ip2 row (fp32) and the 16-byte record of every instance once, the two
+                # vectors of every item once; writes a 16-bit gradient row per distinct row
+                nbytes = U * D * 4.0 + R * 16.0 + B_PER_GPU * 2 * D * 4.0 + U * D * 2.0
+            elif args.dedup == "on" and DROPOUT == 0:
+                # k_score_fwd / k_score_stream: reads every instance's ip2 row (fp32) once; writes a record per instance and two
+                # vectors per item
+                nbytes = R * D * 4.0 + R * 16.0 + B_PER_GPU * 2 * D * 4.0
+            else:
+                # k_score_loss: reads every instance's ip2 row (fp32) once, writes its 16-bit gradient row once
+                nbytes = R * D * 4.0 + R * D * 2.0
             ach = nbytes / (dom_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes}

@@ -91,3 +91,26 @@ def test_shard_of_full_batch_matches_oracle(setup, oracle):
           (rel(dW, refq["dW"]), rel(db, refq["db"]), rel(refq["dW"], ref["dW"])))
     assert rel(dW, refq["dW"]) <= 2e-3 and rel(db, refq["db"]) <= 2e-3
     assert rel(dW, ref["dW"]) <= 5e-2 and rel(db, ref["db"]) <= 5e-2
+
+
+def test_sibling_lead_forward_kernel_is_bit_identical(setup, monkeypatch):
+    """VV_FWD_LEAD=1: the forward GEMM whose column-half siblings ask for different A half-tiles a K-tile early (a different
+    LDS ring and issue order, the same MFMA order): every output bit as the default kernel's."""
+    vv, ds, idx, W, b, eng = setup
+    cfg = vv.StepConfig(B, C, Nn)
+    eng.forward_backward(cfg, idx)
+    ip2 = eng.blobs(cfg)["ip2"].copy()
+    dW, db = eng.grads()
+    try:
+        monkeypatch.setenv("VV_FWD_LEAD", "1")
+        e2 = vv.Engine(0, "f16")                      # (the switch is read when a context is created)
+        e2.table_synth(ds.seed, ds.n_rows, F)
+        e2.params_set(W, b)
+        e2.forward_backward(cfg, idx)
+        ip2_l = e2.blobs(cfg)["ip2"]
+        dW_l, db_l = e2.grads()
+        assert np.array_equal(ip2, ip2_l) and np.array_equal(dW, dW_l) and np.array_equal(db, db_l)
+        del e2
+    finally:
+        monkeypatch.setenv("VV_FWD_LEAD", "0")
+        vv.Engine(0, "f16")                           # back to the default kernel for the tests that follow

@@ -940,10 +940,12 @@ __global__ __launch_bounds__(256) void k_seg_bwd(SegBwdArgs a) {
     SegRec mine; mine.alpha = 0.f; mine.beta = 0.f; mine.vec = 0; mine.pad = 0x7fffffff;
     if (n > 1 && n <= 64 && lane < n) mine = a.rec[b + lane];
     float4 xr0[CH], xr1[CH];
+    if (CH == 1) {                                    // (D = 1024 with its long segments: the early row costs more in registers than it hides -- 0.437 -> 0.473 ms at cfg 5)
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const float* xp = a.H + (int64_t)u * D + 512 * c + c0;
-      xr0[c] = *(const float4*)xp; xr1[c] = *(const float4*)(xp + 4);
+      for (int c = 0; c < CH; ++c) {
+        const float* xp = a.H + (int64_t)u * D + 512 * c + c0;
+        xr0[c] = *(const float4*)xp; xr1[c] = *(const float4*)(xp + 4);
+      }
     }
     if (u + u_step < U) { seg_b = a.seg_start[u + u_step]; seg_e = a.seg_start[u + u_step + 1]; }
     float acc[CH][8];
@@ -1025,6 +1027,10 @@ __global__ __launch_bounds__(256) void k_seg_bwd(SegBwdArgs a) {
     }
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
+      if (CH != 1) {
+        const float* xp = a.H + (int64_t)u * D + 512 * c + c0;
+        xr0[c] = *(const float4*)xp; xr1[c] = *(const float4*)(xp + 4);
+      }
       const float4 x0 = xr0[c], x1 = xr1[c];
       const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
       float g[8];

@@ -22,7 +22,7 @@ constexpr int GEMM_LDS_BYTES = 4 * LDS_TILE_BYTES;    // {A,B} x 2 buffers = 128
 constexpr int F_ALIGN = 256;   // table / W row length (K of fwd, N of wgrad)
 constexpr int D_ALIGN = 256;   // W rows (N of fwd), dY row length (M of wgrad)
 constexpr int R_ALIGN = 256;   // batch rows (M of fwd, K of wgrad)
-constexpr int SGD_BLOCKS = 2048;
+constexpr int SGD_BLOCKS = 1024;
 
 inline __host__ __device__ int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
