@@ -193,14 +193,18 @@ def main():
     cpu_bind = "none (one rank)"
     if world > 1 and args.cpu_bind == "auto":
         # before the sampler's threads and the collective library's helper threads exist: they inherit the mask
-        from videovector_amd import hostbind
-        ndev = max(1, torch.cuda.device_count())
-        n_local = int(os.environ.get("LOCAL_WORLD_SIZE", world))
-        pci = []
-        for r in range(n_local):
-            pr = torch.cuda.get_device_properties(r % ndev)
-            pci.append((pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id))
-        cpu_bind = hostbind.bind(local_rank, pci)
+        try:
+            from videovector_amd import hostbind
+            ndev = max(1, torch.cuda.device_count())
+            n_local = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+            pci = []
+            for r in range(n_local):
+                pr = torch.cuda.get_device_properties(r % ndev)
+                pci.append((pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id))
+            cpu_bind = hostbind.bind(local_rank, pci)
+        except Exception as e:       # an unexpected topology must not cost the run: unbound ranks are merely slower
+            cpu_bind = "not bound (%s: %s)" % (type(e).__name__, e)
+            print("rank %d: cpu binding skipped: %s" % (rank, e), file=sys.stderr)
     elif world > 1:
         cpu_bind = "off"
     if world > 1:
