@@ -1,0 +1,12 @@
+# A/B of environment switches on one box: bash tools/lab/ab_env.sh "LABEL1:ENV1=.. ENV2=.." "LABEL2:..." ...
+cd $GRAFT_REPO_ROOT
+for r in 1 2 3; do
+  for spec in "$@"; do
+    label="${spec%%:*}"; envs="${spec#*:}"
+    env $envs timeout 300 python bench.py --steps 400 --warmup 20 --no-cpu-baseline --no-extra-legs > gpurun_out/ab.log 2>&1
+    echo "$label: $(python3 -c "
+import json
+l=[x for x in open('gpurun_out/ab.log') if x.startswith('{')]
+d=json.loads(l[-1]); print(round(d['ms_per_step'],4), d['kernels_ms'])")"
+  done
+done

@@ -18,6 +18,15 @@
 
 namespace vv {
 
+// 16-byte accesses with the non-temporal hint (streams that nobody reads again soon)
+__device__ __forceinline__ float4 nt_load4(const float* p) {
+  const f32x4 v = __builtin_nontemporal_load((const f32x4*)p);
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void nt_store4(float* p, const float4& v) {
+  __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, (f32x4*)p);
+}
+
 constexpr int SL_THREADS = 256;
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -944,7 +953,7 @@ __global__ __launch_bounds__(256) void k_seg_bwd(SegBwdArgs a) {
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
         const float* xp = a.H + (int64_t)u * D + 512 * c + c0;
-        xr0[c] = *(const float4*)xp; xr1[c] = *(const float4*)(xp + 4);
+        xr0[c] = *(const float4*)xp; xr1[c] = *(const float4*)(xp + 4);      // (as non-temporal loads: no gain, profiles/r03_step_ablations.txt 5d)
       }
     }
     if (u + u_step < U) { seg_b = a.seg_start[u + u_step]; seg_e = a.seg_start[u + u_step + 1]; }
@@ -1225,12 +1234,12 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
          i += (int64_t)nblk * 256) {
       const int d = d0 + (int)(i / f4), f = fb + (int)(i % f4) * 4;
       const float* p = a.slabs + (int64_t)d * a.Fp + f;
-      float4 s = *(const float4*)p;
+      float4 s = nt_load4(p);
       int k = 1;
       if (a.S == 8) {                  // the usual split: all eight loads in flight at once, summed in slab order
         float4 t[7];
 #pragma unroll
-        for (int u = 0; u < 7; ++u) t[u] = *(const float4*)(p + (u + 1) * slab_sz);
+        for (int u = 0; u < 7; ++u) t[u] = nt_load4(p + (u + 1) * slab_sz);
 #pragma unroll
         for (int u = 0; u < 7; ++u) { s.x += t[u].x; s.y += t[u].y; s.z += t[u].z; s.w += t[u].w; }
         k = 8;
@@ -1306,11 +1315,11 @@ __global__ __launch_bounds__(256) void k_sgd(SgdArgs a) {
       const int d = (int)(i / f4), fl = (int)(i % f4) * 4, f = a.f_begin + fl;
       const int64_t o = (int64_t)d * a.F + f;
       const int64_t og = a.chunked ? (int64_t)a.D * a.f_begin + (int64_t)d * fc + fl : o;     // chunk-major gradient buffer
-      float4 w = *(const float4*)(a.W + o), h = *(const float4*)(a.hW + o);
-      const float4 g = *(const float4*)(a.grads + og);
+      float4 w = nt_load4(a.W + o), h = nt_load4(a.hW + o);
+      const float4 g = nt_load4(a.grads + og);
       w.x = upd(w.x, g.x, h.x); w.y = upd(w.y, g.y, h.y); w.z = upd(w.z, g.z, h.z); w.w = upd(w.w, g.w, h.w);
-      *(float4*)(a.W + o) = w;
-      *(float4*)(a.hW + o) = h;
+      nt_store4(a.W + o, w);
+      nt_store4(a.hW + o, h);
       const uint32_t lo = T::from_float(w.x * sw) | ((uint32_t)T::from_float(w.y * sw) << 16);
       const uint32_t hi = T::from_float(w.z * sw) | ((uint32_t)T::from_float(w.w * sw) << 16);
       if (a.pub_flag) __hip_atomic_store((unsigned long long*)(a.Wh + (int64_t)d * a.Fp + f), ((unsigned long long)hi << 32) | lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -639,6 +639,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
         for (int ni = 0; ni < 4; ++ni) {
           const int n = n0 + nh * 128 + wm * 64 + ni * 16 + g * 4;
           const f32x4 v = acc[nh][ni][mh][mi];
+          // (plain stores: as non-temporal ones the 67 MB go straight to HBM and the kernel takes 8 us longer, profiles/r03_step_ablations.txt 5d)
           if (!(ABL & 64) || v[0] == 12345.f) *(float4*)(slab + (int64_t)m * a.Fp + n) = make_float4(v[0], v[1], v[2], v[3]);   // (lab, ABL 64: no stores)
         }
     }
