@@ -50,6 +50,11 @@ __device__ __forceinline__ void ph_glds16_at(const void* gsrc, unsigned lds_addr
   const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_addr);
   asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(m0v), "v"(gsrc) : "m0", "memory");
 }
+// ... with the non-temporal hint (a stream the L2 need not keep)
+__device__ __forceinline__ void ph_glds16_at_nt(const void* gsrc, unsigned lds_addr) {
+  const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_addr);
+  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off nt" :: "s"(m0v), "v"(gsrc) : "m0", "memory");
+}
 // the same with the source 256 bytes further on (the upper 128-column half of a k-major operand): an immediate
 // offset of the instruction instead of a second address register pair.  The hardware adds the instruction offset to
 // the LDS address as well as to the global one (LDS_ADDR = M0 base + inst_offset + lane * size), so the LDS base is
@@ -154,7 +159,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const uint16_t* src = q == 0 ? srcA[0][i] : q == 1 ? srcB[0][i] : q == 2 ? srcB[1][i] : srcA[1][i];
-      ph_glds16_at(src + k * BK, lds_wave + slot * PH_SLOT + i * 8192);
+      if ((ABL & 128) && (q == 0 || q == 3)) ph_glds16_at_nt(src + k * BK, lds_wave + slot * PH_SLOT + i * 8192);   // (lab, ABL 128: gathered rows non-temporal)
+      else if ((ABL & 256) && (q == 1 || q == 2)) ph_glds16_at_nt(src + k * BK, lds_wave + slot * PH_SLOT + i * 8192);   // (lab, ABL 256: W non-temporal)
+      else ph_glds16_at(src + k * BK, lds_wave + slot * PH_SLOT + i * 8192);
     }
   };
 #define PH_WAITQ() PH_WAIT(8)                  /* everything but the four youngest half-tiles has landed */
@@ -918,7 +925,7 @@ static void launch_fwd_ph_t(const FwdArgs& a, hipStream_t s) {
         }                                                                                              \
         return;                                                                                        \
       }
-      VV_LAB_FWP(1) VV_LAB_FWP(2) VV_LAB_FWP(3) VV_LAB_FWP(6) VV_LAB_FWP(8) VV_LAB_FWP(14) VV_LAB_FWP(64) VV_LAB_FWP(67)
+      VV_LAB_FWP(1) VV_LAB_FWP(2) VV_LAB_FWP(3) VV_LAB_FWP(6) VV_LAB_FWP(8) VV_LAB_FWP(14) VV_LAB_FWP(64) VV_LAB_FWP(67) VV_LAB_FWP(128) VV_LAB_FWP(256)
 #undef VV_LAB_FWP
     }
   }
