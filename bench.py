@@ -349,7 +349,7 @@ def main():
     def lr_at(it):     # shipped solver: inv policy, base 1e-3, gamma 1e-3, power .75
         return 1e-3 * (1.0 + 1e-3 * it) ** -0.75
 
-    KERNELS = ("dedup", "fwd_gemm", "score_loss", "segsum", "guard", "wgrad_gemm", "reduce", "sgd")
+    KERNELS = ("dedup", "fwd_gemm", "score_loss", "segsum", "guard", "wgrad_gemm", "reduce", "sgd", "reduce_sgd")
     GEMMS = ("fwd_gemm",)      # timed INSIDE the timed region: the dominant kernel (the roofline's); the others on the same steps of the per-step leg
 
     class Run:

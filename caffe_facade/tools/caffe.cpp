@@ -137,7 +137,7 @@ static int time_net() {
   CHECK_EQ(vv_synchronize(ctx), 0);
   clock_gettime(CLOCK_MONOTONIC, &t1);
   const double total_ms = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
-  const char* kernels[] = {"dedup", "fwd_gemm", "score_loss", "segsum", "wgrad_gemm", "reduce", "sgd"};
+  const char* kernels[] = {"dedup", "fwd_gemm", "score_loss", "segsum", "wgrad_gemm", "reduce", "sgd", "reduce_sgd"};
   for (const char* k : kernels) {
     double ms = 0; int64_t n = 0;
     CHECK_EQ(vv_profile_get(ctx, k, &ms, &n), 0);

@@ -248,14 +248,17 @@ def test_kernel_timing_hook_samples_the_nth_steps_and_honours_the_selection(vv):
     eng.profile_enable(4)
     for _ in range(10):
         eng.step(cfg, idx)
-    got = {k: eng.profile_get(k) for k in ("dedup", "fwd_gemm", "score_loss", "segsum", "wgrad_gemm", "reduce", "sgd")}
+    got = {k: eng.profile_get(k) for k in ("dedup", "fwd_gemm", "score_loss", "segsum", "wgrad_gemm", "reduce", "sgd", "reduce_sgd")}
     assert got["fwd_gemm"][1] == 2 and got["wgrad_gemm"][1] == 2          # steps 4 and 8 of the 10
     assert got["fwd_gemm"][0] > 0 and got["wgrad_gemm"][0] > 0
-    assert all(got[k][1] == 0 for k in ("dedup", "score_loss", "segsum", "reduce", "sgd"))
+    assert all(got[k][1] == 0 for k in ("dedup", "score_loss", "segsum", "reduce", "sgd", "reduce_sgd"))
     eng.profile_select(None)
     eng.profile_enable(1)
     eng.step(cfg, idx)
-    assert all(eng.profile_get(k)[1] == 1 for k in ("dedup", "fwd_gemm", "score_loss", "segsum", "wgrad_gemm", "reduce", "sgd"))
+    assert all(eng.profile_get(k)[1] == 1 for k in ("dedup", "fwd_gemm", "score_loss", "segsum", "wgrad_gemm"))
+    # the reduction and the update: one launch (k_reduce_sgd, the default) or two (VV_FUSE_UPDATE=0)
+    n = {k: eng.profile_get(k)[1] for k in ("reduce", "sgd", "reduce_sgd")}
+    assert n in ({"reduce": 0, "sgd": 0, "reduce_sgd": 1}, {"reduce": 1, "sgd": 1, "reduce_sgd": 0})
     eng.profile_enable(False)
     eng.close()
 

@@ -1,0 +1,62 @@
+"""The reduction and the update in one launch (k_reduce_sgd, the lazy reduction of api.hip): bit for bit the parameters,
+gradients and losses of the two-launch form (VV_FUSE_UPDATE=0), whoever asks for what in between."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import videovector_amd as vv
+from videovector_amd.synth import SyntheticVideos, init_weights
+B, C, Nn, F, D = 256, 5, 50, 4096, 512
+ds = SyntheticVideos(seed=7, n_videos=512)
+smp = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, batch_size=B, context_size=C, num_negative_samples=Nn,
+                 max_buffer_size=5000, negative_swap_percentage=50)
+W, b = init_weights(7, D, F)
+eng = vv.Engine(0, sys.argv[1])
+eng.table_synth(ds.seed, ds.n_rows, F)
+eng.params_set(W, b)
+solver = int(sys.argv[2])
+out = {}
+losses = []
+for it in range(12):
+    idx = smp.next()
+    idx = idx[0] if isinstance(idx, tuple) else idx
+    cfg = vv.StepConfig(B, C, Nn, lr=0.05, momentum=0.0 if solver == 2 else 0.9, weight_decay=5e-4)     # (AdaGrad takes no momentum, solver.hpp:121-122)
+    cfg.set("solver_type", solver)
+    if solver == 2: cfg.set("delta", 1e-8)
+    eng.forward_backward(cfg, idx)
+    if it %% 4 == 1: losses.append(eng.loss())              # loss asked for BEFORE the update: the plain reduction runs
+    if it %% 4 == 2: out["dW_before_%%d" %% it] = eng.grads()[0]
+    eng.apply_update(cfg)
+    if it %% 4 == 3: losses.append(eng.loss())              # ... and after it
+    if it == 7: out["dW_after_7"], out["db_after_7"] = eng.grads()
+    if it == 5: eng.apply_update(cfg)                       # two updates in a row
+Wn, bn, hW, hb = eng.params_get()
+out.update(W=Wn, b=bn, hW=hW, hb=hb, losses=np.array(losses, dtype=np.float64), stats=np.array(eng.grad_scale_stats(), dtype=np.float64))
+np.savez(sys.argv[3], **out)
+"""
+
+
+def _run(tmp_path, prec, solver, fuse):
+    out = tmp_path / ("o_%s_%d_%d.npz" % (prec, solver, fuse))
+    env = dict(os.environ, VV_FUSE_UPDATE=str(fuse))
+    r = subprocess.run([sys.executable, "-c", CHILD % ROOT, prec, str(solver), str(out)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return np.load(out)
+
+
+@pytest.mark.parametrize("prec,solver", [("f16", 0), ("f16", 1), ("f16", 2), ("bf16", 0)])
+def test_fused_update_is_bit_identical(tmp_path, prec, solver):
+    a, b = _run(tmp_path, prec, solver, 0), _run(tmp_path, prec, solver, 1)
+    assert set(a.files) == set(b.files)
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
+    assert np.isfinite(a["W"]).all() and np.abs(a["hW"]).max() > 0

@@ -32,7 +32,7 @@ def run(mode, steps):
     t0 = time.perf_counter(); go(150, n); eng.synchronize(); el = time.perf_counter() - t0
     eng.profile_enable(8)
     go(150, 150 + 200); eng.synchronize()
-    prof = {k: eng.profile_get(k)[0] for k in ("fwd_gemm", "score_loss", "segsum", "guard", "wgrad_gemm", "reduce", "sgd")}
+    prof = {k: eng.profile_get(k)[0] for k in ("fwd_gemm", "score_loss", "segsum", "guard", "wgrad_gemm", "reduce", "sgd", "reduce_sgd")}
     eng.profile_enable(False)
     print("   kernels (us): " + "  ".join("%s %.1f" % (k, v * 1e3) for k, v in prof.items()), flush=True)
     print("%-22s %.4f ms/step  loss %.6f" % (mode + (" delay " + os.environ["VV_COMM_TEST_DELAY_US"] if os.environ.get("VV_COMM_TEST_DELAY_US") else ""), el / steps * 1e3, eng.loss()[0]), flush=True)

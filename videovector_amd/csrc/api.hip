@@ -121,8 +121,8 @@ static int create_init(vv_ctx* c) {
   HIPCHK(hipMalloc(&c->scales, sizeof(Scales)));
   Scales h = {1.f, 1.f, 1.f, 0u};
   HIPCHK(hipMemcpy(c->scales, &h, sizeof(h), hipMemcpyHostToDevice));
-  HIPCHK(hipMalloc(&c->wmax_blocks, SGD_BLOCKS * sizeof(float)));
-  HIPCHK(hipMemset(c->wmax_blocks, 0, SGD_BLOCKS * sizeof(float)));
+  HIPCHK(hipMalloc(&c->wmax_blocks, 2 * WMAX_SLOTS * sizeof(float)));
+  HIPCHK(hipMemset(c->wmax_blocks, 0, 2 * WMAX_SLOTS * sizeof(float)));
   HIPCHK(hipMalloc(&c->loss2, 2 * sizeof(float)));
   HIPCHK(hipMemset(c->loss2, 0, 2 * sizeof(float)));
   const char* tr = getenv("VV_WGRAD_TR");
@@ -430,12 +430,14 @@ int vv_params_set(vv_ctx* c, int32_t D, const float* W, const float* b, const fl
   if (hb) HIPCHK(hipMemcpy(c->hb, hb, D * 4, hipMemcpyHostToDevice)); else HIPCHK(hipMemset(c->hb, 0, D * 4));
   // scale for the half copy from max|W|, then convert (a scale update still pending from an earlier SGD step is void)
   c->scale_pending = false;
+  c->red_lazy = false;                      // (a gradient nobody asked for goes with the parameters it belonged to)
   HIPCHK(hipMemsetAsync(&c->scales->wmax_bits, 0, sizeof(unsigned), c->stream));
   launch_absmax(c->W, (int64_t)nW, &c->scales->wmax_bits, c->stream);
-  launch_scale_update(c->prec, c->scales, nullptr, c->stream);
+  launch_scale_update(c->prec, c->scales, nullptr, 0, c->stream);
   launch_w_convert(c->prec, c->W, c->Wh, D, F, c->Dp, c->Fp, c->scales, c->stream);
   // seed the running max for the first SGD step's scale update
   launch_absmax(c->W, (int64_t)nW, &c->scales->wmax_bits, c->stream);
+  c->wmax_seed_live = true;
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
   c->have_fwd = false;
@@ -558,8 +560,24 @@ static int stage_acquire(vv_ctx* c, size_t bytes, int* slot) {
 
 static void flush_scale_update(vv_ctx* c) {
   if (!c->scale_pending) return;
-  launch_scale_update(c->prec, c->scales, c->wmax_blocks, c->stream);
+  launch_scale_update(c->prec, c->scales, c->wmax_blocks + c->wmax_cur * WMAX_SLOTS, c->wmax_n, c->stream);
   c->scale_pending = false;
+  c->wmax_seed_live = false;               // (the scale update folds and clears Scales::wmax_bits)
+}
+
+// The reduction vv_forward_backward left undone (vv_ctx::red_lazy): run it now, as the plain k_reduce -- somebody reads the
+// gradient or the loss before an update.
+static int reduce_now(vv_ctx* c) {
+  if (!c->red_lazy) return VV_OK;
+  c->red_lazy = false;
+  ReduceArgs ra = c->red_args;
+  if (c->scale_pending) {
+    ra.scale_sc = c->scales; ra.scale_wmax = c->wmax_blocks + c->wmax_cur * WMAX_SLOTS; ra.scale_n = c->wmax_n; ra.scale_prec = c->prec;
+    c->scale_pending = false; c->wmax_seed_live = false;
+  }
+  PROFILED(c, "reduce", launch_reduce(ra, c->stream));
+  HIPCHK(hipGetLastError());
+  return VV_OK;
 }
 
 // F-chunks of the overlapped update: n column blocks of W whose widths fall off geometrically (ratio 0.6: e.g. 51 / 31 / 18 %
@@ -916,9 +934,25 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
     ra.n_chunks = chunk_plan(c);
     for (int i = 0; i <= ra.n_chunks; ++i) ra.chunk_c0[i] = std::min(c->F, c->chunk_kt[i] * BK);
   }
+  // Lazy reduction (vv_ctx::red_lazy): with no communicator in the way, dW stays in the slabs until somebody wants it --
+  // normally vv_apply_update, which reduces and updates in one launch.  VV_FUSE_UPDATE=0: reduce here, as ever.
+  static const bool fuse_on = !(getenv("VV_FUSE_UPDATE") && atoi(getenv("VV_FUSE_UPDATE")) == 0);
+  const bool lazy = fuse_on && !c->comm && c->grads == c->grads_own && c->F % 4 == 0 && c->S <= 8 &&
+                    (int64_t)c->D * (c->F / 4) <= (int64_t)WMAX_SLOTS * 256;
   // the W -> half scale update the previous vv_apply_update left pending rides in this step's reduction launch
-  if (c->scale_pending) { ra.scale_sc = c->scales; ra.scale_wmax = c->wmax_blocks; ra.scale_prec = c->prec; c->scale_pending = false; }
+  if (!lazy && c->scale_pending) {
+    ra.scale_sc = c->scales; ra.scale_wmax = c->wmax_blocks + c->wmax_cur * WMAX_SLOTS; ra.scale_n = c->wmax_n; ra.scale_prec = c->prec;
+    c->scale_pending = false; c->wmax_seed_live = false;
+  }
   PROFILED(c, "wgrad_gemm", launch_wgrad_gemm(c->prec, wa, s));
+  c->red_lazy = false;
+  if (lazy) {
+    c->red_args = ra; c->red_lazy = true;
+    c->grads_pending = false; c->grads_chunked = false; c->chunk0_event = false;
+    HIPCHK(hipGetLastError());
+    c->have_fwd = true;
+    return VV_OK;
+  }
   if (chunked && ra.n_chunks > 1 && ra.chunk_c0[1] < c->F) {
     // the first F-chunk is reduced by a launch of its own and an event marks it: the communication stream starts on
     // chunk 0 (all-reduce, SGD) while the other chunks, db and the loss are still being reduced here
@@ -1037,12 +1071,34 @@ int vv_apply_update(vv_ctx* c, const vv_step_cfg* cfg) {
   const bool overlapped = c->comm && c->grads_pending && c->grads_chunked;
   if (!overlapped && c->grads_pending && (rc = vv_allreduce_grads(c))) return rc;     // data-parallel: the update consumes the SUM over the ranks
   SgdArgs a;
-  a.W = c->W; a.b = c->b; a.hW = c->hW; a.hb = c->hb; a.grads = c->grads; a.Wh = c->Wh; a.scales = c->scales; a.wmax_blocks = c->wmax_blocks;
+  float* const wmax_new = c->wmax_blocks + (1 - c->wmax_cur) * WMAX_SLOTS;     // the buffer the previous update did not write
+  a.W = c->W; a.b = c->b; a.hW = c->hW; a.hb = c->hb; a.grads = c->grads; a.Wh = c->Wh; a.scales = c->scales; a.wmax_blocks = wmax_new;
   a.D = c->D; a.F = c->F; a.Dp = c->Dp; a.Fp = c->Fp;
   a.rate = cfg->lr; a.momentum = cfg->momentum; a.weight_decay = cfg->weight_decay;
   a.lr_mult_w = cfg->lr_mult[0]; a.lr_mult_b = cfg->lr_mult[1];
   a.decay_mult_w = cfg->decay_mult[0]; a.decay_mult_b = cfg->decay_mult[1];
   a.reg = cfg->reg; a.solver_type = cfg->solver_type; a.delta = cfg->delta;
+  if (c->red_lazy && !overlapped) {
+    // the reduction is still due: reduce and update in one launch (k_reduce_sgd)
+    FusedUpdArgs fa;
+    fa.r = c->red_args; fa.g = a; fa.prec = c->prec;
+    fa.recompute_scale = c->scale_pending ? 1 : 0;
+    fa.wmax_prev = c->wmax_blocks + c->wmax_cur * WMAX_SLOTS; fa.wmax_prev_n = c->wmax_n;
+    c->red_lazy = false;
+    int n_new = 0;
+    PROFILED(c, "reduce_sgd", (n_new = launch_reduce_sgd(fa, c->stream)));
+    if (fa.recompute_scale && c->wmax_seed_live) {       // vv_params_set's seed has now been folded into a scale: clear it behind the launch
+      HIPCHK(hipMemsetAsync(&c->scales->wmax_bits, 0, sizeof(unsigned), c->stream));
+      c->wmax_seed_live = false;
+    }
+    c->wmax_cur = 1 - c->wmax_cur; c->wmax_n = n_new;
+    c->scale_pending = true;
+    HIPCHK(hipGetLastError());
+    c->iter++;
+    c->prof_calls++;
+    return VV_OK;
+  }
+  if ((rc = reduce_now(c))) return rc;
   flush_scale_update(c);               // two updates in a row without a step between them
   if (overlapped) {
     // Exact synchronous SGD with the exchange hidden behind the NEXT step's forward GEMM: behind one event of the compute
@@ -1079,6 +1135,7 @@ int vv_apply_update(vv_ctx* c, const vv_step_cfg* cfg) {
   // is left pending and performed by one extra workgroup of the next step's k_reduce; anything else that touches the
   // scales or the parameters first flushes it as its own launch.
   c->scale_pending = true;
+  c->wmax_cur = 1 - c->wmax_cur; c->wmax_n = SGD_BLOCKS;
   HIPCHK(hipGetLastError());
   c->iter++;
   c->prof_calls++;
@@ -1096,6 +1153,7 @@ int vv_loss_get(vv_ctx* c, float* loss, float* violations) {
   if (!c->have_fwd) return fail(VV_ERR_STATE, "vv_loss_get: no forward pass yet");
   HIPCHK(hipSetDevice(c->device));
   if (c->gate_err && *(volatile int32_t*)c->gate_err) { const int rcj = comm_join(c); if (rcj) return rcj; }
+  { const int rcr = reduce_now(c); if (rcr) return rcr; }
   float h[2];
   HIPCHK(hipMemcpyAsync(h, c->loss2, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -1107,6 +1165,7 @@ int vv_loss_get(vv_ctx* c, float* loss, float* violations) {
 int vv_grads_device(vv_ctx* c, void** dev_ptr, int64_t* n_floats) {
   if (!c || !dev_ptr || !n_floats) return fail(VV_ERR_ARG, "vv_grads_device: NULL argument");
   if (!c->grads) return fail(VV_ERR_STATE, "vv_grads_device: no parameters");
+  { const int rcr = reduce_now(c); if (rcr) return rcr; }      // (whoever reads the buffer on the stream finds the gradient queued in front)
   *dev_ptr = c->grads;
   *n_floats = (int64_t)c->D * c->F + c->D;
   return VV_OK;
@@ -1117,6 +1176,7 @@ int vv_grads_bind(vv_ctx* c, void* dev_ptr) {
   if (!c->grads_own) return fail(VV_ERR_STATE, "vv_grads_bind: no parameters");
   // no synchronisation: kernels already queued keep the pointer they were launched with; the next
   // vv_forward_backward writes, and the next vv_apply_update reads, the newly bound buffer
+  { const int rcr = reduce_now(c); if (rcr) return rcr; }      // (a reduction still due goes to the buffer it was computed for)
   c->grads = dev_ptr ? (float*)dev_ptr : c->grads_own;
   return VV_OK;
 }
@@ -1126,6 +1186,7 @@ int vv_grads_get(vv_ctx* c, float* dW, float* db) {
   if (!c->have_fwd) return fail(VV_ERR_STATE, "vv_grads_get: no backward pass yet");
   HIPCHK(hipSetDevice(c->device));
   { const int rcj = comm_join(c); if (rcj) return rcj; }       // block-wise all-reduces in flight: the buffer is read whole
+  { const int rcr = reduce_now(c); if (rcr) return rcr; }
   HIPCHK(hipStreamSynchronize(c->stream));
   const size_t nW = (size_t)c->D * c->F;
   if (dW && !c->grads_chunked) HIPCHK(hipMemcpy(dW, c->grads, nW * 4, hipMemcpyDeviceToHost));

@@ -1215,7 +1215,7 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
   // a pending W -> half scale update of the PREVIOUS step's SGD kernel rides as the last workgroup (its own one-workgroup
   // launch cost ~5 us of stream time a step: the kernel plus two dependent-launch gaps); this step's k_sgd reads the result
   const int G = (int)gridDim.x - (a.scale_sc ? 1 : 0);
-  if (bid == G) { scale_update_body(a.scale_sc, a.scale_wmax, SGD_BLOCKS, a.scale_prec); return; }
+  if (bid == G) { scale_update_body(a.scale_sc, a.scale_wmax, a.scale_n, a.scale_prec); return; }
   if (a.parts & 2) {
     if (bid == G - 1) { reduce_loss(a); return; }
     const int ndb = (a.D + 15) / 16;
@@ -1384,8 +1384,137 @@ void launch_sgd(int prec, const SgdArgs& a, hipStream_t s) {
 }
 
 __global__ void k_scale_update(Scales* sc, const float* wmax_blocks, int nblocks, int prec) { scale_update_body(sc, wmax_blocks, nblocks, prec); }
-void launch_scale_update(int prec, Scales* sc, const float* wmax_blocks, hipStream_t s) {
-  hipLaunchKernelGGL(k_scale_update, dim3(1), dim3(256), 0, s, sc, wmax_blocks, SGD_BLOCKS, prec);
+void launch_scale_update(int prec, Scales* sc, const float* wmax_blocks, int n_blocks, hipStream_t s) {
+  hipLaunchKernelGGL(k_scale_update, dim3(1), dim3(256), 0, s, sc, wmax_blocks, n_blocks, prec);
+}
+
+// ------------------------------------------------------------------------------- reduction + update in one launch ----
+// k_reduce_sgd = k_reduce followed by k_sgd, element by element: a thread sums its 16 bytes of the eight slabs, scales them
+// (the gradient, stored for whoever asks: non-temporal), and applies the solver's rule to the same 16 bytes of W right
+// there -- the gradient is not written and read back between two launches, and one dependent launch boundary goes.  Same
+// sums in the same order, the same rule(): bit for bit the parameters of the two-launch form (tests/test_gpu_fused_update.py).
+// The W -> half scale that k_scale_update would have computed between the two launches is derived by every parameter
+// workgroup for itself from the previous update's per-block maxima (4-8 KB out of L2, while its slab loads fly).
+template <typename T>
+__global__ __launch_bounds__(256) void k_reduce_sgd(FusedUpdArgs fa) {
+  const ReduceArgs& a = fa.r;
+  const SgdArgs& g = fa.g;
+  const int ndb = (a.D + 15) / 16;
+  const int n_special = ndb + 1;
+  const int bid = (int)blockIdx.x < n_special ? (int)gridDim.x - n_special + (int)blockIdx.x : (int)blockIdx.x - n_special;
+  const int G = (int)gridDim.x;
+  auto rule = [&](float w, float gr, float& h, float lr, float dc) {       // (k_sgd's)
+    if (dc != 0.f) gr += dc * (g.reg == 2 ? w : (float)((w > 0.f) - (w < 0.f)));
+    float u;
+    if (g.solver_type == 1) { const float h0 = h; h = lr * gr + g.momentum * h0; u = (1.f + g.momentum) * h - g.momentum * h0; }
+    else if (g.solver_type == 2) { h += gr * gr; u = lr * (gr / (sqrtf(h) + g.delta)); }
+    else { h = lr * gr + g.momentum * h; u = h; }
+    return w - u;
+  };
+  if (bid == G - 1) { reduce_loss(a); return; }
+  if (bid >= G - 1 - ndb) {
+    // bias columns: the partials' sum is the gradient (stored), and the bias is updated from it on the spot
+    __shared__ float part[16][16];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int d = (bid - (G - 1 - ndb)) * 16 + tx;
+    float s = 0.f;
+    if (d < a.D) {
+      const float* p = a.dbp + d;
+      const int nb = a.db_rows > 0 ? a.db_rows : a.B;
+      int b = ty;
+      for (; b + 112 < nb; b += 128) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(b + 16 * u) * a.D];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      for (; b < nb; b += 16) s += p[(int64_t)b * a.D];
+    }
+    part[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && d < a.D) {
+      float t = 0.f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) t += part[u][tx];
+      a.grads[(int64_t)a.D * a.F + d] = t;
+      float h = g.hb[d];
+      g.b[d] = rule(g.b[d], t, h, g.rate * g.lr_mult_b, g.weight_decay * g.decay_mult_b);
+      g.hb[d] = h;
+    }
+    return;
+  }
+  // ---- parameter workgroups: one 16-byte element per thread
+  const int nblk = G - n_special;
+  const int f4 = a.F / 4;
+  const int64_t i = (int64_t)bid * 256 + threadIdx.x;
+  const bool live = i < (int64_t)a.D * f4;
+  const int d = live ? (int)(i / f4) : 0, f = live ? (int)(i % f4) * 4 : 0;
+  const int64_t slab_sz = (int64_t)a.Dp * a.Fp;
+  const float* p = a.slabs + (int64_t)d * a.Fp + f;
+  const int64_t o = (int64_t)d * a.F + f;
+  float4 t[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) t[u] = (live && u < a.S) ? nt_load4(p + u * slab_sz) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 w = make_float4(0.f, 0.f, 0.f, 0.f), h = w;
+  if (live) { w = nt_load4(g.W + o); h = nt_load4(g.hW + o); }
+  // the scale of the new half copy
+  float sw = g.scales->sw_next;
+  if (fa.recompute_scale) {
+    __shared__ float red[4];
+    float mm = 0.f;
+    for (int k = threadIdx.x; k < fa.wmax_prev_n; k += 256) mm = fmaxf(mm, fa.wmax_prev[k]);
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o2, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mm;
+    __syncthreads();
+    mm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float m = fmaxf(mm, __uint_as_float(g.scales->wmax_bits));     // (vv_params_set's seed; the host clears it behind this launch)
+    sw = 1.f;
+    if (fa.prec == 0 && m > 0.f && isfinite(m)) {
+      int e;
+      frexpf(m, &e);
+      sw = ldexpf(1.f, 12 - e);
+    }
+  }
+  float4 s = t[0];
+  for (int u = 1; u < 8; ++u)
+    if (u < a.S) { s.x += t[u].x; s.y += t[u].y; s.z += t[u].z; s.w += t[u].w; }
+  const float sgf = a.sg_dev ? *a.sg_dev : (a.gg ? a.sg * a.gg->mul : a.sg);
+  const float inv = a.ip_scale / (sgf * a.scales->sx);
+  // (rounded products, as the two-launch form stores them: no contraction into the rule's first multiply-add)
+  const float4 gr = make_float4(__fmul_rn(s.x, inv), __fmul_rn(s.y, inv), __fmul_rn(s.z, inv), __fmul_rn(s.w, inv));
+  const float lr_w = g.rate * g.lr_mult_w, dc_w = g.weight_decay * g.decay_mult_w;
+  float wmax = 0.f;
+  if (live) {
+    nt_store4(a.grads + o, gr);
+    w.x = rule(w.x, gr.x, h.x, lr_w, dc_w); w.y = rule(w.y, gr.y, h.y, lr_w, dc_w);
+    w.z = rule(w.z, gr.z, h.z, lr_w, dc_w); w.w = rule(w.w, gr.w, h.w, lr_w, dc_w);
+    wmax = fmaxf(fmaxf(fabsf(w.x), fabsf(w.y)), fmaxf(fabsf(w.z), fabsf(w.w)));
+    nt_store4(g.W + o, w);
+    nt_store4(g.hW + o, h);
+    const uint32_t lo = T::from_float(w.x * sw) | ((uint32_t)T::from_float(w.y * sw) << 16);
+    const uint32_t hi = T::from_float(w.z * sw) | ((uint32_t)T::from_float(w.w * sw) << 16);
+    *(uint2*)(g.Wh + (int64_t)d * g.Fp + f) = make_uint2(lo, hi);
+  }
+  __shared__ float wm[4];
+#pragma unroll
+  for (int o2 = 32; o2 > 0; o2 >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o2, 64));
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = wmax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    g.wmax_blocks[bid] = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    if (bid == 0) { g.scales->sw_cur = sw; if (fa.recompute_scale) g.scales->sw_next = sw; }
+  }
+  (void)nblk;
+}
+int launch_reduce_sgd(const FusedUpdArgs& a, hipStream_t s) {
+  const int ndb = (a.r.D + 15) / 16;
+  const int nblk = (int)(((int64_t)a.r.D * (a.r.F / 4) + 255) / 256);
+  const dim3 grid(nblk + ndb + 1);
+  if (a.prec == 0) VV_LAUNCH((k_reduce_sgd<F16>), grid, dim3(256), 0, s, a);
+  else VV_LAUNCH((k_reduce_sgd<BF16>), grid, dim3(256), 0, s, a);
+  return nblk;
 }
 
 __global__ __launch_bounds__(256) void k_absmax(const float* x, int64_t n, unsigned* out_bits) {

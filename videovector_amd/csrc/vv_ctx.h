@@ -51,6 +51,13 @@ struct vv_ctx {
   uint16_t* Wh = nullptr; vv::Scales* scales = nullptr; float* wmax_blocks = nullptr;
   int n_cu = 256;                           // compute units of the device
   bool scale_pending = false;               // k_sgd ran, its scale update has not (it rides in the next k_reduce)
+  // wmax_blocks holds two buffers of WMAX_SLOTS per-block maxima: an update writes the one the previous update did not
+  int wmax_cur = 0, wmax_n = 0;             // the buffer the latest update wrote, and how many slots of it
+  bool wmax_seed_live = false;              // Scales::wmax_bits still carries vv_params_set's seed (the next scale update consumes it)
+  // Lazy reduction: vv_forward_backward leaves dW in the split-K slabs (and db / the loss in their partials) when nothing
+  // but an update is likely to want them; vv_apply_update then reduces and updates in ONE launch (k_reduce_sgd), and
+  // anything that reads the gradient or the loss first runs the plain k_reduce (reduce_now in api.hip).
+  bool red_lazy = false; vv::ReduceArgs red_args;
   float* grads = nullptr;           // [D*F + D] (own buffer, or the bound external one)
   float* grads_own = nullptr;
   // per-batch buffers

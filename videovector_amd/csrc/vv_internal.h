@@ -247,7 +247,8 @@ struct ReduceArgs {
                                      //   (boundaries multiples of 4) -- so that every F-chunk is one contiguous all-reduce buffer
   int parts = 3;                     // bit 0: the dW rows, bit 1: db and the loss scalars
   Scales* scale_sc = nullptr;        // non-null: one more workgroup performs the W -> half scale update left pending by the
-  const float* scale_wmax = nullptr; //   previous step's k_sgd (its per-block max |w| slots)
+  const float* scale_wmax = nullptr; //   previous step's k_sgd (its per-block max |w| slots,
+  int scale_n = 0;                   //   this many of them)
   int scale_prec = 0;
 };
 
@@ -276,6 +277,16 @@ struct SgdArgs {
   // consumer polls the flag and runs an agent-scope acquire (FwdArgs::gate).  No separate launch, no L2 write-back.
   int32_t* pub_flag = nullptr; int32_t* pub_count = nullptr; int32_t pub_seq = 0;
 };
+
+// Reduction and update in one launch (k_reduce_sgd; api.hip: the lazy reduction).  r: what k_reduce would have been given (its
+// scale_* fields unused), g: what k_sgd would have been given.  Every workgroup that updates parameters derives the scale of
+// the new half copy for itself from the previous update's per-block maxima (wmax_prev: what k_scale_update folds) when
+// recompute_scale is set, else takes Scales::sw_next as it stands; this update's maxima go to g.wmax_blocks (another buffer).
+struct FusedUpdArgs {
+  ReduceArgs r; SgdArgs g;
+  const float* wmax_prev = nullptr; int wmax_prev_n = 0; int recompute_scale = 0; int prec = 0;
+};
+constexpr int WMAX_SLOTS = 2048;      // slots of one per-block-maxima buffer (k_sgd writes SGD_BLOCKS of them, k_reduce_sgd RED_DW_BLOCKS)
 
 // Kernel timing without extra queue packets: when the ABI layer has armed a pair of events (vv_profile_enable),
 // the launch goes through hipExtLaunchKernelGGL, which stamps the events from the dispatch packet's own
@@ -315,7 +326,8 @@ void launch_reduce(const ReduceArgs& a, hipStream_t s);
 void launch_sgd(int prec, const SgdArgs& a, hipStream_t s);
 void launch_publish(int32_t* flag, int32_t seq, hipStream_t s);
 void launch_delay(int us, hipStream_t s);                             // test hook: occupies s for `us` microseconds       // flag <- seq (agent scope), behind everything queued on s
-void launch_scale_update(int prec, Scales* sc, const float* wmax_blocks, hipStream_t s);
+void launch_scale_update(int prec, Scales* sc, const float* wmax_blocks, int n_blocks, hipStream_t s);
+int launch_reduce_sgd(const FusedUpdArgs& a, hipStream_t s);   // -> the number of per-block maxima it writes
 void launch_table_convert(int prec, const float* src, uint16_t* dst, int64_t n_rows, int F, int Fp,
                           float sx, hipStream_t s);
 void launch_table_synth(int prec, uint16_t* dst, uint64_t seed, int64_t n_rows, int F, int Fp,
