@@ -11,7 +11,7 @@ from collections import defaultdict
 
 root = sys.argv[1]
 NAMES = {"k_fwd_gemm": "fwd_gemm", "k_wgrad_gemm": "wgrad_gemm", "k_score_loss": "score_loss", "k_score_fwd": "score_loss",
-         "k_reduce": "reduce", "k_sgd": "sgd", "k_segsum": "segsum", "k_seg_bwd": "segsum", "k_dd_claim": "dd_claim", "k_dd_leaders": "dd_leaders",
+         "k_reduce_sgd": "reduce_sgd", "k_reduce": "reduce", "k_sgd": "sgd", "k_segsum": "segsum", "k_seg_bwd": "segsum", "k_dd_claim": "dd_claim", "k_dd_leaders": "dd_leaders",
          "k_dd_map": "dd_map", "k_dd_segstart": "dd_segstart", "k_dd_pos": "dd_pos"}
 
 

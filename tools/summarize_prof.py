@@ -12,7 +12,7 @@ root = sys.argv[1]
 
 def short(n):
     n = n.split("(")[0]
-    for k in ("k_fwd_gemm", "k_wgrad_gemm", "k_score_loss", "k_score_fwd", "k_seg_bwd", "k_reduce", "k_sgd", "k_map_rows",
+    for k in ("k_fwd_gemm", "k_wgrad_gemm", "k_score_loss", "k_score_fwd", "k_seg_bwd", "k_reduce_sgd", "k_reduce", "k_sgd", "k_map_rows",
               "k_final_loss", "k_scale_update", "k_segsum", "k_dd_claim", "k_dd_leaders", "k_dd_map", "k_dd_segstart", "k_dd_pos"):
         if k in n:
             return k

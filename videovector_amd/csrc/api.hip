@@ -430,7 +430,7 @@ int vv_params_set(vv_ctx* c, int32_t D, const float* W, const float* b, const fl
   if (hb) HIPCHK(hipMemcpy(c->hb, hb, D * 4, hipMemcpyHostToDevice)); else HIPCHK(hipMemset(c->hb, 0, D * 4));
   // scale for the half copy from max|W|, then convert (a scale update still pending from an earlier SGD step is void)
   c->scale_pending = false;
-  c->red_lazy = false;                      // (a gradient nobody asked for goes with the parameters it belonged to)
+  c->red_lazy = false; c->grads_stale = false;   // (a gradient nobody asked for goes with the parameters it belonged to)
   HIPCHK(hipMemsetAsync(&c->scales->wmax_bits, 0, sizeof(unsigned), c->stream));
   launch_absmax(c->W, (int64_t)nW, &c->scales->wmax_bits, c->stream);
   launch_scale_update(c->prec, c->scales, nullptr, 0, c->stream);
@@ -568,6 +568,15 @@ static void flush_scale_update(vv_ctx* c) {
 // The reduction vv_forward_backward left undone (vv_ctx::red_lazy): run it now, as the plain k_reduce -- somebody reads the
 // gradient or the loss before an update.
 static int reduce_now(vv_ctx* c) {
+  if (c->grads_stale) {
+    // the fused update consumed the slabs without writing dW out; they are untouched since: reduce them now (dW only --
+    // db, the loss and the guard's report were produced by the fused launch)
+    c->grads_stale = false;
+    ReduceArgs ra = c->red_args;
+    ra.parts = 1; ra.scale_sc = nullptr; ra.gmax_host = nullptr;
+    launch_reduce(ra, c->stream);
+    HIPCHK(hipGetLastError());
+  }
   if (!c->red_lazy) return VV_OK;
   c->red_lazy = false;
   ReduceArgs ra = c->red_args;
@@ -945,7 +954,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
     c->scale_pending = false; c->wmax_seed_live = false;
   }
   PROFILED(c, "wgrad_gemm", launch_wgrad_gemm(c->prec, wa, s));
-  c->red_lazy = false;
+  c->red_lazy = false; c->grads_stale = false;        // (the slabs now hold this step's gradient)
   if (lazy) {
     c->red_args = ra; c->red_lazy = true;
     c->grads_pending = false; c->grads_chunked = false; c->chunk0_event = false;
@@ -1084,7 +1093,9 @@ int vv_apply_update(vv_ctx* c, const vv_step_cfg* cfg) {
     fa.r = c->red_args; fa.g = a; fa.prec = c->prec;
     fa.recompute_scale = c->scale_pending ? 1 : 0;
     fa.wmax_prev = c->wmax_blocks + c->wmax_cur * WMAX_SLOTS; fa.wmax_prev_n = c->wmax_n;
-    c->red_lazy = false;
+    static const bool keep_grads = getenv("VV_FUSE_KEEP_GRADS") && atoi(getenv("VV_FUSE_KEEP_GRADS")) != 0;
+    fa.store_grads = keep_grads;
+    c->red_lazy = false; c->grads_stale = !keep_grads;
     int n_new = 0;
     PROFILED(c, "reduce_sgd", (n_new = launch_reduce_sgd(fa, c->stream)));
     if (fa.recompute_scale && c->wmax_seed_live) {       // vv_params_set's seed has now been folded into a scale: clear it behind the launch

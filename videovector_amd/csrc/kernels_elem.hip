@@ -1487,7 +1487,7 @@ __global__ __launch_bounds__(256) void k_reduce_sgd(FusedUpdArgs fa) {
   const float lr_w = g.rate * g.lr_mult_w, dc_w = g.weight_decay * g.decay_mult_w;
   float wmax = 0.f;
   if (live) {
-    nt_store4(a.grads + o, gr);
+    if (fa.store_grads) nt_store4(a.grads + o, gr);
     w.x = rule(w.x, gr.x, h.x, lr_w, dc_w); w.y = rule(w.y, gr.y, h.y, lr_w, dc_w);
     w.z = rule(w.z, gr.z, h.z, lr_w, dc_w); w.w = rule(w.w, gr.w, h.w, lr_w, dc_w);
     wmax = fmaxf(fmaxf(fabsf(w.x), fabsf(w.y)), fmaxf(fabsf(w.z), fabsf(w.w)));

@@ -416,7 +416,7 @@ int vv_op_inner_product_bwd(vv_ctx* c, const float* dY, int64_t R, float ip_regu
   wa.Rp = (int)Rp; wa.Dp = Dp; wa.Fp = c->Fp; wa.S = S; wa.ksteps_per_split = (total_steps + S - 1) / S;
   wa.n_dev = nullptr; wa.zero_row = (int32_t)Rp;
   launch_wgrad_gemm(c->prec, wa, c->stream);
-  c->red_lazy = false;                 // (a lazily kept gradient of the fused step is superseded by this one)
+  c->red_lazy = false; c->grads_stale = false;     // (a lazily kept gradient of the fused step is superseded by this one)
   ReduceArgs ra;
   ra.slabs = s.slabs; ra.S = S; ra.Dp = Dp; ra.Fp = c->Fp; ra.dbp = nullptr; ra.B = 0;
   ra.scales = c->scales; ra.sg = 1.f; ra.sg_dev = s.sgs + 1; ra.grads = c->grads; ra.D = D; ra.F = c->F;

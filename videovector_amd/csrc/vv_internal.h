@@ -285,6 +285,7 @@ struct SgdArgs {
 struct FusedUpdArgs {
   ReduceArgs r; SgdArgs g;
   const float* wmax_prev = nullptr; int wmax_prev_n = 0; int recompute_scale = 0; int prec = 0;
+  int store_grads = 0;       // also write dW to the gradient buffer (0: it stays in the slabs, api.hip materialises it on request)
 };
 constexpr int WMAX_SLOTS = 2048;      // slots of one per-block-maxima buffer (k_sgd writes SGD_BLOCKS of them, k_reduce_sgd RED_DW_BLOCKS)
 
