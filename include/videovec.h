@@ -146,7 +146,11 @@ int vv_forward_backward(vv_ctx* ctx, const vv_step_cfg* cfg, const int32_t* idx,
 int vv_forward_backward_q1(vv_ctx* ctx, const vv_step_cfg* cfg, const int32_t* idx,
                            const int32_t* last_src);
 /* SGDSolver::ComputeUpdateValue + Net::Update (solver.cpp:485-531, net.cpp:803-839,
- * blob.cpp:112-136) on the gradients currently in the gradient buffer. */
+ * blob.cpp:112-136) on the gradients of the last vv_forward_backward.
+ * (Without a communicator the last stage of the backward pass -- the sum of the weight gradient's split-K partials -- is
+ * deferred: called right after vv_forward_backward, vv_apply_update reduces and updates in one launch; vv_loss_get,
+ * vv_grads_get, vv_grads_device and vv_grads_bind run the reduction first if it is still due.  Results are bit for bit
+ * those of the eager order; nothing observable through this interface changes.) */
 int vv_apply_update(vv_ctx* ctx, const vv_step_cfg* cfg);
 /* Both of the above: one iteration of Solver::Solve's loop body (solver.cpp:194,219-220). */
 int vv_step(vv_ctx* ctx, const vv_step_cfg* cfg, const int32_t* idx, int idx_on_device);
