@@ -15,7 +15,7 @@ import sys, numpy as np
 sys.path.insert(0, %r)
 import videovector_amd as vv
 from videovector_amd.synth import SyntheticVideos, init_weights
-B, C, Nn, F, D = 256, 5, 50, 4096, 512
+B, C, Nn, F, D = 256, 5, 50, 4096, int(sys.argv[4])
 ds = SyntheticVideos(seed=7, n_videos=512)
 smp = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, batch_size=B, context_size=C, num_negative_samples=Nn,
                  max_buffer_size=5000, negative_swap_percentage=50)
@@ -45,17 +45,18 @@ np.savez(sys.argv[3], **out)
 """
 
 
-def _run(tmp_path, prec, solver, fuse):
-    out = tmp_path / ("o_%s_%d_%d.npz" % (prec, solver, fuse))
+def _run(tmp_path, prec, solver, fuse, D=512):
+    out = tmp_path / ("o_%s_%d_%d_%d.npz" % (prec, solver, fuse, D))
     env = dict(os.environ, VV_FUSE_UPDATE=str(fuse))
-    r = subprocess.run([sys.executable, "-c", CHILD % ROOT, prec, str(solver), str(out)], capture_output=True, text=True, timeout=600, env=env)
+    r = subprocess.run([sys.executable, "-c", CHILD % ROOT, prec, str(solver), str(out), str(D)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     return np.load(out)
 
 
-@pytest.mark.parametrize("prec,solver", [("f16", 0), ("f16", 1), ("f16", 2), ("bf16", 0)])
-def test_fused_update_is_bit_identical(tmp_path, prec, solver):
-    a, b = _run(tmp_path, prec, solver, 0), _run(tmp_path, prec, solver, 1)
+@pytest.mark.parametrize("prec,solver,D", [("f16", 0, 512), ("f16", 1, 512), ("f16", 2, 512), ("bf16", 0, 512), ("f16", 0, 1024)])
+def test_fused_update_is_bit_identical(tmp_path, prec, solver, D):
+    """(D = 1024: more 16-byte elements than the fused launch has threads -- its loop)"""
+    a, b = _run(tmp_path, prec, solver, 0, D), _run(tmp_path, prec, solver, 1, D)
     assert set(a.files) == set(b.files)
     for k in a.files:
         assert np.array_equal(a[k], b[k]), k

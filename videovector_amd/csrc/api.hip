@@ -946,8 +946,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   // Lazy reduction (vv_ctx::red_lazy): with no communicator in the way, dW stays in the slabs until somebody wants it --
   // normally vv_apply_update, which reduces and updates in one launch.  VV_FUSE_UPDATE=0: reduce here, as ever.
   static const bool fuse_on = !(getenv("VV_FUSE_UPDATE") && atoi(getenv("VV_FUSE_UPDATE")) == 0);
-  const bool lazy = fuse_on && !c->comm && c->grads == c->grads_own && c->F % 4 == 0 && c->S <= 8 &&
-                    (int64_t)c->D * (c->F / 4) <= (int64_t)WMAX_SLOTS * 256;
+  const bool lazy = fuse_on && !c->comm && c->grads == c->grads_own && c->F % 4 == 0 && c->S <= 8;
   // the W -> half scale update the previous vv_apply_update left pending rides in this step's reduction launch
   if (!lazy && c->scale_pending) {
     ra.scale_sc = c->scales; ra.scale_wmax = c->wmax_blocks + c->wmax_cur * WMAX_SLOTS; ra.scale_n = c->wmax_n; ra.scale_prec = c->prec;

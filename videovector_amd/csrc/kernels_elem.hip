@@ -1444,20 +1444,23 @@ __global__ __launch_bounds__(256) void k_reduce_sgd(FusedUpdArgs fa) {
     }
     return;
   }
-  // ---- parameter workgroups: one 16-byte element per thread
+  // ---- parameter workgroups: 16-byte elements, one per thread at the benchmark's size (2048 workgroups), more for larger matrices
   const int nblk = G - n_special;
   const int f4 = a.F / 4;
-  const int64_t i = (int64_t)bid * 256 + threadIdx.x;
-  const bool live = i < (int64_t)a.D * f4;
-  const int d = live ? (int)(i / f4) : 0, f = live ? (int)(i % f4) * 4 : 0;
+  const int64_t n4 = (int64_t)a.D * f4;
   const int64_t slab_sz = (int64_t)a.Dp * a.Fp;
-  const float* p = a.slabs + (int64_t)d * a.Fp + f;
-  const int64_t o = (int64_t)d * a.F + f;
-  float4 t[8];
+  int64_t i = (int64_t)bid * 256 + threadIdx.x;
+  // the first element's loads fly while the scale is worked out
+  float4 t[8], w = make_float4(0.f, 0.f, 0.f, 0.f), h = w;
+  auto load = [&](int64_t ii) {
+    const int d = (int)(ii / f4), f = (int)(ii % f4) * 4;
+    const float* p = a.slabs + (int64_t)d * a.Fp + f;
 #pragma unroll
-  for (int u = 0; u < 8; ++u) t[u] = (live && u < a.S) ? nt_load4(p + u * slab_sz) : make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 w = make_float4(0.f, 0.f, 0.f, 0.f), h = w;
-  if (live) { w = nt_load4(g.W + o); h = nt_load4(g.hW + o); }
+    for (int u = 0; u < 8; ++u) t[u] = u < a.S ? nt_load4(p + u * slab_sz) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t o = (int64_t)d * a.F + f;
+    w = nt_load4(g.W + o); h = nt_load4(g.hW + o);
+  };
+  if (i < n4) load(i);
   // the scale of the new half copy
   float sw = g.scales->sw_next;
   if (fa.recompute_scale) {
@@ -1477,24 +1480,29 @@ __global__ __launch_bounds__(256) void k_reduce_sgd(FusedUpdArgs fa) {
       sw = ldexpf(1.f, 12 - e);
     }
   }
-  float4 s = t[0];
-  for (int u = 1; u < 8; ++u)
-    if (u < a.S) { s.x += t[u].x; s.y += t[u].y; s.z += t[u].z; s.w += t[u].w; }
   const float sgf = a.sg_dev ? *a.sg_dev : (a.gg ? a.sg * a.gg->mul : a.sg);
   const float inv = a.ip_scale / (sgf * a.scales->sx);
-  // (rounded products, as the two-launch form stores them: no contraction into the rule's first multiply-add)
-  const float4 gr = make_float4(__fmul_rn(s.x, inv), __fmul_rn(s.y, inv), __fmul_rn(s.z, inv), __fmul_rn(s.w, inv));
   const float lr_w = g.rate * g.lr_mult_w, dc_w = g.weight_decay * g.decay_mult_w;
   float wmax = 0.f;
-  if (live) {
+  for (; i < n4; ) {
+    const int d = (int)(i / f4), f = (int)(i % f4) * 4;
+    const int64_t o = (int64_t)d * a.F + f;
+    float4 s = t[0];
+    for (int u = 1; u < 8; ++u)
+      if (u < a.S) { s.x += t[u].x; s.y += t[u].y; s.z += t[u].z; s.w += t[u].w; }
+    // (rounded products, as the two-launch form stores them: no contraction into the rule's first multiply-add)
+    const float4 gr = make_float4(__fmul_rn(s.x, inv), __fmul_rn(s.y, inv), __fmul_rn(s.z, inv), __fmul_rn(s.w, inv));
     if (fa.store_grads) nt_store4(a.grads + o, gr);
-    w.x = rule(w.x, gr.x, h.x, lr_w, dc_w); w.y = rule(w.y, gr.y, h.y, lr_w, dc_w);
-    w.z = rule(w.z, gr.z, h.z, lr_w, dc_w); w.w = rule(w.w, gr.w, h.w, lr_w, dc_w);
-    wmax = fmaxf(fmaxf(fabsf(w.x), fabsf(w.y)), fmaxf(fabsf(w.z), fabsf(w.w)));
-    nt_store4(g.W + o, w);
-    nt_store4(g.hW + o, h);
-    const uint32_t lo = T::from_float(w.x * sw) | ((uint32_t)T::from_float(w.y * sw) << 16);
-    const uint32_t hi = T::from_float(w.z * sw) | ((uint32_t)T::from_float(w.w * sw) << 16);
+    float4 wn = w, hn = h;
+    wn.x = rule(wn.x, gr.x, hn.x, lr_w, dc_w); wn.y = rule(wn.y, gr.y, hn.y, lr_w, dc_w);
+    wn.z = rule(wn.z, gr.z, hn.z, lr_w, dc_w); wn.w = rule(wn.w, gr.w, hn.w, lr_w, dc_w);
+    wmax = fmaxf(wmax, fmaxf(fmaxf(fabsf(wn.x), fabsf(wn.y)), fmaxf(fabsf(wn.z), fabsf(wn.w))));
+    i += (int64_t)nblk * 256;
+    if (i < n4) load(i);                       // the next element's loads before this one's stores
+    nt_store4(g.W + o, wn);
+    nt_store4(g.hW + o, hn);
+    const uint32_t lo = T::from_float(wn.x * sw) | ((uint32_t)T::from_float(wn.y * sw) << 16);
+    const uint32_t hi = T::from_float(wn.z * sw) | ((uint32_t)T::from_float(wn.w * sw) << 16);
     *(uint2*)(g.Wh + (int64_t)d * g.Fp + f) = make_uint2(lo, hi);
   }
   __shared__ float wm[4];
@@ -1506,11 +1514,10 @@ __global__ __launch_bounds__(256) void k_reduce_sgd(FusedUpdArgs fa) {
     g.wmax_blocks[bid] = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
     if (bid == 0) { g.scales->sw_cur = sw; if (fa.recompute_scale) g.scales->sw_next = sw; }
   }
-  (void)nblk;
 }
 int launch_reduce_sgd(const FusedUpdArgs& a, hipStream_t s) {
   const int ndb = (a.r.D + 15) / 16;
-  const int nblk = (int)(((int64_t)a.r.D * (a.r.F / 4) + 255) / 256);
+  const int nblk = (int)std::min<int64_t>(((int64_t)a.r.D * (a.r.F / 4) + 255) / 256, WMAX_SLOTS);
   const dim3 grid(nblk + ndb + 1);
   if (a.prec == 0) VV_LAUNCH((k_reduce_sgd<F16>), grid, dim3(256), 0, s, a);
   else VV_LAUNCH((k_reduce_sgd<BF16>), grid, dim3(256), 0, s, a);
