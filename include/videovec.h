@@ -149,7 +149,8 @@ int vv_forward_backward_q1(vv_ctx* ctx, const vv_step_cfg* cfg, const int32_t* i
  * blob.cpp:112-136) on the gradients of the last vv_forward_backward.
  * (Without a communicator the last stage of the backward pass -- the sum of the weight gradient's split-K partials -- is
  * deferred: called right after vv_forward_backward, vv_apply_update reduces and updates in one launch; vv_loss_get,
- * vv_grads_get, vv_grads_device and vv_grads_bind run the reduction first if it is still due.  Results are bit for bit
+ * vv_grads_get, vv_grads_device and vv_grads_bind run the reduction first if it is still due, and once vv_grads_device has
+ * handed the buffer out every vv_forward_backward ends with it.  Results are bit for bit
  * those of the eager order; nothing observable through this interface changes.) */
 int vv_apply_update(vv_ctx* ctx, const vv_step_cfg* cfg);
 /* Both of the above: one iteration of Solver::Solve's loop body (solver.cpp:194,219-220). */

@@ -946,7 +946,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   // Lazy reduction (vv_ctx::red_lazy): with no communicator in the way, dW stays in the slabs until somebody wants it --
   // normally vv_apply_update, which reduces and updates in one launch.  VV_FUSE_UPDATE=0: reduce here, as ever.
   static const bool fuse_on = !(getenv("VV_FUSE_UPDATE") && atoi(getenv("VV_FUSE_UPDATE")) == 0);
-  const bool lazy = fuse_on && !c->comm && c->grads == c->grads_own && c->F % 4 == 0 && c->S <= 8;
+  const bool lazy = fuse_on && !c->comm && !c->grads_exposed && c->grads == c->grads_own && c->F % 4 == 0 && c->S <= 8;
   // the W -> half scale update the previous vv_apply_update left pending rides in this step's reduction launch
   if (!lazy && c->scale_pending) {
     ra.scale_sc = c->scales; ra.scale_wmax = c->wmax_blocks + c->wmax_cur * WMAX_SLOTS; ra.scale_n = c->wmax_n; ra.scale_prec = c->prec;
@@ -1176,6 +1176,7 @@ int vv_grads_device(vv_ctx* c, void** dev_ptr, int64_t* n_floats) {
   if (!c || !dev_ptr || !n_floats) return fail(VV_ERR_ARG, "vv_grads_device: NULL argument");
   if (!c->grads) return fail(VV_ERR_STATE, "vv_grads_device: no parameters");
   { const int rcr = reduce_now(c); if (rcr) return rcr; }      // (whoever reads the buffer on the stream finds the gradient queued in front)
+  c->grads_exposed = true;                                     // ... and every later one at the end of its vv_forward_backward
   *dev_ptr = c->grads;
   *n_floats = (int64_t)c->D * c->F + c->D;
   return VV_OK;

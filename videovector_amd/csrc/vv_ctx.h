@@ -58,6 +58,7 @@ struct vv_ctx {
   // but an update is likely to want them; vv_apply_update then reduces and updates in ONE launch (k_reduce_sgd), and
   // anything that reads the gradient or the loss first runs the plain k_reduce (reduce_now in api.hip).
   bool red_lazy = false; vv::ReduceArgs red_args;
+  bool grads_exposed = false;               // vv_grads_device handed the buffer out: its holder may read it any time, so the reduction is eager from then on
   bool grads_stale = false;                 // the fused update ran without writing dW to the gradient buffer: it is still in the slabs
   float* grads = nullptr;           // [D*F + D] (own buffer, or the bound external one)
   float* grads_own = nullptr;
