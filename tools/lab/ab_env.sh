@@ -1,5 +1,6 @@
 # A/B of environment switches on one box: bash tools/lab/ab_env.sh "LABEL1:ENV1=.. ENV2=.." "LABEL2:..." ...
 cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_dedup.py tests/test_gpu_comm.py tests/test_gpu_cfg5.py tests/test_gpu_segbwd.py tests/test_gpu_shipped.py -m gpu -x -q 2>&1 | tail -2
 for r in 1 2 3; do
   for spec in "$@"; do
     label="${spec%%:*}"; envs="${spec#*:}"
