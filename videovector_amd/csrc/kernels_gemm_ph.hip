@@ -98,7 +98,10 @@ constexpr int PH_LDS_BYTES = 8 * PH_SLOT;      // ring of 8 slots = 128 KiB
 // EARLY and the odd ones for their A_hi half-tile: every line's missing request comes from one sibling, and the other's,
 // a K-tile later, is an L2 hit (lab: 92 us; two or more K-tiles of lead are slower again).  The stream keeps its order and
 // its counts -- only the address of the leading half-tile's instructions moves a K-tile on -- so the counted waits hold
-// as they are; the leading half lives one K-tile longer and gets a ring of three slots (its two natural ones + a ninth).
+// as they are.  Nothing of it may cost the LOAD segment anything (a first build with run-time ring positions lost more there
+// than the stream gained): in the code the leading half is ALWAYS A_lo -- odd column tiles swap which rows are their lower and
+// upper half instead --, it lives one K-tile longer in a ring of FOUR slots (its two natural ones + a ninth and a tenth: all
+// 160 KiB of LDS), and the loop is unrolled by four K-tiles so that every ring position is a constant.
 template <typename T, bool DROP, bool VEC, int MQ, int ABL = 0, bool GATE = false, int DEAD = 0, int LEAD = 0>
 __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -118,6 +121,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
   const int Fp = a.Fp;
 
   // staging sources: LDS-DMA instruction i (0, 1) of this wave fills rows (i*8 + wave)*8 .. +7 of a half-tile
+  // (LEAD: odd column tiles hold the tile's UPPER rows in their "lower" half, the one that leads)
+  const int hswap = LEAD ? ((L % tilesN) & 1) : 0;
   const uint16_t* srcA[2][2];
   const uint16_t* srcB[2][2];
 #pragma unroll
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = (i * 8 + wave) * 8 + (lane >> 3), lc = (lane & 7) ^ (row & 7);
-      const int grow = m0 + hf * HROWS + row;
+      const int grow = m0 + (hf ^ hswap) * HROWS + row;
       const int trow = (row < HROWS - 16 * DEAD * hf && grow < R && !(ABL & 8)) ? a.rows[grow] : a.zero_row;
       srcA[hf][i] = a.table + (int64_t)trow * Fp + lc * 8;
       srcB[hf][i] = a.Wh + (int64_t)(n0 + hf * 128 + row) * Fp + lc * 8;
@@ -145,17 +150,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
   const int H = 4 * nk;                        // half-tiles of this workgroup's stream
   // half-tile h = 4*kt + q, q: 0 A_lo, 1 B_lo, 2 B_hi, 3 A_hi; slot = h & 7
   const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(smem)) + wave * 1024;   // this wave's first piece of slot 0
-  // LEAD: the leading A half (q = lead_q) of K-tile k lives in ring position k % 3 = slot lead_q, 4 + lead_q, 8
-  const int lead_q = LEAD ? (((L % tilesN) & 1) ? 3 : 0) : -1;
-  int ring_w = 0, ring_r = 0;                  // ring position the next leading half-tile goes to / K-tile t's is read from
-  auto ring_slot = [&](int r) { return r == 2 ? 8 : 4 * r + lead_q; };
+  // LEAD: A_lo of K-tile k lives in ring position k & 3 = slot 0, 4, 8, 9 (PH_RING); its place in the stream carries A_lo of the
+  // NEXT K-tile (the last K-tile's place re-stages K-tile nk - 1 into the position that is free: counts stay exact)
+#define PH_RING(r) (((r) & 3) == 0 ? 0 : ((r) & 3) == 1 ? 4 : ((r) & 3) == 2 ? 8 : 9)
   auto issue = [&](int kt, int q, int slot) {
     int k = kt;
-    if (LEAD && q == lead_q) {                 // (the last K-tile's place in the stream re-stages K-tile nk - 1 into the free position: counts stay exact)
-      k = kt + 1 < nk ? kt + 1 : nk - 1;
-      slot = ring_slot(ring_w);
-      ring_w = ring_w == 2 ? 0 : ring_w + 1;
-    }
+    if (LEAD && q == 0) k = kt + 1 < nk ? kt + 1 : nk - 1;          // (slot: the caller's PH_RING position of K-tile kt + 1)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const uint16_t* src = q == 0 ? srcA[0][i] : q == 1 ? srcB[0][i] : q == 2 ? srcB[1][i] : srcA[1][i];
@@ -204,16 +204,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
     } else if (wave == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the flags were read after the kernel began: order the W loads behind them
   }
 
-  // prologue: half-tiles 0 .. 5 (LEAD: the leading half of K-tile 0 in front of them)
+  // prologue: half-tiles 0 .. 5 (LEAD: A_lo of K-tile 0 in front of them, and every A_lo place carries the next K-tile's)
   if (LEAD) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const uint64_t lo = (uint64_t)srcA[0][i], hi = (uint64_t)srcA[1][i];
-      ph_glds16_at((const uint16_t*)(lead_q == 0 ? lo : hi), lds_wave + ring_slot(0) * PH_SLOT + i * 8192);
-    }
-    ring_w = 1;
+    for (int i = 0; i < 2; ++i) ph_glds16_at(srcA[0][i], lds_wave + PH_RING(0) * PH_SLOT + i * 8192);
+    issue(0, 0, PH_RING(1)); issue(0, 1, 1); issue(0, 2, 2); issue(0, 3, 3); issue(1, 0, PH_RING(2)); issue(1, 1, 5);
+  } else {
+    issue(0, 0, 0); issue(0, 1, 1); issue(0, 2, 2); issue(0, 3, 3); issue(1, 0, 4); issue(1, 1, 5);
   }
-  issue(0, 0, 0); issue(0, 1, 1); issue(0, 2, 2); issue(0, 3, 3); issue(1, 0, 4); issue(1, 1, 5);
   PH_WAITQ();                                  // half-tiles 0, 1 (A_lo, B_lo of K-tile 0) have landed
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one segment behind
@@ -229,7 +227,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
   const bool dead_hi = DEAD && wm == 1;        // this wave's last tile of the upper A half does not exist
 #define PH_LOAD_A(slot)                                                                              \
   if (!abl_rd) {                                                                                     \
-    const int a_slot = (LEAD && ((slot) & 3) == lead_q) ? ring_slot(ring_r) : (slot);                \
+    constexpr int a_slot = (LEAD && ((slot) & 3) == 0) ? PH_RING(J) : (slot);                        \
     _Pragma("unroll") for (int mi = 0; mi < MQ; ++mi) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) \
     if (!(DEAD && ((slot) & 3) == 3 && mi == MQ - 1 && dead_hi))                                     \
     af[mi][kk] = *(const i16x8*)(smem + a_slot * PH_SLOT + a_off + mi * 2048 + (((kk * 4 + fq) ^ sw) << 4)); \
@@ -251,7 +249,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
 #define PH_STREAM(tpar, t, p, wait)                                                                  \
   {                                                                                                  \
     const int h = 4 * (t) + (p) + 6;                                                                 \
-    if ((!CHK || h < H) && !abl_st) { issue(h >> 2, ((p) + 2) & 3, 4 * (((tpar) + (((p) + 6) >> 2)) & 1) + (((p) + 2) & 3)); if (wait) PH_WAITQ(); } \
+    constexpr int q_ = ((p) + 2) & 3;                                                                \
+    constexpr int slot_ = (LEAD && q_ == 0) ? PH_RING(J + 3) : 4 * (((tpar) + (((p) + 6) >> 2)) & 1) + q_;   /* A_lo's place (p = 2) carries K-tile t + 3 */ \
+    if ((!CHK || h < H) && !abl_st) { issue(h >> 2, q_, slot_); if (wait) PH_WAITQ(); }              \
     else if (wait) PH_WAIT(0);                                                                       \
   }
   // ABL: timing studies only (VV_ABLATE, results wrong): 1 no LDS-DMA stream in the loop, 2 no MFMA, 4 no fragment
@@ -264,35 +264,43 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
     for (int ni = 0; ni < 2; ++ni) { b0[ni][0] = b0[ni][1] = b1[ni][0] = b1[ni][1] = i16x8{1, 2, 3, 4, 5, 6, 7, (short)ni}; }
   }
 
-  // two K-tiles; CHK: the stream may have run out (only the last pair of K-tiles can see that: its issues reach K-tile t + 3)
-  auto pair = [&](int t, auto chk) {
+  // one K-tile of parity PAR (slots 4 PAR ..), number J of its group of four (LEAD's ring positions); CHK: the stream may have
+  // run out (only the last K-tiles can see that: a K-tile's issues reach two K-tiles on)
+  auto ktile = [&](int t, auto par_c, auto j_c, auto chk) {
+    constexpr int PAR = decltype(par_c)::value, J = decltype(j_c)::value;
     constexpr bool CHK = decltype(chk)::value;
-    // ---- K-tile t (even): slots 0..3
-    PH_LOAD_A(0) PH_LOAD_B(b0, 1) PH_STREAM(0, t, 0, true) PH_MFMA(0, 0, b0)
-    PH_LOAD_B(b1, 2) PH_STREAM(0, t, 1, true) PH_MFMA(0, 1, b1)
-    PH_LOAD_A(3) PH_STREAM(0, t, 2, false) PH_MFMA(1, 1, b1)
-    if (GATE && gated && t + 2 == a.gate_kt[g_next]) {                   // B_lo(t + 2) opens a chunk
+    (void)J;
+    PH_LOAD_A(4 * PAR + 0) PH_LOAD_B(b0, 4 * PAR + 1) PH_STREAM(PAR, t, 0, true) PH_MFMA(0, 0, b0)
+    PH_LOAD_B(b1, 4 * PAR + 2) PH_STREAM(PAR, t, 1, true) PH_MFMA(0, 1, b1)
+    PH_LOAD_A(4 * PAR + 3) PH_STREAM(PAR, t, 2, false) PH_MFMA(1, 1, b1)
+    if (GATE && PAR == 0 && gated && t + 2 == a.gate_kt[g_next]) {       // B_lo(t + 2) opens a chunk
       gate_wait(g_next);
       if (++g_next >= a.gate_n) gated = false;
     }
-    PH_STREAM(0, t, 3, true) PH_MFMA(1, 0, b0)
-    if (LEAD) ring_r = ring_r == 2 ? 0 : ring_r + 1;
-    // ---- K-tile t + 1 (odd): slots 4..7
-    PH_LOAD_A(4) PH_LOAD_B(b0, 5) PH_STREAM(1, t + 1, 0, true) PH_MFMA(0, 0, b0)
-    PH_LOAD_B(b1, 6) PH_STREAM(1, t + 1, 1, true) PH_MFMA(0, 1, b1)
-    PH_LOAD_A(7) PH_STREAM(1, t + 1, 2, false) PH_MFMA(1, 1, b1)
-    PH_STREAM(1, t + 1, 3, true) PH_MFMA(1, 0, b0)
-    if (LEAD) ring_r = ring_r == 2 ? 0 : ring_r + 1;
+    PH_STREAM(PAR, t, 3, true) PH_MFMA(1, 0, b0)
   };
-  int t_main = 0;
-  for (; t_main < nk - 2; t_main += 2) pair(t_main, std::false_type{});
-  pair(t_main, std::true_type{});
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+  if (LEAD) {                                  // groups of four K-tiles (nk % 4 == 0)
+    int t = 0;
+    for (; t < nk - 4; t += 4) {
+      ktile(t, I0{}, I0{}, std::false_type{}); ktile(t + 1, I1{}, I1{}, std::false_type{});
+      ktile(t + 2, I0{}, I2{}, std::false_type{}); ktile(t + 3, I1{}, I3{}, std::false_type{});
+    }
+    ktile(t, I0{}, I0{}, std::true_type{}); ktile(t + 1, I1{}, I1{}, std::true_type{});
+    ktile(t + 2, I0{}, I2{}, std::true_type{}); ktile(t + 3, I1{}, I3{}, std::true_type{});
+  } else {
+    int t = 0;
+    for (; t < nk - 2; t += 2) { ktile(t, I0{}, I0{}, std::false_type{}); ktile(t + 1, I1{}, I1{}, std::false_type{}); }
+    ktile(t, I0{}, I0{}, std::true_type{}); ktile(t + 1, I1{}, I1{}, std::true_type{});
+  }
   if (wm == 0) __builtin_amdgcn_s_barrier();   // waves 0-3 catch the extra barrier of waves 4-7
 #undef PH_LOAD_A
 #undef PH_LOAD_B
 #undef PH_MFMA
 #undef PH_STREAM
 #undef PH_WAITQ
+#undef PH_RING
 
   // Epilogue: descale, bias, ReLU, dropout.  The MFMA was issued with the operands swapped (D' = W_tile X_tile^T):
   // the lane's column is the batch row m and its 4 registers are 4 consecutive outputs n -> one 16-B store.
@@ -306,7 +314,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
 #pragma unroll
     for (int mi = 0; mi < MQ; ++mi) {
       if (DEAD && mh == 1 && mi == MQ - 1 && dead_hi) continue;
-      const int m = m0 + mh * HROWS + wm * 16 * MQ + mi * 16 + frow;
+      const int m = m0 + (mh ^ hswap) * HROWS + wm * 16 * MQ + mi * 16 + frow;
       if (m >= R) continue;
       int64_t ref_row = 0;
       if (DROP) {
@@ -815,11 +823,11 @@ void launch_wgrad_gemm_w4(int prec, const WgradArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------- launchers ----
-static int g_fwd_lead = 0;                // VV_FWD_LEAD=1: the LEAD instantiation (measured: no gain in the full kernel, profiles/r03_step_ablations.txt)
+static int g_fwd_lead = 1;                // VV_FWD_LEAD=0: sibling workgroups ask for their gathered rows at the same moment again
 void set_fwd_lead(int v) { g_fwd_lead = v; }
 
 template <typename T, bool DROP, bool VEC, int MQ, int DEAD = 0>
-static void launch_fwd_ph_q(const FwdArgs& a, hipStream_t s) {
+static void launch_fwd_ph_q(const FwdArgs& a, hipStream_t s, long tiles_est) {
   static bool once = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, false, DEAD>,
                       hipFuncAttributeMaxDynamicSharedMemorySize, PH_LDS_BYTES), true);
   (void)once;
@@ -827,19 +835,14 @@ static void launch_fwd_ph_q(const FwdArgs& a, hipStream_t s) {
   constexpr int BMT = 64 * MQ - 16 * DEAD;
   const dim3 grid(((a.R + BMT - 1) / BMT) * (Dp / BN)), block(GEMM_THREADS);
   if constexpr (!DROP && VEC && DEAD == 0) {
-    if (g_fwd_lead && Dp / BN > 1) {
-      constexpr int LDS9 = 9 * PH_SLOT;
-      if (a.gate) {
-        static bool once_lg = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, true, DEAD, 1>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS9), true);
-        (void)once_lg;
-        VV_LAUNCH((k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, true, DEAD, 1>), grid, block, LDS9, s, a);
-      } else {
-        static bool once_l = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, false, DEAD, 1>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS9), true);
-        (void)once_l;
-        VV_LAUNCH((k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, false, DEAD, 1>), grid, block, LDS9, s, a);
-      }
+    // the sibling lead pays where all workgroups run at once (one round: 78.6-79.7 against 81.7-82.9 us at the benchmark's
+    // de-duplicated size); launches of several rounds lose by it (dense 223 against 179 us, cfg 5 560 against 470 us)
+    if (g_fwd_lead && Dp / BN > 1 && !a.gate && tiles_est <= 256) {        // (the gated kernel keeps its static LDS word: no room beside ten slots)
+      constexpr int LDS10 = 10 * PH_SLOT;
+      static bool once_l = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, false, DEAD, 1>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS10), true);
+      (void)once_l;
+      VV_LAUNCH((k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, false, DEAD, 1>), grid, block, LDS10, s, a);
       return;
     }
   }
@@ -917,8 +920,8 @@ static void launch_fwd_ph_t(const FwdArgs& a, hipStream_t s) {
 #define VV_LAB_FWP(N)                                                                                  \
       if (lab_abl == N) {                                                                              \
         if (g_fwd_lead) {                                                                              \
-          (void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, 3, N, false, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * PH_SLOT); \
-          VV_LAUNCH((k_fwd_gemm_ph<T, DROP, VEC, 3, N, false, 0, 1>), grid, block, 9 * PH_SLOT, s, a);  \
+          (void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, 3, N, false, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * PH_SLOT); \
+          VV_LAUNCH((k_fwd_gemm_ph<T, DROP, VEC, 3, N, false, 0, 1>), grid, block, 10 * PH_SLOT, s, a);  \
         } else {                                                                                       \
           (void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, 3, N>, hipFuncAttributeMaxDynamicSharedMemorySize, PH_LDS_BYTES); \
           VV_LAUNCH((k_fwd_gemm_ph<T, DROP, VEC, 3, N>), grid, block, PH_LDS_BYTES, s, a);              \
@@ -942,10 +945,12 @@ static void launch_fwd_ph_t(const FwdArgs& a, hipStream_t s) {
       return;
     }
   }
-  if (best == 0) launch_fwd_ph_q<T, DROP, VEC, 4>(a, s);
-  else if (best == 1) launch_fwd_ph_q<T, DROP, VEC, 3>(a, s);
-  else if (best == 2) launch_fwd_ph_q<T, DROP, VEC, 3, 1>(a, s);
-  else launch_fwd_ph_q<T, DROP, VEC, 2>(a, s);
+  long tiles_est = 0;
+  (void)fwd_pick_tile(a.R, a.n_dev ? a.R_hint : 0, a.D, &tiles_est);
+  if (best == 0) launch_fwd_ph_q<T, DROP, VEC, 4>(a, s, tiles_est);
+  else if (best == 1) launch_fwd_ph_q<T, DROP, VEC, 3>(a, s, tiles_est);
+  else if (best == 2) launch_fwd_ph_q<T, DROP, VEC, 3, 1>(a, s, tiles_est);
+  else launch_fwd_ph_q<T, DROP, VEC, 2>(a, s, tiles_est);
 }
 
 template <typename T>
