@@ -834,10 +834,12 @@ static void launch_fwd_ph_q(const FwdArgs& a, hipStream_t s, long tiles_est) {
   const int Dp = (int)round_up(a.D, D_ALIGN);
   constexpr int BMT = 64 * MQ - 16 * DEAD;
   const dim3 grid(((a.R + BMT - 1) / BMT) * (Dp / BN)), block(GEMM_THREADS);
-  if constexpr (!DROP && VEC && DEAD == 0) {
-    // the sibling lead pays where all workgroups run at once (one round: 78.6-79.7 against 81.7-82.9 us at the benchmark's
-    // de-duplicated size); launches of several rounds lose by it (dense 223 against 179 us, cfg 5 560 against 470 us)
-    if (g_fwd_lead && Dp / BN > 1 && !a.gate && tiles_est <= 256) {        // (the gated kernel keeps its static LDS word: no room beside ten slots)
+  (void)tiles_est;
+  if constexpr (!DROP && VEC && DEAD == 0 && MQ <= 3) {
+    // the sibling lead: 78.6-79.7 against 81.7-82.9 us at the benchmark's de-duplicated size (192-row tiles, one round), 215
+    // against 218 us for 192-row tiles in three rounds.  Not for 256-row tiles: that instantiation has no registers left for
+    // it (256 + 48 bytes of scratch: dense 229 against 183 us, cfg 5 560 against 470 us)
+    if (g_fwd_lead && Dp / BN > 1 && !a.gate) {        // (the gated kernel keeps its static LDS word: no room beside ten slots)        // (the gated kernel keeps its static LDS word: no room beside ten slots)
       constexpr int LDS10 = 10 * PH_SLOT;
       static bool once_l = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, false, DEAD, 1>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS10), true);
