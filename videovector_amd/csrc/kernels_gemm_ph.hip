@@ -186,7 +186,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
   if (GATE) {
     // (every wave reads the flags itself here: `gated` must be the same in all eight, and a flag only ever grows --
     // a wave that sees all set while another does not is excluded by re-reading after a barrier)
-    int& s_behind = *(int*)smem;               // (the ring's first bytes, before the stream starts: the ring takes all of LDS with LEAD)
+    __shared__ int s_behind;
     if (tid == 0) {
       int behind = 0;
 #pragma unroll
@@ -196,7 +196,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
     }
     __syncthreads();
     gated = s_behind != 0;
-    __syncthreads();                           // everybody has read the word before the prologue's first LDS-DMA lands on it
     if (gated) {
       // chunk 0 in front of the prologue; with it every chunk that starts before K-tile 4 (the prologue's loads reach K-tile 1)
       gate_wait(0);
@@ -840,19 +839,12 @@ static void launch_fwd_ph_q(const FwdArgs& a, hipStream_t s, long tiles_est) {
     // the sibling lead: 78.6-79.7 against 81.7-82.9 us at the benchmark's de-duplicated size (192-row tiles, one round), 215
     // against 218 us for 192-row tiles in three rounds.  Not for 256-row tiles: that instantiation has no registers left for
     // it (256 + 48 bytes of scratch: dense 229 against 183 us, cfg 5 560 against 470 us)
-    if (g_fwd_lead && Dp / BN > 1) {
+    if (g_fwd_lead && Dp / BN > 1 && !a.gate) {        // (the gated kernel keeps its static LDS word: no room beside ten slots)        // (the gated kernel keeps its static LDS word: no room beside ten slots)
       constexpr int LDS10 = 10 * PH_SLOT;
-      if (a.gate) {
-        static bool once_lg = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, true, DEAD, 1>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS10), true);
-        (void)once_lg;
-        VV_LAUNCH((k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, true, DEAD, 1>), grid, block, LDS10, s, a);
-      } else {
-        static bool once_l = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, false, DEAD, 1>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS10), true);
-        (void)once_l;
-        VV_LAUNCH((k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, false, DEAD, 1>), grid, block, LDS10, s, a);
-      }
+      static bool once_l = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, false, DEAD, 1>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS10), true);
+      (void)once_l;
+      VV_LAUNCH((k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, false, DEAD, 1>), grid, block, LDS10, s, a);
       return;
     }
   }
