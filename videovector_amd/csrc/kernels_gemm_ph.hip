@@ -169,6 +169,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
   // chunk gates (GATE only)
   bool gated = false;
   int g_next = 1;                              // the next chunk whose gate lies inside the K loop
+  int gate_at = -1;                            // ... and the K-tile in front of whose B_lo issue it sits (-1: none; one compare per K-tile in the loop)
   auto gate_wait = [&](int chunk) {
     if (wave == 0) {
       unsigned spins = 0;
@@ -201,6 +202,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
       gate_wait(0);
       while (g_next < a.gate_n && a.gate_kt[g_next] < 4) { gate_wait(g_next); ++g_next; }
       if (g_next >= a.gate_n) gated = false;
+      gate_at = gated ? a.gate_kt[g_next] : -1;
     } else if (wave == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the flags were read after the kernel began: order the W loads behind them
   }
 
@@ -273,9 +275,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
     PH_LOAD_A(4 * PAR + 0) PH_LOAD_B(b0, 4 * PAR + 1) PH_STREAM(PAR, t, 0, true) PH_MFMA(0, 0, b0)
     PH_LOAD_B(b1, 4 * PAR + 2) PH_STREAM(PAR, t, 1, true) PH_MFMA(0, 1, b1)
     PH_LOAD_A(4 * PAR + 3) PH_STREAM(PAR, t, 2, false) PH_MFMA(1, 1, b1)
-    if (GATE && PAR == 0 && gated && t + 2 == a.gate_kt[g_next]) {       // B_lo(t + 2) opens a chunk
+    if (GATE && PAR == 0 && t + 2 == gate_at) {                          // B_lo(t + 2) opens a chunk
       gate_wait(g_next);
       if (++g_next >= a.gate_n) gated = false;
+      gate_at = gated ? a.gate_kt[g_next] : -1;
     }
     PH_STREAM(PAR, t, 3, true) PH_MFMA(1, 0, b0)
   };
