@@ -55,6 +55,22 @@ int vv_synchronize(vv_ctx* ctx);
  * sums, reassociated.  Steps with dropout always take the dense path.  vv_dedup_stats reports the rows of
  * the last forward/backward pass and how many were distinct (rows == unique_rows on the dense path). */
 int vv_set_dedup(vv_ctx* ctx, int on);
+/* Per-context execution switches by name; none of them changes a result beyond rounding, none is process-global (two contexts
+ * of one process keep their own).  Each also has an environment variable that sets its INITIAL value when the context is
+ * created.  The reference's counterpart is Caffe::set_mode / the layer's *_param fields (include/caffe/common.hpp:108-135):
+ * per-object configuration, not globals.
+ *   "dedup" (VV_DEDUP, 1)            row de-duplication, as vv_set_dedup
+ *   "seg_bwd" (VV_SEG_BWD, 1)        segment-wise backward of de-duplicated batches (0: per-instance gradient rows + their sums)
+ *   "fuse_update" (VV_FUSE_UPDATE, 1) reduction of the split-K partials and the solver update in one launch (0: two launches)
+ *   "fwd_lead" (VV_FWD_LEAD, 1)      the forward GEMM's sibling lead
+ *   "wgrad_tr" (VV_WGRAD_TR, 1)      transposed LDS reads in the weight-gradient GEMM (0: the first-round kernel)
+ *   "score_stream" (VV_SCORE_STREAM, 0)  1: the one-sweep score kernel for every shape
+ *   "comm_gate" (VV_COMM_GATE, 1)    the overlapped update gates the next forward GEMM chunk by chunk (0: the stream joins)
+ *   "comm_chunks" (VV_COMM_CHUNKS, 3)  F-chunks of the overlapped update, 1 .. 4
+ *   "comm_test_delay_us" (VV_COMM_TEST_DELAY_US, 0)  TEST HOOK: holds the communication stream this long in front of every chunk
+ * Ablated / experimental kernels (timing studies whose results may be wrong) are NOT reachable through this library: they and their
+ * switches exist only in the lab build (make -C videovector_amd/csrc lab).  Unknown name: VV_ERR_ARG. */
+int vv_set_option(vv_ctx* ctx, const char* name, double value);
 int vv_dedup_stats(vv_ctx* ctx, int64_t* rows, int64_t* unique_rows);
 /* f16 operands: the 16-bit gradient operand of the weight-gradient product (InnerProductLayer::Backward,
  * inner_product_layer.cpp:80-97) carries one power-of-two scale per step.  A gradient value outside f16's range is never

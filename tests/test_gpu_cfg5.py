@@ -49,7 +49,11 @@ def test_cfg5_dedup_equals_dense_at_full_size(setup):
     assert np.isfinite(l1[0]) and 0 < l1[0] < 16 and 0 <= l1[1] <= B * Nn
 
 
-def test_cfg5_shard_matches_oracle_within_bf16_tolerance(setup, oracle):
+@pytest.mark.parametrize("prec,tol_emb,tol_score", [("bf16", 4e-3, 2e-3), ("f16", 1e-3, 1e-3)])
+def test_cfg5_shard_matches_oracle(setup, oracle, prec, tol_emb, tol_score):
+    """configs[4]'s shapes against the fp32 oracle in both operand types: f16 -- what the product defaults to -- inside the
+    north star's 1e-3 (embeddings, loss, scores); bf16 -- what configs[4] is quoted for -- at what 8 significant bits allow
+    (the tolerance study: DESIGN.md, Precision)."""
     vv, ds, idx, W, b = setup
     sh = idx[1000:1032]
     uniq, inv = np.unique(sh.reshape(-1), return_inverse=True)
@@ -57,14 +61,15 @@ def test_cfg5_shard_matches_oracle_within_bf16_tolerance(setup, oracle):
     idx_local = inv.reshape(sh.shape).astype(np.int32)
     ref = oracle.forward_backward(table, idx_local, W, b, C_=C, Nn=Nn, global_count=B * Nn,
                                   want=("H", "s_true", "s_bogus"))
-    eng = vv.Engine(0, "bf16")
+    eng = vv.Engine(0, prec)
     eng.table_synth(ds.seed, ds.n_rows, F)
     eng.params_set(W, b)
     cfg = vv.StepConfig(32, C, Nn, global_count=B * Nn)
     eng.forward_backward(cfg, sh)
     got = eng.blobs(cfg)
     e_emb = (np.linalg.norm(got["ip2"] - ref["H"], axis=1) / np.maximum(np.linalg.norm(ref["H"], axis=1), 1e-30)).max()
-    print("CFG5 shard emb=%.3e loss=%.6f/%.6f" % (e_emb, eng.loss()[0], ref["loss"]))
-    assert e_emb <= 4e-3                                           # bf16 operands: 8 significant bits
+    e_sc = np.abs(got["negative_scores"] - ref["s_bogus"]).max()
+    print("CFG5 shard %s emb=%.3e scores=%.3e loss=%.6f/%.6f" % (prec, e_emb, e_sc, eng.loss()[0], ref["loss"]))
+    assert e_emb <= tol_emb
     assert abs(eng.loss()[0] - ref["loss"]) <= 1e-3 * ref["loss"]
-    assert np.abs(got["negative_scores"] - ref["s_bogus"]).max() <= 2e-3
+    assert e_sc <= tol_score

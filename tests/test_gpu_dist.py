@@ -103,3 +103,45 @@ def test_bench_bare_command_a_dead_rank_fails_the_job():
     assert r.returncode == 7, (r.returncode, r.stderr[-2000:])
     assert "rank 1 exited with code 7" in r.stderr
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_eight_ranks_overlap_node_sampler_matches_one_process_at_the_global_batch():
+    """What the driver's N = 8 run executes by default in the library -- eight ranks, the launcher, the eight-rank chunk plan,
+    k_sgd's publication, the gated forward GEMM, the node's ONE sampler sliced per rank -- on the one-device hook, against ONE
+    process that takes the same global batches (B = 8192) through a single engine: after the same number of iterations the
+    parameters are the same to rounding, so rank 0's loss on its 1024 items of the last batch is (<= 1e-5)."""
+    import numpy as np
+    import videovector_amd as vv
+    from videovector_amd.synth import SyntheticVideos, init_weights
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(VV_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    K, Wm, settle_ms = 3, 1, 0.5                                   # settle steps = ceil(0.5 / 0.25) = 2 -> 6 iterations
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", str(K), "--warmup", str(Wm),
+                        "--no-cpu-baseline", "--no-extra-legs", "--allreduce", "overlap", "--sampler", "node",
+                        "--settle-ms", str(settle_ms), "--sampler-threads", "2"], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 8192 and d["config"]["parallelism"] == "dp8"
+    assert "overlap" in d["config"]["allreduce"] and "shared-memory ring" in d["config"]["sampler"]
+    n_it = d["settle"]["steps"] + Wm + K
+    assert n_it == 6
+    # ---- the same iterations in ONE process at the global batch
+    B, C, NN, F, D, BG = 1024, 5, 50, 4096, 512, 8192
+    ds = SyntheticVideos(seed=1701, n_videos=2048)
+    smp = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, batch_size=BG, context_size=C, num_negative_samples=NN,
+                     max_buffer_size=5000, negative_swap_percentage=50, max_same_video_negs=0)
+    W0, b0 = init_weights(1701, D, F)
+    eng = vv.Engine(0, "f16")
+    eng.table_synth(ds.seed, ds.n_rows, F)
+    eng.params_set(W0, b0)
+    cfg_g = vv.StepConfig(BG, C, NN)
+    cfg_r = vv.StepConfig(B, C, NN, global_count=BG * NN)
+    lr_at = lambda it: 1e-3 * (1.0 + 1e-3 * it) ** -0.75
+    for it in range(n_it - 1):
+        cfg_g.set("lr", lr_at(it))
+        eng.forward_backward(cfg_g, smp.next())
+        eng.apply_update(cfg_g)
+    eng.forward_backward(cfg_r, smp.next()[:B])                    # rank 0's items of the last batch, at the parameters of 5 global updates
+    loss, viol = eng.loss()
+    print("DIST8 rank-0 loss after %d iterations: 8 ranks %.7f, one process %.7f" % (n_it, d["final_loss"], loss))
+    assert abs(d["final_loss"] - loss) <= 1e-5 * loss

@@ -79,6 +79,65 @@ def test_overall_timeout(tmp_path):
     assert rc == 124 and "did not finish" in err
 
 
+def _alive(pid):
+    try:
+        os.kill(pid, 0)
+    except OSError:
+        return False
+    try:                                           # a zombie still answers kill(0)
+        return open("/proc/%d/stat" % pid).read().split(")")[-1].split()[0] != "Z"
+    except OSError:
+        return False
+
+
+def _launcher_with_sleeping_ranks(tmp_path, world):
+    script = _script(tmp_path, """
+        import os, sys, time
+        open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "pid%s" % os.environ["RANK"]), "w").write(str(os.getpid()))
+        time.sleep(600)
+        """)
+    code = ("import sys; sys.path.insert(0, %r); from videovector_amd.launch import launch_ranks; "
+            "sys.exit(launch_ranks(%r, [], %d))" % (ROOT, script, world))
+    p = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    pids = []
+    t0 = time.monotonic()
+    while len(pids) < world and time.monotonic() - t0 < 60:
+        pids = []
+        for r in range(world):
+            f = tmp_path / ("pid%d" % r)
+            if f.exists() and f.read_text().strip():
+                pids.append(int(f.read_text()))
+        time.sleep(0.05)
+    assert len(pids) == world
+    return p, pids
+
+
+def test_a_terminated_launcher_takes_its_ranks_down(tmp_path):
+    """`timeout N python bench.py --gpus 8` ends the launcher with SIGTERM; the ranks must not outlive it."""
+    import signal
+    p, pids = _launcher_with_sleeping_ranks(tmp_path, 3)
+    p.send_signal(signal.SIGTERM)
+    out, err = p.communicate(timeout=60)
+    assert p.returncode == 128 + signal.SIGTERM, (p.returncode, err)
+    assert "signal 15: stopping 3 rank(s)" in err
+    t0 = time.monotonic()
+    while any(_alive(x) for x in pids) and time.monotonic() - t0 < 10:
+        time.sleep(0.05)
+    assert not any(_alive(x) for x in pids)
+
+
+def test_a_killed_launcher_takes_its_ranks_down(tmp_path):
+    """SIGKILL runs no handler: the ranks asked the kernel for SIGTERM at their parent's death."""
+    import signal
+    p, pids = _launcher_with_sleeping_ranks(tmp_path, 2)
+    p.send_signal(signal.SIGKILL)
+    p.communicate(timeout=60)
+    t0 = time.monotonic()
+    while any(_alive(x) for x in pids) and time.monotonic() - t0 < 10:
+        time.sleep(0.05)
+    assert not any(_alive(x) for x in pids)
+
+
 def test_bench_refuses_a_world_that_contradicts_gpus():
     """(no GPU needed: the check sits in front of anything that touches the device)"""
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")

@@ -1,4 +1,6 @@
 cd $GRAFT_REPO_ROOT
+# needs the lab build of the library (make -C videovector_amd/csrc lab): the ablated kernels are not in the product library
+export VV_LIB=${GRAFT_REPO_ROOT:-/root/repo}/videovector_amd/lib/libvideovec_lab.so
 run() { # label, env...
   env "${@:2}" timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extra-legs > gpurun_out/ab.log 2>&1
   echo "$1: $(python3 -c "

@@ -1,4 +1,6 @@
 # what the weight-gradient kernel is made of at the de-duplicated size (VV_LAB_WG_ABL: 1 no LDS-DMA stream, 2 no MFMA, 4 no fragment reads, 8 every row the zero row)
+# needs the lab build of the library (make -C videovector_amd/csrc lab): the ablated kernels are not in the product library
+export VV_LIB=${GRAFT_REPO_ROOT:-/root/repo}/videovector_amd/lib/libvideovec_lab.so
 cd $GRAFT_REPO_ROOT
 run() { # label, env...
   env "${@:2}" timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extra-legs > gpurun_out/ab.log 2>&1

@@ -17,7 +17,16 @@
 
 #include "vv_ctx.h"
 
-namespace vv { void set_fwd_lead(int v); void set_fwd_ring10(bool on); void set_wgrad_tr(bool on); void set_gemm_variant(int v); void set_ablate(int v); void set_score_reg(int v); void set_score_waves(int v); void set_ph_mq(int v); void set_score_stream(int v); int gemm_variant(); bool ablate_on(); }
+namespace vv { int gemm_variant(); bool ablate_on(); thread_local const KernelOpts* g_ko = nullptr; }
+// every entry point that launches kernels: the device of the context, and ITS kernel options for the launchers on this thread
+#define VV_ENTER(c) do { HIPCHK(hipSetDevice((c)->device)); vv::g_ko = &(c)->ko; } while (0)
+// environment of a PRODUCT option (read once per context) / of a lab switch (ignored unless the library was built with -DVV_LAB)
+static inline const char* opt_env(const char* name) { return getenv(name); }
+#ifdef VV_LAB
+static inline const char* lab_env(const char* name) { return getenv(name); }
+#else
+static inline const char* lab_env(const char*) { return nullptr; }
+#endif
 using namespace vv;
 
 thread_local char vv_g_err[512] = "";
@@ -58,8 +67,6 @@ static void prof_end(vv_ctx* c, const char* name, hipEvent_t e0, hipEvent_t e1) 
 }
 // VV_TRACE_HOST=<ms>: report every launcher call that keeps the HOST longer than that (first use of a kernel variant,
 // a runtime pool growing, ...) -- the GPU queue runs dry behind such a call.
-static double g_trace_host_ms = -1.0;
-static double g_wait_ms[5] = {0, 0, 0, 0, 0}; static long g_wait_calls = 0;      // VV_TRACE_WAITS: where the host waits (ms, summed)
 static inline double host_now_ms() {
   timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
   return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
@@ -68,9 +75,9 @@ static inline double host_now_ms() {
   do {                                          \
     hipEvent_t e0_, e1_;                        \
     prof_begin(c, name, &e0_, &e1_);            \
-    const double th_ = g_trace_host_ms >= 0 ? host_now_ms() : 0.0; \
+    const double th_ = (c)->trace_host_ms >= 0 ? host_now_ms() : 0.0; \
     call;                                       \
-    if (g_trace_host_ms >= 0) { const double d_ = host_now_ms() - th_; if (d_ > g_trace_host_ms) fprintf(stderr, "[vv host] %s: %.3f ms (call %llu)\n", name, d_, (unsigned long long)c->iter); } \
+    if ((c)->trace_host_ms >= 0) { const double d_ = host_now_ms() - th_; if (d_ > (c)->trace_host_ms) fprintf(stderr, "[vv host] %s: %.3f ms (call %llu)\n", name, d_, (unsigned long long)c->iter); } \
     prof_end(c, name, e0_, e1_);                \
   } while (0)
 
@@ -125,28 +132,32 @@ static int create_init(vv_ctx* c) {
   HIPCHK(hipMemset(c->wmax_blocks, 0, 2 * WMAX_SLOTS * sizeof(float)));
   HIPCHK(hipMalloc(&c->loss2, 2 * sizeof(float)));
   HIPCHK(hipMemset(c->loss2, 0, 2 * sizeof(float)));
-  const char* tr = getenv("VV_WGRAD_TR");
-  if (tr) set_wgrad_tr(atoi(tr) != 0);
-  const char* gv = getenv("VV_GEMM_VARIANT");
-  if (gv) set_gemm_variant(atoi(gv));
-  if (const char* fl = getenv("VV_FWD_LEAD")) set_fwd_lead(atoi(fl));
-  const char* ab = getenv("VV_ABLATE");
-  set_ablate(ab ? atoi(ab) : 0);
-  const char* sr = getenv("VV_SCORE_REG");
-  set_score_reg(sr ? atoi(sr) : 1);
-  const char* sw = getenv("VV_SCORE_WAVES");
-  set_score_waves(sw ? atoi(sw) : 8);
-  const char* sst = getenv("VV_SCORE_STREAM");
-  set_score_stream(sst ? atoi(sst) : 0);
-  set_fwd_ring10(getenv("VV_FWD_RING10") && atoi(getenv("VV_FWD_RING10")) != 0);
-  const char* pq = getenv("VV_PH_MQ");
-  set_ph_mq(pq ? atoi(pq) : 0);
-  const char* th = getenv("VV_TRACE_HOST");
-  g_trace_host_ms = th ? atof(th) : -1.0;
-  const char* sb = getenv("VV_SEG_BWD");
-  if (sb) c->seg_bwd = atoi(sb) != 0;
-  const char* dd = getenv("VV_DEDUP");
-  if (dd) c->dedup = atoi(dd) != 0;
+  // product options: initial values from the environment, per context (vv_set_option changes them afterwards)
+  if (const char* v = opt_env("VV_WGRAD_TR")) c->ko.wgrad_tr = atoi(v) != 0;
+  if (const char* v = opt_env("VV_FWD_LEAD")) c->ko.fwd_lead = atoi(v);
+  if (const char* v = opt_env("VV_SCORE_STREAM")) c->ko.score_stream = atoi(v);
+  if (const char* v = opt_env("VV_SEG_BWD")) c->seg_bwd = atoi(v) != 0;
+  if (const char* v = opt_env("VV_DEDUP")) c->dedup = atoi(v) != 0;
+  if (const char* v = opt_env("VV_FUSE_UPDATE")) c->fuse_update = atoi(v) != 0;
+  if (const char* v = opt_env("VV_COMM_GATE")) c->comm_gate = atoi(v) != 0;
+  if (const char* v = opt_env("VV_COMM_TEST_DELAY_US")) c->comm_test_delay_us = atoi(v);
+  // lab switches (-DVV_LAB builds only; several of them produce WRONG results by design)
+  if (const char* v = lab_env("VV_GEMM_VARIANT")) c->ko.gemm_variant = atoi(v);
+  if (const char* v = lab_env("VV_ABLATE")) c->ko.ablate = atoi(v);
+  if (const char* v = lab_env("VV_LAB_FWD_ABL")) c->ko.lab_fwd_abl = atoi(v);
+  if (const char* v = lab_env("VV_LAB_WG_ABL")) c->ko.lab_wg_abl = atoi(v);
+  if (const char* v = lab_env("VV_FWD_RING10")) c->ko.fwd_ring10 = atoi(v) != 0;
+  if (const char* v = lab_env("VV_PH_MQ")) c->ko.ph_mq = atoi(v);
+  if (const char* v = lab_env("VV_SCORE_REG")) c->ko.score_reg = atoi(v);
+  if (const char* v = lab_env("VV_SCORE_WAVES")) c->ko.score_waves = atoi(v);
+  if (const char* v = lab_env("VV_GUARD_PROACTIVE")) c->guard_proactive = atoi(v) != 0;
+  if (const char* v = lab_env("VV_FUSE_KEEP_GRADS")) c->fuse_keep_grads = atoi(v) != 0;
+  if (const char* v = lab_env("VV_COMM_SKIP_AR1")) c->comm_skip_ar1 = atoi(v) != 0;
+  if (const char* v = lab_env("VV_DEDUP_GATE")) c->dd_gate_word = atoi(v) != 0;
+  if (const char* v = lab_env("VV_DEDUP_LDS_KB")) c->dd_lds_kb = atoi(v);
+  if (const char* v = lab_env("VV_TRACE_HOST")) c->trace_host_ms = atof(v);
+  c->trace_waits = lab_env("VV_TRACE_WAITS") != nullptr;
+  vv::g_ko = &c->ko;
   HIPCHK(hipMalloc(&c->dd_info_all, vv_ctx::kDdSets * 4 * sizeof(int32_t)));
   HIPCHK(hipMemset(c->dd_info_all, 0, vv_ctx::kDdSets * 4 * sizeof(int32_t)));
   HIPCHK(hipStreamCreateWithFlags(&c->dd_stream, hipStreamNonBlocking));
@@ -156,17 +167,15 @@ static int create_init(vv_ctx* c) {
     HIPCHK(hipEventCreateWithFlags(&c->dd_set[i].done, hipEventDisableTiming));
   }
   c->dd_info = c->dd_set[0].info;
-  const char* da = getenv("VV_DEDUP_ASYNC");
-  if (da) c->dd_async = atoi(da) != 0;
-  const char* dsp = getenv("VV_DEDUP_SPIN_US");
-  if (dsp) c->dd_spin_us = atof(dsp);
+  if (const char* v = lab_env("VV_DEDUP_ASYNC")) c->dd_async = atoi(v) != 0;
+  if (const char* v = lab_env("VV_DEDUP_SPIN_US")) c->dd_spin_us = atof(v);
   HIPCHK(hipHostMalloc((void**)&c->U_host, 2 * sizeof(int32_t), hipHostMallocMapped));   // {U, saturated f16 gradient sums}
   c->U_host[0] = c->U_host[1] = 0;
   HIPCHK(hipHostGetDevicePointer((void**)&c->U_host_dev, c->U_host, 0));
   HIPCHK(hipMalloc(&c->w_gate, (W_CHUNKS_MAX + 1) * W_GATE_STRIDE * sizeof(int32_t)));
   HIPCHK(hipMemset(c->w_gate, 0, (W_CHUNKS_MAX + 1) * W_GATE_STRIDE * sizeof(int32_t)));
   c->pub_count = c->w_gate + W_CHUNKS_MAX * W_GATE_STRIDE;      // the arrival counter of the publishing kernels: a line of its own
-  { const char* nc = getenv("VV_COMM_CHUNKS"); if (nc) c->n_chunks = std::max(1, std::min(W_CHUNKS_MAX, atoi(nc))); }
+  { const char* nc = opt_env("VV_COMM_CHUNKS"); if (nc) c->n_chunks = std::max(1, std::min(W_CHUNKS_MAX, atoi(nc))); }
   HIPCHK(hipEventCreateWithFlags(&c->ev_chunk0, hipEventDisableTiming));
   HIPCHK(hipHostMalloc((void**)&c->gate_err, sizeof(int32_t), hipHostMallocMapped));
   *c->gate_err = 0;
@@ -226,6 +235,7 @@ static void free_batch(vv_ctx* c) {
   c->loss_part = c->viol_part = c->s_true = c->s_bogus = c->coeff = nullptr; c->slabs = nullptr;
   c->slab_bytes = 0; c->B = c->C = c->Nn = c->R = c->Rp = 0; c->coeff_host.clear();
   c->have_fwd = false;
+  c->red_lazy = c->grads_stale = false;       // a reduction that was still due named the buffers just freed (red_args)
 }
 
 int vv_destroy(vv_ctx* c) {
@@ -258,6 +268,30 @@ int vv_destroy(vv_ctx* c) {
   return VV_OK;
 }
 
+// Per-context switches by name (include/videovec.h).  A name of a lab switch is refused unless the library was built with -DVV_LAB.
+int vv_set_option(vv_ctx* c, const char* name, double value) {
+  if (!c || !name) return fail(VV_ERR_ARG, "vv_set_option: ctx / name is NULL");
+  const std::string n(name);
+  const int iv = (int)value;
+  if (n == "dedup") return vv_set_dedup(c, iv);
+  if (n == "seg_bwd") { c->seg_bwd = iv != 0; return VV_OK; }
+  if (n == "fuse_update") { c->fuse_update = iv != 0; return VV_OK; }
+  if (n == "fwd_lead") { c->ko.fwd_lead = iv; return VV_OK; }
+  if (n == "wgrad_tr") { c->ko.wgrad_tr = iv != 0; return VV_OK; }
+  if (n == "score_stream") { c->ko.score_stream = iv; return VV_OK; }
+  if (n == "comm_gate") { c->comm_gate = iv != 0; return VV_OK; }
+  if (n == "comm_chunks") { c->n_chunks = std::max(1, std::min(W_CHUNKS_MAX, iv)); return VV_OK; }
+  if (n == "comm_test_delay_us") { c->comm_test_delay_us = iv; return VV_OK; }
+#ifdef VV_LAB
+  if (n == "gemm_variant") { c->ko.gemm_variant = iv; return VV_OK; }
+  if (n == "ablate") { c->ko.ablate = iv; return VV_OK; }
+  if (n == "lab_fwd_abl") { c->ko.lab_fwd_abl = iv; return VV_OK; }
+  if (n == "lab_wg_abl") { c->ko.lab_wg_abl = iv; return VV_OK; }
+  if (n == "ph_mq") { c->ko.ph_mq = iv; return VV_OK; }
+#endif
+  return fail(VV_ERR_ARG, "vv_set_option: unknown option '%s'", name);
+}
+
 int vv_set_dedup(vv_ctx* c, int on) {
   if (!c) return fail(VV_ERR_ARG, "vv_set_dedup: ctx is NULL");
   c->dedup = on != 0;
@@ -268,7 +302,7 @@ int vv_set_dedup(vv_ctx* c, int on) {
 int vv_dedup_stats(vv_ctx* c, int64_t* rows, int64_t* unique_rows) {
   if (!c) return fail(VV_ERR_ARG, "vv_dedup_stats: ctx is NULL");
   if (!c->have_fwd) return fail(VV_ERR_STATE, "vv_dedup_stats: no forward pass yet");
-  HIPCHK(hipSetDevice(c->device));
+  VV_ENTER(c);
   HIPCHK(hipStreamSynchronize(c->stream));
   int32_t U = c->R;
   if (c->last_dedup) HIPCHK(hipMemcpy(&U, c->dd_info, sizeof(U), hipMemcpyDeviceToHost));
@@ -303,7 +337,7 @@ int vv_synchronize(vv_ctx* c) {
 static int table_alloc(vv_ctx* c, int64_t n_rows, int F) {
   if (n_rows <= 0 || F <= 0) return fail(VV_ERR_ARG, "table: n_rows=%lld F=%d", (long long)n_rows, F);
   if (n_rows >= (1ll << 31) - 1) return fail(VV_ERR_ARG, "table: too many rows for int32 indices");
-  HIPCHK(hipSetDevice(c->device));
+  VV_ENTER(c);
   HIPCHK(hipStreamSynchronize(c->stream));
   if (c->D && F != c->F) return fail(VV_ERR_STATE, "table: F=%d differs from the parameters' F=%d", F, c->F);
   dfree(c->table); c->table = nullptr; c->patch_cap = 0;
@@ -385,7 +419,7 @@ int vv_table_synth(vv_ctx* c, uint64_t seed, int64_t n_rows, int32_t F) {
 int vv_table_get(vv_ctx* c, const int32_t* rows, int64_t n, float* out) {
   if (!c || !out || n <= 0) return fail(VV_ERR_ARG, "vv_table_get: bad argument");
   if (!c->table) return fail(VV_ERR_STATE, "vv_table_get: no table");
-  HIPCHK(hipSetDevice(c->device));
+  VV_ENTER(c);
   DevTmp<int32_t> drows; DevTmp<float> dout;
   if (rows) {
     for (int64_t i = 0; i < n; ++i)
@@ -405,7 +439,7 @@ int vv_params_set(vv_ctx* c, int32_t D, const float* W, const float* b, const fl
                   const float* hb) {
   if (!c || !W || D <= 0) return fail(VV_ERR_ARG, "vv_params_set: bad argument");
   if (!c->table) return fail(VV_ERR_STATE, "vv_params_set: set the feature table first (defines F)");
-  HIPCHK(hipSetDevice(c->device));
+  VV_ENTER(c);
   { const int rcj = comm_join(c); if (rcj) return rcj; }
   HIPCHK(hipStreamSynchronize(c->stream));
   const int F = c->F;
@@ -447,7 +481,7 @@ int vv_params_set(vv_ctx* c, int32_t D, const float* W, const float* b, const fl
 int vv_params_get(vv_ctx* c, float* W, float* b, float* hW, float* hb) {
   if (!c) return fail(VV_ERR_ARG, "vv_params_get: ctx is NULL");
   if (!c->W) return fail(VV_ERR_STATE, "vv_params_get: no parameters");
-  HIPCHK(hipSetDevice(c->device));
+  VV_ENTER(c);
   { const int rcj = comm_join(c); if (rcj) return rcj; }
   HIPCHK(hipStreamSynchronize(c->stream));
   const size_t nW = (size_t)c->D * c->F;
@@ -553,7 +587,7 @@ static int stage_acquire(vv_ctx* c, size_t bytes, int* slot) {
     if (spins > 4096) { timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
     if (hipStreamQuery(c->stream) == hipSuccess) break;     // nothing queued any more: every earlier step is done
   }
-  g_wait_ms[3] += host_now_ms() - tw0;
+  c->wait_ms[3] += host_now_ms() - tw0;
   *slot = sl;
   return VV_OK;
 }
@@ -620,9 +654,11 @@ static int chunk_plan(vv_ctx* c) {
 // that reads or writes the parameters, their half copy, the momentum or the gradient buffer goes through here first;
 // the one reader that does not is the next step's forward GEMM, which waits chunk by chunk inside the kernel instead.
 extern "C++" int vv_comm_join(vv_ctx* c) {
-  if (c->comm && c->upd_inflight) {
+  // upd_unjoined: the gated forward GEMM has consumed the update chunk by chunk, but nothing on the compute stream waits for
+  // the END of the update's kernels (their plain stores -- W, the history -- are released at that end, not at the gate)
+  if (c->comm && (c->upd_inflight || c->upd_unjoined)) {
     HIPCHK(hipStreamWaitEvent(c->stream, vv::comm_done_event(c->comm), 0));
-    c->upd_inflight = false;
+    c->upd_inflight = c->upd_unjoined = false;
   }
   if (c->gate_err && *(volatile int32_t*)c->gate_err) {
     *c->gate_err = 0;
@@ -680,13 +716,13 @@ static int dd_issue(vv_ctx* c, const int32_t* didx, int idx_on_device, int64_t r
       // (80 us instead of 33) and the next step waits for it (0.239-0.253 ms).  Default: the forward GEMM's stamp -- the
       // faster step, at the price of a forward-GEMM duration (and roofline fraction) that includes the co-running kernels.
       // VV_DEDUP_GATE=1 selects the other.
-      static const int gate_word = getenv("VV_DEDUP_GATE") ? (atoi(getenv("VV_DEDUP_GATE")) != 0) : 0;
+      const int gate_word = c->dd_gate_word;
       const double tw0 = host_now_ms();
       for (unsigned spins = 0; (int32_t)(__atomic_load_n(c->seq_host + gate_word, __ATOMIC_ACQUIRE) - set.used_seq) <= 0; ++spins) {
         if (spins > 4096) { timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
         if (hipStreamQuery(s) == hipSuccess) break;             // nothing queued any more: every earlier step is done
       }
-      g_wait_ms[1] += host_now_ms() - tw0;
+      c->wait_ms[1] += host_now_ms() - tw0;
     }
     set.used_seq = seq;
     DedupArgs da;
@@ -696,7 +732,7 @@ static int dd_issue(vv_ctx* c, const int32_t* didx, int idx_on_device, int64_t r
     {
       // placement of the grouping workgroups beside the forward GEMM (kernels_dedup.hip): only when that GEMM -- sized for
       // the previous step's distinct-row count, as launch_fwd_gemm will size it -- leaves at least 24 CUs idle
-      static const int lds_kb = getenv("VV_DEDUP_LDS_KB") ? atoi(getenv("VV_DEDUP_LDS_KB")) : -1;
+      const int lds_kb = c->dd_lds_kb;
       const int hint = *(volatile int32_t*)c->U_host;
       const long tiles = fwd_gemm_plan(c->R, hint, D, nullptr);
       da.lds_bytes = lds_kb >= 0 ? lds_kb * 1024 : (c->dd_async && gemm_variant() == 5 && hint > 0 && tiles <= c->n_cu - 16 ? 36 * 1024 : 0);
@@ -714,7 +750,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   int rc = check_cfg(c, cfg);
   if (rc) return rc;
   if (!idx) return fail(VV_ERR_ARG, "vv_forward_backward: idx is NULL");
-  HIPCHK(hipSetDevice(c->device));
+  VV_ENTER(c);
   // (an overlapped update of the previous step may still be arriving: see the forward GEMM below)
   if (c->upd_inflight && (cfg->B != c->B || cfg->C != c->C || cfg->Nn != c->Nn || !c->H) && (rc = comm_join(c))) return rc;
   if ((rc = ensure_batch(c, cfg->B, cfg->C, cfg->Nn))) return rc;
@@ -778,7 +814,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
       if (!fired && c->dd_spin_us > 0 && hipStreamQuery(s) != hipSuccess) {
         const double t0 = host_now_ms();
         do { fired = hipEventQuery(set.done) == hipSuccess; } while (!fired && (host_now_ms() - t0) * 1e3 < c->dd_spin_us);
-        g_wait_ms[2] += host_now_ms() - t0;
+        c->wait_ms[2] += host_now_ms() - t0;
       }
       if (!fired) HIPCHK(hipStreamWaitEvent(s, set.done, 0));
     }
@@ -801,12 +837,13 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
     // workgroups leave compute units free for the update's own kernels (all-reduce, SGD: they must be able to run
     // BESIDE the waiting GEMM, or nothing would ever release it); otherwise the stream joins here, as without overlap.
     const long tiles = fwd_gemm_plan(c->R, dd ? fa.R_hint : 0, D, nullptr);
-    static const bool no_gate = getenv("VV_COMM_GATE") && atoi(getenv("VV_COMM_GATE")) == 0;
+    const bool no_gate = !c->comm_gate;
     if (!no_gate && gemm_variant() == 5 && !ablate_on() && fwd_gemm_can_gate(fa) && (!dd || fa.R_hint > 0) && tiles <= c->n_cu - 16) {
       fa.gate = c->w_gate; fa.gate_seq = c->upd_seq; fa.gate_err = c->gate_err_dev;
       fa.gate_n = chunk_plan(c);
       for (int i = 0; i <= fa.gate_n; ++i) fa.gate_kt[i] = c->chunk_kt[i];
-      c->upd_inflight = false;              // whatever follows the forward GEMM on this stream follows the whole update
+      c->upd_inflight = false;              // whatever follows the forward GEMM on this stream follows every PUBLISHED store of the update
+      c->upd_unjoined = true;               // ... its plain stores (W, the history) only behind the event: vv_comm_join for whoever reads those
     } else if ((rc = comm_join(c))) return rc;
   }
   PROFILED(c, "fwd_gemm", launch_fwd_gemm(c->prec, fa, s));
@@ -833,12 +870,11 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
         if (spins > 4096) { timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
         if (hipStreamQuery(s) == hipSuccess) { have = (int32_t)(uint32_t)__atomic_load_n(en, __ATOMIC_ACQUIRE) == want; break; }
       }
-      g_wait_ms[0] += host_now_ms() - tw0;
-      static const bool trace_waits = getenv("VV_TRACE_WAITS") != nullptr;
-      if (trace_waits && ++g_wait_calls % 100 == 0) {
+      c->wait_ms[0] += host_now_ms() - tw0;
+      if (c->trace_waits && ++c->wait_calls % 100 == 0) {
         fprintf(stderr, "[vv waits] per step over the last 100: gradient-scale report %.3f, grouping-set gate %.3f, grouping event %.3f, staging slot %.3f ms\n",
-                g_wait_ms[0] / 100, g_wait_ms[1] / 100, g_wait_ms[2] / 100, g_wait_ms[3] / 100);
-        g_wait_ms[0] = g_wait_ms[1] = g_wait_ms[2] = g_wait_ms[3] = 0;
+                c->wait_ms[0] / 100, c->wait_ms[1] / 100, c->wait_ms[2] / 100, c->wait_ms[3] / 100);
+        c->wait_ms[0] = c->wait_ms[1] = c->wait_ms[2] = c->wait_ms[3] = 0;
       }
       if (have) {
         const uint32_t bits = (uint32_t)(en[0] >> 32), gbits = (uint32_t)(en[1] >> 32);
@@ -885,7 +921,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   if (c->prec == VV_PREC_F16) { gd.gg = c->gg; gd.slots = c->gg_slots; gd.nslot = c->gg_nslot; gd.seq = seq; }
   // (the segment-wise backward needs no repeat at all: its score kernel bounds every instance's gradient and k_seg_bwd
   // settles the scale before it rounds anything -- GuardArgs::proactive)
-  static const bool proactive_on = !(getenv("VV_GUARD_PROACTIVE") && atoi(getenv("VV_GUARD_PROACTIVE")) == 0);   // 0: the repeat form on this path too (A/B)
+  const bool proactive_on = c->guard_proactive;   // (lab) false: the repeat form on this path too (A/B)
   const bool proactive = seg && proactive_on;
   const int n_rounds = c->prec != VV_PREC_F16 ? 0 : (proactive ? 0 : (dd && !seg ? 2 : 1));
   gd.n_of[0] = seg ? 0 : B;
@@ -938,14 +974,14 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
 
   // Data-parallel overlap: the gradient buffer is laid out chunk-major (a few column blocks, each one contiguous
   // all-reduce message) and vv_apply_update runs the update chunk by chunk on the communication stream.
-  const bool chunked = c->comm && c->comm_overlap && c->F % 4 == 0 && c->grads == c->grads_own;
+  const bool chunked = c->comm && c->comm_overlap && c->F % 4 == 0 && c->grads == c->grads_own && !c->grads_exposed;   // (a holder of vv_grads_device's pointer reads the documented flat layout)
   if (chunked) {
     ra.n_chunks = chunk_plan(c);
     for (int i = 0; i <= ra.n_chunks; ++i) ra.chunk_c0[i] = std::min(c->F, c->chunk_kt[i] * BK);
   }
   // Lazy reduction (vv_ctx::red_lazy): with no communicator in the way, dW stays in the slabs until somebody wants it --
   // normally vv_apply_update, which reduces and updates in one launch.  VV_FUSE_UPDATE=0: reduce here, as ever.
-  static const bool fuse_on = !(getenv("VV_FUSE_UPDATE") && atoi(getenv("VV_FUSE_UPDATE")) == 0);
+  const bool fuse_on = c->fuse_update;
   const bool lazy = fuse_on && !c->comm && !c->grads_exposed && c->grads == c->grads_own && c->F % 4 == 0 && c->S <= 8;
   // the W -> half scale update the previous vv_apply_update left pending rides in this step's reduction launch
   if (!lazy && c->scale_pending) {
@@ -1006,17 +1042,17 @@ int vv_forward_backward_ring(vv_ctx* c, const vv_step_cfg* cfg, vv_batch_ring* r
   if (rcn != cfg->C + cfg->Nn || item_begin < 0 || item_begin + cfg->B > rb)
     return fail(VV_ERR_ARG, "vv_forward_backward_ring: the ring holds batches of %d x %d slots; asked for items [%d, %d) x %d",
                 rb, rcn, item_begin, item_begin + cfg->B, cfg->C + cfg->Nn);
-  HIPCHK(hipSetDevice(c->device));
+  VV_ENTER(c);
   const size_t bytes = (size_t)cfg->B * rcn * sizeof(int32_t);
   int sl = 0;
-  const double t0 = g_trace_host_ms >= 0 ? host_now_ms() : 0.0;
+  const double t0 = c->trace_host_ms >= 0 ? host_now_ms() : 0.0;
   if ((rc = stage_acquire(c, bytes, &sl))) return rc;
-  const double t1 = g_trace_host_ms >= 0 ? host_now_ms() : 0.0;
+  const double t1 = c->trace_host_ms >= 0 ? host_now_ms() : 0.0;
   if (vv_batch_ring_next(ring, consumer, item_begin, cfg->B, c->stage_host[sl], label_out, timeout_s))
     return fail(VV_ERR_STATE, "vv_forward_backward_ring: no batch (the sampler's prefetch stopped, or timeout)");
-  if (g_trace_host_ms >= 0) {
+  if (c->trace_host_ms >= 0) {
     const double t2 = host_now_ms();
-    if (t2 - t0 > g_trace_host_ms)
+    if (t2 - t0 > c->trace_host_ms)
       fprintf(stderr, "[vv host] ring stage: slot wait %.3f, batch wait + copy %.3f ms (call %llu)\n", t1 - t0, t2 - t1, (unsigned long long)c->iter);
   }
   const int32_t seq = ++c->step_seq;
@@ -1048,7 +1084,7 @@ int vv_forward_backward_q1(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx
   int rc = check_cfg(c, cfg);
   if (rc) return rc;
   if (!idx || !last_src) return fail(VV_ERR_ARG, "vv_forward_backward_q1: NULL index array");
-  HIPCHK(hipSetDevice(c->device));
+  VV_ENTER(c);
   const int64_t R = (int64_t)cfg->B * (cfg->C + cfg->Nn);
   std::vector<int32_t> patched(idx, idx + R), desc;
   for (int64_t i = 0; i < R; ++i) {
@@ -1074,8 +1110,11 @@ int vv_apply_update(vv_ctx* c, const vv_step_cfg* cfg) {
   int rc = check_cfg(c, cfg);
   if (rc) return rc;
   if (!c->have_fwd) return fail(VV_ERR_STATE, "vv_apply_update: no gradients (call vv_forward_backward)");
-  HIPCHK(hipSetDevice(c->device));
-  if ((rc = comm_join(c))) return rc;                                  // two updates in a row: the first one completes first
+  VV_ENTER(c);
+  // two updates in a row: the first one completes first.  (After a gated forward GEMM -- upd_unjoined -- nothing is due here: the
+  // new update is queued on the communication stream behind the old one, and what this step's kernels on the compute stream read
+  // of the old one -- the half copy, its scale, the bias, the per-block maxima -- was stored at agent scope before the gates opened.)
+  if (c->upd_inflight && (rc = comm_join(c))) return rc;
   const bool overlapped = c->comm && c->grads_pending && c->grads_chunked;
   if (!overlapped && c->grads_pending && (rc = vv_allreduce_grads(c))) return rc;     // data-parallel: the update consumes the SUM over the ranks
   SgdArgs a;
@@ -1092,7 +1131,7 @@ int vv_apply_update(vv_ctx* c, const vv_step_cfg* cfg) {
     fa.r = c->red_args; fa.g = a; fa.prec = c->prec;
     fa.recompute_scale = c->scale_pending ? 1 : 0;
     fa.wmax_prev = c->wmax_blocks + c->wmax_cur * WMAX_SLOTS; fa.wmax_prev_n = c->wmax_n;
-    static const bool keep_grads = getenv("VV_FUSE_KEEP_GRADS") && atoi(getenv("VV_FUSE_KEEP_GRADS")) != 0;
+    const bool keep_grads = c->fuse_keep_grads;
     fa.store_grads = keep_grads;
     c->red_lazy = false; c->grads_stale = !keep_grads;
     int n_new = 0;
@@ -1126,10 +1165,10 @@ int vv_apply_update(vv_ctx* c, const vv_step_cfg* cfg) {
       const int c0 = std::min(c->F, c->chunk_kt[k] * BK), c1 = std::min(c->F, c->chunk_kt[k + 1] * BK);
       const bool last = k == nch - 1;
       const size_t off = (size_t)c->D * c0, n = (size_t)c->D * (c1 - c0) + (last ? (size_t)c->D : 0);
-      static const int delay_us = getenv("VV_COMM_TEST_DELAY_US") ? atoi(getenv("VV_COMM_TEST_DELAY_US")) : 0;
+      const int delay_us = c->comm_test_delay_us;
       if (after) HIPCHK(hipStreamWaitEvent(cs, after, 0));
       if (delay_us > 0) launch_delay(delay_us, cs);      // test hook: a slow exchange, so that the next forward GEMM really waits at its gates
-      static const bool skip_ar1 = getenv("VV_COMM_SKIP_AR1") && atoi(getenv("VV_COMM_SKIP_AR1")) != 0;   // diagnosis: no collective call at world 1
+      const bool skip_ar1 = c->comm_skip_ar1;   // (lab) diagnosis: no collective call at world 1
       if (!(skip_ar1 && vv::comm_world(c->comm) == 1) && n > 0 && vv::comm_allreduce(c->comm, c->grads, off, n, nullptr))
         return fail(VV_ERR_HIP, "all-reduce: %s", vv::comm_error(c->comm));
       a.chunked = 1; a.f_begin = c0; a.f_count = c1 - c0; a.do_bias = last; a.set_scale = k == 0;
@@ -1138,7 +1177,7 @@ int vv_apply_update(vv_ctx* c, const vv_step_cfg* cfg) {
       if (k == 0) PROFILED(c, "sgd", launch_sgd(c->prec, a, cs)); else launch_sgd(c->prec, a, cs);     // (an empty chunk: its wmax slots become 0, the bias if it is the last)
     }
     if (vv::comm_record_done(c->comm)) return fail(VV_ERR_HIP, "all-reduce: %s", vv::comm_error(c->comm));
-    c->grads_pending = false; c->upd_inflight = true;
+    c->grads_pending = false; c->upd_inflight = true; c->upd_unjoined = false;    // (comm_done_event now marks the end of THIS update, behind the old one)
   } else
   PROFILED(c, "sgd", launch_sgd(c->prec, a, c->stream));
   // The next W -> half scale (k_scale_update: folds this kernel's per-block max |w|) is needed by the NEXT k_sgd only.  It
@@ -1161,7 +1200,7 @@ int vv_step(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int idx_on_de
 int vv_loss_get(vv_ctx* c, float* loss, float* violations) {
   if (!c) return fail(VV_ERR_ARG, "vv_loss_get: ctx is NULL");
   if (!c->have_fwd) return fail(VV_ERR_STATE, "vv_loss_get: no forward pass yet");
-  HIPCHK(hipSetDevice(c->device));
+  VV_ENTER(c);
   if (c->gate_err && *(volatile int32_t*)c->gate_err) { const int rcj = comm_join(c); if (rcj) return rcj; }
   { const int rcr = reduce_now(c); if (rcr) return rcr; }
   float h[2];
@@ -1195,7 +1234,7 @@ int vv_grads_bind(vv_ctx* c, void* dev_ptr) {
 int vv_grads_get(vv_ctx* c, float* dW, float* db) {
   if (!c) return fail(VV_ERR_ARG, "vv_grads_get: ctx is NULL");
   if (!c->have_fwd) return fail(VV_ERR_STATE, "vv_grads_get: no backward pass yet");
-  HIPCHK(hipSetDevice(c->device));
+  VV_ENTER(c);
   { const int rcj = comm_join(c); if (rcj) return rcj; }       // block-wise all-reduces in flight: the buffer is read whole
   { const int rcr = reduce_now(c); if (rcr) return rcr; }
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -1218,7 +1257,7 @@ int vv_grads_get(vv_ctx* c, float* dW, float* db) {
 int vv_blobs_get(vv_ctx* c, float* ip2, float* target_score, float* negative_scores, float* ip1_diff) {
   if (!c) return fail(VV_ERR_ARG, "vv_blobs_get: ctx is NULL");
   if (!c->have_fwd) return fail(VV_ERR_STATE, "vv_blobs_get: no forward pass yet");
-  HIPCHK(hipSetDevice(c->device));
+  VV_ENTER(c);
   { const int rcj = comm_join(c); if (rcj) return rcj; }
   HIPCHK(hipStreamSynchronize(c->stream));
   const int B = c->B, CN = c->C + c->Nn, D = c->D, Nn = c->Nn;
@@ -1287,7 +1326,7 @@ int vv_embed(vv_ctx* c, const int32_t* rows, int64_t n, int relu, int l2norm, fl
   if (!c || !out || n <= 0) return fail(VV_ERR_ARG, "vv_embed: bad argument");
   if (!c->table || !c->W) return fail(VV_ERR_STATE, "vv_embed: table and parameters must be set first");
   if (n > (1ll << 30)) return fail(VV_ERR_ARG, "vv_embed: n too large");
-  HIPCHK(hipSetDevice(c->device));
+  VV_ENTER(c);
   { const int rcj = comm_join(c); if (rcj) return rcj; }
   const int D = c->D;
   const int Rp = (int)round_up(n, R_ALIGN);
@@ -1318,7 +1357,7 @@ int vv_embed_mean(vv_ctx* c, const int32_t* rows, int64_t n, int32_t k, const fl
   if (!c || !rows || !out || n <= 0 || k <= 0) return fail(VV_ERR_ARG, "vv_embed_mean: bad argument");
   if (!c->table || !c->W) return fail(VV_ERR_STATE, "vv_embed_mean: table and parameters must be set first");
   if (n > (1ll << 24)) return fail(VV_ERR_ARG, "vv_embed_mean: n too large");
-  HIPCHK(hipSetDevice(c->device));
+  VV_ENTER(c);
   { const int rcj = comm_join(c); if (rcj) return rcj; }
   for (int64_t i = 0; i < n * k; ++i)
     if (rows[i] < 0 || rows[i] >= c->n_rows) return fail(VV_ERR_ARG, "vv_embed_mean: row %d out of range", rows[i]);
@@ -1355,7 +1394,7 @@ int vv_retrieval_stats(vv_ctx* c, const float* feat, int32_t n, int32_t dim, con
   if (!c || !feat || !video_ids || n < 2 || dim < 1 || (n_map > 0 && (!map_ids || !map_cls)))
     return fail(VV_ERR_ARG, "vv_retrieval_stats: bad argument");
   if (n_map < 1) return fail(VV_ERR_ARG, "need atleast one entry in id-to-class map!");   // retrieval_stats_layer.cpp:49
-  HIPCHK(hipSetDevice(c->device));
+  VV_ENTER(c);
   DevTmp<float> dx, dd;
   HIPCHK(dx.alloc((size_t)n * dim)); HIPCHK(dd.alloc((size_t)n * n));
   HIPCHK(hipMemcpyAsync(dx, feat, (size_t)n * dim * 4, hipMemcpyHostToDevice, c->stream));
@@ -1401,7 +1440,7 @@ int vv_comm_init(vv_ctx* c, int32_t world, int32_t rank, const char* id_path, in
   if (transport != VV_COMM_RCCL && transport != VV_COMM_SHM) return fail(VV_ERR_ARG, "vv_comm_init: unknown transport %d", transport);
   if (!c->W) return fail(VV_ERR_STATE, "vv_comm_init: set the parameters first (they size the gradient buffer)");
   if (c->comm) return fail(VV_ERR_STATE, "vv_comm_init: a communicator already exists");
-  HIPCHK(hipSetDevice(c->device));
+  VV_ENTER(c);
   std::string err;
   c->comm = vv::comm_create(world, rank, id_path ? id_path : "", transport, (size_t)c->D * c->F + c->D, &err);
   if (!c->comm) return fail(VV_ERR_HIP, "vv_comm_init: %s", err.c_str());
@@ -1421,7 +1460,7 @@ int vv_allreduce_grads(vv_ctx* c) {
   if (!c->have_fwd) return fail(VV_ERR_STATE, "vv_allreduce_grads: no gradients (call vv_forward_backward)");
   if (!c->grads_pending) return VV_OK;                         // already summed
   if (c->grads_chunked) return VV_OK;                          // overlapped schedule: vv_apply_update exchanges chunk by chunk
-  HIPCHK(hipSetDevice(c->device));
+  VV_ENTER(c);
   // synchronous schedule over RCCL: the collective goes straight into the compute stream (nothing would run beside it)
   const int rc = vv::comm_allreduce_inline(c->comm, c->grads, (size_t)c->D * c->F + c->D, c->stream);
   if (rc < 0) return fail(VV_ERR_HIP, "all-reduce: %s", vv::comm_error(c->comm));
@@ -1437,7 +1476,7 @@ int vv_allreduce_grads(vv_ctx* c) {
 int vv_comm_destroy(vv_ctx* c) {
   if (!c) return VV_OK;
   if (c->comm) { (void)comm_join(c); (void)hipStreamSynchronize(c->stream); vv::comm_destroy(c->comm); c->comm = nullptr; }
-  c->grads_pending = c->grads_chunked = c->upd_inflight = false;
+  c->grads_pending = c->grads_chunked = c->upd_inflight = c->upd_unjoined = false;
   return VV_OK;
 }
 

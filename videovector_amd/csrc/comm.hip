@@ -240,10 +240,14 @@ Comm* comm_create(int world, int rank, const char* id_path, int transport, size_
       // before this launch's rank 0 unlinked and re-created the name) is dropped and the name opened again
       const auto t0 = std::chrono::steady_clock::now();
       for (;;) {
+        // (checked on every turn, whatever branch it takes: a stale object that stays in place because this launch's rank 0 never
+        // arrives must end in the time-out, not in a hot loop of re-opens)
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return fail("timed out waiting for " + c->shm_name + " to be initialised by a live rank 0");
         volatile ShmHdr* h = (volatile ShmHdr*)c->shm;
         if (h->magic == kShmMagic) {
           std::atomic_thread_fence(std::memory_order_acquire);
           if (writer_alive(h->pid, h->start)) break;
+          std::this_thread::sleep_for(std::chrono::milliseconds(2));
           munmap((void*)c->shm, c->shm_bytes); c->shm = nullptr;
           for (;;) {
             const int fd2 = shm_open(c->shm_name.c_str(), O_RDWR, 0600);

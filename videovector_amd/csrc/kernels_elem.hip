@@ -477,15 +477,13 @@ __global__ __launch_bounds__(64 * NW) void k_score_loss_reg(ScoreArgs a) {
 }
 #undef HROW
 
-static int g_score_waves = 8;
-void set_score_waves(int v) { g_score_waves = v == 4 ? 4 : 8; }
 
 template <typename T>
 static bool launch_score_loss_reg(const ScoreArgs& a, hipStream_t s) {
   // fast path: D == 512, at most 6 context rows, at most 56 target/negative rows (52 with four waves)
   if (a.D != 512 || a.C - 1 > 6) return false;
   const int rows = 1 + a.Nn;
-  const int nw = g_score_waves;
+  const int nw = ko().score_waves == 4 ? 4 : 8;
   const size_t lds = sizeof(float) * ((size_t)(2 + 2 * nw) * a.D + 4 * (a.C + a.Nn) + 3 * nw);
 #define VV_SLR(NW, RPW)                                                                                   \
   do {                                                                                                    \
@@ -868,11 +866,10 @@ __global__ __launch_bounds__(64 * NW, DV == 4 ? 4 : 1) void k_score_stream(Score
 // k_score_fwd where an item fits (D = 512, up to 56 target / negative rows, 6 context rows), else the streaming kernel
 bool score_fwd_supported(const ScoreArgs& a) { return a.D == 512 || a.D == 1024; }
 
-static int g_score_stream = 0;            // VV_SCORE_STREAM=1: the one-sweep streaming kernel for every shape (A/B against k_score_fwd)
-void set_score_stream(int v) { g_score_stream = v; }
+// (KernelOpts::score_stream = 1: the one-sweep streaming kernel for every shape, A/B against k_score_fwd)
 void launch_score_fwd(const ScoreArgs& a, hipStream_t s) {
   const int rows = 1 + a.Nn;
-  if (!(a.D == 512 && a.C - 1 <= 6 && rows <= 56) || g_score_stream == 1) {
+  if (!(a.D == 512 && a.C - 1 <= 6 && rows <= 56) || ko().score_stream == 1) {
     const size_t lds = sizeof(float) * ((size_t)(2 + 8) * a.D + 4 * 8);
     if (a.D == 512) {
       (void)hipFuncSetAttribute((const void*)k_score_stream<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1080,11 +1077,9 @@ void launch_seg_bwd(int prec, const SegBwdArgs& a, hipStream_t s) {
 #undef VV_SB
 }
 
-static int g_score_reg = 1;
-void set_score_reg(int v) { g_score_reg = v; }
 
 void launch_score_loss(int prec, const ScoreArgs& a, hipStream_t s) {
-  if (g_score_reg && (prec == 0 ? launch_score_loss_reg<F16>(a, s) : launch_score_loss_reg<BF16>(a, s))) return;
+  if (ko().score_reg && (prec == 0 ? launch_score_loss_reg<F16>(a, s) : launch_score_loss_reg<BF16>(a, s))) return;
   const size_t lds = sizeof(float) * ((size_t)2 * a.D + 2 * (a.D > 1024 ? a.D : 1024) + 8 * (a.C + a.Nn) + 8);
   const bool vec = a.D % 4 == 0;
   const dim3 grid(a.B), block(SL_THREADS);
@@ -1351,7 +1346,11 @@ __global__ __launch_bounds__(256) void k_sgd(SgdArgs a) {
   if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = wmax;
   __syncthreads();
   if (threadIdx.x == 0) {
-    a.wmax_blocks[a.blk_off + blockIdx.x] = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    // (published launches: at agent scope like everything else a kernel of the COMPUTE stream reads behind the gates -- the scale
+    // workgroup of the next k_reduce folds these slots and is ordered behind this kernel by the gate flag only, not by its end)
+    const float wmb = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    if (a.pub_flag) __hip_atomic_store(a.wmax_blocks + a.blk_off + blockIdx.x, wmb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else a.wmax_blocks[a.blk_off + blockIdx.x] = wmb;
     if (blockIdx.x == 0 && a.set_scale) {
       if (a.pub_flag) __hip_atomic_store(&a.scales->sw_cur, sw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else a.scales->sw_cur = sw;
     }

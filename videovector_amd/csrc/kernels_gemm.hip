@@ -392,14 +392,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm(WgradArgs a) {
 // only the forward one of them; 8 = phase-staggered forward + four-wave weight gradient; 0 = the round-1 kernels of this
 // file (two-buffer K = 64 steps, full drain per step), kept as the measured baseline and for VV_WGRAD_TR=0 (operands
 // transposed while staging instead of transposed LDS reads).  VV_ABLATE applies to the phase-staggered kernels.
-static bool g_wgrad_tr = true;
-static int g_ablate = 0;
-void set_ablate(int v) { g_ablate = v; }
-static int g_gemm_variant = 5;
-void set_wgrad_tr(bool on) { g_wgrad_tr = on; }
-void set_gemm_variant(int v) { g_gemm_variant = v; }
-int gemm_variant() { return g_gemm_variant; }
-bool ablate_on() { return g_ablate != 0; }
+// (per context: KernelOpts, vv_internal.h; the variants and ablations are settable in a -DVV_LAB build only)
+int gemm_variant() { return ko().gemm_variant; }
+bool ablate_on() { return ko().ablate != 0; }
 
 template <typename T, bool DROP, bool VEC>
 static void launch_fwd_t(const FwdArgs& a, hipStream_t s) {
@@ -444,7 +439,8 @@ static void launch_fwd_p(const FwdArgs& a, hipStream_t s) {
 
 void launch_fwd_gemm_ph(int prec, const FwdArgs& a, hipStream_t s);
 void launch_fwd_gemm(int prec, const FwdArgs& a, hipStream_t s) {
-  if (g_gemm_variant == 5 || g_gemm_variant == 7 || g_gemm_variant == 8) { FwdArgs b = a; b.abl = g_ablate; launch_fwd_gemm_ph(prec, b, s); return; }
+  const int g_gemm_variant = ko().gemm_variant;
+  if (g_gemm_variant == 5 || g_gemm_variant == 7 || g_gemm_variant == 8) { FwdArgs b = a; b.abl = ko().ablate; launch_fwd_gemm_ph(prec, b, s); return; }
   if (prec == 0) launch_fwd_p<F16>(a, s); else launch_fwd_p<BF16>(a, s);
 }
 
@@ -460,11 +456,13 @@ static void launch_wgrad_t(const WgradArgs& a, hipStream_t s) {
 void launch_wgrad_gemm_ph(int prec, const WgradArgs& a, hipStream_t s);
 void launch_wgrad_gemm_w4(int prec, const WgradArgs& a, hipStream_t s);
 void launch_wgrad_gemm(int prec, const WgradArgs& a, hipStream_t s) {
+  const int g_gemm_variant = ko().gemm_variant; const bool g_wgrad_tr = ko().wgrad_tr != 0;
+#ifdef VV_LAB
   if (g_gemm_variant == 8 && g_wgrad_tr) { launch_wgrad_gemm_w4(prec, a, s); return; }
-  if ((g_gemm_variant == 5 || g_gemm_variant == 6) && g_wgrad_tr) {
+#endif
+  if ((g_gemm_variant == 5 || g_gemm_variant == 6 || g_gemm_variant == 8) && g_wgrad_tr) {
     // (lab: VV_LAB_WG_ABL ablates this kernel alone, at whatever size the step runs -- VV_ABLATE switches the de-duplication off)
-    static const int lab_abl = getenv("VV_LAB_WG_ABL") ? atoi(getenv("VV_LAB_WG_ABL")) : 0;
-    WgradArgs b = a; b.abl = g_ablate ? g_ablate : lab_abl; launch_wgrad_gemm_ph(prec, b, s); return;
+    WgradArgs b = a; b.abl = ko().ablate ? ko().ablate : ko().lab_wg_abl; launch_wgrad_gemm_ph(prec, b, s); return;
   }
   if (prec == 0) { if (g_wgrad_tr) launch_wgrad_t<F16, true>(a, s); else launch_wgrad_t<F16, false>(a, s); }
   else { if (g_wgrad_tr) launch_wgrad_t<BF16, true>(a, s); else launch_wgrad_t<BF16, false>(a, s); }

@@ -352,6 +352,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
     }
 }
 
+#ifdef VV_LAB
 // ------------------------------------------------------------------------------- forward, ten-slot ring (experiment) ----
 // The same kernel with the WHOLE LDS as its ring: ten slots of 16 KiB, half-tiles issued EIGHT ahead of their use (two full
 // K-tiles), counted wait vmcnt(12): six half-tiles (96 KiB per CU) stay in flight across every barrier instead of four.
@@ -482,6 +483,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph10(FwdArgs a) {
     }
 }
 
+#endif  // VV_LAB
 // ------------------------------------------------------------------------------- wgrad --------
 // dW = dY^T X, one split of K per workgroup.  Both operands are k-major in HBM (dY rows / gathered feature rows), so a
 // half-tile is 64 k-rows x 128 columns: 256-B LDS rows of 16 chunks, chunk' = chunk ^ (h(row) << 1) with
@@ -663,6 +665,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
     }
 }
 
+#ifdef VV_LAB
 // ------------------------------------------------------------------------------- weight gradient, four waves ----
 // k_wgrad_gemm_w4: the same product and the same 256 x 256 tile as k_wgrad_gemm_ph with FOUR waves, one per SIMD, each
 // owning a 128 x 128 quadrant (64 accumulator tiles = 256 registers; the fragments live in the other half of the
@@ -824,10 +827,10 @@ static void launch_wgrad_w4_t(const WgradArgs& a, hipStream_t s) {
 void launch_wgrad_gemm_w4(int prec, const WgradArgs& a, hipStream_t s) {
   if (prec == 0) launch_wgrad_w4_t<F16>(a, s); else launch_wgrad_w4_t<BF16>(a, s);
 }
+#endif  // VV_LAB
 
 // ------------------------------------------------------------------------------- launchers ----
-static int g_fwd_lead = 1;                // VV_FWD_LEAD=0: sibling workgroups ask for their gathered rows at the same moment again
-void set_fwd_lead(int v) { g_fwd_lead = v; }
+// (KernelOpts::fwd_lead = 0: sibling workgroups ask for their gathered rows at the same moment again)
 
 template <typename T, bool DROP, bool VEC, int MQ, int DEAD = 0>
 static void launch_fwd_ph_q(const FwdArgs& a, hipStream_t s, long tiles_est) {
@@ -842,7 +845,7 @@ static void launch_fwd_ph_q(const FwdArgs& a, hipStream_t s, long tiles_est) {
     // the sibling lead: 78.6-79.7 against 81.7-82.9 us at the benchmark's de-duplicated size (192-row tiles, one round), 215
     // against 218 us for 192-row tiles in three rounds.  Not for 256-row tiles: that instantiation has no registers left for
     // it (256 + 48 bytes of scratch: dense 229 against 183 us, cfg 5 560 against 470 us)
-    if (g_fwd_lead && Dp / BN > 1 && !a.gate) {        // (the gated kernel keeps its static LDS word: no room beside ten slots)        // (the gated kernel keeps its static LDS word: no room beside ten slots)
+    if (ko().fwd_lead && Dp / BN > 1 && !a.gate) {        // (the gated kernel keeps its static LDS word: no room beside ten slots)        // (the gated kernel keeps its static LDS word: no room beside ten slots)
       constexpr int LDS10 = 10 * PH_SLOT;
       static bool once_l = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, false, DEAD, 1>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS10), true);
@@ -865,10 +868,7 @@ static void launch_fwd_ph_q(const FwdArgs& a, hipStream_t s, long tiles_est) {
 // the gated instantiation exists for the plain forward (no dropout, D % 4 == 0): the caller gates only then
 bool fwd_gemm_can_gate(const FwdArgs& a) { return a.drop_ratio == 0.f && a.D % 4 == 0; }
 
-static bool g_fwd_ring10 = false;         // VV_FWD_RING10=1: the ten-slot forward kernel (experiment)
-void set_fwd_ring10(bool on) { g_fwd_ring10 = on; }
-static int g_ph_mq = 0;                   // VV_PH_MQ: force the tile (2, 3, 4 = 128 / 192 / 256 rows, 31 = 176 rows); 0 = automatic
-void set_ph_mq(int v) { g_ph_mq = v; }
+// (lab: KernelOpts::fwd_ring10 selects the ten-slot forward kernel, KernelOpts::ph_mq forces the tile)
 
 // Tile of the forward GEMM for R rows (R_hint > 0: the distinct-row count of the previous step, the rows the workgroups
 // will really find) and the number of workgroups that get a tile: the least (rounds of 256 workgroups) x (cost of one
@@ -889,7 +889,7 @@ static int fwd_pick_tile(int R, int R_hint, int D, long* tiles_out) {
     const long cost = ((tiles + 255) / 256) * kTileCost[t];
     if (best_cost < 0 || cost < best_cost) { best = t; best_cost = cost; }
   }
-  if (g_ph_mq == 4) best = 0; else if (g_ph_mq == 3) best = 1; else if (g_ph_mq == 31) best = 2; else if (g_ph_mq == 2) best = 3;
+  { const int g_ph_mq = ko().ph_mq; if (g_ph_mq == 4) best = 0; else if (g_ph_mq == 3) best = 1; else if (g_ph_mq == 31) best = 2; else if (g_ph_mq == 2) best = 3; }
   if (tiles_out) *tiles_out = ((Rh + kTileRows[best] - 1) / kTileRows[best]) * (long)(Dp / BN);
   return best;
 }
@@ -903,7 +903,9 @@ long fwd_gemm_plan(int R, int R_hint, int D, int* mq_out) {
 template <typename T, bool DROP, bool VEC>
 static void launch_fwd_ph_t(const FwdArgs& a, hipStream_t s) {
   const int Dp = (int)round_up(a.D, D_ALIGN);
+  (void)Dp;
   const int best = fwd_pick_tile(a.R, a.n_dev ? a.R_hint : 0, a.D, nullptr);
+#ifdef VV_LAB
   if constexpr (T::id == 0 && !DROP && VEC) {
     if (a.abl) {
       const dim3 grid(((a.R + 255) / 256) * (Dp / BN)), block(GEMM_THREADS);
@@ -919,12 +921,12 @@ static void launch_fwd_ph_t(const FwdArgs& a, hipStream_t s) {
   }
   if constexpr (T::id == 0 && !DROP && VEC) {
     // lab: ablations of the 192-row kernel at the de-duplicated size (VV_LAB_FWD_ABL; the step's results are wrong)
-    static const int lab_abl = getenv("VV_LAB_FWD_ABL") ? atoi(getenv("VV_LAB_FWD_ABL")) : 0;
+    const int lab_abl = ko().lab_fwd_abl;
     if (lab_abl && best == 1 && !a.gate) {
       const dim3 grid(((a.R + 191) / 192) * (Dp / BN)), block(GEMM_THREADS);
 #define VV_LAB_FWP(N)                                                                                  \
       if (lab_abl == N) {                                                                              \
-        if (g_fwd_lead) {                                                                              \
+        if (ko().fwd_lead) {                                                                           \
           (void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, 3, N, false, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * PH_SLOT); \
           VV_LAUNCH((k_fwd_gemm_ph<T, DROP, VEC, 3, N, false, 0, 1>), grid, block, 10 * PH_SLOT, s, a);  \
         } else {                                                                                       \
@@ -938,7 +940,7 @@ static void launch_fwd_ph_t(const FwdArgs& a, hipStream_t s) {
     }
   }
   if constexpr (!DROP && VEC) {
-    if (g_fwd_ring10 && !a.gate && a.D % 4 == 0 && a.bias && (best == 0 || best == 1)) {
+    if (ko().fwd_ring10 && !a.gate && a.D % 4 == 0 && a.bias && (best == 0 || best == 1)) {
       const dim3 block(GEMM_THREADS);
       if (best == 0) {
         static bool o4 = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph10<T, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * PH_SLOT), true); (void)o4;
@@ -950,11 +952,14 @@ static void launch_fwd_ph_t(const FwdArgs& a, hipStream_t s) {
       return;
     }
   }
+#endif
   long tiles_est = 0;
   (void)fwd_pick_tile(a.R, a.n_dev ? a.R_hint : 0, a.D, &tiles_est);
   if (best == 0) launch_fwd_ph_q<T, DROP, VEC, 4>(a, s, tiles_est);
   else if (best == 1) launch_fwd_ph_q<T, DROP, VEC, 3>(a, s, tiles_est);
-  else if (best == 2) launch_fwd_ph_q<T, DROP, VEC, 3, 1>(a, s, tiles_est);
+#ifdef VV_LAB
+  else if (best == 2) launch_fwd_ph_q<T, DROP, VEC, 3, 1>(a, s, tiles_est);      // (176-row tile: only on request, KernelOpts::ph_mq = 31)
+#endif
   else launch_fwd_ph_q<T, DROP, VEC, 2>(a, s, tiles_est);
 }
 
@@ -971,6 +976,7 @@ static void launch_wgrad_ph_t(const WgradArgs& a, hipStream_t s) {
                       hipFuncAttributeMaxDynamicSharedMemorySize, PH_WG_LDS_BYTES), true);
   (void)once;
   const dim3 grid((a.tm_count > 0 ? a.tm_count : a.Dp / BM) * (a.Fp / BN) * a.S), block(GEMM_THREADS);
+#ifdef VV_LAB
   if constexpr (T::id == 0) {
     if (a.abl) {
 #define VV_ABL_WGP(N)                                                                                  \
@@ -983,6 +989,7 @@ static void launch_wgrad_ph_t(const WgradArgs& a, hipStream_t s) {
 #undef VV_ABL_WGP
     }
   }
+#endif
   VV_LAUNCH((k_wgrad_gemm_ph<T>), grid, block, PH_WG_LDS_BYTES, s, a);
 }
 

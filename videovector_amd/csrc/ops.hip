@@ -212,7 +212,7 @@ void vv_ops_release(vv_ctx* c) {
   scratch.erase(it);
 }
 
-#define NEED(c) do { if (!(c)) return vv_fail(VV_ERR_ARG, "%s: ctx is NULL", __func__); HIPCHK(hipSetDevice((c)->device)); } while (0)
+#define NEED(c) do { if (!(c)) return vv_fail(VV_ERR_ARG, "%s: ctx is NULL", __func__); HIPCHK(hipSetDevice((c)->device)); vv::g_ko = &(c)->ko; } while (0)
 
 extern "C" {
 

@@ -132,7 +132,22 @@ struct vv_ctx {
                                     // the NEXT step's forward GEMM waits per chunk inside the kernel (FwdArgs::gate)
   bool grads_pending = false;       // a backward pass has produced gradients that have not been all-reduced yet
   bool grads_chunked = false;       // the gradient buffer of the last backward pass is laid out chunk-major (ReduceArgs::n_chunks)
+  // per-context switches (vv_set_option; environment read once, in vv_create).  Nothing of this is process-global.
+  vv::KernelOpts ko;                // which kernels the launchers pick (vv_internal.h)
+  bool fuse_update = true;          // "fuse_update" / VV_FUSE_UPDATE=0: reduce at the end of every backward pass, update apart
+  bool comm_gate = true;            // "comm_gate" / VV_COMM_GATE=0: the overlapped update never gates the forward GEMM (the stream joins)
+  int comm_test_delay_us = 0;       // "comm_test_delay_us" / VV_COMM_TEST_DELAY_US: TEST HOOK -- the communication stream held this long per chunk
+  // (lab) -- settable in a -DVV_LAB build only
+  bool guard_proactive = true;      // VV_GUARD_PROACTIVE=0: the repeat form of the gradient-scale guard on the segment-wise path too
+  bool fuse_keep_grads = false;     // VV_FUSE_KEEP_GRADS=1: the fused update also writes dW out
+  bool comm_skip_ar1 = false;       // VV_COMM_SKIP_AR1=1: no collective call at world 1 (diagnosis)
+  int dd_gate_word = 0;             // VV_DEDUP_GATE=1: the grouping is released by the score kernel's stamp
+  int dd_lds_kb = -1;               // VV_DEDUP_LDS_KB: dynamic LDS the grouping kernels ask for (placement)
+  double trace_host_ms = -1.0;      // VV_TRACE_HOST: report ABI calls that keep the host longer than this
+  bool trace_waits = false;         // VV_TRACE_WAITS: where the host waits
+  double wait_ms[5] = {0, 0, 0, 0, 0}; long wait_calls = 0;
   bool upd_inflight = false;        // an overlapped update is on the communication stream and the compute stream has not joined it
+  bool upd_unjoined = false;        // ... the gated forward GEMM has consumed it, the compute stream has still not waited for its end
   int32_t upd_seq = 0;              // sequence number of the last overlapped update (what w_gate[c] reaches when chunk c is done)
   int32_t* w_gate = nullptr;        // device [W_CHUNKS_MAX * W_GATE_STRIDE]: one flag per 128-B line
   int n_chunks = 3;                 // F-chunks of the overlapped update (env VV_COMM_CHUNKS, 1 .. 4)

@@ -289,6 +289,28 @@ struct FusedUpdArgs {
 };
 constexpr int WMAX_SLOTS = 2048;      // slots of one per-block-maxima buffer (k_sgd writes SGD_BLOCKS of them, k_reduce_sgd RED_DW_BLOCKS)
 
+// Which kernels a context runs (vv_ctx::ko).  The launchers read the options of the context whose entry point is running on this
+// thread (g_ko, set by every ABI entry point next to hipSetDevice); nothing here is process-global, so two contexts of one process
+// do not inherit each other's choices.  Product options are set by vv_set_option (their environment variables are read ONCE per
+// context, in vv_create); the fields marked (lab) select ablated / experimental kernels whose results may be WRONG: they are
+// settable only in a build with -DVV_LAB (make lab -> lib/libvideovec_lab.so, what tools/lab/* use), and the ablated
+// instantiations are compiled only there.
+struct KernelOpts {
+  int fwd_lead = 1;        // "fwd_lead" / VV_FWD_LEAD: the forward GEMM's sibling lead (kernels_gemm_ph.hip)
+  int wgrad_tr = 1;        // "wgrad_tr" / VV_WGRAD_TR: transposed LDS reads in the weight-gradient GEMM (0: the round-1 kernel)
+  int score_stream = 0;    // "score_stream" / VV_SCORE_STREAM: the one-sweep score kernel for every shape
+  int gemm_variant = 5;    // (lab) VV_GEMM_VARIANT: 5 = the phase-staggered kernels; 0 = the round-1 kernels; 6 / 7 / 8 mixtures
+  int ablate = 0;          // (lab) VV_ABLATE: ablated instantiations of the dense-size GEMMs (results wrong)
+  int lab_fwd_abl = 0;     // (lab) VV_LAB_FWD_ABL: ablations of the 192-row forward kernel at the de-duplicated size (results wrong)
+  int lab_wg_abl = 0;      // (lab) VV_LAB_WG_ABL
+  int fwd_ring10 = 0;      // (lab) VV_FWD_RING10: the ten-slot forward kernel
+  int ph_mq = 0;           // (lab) VV_PH_MQ: force the forward tile (2, 3, 4 = 128 / 192 / 256 rows, 31 = 176 rows)
+  int score_reg = 1;       // (lab) VV_SCORE_REG=0: the LDS-resident score kernel
+  int score_waves = 8;     // (lab) VV_SCORE_WAVES=4
+};
+extern thread_local const KernelOpts* g_ko;
+inline const KernelOpts& ko() { static const KernelOpts dflt; return g_ko ? *g_ko : dflt; }
+
 // Kernel timing without extra queue packets: when the ABI layer has armed a pair of events (vv_profile_enable),
 // the launch goes through hipExtLaunchKernelGGL, which stamps the events from the dispatch packet's own
 // start / completion signal.  (A hipEventRecord pair around every kernel costs ~3 us of queue time per record on

@@ -17,7 +17,9 @@ class VVError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libvideovec.so")
+    """The product library.  VV_LIB names another build of the same ABI (tools/lab/*: the -DVV_LAB build with the ablated
+    kernels; A/B of two builds); it must exist -- nothing falls back."""
+    return os.environ.get("VV_LIB") or os.path.join(_HERE, "lib", "libvideovec.so")
 
 
 class _StepCfg(C.Structure):
@@ -61,6 +63,7 @@ def load_library():
         "vv_create": [C.c_int, C.c_int, C.POINTER(vp)],
         "vv_destroy": [vp], "vv_set_stream": [vp, vp], "vv_synchronize": [vp],
         "vv_device_query": [C.c_int, C.c_char_p, C.c_size_t],
+        "vv_set_option": [vp, C.c_char_p, C.c_double],
         "vv_set_dedup": [vp, C.c_int], "vv_dedup_stats": [vp, C.POINTER(i64), C.POINTER(i64)],
         "vv_grad_scale_stats": [vp, C.POINTER(i64), C.POINTER(C.c_float)],
         "vv_table_set": [vp, vp, i64, i32], "vv_table_synth": [vp, C.c_uint64, i64, i32],
@@ -180,6 +183,10 @@ class Engine:
 
     def synchronize(self):
         self._chk(self.L.vv_synchronize(self.h))
+
+    def set_option(self, name, value):
+        """Per-context execution switch by name (include/videovec.h: vv_set_option)."""
+        self._chk(self.L.vv_set_option(self.h, name.encode(), float(value)))
 
     def set_dedup(self, on):
         """Row de-duplication of the batch (include/videovec.h: vv_set_dedup); default on."""
