@@ -122,7 +122,7 @@ def test_bench_eight_ranks_overlap_node_sampler_matches_one_process_at_the_globa
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 8192 and d["config"]["parallelism"] == "dp8"
-    assert "overlap" in d["config"]["allreduce"] and "shared-memory ring" in d["config"]["sampler"]
+    assert "F-chunk by F-chunk" in d["config"]["allreduce"] and "shared-memory ring" in d["config"]["sampler"]
     n_it = d["settle"]["steps"] + Wm + K
     assert n_it == 6
     # ---- the same iterations in ONE process at the global batch

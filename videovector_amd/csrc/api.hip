@@ -1086,24 +1086,30 @@ int vv_forward_backward_q1(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx
   if (!idx || !last_src) return fail(VV_ERR_ARG, "vv_forward_backward_q1: NULL index array");
   VV_ENTER(c);
   const int64_t R = (int64_t)cfg->B * (cfg->C + cfg->Nn);
-  std::vector<int32_t> patched(idx, idx + R), desc;
+  // The patched indices AND the composite rows' descriptors travel in one pinned, device-mapped staging slot that the kernels read
+  // in place (as vv_forward_backward_ring's indices do): no host-side copy to wait for.  (Round 3 copied the descriptors from a
+  // host temporary and synchronised the stream on EVERY step: the device idled ~30 us of the shipped configuration's 0.29 ms.)
+  int sl = 0;
+  if ((rc = stage_acquire(c, (size_t)R * 12, &sl))) return rc;          // R indices + at most R descriptors of two words
+  int32_t* dst = c->stage_host[sl];
+  int32_t* desc = dst + R;
+  int64_t P = 0;
   for (int64_t i = 0; i < R; ++i) {
     if (idx[i] < -1 || idx[i] >= c->n_rows || last_src[i] < -1 || last_src[i] >= c->n_rows)
       return fail(VV_ERR_ARG, "index %lld out of range", (long long)i);
+    int32_t v = idx[i];
     if (idx[i] != last_src[i] && idx[i] >= 0) {
-      patched[i] = (int32_t)(c->n_rows + 1 + (int64_t)desc.size() / 2);
-      desc.push_back(idx[i]); desc.push_back(last_src[i]);
+      v = (int32_t)(c->n_rows + 1 + P);
+      desc[2 * P] = idx[i]; desc[2 * P + 1] = last_src[i];
+      ++P;
     }
+    dst[i] = v;
   }
-  const int64_t P = (int64_t)desc.size() / 2;
-  if (P > 0) {
-    if ((rc = ensure_scratch_rows(c, P))) return rc;
-    if (2 * P > c->patch_desc_cap) { dfree(c->patch_desc); c->patch_desc = nullptr; HIPCHK(hipMalloc(&c->patch_desc, 4 * P * sizeof(int32_t))); c->patch_desc_cap = 4 * P; }
-    HIPCHK(hipMemcpyAsync(c->patch_desc, desc.data(), desc.size() * 4, hipMemcpyHostToDevice, c->stream));
-    launch_patch_rows(c->table, c->patch_desc, P, c->n_rows + 1, c->F, c->Fp, c->stream);
-    HIPCHK(hipStreamSynchronize(c->stream));     // desc is a host temporary
-  }
-  return fb_impl(c, cfg, patched.data(), 0, c->n_rows + 1 + P);
+  if (P > 0 && (rc = ensure_scratch_rows(c, P))) return rc;
+  const int32_t seq = ++c->step_seq;
+  c->stage_seq[sl] = seq;                                               // the slot is free again when this step's forward GEMM has started
+  if (P > 0) launch_patch_rows(c->table, c->stage_dev[sl] + R, P, c->n_rows + 1, c->F, c->Fp, c->stream);
+  return fb_impl(c, cfg, c->stage_dev[sl], 2, c->n_rows + 1 + P, seq);
 }
 
 int vv_apply_update(vv_ctx* c, const vv_step_cfg* cfg) {

@@ -71,8 +71,24 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 //   dAh = sum_q c_q H[q]/(n_q+eps);   dH[q] = c_q (n_q^2 Ah - H[q] t_q)/(n_q^3 + eps)
 //   dA  = (sA dAh - A (A.dAh))/(sA^1.5 + eps), dH[j] = c_j dA
 //   dY  = dH * drop_scale * [H > 0]
-template <typename T, bool VEC>
-__global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
+// block-wide sums over NW waves; red must hold >= 3 * NW floats; results broadcast to all threads
+template <int NW>
+__device__ __forceinline__ float block_sum_w(float v, float* red) {
+  v = wave_sum63(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) s += red[w];
+  return s;
+}
+// NT threads per item: 256 (four waves) where a batch brings a thousand items; 1024 for wide rows in small batches (the reference's
+// shipped configuration: 128 items of 15 rows x 4096 columns -- with four waves per item half of the chip's SIMDs had no wave at all
+// and every row was one wave's serial chain of loads: 55 us for 47 MB)
+template <typename T, bool VEC, int NT = SL_THREADS>
+__global__ __launch_bounds__(NT) void k_score_loss(ScoreArgs a) {
+  constexpr int NWV = NT / 64;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int D = a.D, C = a.C, Nn = a.Nn, CN = C + Nn;
   float* A = sm;               // [D] context mean
@@ -83,8 +99,8 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
   float* n2 = acc1 + PD;       // [CN] squared norms
   float* tq = n2 + CN;         // [CN] dots with Ah
   float* cq = tq + CN;         // [CN] upstream coefficients
-  float* red = cq + CN;        // [8]
-  int* hoff = (int*)(red + 8); // [CN] row of H holding channel ch (dedup: the shared per-slot row)
+  float* red = cq + CN;        // [16]
+  int* hoff = (int*)(red + 16); // [CN] row of H holding channel ch (dedup: the shared per-slot row)
   int* ooff = hoff + CN;       // [CN] row of dYh receiving channel ch's gradient
   float* k1 = (float*)(ooff + CN);   // [CN] per-row constants of the backward pass (see phase 4)
   float* k2 = k1 + CN;
@@ -95,7 +111,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
   float sgm;
   if (!gg_begin(a.guard, ggs, sgm)) return;
   const float sg = a.sg * sgm;
-  for (int ch = tid; ch < CN; ch += SL_THREADS) {
+  for (int ch = tid; ch < CN; ch += NT) {
     const int r = b * CN + ch;
     hoff[ch] = a.map ? a.map[r] : r;
     ooff[ch] = a.map ? a.seg_start[a.map[r]] + a.ord[r] : r;
@@ -105,21 +121,21 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
 
   // ---- phase 1: context mean (column-parallel) and its norm
   float ssq = 0.f;
-  for (int d = tid; d < D; d += SL_THREADS) {
+  for (int d = tid; d < D; d += NT) {
     float s = 0.f;
     for (int j = 1; j < C; ++j) s += a.coeff[j - 1] * HROW(j)[d];
     A[d] = s;
     ssq += s * s;
   }
-  const float sA = block_sum(ssq, red);
+  const float sA = block_sum_w<NWV>(ssq, red);
   const float nA = sqrtf(sA) + eps;
-  for (int d = tid; d < D; d += SL_THREADS) {
+  for (int d = tid; d < D; d += NT) {
     Ah[d] = A[d] / nA;
   }
   __syncthreads();
 
   // ---- phase 2: norms and dots of target / negative rows (one row per wave at a time)
-  for (int qi = wave; qi < 1 + Nn; qi += 4) {
+  for (int qi = wave; qi < 1 + Nn; qi += NWV) {
     const int ch = qi == 0 ? 0 : C + qi - 1;
     const float* h = HROW(ch);
     float s = 0.f, t = 0.f;
@@ -142,7 +158,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
   const float sp = tq[0] / (sqrtf(n2[0]) + eps);
   const float wb = a.item_w ? a.item_w[b] : 1.f;
   float lsum = 0.f, vsum = 0.f, gsum = 0.f;
-  for (int k = tid; k < Nn; k += SL_THREADS) {
+  for (int k = tid; k < Nn; k += NT) {
     const int ch = C + k;
     const float sn = tq[ch] / (sqrtf(n2[ch]) + eps);
     const float d = sp - sn;
@@ -155,9 +171,9 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
     cq[ch] = g;
     if (a.s_bogus) a.s_bogus[(int64_t)b * Nn + k] = sn;
   }
-  lsum = block_sum(lsum, red);
-  vsum = block_sum(vsum, red);
-  gsum = block_sum(gsum, red);
+  lsum = block_sum_w<NWV>(lsum, red);
+  vsum = block_sum_w<NWV>(vsum, red);
+  gsum = block_sum_w<NWV>(gsum, red);
   if (tid == 0) {
     cq[0] = -gsum;
     a.loss_part[b] = lsum;
@@ -169,7 +185,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
   }
   __syncthreads();
   // per-row constants, once per row instead of once per (row, column group): g*sg = k1*Ah - k2*x, dAh += k3*x
-  for (int qi = tid; qi < 1 + Nn; qi += SL_THREADS) {
+  for (int qi = tid; qi < 1 + Nn; qi += NT) {
     const int ch = qi == 0 ? 0 : C + qi - 1;
     const float c = cq[ch], s = n2[ch], rs = sqrtf(s);
     const float cd = c * __builtin_amdgcn_rcpf(s * rs + eps) * a.drop_scale * sg;
@@ -183,8 +199,8 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
   float gmx = 0.f;                            // max |g| in scaled units before rounding (f16 gradient-scale guard)
   constexpr int W = VEC ? 4 : 1;
   const int Dv = D / W;                       // column groups
-  const int Dvp = Dv < SL_THREADS ? Dv : SL_THREADS;
-  const int G = SL_THREADS / Dvp;             // row groups running side by side
+  const int Dvp = Dv < NT ? Dv : NT;
+  const int G = NT / Dvp;             // row groups running side by side
   if (tid < G * Dvp) {
     const int rg = tid / Dvp;
     for (int cg = tid % Dvp; cg < Dv; cg += Dvp) {
@@ -221,15 +237,15 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
 
   // ---- phase 5: backward of the context normalisation and mean (column-parallel)
   float dot = 0.f;
-  for (int d = tid; d < D; d += SL_THREADS) {
+  for (int d = tid; d < D; d += NT) {
     float u = 0.f;
     for (int gI = 0; gI < G; ++gI) u += acc0[gI * D + d];
     acc0[d] = u;                 // each column is owned by one thread from here on
     dot += A[d] * u;
   }
-  dot = block_sum(dot, red);
+  dot = block_sum_w<NWV>(dot, red);
   const float inv_denA = 1.f / (sA * sqrtf(sA) + eps);
-  for (int d = tid; d < D; d += SL_THREADS) {
+  for (int d = tid; d < D; d += NT) {
     const float dA = (sA * acc0[d] - A[d] * dot) * inv_denA;
     float dbv = 0.f;
     for (int gI = 0; gI < G; ++gI) dbv += acc1[gI * D + d];
@@ -250,18 +266,6 @@ __global__ __launch_bounds__(SL_THREADS) void k_score_loss(ScoreArgs a) {
 // VGPRs between the forward reductions and the backward pass, so every row of ip2 is read from HBM
 // exactly once (the streaming kernel above re-reads them, and at ~8 workgroups per CU the 110 KB per
 // item do not survive in L2).  RPW = rows per wave, DV = float4 chunks per lane (D = 256*DV).
-// block-wide sums over NW waves; red must hold >= 3 * NW floats; results broadcast to all threads
-template <int NW>
-__device__ __forceinline__ float block_sum_w(float v, float* red) {
-  v = wave_sum63(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  float s = 0.f;
-#pragma unroll
-  for (int w = 0; w < NW; ++w) s += red[w];
-  return s;
-}
 template <int NW>
 __device__ __forceinline__ void block_sum3_w(float& x, float& y, float& z, float* red) {
   x = wave_sum63(x); y = wave_sum63(y); z = wave_sum63(z);
@@ -1080,17 +1084,18 @@ void launch_seg_bwd(int prec, const SegBwdArgs& a, hipStream_t s) {
 
 void launch_score_loss(int prec, const ScoreArgs& a, hipStream_t s) {
   if (ko().score_reg && (prec == 0 ? launch_score_loss_reg<F16>(a, s) : launch_score_loss_reg<BF16>(a, s))) return;
-  const size_t lds = sizeof(float) * ((size_t)2 * a.D + 2 * (a.D > 1024 ? a.D : 1024) + 8 * (a.C + a.Nn) + 8);
+  const size_t lds = sizeof(float) * ((size_t)2 * a.D + 2 * (a.D > 1024 ? a.D : 1024) + 8 * (a.C + a.Nn) + 16);
   const bool vec = a.D % 4 == 0;
-  const dim3 grid(a.B), block(SL_THREADS);
-#define VV_SL(T, V)                                                                              \
+  const bool wide = vec && a.D >= 2048 && a.B <= 512;       // few items of wide rows: sixteen waves per item
+  const dim3 grid(a.B), block(wide ? 1024 : SL_THREADS);
+#define VV_SL(T, V, NT)                                                                          \
   do {                                                                                           \
-    (void)hipFuncSetAttribute((const void*)k_score_loss<T, V>,                                   \
+    (void)hipFuncSetAttribute((const void*)k_score_loss<T, V, NT>,                               \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
-    VV_LAUNCH((k_score_loss<T, V>), grid, block, lds, s, a);                            \
+    VV_LAUNCH((k_score_loss<T, V, NT>), grid, block, lds, s, a);                        \
   } while (0)
-  if (prec == 0) { if (vec) VV_SL(F16, true); else VV_SL(F16, false); }
-  else { if (vec) VV_SL(BF16, true); else VV_SL(BF16, false); }
+  if (prec == 0) { if (wide) VV_SL(F16, true, 1024); else if (vec) VV_SL(F16, true, SL_THREADS); else VV_SL(F16, false, SL_THREADS); }
+  else { if (wide) VV_SL(BF16, true, 1024); else if (vec) VV_SL(BF16, true, SL_THREADS); else VV_SL(BF16, false, SL_THREADS); }
 #undef VV_SL
 }
 

@@ -68,6 +68,11 @@ __device__ __forceinline__ int ph_xcd_remap(int bid, int nblk) {
   return x * q + (x < rem ? x : rem) + (bid >> 3);
 }
 
+// 32-bit finaliser of the dropout mask's counter hash (two multiply-xorshift rounds: C. Wellons' "lowbias32" constants)
+__device__ __forceinline__ uint32_t drop_mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
 constexpr int PH_SLOT = 16384;                 // one half-tile: 128 rows x 64 halves
 constexpr int PH_LDS_BYTES = 8 * PH_SLOT;      // ring of 8 slots = 128 KiB
 #define PH_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -102,7 +107,9 @@ constexpr int PH_LDS_BYTES = 8 * PH_SLOT;      // ring of 8 slots = 128 KiB
 // than the stream gained): in the code the leading half is ALWAYS A_lo -- odd column tiles swap which rows are their lower and
 // upper half instead --, it lives one K-tile longer in a ring of FOUR slots (its two natural ones + a ninth and a tenth: all
 // 160 KiB of LDS), and the loop is unrolled by four K-tiles so that every ring position is a constant.
-template <typename T, bool DROP, bool VEC, int MQ, int ABL = 0, bool GATE = false, int DEAD = 0, int LEAD = 0>
+// DROP: 0 no dropout, 1 the counter-based mask, 2 an explicit mask (FwdArgs::mask) -- separate instantiations: with the choice made per
+// element at run time the epilogue was 700 branches and 50 KB of code, and the dense-size kernel took 17 us longer for it
+template <typename T, int DROP, bool VEC, int MQ, int ABL = 0, bool GATE = false, int DEAD = 0, int LEAD = 0>
 __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int HROWS = 32 * MQ;               // rows of the lower A half-tile (upper: HROWS - 16 DEAD)
@@ -311,6 +318,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
   const float sw_now = GATE ? __hip_atomic_load(&a.scales->sw_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.scales->sw_cur;
   const float descale = 1.0f / (a.scales->sx * sw_now);
   const float dscale = DROP ? 1.0f / (1.0f - a.drop_ratio) : 1.0f;
+  const float descale_d = descale * dscale;
+  const float rcp_cn = DROP ? 1.0f / (float)a.CN : 0.f;
+  const uint32_t drop_thr = DROP ? (uint32_t)(a.drop_ratio * 65536.f + 0.5f) : 0u;      // keep <=> 16-bit uniform >= thr
+  const uint32_t drop_s32 = DROP ? (uint32_t)(mix64(a.drop_seed, 0x5eedull) >> 32) : 0u;  // the step's stream
   const float lo = a.relu ? 0.f : -INFINITY;
 #pragma unroll
   for (int mh = 0; mh < 2; ++mh)
@@ -320,9 +331,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
       const int m = m0 + (mh ^ hswap) * HROWS + wm * 16 * MQ + mi * 16 + frow;
       if (m >= R) continue;
       int64_t ref_row = 0;
+      uint32_t row_ctr = 0;                    // counter of the row's first quad of outputs (two counters per quad)
       if (DROP) {
-        const int bb = m / a.CN, ch = m - bb * a.CN;
+        // m = bb CN + ch without an integer division (m < 2^24: exact in fp32 up to the correction step)
+        int bb = (int)((float)m * rcp_cn), ch = m - bb * a.CN;
+        if (ch < 0) { --bb; ch += a.CN; } else if (ch >= a.CN) { ++bb; ch -= a.CN; }
         ref_row = (int64_t)ch * a.B + bb;
+        const uint64_t r2 = (uint64_t)ref_row * (uint64_t)(2 * ((a.D + 3) >> 2));
+        row_ctr = (uint32_t)r2 + (uint32_t)(r2 >> 32) * 0x9E3779B9u + drop_s32;
       }
 #pragma unroll
       for (int nh = 0; nh < 2; ++nh)
@@ -331,16 +347,23 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
           const int n = n0 + nh * 128 + wn * 32 + ni * 16 + fq * 4;
           if (n >= a.D) continue;
           float v[4];
+          // counter-based mask: ONE 32-bit hash serves two outputs (16-bit uniforms: the drop probability is ratio to 2^-16), two hashes
+          // the lane's four -- instead of a 64-bit splitmix per output (+30 us on the 0.19 ms dense-size kernel)
+          uint32_t u16x2[2] = {0u, 0u};
+          if (DROP == 1) {
+            const uint32_t c0 = row_ctr + (uint32_t)(n >> 1);                 // (n is a multiple of 4: quad n / 4, counters 2 (n / 4), + 1)
+            u16x2[0] = drop_mix32(c0); u16x2[1] = drop_mix32(c0 + 1u);
+          }
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const float bj = (n + j < a.D) ? a.bias[n + j] : 0.f;
-            v[j] = fmaxf(acc[mh][mi][nh][ni][j] * descale + bj, lo);
+            // (dropout: the 1 / (1 - ratio) of the kept values rides in the descale and the bias -- ReLU commutes with a positive factor)
+            v[j] = fmaxf(acc[mh][mi][nh][ni][j] * descale_d + bj * dscale, lo);
             if (DROP) {
-              const uint64_t e = (uint64_t)(ref_row * a.D + n + j);
               bool keep;
-              if (a.mask) keep = (n + j < a.D) && a.mask[e] != 0;
-              else keep = (float)(mix64(a.drop_seed, e) >> 40) * (1.0f / 16777216.0f) >= a.drop_ratio;
-              v[j] = keep ? v[j] * dscale : 0.f;
+              if (DROP == 2) keep = (n + j < a.D) && a.mask[(uint64_t)(ref_row * a.D + n + j)] != 0;
+              else keep = ((u16x2[j >> 1] >> (16 * (j & 1))) & 0xffffu) >= drop_thr;
+              v[j] = keep ? v[j] : 0.f;
             }
           }
           float* dst = a.H + (int64_t)m * a.D + n;
@@ -832,7 +855,7 @@ void launch_wgrad_gemm_w4(int prec, const WgradArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------- launchers ----
 // (KernelOpts::fwd_lead = 0: sibling workgroups ask for their gathered rows at the same moment again)
 
-template <typename T, bool DROP, bool VEC, int MQ, int DEAD = 0>
+template <typename T, int DROP, bool VEC, int MQ, int DEAD = 0>
 static void launch_fwd_ph_q(const FwdArgs& a, hipStream_t s, long tiles_est) {
   static bool once = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, false, DEAD>,
                       hipFuncAttributeMaxDynamicSharedMemorySize, PH_LDS_BYTES), true);
@@ -900,7 +923,7 @@ long fwd_gemm_plan(int R, int R_hint, int D, int* mq_out) {
   return tiles;
 }
 
-template <typename T, bool DROP, bool VEC>
+template <typename T, int DROP, bool VEC>
 static void launch_fwd_ph_t(const FwdArgs& a, hipStream_t s) {
   const int Dp = (int)round_up(a.D, D_ALIGN);
   (void)Dp;
@@ -966,8 +989,9 @@ static void launch_fwd_ph_t(const FwdArgs& a, hipStream_t s) {
 template <typename T>
 static void launch_fwd_ph_p(const FwdArgs& a, hipStream_t s) {
   const bool drop = a.drop_ratio > 0.f, vec = a.D % 4 == 0;
-  if (drop) { if (vec) launch_fwd_ph_t<T, true, true>(a, s); else launch_fwd_ph_t<T, true, false>(a, s); }
-  else { if (vec) launch_fwd_ph_t<T, false, true>(a, s); else launch_fwd_ph_t<T, false, false>(a, s); }
+  if (drop && a.mask) { if (vec) launch_fwd_ph_t<T, 2, true>(a, s); else launch_fwd_ph_t<T, 2, false>(a, s); }
+  else if (drop) { if (vec) launch_fwd_ph_t<T, 1, true>(a, s); else launch_fwd_ph_t<T, 1, false>(a, s); }
+  else { if (vec) launch_fwd_ph_t<T, 0, true>(a, s); else launch_fwd_ph_t<T, 0, false>(a, s); }
 }
 
 template <typename T>
