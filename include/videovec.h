@@ -71,6 +71,7 @@ int vv_set_dedup(vv_ctx* ctx, int on);
  * Ablated / experimental kernels (timing studies whose results may be wrong) are NOT reachable through this library: they and their
  * switches exist only in the lab build (make -C videovector_amd/csrc lab).  Unknown name: VV_ERR_ARG. */
 int vv_set_option(vv_ctx* ctx, const char* name, double value);
+int vv_get_option(vv_ctx* ctx, const char* name, double* value);      /* ... and their current values */
 int vv_dedup_stats(vv_ctx* ctx, int64_t* rows, int64_t* unique_rows);
 /* f16 operands: the 16-bit gradient operand of the weight-gradient product (InnerProductLayer::Backward,
  * inner_product_layer.cpp:80-97) carries one power-of-two scale per step.  A gradient value outside f16's range is never

@@ -292,6 +292,22 @@ int vv_set_option(vv_ctx* c, const char* name, double value) {
   return fail(VV_ERR_ARG, "vv_set_option: unknown option '%s'", name);
 }
 
+int vv_get_option(vv_ctx* c, const char* name, double* value) {
+  if (!c || !name || !value) return fail(VV_ERR_ARG, "vv_get_option: NULL argument");
+  const std::string n(name);
+  if (n == "dedup") *value = c->dedup;
+  else if (n == "seg_bwd") *value = c->seg_bwd;
+  else if (n == "fuse_update") *value = c->fuse_update;
+  else if (n == "fwd_lead") *value = c->ko.fwd_lead;
+  else if (n == "wgrad_tr") *value = c->ko.wgrad_tr;
+  else if (n == "score_stream") *value = c->ko.score_stream;
+  else if (n == "comm_gate") *value = c->comm_gate;
+  else if (n == "comm_chunks") *value = c->n_chunks;
+  else if (n == "comm_test_delay_us") *value = c->comm_test_delay_us;
+  else return fail(VV_ERR_ARG, "vv_get_option: unknown option '%s'", name);
+  return VV_OK;
+}
+
 int vv_set_dedup(vv_ctx* c, int on) {
   if (!c) return fail(VV_ERR_ARG, "vv_set_dedup: ctx is NULL");
   c->dedup = on != 0;

@@ -63,7 +63,7 @@ def load_library():
         "vv_create": [C.c_int, C.c_int, C.POINTER(vp)],
         "vv_destroy": [vp], "vv_set_stream": [vp, vp], "vv_synchronize": [vp],
         "vv_device_query": [C.c_int, C.c_char_p, C.c_size_t],
-        "vv_set_option": [vp, C.c_char_p, C.c_double],
+        "vv_set_option": [vp, C.c_char_p, C.c_double], "vv_get_option": [vp, C.c_char_p, C.POINTER(C.c_double)],
         "vv_set_dedup": [vp, C.c_int], "vv_dedup_stats": [vp, C.POINTER(i64), C.POINTER(i64)],
         "vv_grad_scale_stats": [vp, C.POINTER(i64), C.POINTER(C.c_float)],
         "vv_table_set": [vp, vp, i64, i32], "vv_table_synth": [vp, C.c_uint64, i64, i32],
@@ -187,6 +187,11 @@ class Engine:
     def set_option(self, name, value):
         """Per-context execution switch by name (include/videovec.h: vv_set_option)."""
         self._chk(self.L.vv_set_option(self.h, name.encode(), float(value)))
+
+    def get_option(self, name):
+        v = C.c_double(0)
+        self._chk(self.L.vv_get_option(self.h, name.encode(), C.byref(v)))
+        return v.value
 
     def set_dedup(self, on):
         """Row de-duplication of the batch (include/videovec.h: vv_set_dedup); default on."""
