@@ -132,12 +132,14 @@ def main():
                          "the reference's own project files (mednet_embedding_train.prototxt:13-23,200,226: batch 128, window 5, "
                          "10 negatives of which up to 6 from the same video -- quirk Q1 --, 4096->4096, dropout 0.9).  The last two "
                          "are informational, not the contract's bench line")
-    ap.add_argument("--allreduce", default="auto", choices=["auto", "sync", "overlap", "stale"],
+    ap.add_argument("--allreduce", default="auto", choices=["auto", "sync", "overlap", "sharded", "stale"],
                     help="N>1.  'overlap' (auto with --comm lib): exact synchronous SGD with the exchange hidden behind the NEXT "
                          "step's forward GEMM -- the update runs F-chunk by F-chunk on the library's communication stream "
                          "(all-reduce of the chunk, SGD on its columns, publish) while the forward GEMM already runs and "
                          "waits per chunk inside the kernel.  'sync': the same update, the whole all-reduce of [dW|db] "
-                         "between backward and update, exposed.  'stale': the all-reduce of iteration t overlaps "
+                         "between backward and update, exposed.  'sharded': reduce-scatter of the gradients, the solver's rule on this rank's "
+                         "D / N rows of W, all-gather of the 16-bit copy of W and the bias (3/4 of the wire bytes, 1/N of the update's "
+                         "memory traffic; the same parameters bit for bit).  'stale': the all-reduce of iteration t overlaps "
                          "iteration t+1 and gradients are applied one update late (NOT the reference's algorithm; opt-in, "
                          "labelled)")
     ap.add_argument("--comm", default="lib", choices=["lib", "torch"],
@@ -337,11 +339,11 @@ def main():
     stride = B_PER_GPU * (C + NN) * 4
     idx_dev = torch.from_numpy(batches).to(dev) if batches is not None else None
     mode = args.allreduce if args.allreduce != "auto" else (("overlap" if args.comm == "lib" else "sync") if world > 1 else "none")
-    if world == 1 and mode in ("sync", "overlap"):
+    if world == 1 and mode in ("sync", "overlap", "sharded"):
         mode = "none"
-    comm = args.comm if mode in ("sync", "overlap") else "none"
-    if mode == "overlap" and comm == "torch":
-        raise SystemExit("--allreduce overlap needs --comm lib (the chunked all-reduce lives in the library)")
+    comm = args.comm if mode in ("sync", "overlap", "sharded") else "none"
+    if mode in ("overlap", "sharded") and comm == "torch":
+        raise SystemExit("--allreduce %s needs --comm lib (the chunked all-reduce / the sharded update live in the library)" % mode)
     # the library's communicator: RCCL, or the shared-memory transport under the one-device test hook
     comm_transport = "rccl" if os.environ.get("VV_DIST_BACKEND", "nccl") == "nccl" else "shm"
     comm_id_path = "/tmp/vv_comm_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", str(os.getppid())))
@@ -384,7 +386,7 @@ def main():
                 ok = 1
                 try:
                     self.eng.comm_init(world, rank, comm_id_path + "_%d" % Run.n_comm, comm_transport)
-                    self.eng.comm_overlap(mode == "overlap")
+                    self.eng.comm_schedule(mode)
                 except vv.VVError as e:
                     ok = 0
                     print("rank %d: library communicator failed (%s)" % (rank, e), file=sys.stderr)
@@ -639,6 +641,9 @@ def main():
                        "allreduce": {"none": "none (1 GPU)", "sync": "synchronous (exact SGD), exposed",
                                      "overlap": "exact SGD; the update (all-reduce, SGD, publish) runs F-chunk by F-chunk on the communication "
                                                 "stream while the next step's forward GEMM runs and waits per chunk inside the kernel",
+                                     "sharded": "exact SGD; reduce-scatter of the gradients, the solver's rule on this rank's D / N rows, all-gather of "
+                                                "the 16-bit copy of W + the bias (3/4 of the all-reduce's wire bytes, 1/N of the update's "
+                                                "traffic) on the communication stream; the next forward GEMM waits at one gate",
                                      "stale": "overlapped with the next iteration's forward/backward "
                                               "(one-update delayed gradients: NOT the reference's algorithm)"}[mode]},
             "roofline": roof,

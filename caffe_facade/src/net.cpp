@@ -163,6 +163,13 @@ void Net<Dtype>::Init(const NetParameter& in_param) {
     const bool shm = getenv("VV_COMM") && !strcmp(getenv("VV_COMM"), "shm");
     VV_CHECK(vv_comm_init(ctx_, Caffe::world(), Caffe::rank(), id_path.c_str(), shm ? VV_COMM_SHM : VV_COMM_RCCL));
     VV_CHECK(vv_comm_overlap(ctx_, !(getenv("VV_COMM_OVERLAP") && atoi(getenv("VV_COMM_OVERLAP")) == 0)));
+    // VV_COMM_SCHEDULE=sync | overlap | sharded names the schedule outright (sharded: reduce-scatter, the update on this rank's rows,
+    // all-gather of the 16-bit copy: include/videovec.h, vv_comm_schedule)
+    if (const char* sch = getenv("VV_COMM_SCHEDULE")) {
+      const int which = !strcmp(sch, "sync") ? 0 : !strcmp(sch, "overlap") ? 1 : !strcmp(sch, "sharded") ? 2 : -1;
+      CHECK_GE(which, 0) << "VV_COMM_SCHEDULE=" << sch << ": sync, overlap or sharded";
+      VV_CHECK(vv_comm_schedule(ctx_, which));
+    }
     cfg_.global_count = (int64_t)Caffe::world() * plan_.B * plan_.Nn;
     LOG(INFO) << "Data-parallel rank " << Caffe::rank() << " of " << Caffe::world() << ": per-GPU batch " << plan_.B
               << ", global batch " << Caffe::world() * plan_.B << ", gradients all-reduced over "

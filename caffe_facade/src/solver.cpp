@@ -224,7 +224,10 @@ void Solver<Dtype>::Test(const int test_net_id) {
 // Solver::Snapshot (solver.cpp:320-341): <prefix>_iter_<N>.caffemodel + .solverstate naming the model file.
 template <typename Dtype>
 void Solver<Dtype>::Snapshot() {
-  if (Caffe::rank() != 0) return;                     // data-parallel: parameters are identical on every rank
+  // data-parallel: parameters are identical on every rank, rank 0 writes.  (Under the sharded update the fp32 master rows live on
+  // their owners: reading them back is a collective of the library -- vv_params_get -- so EVERY rank makes the call, then the others leave.)
+  if (Caffe::world() > 1) net_->params();
+  if (Caffe::rank() != 0) return;
   const string stem = param_.get_str("snapshot_prefix") + "_iter_" + std::to_string(iter_);
   const string model_file = stem + ".caffemodel", state_file = stem + ".solverstate";
   NetParameter learned("NetParameter");

@@ -206,6 +206,14 @@ int vv_grads_bind(vv_ctx* ctx, void* dev_ptr);
 enum { VV_COMM_RCCL = 0, VV_COMM_SHM = 1 };
 int vv_comm_init(vv_ctx* ctx, int32_t world, int32_t rank, const char* id_path, int32_t transport);
 int vv_comm_overlap(vv_ctx* ctx, int on);
+/* The three exchange schedules by number: 0 = sync, 1 = overlap (as vv_comm_overlap), 2 = SHARDED -- reduce-scatter of the gradients
+ * (fp32), the solver's rule (SGDSolver::ComputeUpdateValue, solver.cpp:485-531, + Net::Update, net.cpp:803-839) on this rank's
+ * D / world rows of W, the history and the bias, all-gather of the 16-bit copy of W + the bias that the next forward pass reads: 3/4 of
+ * the all-reduce's bytes on the wire and 1/world of the update's memory traffic; the same parameters as the other schedules, bit for
+ * bit in what the forward pass reads.  The fp32 master W and the history are then complete on their owner only: vv_params_get (and
+ * vv_comm_destroy, and leaving the schedule) gather them and are COLLECTIVE calls -- every rank makes them, as every rank of
+ * `caffe train` does at a snapshot.  Needs D divisible by world (else the step falls back to sync). */
+int vv_comm_schedule(vv_ctx* ctx, int schedule);
 int vv_allreduce_grads(vv_ctx* ctx);
 int vv_comm_destroy(vv_ctx* ctx);
 /* InnerProductLayer blobs_[0]/[1] cpu_diff() after Backward (inner_product_layer.cpp:76-98). */

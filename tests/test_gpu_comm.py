@@ -1,4 +1,4 @@
-"""The data-parallel exchange through the C ABI (vv_comm_init / vv_allreduce_grads / vv_comm_overlap):
+"""The data-parallel exchange through the C ABI (vv_comm_init / vv_allreduce_grads / vv_comm_overlap / vv_comm_schedule):
 
   * two ranks = two PROCESSES on the one visible GPU, host-staged shared-memory transport (RCCL refuses two ranks on one
     device): both schedules -- whole buffer after the backward pass ("sync") and the update F-chunk by F-chunk on the
@@ -45,14 +45,15 @@ def _rank_main(rank, world, id_path, overlap, transport, q, env=None):
     eng.table_synth(ds.seed, ds.n_rows, F)
     eng.params_set(W, b)
     eng.comm_init(world, rank, id_path, transport)
-    eng.comm_overlap(overlap)
+    if overlap == "sharded": eng.comm_schedule("sharded")
+    else: eng.comm_overlap(overlap)
     cfg = vv.StepConfig(B, C, Nn, global_count=world * B * Nn, lr=0.05)
     losses = []
     for g in _batches(ds, world):
         eng.forward_backward(cfg, g[rank * B:(rank + 1) * B])
         eng.apply_update(cfg)                      # all-reduces first
         losses.append(eng.loss()[0])
-    Wn, bn, hW, hb = eng.params_get()
+    Wn, bn, hW, hb = eng.params_get()              # (sharded schedule: a collective -- every rank is here)
     eng.comm_destroy()
     q.put((rank, Wn, bn, hW, losses))
 
@@ -60,7 +61,7 @@ def _rank_main(rank, world, id_path, overlap, transport, q, env=None):
 def _run_world(world, overlap, transport="shm", env=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    id_path = os.path.join(tempfile.gettempdir(), "vv_comm_test_%d_%d_%d" % (os.getpid(), world, int(overlap)))
+    id_path = os.path.join(tempfile.gettempdir(), "vv_comm_test_%d_%d_%s" % (os.getpid(), world, str(overlap)))
     if os.path.exists(id_path):
         os.unlink(id_path)
     procs = [ctx.Process(target=_rank_main, args=(r, world, id_path, overlap, transport, q, env)) for r in range(world)]
@@ -110,7 +111,23 @@ def test_two_ranks_on_one_gpu_match_the_global_batch():
     assert np.array_equal(out[False][0], out[True][0]) and np.array_equal(out[False][1], out[True][1])
 
 
-@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_update_is_the_synchronous_update_bit_for_bit(world):
+    """reduce-scatter -> the solver's rule on this rank's D / world rows -> all-gather of the 16-bit copy, the bias and the per-block
+    maxima (vv_comm_schedule 2), on `world` processes sharing the one GPU: every rank ends with the parameters, the bias and the history
+    (gathered by the collective vv_params_get) that the synchronous all-reduce schedule gives -- the shard's sums are the all-reduce's
+    sums in the same rank order, the rule is elementwise, the W -> half scale comes from the same maxima -- bit for bit, on every rank."""
+    sync = _run_world(world, False)
+    shard = _run_world(world, "sharded")
+    for r in range(world):
+        for k in range(3):
+            assert np.array_equal(shard[r][k], shard[0][k]), "ranks diverged (rank %d, array %d)" % (r, k)
+            assert np.array_equal(shard[r][k], sync[r][k]), "sharded differs from sync (rank %d, array %d)" % (r, k)
+        assert shard[r][3] == sync[r][3]                       # the per-rank losses of all six iterations: the forward passes read the same bits
+    assert np.isfinite(shard[0][0]).all() and np.abs(shard[0][2]).max() > 0
+
+
+@pytest.mark.parametrize("overlap", [False, True, "sharded"])
 def test_one_rank_over_real_rccl(overlap):
     import videovector_amd as vv
     ds, W, b = _case()
@@ -141,4 +158,7 @@ def test_gated_forward_waits_for_a_slow_exchange():
     W0, b0, h0, _ = ref.params_get()
     ref.close()
     res = _run_world(1, True, transport="rccl", env={"VV_COMM_TEST_DELAY_US": "300"})
+    assert np.array_equal(res[0][0], W0) and np.array_equal(res[0][1], b0) and np.array_equal(res[0][2], h0)
+    # the sharded schedule's one gate (in front of the forward GEMM's first W tile), the exchange held 300 us
+    res = _run_world(1, "sharded", transport="rccl", env={"VV_COMM_TEST_DELAY_US": "300"})
     assert np.array_equal(res[0][0], W0) and np.array_equal(res[0][1], b0) and np.array_equal(res[0][2], h0)

@@ -13,10 +13,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("mode", ["sync", "overlap", "torch-sync", "stale"])
+@pytest.mark.parametrize("mode", ["sync", "overlap", "sharded", "torch-sync", "stale"])
 def test_bench_two_ranks_on_one_device(mode):
     env = dict(os.environ, VV_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    port = "295%02d" % {"sync": 17, "overlap": 19, "torch-sync": 21, "stale": 23}[mode]
+    port = "295%02d" % {"sync": 17, "overlap": 19, "torch-sync": 21, "stale": 23, "sharded": 25}[mode]
     extra = ["--comm", "torch"] if mode == "torch-sync" else []
     ar = "sync" if mode == "torch-sync" else mode
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",

@@ -475,7 +475,7 @@ def test_caffe_train_with_test_net_and_extract_features(tool, pb, oracle, tmp_pa
     assert (np.linalg.norm(got - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-20)).max() <= 1e-3
 
 
-@pytest.mark.parametrize("overlap", ["0", "1"])
+@pytest.mark.parametrize("overlap", ["0", "1", "sharded"])
 def test_caffe_train_data_parallel_two_ranks(tool, pb, tmp_path, overlap):
     """`caffe train` as a data-parallel job: two processes (WORLD_SIZE / RANK / LOCAL_RANK as torch.distributed.run sets
     them) on the one visible GPU, gradients over the shared-memory test transport.  Rank 0's sampler draws the global
@@ -501,8 +501,10 @@ def test_caffe_train_data_parallel_two_ranks(tool, pb, tmp_path, overlap):
     two = files("two", B)
     procs = []
     for r in range(2):
-        env = dict(os.environ, WORLD_SIZE="2", RANK=str(r), LOCAL_RANK="0", VV_COMM="shm", VV_COMM_OVERLAP=overlap,
+        env = dict(os.environ, WORLD_SIZE="2", RANK=str(r), LOCAL_RANK="0", VV_COMM="shm", VV_COMM_OVERLAP=overlap if overlap != "sharded" else "0",
                    VV_JOB_ID="t%d_%s" % (os.getpid(), overlap), VV_SAMPLER_MODE="node")
+        if overlap == "sharded":
+            env["VV_COMM_SCHEDULE"] = "sharded"        # (snapshots at iterations 2 and 3: every rank gathers, rank 0 writes)
         procs.append(subprocess.Popen([CAFFE, "train", "--solver=%s" % two, "--weights=%s" % (tmp_path / "init.caffemodel"),
                                        "--gpu=0", "--log_file=%s" % (tmp_path / "two.log")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))

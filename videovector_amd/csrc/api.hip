@@ -485,6 +485,7 @@ int vv_params_set(vv_ctx* c, int32_t D, const float* W, const float* b, const fl
   launch_absmax(c->W, (int64_t)nW, &c->scales->wmax_bits, c->stream);
   launch_scale_update(c->prec, c->scales, nullptr, 0, c->stream);
   launch_w_convert(c->prec, c->W, c->Wh, D, F, c->Dp, c->Fp, c->scales, c->stream);
+  c->params_partial = false;                 // (every rank is given the whole matrix)
   // seed the running max for the first SGD step's scale update
   launch_absmax(c->W, (int64_t)nW, &c->scales->wmax_bits, c->stream);
   c->wmax_seed_live = true;
@@ -494,11 +495,30 @@ int vv_params_set(vv_ctx* c, int32_t D, const float* W, const float* b, const fl
   return VV_OK;
 }
 
+// Sharded update: every rank holds the fp32 master rows and the history of ITS shard only.  Gathers them -- a COLLECTIVE: every rank of
+// the communicator makes the call that leads here (vv_params_get as the facade's Snapshot does, vv_comm_schedule, vv_comm_destroy): one
+// grouped all-gather of W, hW and hb (b is complete already).
+static int gather_params(vv_ctx* c) {
+  if (!c->params_partial || !c->comm) { c->params_partial = false; return VV_OK; }
+  { const int rcj = comm_join(c); if (rcj) return rcj; }
+  const int world = vv::comm_world(c->comm), rps = c->D / world;
+  void* bufs[3] = {c->W, c->hW, c->hb};
+  const size_t sbytes[3] = {(size_t)rps * c->F * 4, (size_t)rps * c->F * 4, (size_t)rps * 4};
+  HIPCHK(hipEventRecord(c->ev_chunk, c->stream));
+  HIPCHK(hipStreamWaitEvent(vv::comm_stream(c->comm), c->ev_chunk, 0));
+  if (vv::comm_allgather(c->comm, bufs, sbytes, 3)) return fail(VV_ERR_HIP, "all-gather of the parameters: %s", vv::comm_error(c->comm));
+  if (vv::comm_record_done(c->comm)) return fail(VV_ERR_HIP, "all-gather of the parameters: %s", vv::comm_error(c->comm));
+  HIPCHK(hipStreamWaitEvent(c->stream, vv::comm_done_event(c->comm), 0));
+  c->params_partial = false;
+  return VV_OK;
+}
+
 int vv_params_get(vv_ctx* c, float* W, float* b, float* hW, float* hb) {
   if (!c) return fail(VV_ERR_ARG, "vv_params_get: ctx is NULL");
   if (!c->W) return fail(VV_ERR_STATE, "vv_params_get: no parameters");
   VV_ENTER(c);
   { const int rcj = comm_join(c); if (rcj) return rcj; }
+  { const int rcg = gather_params(c); if (rcg) return rcg; }
   HIPCHK(hipStreamSynchronize(c->stream));
   const size_t nW = (size_t)c->D * c->F;
   if (W) HIPCHK(hipMemcpy(W, c->W, nW * 4, hipMemcpyDeviceToHost));
@@ -856,8 +876,8 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
     const bool no_gate = !c->comm_gate;
     if (!no_gate && gemm_variant() == 5 && !ablate_on() && fwd_gemm_can_gate(fa) && (!dd || fa.R_hint > 0) && tiles <= c->n_cu - 16) {
       fa.gate = c->w_gate; fa.gate_seq = c->upd_seq; fa.gate_err = c->gate_err_dev;
-      fa.gate_n = chunk_plan(c);
-      for (int i = 0; i <= fa.gate_n; ++i) fa.gate_kt[i] = c->chunk_kt[i];
+      if (c->grads_sharded) { fa.gate_n = 1; fa.gate_kt[0] = 0; fa.gate_kt[1] = c->Fp / BK; }        // the sharded update publishes once
+      else { fa.gate_n = chunk_plan(c); for (int i = 0; i <= fa.gate_n; ++i) fa.gate_kt[i] = c->chunk_kt[i]; }
       c->upd_inflight = false;              // whatever follows the forward GEMM on this stream follows every PUBLISHED store of the update
       c->upd_unjoined = true;               // ... its plain stores (W, the history) only behind the event: vv_comm_join for whoever reads those
     } else if ((rc = comm_join(c))) return rc;
@@ -990,7 +1010,11 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
 
   // Data-parallel overlap: the gradient buffer is laid out chunk-major (a few column blocks, each one contiguous
   // all-reduce message) and vv_apply_update runs the update chunk by chunk on the communication stream.
-  const bool chunked = c->comm && c->comm_overlap && c->F % 4 == 0 && c->grads == c->grads_own && !c->grads_exposed;   // (a holder of vv_grads_device's pointer reads the documented flat layout)
+  const int shard_rows = c->comm ? c->D / vv::comm_world(c->comm) : 0;
+  const bool sharded = c->comm && c->comm_sharded && c->F % 4 == 0 && c->grads == c->grads_own && !c->grads_exposed &&
+                       shard_rows * vv::comm_world(c->comm) == c->D && shard_rows % 4 == 0 && vv::comm_world(c->comm) * (SGD_BLOCKS / vv::comm_world(c->comm)) <= WMAX_SLOTS;
+  if (sharded) ra.shard_rows = shard_rows;
+  const bool chunked = !sharded && c->comm && c->comm_overlap && c->F % 4 == 0 && c->grads == c->grads_own && !c->grads_exposed;   // (a holder of vv_grads_device's pointer reads the documented flat layout)
   if (chunked) {
     ra.n_chunks = chunk_plan(c);
     for (int i = 0; i <= ra.n_chunks; ++i) ra.chunk_c0[i] = std::min(c->F, c->chunk_kt[i] * BK);
@@ -1030,6 +1054,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   }
   c->grads_pending = c->comm != nullptr;       // (a one-rank communicator still runs its collective: same code path)
   c->grads_chunked = chunked;
+  c->grads_sharded = sharded;
 
   HIPCHK(hipGetLastError());
   c->have_fwd = true;
@@ -1138,7 +1163,8 @@ int vv_apply_update(vv_ctx* c, const vv_step_cfg* cfg) {
   // of the old one -- the half copy, its scale, the bias, the per-block maxima -- was stored at agent scope before the gates opened.)
   if (c->upd_inflight && (rc = comm_join(c))) return rc;
   const bool overlapped = c->comm && c->grads_pending && c->grads_chunked;
-  if (!overlapped && c->grads_pending && (rc = vv_allreduce_grads(c))) return rc;     // data-parallel: the update consumes the SUM over the ranks
+  const bool sharded = c->comm && c->grads_pending && c->grads_sharded;
+  if (!overlapped && !sharded && c->grads_pending && (rc = vv_allreduce_grads(c))) return rc;     // data-parallel: the update consumes the SUM over the ranks
   SgdArgs a;
   float* const wmax_new = c->wmax_blocks + (1 - c->wmax_cur) * WMAX_SLOTS;     // the buffer the previous update did not write
   a.W = c->W; a.b = c->b; a.hW = c->hW; a.hb = c->hb; a.grads = c->grads; a.Wh = c->Wh; a.scales = c->scales; a.wmax_blocks = wmax_new;
@@ -1171,6 +1197,45 @@ int vv_apply_update(vv_ctx* c, const vv_step_cfg* cfg) {
   }
   if ((rc = reduce_now(c))) return rc;
   flush_scale_update(c);               // two updates in a row without a step between them
+  if (sharded) {
+    // Exact synchronous SGD, the update SHARDED over the ranks (Multi-GPU): on the communication stream, behind one event of
+    // the compute stream,   reduce-scatter (fp32, shard-major buffer: 7/8 of it on the wire at N = 8, once)  ->  k_sgd on THIS rank's
+    // D / N rows (1/N of the update's 46 MB)  ->  ONE grouped all-gather of what every rank's next forward pass reads: the 16-bit copy
+    // of W (4 MB instead of the all-reduce's second 8.4 MB), the bias, the per-block maxima the next W -> half scale comes from  ->
+    // publish.  3/4 of the all-reduce's wire bytes.  The next forward GEMM is gated on the one flag (it starts, and waits in front of
+    // its first W tile); the fp32 master W and the history stay sharded until vv_params_get gathers them.
+    hipStream_t cs = vv::comm_stream(c->comm);
+    const int world = vv::comm_world(c->comm), rank = vv::comm_rank(c->comm);
+    const int rps = c->D / world;
+    const size_t shard_f = (size_t)rps * c->F + rps;
+    HIPCHK(hipEventRecord(c->ev_chunk, c->stream));
+    const int32_t useq = ++c->upd_seq;
+    if (c->comm_test_delay_us > 0) { HIPCHK(hipStreamWaitEvent(cs, c->ev_chunk, 0)); launch_delay(c->comm_test_delay_us, cs); }
+    if (vv::comm_reduce_scatter(c->comm, c->grads, shard_f, c->ev_chunk)) return fail(VV_ERR_HIP, "reduce-scatter: %s", vv::comm_error(c->comm));
+    const int nb = SGD_BLOCKS / world;
+    SgdArgs g = a;                                    // the shard as a parameter matrix of its own: rps rows, its gradient buffer [dW rows | db entries]
+    g.D = rps;
+    g.W = c->W + (size_t)rank * rps * c->F; g.hW = c->hW + (size_t)rank * rps * c->F;
+    g.b = c->b + (size_t)rank * rps; g.hb = c->hb + (size_t)rank * rps;
+    g.grads = c->grads + (size_t)rank * shard_f;
+    g.Wh = c->Wh + (size_t)rank * rps * c->Fp;
+    g.chunked = 1; g.f_begin = 0; g.f_count = c->F; g.do_bias = 1; g.set_scale = 1;      // (chunked = 1 with the whole width: this launch's own grid and slots)
+    g.blk_off = rank * nb; g.n_blk = nb;
+    PROFILED(c, "sgd", launch_sgd(c->prec, g, cs));
+    void* bufs[3] = {c->Wh, c->b, wmax_new};
+    const size_t sbytes[3] = {(size_t)rps * c->Fp * 2, (size_t)rps * 4, (size_t)nb * 4};
+    if (vv::comm_allgather(c->comm, bufs, sbytes, 3)) return fail(VV_ERR_HIP, "all-gather: %s", vv::comm_error(c->comm));
+    launch_publish(c->w_gate, useq, cs);
+    if (vv::comm_record_done(c->comm)) return fail(VV_ERR_HIP, "all-gather: %s", vv::comm_error(c->comm));
+    c->grads_pending = false; c->upd_inflight = true; c->upd_unjoined = false;
+    c->params_partial = world > 1;
+    c->scale_pending = true;
+    c->wmax_cur = 1 - c->wmax_cur; c->wmax_n = nb * world;
+    HIPCHK(hipGetLastError());
+    c->iter++;
+    c->prof_calls++;
+    return VV_OK;
+  }
   if (overlapped) {
     // Exact synchronous SGD with the exchange hidden behind the NEXT step's forward GEMM: behind one event of the compute
     // stream, the communication stream runs per F-chunk  all-reduce -> SGD on the chunk's columns -> publish w_gate[chunk];
@@ -1261,6 +1326,17 @@ int vv_grads_get(vv_ctx* c, float* dW, float* db) {
   { const int rcr = reduce_now(c); if (rcr) return rcr; }
   HIPCHK(hipStreamSynchronize(c->stream));
   const size_t nW = (size_t)c->D * c->F;
+  if (c->grads_sharded) {              // shard-major buffer (ReduceArgs::shard_rows) -> the blob's [dW | db]
+    const int rps = c->D / vv::comm_world(c->comm);
+    const size_t sf = (size_t)rps * c->F + rps;
+    std::vector<float> tmp(nW + c->D);
+    HIPCHK(hipMemcpy(tmp.data(), c->grads, tmp.size() * 4, hipMemcpyDeviceToHost));
+    for (int s = 0; s * rps < c->D; ++s) {
+      if (dW) memcpy(dW + (size_t)s * rps * c->F, tmp.data() + s * sf, (size_t)rps * c->F * 4);
+      if (db) memcpy(db + (size_t)s * rps, tmp.data() + s * sf + (size_t)rps * c->F, (size_t)rps * 4);
+    }
+    return VV_OK;
+  }
   if (dW && !c->grads_chunked) HIPCHK(hipMemcpy(dW, c->grads, nW * 4, hipMemcpyDeviceToHost));
   if (dW && c->grads_chunked) {        // chunk-major buffer (ReduceArgs::n_chunks) -> the blob's row-major D x F
     std::vector<float> tmp(nW);
@@ -1473,6 +1549,16 @@ int vv_comm_init(vv_ctx* c, int32_t world, int32_t rank, const char* id_path, in
 int vv_comm_overlap(vv_ctx* c, int on) {
   if (!c) return fail(VV_ERR_ARG, "vv_comm_overlap: ctx is NULL");
   c->comm_overlap = on != 0;
+  if (on) c->comm_sharded = false;
+  return VV_OK;
+}
+
+int vv_comm_schedule(vv_ctx* c, int schedule) {
+  if (!c) return fail(VV_ERR_ARG, "vv_comm_schedule: ctx is NULL");
+  if (schedule < 0 || schedule > 2) return fail(VV_ERR_ARG, "vv_comm_schedule: 0 sync, 1 overlap, 2 sharded");
+  if (schedule != 2 && c->params_partial) { VV_ENTER(c); const int rcg = gather_params(c); if (rcg) return rcg; }     // (collective: the other schedules update the whole matrix)
+  c->comm_overlap = schedule == 1;
+  c->comm_sharded = schedule == 2;
   return VV_OK;
 }
 
@@ -1481,7 +1567,7 @@ int vv_allreduce_grads(vv_ctx* c) {
   if (!c->comm) { c->grads_pending = false; return VV_OK; }
   if (!c->have_fwd) return fail(VV_ERR_STATE, "vv_allreduce_grads: no gradients (call vv_forward_backward)");
   if (!c->grads_pending) return VV_OK;                         // already summed
-  if (c->grads_chunked) return VV_OK;                          // overlapped schedule: vv_apply_update exchanges chunk by chunk
+  if (c->grads_chunked || c->grads_sharded) return VV_OK;      // overlapped / sharded schedule: vv_apply_update runs the exchange
   VV_ENTER(c);
   // synchronous schedule over RCCL: the collective goes straight into the compute stream (nothing would run beside it)
   const int rc = vv::comm_allreduce_inline(c->comm, c->grads, (size_t)c->D * c->F + c->D, c->stream);
@@ -1497,8 +1583,12 @@ int vv_allreduce_grads(vv_ctx* c) {
 
 int vv_comm_destroy(vv_ctx* c) {
   if (!c) return VV_OK;
-  if (c->comm) { (void)comm_join(c); (void)hipStreamSynchronize(c->stream); vv::comm_destroy(c->comm); c->comm = nullptr; }
-  c->grads_pending = c->grads_chunked = c->upd_inflight = c->upd_unjoined = false;
+  if (c->comm) {
+    (void)hipSetDevice(c->device);
+    (void)gather_params(c);                    // (collective: a sharded update leaves the master parameters whole again)
+    (void)comm_join(c); (void)hipStreamSynchronize(c->stream); vv::comm_destroy(c->comm); c->comm = nullptr;
+  }
+  c->grads_pending = c->grads_chunked = c->grads_sharded = c->upd_inflight = c->upd_unjoined = c->params_partial = false;
   return VV_OK;
 }
 

@@ -40,9 +40,12 @@ typedef void* NcclComm;
 typedef int (*fn_GetUniqueId)(NcclUniqueId*);
 typedef int (*fn_CommInitRank)(NcclComm*, int, NcclUniqueId, int);
 typedef int (*fn_AllReduce)(const void*, void*, size_t, int /*dtype*/, int /*op*/, NcclComm, hipStream_t);
+typedef int (*fn_ReduceScatter)(const void*, void*, size_t, int /*dtype*/, int /*op*/, NcclComm, hipStream_t);   // rccl.h: ncclReduceScatter
+typedef int (*fn_AllGather)(const void*, void*, size_t, int /*dtype*/, NcclComm, hipStream_t);                   // ncclAllGather
+typedef int (*fn_Group)(void);                                                                                  // ncclGroupStart / ncclGroupEnd
 typedef int (*fn_CommDestroy)(NcclComm);
 typedef const char* (*fn_GetErrorString)(int);
-enum { kNcclFloat32 = 7, kNcclSum = 0 };
+enum { kNcclFloat32 = 7, kNcclInt8 = 0, kNcclSum = 0 };
 
 // Who wrote a rendezvous object: the writer's pid and its start time (field 22 of /proc/<pid>/stat).  Rank 0 stays
 // inside comm_create until every rank has joined, so a reader accepts an id file / a shared-memory header only while
@@ -95,6 +98,7 @@ struct Comm {
   // RCCL
   void* dl = nullptr; NcclComm nccl = nullptr;
   fn_AllReduce AllReduce = nullptr; fn_CommDestroy CommDestroy = nullptr; fn_GetErrorString ErrStr = nullptr;
+  fn_ReduceScatter ReduceScatter = nullptr; fn_AllGather AllGather = nullptr; fn_Group GroupStart = nullptr, GroupEnd = nullptr;
   // shared-memory stub
   ShmHdr* shm = nullptr; size_t shm_bytes = 0; std::string shm_name; float* stage = nullptr; size_t stage_floats = 0;
   int64_t barriers = 0;
@@ -160,6 +164,10 @@ Comm* comm_create(int world, int rank, const char* id_path, int transport, size_
     c->AllReduce = (fn_AllReduce)dlsym(c->dl, "ncclAllReduce");
     c->CommDestroy = (fn_CommDestroy)dlsym(c->dl, "ncclCommDestroy");
     c->ErrStr = (fn_GetErrorString)dlsym(c->dl, "ncclGetErrorString");
+    c->ReduceScatter = (fn_ReduceScatter)dlsym(c->dl, "ncclReduceScatter");       // (the sharded schedule's; their absence is reported when it is asked for)
+    c->AllGather = (fn_AllGather)dlsym(c->dl, "ncclAllGather");
+    c->GroupStart = (fn_Group)dlsym(c->dl, "ncclGroupStart");
+    c->GroupEnd = (fn_Group)dlsym(c->dl, "ncclGroupEnd");
     if (!GetUniqueId || !CommInitRank || !c->AllReduce || !c->CommDestroy) return fail("librccl lacks the expected entry points");
     NcclUniqueId id;
     memset(&id, 0, sizeof(id));
@@ -312,6 +320,73 @@ int comm_allreduce(Comm* c, float* buf, size_t off, size_t n, hipEvent_t after) 
     if (hipMemcpyAsync(buf + off, out, n * sizeof(float), hipMemcpyHostToDevice, c->stream) != hipSuccess) { c->err = "host-to-device copy failed"; return -1; }
   }
   if (hipEventRecord(c->ev_done, c->stream) != hipSuccess) { c->err = "hipEventRecord failed"; return -1; }
+  return 0;
+}
+
+// ---- the sharded update's two collectives
+int comm_reduce_scatter(Comm* c, float* buf, size_t shard, hipEvent_t after) {
+  if (after && hipStreamWaitEvent(c->stream, after, 0) != hipSuccess) { c->err = "hipStreamWaitEvent failed"; return -1; }
+  if (c->transport == VV_COMM_RCCL) {
+    if (!c->ReduceScatter) { c->err = "librccl has no ncclReduceScatter"; return -1; }
+    const int rc = c->ReduceScatter(buf, buf + (size_t)c->rank * shard, shard, kNcclFloat32, kNcclSum, c->nccl, c->stream);   // in place: recv = send + rank * count
+    if (rc != 0) { c->err = std::string("ncclReduceScatter: ") + (c->ErrStr ? c->ErrStr(rc) : "error"); return -1; }
+    return 0;
+  }
+  // shared-memory stand-in: every rank publishes its whole buffer, then sums ITS shard over the ranks in rank order -- the
+  // order of comm_allreduce's sums, so the shard is bit for bit what the all-reduce would have left there
+  const double timeout_s = getenv("VV_COMM_TIMEOUT") ? atof(getenv("VV_COMM_TIMEOUT")) : 120.0;
+  const size_t n = shard * c->world;
+  if (n > c->stage_floats) { c->err = "reduce-scatter larger than the communicator's buffer"; return -1; }
+  float* slabs = (float*)((unsigned char*)c->shm + shm_hdr_bytes());
+  if (hipMemcpyAsync(c->stage, buf, n * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+      hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "device-to-host copy failed"; return -1; }
+  memcpy(slabs + (size_t)c->rank * c->stage_floats, c->stage, n * sizeof(float));
+  if (!shm_barrier(c, timeout_s)) { c->err = "reduce-scatter barrier timed out (a rank is missing)"; return -1; }
+  const size_t off = (size_t)c->rank * shard;
+  float* out = c->stage + off;
+  for (size_t i = 0; i < shard; ++i) out[i] = slabs[off + i];
+  for (int r = 1; r < c->world; ++r) {
+    const float* s = slabs + (size_t)r * c->stage_floats + off;
+    for (size_t i = 0; i < shard; ++i) out[i] += s[i];
+  }
+  if (!shm_barrier(c, timeout_s)) { c->err = "reduce-scatter barrier timed out (a rank is missing)"; return -1; }
+  if (hipMemcpyAsync(buf + off, out, shard * sizeof(float), hipMemcpyHostToDevice, c->stream) != hipSuccess) { c->err = "host-to-device copy failed"; return -1; }
+  return 0;
+}
+
+int comm_allgather(Comm* c, void* const* bufs, const size_t* shard_bytes, int n) {
+  if (c->transport == VV_COMM_RCCL) {
+    if (!c->AllGather) { c->err = "librccl has no ncclAllGather"; return -1; }
+    if (n > 1 && c->GroupStart) c->GroupStart();
+    int rc = 0;
+    for (int i = 0; i < n && rc == 0; ++i) {
+      unsigned char* b = (unsigned char*)bufs[i];
+      rc = c->AllGather(b + (size_t)c->rank * shard_bytes[i], b, shard_bytes[i], kNcclInt8, c->nccl, c->stream);            // in place: send = recv + rank * count
+    }
+    if (n > 1 && c->GroupEnd) { const int rg = c->GroupEnd(); if (rc == 0) rc = rg; }
+    if (rc != 0) { c->err = std::string("ncclAllGather: ") + (c->ErrStr ? c->ErrStr(rc) : "error"); return -1; }
+    return 0;
+  }
+  const double timeout_s = getenv("VV_COMM_TIMEOUT") ? atof(getenv("VV_COMM_TIMEOUT")) : 120.0;
+  unsigned char* slabs = (unsigned char*)c->shm + shm_hdr_bytes();
+  const size_t slab_bytes = c->stage_floats * sizeof(float);
+  for (int i = 0; i < n; ++i) {
+    const size_t sb = shard_bytes[i];
+    if (sb > slab_bytes) { c->err = "all-gather shard larger than the communicator's buffer"; return -1; }
+    unsigned char* b = (unsigned char*)bufs[i];
+    if (hipMemcpyAsync(c->stage, b + (size_t)c->rank * sb, sb, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "device-to-host copy failed"; return -1; }
+    memcpy(slabs + (size_t)c->rank * slab_bytes, c->stage, sb);
+    if (!shm_barrier(c, timeout_s)) { c->err = "all-gather barrier timed out (a rank is missing)"; return -1; }
+    for (int r = 0; r < c->world; ++r) {
+      if (r == c->rank) continue;
+      // (pageable source: the copy is staged by the runtime before the call returns for sizes like these; the barrier below keeps the
+      // slab intact until every rank has issued its copies and synchronised)
+      if (hipMemcpyAsync(b + (size_t)r * sb, slabs + (size_t)r * slab_bytes, sb, hipMemcpyHostToDevice, c->stream) != hipSuccess) { c->err = "host-to-device copy failed"; return -1; }
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "host-to-device copy failed"; return -1; }
+    if (!shm_barrier(c, timeout_s)) { c->err = "all-gather barrier timed out (a rank is missing)"; return -1; }
+  }
   return 0;
 }
 

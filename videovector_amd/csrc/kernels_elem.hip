@@ -1144,7 +1144,8 @@ __device__ __forceinline__ void reduce_db(const ReduceArgs& a, int blk) {
     float t = 0.f;
 #pragma unroll
     for (int u = 0; u < 16; ++u) t += part[u][tx];
-    a.grads[(int64_t)a.D * a.F + d] = t;
+    if (a.shard_rows > 0) a.grads[(int64_t)(d / a.shard_rows) * ((int64_t)a.shard_rows * a.F + a.shard_rows) + (int64_t)a.shard_rows * a.F + d % a.shard_rows] = t;
+    else a.grads[(int64_t)a.D * a.F + d] = t;
   }
 }
 
@@ -1263,6 +1264,7 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
         const int c0 = a.chunk_c0[cc], c1 = a.chunk_c0[cc + 1];
         o = (int64_t)a.D * c0 + (int64_t)d * (c1 - c0) + (f - c0);
       }
+      if (a.shard_rows > 0) o += (int64_t)(d / a.shard_rows) * a.shard_rows;       // shard-major: every shard carries its db entries behind its rows
       *(float4*)(a.grads + o) = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
     }
   } else {

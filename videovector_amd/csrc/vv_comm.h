@@ -15,6 +15,13 @@ void comm_destroy(Comm* c);
 // compute stream, or null); comm_done_event marks its completion
 int comm_allreduce(Comm* c, float* buf, size_t off, size_t n, hipEvent_t after);
 int comm_allreduce_inline(Comm* c, float* buf, size_t n, hipStream_t stream);   // on the caller's stream (RCCL); 1 = not available
+// Sharded update (api.hip: the `sharded` schedule), both in place on the communication stream:
+//   comm_reduce_scatter  buf holds `world` shards of shard_floats each; on return rank r's shard holds the sum over the ranks of that
+//                        shard (the other shards are unspecified); started after `after`
+//   comm_allgather       n buffers at once (one grouped launch on RCCL), buffer i = `world` shards of shard_bytes[i]; rank r's shard is
+//                        the input, on return every shard holds its owner's bytes
+int comm_reduce_scatter(Comm* c, float* buf, size_t shard_floats, hipEvent_t after);
+int comm_allgather(Comm* c, void* const* bufs, const size_t* shard_bytes, int n);
 hipEvent_t comm_done_event(Comm* c);
 hipStream_t comm_stream(Comm* c);          // the communication stream (the overlapped update queues its kernels there)
 int comm_record_done(Comm* c);             // records comm_done_event behind everything queued on the communication stream

@@ -146,6 +146,12 @@ struct vv_ctx {
   double trace_host_ms = -1.0;      // VV_TRACE_HOST: report ABI calls that keep the host longer than this
   bool trace_waits = false;         // VV_TRACE_WAITS: where the host waits
   double wait_ms[5] = {0, 0, 0, 0, 0}; long wait_calls = 0;
+  // SHARDED update (vv_comm_schedule 2): fp32 reduce-scatter of the shard-major [dW rows | db entries] buffer, the solver's rule on this
+  // rank's D / world rows of W / history / bias, all-gather of the 16-bit copy + the bias + the per-block maxima that every rank's next
+  // forward pass reads.  The fp32 master W and the history are complete only on their owner until vv_params_get gathers them.
+  bool comm_sharded = false;
+  bool grads_sharded = false;       // the gradient buffer of the last backward pass is laid out shard-major (ReduceArgs::shard_rows)
+  bool params_partial = false;      // W / hW / hb rows of the other ranks' shards are stale (a sharded update ran since the last gather)
   bool upd_inflight = false;        // an overlapped update is on the communication stream and the compute stream has not joined it
   bool upd_unjoined = false;        // ... the gated forward GEMM has consumed it, the compute stream has still not waited for its end
   int32_t upd_seq = 0;              // sequence number of the last overlapped update (what w_gate[c] reaches when chunk c is done)

@@ -245,6 +245,9 @@ struct ReduceArgs {
   int n_chunks = 0;                  // > 0: dW is stored CHUNK-MAJOR -- n_chunks column blocks, block c = all D rows of columns
   int chunk_c0[5] = {0, 0, 0, 0, 0}; //   [chunk_c0[c], chunk_c0[c+1]) at float offset D chunk_c0[c], row stride = the block's width
                                      //   (boundaries multiples of 4) -- so that every F-chunk is one contiguous all-reduce buffer
+  int shard_rows = 0;                // > 0: the gradient buffer is SHARD-MAJOR (the sharded update, api.hip): D / shard_rows shards, shard s =
+                                     //   rows [s shard_rows, (s + 1) shard_rows) of dW (row-major) followed by their shard_rows entries of db --
+                                     //   one reduce-scatter message per rank, and k_sgd sees its shard as a small [dW | db] buffer of its own
   int parts = 3;                     // bit 0: the dW rows, bit 1: db and the loss scalars
   Scales* scale_sc = nullptr;        // non-null: one more workgroup performs the W -> half scale update left pending by the
   const float* scale_wmax = nullptr; //   previous step's k_sgd (its per-block max |w| slots,

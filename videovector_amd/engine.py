@@ -87,7 +87,7 @@ def load_library():
         "vv_op_max_margin_bwd": [vp, i32, vp, vp, vp, f32, i32, f32, vp, vp],
         "vv_op_gather_rows": [vp, vp, i64, vp],
         "vv_op_inner_product": [vp, vp, i64, vp], "vv_op_inner_product_bwd": [vp, vp, i64, f32],
-        "vv_comm_init": [vp, i32, i32, C.c_char_p, i32], "vv_comm_overlap": [vp, C.c_int],
+        "vv_comm_init": [vp, i32, i32, C.c_char_p, i32], "vv_comm_overlap": [vp, C.c_int], "vv_comm_schedule": [vp, C.c_int],
         "vv_allreduce_grads": [vp], "vv_comm_destroy": [vp],
         "vv_loss_get": [vp, C.POINTER(f32), C.POINTER(f32)],
         "vv_grads_device": [vp, C.POINTER(vp), C.POINTER(i64)], "vv_grads_get": [vp, vp, vp],
@@ -278,6 +278,10 @@ class Engine:
 
     def comm_overlap(self, on=True):
         self._chk(self.L.vv_comm_overlap(self.h, int(bool(on))))
+
+    def comm_schedule(self, name):
+        """'sync', 'overlap' or 'sharded' (include/videovec.h: vv_comm_schedule)."""
+        self._chk(self.L.vv_comm_schedule(self.h, {"sync": 0, "overlap": 1, "sharded": 2}[name]))
 
     def allreduce_grads(self):
         self._chk(self.L.vv_allreduce_grads(self.h))
