@@ -21,7 +21,8 @@ def run(mode, steps):
     eng = vv.Engine(0, "f16"); eng.table_synth(ds.seed, ds.n_rows, F); eng.params_set(W, b)
     if mode != "none":
         eng.comm_init(1, 0, "/tmp/vv_overlap_cost_%d" % os.getpid(), "rccl")
-        eng.comm_overlap(mode.startswith("overlap"))
+        if mode.startswith("sharded"): eng.comm_schedule("sharded")
+        else: eng.comm_overlap(mode.startswith("overlap"))
     cfg = vv.StepConfig(B, C, Nn)
     stride = B * (C + Nn) * 4
     def go(a, bnd):
@@ -45,5 +46,5 @@ if __name__ == "__main__":
         steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
         for rep in range(2):
             for mode, env in (("none", {}), ("sync", {}), ("overlap", {}), ("overlap_chunks2", {"VV_COMM_CHUNKS": "2"}), ("overlap_chunks4", {"VV_COMM_CHUNKS": "4"}),
-                              ("overlap", {"VV_COMM_TEST_DELAY_US": "20"}), ("overlap_chunks2", {"VV_COMM_CHUNKS": "2", "VV_COMM_TEST_DELAY_US": "30"}), ("overlap_nogate", {"VV_COMM_GATE": "0"})):
+                              ("sharded", {}), ("sharded", {"VV_COMM_TEST_DELAY_US": "60"}), ("overlap", {"VV_COMM_TEST_DELAY_US": "20"}), ("overlap_chunks2", {"VV_COMM_CHUNKS": "2", "VV_COMM_TEST_DELAY_US": "30"}), ("overlap_nogate", {"VV_COMM_GATE": "0"})):
                 subprocess.run([sys.executable, os.path.abspath(__file__), mode, str(steps)], env=dict(os.environ, **env))
