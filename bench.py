@@ -105,7 +105,12 @@ def cpu_baseline(ds, idx, W, b, items, iters, threads=0):
            "blas": ("cblas_sgemm of " + os.path.basename(blas)) if use_ext else "the oracle's own blocked OpenMP sgemm",
            "sample": "%d of %d batch items (%d rows) of the same 4096->%d, C5, Nn%d step, "
                      "%d timed iterations after warm-up, %.2f s each" % (items, B_PER_GPU, items * (C + NN), D, NN, iters, t),
-           "iteration_gflops": 4.0 * items * (C + NN) * F * D / t / 1e9}
+           "iteration_gflops": 4.0 * items * (C + NN) * F * D / t / 1e9,
+           "host_logical_cpus": os.cpu_count(),
+           "note": "thread count picked on one warm-up iteration each (all / half / a quarter of the host's threads): on the two-socket "
+                   "hosts of the MI355X boxes that is a fraction of the machine -- the oracle's sgemm is not NUMA-aware (it packs its "
+                   "panels on the calling thread's node), so this baseline is UNDERSTATED against what a NUMA-aware BLAS on every core "
+                   "would do; it is a stated baseline, never the target"}
     if tried:
         out["threads_tried_s_per_iteration"] = {str(k): round(v, 3) for k, v in tried.items()}
     if gemm is not None:

@@ -10,7 +10,7 @@
 #include <algorithm>
 #include <random>
 #include "../../videovector_amd/csrc/vv_internal.h"
-namespace vv { thread_local ProfPair g_prof; }
+namespace vv { thread_local ProfPair g_prof; thread_local const KernelOpts* g_ko = nullptr; }
 #include "../../videovector_amd/csrc/kernels_gemm_ph.hip"
 #include "kernels_gemm_dr.hip"
 
@@ -92,7 +92,10 @@ int main(int argc, char** argv) {
                            {"dr12p4_hotA", 6}, {"dr12p4_noB", 7}, {"dr12p4_noAnoB", 8}, {"dr12p4_onlyMM", 9}, {"dr16p4", 10}, {"dr8p4", 11},
                            {"dr12_onlyA", 12}, {"dr12_onlyB", 13}, {"dr12_onlyAB", 14}, {"dr12_t4", 15}, {"dr12_t8", 16}, {"dr12_lgkm", 17},
                            {"dr12_t8_onlyA", 18}, {"dr12_t8_noB", 19},
-                           {"dr12_xcd", 20}, {"dr12_xcd_onlyA", 21}, {"dr12_sc1", 22}, {"dr12_nt", 23}, {"dr12_sc01", 24}, {"dr12_sc1_onlyA", 25}, {"dr12_xcd_onlyB", 26}};
+                           {"dr12_xcd", 20}, {"dr12_xcd_onlyA", 21}, {"dr12_sc1", 22}, {"dr12_nt", 23}, {"dr12_sc01", 24}, {"dr12_sc1_onlyA", 25}, {"dr12_xcd_onlyB", 26},
+                           {"dr12_run256_onlyA", 27}, {"dr12_run256_onlyAB", 28}, {"dr12_run256_full", 29},
+                           {"dr12_rot1", 30}, {"dr12_rot2", 31}, {"dr12_rot4", 32}, {"dr12_rot1_onlyA", 33}, {"dr12_rot2_onlyA", 34}, {"dr12_rot4_onlyA", 35},
+                           {"dr12_run512_onlyA", 36}, {"dr12_run1k_onlyA", 37}};
   auto run = [&](int kind, int set, float* Hout) {
     FwdArgs a = base; a.rows = rows + (size_t)set * Rp; a.H = Hout;
     if (kind == 0) { a.Wh = Wh; launch_fwd_gemm_ph(0, a, st); return; }
@@ -124,6 +127,17 @@ int main(int argc, char** argv) {
       case 24: launch_dr<12, 4, 0, 0, 1 + 12>(a, st); break;
       case 25: launch_dr<12, 4, 2 + 4 + 16, 0, 1 + 4>(a, st); break;
       case 26: launch_dr<12, 4, 2 + 4 + 1, 0, 1 + 2>(a, st); break;
+      case 27: launch_dr<12, 4, 2 + 4 + 16, 0, 1 + 16>(a, st); break;
+      case 28: launch_dr<12, 4, 2 + 4, 0, 1 + 16>(a, st); break;
+      case 29: launch_dr<12, 4, 0, 0, 1 + 16>(a, st); break;
+      case 30: launch_dr<12, 4, 0, 0, 1 + 32>(a, st); break;
+      case 31: launch_dr<12, 4, 0, 0, 1 + 64>(a, st); break;
+      case 32: launch_dr<12, 4, 0, 0, 1 + 96>(a, st); break;
+      case 33: launch_dr<12, 4, 2 + 4 + 16, 0, 1 + 32>(a, st); break;
+      case 34: launch_dr<12, 4, 2 + 4 + 16, 0, 1 + 64>(a, st); break;
+      case 35: launch_dr<12, 4, 2 + 4 + 16, 0, 1 + 96>(a, st); break;
+      case 36: launch_dr<12, 4, 2 + 4 + 16, 0, 1 + 16 + 128>(a, st); break;
+      case 37: launch_dr<12, 4, 2 + 4 + 16, 0, 1 + 16 + 256>(a, st); break;
     }
   };
   // correctness: the real variants against the LDS kernel, bit for bit, on every row set

@@ -136,16 +136,39 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_dr(FwdArgs a) {
   i16x8 bq[P][2][2];                           // [K-tile % P][kk][ni]
   i16x8 af[AD];
 
-  auto a_issue = [&](int tt, int slot, int i) {
-    if (!(ABL & 1) || tt < P) dr_glds16<(OPT >> 2) & 3>(aoff[i], a.table + (int64_t)tt * BK, lds0 + slot * SLOTB + (i * 8 + wave) * 1024);
+  // (lab, OPT bit 4, stream timing only -- the LDS image is wrong): a piece = 4 rows x 256 B instead of 8 rows x 128 B; even K-tiles fetch
+  // the lower half of the rows for TWO K-tiles, odd ones the upper half: the same bytes, in 256-byte runs per row visit
+  // RUNG = row groups = bytes per row visit / 128 (OPT bits 7-8 on top of bit 4: 2 -> 256 B, 4 -> 512 B, 8 -> 1 KiB)
+  constexpr int RUNG = !(OPT & 16) ? 1 : (((OPT >> 7) & 3) == 0 ? 2 : ((OPT >> 7) & 3) == 1 ? 4 : 8);
+  unsigned aoff2[RUNG][NPW];
+  if (OPT & 16) {
+#pragma unroll
+    for (int hf = 0; hf < RUNG; ++hf)
+#pragma unroll
+      for (int i = 0; i < NPW; ++i) {
+        constexpr int LPR = 8 * RUNG;            // lanes per row (16 B each)
+        const int row = hf * (BMT / RUNG) + (i * 8 + wave) * (64 / LPR) + lane / LPR, grow = m0 + row;
+        const int trow = (grow < R && !(ABL & 8)) ? a.rows[grow] : a.zero_row;
+        aoff2[hf][i] = (unsigned)((int64_t)trow * Fp * 2) + ((lane % LPR) << 4);
+      }
+  }
+  // (lab, OPT bits 5-6: K ROTATION) odd column tiles run their K loop 1 / 2 / 4 tiles ahead (tile (t + rot) mod nk at step t): a row tile's
+  // two siblings never ask for the same gathered lines at the same time -- the odd one is every line's first toucher, the even one finds it
+  // in L2 rot steps later -- with no extra LDS.  The accumulation order of the odd tiles is rotated with it (not bit-identical to k_fwd_gemm_ph).
+  const int rot = ((OPT >> 5) & 3) == 0 ? 0 : (((L % tilesN) & 1) ? (1 << (((OPT >> 5) & 3) - 1)) : 0);
+  auto rotk = [&](int tt) { const int k = tt + rot; return k >= nk ? k - nk : k; };
+  auto a_issue = [&](int tt0, int slot, int i) {
+    const int tt = rotk(tt0);
+    if ((OPT & 16) && (!(ABL & 1) || tt0 < P)) { dr_glds16<(OPT >> 2) & 3>(aoff2[tt % RUNG][i], a.table + (int64_t)(tt - tt % RUNG) * BK, lds0 + slot * SLOTB + (i * 8 + wave) * 1024); return; }
+    if (!(ABL & 1) || tt0 < P) dr_glds16<(OPT >> 2) & 3>(aoff[i], a.table + (int64_t)tt * BK, lds0 + slot * SLOTB + (i * 8 + wave) * 1024);
   };
   // issue group of K-tile tt, first / second part (the same order in the prologue and in the loop)
 #define DR_ISSUE0(tt, J, slot)                                                                        \
-  { const uint16_t* wp_ = wbase + (int64_t)(tt) * 2048;                                               \
+  { const uint16_t* wp_ = wbase + (int64_t)rotk(tt) * 2048;                                           \
     if (!(ABL & 16)) { dr_gload16<0>(bq[J][0][0], voff, wp_); dr_gload16<1024>(bq[J][0][1], voff, wp_); }  \
     _Pragma("unroll") for (int i_ = 0; i_ < N0; ++i_) a_issue(tt, slot, i_); }
 #define DR_ISSUE1(tt, J, slot)                                                                        \
-  { const uint16_t* wp_ = wbase + (int64_t)(tt) * 2048;                                               \
+  { const uint16_t* wp_ = wbase + (int64_t)rotk(tt) * 2048;                                           \
     if (!(ABL & 16)) { dr_gload16<2048>(bq[J][1][0], voff, wp_); dr_gload16<3072>(bq[J][1][1], voff, wp_); } \
     _Pragma("unroll") for (int i_ = N0; i_ < NPW; ++i_) a_issue(tt, slot, i_); }
 
