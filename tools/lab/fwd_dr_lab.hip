@@ -95,7 +95,8 @@ int main(int argc, char** argv) {
                            {"dr12_xcd", 20}, {"dr12_xcd_onlyA", 21}, {"dr12_sc1", 22}, {"dr12_nt", 23}, {"dr12_sc01", 24}, {"dr12_sc1_onlyA", 25}, {"dr12_xcd_onlyB", 26},
                            {"dr12_run256_onlyA", 27}, {"dr12_run256_onlyAB", 28}, {"dr12_run256_full", 29},
                            {"dr12_rot1", 30}, {"dr12_rot2", 31}, {"dr12_rot4", 32}, {"dr12_rot1_onlyA", 33}, {"dr12_rot2_onlyA", 34}, {"dr12_rot4_onlyA", 35},
-                           {"dr12_run512_onlyA", 36}, {"dr12_run1k_onlyA", 37}};
+                           {"dr12_run512_onlyA", 36}, {"dr12_run1k_onlyA", 37},
+                           {"dr12_bl1_onlyA", 38}, {"dr12_bl2_onlyA", 39}, {"dr12_bl4_onlyA", 40}, {"dr12_bl2_onlyAB", 41}, {"dr12_bl2_noRD", 42}};
   auto run = [&](int kind, int set, float* Hout) {
     FwdArgs a = base; a.rows = rows + (size_t)set * Rp; a.H = Hout;
     if (kind == 0) { a.Wh = Wh; launch_fwd_gemm_ph(0, a, st); return; }
@@ -138,6 +139,11 @@ int main(int argc, char** argv) {
       case 35: launch_dr<12, 4, 2 + 4 + 16, 0, 1 + 96>(a, st); break;
       case 36: launch_dr<12, 4, 2 + 4 + 16, 0, 1 + 16 + 128>(a, st); break;
       case 37: launch_dr<12, 4, 2 + 4 + 16, 0, 1 + 16 + 256>(a, st); break;
+      case 38: launch_dr<12, 4, 2 + 4 + 16, 0, 1 + 512>(a, st); break;
+      case 39: launch_dr<12, 4, 2 + 4 + 16, 0, 1 + 1024>(a, st); break;
+      case 40: launch_dr<12, 4, 2 + 4 + 16, 0, 1 + 1536>(a, st); break;
+      case 41: launch_dr<12, 4, 2 + 4, 0, 1 + 1024>(a, st); break;
+      case 42: launch_dr<12, 4, 4, 0, 1 + 1024>(a, st); break;
     }
   };
   // correctness: the real variants against the LDS kernel, bit for bit, on every row set

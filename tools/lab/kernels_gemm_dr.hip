@@ -157,8 +157,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_dr(FwdArgs a) {
   // in L2 rot steps later -- with no extra LDS.  The accumulation order of the odd tiles is rotated with it (not bit-identical to k_fwd_gemm_ph).
   const int rot = ((OPT >> 5) & 3) == 0 ? 0 : (((L % tilesN) & 1) ? (1 << (((OPT >> 5) & 3) - 1)) : 0);
   auto rotk = [&](int tt) { const int k = tt + rot; return k >= nk ? k - nk : k; };
+  // (lab, OPT bits 9-10, STREAM TIMING ONLY: the LDS image is wrong) BALANCED lead: every workgroup asks for the half of its rows that matches its
+  // column parity 1 / 2 / 4 K-tiles early -- each sibling is the first toucher of half of the lines and finds the other half in L2
+  const int blead = ((OPT >> 9) & 3) == 0 ? 0 : (1 << (((OPT >> 9) & 3) - 1));
+  const int sibp = (L % tilesN) & 1;
   auto a_issue = [&](int tt0, int slot, int i) {
-    const int tt = rotk(tt0);
+    int tt = rotk(tt0);
+    if (blead && (((i * 8 + wave) * 8 >= BMT / 2) ? 1 : 0) == sibp) { tt += blead; if (tt >= nk) tt -= nk; }
     if ((OPT & 16) && (!(ABL & 1) || tt0 < P)) { dr_glds16<(OPT >> 2) & 3>(aoff2[tt % RUNG][i], a.table + (int64_t)(tt - tt % RUNG) * BK, lds0 + slot * SLOTB + (i * 8 + wave) * 1024); return; }
     if (!(ABL & 1) || tt0 < P) dr_glds16<(OPT >> 2) & 3>(aoff[i], a.table + (int64_t)tt * BK, lds0 + slot * SLOTB + (i * 8 + wave) * 1024);
   };
