@@ -13,8 +13,12 @@
  *     algorithms the sampler delegates to; tests/test_oracle_rng.py),
  *   - every property / known-answer assertion of the reference's unit tests for the layers on the
  *     path (tests/test_oracle_reference_kats.py cites each test file:line).
- * The sampler and the assembled graph are NOT pinned by any reference fixture ("parity unpinned"
- * for those two; the reference has no test for either).
+ *   - the WIRING of the assembled graph (orc_forward_backward) against the reference's own project file: the TRAIN-phase topology of
+ *     projects/videovec_embedding/mednet_embedding_train.prototxt (tests/golden/mednet_train_graph.json: 37 layers, their types,
+ *     bottoms, tops and parameters) is executed layer by layer with the layer functions above and must give the assembled step's loss,
+ *     scores, ip2, dW and db (tests/test_oracle_graph_topology.py).
+ * The SAMPLER is NOT pinned by any reference fixture ("parity unpinned" for it: the reference has no test and no recorded batch for
+ * it); it is cross-checked against an independent restatement driven by the real glibc rand() (tests/pyref.py).
  *
  * All citations are relative to /root/reference.
  */
