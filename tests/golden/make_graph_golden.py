@@ -20,5 +20,6 @@ if __name__ == "__main__":
     net = parse_prototxt(open(REF).read())
     topo = train_topology(net)
     topo["_source"] = "projects/videovec_embedding/mednet_embedding_train.prototxt (TRAIN phase), via tests/golden/make_graph_golden.py"
+    topo["test_layers"] = train_topology(net, "TEST")["layers"]       # the TEST phase of the same file (the extraction / retrieval branch)
     json.dump(topo, open(os.path.join(HERE, "mednet_train_graph.json"), "w"), indent=1, sort_keys=True)
-    print("%d TRAIN layers" % len(topo["layers"]))
+    print("%d TRAIN layers, %d TEST layers" % (len(topo["layers"]), len(topo["test_layers"])))

@@ -66,10 +66,10 @@ def in_phase(layer, phase):
     return any(_one(r, "phase", phase) == phase for r in inc)
 
 
-def train_topology(net):
+def train_topology(net, phase="TRAIN"):
     layers = []
     for l in net["layers"]:
-        if not in_phase(l, "TRAIN"):
+        if not in_phase(l, phase):
             continue
         e = {"name": _one(l, "name"), "type": _one(l, "type"), "bottom": l.get("bottom", []), "top": l.get("top", [])}
         p = {}
@@ -87,6 +87,8 @@ def train_topology(net):
         if "loss_weight" in l: p["loss_weight"] = [float(x) for x in l["loss_weight"]]
         if "blobs_lr" in l: p["blobs_lr"] = [float(x) for x in l["blobs_lr"]]
         if "weight_decay" in l: p["weight_decay"] = [float(x) for x in l["weight_decay"]]
+        if "video_shot_window_test_data_param" in l:
+            p["batch_size"] = _one(l["video_shot_window_test_data_param"][0], "batch_size")
         if "video_sampled_shots_data_param" in l:
             d = l["video_sampled_shots_data_param"][0]
             for k in ("batch_size", "num_negative_samples", "max_buffer_size", "negative_swap_percentage", "max_same_video_negs", "context_type", "context_size"):
