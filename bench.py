@@ -543,8 +543,6 @@ def main():
     # the other operand type, end to end (configs[4] is quoted for bf16 operands while the product defaults to f16: --workload cfg5 always
     # shows both; their parity bounds against the fp32 CPU path are tests/test_gpu_cfg5.py's -- f16 1e-3, bf16 4e-3 on the embeddings)
     if (not args.no_extra_legs or args.workload == "cfg5") and not shipped:
-        if args.no_extra_legs:
-            run.eng.close()
         other = "bf16" if args.prec == "f16" else "f16"
         if mode != "stale":
             run2 = Run(other, args.dedup == "on")

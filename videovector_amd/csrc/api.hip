@@ -150,6 +150,7 @@ static int create_init(vv_ctx* c) {
   if (const char* v = lab_env("VV_PH_MQ")) c->ko.ph_mq = atoi(v);
   if (const char* v = lab_env("VV_SCORE_REG")) c->ko.score_reg = atoi(v);
   if (const char* v = lab_env("VV_SCORE_WAVES")) c->ko.score_waves = atoi(v);
+  if (const char* v = lab_env("VV_SCORE_RR")) c->ko.score_rr = atoi(v);
   if (const char* v = lab_env("VV_GUARD_PROACTIVE")) c->guard_proactive = atoi(v) != 0;
   if (const char* v = lab_env("VV_FUSE_KEEP_GRADS")) c->fuse_keep_grads = atoi(v) != 0;
   if (const char* v = lab_env("VV_COMM_SKIP_AR1")) c->comm_skip_ar1 = atoi(v) != 0;

@@ -29,6 +29,16 @@ __device__ __forceinline__ void nt_store4(float* p, const float4& v) {
 
 constexpr int SL_THREADS = 256;
 
+// Item of a workgroup in the item-major kernels (one workgroup per batch item).  Workgroups b, b + 8, ... share an XCD (and its L2): instead
+// of dealing the items round-robin, XCD x takes the contiguous items [x B/8, (x+1) B/8) -- neighbouring items' own rows (target, context)
+// are neighbouring rows of the de-duplicated H, so an XCD's L2 sees runs instead of every eighth row: k_score_fwd 26.5 -> 25.2 us at the benchmark's batch
+// (bit-identical results: only which workgroup takes which item changes).  (rr: the lab's switch back to round-robin.)
+__device__ __forceinline__ int item_of_block(int rr) {
+  const int n = (int)gridDim.x, bid = (int)blockIdx.x;
+  if (rr || (n & 7)) return bid;
+  return (bid & 7) * (n >> 3) + (bid >> 3);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -105,7 +115,7 @@ __global__ __launch_bounds__(NT) void k_score_loss(ScoreArgs a) {
   float* k1 = (float*)(ooff + CN);   // [CN] per-row constants of the backward pass (see phase 4)
   float* k2 = k1 + CN;
   float* k3 = k2 + CN;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = item_of_block(a.items_rr), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float eps = 1e-10f;
   __shared__ float ggs[16];
   float sgm;
@@ -299,7 +309,7 @@ __global__ __launch_bounds__(64 * NW) void k_score_loss_reg(ScoreArgs a) {
   float* cq = tq + CN;         // [CN]
   float* red = cq + CN;        // [3 NW]
   int* ooff = (int*)(red + 3 * NW);   // [CN] row of dYh receiving channel ch's gradient
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = item_of_block(a.items_rr), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float eps = 1e-10f;
   __shared__ float ggs[16];
   float sgm;
@@ -521,7 +531,7 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
   float* cq = tq + CN;         // [CN]
   float* red = cq + CN;        // [3 NW]
   int* ooff = (int*)(red + 3 * NW);   // [CN] grouped position of channel ch's instance
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = item_of_block(a.items_rr), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float eps = 1e-10f;
 
   float4 x[RPW][DV];
@@ -704,7 +714,7 @@ __global__ __launch_bounds__(64 * NW, DV == 4 ? 4 : 1) void k_score_stream(Score
   float* Ah = A + D;           // [D]
   float* acc0 = Ah + D;        // [NW][D] per-wave partial dAh
   float* red = acc0 + NW * D;  // [4 NW]: three groups for the loss sums, one for the waves' gradient bounds
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = item_of_block(a.items_rr), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float eps = 1e-10f;
   const int32_t* map = a.map + (int64_t)b * CN;
   const int32_t* ord = a.ord + (int64_t)b * CN;
@@ -871,7 +881,9 @@ __global__ __launch_bounds__(64 * NW, DV == 4 ? 4 : 1) void k_score_stream(Score
 bool score_fwd_supported(const ScoreArgs& a) { return a.D == 512 || a.D == 1024; }
 
 // (KernelOpts::score_stream = 1: the one-sweep streaming kernel for every shape, A/B against k_score_fwd)
-void launch_score_fwd(const ScoreArgs& a, hipStream_t s) {
+void launch_score_fwd(const ScoreArgs& a_in, hipStream_t s) {
+  ScoreArgs a = a_in;
+  a.items_rr = ko().score_rr;
   const int rows = 1 + a.Nn;
   if (!(a.D == 512 && a.C - 1 <= 6 && rows <= 56) || ko().score_stream == 1) {
     const size_t lds = sizeof(float) * ((size_t)(2 + 8) * a.D + 4 * 8);
@@ -937,7 +949,7 @@ __global__ __launch_bounds__(256) void k_seg_bwd(SegBwdArgs a) {
   // itself.  The row's own values (needed last) and the NEXT row's segment bounds are requested right behind the records,
   // so that only records -> vectors is exposed: 18.7 -> 17.9 us.  (More waves do not help: 89 registers and five blocks per
   // CU instead of four measured the same 17.8-18.3 us.)
-  const int u_first = blockIdx.x * 4 + wave, u_step = 4 * (int)gridDim.x;
+  const int u_first = blockIdx.x * 4 + wave, u_step = 4 * (int)gridDim.x;     // (block numbers by XCD ranges, as item_of_block: measured, no change)
   int seg_b = 0, seg_e = 0;
   if (u_first < U) { seg_b = a.seg_start[u_first]; seg_e = a.seg_start[u_first + 1]; }
   for (int u = u_first; u < Uk; u += u_step) {
@@ -1082,7 +1094,9 @@ void launch_seg_bwd(int prec, const SegBwdArgs& a, hipStream_t s) {
 }
 
 
-void launch_score_loss(int prec, const ScoreArgs& a, hipStream_t s) {
+void launch_score_loss(int prec, const ScoreArgs& a_in, hipStream_t s) {
+  ScoreArgs a = a_in;
+  a.items_rr = 1;          // per-instance rows (dense execution): an item's rows are contiguous already; XCD ranges measured + 1 us (42.8 against 41.8)
   if (ko().score_reg && (prec == 0 ? launch_score_loss_reg<F16>(a, s) : launch_score_loss_reg<BF16>(a, s))) return;
   const size_t lds = sizeof(float) * ((size_t)2 * a.D + 2 * (a.D > 1024 ? a.D : 1024) + 8 * (a.C + a.Nn) + 16);
   const bool vec = a.D % 4 == 0;

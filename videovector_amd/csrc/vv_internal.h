@@ -152,6 +152,7 @@ struct ScoreArgs {
   const int32_t* seg_start = nullptr;  // [U + 1]   pos[r] = seg_start[map[r]] + ord[r]
   const int32_t* ord = nullptr;      // [R]
   GuardArgs guard;                   // f16 gradient-scale guard (kernels that write dYh)
+  int items_rr = 0;                  // (lab, KernelOpts::score_rr) workgroup -> item round-robin instead of by XCD ranges
   int32_t* gate_host = nullptr;      // host-mapped word that receives gate_seq when the kernel starts ("the forward GEMM
   int32_t gate_seq = 0;              //   of this step has finished": releases the host to queue a later step's grouping)
   // segment-wise backward (launch_score_fwd): outputs instead of dYh / dbp
@@ -310,6 +311,7 @@ struct KernelOpts {
   int ph_mq = 0;           // (lab) VV_PH_MQ: force the forward tile (2, 3, 4 = 128 / 192 / 256 rows, 31 = 176 rows)
   int score_reg = 1;       // (lab) VV_SCORE_REG=0: the LDS-resident score kernel
   int score_waves = 8;     // (lab) VV_SCORE_WAVES=4
+  int score_rr = 0;        // (lab) VV_SCORE_RR=1: the item-major kernels deal their items round-robin over the XCDs again (kernels_elem.hip: item_of_block)
 };
 extern thread_local const KernelOpts* g_ko;
 inline const KernelOpts& ko() { static const KernelOpts dflt; return g_ko ? *g_ko : dflt; }
