@@ -948,7 +948,8 @@ __global__ __launch_bounds__(256) void k_seg_bwd(SegBwdArgs a) {
   // A wave's rows are a chain of dependent reads each: segment bounds, records, the vectors the records name, and the row
   // itself.  The row's own values (needed last) and the NEXT row's segment bounds are requested right behind the records,
   // so that only records -> vectors is exposed: 18.7 -> 17.9 us.  (More waves do not help: 89 registers and five blocks per
-  // CU instead of four measured the same 17.8-18.3 us.)
+  // CU instead of four measured the same 17.8-18.3 us; so did requesting the NEXT row's records one row early, bounds two rows
+  // early -- 17.8 us: the kernel moves 42 MB of fp32 rows in and 21 MB out, ~3.5 TB/s, and is not latency-chained any more.)
   const int u_first = blockIdx.x * 4 + wave, u_step = 4 * (int)gridDim.x;     // (block numbers by XCD ranges, as item_of_block: measured, no change)
   int seg_b = 0, seg_e = 0;
   if (u_first < U) { seg_b = a.seg_start[u_first]; seg_e = a.seg_start[u_first + 1]; }
