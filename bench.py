@@ -147,10 +147,13 @@ def main():
                          "memory traffic; the same parameters bit for bit).  'stale': the all-reduce of iteration t overlaps "
                          "iteration t+1 and gradients are applied one update late (NOT the reference's algorithm; opt-in, "
                          "labelled)")
-    ap.add_argument("--comm", default="lib", choices=["lib", "torch"],
+    ap.add_argument("--comm", default="lib", choices=["lib", "torch", "peer"],
                     help="N>1: who runs the gradient all-reduce.  'lib' (default): the product library's own RCCL "
                          "communicator on its communication stream (vv_comm_init / vv_allreduce_grads).  'torch': "
-                         "torch.distributed.all_reduce on the tensor the gradients are bound to (cross-check; no overlap mode)")
+                         "torch.distributed.all_reduce on the tensor the gradients are bound to (cross-check; no overlap mode).  "
+                         "'peer': the library's one-shot direct exchange over hipIpc peer mappings (VV_COMM_PEER: reduce-scatter and "
+                         "all-gather as one kernel each over all xGMI links; opt-in -- RCCL stays the default until this has run on an "
+                         "eight-GPU node)")
     ap.add_argument("--sampler", default="auto", choices=["auto", "node", "rank"],
                     help="N>1: who draws the batches.  'rank' (auto for N>1): every rank runs the reference's sampler for its own "
                          "batch of 1024 (its own draw stream: srand(1 + rank), and its own starting record) -- the global batch is "
@@ -343,6 +346,9 @@ def main():
     assert work_stream.cuda_stream != 0
     stride = B_PER_GPU * (C + NN) * 4
     idx_dev = torch.from_numpy(batches).to(dev) if batches is not None else None
+    want_peer = args.comm == "peer"                 # the library's communicator, over its direct peer transport
+    if want_peer:
+        args.comm = "lib"
     mode = args.allreduce if args.allreduce != "auto" else (("overlap" if args.comm == "lib" else "sync") if world > 1 else "none")
     if world == 1 and mode in ("sync", "overlap", "sharded"):
         mode = "none"
@@ -350,7 +356,7 @@ def main():
     if mode in ("overlap", "sharded") and comm == "torch":
         raise SystemExit("--allreduce %s needs --comm lib (the chunked all-reduce / the sharded update live in the library)" % mode)
     # the library's communicator: RCCL, or the shared-memory transport under the one-device test hook
-    comm_transport = "rccl" if os.environ.get("VV_DIST_BACKEND", "nccl") == "nccl" else "shm"
+    comm_transport = "peer" if want_peer else ("rccl" if os.environ.get("VV_DIST_BACKEND", "nccl") == "nccl" else "shm")
     comm_id_path = "/tmp/vv_comm_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", str(os.getppid())))
 
     def lr_at(it):     # shipped solver: inv policy, base 1e-3, gamma 1e-3, power .75
@@ -646,7 +652,8 @@ def main():
                                   ("one per node (rank 0), %d stage thread(s), prefetch depth %d%s"
                                    % (args.sampler_threads, args.prefetch_depth, ", POSIX shared-memory ring" if world > 1 else "") + sampler_note),
                        "comm": {"none": "none", "lib": "the library's RCCL communicator on its own communication stream (vv_comm_*)"
-                                if comm_transport == "rccl" else "the library's shared-memory test transport (one-device hook)",
+                                if comm_transport == "rccl" else ("the library's direct peer exchange (hipIpc mappings, one-shot reduce-scatter / all-gather kernels)"
+                                                                  if comm_transport == "peer" else "the library's shared-memory test transport (one-device hook)"),
                                 "torch": "torch.distributed.all_reduce"}[Run.comm_kind or comm]
                                + (" (fallback: the library's communicator did not come up)" if Run.comm_kind == "torch" and comm == "lib" else ""),
                        "allreduce": {"none": "none (1 GPU)", "sync": "synchronous (exact SGD), exposed",

@@ -161,7 +161,8 @@ void Net<Dtype>::Init(const NetParameter& in_param) {
     // (vv_comm_overlap: F-chunks on the communication stream, gated forward) unless VV_COMM_OVERLAP=0
     const string id_path = "/tmp/vv_caffe_comm_" + Caffe::job_id();
     const bool shm = getenv("VV_COMM") && !strcmp(getenv("VV_COMM"), "shm");
-    VV_CHECK(vv_comm_init(ctx_, Caffe::world(), Caffe::rank(), id_path.c_str(), shm ? VV_COMM_SHM : VV_COMM_RCCL));
+    const bool peer = getenv("VV_COMM") && !strcmp(getenv("VV_COMM"), "peer");   // the one-shot direct exchange over peer mappings
+    VV_CHECK(vv_comm_init(ctx_, Caffe::world(), Caffe::rank(), id_path.c_str(), shm ? VV_COMM_SHM : peer ? VV_COMM_PEER : VV_COMM_RCCL));
     VV_CHECK(vv_comm_overlap(ctx_, !(getenv("VV_COMM_OVERLAP") && atoi(getenv("VV_COMM_OVERLAP")) == 0)));
     // VV_COMM_SCHEDULE=sync | overlap | sharded names the schedule outright (sharded: reduce-scatter, the update on this rank's rows,
     // all-gather of the 16-bit copy: include/videovec.h, vv_comm_schedule)
@@ -173,7 +174,7 @@ void Net<Dtype>::Init(const NetParameter& in_param) {
     cfg_.global_count = (int64_t)Caffe::world() * plan_.B * plan_.Nn;
     LOG(INFO) << "Data-parallel rank " << Caffe::rank() << " of " << Caffe::world() << ": per-GPU batch " << plan_.B
               << ", global batch " << Caffe::world() * plan_.B << ", gradients all-reduced over "
-              << (shm ? "shared memory (test transport)" : "RCCL");
+              << (shm ? "shared memory (test transport)" : peer ? "direct peer mappings (one-shot reduce-scatter / all-gather)" : "RCCL");
   }
   LOG(INFO) << "Network initialization done.";
 }

@@ -191,7 +191,12 @@ int vv_grads_bind(vv_ctx* ctx, void* dev_ptr);
  *   vv_comm_init      after vv_params_set.  transport VV_COMM_RCCL: RCCL (loaded at this call; the copy a host framework
  *                     already loaded is reused); rank 0 writes the communicator id to the file id_path, the others wait
  *                     for it.  VV_COMM_SHM: a host-staged all-reduce through POSIX shared memory named after id_path, for
- *                     tests of the multi-rank path on a box with one device.  Pair it with cfg.global_count = the
+ *                     tests of the multi-rank path on a box with one device.  VV_COMM_PEER: the one-shot DIRECT exchange of one
+ *                     node (<= 16 ranks): every rank's gradient and parameter buffers are mapped into every other rank (hipIpc, the
+ *                     handles passed through a shared-memory object named after id_path), a reduce-scatter is one kernel that reads
+ *                     this rank's shard of all N buffers over xGMI and adds them in rank order, an all-gather one kernel that pulls
+ *                     the foreign shards; the ranks meet at flag words in host-coherent memory, the host is not in the loop.
+ *                     Bit for bit the sums of VV_COMM_SHM; also works between processes that share one device.  Pair it with cfg.global_count = the
  *                     global B * Nn, and give every rank its items of the same global batch (vv_batch_ring_next).
  *   vv_allreduce_grads  sums [dW | db] over the ranks on the context's communication stream and makes the compute stream
  *                     wait for it (the host does not block with RCCL).  vv_apply_update calls it when the caller has not.
@@ -203,7 +208,7 @@ int vv_grads_bind(vv_ctx* ctx, void* dev_ptr);
  *                     (InnerProductLayer::Forward reads every column of W: inner_product_layer.cpp:60-69).  Same sums,
  *                     same update as without overlap; every other entry point that touches the parameters first orders
  *                     itself behind the update in flight.  vv_allreduce_grads is a no-op in this mode. */
-enum { VV_COMM_RCCL = 0, VV_COMM_SHM = 1 };
+enum { VV_COMM_RCCL = 0, VV_COMM_SHM = 1, VV_COMM_PEER = 2 };
 int vv_comm_init(vv_ctx* ctx, int32_t world, int32_t rank, const char* id_path, int32_t transport);
 int vv_comm_overlap(vv_ctx* ctx, int on);
 /* The three exchange schedules by number: 0 = sync, 1 = overlap (as vv_comm_overlap), 2 = SHARDED -- reduce-scatter of the gradients

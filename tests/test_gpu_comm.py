@@ -5,6 +5,9 @@
     communication stream while the NEXT step's forward GEMM already runs and waits per chunk inside the kernel ("overlap")
     -- give bit-identical parameters on both ranks, equal to each other, and the same step as ONE process on the global
     batch (sums reassociated: <= 5e-4);
+  * the one-shot DIRECT exchange (VV_COMM_PEER: hipIpc peer mappings, the reduce-scatter and the all-gather one kernel each, meeting
+    points in host-coherent flags) between 2 and 8 processes on the one GPU: bit for bit the shared-memory transport's results in all
+    three schedules; a missing rank ends in an error, not in a hang;
   * one rank over real RCCL: the dlopen'ed library, the communication stream, the chunk gates run on the GPU box;
   * the gates under a slow exchange (test hook: the communication stream is held 300 us in front of every chunk): the
     forward GEMM really waits where its K loop reaches a chunk that has not arrived; results unchanged bit for bit.
@@ -61,7 +64,7 @@ def _rank_main(rank, world, id_path, overlap, transport, q, env=None):
 def _run_world(world, overlap, transport="shm", env=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    id_path = os.path.join(tempfile.gettempdir(), "vv_comm_test_%d_%d_%s" % (os.getpid(), world, str(overlap)))
+    id_path = os.path.join(tempfile.gettempdir(), "vv_comm_test_%d_%d_%s_%s" % (os.getpid(), world, str(overlap), transport))
     if os.path.exists(id_path):
         os.unlink(id_path)
     procs = [ctx.Process(target=_rank_main, args=(r, world, id_path, overlap, transport, q, env)) for r in range(world)]
@@ -162,3 +165,56 @@ def test_gated_forward_waits_for_a_slow_exchange():
     # the sharded schedule's one gate (in front of the forward GEMM's first W tile), the exchange held 300 us
     res = _run_world(1, "sharded", transport="rccl", env={"VV_COMM_TEST_DELAY_US": "300"})
     assert np.array_equal(res[0][0], W0) and np.array_equal(res[0][1], b0) and np.array_equal(res[0][2], h0)
+
+
+@pytest.mark.parametrize("world,schedule", [(2, False), (2, True), (2, "sharded"), (8, False), (8, "sharded")])
+def test_direct_peer_exchange_is_the_shared_memory_sum_bit_for_bit(world, schedule):
+    """VV_COMM_PEER between `world` processes on the one GPU (the peer mappings are then local; the code path -- handle exchange,
+    meeting kernels, one-shot reduce and gather kernels -- is the one an xGMI node runs): the sums are taken in rank order like the
+    shared-memory transport's, so parameters, bias, history and every iteration's loss are the same bits, on every rank."""
+    shm = _run_world(world, schedule)
+    peer = _run_world(world, schedule, transport="peer")
+    for r in range(world):
+        for k in range(3):
+            assert np.array_equal(peer[r][k], peer[0][k]), "ranks diverged (rank %d, array %d)" % (r, k)
+            assert np.array_equal(peer[r][k], shm[r][k]), "peer differs from shm (rank %d, array %d)" % (r, k)
+        assert peer[r][3] == shm[r][3]
+    assert np.isfinite(peer[0][0]).all() and np.abs(peer[0][2]).max() > 0
+
+
+def _one_step_rank(rank, id_path, q):
+    """both ranks take one step together (the buffers get mapped); rank 1 then leaves, rank 0 takes another"""
+    os.environ["VV_COMM_TIMEOUT"] = "3"
+    import videovector_amd as vv
+    ds, W, b = _case()
+    eng = vv.Engine(0, "f16")
+    eng.table_synth(ds.seed, ds.n_rows, F)
+    eng.params_set(W, b)
+    eng.comm_init(2, rank, id_path, "peer")
+    cfg = vv.StepConfig(B, C, Nn, global_count=2 * B * Nn, lr=0.05)
+    g = _batches(ds, 2)
+    eng.forward_backward(cfg, g[0][rank * B:(rank + 1) * B])
+    eng.apply_update(cfg)
+    eng.params_get()
+    if rank == 1:
+        os._exit(0)
+    try:
+        eng.forward_backward(cfg, g[1][:B])
+        eng.apply_update(cfg)                      # rank 1 never raises its flag again: the meeting kernel gives up after 3 s
+        eng.params_get()                           # waits for the update in flight, then reports what it ran into
+        q.put("no error")
+    except Exception as e:                         # noqa: BLE001
+        q.put(str(e))
+
+
+def test_direct_peer_exchange_a_missing_rank_is_an_error_not_a_hang():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    id_path = os.path.join(tempfile.gettempdir(), "vv_comm_test_%d_lonely" % os.getpid())
+    procs = [ctx.Process(target=_one_step_rank, args=(r, id_path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    msg = q.get(timeout=180)
+    for p in procs:
+        p.join(60)
+    assert "did not reach the exchange in time" in msg, msg

@@ -475,7 +475,7 @@ def test_caffe_train_with_test_net_and_extract_features(tool, pb, oracle, tmp_pa
     assert (np.linalg.norm(got - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-20)).max() <= 1e-3
 
 
-@pytest.mark.parametrize("overlap", ["0", "1", "sharded"])
+@pytest.mark.parametrize("overlap", ["0", "1", "sharded", "peer-sharded"])
 def test_caffe_train_data_parallel_two_ranks(tool, pb, tmp_path, overlap):
     """`caffe train` as a data-parallel job: two processes (WORLD_SIZE / RANK / LOCAL_RANK as torch.distributed.run sets
     them) on the one visible GPU, gradients over the shared-memory test transport.  Rank 0's sampler draws the global
@@ -500,9 +500,11 @@ def test_caffe_train_data_parallel_two_ranks(tool, pb, tmp_path, overlap):
 
     two = files("two", B)
     procs = []
+    transport = "peer" if overlap.startswith("peer-") else "shm"     # peer: the one-shot direct exchange over hipIpc mappings (VV_COMM_PEER)
+    overlap = overlap.replace("peer-", "")
     for r in range(2):
-        env = dict(os.environ, WORLD_SIZE="2", RANK=str(r), LOCAL_RANK="0", VV_COMM="shm", VV_COMM_OVERLAP=overlap if overlap != "sharded" else "0",
-                   VV_JOB_ID="t%d_%s" % (os.getpid(), overlap), VV_SAMPLER_MODE="node")
+        env = dict(os.environ, WORLD_SIZE="2", RANK=str(r), LOCAL_RANK="0", VV_COMM=transport, VV_COMM_OVERLAP=overlap if overlap != "sharded" else "0",
+                   VV_JOB_ID="t%d_%s_%s" % (os.getpid(), overlap, transport), VV_SAMPLER_MODE="node")
         if overlap == "sharded":
             env["VV_COMM_SCHEDULE"] = "sharded"        # (snapshots at iterations 2 and 3: every rank gathers, rank 0 writes)
         procs.append(subprocess.Popen([CAFFE, "train", "--solver=%s" % two, "--weights=%s" % (tmp_path / "init.caffemodel"),

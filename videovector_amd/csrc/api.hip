@@ -19,7 +19,8 @@
 
 namespace vv { int gemm_variant(); bool ablate_on(); thread_local const KernelOpts* g_ko = nullptr; }
 // every entry point that launches kernels: the device of the context, and ITS kernel options for the launchers on this thread
-#define VV_ENTER(c) do { HIPCHK(hipSetDevice((c)->device)); vv::g_ko = &(c)->ko; } while (0)
+#define VV_ENTER(c) do { HIPCHK(hipSetDevice((c)->device)); vv::g_ko = &(c)->ko; \
+    if ((c)->comm && vv::comm_failed((c)->comm)) return fail(VV_ERR_HIP, "the data-parallel exchange failed: %s", vv::comm_error((c)->comm)); } while (0)
 // environment of a PRODUCT option (read once per context) / of a lab switch (ignored unless the library was built with -DVV_LAB)
 static inline const char* opt_env(const char* name) { return getenv(name); }
 #ifdef VV_LAB
@@ -507,7 +508,7 @@ static int gather_params(vv_ctx* c) {
   const size_t sbytes[3] = {(size_t)rps * c->F * 4, (size_t)rps * c->F * 4, (size_t)rps * 4};
   HIPCHK(hipEventRecord(c->ev_chunk, c->stream));
   HIPCHK(hipStreamWaitEvent(vv::comm_stream(c->comm), c->ev_chunk, 0));
-  if (vv::comm_allgather(c->comm, bufs, sbytes, 3)) return fail(VV_ERR_HIP, "all-gather of the parameters: %s", vv::comm_error(c->comm));
+  if (vv::comm_allgather(c->comm, bufs, sbytes, 3, 1)) return fail(VV_ERR_HIP, "all-gather of the parameters: %s", vv::comm_error(c->comm));
   if (vv::comm_record_done(c->comm)) return fail(VV_ERR_HIP, "all-gather of the parameters: %s", vv::comm_error(c->comm));
   HIPCHK(hipStreamWaitEvent(c->stream, vv::comm_done_event(c->comm), 0));
   c->params_partial = false;
@@ -521,6 +522,7 @@ int vv_params_get(vv_ctx* c, float* W, float* b, float* hW, float* hb) {
   { const int rcj = comm_join(c); if (rcj) return rcj; }
   { const int rcg = gather_params(c); if (rcg) return rcg; }
   HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->comm && vv::comm_failed(c->comm)) return fail(VV_ERR_HIP, "vv_params_get: the data-parallel exchange failed: %s", vv::comm_error(c->comm));   // (what the update in flight ran into)
   const size_t nW = (size_t)c->D * c->F;
   if (W) HIPCHK(hipMemcpy(W, c->W, nW * 4, hipMemcpyDeviceToHost));
   if (b) HIPCHK(hipMemcpy(b, c->b, c->D * 4, hipMemcpyDeviceToHost));
@@ -1536,7 +1538,7 @@ int vv_comm_init(vv_ctx* c, int32_t world, int32_t rank, const char* id_path, in
   if (!c) return fail(VV_ERR_ARG, "vv_comm_init: ctx is NULL");
   if (world < 1 || rank < 0 || rank >= world) return fail(VV_ERR_ARG, "vv_comm_init: rank %d of %d", rank, world);
   if (world > 1 && (!id_path || !*id_path)) return fail(VV_ERR_ARG, "vv_comm_init: id_path is required for world > 1");
-  if (transport != VV_COMM_RCCL && transport != VV_COMM_SHM) return fail(VV_ERR_ARG, "vv_comm_init: unknown transport %d", transport);
+  if (transport != VV_COMM_RCCL && transport != VV_COMM_SHM && transport != VV_COMM_PEER) return fail(VV_ERR_ARG, "vv_comm_init: unknown transport %d", transport);
   if (!c->W) return fail(VV_ERR_STATE, "vv_comm_init: set the parameters first (they size the gradient buffer)");
   if (c->comm) return fail(VV_ERR_STATE, "vv_comm_init: a communicator already exists");
   VV_ENTER(c);

@@ -10,9 +10,16 @@
 //                  its buffer out, all ranks add the world's buffers in rank order (bit-identical results on every
 //                  rank), copy back.  For tests of the N > 1 path on a box with ONE device (RCCL refuses two ranks on
 //                  one device); never the benchmark's transport.
+//   VV_COMM_PEER   one-shot DIRECT exchange over peer mappings (hipIpc): every rank's gradient / parameter buffers are mapped
+//                  into every other rank, a reduce-scatter is ONE kernel in which rank r reads shard r of all N buffers
+//                  (N - 1 of them over xGMI, all seven links at once) and adds them in rank order, an all-gather ONE
+//                  kernel that pulls the N - 1 foreign shards; ranks meet at flag words in host-coherent shared memory
+//                  (a one-wave kernel signals and polls: the host is not in the loop).  Two hops of 1/N of the bytes
+//                  each instead of the ring's 2 (N - 1) steps; bit for bit the VV_COMM_SHM sums.  Works between
+//                  processes on ONE device too (the mappings are then local), which is how it is tested here.
 //
 // The collective runs on a communication stream owned by the context; events join it with the compute stream, the
-// host never blocks (RCCL transport).
+// host never blocks (RCCL and PEER transports).
 #include <cerrno>
 #include <chrono>
 #include <cstdio>
@@ -21,6 +28,8 @@
 #include <string>
 #include <thread>
 #include <atomic>
+#include <vector>
+#include <algorithm>
 
 #include <dlfcn.h>
 #include <fcntl.h>
@@ -91,6 +100,12 @@ struct ShmHdr {
 };
 static constexpr uint64_t kShmMagic = 0x5656434f4d4d3031ull;   // "VVCOMM01"
 
+static constexpr int kPeerMax = 16;               // ranks of a direct exchange (one node)
+static constexpr int kPeerFlagStride = 16;        // words between two ranks' flags (64 bytes)
+struct PeerReg { unsigned char* base = nullptr; size_t size = 0; unsigned char* peer[kPeerMax] = {}; };
+struct PeerSlot { hipIpcMemHandle_t h; uint64_t size; };          // one rank's entry of the handle table in the shared object
+static_assert(sizeof(PeerSlot) <= 256, "handle table slot");
+
 struct Comm {
   int world = 1, rank = 0, transport = VV_COMM_RCCL;
   hipStream_t stream = nullptr;                 // communication stream
@@ -102,6 +117,12 @@ struct Comm {
   // shared-memory stub
   ShmHdr* shm = nullptr; size_t shm_bytes = 0; std::string shm_name; float* stage = nullptr; size_t stage_floats = 0;
   int64_t barriers = 0;
+  // direct peer exchange
+  std::vector<PeerReg> regs;                     // buffers mapped so far (the allocation that holds them, in every rank)
+  uint32_t* flags_host = nullptr; uint32_t* flags_dev = nullptr;   // world words, kPeerFlagStride apart (shared, host coherent)
+  uint32_t* status_host = nullptr; uint32_t* status_dev = nullptr; // != 0: a wait gave up (a rank is missing)
+  uint32_t seq = 0;                              // meeting points so far (every rank counts the same ones)
+  double peer_timeout_s = 30.0;
   std::string err;
 };
 
@@ -120,6 +141,11 @@ static bool shm_barrier(Comm* c, double timeout_s) {
 }
 
 const char* comm_error(Comm* c) { return c ? c->err.c_str() : "no communicator"; }
+bool comm_failed(Comm* c) {
+  if (!c || !c->status_host || !*(volatile uint32_t*)c->status_host) return false;
+  c->err = "a rank did not reach the exchange in time (direct peer transport)";
+  return true;
+}
 int comm_world(Comm* c) { return c ? c->world : 1; }
 int comm_rank(Comm* c) { return c ? c->rank : 0; }
 
@@ -127,6 +153,16 @@ void comm_destroy(Comm* c) {
   if (!c) return;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->nccl && c->CommDestroy) c->CommDestroy(c->nccl);
+  if (c->transport == VV_COMM_PEER && c->shm) {
+    // nobody unmaps or frees what a peer may still be reading: the ranks meet once more (briefly: a rank that died does not hold the others)
+    if (c->flags_host && c->world > 1) (void)shm_barrier(c, 5.0);
+    for (auto& r : c->regs)
+      for (int k = 0; k < c->world; ++k)
+        if (k != c->rank && r.peer[k]) (void)hipIpcCloseMemHandle(r.peer[k]);
+    c->regs.clear();
+    if (c->flags_host) (void)hipHostUnregister(c->flags_host);
+    if (c->status_host) (void)hipHostFree(c->status_host);
+  }
   if (c->shm) { munmap((void*)c->shm, c->shm_bytes); if (c->rank == 0) shm_unlink(c->shm_name.c_str()); }
   if (c->stage) (void)hipHostFree(c->stage);
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
@@ -215,9 +251,11 @@ Comm* comm_create(int world, int rank, const char* id_path, int transport, size_
       (void)hipFree(warm);
       if (rw != 0 || es != hipSuccess) return fail(std::string("the communicator's first all-reduce failed: ") + (rw != 0 && c->ErrStr ? c->ErrStr(rw) : hipGetErrorString(es)));
     }
-  } else if (transport == VV_COMM_SHM) {
+  } else if (transport == VV_COMM_SHM || transport == VV_COMM_PEER) {
+    if (transport == VV_COMM_PEER && world > kPeerMax) return fail("the direct peer exchange takes at most 16 ranks");
     c->shm_name = shm_name_of(id_path);
-    c->shm_bytes = shm_hdr_bytes() + (size_t)world * n_floats * sizeof(float);
+    // VV_COMM_SHM: the header and one gradient-sized slab per rank.  VV_COMM_PEER: the header, a page of flag words, a page of handle slots.
+    c->shm_bytes = transport == VV_COMM_SHM ? shm_hdr_bytes() + (size_t)world * n_floats * sizeof(float) : shm_hdr_bytes() + 2 * 4096;
     int fd = -1;
     if (rank == 0) {
       shm_unlink(c->shm_name.c_str());
@@ -275,14 +313,175 @@ Comm* comm_create(int world, int rank, const char* id_path, int transport, size_
       }
       if (c->shm->world != world || c->shm->n_floats != n_floats) return fail("shared-memory object belongs to a different job shape");
     }
-    c->stage_floats = n_floats;
-    if (hipHostMalloc((void**)&c->stage, n_floats * sizeof(float), hipHostMallocDefault) != hipSuccess) return fail("hipHostMalloc failed");
+    if (transport == VV_COMM_SHM) {
+      c->stage_floats = n_floats;
+      if (hipHostMalloc((void**)&c->stage, n_floats * sizeof(float), hipHostMallocDefault) != hipSuccess) return fail("hipHostMalloc failed");
+    } else {
+      // the flag page, seen by this rank's device: system-scope atomics of the meeting kernel go to host memory every rank maps
+      c->flags_host = (uint32_t*)((unsigned char*)c->shm + shm_hdr_bytes());
+      if (rank == 0) memset(c->flags_host, 0, 4096);
+      if (hipHostRegister(c->flags_host, 4096, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) { c->flags_host = nullptr; return fail("hipHostRegister of the flag page failed"); }
+      if (hipHostGetDevicePointer((void**)&c->flags_dev, c->flags_host, 0) != hipSuccess) return fail("hipHostGetDevicePointer failed");
+      if (hipHostMalloc((void**)&c->status_host, 64, hipHostMallocMapped) != hipSuccess) return fail("hipHostMalloc failed");
+      c->status_host[0] = 0;
+      if (hipHostGetDevicePointer((void**)&c->status_dev, c->status_host, 0) != hipSuccess) return fail("hipHostGetDevicePointer failed");
+      c->peer_timeout_s = getenv("VV_COMM_TIMEOUT") ? atof(getenv("VV_COMM_TIMEOUT")) : 30.0;
+    }
     if (!shm_barrier(c, timeout_s)) return fail("ranks did not all arrive");
     if (rank == 0) shm_unlink(c->shm_name.c_str());     // every rank holds its mapping: the name has done its job (nothing is left behind, crash or not)
   } else {
     return fail("unknown transport");
   }
   return c;
+}
+
+
+// ---- VV_COMM_PEER: the meeting point, the one-shot reduce and the one-shot gather ---------------------------------------------
+// Meeting point `seq`: this rank's flag is raised to seq (release, system scope: everything the stream ran before this kernel is
+// visible to whoever sees the flag -- the kernels before it ended with a system-scope release of their own), then lane r waits for rank
+// r's flag.  One wave: it occupies nothing a peer process on the same device needs in order to get there.  A wait that outlasts
+// `timeout_ticks` (100 MHz) gives up and sets *status; the host reports it at the next call.
+__global__ void k_peer_meet(uint32_t* flags, int world, int rank, uint32_t seq, unsigned long long timeout_ticks, uint32_t* status) {
+  const int t = threadIdx.x;
+  if (t == rank) __hip_atomic_store(flags + (size_t)rank * kPeerFlagStride, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (t < world && t != rank) {
+    const unsigned long long t0 = wall_clock64();
+    unsigned spins = 0;
+    while ((int32_t)(__hip_atomic_load(flags + (size_t)t * kPeerFlagStride, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+      __builtin_amdgcn_s_sleep(8);
+      if ((++spins & 255u) == 0 && wall_clock64() - t0 > timeout_ticks) { __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+    }
+  }
+}
+
+struct PeerSrc { const float* p[kPeerMax]; };
+// out[i] = ((src0[i] + src1[i]) + src2[i]) + ...   -- rank order, the order of the shared-memory transport's sums
+__global__ void __launch_bounds__(256) k_peer_reduce(PeerSrc src, float* __restrict__ out, size_t n, int world, int vec) {
+  const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nth = (size_t)gridDim.x * 256;
+  if (vec) {
+    const size_t n4 = n / 4;
+    for (size_t i = tid; i < n4; i += nth) {
+      float4 a = ((const float4*)src.p[0])[i];
+      for (int r = 1; r < world; ++r) {
+        const float4 b = ((const float4*)src.p[r])[i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      }
+      ((float4*)out)[i] = a;
+    }
+    for (size_t i = n4 * 4 + tid; i < n; i += nth) {
+      float a = src.p[0][i];
+      for (int r = 1; r < world; ++r) a += src.p[r][i];
+      out[i] = a;
+    }
+  } else {
+    for (size_t i = tid; i < n; i += nth) {
+      float a = src.p[0][i];
+      for (int r = 1; r < world; ++r) a += src.p[r][i];
+      out[i] = a;
+    }
+  }
+}
+
+constexpr int kGatherBufs = 4;
+struct GatherArgs {
+  int n, world, rank, blocks_per_piece;
+  unsigned char* dst[kGatherBufs];                       // this rank's buffers
+  const unsigned char* src[kGatherBufs][kPeerMax];       // the same buffers in every rank (peer mappings)
+  size_t stride[kGatherBufs], total[kGatherBufs];        // rank r owns bytes [r stride, min((r + 1) stride, total))
+};
+// piece (buffer i, peer r) = blockIdx.y: the peer's own bytes of buffer i pulled into this rank's copy
+__global__ void __launch_bounds__(256) k_peer_gather(GatherArgs g) {
+  const int i = blockIdx.y / g.world, r = blockIdx.y % g.world;
+  if (r == g.rank) return;
+  const size_t lo = (size_t)r * g.stride[i];
+  if (lo >= g.total[i]) return;
+  const size_t nb = (g.total[i] - lo < g.stride[i]) ? g.total[i] - lo : g.stride[i];
+  const unsigned char* s = g.src[i][r] + lo;
+  unsigned char* d = g.dst[i] + lo;
+  const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nth = (size_t)gridDim.x * 256;
+  size_t body = 0;
+  if ((((uintptr_t)s | (uintptr_t)d) & 15) == 0) {
+    body = nb / 16;
+    for (size_t k = tid; k < body; k += nth) ((uint4*)d)[k] = ((const uint4*)s)[k];
+    body *= 16;
+  }
+  for (size_t k = body + tid; k < nb; k += nth) d[k] = s[k];
+}
+
+// The allocation that holds `ptr`, mapped in every rank (found, or exchanged now: a COLLECTIVE the first time a buffer is used --
+// every rank runs the same sequence of collectives on the same buffers, so every rank gets here together).
+static PeerReg* peer_reg(Comm* c, const void* ptr) {
+  for (auto& r : c->regs)
+    if ((const unsigned char*)ptr >= r.base && (const unsigned char*)ptr < r.base + r.size) return &r;
+  PeerReg reg;
+  void* base = nullptr; size_t size = 0;
+  if (hipMemGetAddressRange((hipDeviceptr_t*)&base, &size, (hipDeviceptr_t)ptr) != hipSuccess) { c->err = "hipMemGetAddressRange failed (the buffer is not a device allocation)"; return nullptr; }
+  reg.base = (unsigned char*)base; reg.size = size; reg.peer[c->rank] = reg.base;
+  if (c->world > 1) {
+    PeerSlot* table = (PeerSlot*)((unsigned char*)c->shm + shm_hdr_bytes() + 4096);
+    PeerSlot* mine = (PeerSlot*)((unsigned char*)table + (size_t)c->rank * 256);
+    if (hipIpcGetMemHandle(&mine->h, base) != hipSuccess) { c->err = "hipIpcGetMemHandle failed"; return nullptr; }
+    mine->size = size;
+    const double timeout_s = getenv("VV_COMM_TIMEOUT") ? atof(getenv("VV_COMM_TIMEOUT")) : 120.0;
+    if (!shm_barrier(c, timeout_s)) { c->err = "mapping a buffer into the peers: a rank is missing"; return nullptr; }
+    for (int k = 0; k < c->world; ++k) {
+      if (k == c->rank) continue;
+      const PeerSlot* theirs = (const PeerSlot*)((const unsigned char*)table + (size_t)k * 256);
+      if (theirs->size != size) { c->err = "a peer's buffer has another size"; return nullptr; }
+      void* p = nullptr;
+      const hipError_t e = hipIpcOpenMemHandle(&p, theirs->h, hipIpcMemLazyEnablePeerAccess);
+      if (e != hipSuccess) { c->err = std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e); return nullptr; }
+      reg.peer[k] = (unsigned char*)p;
+    }
+    if (!shm_barrier(c, timeout_s)) { c->err = "mapping a buffer into the peers: a rank is missing"; return nullptr; }   // the table is free again
+  }
+  c->regs.push_back(reg);
+  return &c->regs.back();
+}
+
+static int peer_meet(Comm* c) {
+  if (c->status_host && *(volatile uint32_t*)c->status_host) { c->err = "a rank did not reach the exchange in time (direct peer transport)"; return -1; }
+  if (c->world == 1) return 0;
+  ++c->seq;
+  k_peer_meet<<<1, 64, 0, c->stream>>>(c->flags_dev, c->world, c->rank, c->seq, (unsigned long long)(c->peer_timeout_s * 1e8), c->status_dev);
+  return hipGetLastError() == hipSuccess ? 0 : (c->err = "launch of the meeting kernel failed", -1);
+}
+
+// rank r's range [lo, lo + n) of `buf` (floats) <- the sum over the ranks of that range, in rank order
+static int peer_reduce_range(Comm* c, float* buf, size_t lo, size_t n) {
+  PeerReg* reg = peer_reg(c, buf);
+  if (!reg) return -1;
+  if (n == 0 || c->world == 1) return 0;
+  const size_t off = (unsigned char*)(buf + lo) - reg->base;
+  PeerSrc src;
+  for (int k = 0; k < c->world; ++k) src.p[k] = (const float*)(reg->peer[k] + off);
+  const int vec = (off & 15) == 0;
+  const size_t work = vec ? (n + 3) / 4 : n;
+  const int blocks = (int)std::min<size_t>(1024, std::max<size_t>(1, (work + 255) / 256));
+  k_peer_reduce<<<blocks, 256, 0, c->stream>>>(src, buf + lo, n, c->world, vec);
+  return hipGetLastError() == hipSuccess ? 0 : (c->err = "launch of the reduce kernel failed", -1);
+}
+
+// buffers i < n: every rank's own bytes [r stride_i, ...) of `total_i` pulled from their owners
+static int peer_gather(Comm* c, void* const* bufs, const size_t* stride, const size_t* total, int n) {
+  if (n > kGatherBufs) { c->err = "too many buffers in one all-gather"; return -1; }
+  GatherArgs g;
+  memset(&g, 0, sizeof(g));
+  g.n = n; g.world = c->world; g.rank = c->rank;
+  size_t largest = 0;
+  for (int i = 0; i < n; ++i) {
+    PeerReg* reg = peer_reg(c, bufs[i]);
+    if (!reg) return -1;
+    const size_t off = (unsigned char*)bufs[i] - reg->base;
+    g.dst[i] = (unsigned char*)bufs[i];
+    for (int k = 0; k < c->world; ++k) g.src[i][k] = reg->peer[k] + off;
+    g.stride[i] = stride[i]; g.total[i] = total[i];
+    largest = std::max(largest, stride[i]);
+  }
+  if (c->world == 1 || largest == 0) return 0;
+  const int bx = (int)std::min<size_t>(64, std::max<size_t>(1, (largest / 16 + 255) / 256));
+  k_peer_gather<<<dim3(bx, n * c->world), 256, 0, c->stream>>>(g);
+  return hipGetLastError() == hipSuccess ? 0 : (c->err = "launch of the gather kernel failed", -1);
 }
 
 // all-reduce(sum) of buf[0 .. n) in place.  `after`: the collective starts once this event (recorded on the compute
@@ -302,6 +501,16 @@ int comm_allreduce(Comm* c, float* buf, size_t off, size_t n, hipEvent_t after) 
   if (c->transport == VV_COMM_RCCL) {
     const int rc = c->AllReduce(buf + off, buf + off, n, kNcclFloat32, kNcclSum, c->nccl, c->stream);
     if (rc != 0) { c->err = std::string("ncclAllReduce: ") + (c->ErrStr ? c->ErrStr(rc) : "error"); return -1; }
+  } else if (c->transport == VV_COMM_PEER) {
+    // reduce-scatter + all-gather of the range, both direct: rank r sums slice r (a multiple of four floats; the last one may be
+    // short), the ranks meet, every rank pulls the other slices; a third meeting keeps a fast rank's NEXT gradients out of a buffer a
+    // slow rank is still pulling from
+    if (!peer_reg(c, buf)) return -1;
+    const size_t per = ((n + c->world - 1) / c->world + 3) / 4 * 4;
+    const size_t lo = std::min(n, (size_t)c->rank * per), hi = std::min(n, lo + per);
+    void* bufs[1] = {buf + off};
+    const size_t stride[1] = {per * sizeof(float)}, total[1] = {n * sizeof(float)};
+    if (peer_meet(c) || peer_reduce_range(c, buf, off + lo, hi - lo) || peer_meet(c) || peer_gather(c, bufs, stride, total, 1) || peer_meet(c)) return -1;
   } else {
     const double timeout_s = getenv("VV_COMM_TIMEOUT") ? atof(getenv("VV_COMM_TIMEOUT")) : 120.0;
     float* slabs = (float*)((unsigned char*)c->shm + shm_hdr_bytes());
@@ -332,6 +541,14 @@ int comm_reduce_scatter(Comm* c, float* buf, size_t shard, hipEvent_t after) {
     if (rc != 0) { c->err = std::string("ncclReduceScatter: ") + (c->ErrStr ? c->ErrStr(rc) : "error"); return -1; }
     return 0;
   }
+  if (c->transport == VV_COMM_PEER) {
+    // every rank's buffer is complete (meeting), then ONE kernel: shard `rank` of all the buffers, summed in rank order, into this
+    // rank's.  Nobody writes what a peer reads: rank r's shard of rank k's buffer is read by r alone and written by nobody but k's NEXT
+    // backward pass -- which follows k's next forward pass, which follows the all-gather every rank enters only after this kernel.
+    if (!peer_reg(c, buf)) return -1;
+    if (peer_meet(c) || peer_reduce_range(c, buf, (size_t)c->rank * shard, shard)) return -1;
+    return 0;
+  }
   // shared-memory stand-in: every rank publishes its whole buffer, then sums ITS shard over the ranks in rank order -- the
   // order of comm_allreduce's sums, so the shard is bit for bit what the all-reduce would have left there
   const double timeout_s = getenv("VV_COMM_TIMEOUT") ? atof(getenv("VV_COMM_TIMEOUT")) : 120.0;
@@ -354,7 +571,7 @@ int comm_reduce_scatter(Comm* c, float* buf, size_t shard, hipEvent_t after) {
   return 0;
 }
 
-int comm_allgather(Comm* c, void* const* bufs, const size_t* shard_bytes, int n) {
+int comm_allgather(Comm* c, void* const* bufs, const size_t* shard_bytes, int n, int fence_after) {
   if (c->transport == VV_COMM_RCCL) {
     if (!c->AllGather) { c->err = "librccl has no ncclAllGather"; return -1; }
     if (n > 1 && c->GroupStart) c->GroupStart();
@@ -365,6 +582,16 @@ int comm_allgather(Comm* c, void* const* bufs, const size_t* shard_bytes, int n)
     }
     if (n > 1 && c->GroupEnd) { const int rg = c->GroupEnd(); if (rc == 0) rc = rg; }
     if (rc != 0) { c->err = std::string("ncclAllGather: ") + (c->ErrStr ? c->ErrStr(rc) : "error"); return -1; }
+    return 0;
+  }
+  if (c->transport == VV_COMM_PEER) {
+    // every rank's shard is final (meeting), then ONE kernel pulls the foreign shards of all n buffers.  `fence_after`: a closing
+    // meeting, for a gather that no later collective orders against the owners' next writes.
+    size_t total[kGatherBufs];
+    if (n > kGatherBufs) { c->err = "too many buffers in one all-gather"; return -1; }
+    for (int i = 0; i < n; ++i) { total[i] = shard_bytes[i] * c->world; if (!peer_reg(c, bufs[i])) return -1; }
+    if (peer_meet(c) || peer_gather(c, bufs, shard_bytes, total, n)) return -1;
+    if (fence_after && peer_meet(c)) return -1;
     return 0;
   }
   const double timeout_s = getenv("VV_COMM_TIMEOUT") ? atof(getenv("VV_COMM_TIMEOUT")) : 120.0;

@@ -19,13 +19,15 @@ int comm_allreduce_inline(Comm* c, float* buf, size_t n, hipStream_t stream);   
 //   comm_reduce_scatter  buf holds `world` shards of shard_floats each; on return rank r's shard holds the sum over the ranks of that
 //                        shard (the other shards are unspecified); started after `after`
 //   comm_allgather       n buffers at once (one grouped launch on RCCL), buffer i = `world` shards of shard_bytes[i]; rank r's shard is
-//                        the input, on return every shard holds its owner's bytes
+//                        the input, on return every shard holds its owner's bytes.  fence_after (direct peer transport): the ranks meet
+//                        once more behind the gather -- for a gather that no later collective orders against the owners' next writes
 int comm_reduce_scatter(Comm* c, float* buf, size_t shard_floats, hipEvent_t after);
-int comm_allgather(Comm* c, void* const* bufs, const size_t* shard_bytes, int n);
+int comm_allgather(Comm* c, void* const* bufs, const size_t* shard_bytes, int n, int fence_after = 0);
 hipEvent_t comm_done_event(Comm* c);
 hipStream_t comm_stream(Comm* c);          // the communication stream (the overlapped update queues its kernels there)
 int comm_record_done(Comm* c);             // records comm_done_event behind everything queued on the communication stream
 const char* comm_error(Comm* c);
+bool comm_failed(Comm* c);                 // a wait inside the exchange gave up (direct peer transport: a rank is missing); comm_error says so
 int comm_world(Comm* c);
 int comm_rank(Comm* c);
 }  // namespace vv

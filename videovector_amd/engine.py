@@ -274,7 +274,7 @@ class Engine:
     # ---- data parallel (vv_comm_*)
     def comm_init(self, world, rank, id_path, transport="rccl"):
         self._chk(self.L.vv_comm_init(self.h, world, rank, None if id_path is None else id_path.encode(),
-                                      {"rccl": 0, "shm": 1}[transport]))
+                                      {"rccl": 0, "shm": 1, "peer": 2}[transport]))
 
     def comm_overlap(self, on=True):
         self._chk(self.L.vv_comm_overlap(self.h, int(bool(on))))
