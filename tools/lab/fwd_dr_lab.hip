@@ -96,7 +96,8 @@ int main(int argc, char** argv) {
                            {"dr12_run256_onlyA", 27}, {"dr12_run256_onlyAB", 28}, {"dr12_run256_full", 29},
                            {"dr12_rot1", 30}, {"dr12_rot2", 31}, {"dr12_rot4", 32}, {"dr12_rot1_onlyA", 33}, {"dr12_rot2_onlyA", 34}, {"dr12_rot4_onlyA", 35},
                            {"dr12_run512_onlyA", 36}, {"dr12_run1k_onlyA", 37},
-                           {"dr12_bl1_onlyA", 38}, {"dr12_bl2_onlyA", 39}, {"dr12_bl4_onlyA", 40}, {"dr12_bl2_onlyAB", 41}, {"dr12_bl2_noRD", 42}};
+                           {"dr12_bl1_onlyA", 38}, {"dr12_bl2_onlyA", 39}, {"dr12_bl4_onlyA", 40}, {"dr12_bl2_onlyAB", 41}, {"dr12_bl2_noRD", 42},
+                           {"dr12_spread_onlyA", 43}, {"dr12_spread_full", 44}, {"dr12_spread_noRD", 45}, {"dr12_spread_run1k_onlyA", 46}};
   auto run = [&](int kind, int set, float* Hout) {
     FwdArgs a = base; a.rows = rows + (size_t)set * Rp; a.H = Hout;
     if (kind == 0) { a.Wh = Wh; launch_fwd_gemm_ph(0, a, st); return; }
@@ -144,6 +145,10 @@ int main(int argc, char** argv) {
       case 40: launch_dr<12, 4, 2 + 4 + 16, 0, 1 + 1536>(a, st); break;
       case 41: launch_dr<12, 4, 2 + 4, 0, 1 + 1024>(a, st); break;
       case 42: launch_dr<12, 4, 4, 0, 1 + 1024>(a, st); break;
+      case 43: launch_dr<12, 4, 2 + 4 + 16, 0, 1 + 2048>(a, st); break;      // gathered rows alone, K spread over the row tiles
+      case 44: launch_dr<12, 4, 0, 0, 1 + 2048>(a, st); break;               // full kernel, K spread
+      case 45: launch_dr<12, 4, 4, 0, 1 + 2048>(a, st); break;               // both streams, no fragment reads
+      case 46: launch_dr<12, 4, 2 + 4 + 16, 0, 1 + 2048 + 16 + 256>(a, st); break;   // rows alone, K spread, 1-KiB runs
     }
   };
   // correctness: the real variants against the LDS kernel, bit for bit, on every row set

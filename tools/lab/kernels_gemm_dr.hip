@@ -155,7 +155,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_dr(FwdArgs a) {
   // (lab, OPT bits 5-6: K ROTATION) odd column tiles run their K loop 1 / 2 / 4 tiles ahead (tile (t + rot) mod nk at step t): a row tile's
   // two siblings never ask for the same gathered lines at the same time -- the odd one is every line's first toucher, the even one finds it
   // in L2 rot steps later -- with no extra LDS.  The accumulation order of the odd tiles is rotated with it (not bit-identical to k_fwd_gemm_ph).
-  const int rot = ((OPT >> 5) & 3) == 0 ? 0 : (((L % tilesN) & 1) ? (1 << (((OPT >> 5) & 3) - 1)) : 0);
+  // (lab, OPT bit 11: K SPREAD) every ROW tile starts its K loop at another tile (19 * row tile mod nk; the column siblings together): at any
+  // moment the workgroups of the chip ask for different 128-byte offsets of their 8-KiB rows, i.e. for different L2 / memory channels, instead
+  // of marching through the offsets in step.
+  const int rot = (OPT & 2048) ? (int)(((unsigned)(L / tilesN) * 19u) % (unsigned)nk)
+                : ((OPT >> 5) & 3) == 0 ? 0 : (((L % tilesN) & 1) ? (1 << (((OPT >> 5) & 3) - 1)) : 0);
   auto rotk = [&](int tt) { const int k = tt + rot; return k >= nk ? k - nk : k; };
   // (lab, OPT bits 9-10, STREAM TIMING ONLY: the LDS image is wrong) BALANCED lead: every workgroup asks for the half of its rows that matches its
   // column parity 1 / 2 / 4 K-tiles early -- each sibling is the first toucher of half of the lines and finds the other half in L2
