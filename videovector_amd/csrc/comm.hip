@@ -121,6 +121,7 @@ struct Comm {
   std::vector<PeerReg> regs;                     // buffers mapped so far (the allocation that holds them, in every rank)
   uint32_t* flags_host = nullptr; uint32_t* flags_dev = nullptr;   // world words, kPeerFlagStride apart (shared, host coherent)
   uint32_t* status_host = nullptr; uint32_t* status_dev = nullptr; // != 0: a wait gave up (a rank is missing)
+  uint32_t* xcd_count = nullptr;                 // device word: the meeting kernel's workgroups 1..7 count themselves in
   uint32_t seq = 0;                              // meeting points so far (every rank counts the same ones)
   double peer_timeout_s = 30.0;
   std::string err;
@@ -162,6 +163,7 @@ void comm_destroy(Comm* c) {
     c->regs.clear();
     if (c->flags_host) (void)hipHostUnregister(c->flags_host);
     if (c->status_host) (void)hipHostFree(c->status_host);
+    if (c->xcd_count) (void)hipFree(c->xcd_count);
   }
   if (c->shm) { munmap((void*)c->shm, c->shm_bytes); if (c->rank == 0) shm_unlink(c->shm_name.c_str()); }
   if (c->stage) (void)hipHostFree(c->stage);
@@ -325,6 +327,7 @@ Comm* comm_create(int world, int rank, const char* id_path, int transport, size_
       if (hipHostMalloc((void**)&c->status_host, 64, hipHostMallocMapped) != hipSuccess) return fail("hipHostMalloc failed");
       c->status_host[0] = 0;
       if (hipHostGetDevicePointer((void**)&c->status_dev, c->status_host, 0) != hipSuccess) return fail("hipHostGetDevicePointer failed");
+      if (hipMalloc((void**)&c->xcd_count, 64) != hipSuccess || hipMemset(c->xcd_count, 0, 64) != hipSuccess) return fail("hipMalloc failed");
       c->peer_timeout_s = getenv("VV_COMM_TIMEOUT") ? atof(getenv("VV_COMM_TIMEOUT")) : 30.0;
     }
     if (!shm_barrier(c, timeout_s)) return fail("ranks did not all arrive");
@@ -337,15 +340,30 @@ Comm* comm_create(int world, int rank, const char* id_path, int transport, size_
 
 
 // ---- VV_COMM_PEER: the meeting point, the one-shot reduce and the one-shot gather ---------------------------------------------
-// Meeting point `seq`: this rank's flag is raised to seq (release, system scope: everything the stream ran before this kernel is
-// visible to whoever sees the flag -- the kernels before it ended with a system-scope release of their own), then lane r waits for rank
-// r's flag.  One wave: it occupies nothing a peer process on the same device needs in order to get there.  A wait that outlasts
+// Meeting point `seq`, EIGHT one-wave workgroups (one per XCD: workgroup -> XCD is blockIdx mod 8).  Every one of them first runs a
+// system-scope release fence -- a write-back of ITS XCD's L2 -- so that whatever the stream's earlier kernels wrote is at the memory side
+// (where a peer's read over xGMI is served) without relying on the scope the runtime gives a kernel's end-of-kernel release; workgroup 0
+// waits for the other seven (a device counter), raises this rank's flag to seq (release, system scope), and lane r waits for rank r's
+// flag.  One wave polls: it occupies nothing a peer process on the same device needs in order to get there.  A wait that outlasts
 // `timeout_ticks` (100 MHz) gives up and sets *status; the host reports it at the next call.
-__global__ void k_peer_meet(uint32_t* flags, int world, int rank, uint32_t seq, unsigned long long timeout_ticks, uint32_t* status) {
+__global__ void __launch_bounds__(64) k_peer_meet(uint32_t* flags, uint32_t* xcd_count, int world, int rank, uint32_t seq, unsigned long long timeout_ticks, uint32_t* status) {
   const int t = threadIdx.x;
-  if (t == rank) __hip_atomic_store(flags + (size_t)rank * kPeerFlagStride, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  __atomic_thread_fence(__ATOMIC_RELEASE);                       // (system scope: buffer_wbl2 sc0 sc1)
+  if (blockIdx.x != 0) {
+    if (t == 0) __hip_atomic_fetch_add(xcd_count, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  const unsigned long long t0 = wall_clock64();
+  if (t == 0) {
+    const uint32_t want = (gridDim.x - 1) * seq;                 // seq counts the meetings: every one adds gridDim.x - 1
+    unsigned spins = 0;
+    while ((int32_t)(__hip_atomic_load(xcd_count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+      __builtin_amdgcn_s_sleep(2);
+      if ((++spins & 255u) == 0 && wall_clock64() - t0 > timeout_ticks) { __hip_atomic_store(status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+    }
+    __hip_atomic_store(flags + (size_t)rank * kPeerFlagStride, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if (t < world && t != rank) {
-    const unsigned long long t0 = wall_clock64();
     unsigned spins = 0;
     while ((int32_t)(__hip_atomic_load(flags + (size_t)t * kPeerFlagStride, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
       __builtin_amdgcn_s_sleep(8);
@@ -354,31 +372,42 @@ __global__ void k_peer_meet(uint32_t* flags, int world, int rank, uint32_t seq, 
   }
 }
 
+// What a peer wrote is read past this device's caches: system-scope loads (sc0 sc1), 8 bytes per lane -- a line of a peer's buffer
+// that an earlier step left in this device's L2 is never served again, whatever scope the kernel's start-of-kernel acquire had.
+__device__ __forceinline__ float2 ld_peer8(const float* p) {
+  const unsigned long long v = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
+}
+__device__ __forceinline__ float ld_peer4(const float* p) {
+  return __uint_as_float(__hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+}
+
 struct PeerSrc { const float* p[kPeerMax]; };
 // out[i] = ((src0[i] + src1[i]) + src2[i]) + ...   -- rank order, the order of the shared-memory transport's sums
-__global__ void __launch_bounds__(256) k_peer_reduce(PeerSrc src, float* __restrict__ out, size_t n, int world, int vec) {
+template <int WORLD>      // 0: any world (run-time loop)
+__global__ void __launch_bounds__(256) k_peer_reduce(PeerSrc src, float* __restrict__ out, size_t n, int world_rt, int vec) {
+  const int world = WORLD ? WORLD : world_rt;
   const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nth = (size_t)gridDim.x * 256;
-  if (vec) {
-    const size_t n4 = n / 4;
-    for (size_t i = tid; i < n4; i += nth) {
-      float4 a = ((const float4*)src.p[0])[i];
-      for (int r = 1; r < world; ++r) {
-        const float4 b = ((const float4*)src.p[r])[i];
-        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-      }
-      ((float4*)out)[i] = a;
+  const size_t n2 = vec ? n / 2 : 0;
+  for (size_t i = tid; i < n2; i += nth) {
+    float2 v[WORLD ? WORLD : 1];
+    if (WORLD) {
+#pragma unroll
+      for (int r = 0; r < WORLD; ++r) v[r] = ld_peer8(src.p[r] + 2 * i);       // all the peers' loads in flight together
+      float2 a = v[0];
+#pragma unroll
+      for (int r = 1; r < WORLD; ++r) { a.x += v[r].x; a.y += v[r].y; }
+      ((float2*)out)[i] = a;
+    } else {
+      float2 a = ld_peer8(src.p[0] + 2 * i);
+      for (int r = 1; r < world; ++r) { const float2 b = ld_peer8(src.p[r] + 2 * i); a.x += b.x; a.y += b.y; }
+      ((float2*)out)[i] = a;
     }
-    for (size_t i = n4 * 4 + tid; i < n; i += nth) {
-      float a = src.p[0][i];
-      for (int r = 1; r < world; ++r) a += src.p[r][i];
-      out[i] = a;
-    }
-  } else {
-    for (size_t i = tid; i < n; i += nth) {
-      float a = src.p[0][i];
-      for (int r = 1; r < world; ++r) a += src.p[r][i];
-      out[i] = a;
-    }
+  }
+  for (size_t i = n2 * 2 + tid; i < n; i += nth) {
+    float a = ld_peer4(src.p[0] + i);
+    for (int r = 1; r < world; ++r) a += ld_peer4(src.p[r] + i);
+    out[i] = a;
   }
 }
 
@@ -400,12 +429,21 @@ __global__ void __launch_bounds__(256) k_peer_gather(GatherArgs g) {
   unsigned char* d = g.dst[i] + lo;
   const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nth = (size_t)gridDim.x * 256;
   size_t body = 0;
-  if ((((uintptr_t)s | (uintptr_t)d) & 15) == 0) {
-    body = nb / 16;
-    for (size_t k = tid; k < body; k += nth) ((uint4*)d)[k] = ((const uint4*)s)[k];
-    body *= 16;
+  if ((((uintptr_t)s | (uintptr_t)d) & 7) == 0) {
+    body = nb / 8;
+    size_t k = tid;
+    for (; k + 3 * nth < body; k += 4 * nth) {           // four loads in flight per lane
+      unsigned long long v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = __hip_atomic_load((const unsigned long long*)s + k + j * nth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ((unsigned long long*)d)[k + j * nth] = v[j];
+    }
+    for (; k < body; k += nth) ((unsigned long long*)d)[k] = __hip_atomic_load((const unsigned long long*)s + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    body *= 8;
   }
-  for (size_t k = body + tid; k < nb; k += nth) d[k] = s[k];
+  for (size_t k = body + tid; k < nb; k += nth)
+    d[k] = (unsigned char)(__hip_atomic_load((const unsigned*)((uintptr_t)(s + k) & ~(uintptr_t)3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >> (8 * ((uintptr_t)(s + k) & 3)));
 }
 
 // The allocation that holds `ptr`, mapped in every rank (found, or exchanged now: a COLLECTIVE the first time a buffer is used --
@@ -443,7 +481,7 @@ static int peer_meet(Comm* c) {
   if (c->status_host && *(volatile uint32_t*)c->status_host) { c->err = "a rank did not reach the exchange in time (direct peer transport)"; return -1; }
   if (c->world == 1) return 0;
   ++c->seq;
-  k_peer_meet<<<1, 64, 0, c->stream>>>(c->flags_dev, c->world, c->rank, c->seq, (unsigned long long)(c->peer_timeout_s * 1e8), c->status_dev);
+  k_peer_meet<<<8, 64, 0, c->stream>>>(c->flags_dev, c->xcd_count, c->world, c->rank, c->seq, (unsigned long long)(c->peer_timeout_s * 1e8), c->status_dev);
   return hipGetLastError() == hipSuccess ? 0 : (c->err = "launch of the meeting kernel failed", -1);
 }
 
@@ -455,10 +493,15 @@ static int peer_reduce_range(Comm* c, float* buf, size_t lo, size_t n) {
   const size_t off = (unsigned char*)(buf + lo) - reg->base;
   PeerSrc src;
   for (int k = 0; k < c->world; ++k) src.p[k] = (const float*)(reg->peer[k] + off);
-  const int vec = (off & 15) == 0;
-  const size_t work = vec ? (n + 3) / 4 : n;
+  const int vec = (off & 7) == 0;
+  const size_t work = vec ? (n + 1) / 2 : n;
   const int blocks = (int)std::min<size_t>(1024, std::max<size_t>(1, (work + 255) / 256));
-  k_peer_reduce<<<blocks, 256, 0, c->stream>>>(src, buf + lo, n, c->world, vec);
+  switch (c->world) {
+    case 2: k_peer_reduce<2><<<blocks, 256, 0, c->stream>>>(src, buf + lo, n, c->world, vec); break;
+    case 4: k_peer_reduce<4><<<blocks, 256, 0, c->stream>>>(src, buf + lo, n, c->world, vec); break;
+    case 8: k_peer_reduce<8><<<blocks, 256, 0, c->stream>>>(src, buf + lo, n, c->world, vec); break;
+    default: k_peer_reduce<0><<<blocks, 256, 0, c->stream>>>(src, buf + lo, n, c->world, vec); break;
+  }
   return hipGetLastError() == hipSuccess ? 0 : (c->err = "launch of the reduce kernel failed", -1);
 }
 
@@ -479,7 +522,7 @@ static int peer_gather(Comm* c, void* const* bufs, const size_t* stride, const s
     largest = std::max(largest, stride[i]);
   }
   if (c->world == 1 || largest == 0) return 0;
-  const int bx = (int)std::min<size_t>(64, std::max<size_t>(1, (largest / 16 + 255) / 256));
+  const int bx = (int)std::min<size_t>(64, std::max<size_t>(1, (largest / 32 + 255) / 256));
   k_peer_gather<<<dim3(bx, n * c->world), 256, 0, c->stream>>>(g);
   return hipGetLastError() == hipSuccess ? 0 : (c->err = "launch of the gather kernel failed", -1);
 }
