@@ -1416,6 +1416,9 @@ void launch_scale_update(int prec, Scales* sc, const float* wmax_blocks, int n_b
 // sums in the same order, the same rule(): bit for bit the parameters of the two-launch form (tests/test_gpu_fused_update.py).
 // The W -> half scale that k_scale_update would have computed between the two launches is derived by every parameter
 // workgroup for itself from the previous update's per-block maxima (4-8 KB out of L2, while its slab loads fly).
+// (Round 4, residency: 76 registers = six workgroups per CU resident, the eight of a CU in two uneven rounds.  A one-element form at 57
+// registers with all eight resident is SLOWER (23.7 against 21.8 us), so is every cap below six (LDS-limited 5 / 4 / 3 per CU: 23.8-25 /
+// 24.7 / 29.5 us); half or a quarter of the workgroups with two / four elements per thread: the same 21.3-22.6 us.)
 template <typename T>
 __global__ __launch_bounds__(256) void k_reduce_sgd(FusedUpdArgs fa) {
   const ReduceArgs& a = fa.r;
