@@ -114,14 +114,14 @@ def test_two_ranks_on_one_gpu_match_the_global_batch():
     assert np.array_equal(out[False][0], out[True][0]) and np.array_equal(out[False][1], out[True][1])
 
 
-@pytest.mark.parametrize("world", [2, 8])
-def test_sharded_update_is_the_synchronous_update_bit_for_bit(world):
+@pytest.mark.parametrize("world,inline", [(2, "1"), (2, "0"), (8, "1")])
+def test_sharded_update_is_the_synchronous_update_bit_for_bit(world, inline):
     """reduce-scatter -> the solver's rule on this rank's D / world rows -> all-gather of the 16-bit copy, the bias and the per-block
     maxima (vv_comm_schedule 2), on `world` processes sharing the one GPU: every rank ends with the parameters, the bias and the history
     (gathered by the collective vv_params_get) that the synchronous all-reduce schedule gives -- the shard's sums are the all-reduce's
     sums in the same rank order, the rule is elementwise, the W -> half scale comes from the same maxima -- bit for bit, on every rank."""
     sync = _run_world(world, False)
-    shard = _run_world(world, "sharded")
+    shard = _run_world(world, "sharded", env={"VV_COMM_INLINE": inline})      # 1 (default): in the compute stream; 0: on the communication stream, one gate
     for r in range(world):
         for k in range(3):
             assert np.array_equal(shard[r][k], shard[0][k]), "ranks diverged (rank %d, array %d)" % (r, k)
@@ -163,6 +163,9 @@ def test_gated_forward_waits_for_a_slow_exchange():
     res = _run_world(1, True, transport="rccl", env={"VV_COMM_TEST_DELAY_US": "300"})
     assert np.array_equal(res[0][0], W0) and np.array_equal(res[0][1], b0) and np.array_equal(res[0][2], h0)
     # the sharded schedule's one gate (in front of the forward GEMM's first W tile), the exchange held 300 us
+    res = _run_world(1, "sharded", transport="rccl", env={"VV_COMM_TEST_DELAY_US": "300", "VV_COMM_INLINE": "0"})
+    assert np.array_equal(res[0][0], W0) and np.array_equal(res[0][1], b0) and np.array_equal(res[0][2], h0)
+    # ... and the default form of the sharded schedule (its three steps in the compute stream, no gate), held the same way
     res = _run_world(1, "sharded", transport="rccl", env={"VV_COMM_TEST_DELAY_US": "300"})
     assert np.array_equal(res[0][0], W0) and np.array_equal(res[0][1], b0) and np.array_equal(res[0][2], h0)
 

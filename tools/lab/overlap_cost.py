@@ -46,5 +46,5 @@ if __name__ == "__main__":
         steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
         for rep in range(2):
             for mode, env in (("none", {}), ("sync", {}), ("overlap", {}), ("overlap_chunks2", {"VV_COMM_CHUNKS": "2"}), ("overlap_chunks4", {"VV_COMM_CHUNKS": "4"}),
-                              ("sharded", {}), ("sharded", {"VV_COMM_TEST_DELAY_US": "60"}), ("overlap", {"VV_COMM_TEST_DELAY_US": "20"}), ("overlap_chunks2", {"VV_COMM_CHUNKS": "2", "VV_COMM_TEST_DELAY_US": "30"}), ("overlap_nogate", {"VV_COMM_GATE": "0"})):
+                              ("sharded", {}), ("sharded_comm_stream", {"VV_COMM_INLINE": "0"}), ("sharded", {"VV_COMM_TEST_DELAY_US": "60"}), ("sharded_comm_stream", {"VV_COMM_INLINE": "0", "VV_COMM_TEST_DELAY_US": "60"}), ("overlap", {"VV_COMM_TEST_DELAY_US": "20"}), ("overlap_chunks2", {"VV_COMM_CHUNKS": "2", "VV_COMM_TEST_DELAY_US": "30"}), ("overlap_nogate", {"VV_COMM_GATE": "0"})):
                 subprocess.run([sys.executable, os.path.abspath(__file__), mode, str(steps)], env=dict(os.environ, **env))

@@ -141,6 +141,7 @@ static int create_init(vv_ctx* c) {
   if (const char* v = opt_env("VV_DEDUP")) c->dedup = atoi(v) != 0;
   if (const char* v = opt_env("VV_FUSE_UPDATE")) c->fuse_update = atoi(v) != 0;
   if (const char* v = opt_env("VV_COMM_GATE")) c->comm_gate = atoi(v) != 0;
+  if (const char* v = opt_env("VV_COMM_INLINE")) c->comm_inline = atoi(v) != 0;
   if (const char* v = opt_env("VV_COMM_TEST_DELAY_US")) c->comm_test_delay_us = atoi(v);
   // lab switches (-DVV_LAB builds only; several of them produce WRONG results by design)
   if (const char* v = lab_env("VV_GEMM_VARIANT")) c->ko.gemm_variant = atoi(v);
@@ -282,6 +283,7 @@ int vv_set_option(vv_ctx* c, const char* name, double value) {
   if (n == "wgrad_tr") { c->ko.wgrad_tr = iv != 0; return VV_OK; }
   if (n == "score_stream") { c->ko.score_stream = iv; return VV_OK; }
   if (n == "comm_gate") { c->comm_gate = iv != 0; return VV_OK; }
+  if (n == "comm_inline") { c->comm_inline = iv != 0; return VV_OK; }
   if (n == "comm_chunks") { c->n_chunks = std::max(1, std::min(W_CHUNKS_MAX, iv)); return VV_OK; }
   if (n == "comm_test_delay_us") { c->comm_test_delay_us = iv; return VV_OK; }
 #ifdef VV_LAB
@@ -304,6 +306,7 @@ int vv_get_option(vv_ctx* c, const char* name, double* value) {
   else if (n == "wgrad_tr") *value = c->ko.wgrad_tr;
   else if (n == "score_stream") *value = c->ko.score_stream;
   else if (n == "comm_gate") *value = c->comm_gate;
+  else if (n == "comm_inline") *value = c->comm_inline;
   else if (n == "comm_chunks") *value = c->n_chunks;
   else if (n == "comm_test_delay_us") *value = c->comm_test_delay_us;
   else return fail(VV_ERR_ARG, "vv_get_option: unknown option '%s'", name);
@@ -1207,14 +1210,20 @@ int vv_apply_update(vv_ctx* c, const vv_step_cfg* cfg) {
     // of W (4 MB instead of the all-reduce's second 8.4 MB), the bias, the per-block maxima the next W -> half scale comes from  ->
     // publish.  3/4 of the all-reduce's wire bytes.  The next forward GEMM is gated on the one flag (it starts, and waits in front of
     // its first W tile); the fp32 master W and the history stay sharded until vv_params_get gathers them.
-    hipStream_t cs = vv::comm_stream(c->comm);
+    // comm_inline (default): this schedule has ONE gate, in front of the GEMM's first W tile -- nothing of the exchange hides behind the
+    // GEMM, and the second stream costs its hand-off chain (event -> wake -> ... -> publish: + 17 us on one rank).  So the
+    // three steps are queued on the COMPUTE stream itself, in order, and the next forward GEMM is the plain kernel (with its sibling lead).
+    const bool inl = c->comm_inline;
+    hipStream_t cs = inl ? c->stream : vv::comm_stream(c->comm);
     const int world = vv::comm_world(c->comm), rank = vv::comm_rank(c->comm);
     const int rps = c->D / world;
     const size_t shard_f = (size_t)rps * c->F + rps;
-    HIPCHK(hipEventRecord(c->ev_chunk, c->stream));
-    const int32_t useq = ++c->upd_seq;
-    if (c->comm_test_delay_us > 0) { HIPCHK(hipStreamWaitEvent(cs, c->ev_chunk, 0)); launch_delay(c->comm_test_delay_us, cs); }
-    if (vv::comm_reduce_scatter(c->comm, c->grads, shard_f, c->ev_chunk)) return fail(VV_ERR_HIP, "reduce-scatter: %s", vv::comm_error(c->comm));
+    int32_t useq = c->upd_seq;
+    if (!inl) { HIPCHK(hipEventRecord(c->ev_chunk, c->stream)); useq = ++c->upd_seq; }
+    if (c->comm_test_delay_us > 0) { if (!inl) HIPCHK(hipStreamWaitEvent(cs, c->ev_chunk, 0)); launch_delay(c->comm_test_delay_us, cs); }
+    struct StreamScope { vv::Comm* k; ~StreamScope() { vv::comm_use_stream(k, nullptr); } } scope{c->comm};
+    vv::comm_use_stream(c->comm, inl ? c->stream : nullptr);
+    if (vv::comm_reduce_scatter(c->comm, c->grads, shard_f, inl ? nullptr : c->ev_chunk)) return fail(VV_ERR_HIP, "reduce-scatter: %s", vv::comm_error(c->comm));
     const int nb = SGD_BLOCKS / world;
     SgdArgs g = a;                                    // the shard as a parameter matrix of its own: rps rows, its gradient buffer [dW rows | db entries]
     g.D = rps;
@@ -1228,9 +1237,11 @@ int vv_apply_update(vv_ctx* c, const vv_step_cfg* cfg) {
     void* bufs[3] = {c->Wh, c->b, wmax_new};
     const size_t sbytes[3] = {(size_t)rps * c->Fp * 2, (size_t)rps * 4, (size_t)nb * 4};
     if (vv::comm_allgather(c->comm, bufs, sbytes, 3)) return fail(VV_ERR_HIP, "all-gather: %s", vv::comm_error(c->comm));
-    launch_publish(c->w_gate, useq, cs);
-    if (vv::comm_record_done(c->comm)) return fail(VV_ERR_HIP, "all-gather: %s", vv::comm_error(c->comm));
-    c->grads_pending = false; c->upd_inflight = true; c->upd_unjoined = false;
+    if (!inl) {
+      launch_publish(c->w_gate, useq, cs);
+      if (vv::comm_record_done(c->comm)) return fail(VV_ERR_HIP, "all-gather: %s", vv::comm_error(c->comm));
+    }
+    c->grads_pending = false; c->upd_inflight = !inl; c->upd_unjoined = false;
     c->params_partial = world > 1;
     c->scale_pending = true;
     c->wmax_cur = 1 - c->wmax_cur; c->wmax_n = nb * world;

@@ -109,6 +109,7 @@ static_assert(sizeof(PeerSlot) <= 256, "handle table slot");
 struct Comm {
   int world = 1, rank = 0, transport = VV_COMM_RCCL;
   hipStream_t stream = nullptr;                 // communication stream
+  hipStream_t cur = nullptr;                    // where the collectives are queued: the communication stream, or the caller's (comm_use_stream)
   hipEvent_t ev_ready = nullptr, ev_done = nullptr;
   // RCCL
   void* dl = nullptr; NcclComm nccl = nullptr;
@@ -190,6 +191,7 @@ Comm* comm_create(int world, int rank, const char* id_path, int transport, size_
   int prio_lo = 0, prio_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
   if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) != hipSuccess) return fail("hipStreamCreate failed");
+  c->cur = c->stream;
   if (hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
   const double timeout_s = getenv("VV_COMM_TIMEOUT") ? atof(getenv("VV_COMM_TIMEOUT")) : 120.0;
@@ -481,7 +483,7 @@ static int peer_meet(Comm* c) {
   if (c->status_host && *(volatile uint32_t*)c->status_host) { c->err = "a rank did not reach the exchange in time (direct peer transport)"; return -1; }
   if (c->world == 1) return 0;
   ++c->seq;
-  k_peer_meet<<<8, 64, 0, c->stream>>>(c->flags_dev, c->xcd_count, c->world, c->rank, c->seq, (unsigned long long)(c->peer_timeout_s * 1e8), c->status_dev);
+  k_peer_meet<<<8, 64, 0, c->cur>>>(c->flags_dev, c->xcd_count, c->world, c->rank, c->seq, (unsigned long long)(c->peer_timeout_s * 1e8), c->status_dev);
   return hipGetLastError() == hipSuccess ? 0 : (c->err = "launch of the meeting kernel failed", -1);
 }
 
@@ -497,10 +499,10 @@ static int peer_reduce_range(Comm* c, float* buf, size_t lo, size_t n) {
   const size_t work = vec ? (n + 1) / 2 : n;
   const int blocks = (int)std::min<size_t>(1024, std::max<size_t>(1, (work + 255) / 256));
   switch (c->world) {
-    case 2: k_peer_reduce<2><<<blocks, 256, 0, c->stream>>>(src, buf + lo, n, c->world, vec); break;
-    case 4: k_peer_reduce<4><<<blocks, 256, 0, c->stream>>>(src, buf + lo, n, c->world, vec); break;
-    case 8: k_peer_reduce<8><<<blocks, 256, 0, c->stream>>>(src, buf + lo, n, c->world, vec); break;
-    default: k_peer_reduce<0><<<blocks, 256, 0, c->stream>>>(src, buf + lo, n, c->world, vec); break;
+    case 2: k_peer_reduce<2><<<blocks, 256, 0, c->cur>>>(src, buf + lo, n, c->world, vec); break;
+    case 4: k_peer_reduce<4><<<blocks, 256, 0, c->cur>>>(src, buf + lo, n, c->world, vec); break;
+    case 8: k_peer_reduce<8><<<blocks, 256, 0, c->cur>>>(src, buf + lo, n, c->world, vec); break;
+    default: k_peer_reduce<0><<<blocks, 256, 0, c->cur>>>(src, buf + lo, n, c->world, vec); break;
   }
   return hipGetLastError() == hipSuccess ? 0 : (c->err = "launch of the reduce kernel failed", -1);
 }
@@ -523,7 +525,7 @@ static int peer_gather(Comm* c, void* const* bufs, const size_t* stride, const s
   }
   if (c->world == 1 || largest == 0) return 0;
   const int bx = (int)std::min<size_t>(64, std::max<size_t>(1, (largest / 32 + 255) / 256));
-  k_peer_gather<<<dim3(bx, n * c->world), 256, 0, c->stream>>>(g);
+  k_peer_gather<<<dim3(bx, n * c->world), 256, 0, c->cur>>>(g);
   return hipGetLastError() == hipSuccess ? 0 : (c->err = "launch of the gather kernel failed", -1);
 }
 
@@ -540,9 +542,9 @@ int comm_allreduce_inline(Comm* c, float* buf, size_t n, hipStream_t stream) {
 }
 
 int comm_allreduce(Comm* c, float* buf, size_t off, size_t n, hipEvent_t after) {
-  if (after && hipStreamWaitEvent(c->stream, after, 0) != hipSuccess) { c->err = "hipStreamWaitEvent failed"; return -1; }
+  if (after && hipStreamWaitEvent(c->cur, after, 0) != hipSuccess) { c->err = "hipStreamWaitEvent failed"; return -1; }
   if (c->transport == VV_COMM_RCCL) {
-    const int rc = c->AllReduce(buf + off, buf + off, n, kNcclFloat32, kNcclSum, c->nccl, c->stream);
+    const int rc = c->AllReduce(buf + off, buf + off, n, kNcclFloat32, kNcclSum, c->nccl, c->cur);
     if (rc != 0) { c->err = std::string("ncclAllReduce: ") + (c->ErrStr ? c->ErrStr(rc) : "error"); return -1; }
   } else if (c->transport == VV_COMM_PEER) {
     // reduce-scatter + all-gather of the range, both direct: rank r sums slice r (a multiple of four floats; the last one may be
@@ -558,8 +560,8 @@ int comm_allreduce(Comm* c, float* buf, size_t off, size_t n, hipEvent_t after) 
     const double timeout_s = getenv("VV_COMM_TIMEOUT") ? atof(getenv("VV_COMM_TIMEOUT")) : 120.0;
     float* slabs = (float*)((unsigned char*)c->shm + shm_hdr_bytes());
     float* mine = slabs + (size_t)c->rank * c->stage_floats + off;
-    if (hipMemcpyAsync(c->stage + off, buf + off, n * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-        hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "device-to-host copy failed"; return -1; }
+    if (hipMemcpyAsync(c->stage + off, buf + off, n * sizeof(float), hipMemcpyDeviceToHost, c->cur) != hipSuccess ||
+        hipStreamSynchronize(c->cur) != hipSuccess) { c->err = "device-to-host copy failed"; return -1; }
     memcpy(mine, c->stage + off, n * sizeof(float));
     if (!shm_barrier(c, timeout_s)) { c->err = "all-reduce barrier timed out (a rank is missing)"; return -1; }
     float* out = c->stage + off;
@@ -569,18 +571,18 @@ int comm_allreduce(Comm* c, float* buf, size_t off, size_t n, hipEvent_t after) 
       for (size_t i = 0; i < n; ++i) out[i] += s[i];
     }
     if (!shm_barrier(c, timeout_s)) { c->err = "all-reduce barrier timed out (a rank is missing)"; return -1; }
-    if (hipMemcpyAsync(buf + off, out, n * sizeof(float), hipMemcpyHostToDevice, c->stream) != hipSuccess) { c->err = "host-to-device copy failed"; return -1; }
+    if (hipMemcpyAsync(buf + off, out, n * sizeof(float), hipMemcpyHostToDevice, c->cur) != hipSuccess) { c->err = "host-to-device copy failed"; return -1; }
   }
-  if (hipEventRecord(c->ev_done, c->stream) != hipSuccess) { c->err = "hipEventRecord failed"; return -1; }
+  if (hipEventRecord(c->ev_done, c->cur) != hipSuccess) { c->err = "hipEventRecord failed"; return -1; }
   return 0;
 }
 
 // ---- the sharded update's two collectives
 int comm_reduce_scatter(Comm* c, float* buf, size_t shard, hipEvent_t after) {
-  if (after && hipStreamWaitEvent(c->stream, after, 0) != hipSuccess) { c->err = "hipStreamWaitEvent failed"; return -1; }
+  if (after && hipStreamWaitEvent(c->cur, after, 0) != hipSuccess) { c->err = "hipStreamWaitEvent failed"; return -1; }
   if (c->transport == VV_COMM_RCCL) {
     if (!c->ReduceScatter) { c->err = "librccl has no ncclReduceScatter"; return -1; }
-    const int rc = c->ReduceScatter(buf, buf + (size_t)c->rank * shard, shard, kNcclFloat32, kNcclSum, c->nccl, c->stream);   // in place: recv = send + rank * count
+    const int rc = c->ReduceScatter(buf, buf + (size_t)c->rank * shard, shard, kNcclFloat32, kNcclSum, c->nccl, c->cur);   // in place: recv = send + rank * count
     if (rc != 0) { c->err = std::string("ncclReduceScatter: ") + (c->ErrStr ? c->ErrStr(rc) : "error"); return -1; }
     return 0;
   }
@@ -598,8 +600,8 @@ int comm_reduce_scatter(Comm* c, float* buf, size_t shard, hipEvent_t after) {
   const size_t n = shard * c->world;
   if (n > c->stage_floats) { c->err = "reduce-scatter larger than the communicator's buffer"; return -1; }
   float* slabs = (float*)((unsigned char*)c->shm + shm_hdr_bytes());
-  if (hipMemcpyAsync(c->stage, buf, n * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-      hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "device-to-host copy failed"; return -1; }
+  if (hipMemcpyAsync(c->stage, buf, n * sizeof(float), hipMemcpyDeviceToHost, c->cur) != hipSuccess ||
+      hipStreamSynchronize(c->cur) != hipSuccess) { c->err = "device-to-host copy failed"; return -1; }
   memcpy(slabs + (size_t)c->rank * c->stage_floats, c->stage, n * sizeof(float));
   if (!shm_barrier(c, timeout_s)) { c->err = "reduce-scatter barrier timed out (a rank is missing)"; return -1; }
   const size_t off = (size_t)c->rank * shard;
@@ -610,7 +612,7 @@ int comm_reduce_scatter(Comm* c, float* buf, size_t shard, hipEvent_t after) {
     for (size_t i = 0; i < shard; ++i) out[i] += s[i];
   }
   if (!shm_barrier(c, timeout_s)) { c->err = "reduce-scatter barrier timed out (a rank is missing)"; return -1; }
-  if (hipMemcpyAsync(buf + off, out, shard * sizeof(float), hipMemcpyHostToDevice, c->stream) != hipSuccess) { c->err = "host-to-device copy failed"; return -1; }
+  if (hipMemcpyAsync(buf + off, out, shard * sizeof(float), hipMemcpyHostToDevice, c->cur) != hipSuccess) { c->err = "host-to-device copy failed"; return -1; }
   return 0;
 }
 
@@ -621,7 +623,7 @@ int comm_allgather(Comm* c, void* const* bufs, const size_t* shard_bytes, int n,
     int rc = 0;
     for (int i = 0; i < n && rc == 0; ++i) {
       unsigned char* b = (unsigned char*)bufs[i];
-      rc = c->AllGather(b + (size_t)c->rank * shard_bytes[i], b, shard_bytes[i], kNcclInt8, c->nccl, c->stream);            // in place: send = recv + rank * count
+      rc = c->AllGather(b + (size_t)c->rank * shard_bytes[i], b, shard_bytes[i], kNcclInt8, c->nccl, c->cur);            // in place: send = recv + rank * count
     }
     if (n > 1 && c->GroupEnd) { const int rg = c->GroupEnd(); if (rc == 0) rc = rg; }
     if (rc != 0) { c->err = std::string("ncclAllGather: ") + (c->ErrStr ? c->ErrStr(rc) : "error"); return -1; }
@@ -644,17 +646,17 @@ int comm_allgather(Comm* c, void* const* bufs, const size_t* shard_bytes, int n,
     const size_t sb = shard_bytes[i];
     if (sb > slab_bytes) { c->err = "all-gather shard larger than the communicator's buffer"; return -1; }
     unsigned char* b = (unsigned char*)bufs[i];
-    if (hipMemcpyAsync(c->stage, b + (size_t)c->rank * sb, sb, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-        hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "device-to-host copy failed"; return -1; }
+    if (hipMemcpyAsync(c->stage, b + (size_t)c->rank * sb, sb, hipMemcpyDeviceToHost, c->cur) != hipSuccess ||
+        hipStreamSynchronize(c->cur) != hipSuccess) { c->err = "device-to-host copy failed"; return -1; }
     memcpy(slabs + (size_t)c->rank * slab_bytes, c->stage, sb);
     if (!shm_barrier(c, timeout_s)) { c->err = "all-gather barrier timed out (a rank is missing)"; return -1; }
     for (int r = 0; r < c->world; ++r) {
       if (r == c->rank) continue;
       // (pageable source: the copy is staged by the runtime before the call returns for sizes like these; the barrier below keeps the
       // slab intact until every rank has issued its copies and synchronised)
-      if (hipMemcpyAsync(b + (size_t)r * sb, slabs + (size_t)r * slab_bytes, sb, hipMemcpyHostToDevice, c->stream) != hipSuccess) { c->err = "host-to-device copy failed"; return -1; }
+      if (hipMemcpyAsync(b + (size_t)r * sb, slabs + (size_t)r * slab_bytes, sb, hipMemcpyHostToDevice, c->cur) != hipSuccess) { c->err = "host-to-device copy failed"; return -1; }
     }
-    if (hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "host-to-device copy failed"; return -1; }
+    if (hipStreamSynchronize(c->cur) != hipSuccess) { c->err = "host-to-device copy failed"; return -1; }
     if (!shm_barrier(c, timeout_s)) { c->err = "all-gather barrier timed out (a rank is missing)"; return -1; }
   }
   return 0;
@@ -662,6 +664,7 @@ int comm_allgather(Comm* c, void* const* bufs, const size_t* shard_bytes, int n,
 
 hipEvent_t comm_done_event(Comm* c) { return c->ev_done; }
 hipStream_t comm_stream(Comm* c) { return c->stream; }
+void comm_use_stream(Comm* c, hipStream_t s) { c->cur = s ? s : c->stream; }
 int comm_record_done(Comm* c) {
   if (hipEventRecord(c->ev_done, c->stream) != hipSuccess) { c->err = "hipEventRecord failed"; return -1; }
   return 0;

@@ -25,6 +25,8 @@ int comm_reduce_scatter(Comm* c, float* buf, size_t shard_floats, hipEvent_t aft
 int comm_allgather(Comm* c, void* const* bufs, const size_t* shard_bytes, int n, int fence_after = 0);
 hipEvent_t comm_done_event(Comm* c);
 hipStream_t comm_stream(Comm* c);          // the communication stream (the overlapped update queues its kernels there)
+void comm_use_stream(Comm* c, hipStream_t s);   // the collectives called from now on are queued on s (the caller's stream: no second stream, no
+                                                // events between the two); nullptr: back to the communication stream
 int comm_record_done(Comm* c);             // records comm_done_event behind everything queued on the communication stream
 const char* comm_error(Comm* c);
 bool comm_failed(Comm* c);                 // a wait inside the exchange gave up (direct peer transport: a rank is missing); comm_error says so

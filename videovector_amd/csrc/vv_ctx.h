@@ -136,6 +136,7 @@ struct vv_ctx {
   vv::KernelOpts ko;                // which kernels the launchers pick (vv_internal.h)
   bool fuse_update = true;          // "fuse_update" / VV_FUSE_UPDATE=0: reduce at the end of every backward pass, update apart
   bool comm_gate = true;            // "comm_gate" / VV_COMM_GATE=0: the overlapped update never gates the forward GEMM (the stream joins)
+  bool comm_inline = true;                  // option "comm_inline" (VV_COMM_INLINE): the sharded update queued on the compute stream itself (no second stream, no gate)
   int comm_test_delay_us = 0;       // "comm_test_delay_us" / VV_COMM_TEST_DELAY_US: TEST HOOK -- the communication stream held this long per chunk
   // (lab) -- settable in a -DVV_LAB build only
   bool guard_proactive = true;      // VV_GUARD_PROACTIVE=0: the repeat form of the gradient-scale guard on the segment-wise path too
