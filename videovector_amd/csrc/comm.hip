@@ -534,10 +534,31 @@ static int peer_gather(Comm* c, void* const* bufs, const size_t* stride, const s
 // The collective queued directly on the caller's stream (RCCL only): no second stream, no events.  For the synchronous
 // schedule, where nothing runs beside the all-reduce anyway, this saves the two stream joins (~6 us of stream time each).
 // Returns 1 when the transport cannot do that (the caller then uses comm_allreduce), 0 on success, -1 on error.
+static int peer_allreduce(Comm* c, float* buf, size_t off, size_t n);
 int comm_allreduce_inline(Comm* c, float* buf, size_t n, hipStream_t stream) {
+  if (c->transport == VV_COMM_PEER) {           // the direct exchange's kernels queued on the caller's stream
+    hipStream_t keep = c->cur;
+    c->cur = stream;
+    const int rc = peer_allreduce(c, buf, 0, n);
+    c->cur = keep;
+    return rc;
+  }
   if (c->transport != VV_COMM_RCCL) return 1;
   const int rc = c->AllReduce(buf, buf, n, kNcclFloat32, kNcclSum, c->nccl, stream);
   if (rc != 0) { c->err = std::string("ncclAllReduce: ") + (c->ErrStr ? c->ErrStr(rc) : "error"); return -1; }
+  return 0;
+}
+
+// VV_COMM_PEER: reduce-scatter + all-gather of the range, both direct: rank r sums slice r (a multiple of four floats; the last one may
+// be short), the ranks meet, every rank pulls the other slices; a third meeting keeps a fast rank's NEXT gradients out of a buffer a slow
+// rank is still pulling from
+static int peer_allreduce(Comm* c, float* buf, size_t off, size_t n) {
+  if (!peer_reg(c, buf)) return -1;
+  const size_t per = ((n + c->world - 1) / c->world + 3) / 4 * 4;
+  const size_t lo = std::min(n, (size_t)c->rank * per), hi = std::min(n, lo + per);
+  void* bufs[1] = {buf + off};
+  const size_t stride[1] = {per * sizeof(float)}, total[1] = {n * sizeof(float)};
+  if (peer_meet(c) || peer_reduce_range(c, buf, off + lo, hi - lo) || peer_meet(c) || peer_gather(c, bufs, stride, total, 1) || peer_meet(c)) return -1;
   return 0;
 }
 
@@ -547,15 +568,7 @@ int comm_allreduce(Comm* c, float* buf, size_t off, size_t n, hipEvent_t after) 
     const int rc = c->AllReduce(buf + off, buf + off, n, kNcclFloat32, kNcclSum, c->nccl, c->cur);
     if (rc != 0) { c->err = std::string("ncclAllReduce: ") + (c->ErrStr ? c->ErrStr(rc) : "error"); return -1; }
   } else if (c->transport == VV_COMM_PEER) {
-    // reduce-scatter + all-gather of the range, both direct: rank r sums slice r (a multiple of four floats; the last one may be
-    // short), the ranks meet, every rank pulls the other slices; a third meeting keeps a fast rank's NEXT gradients out of a buffer a
-    // slow rank is still pulling from
-    if (!peer_reg(c, buf)) return -1;
-    const size_t per = ((n + c->world - 1) / c->world + 3) / 4 * 4;
-    const size_t lo = std::min(n, (size_t)c->rank * per), hi = std::min(n, lo + per);
-    void* bufs[1] = {buf + off};
-    const size_t stride[1] = {per * sizeof(float)}, total[1] = {n * sizeof(float)};
-    if (peer_meet(c) || peer_reduce_range(c, buf, off + lo, hi - lo) || peer_meet(c) || peer_gather(c, bufs, stride, total, 1) || peer_meet(c)) return -1;
+    if (peer_allreduce(c, buf, off, n)) return -1;
   } else {
     const double timeout_s = getenv("VV_COMM_TIMEOUT") ? atof(getenv("VV_COMM_TIMEOUT")) : 120.0;
     float* slabs = (float*)((unsigned char*)c->shm + shm_hdr_bytes());
