@@ -349,7 +349,9 @@ def main():
     want_peer = args.comm == "peer"                 # the library's communicator, over its direct peer transport
     if want_peer:
         args.comm = "lib"
-    mode = args.allreduce if args.allreduce != "auto" else (("overlap" if args.comm == "lib" else "sync") if world > 1 else "none")
+    # auto: the library's communicator overlaps the exchange with the next forward GEMM (RCCL's rings: wire time worth hiding); over the
+    # direct peer transport the short exchange runs sharded in the compute stream; torch's collective is synchronous
+    mode = args.allreduce if args.allreduce != "auto" else ((("sharded" if want_peer else "overlap") if args.comm == "lib" else "sync") if world > 1 else "none")
     if world == 1 and mode in ("sync", "overlap", "sharded"):
         mode = "none"
     comm = args.comm if mode in ("sync", "overlap", "sharded") else "none"

@@ -13,12 +13,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("mode", ["sync", "overlap", "sharded", "torch-sync", "stale", "peer-sharded", "peer-overlap"])
+@pytest.mark.parametrize("mode", ["sync", "overlap", "sharded", "torch-sync", "stale", "peer-sharded", "peer-overlap", "peer-auto"])
 def test_bench_two_ranks_on_one_device(mode):
     env = dict(os.environ, VV_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    port = "295%02d" % {"sync": 17, "overlap": 19, "torch-sync": 21, "stale": 23, "sharded": 25, "peer-sharded": 27, "peer-overlap": 29}[mode]
+    port = "295%02d" % {"sync": 17, "overlap": 19, "torch-sync": 21, "stale": 23, "sharded": 25, "peer-sharded": 27, "peer-overlap": 29, "peer-auto": 37}[mode]
     extra = ["--comm", "torch"] if mode == "torch-sync" else (["--comm", "peer"] if mode.startswith("peer-") else [])   # peer: the one-shot direct exchange (hipIpc mappings)
-    ar = "sync" if mode == "torch-sync" else mode.replace("peer-", "")
+    ar = "sync" if mode == "torch-sync" else mode.replace("peer-", "")          # (peer-auto: --allreduce auto = sharded over this transport)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"),
                         "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
@@ -35,6 +35,8 @@ def test_bench_two_ranks_on_one_device(mode):
         assert d["value_scope"].startswith("end to end") and "shared-memory ring" in d["config"]["sampler"]
         assert ("torch" in d["config"]["comm"]) == (mode == "torch-sync")
         assert ("direct peer exchange" in d["config"]["comm"]) == mode.startswith("peer-")
+        if mode == "peer-auto":
+            assert "reduce-scatter" in d["config"]["allreduce"]
     else:
         assert d["gpu_path_only"]["value"] > 0 and d["step_ms_stats"]["n"] == 4      # 4 steps (kernels are individually timed on every 5th step at the earliest)
 
