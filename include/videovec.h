@@ -61,6 +61,7 @@ int vv_set_dedup(vv_ctx* ctx, int on);
  * per-object configuration, not globals.
  *   "dedup" (VV_DEDUP, 1)            row de-duplication, as vv_set_dedup
  *   "seg_bwd" (VV_SEG_BWD, 1)        segment-wise backward of de-duplicated batches (0: per-instance gradient rows + their sums)
+ *   "drop_dedup" (VV_DROP_DEDUP, 1)  dropout on the de-duplicated path where the kernels carry per-instance masks (D = 512); 0: dense
  *   "fuse_update" (VV_FUSE_UPDATE, 1) reduction of the split-K partials and the solver update in one launch (0: two launches)
  *   "fwd_lead" (VV_FWD_LEAD, 1)      the forward GEMM's sibling lead
  *   "wgrad_tr" (VV_WGRAD_TR, 1)      transposed LDS reads in the weight-gradient GEMM (0: the first-round kernel)

@@ -209,6 +209,59 @@ def test_dropout_with_explicit_mask_and_options(vv, oracle, prec):
     check(got, ref, TOL[prec], "dropout/%s" % prec)
 
 
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+def test_dropout_on_the_deduplicated_path_matches_oracle(vv, oracle, prec):
+    """drop2 sits behind fc7 + ReLU (mednet_embedding_train.prototxt:190-230), so equal table rows share their projection and only the mask
+    is per instance: at D = 512 dropout rides the de-duplicated path (k_score_fwd masks every instance's row, k_seg_bwd sums the
+    mask-weighted terms per distinct row).  Explicit mask, rows that repeat inside and across items, every blob against the oracle."""
+    B, C, Nn, F, D = 16, 5, 7, 256, 512
+    ds, table, idx, W, b = make_case(19, 30, B, C, Nn, F, D, wstd=0.01)
+    rng = np.random.default_rng(3)
+    idx = rng.integers(0, 60, size=(B, C + Nn)).astype(np.int32)          # 192 instances of <= 60 rows: segments of several instances
+    mask = (rng.random(((C + Nn) * B, D)) > 0.6).astype(np.uint8)
+    coeff = np.array([0.4, 0.3, 0.2, 0.1], np.float32)
+    eng, _, got, ref = run_both(vv, oracle, prec, table, idx, W, b, C, Nn, dropout_ratio=0.6, dropout_mask=mask, ctx_coeff=coeff,
+                                loss_weight=0.7, global_count=4 * B * Nn, margin=1.5)
+    rows, uniq = eng.dedup_stats()
+    assert rows == B * (C + Nn) and uniq == len(np.unique(idx)) < rows, "the de-duplicated path did not run"
+    check(got, ref, TOL[prec], "dropout-dedup/%s" % prec)
+    # the same step with the switch off: dense execution, same mask -> the same blobs to rounding
+    eng2 = vv.Engine(0, prec)
+    eng2.set_option("drop_dedup", 0)
+    eng2.table_set(table); eng2.params_set(W, b)
+    cfg = vv.StepConfig(B, C, Nn, dropout_ratio=0.6, dropout_mask=mask, ctx_coeff=coeff, loss_weight=0.7, global_count=4 * B * Nn, margin=1.5)
+    eng2.forward_backward(cfg, idx)
+    assert eng2.dedup_stats() == (rows, rows)
+    b2 = eng2.blobs(cfg, ip1_diff=True)
+    assert np.array_equal(b2["ip2"] != 0, got["ip2"] != 0) and np.allclose(b2["ip2"], got["ip2"], rtol=1e-5, atol=1e-6)      # (the dense epilogue folds 1 / (1 - ratio) into its descale: last-bit differences)
+    assert abs(eng2.loss()[0] - got["loss"]) <= 1e-6 * got["loss"]
+    assert rel_fro(eng2.grads()[0], got["dW"]) <= (4e-3 if prec == "bf16" else 2e-3)
+
+
+def test_counter_based_dropout_dedup_equals_dense(vv):
+    """Counter-hash masks (the product's own generator) at D = 512: the de-duplicated and the dense execution evaluate the same mask
+    function, so they drop the same elements of every instance's row; loss equal to rounding, gradients to the reassociation of the sums."""
+    B, C, Nn, F, D = 64, 5, 20, 512, 512
+    ds, table, idx, W, b = make_case(23, 60, B, C, Nn, F, D, wstd=0.02)
+    idx = np.random.default_rng(5).integers(0, 300, size=(B, C + Nn)).astype(np.int32)
+    out = {}
+    for dd in (1, 0):
+        eng = vv.Engine(0, "f16")
+        eng.set_option("drop_dedup", dd)
+        eng.table_set(table); eng.params_set(W, b)
+        cfg = vv.StepConfig(B, C, Nn, dropout_ratio=0.9, dropout_seed=4242)
+        eng.forward_backward(cfg, idx)
+        out[dd] = (eng.dedup_stats(), eng.loss(), eng.blobs(cfg)["ip2"], eng.grads())
+    (st1, l1, h1, (dW1, db1)), (st0, l0, h0, (dW0, db0)) = out[1], out[0]
+    assert st1[1] < st1[0] and st0[1] == st0[0]
+    kept = h1 != 0
+    assert np.array_equal(kept, h0 != 0) and 0.02 < kept.mean() < 0.12           # the same elements: ~10 % of the positive ones
+    assert np.allclose(h1, h0, rtol=1e-5, atol=1e-6)
+    assert abs(l1[0] - l0[0]) <= 1e-6 * l0[0] and l1[1] == l0[1]
+    assert rel_fro(dW1, dW0) <= 2e-3 and rel_fro(db1, db0) <= 1e-4
+    print("DROP-DEDUP rows %d distinct %d; loss %.6f / %.6f; dW %.2e db %.2e" % (st1 + (l1[0], l0[0], rel_fro(dW1, dW0), rel_fro(db1, db0))))
+
+
 def test_counter_based_dropout_statistics(vv):
     # reference TestDropoutHalf (test_neuron_layer.cpp): kept fraction within 1.96 sigma of 1-p and
     # kept values scaled by 1/(1-p)

@@ -140,6 +140,7 @@ static int create_init(vv_ctx* c) {
   if (const char* v = opt_env("VV_SEG_BWD")) c->seg_bwd = atoi(v) != 0;
   if (const char* v = opt_env("VV_DEDUP")) c->dedup = atoi(v) != 0;
   if (const char* v = opt_env("VV_FUSE_UPDATE")) c->fuse_update = atoi(v) != 0;
+  if (const char* v = opt_env("VV_DROP_DEDUP")) c->drop_dedup = atoi(v) != 0;
   if (const char* v = opt_env("VV_COMM_GATE")) c->comm_gate = atoi(v) != 0;
   if (const char* v = opt_env("VV_COMM_INLINE")) c->comm_inline = atoi(v) != 0;
   if (const char* v = opt_env("VV_COMM_TEST_DELAY_US")) c->comm_test_delay_us = atoi(v);
@@ -278,6 +279,7 @@ int vv_set_option(vv_ctx* c, const char* name, double value) {
   const int iv = (int)value;
   if (n == "dedup") return vv_set_dedup(c, iv);
   if (n == "seg_bwd") { c->seg_bwd = iv != 0; return VV_OK; }
+  if (n == "drop_dedup") { c->drop_dedup = iv != 0; return VV_OK; }
   if (n == "fuse_update") { c->fuse_update = iv != 0; return VV_OK; }
   if (n == "fwd_lead") { c->ko.fwd_lead = iv; return VV_OK; }
   if (n == "wgrad_tr") { c->ko.wgrad_tr = iv != 0; return VV_OK; }
@@ -301,6 +303,7 @@ int vv_get_option(vv_ctx* c, const char* name, double* value) {
   const std::string n(name);
   if (n == "dedup") *value = c->dedup;
   else if (n == "seg_bwd") *value = c->seg_bwd;
+  else if (n == "drop_dedup") *value = c->drop_dedup;
   else if (n == "fuse_update") *value = c->fuse_update;
   else if (n == "fwd_lead") *value = c->ko.fwd_lead;
   else if (n == "wgrad_tr") *value = c->ko.wgrad_tr;
@@ -833,9 +836,24 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
     HIPCHK(hipMemcpyAsync(c->mask, cfg->dropout_mask, nb, hipMemcpyHostToDevice, s));
   }
 
-  // De-duplicate the batch rows when dropout is off (with dropout every instance has its own mask on
-  // top of the shared projection; that path stays dense).  Needs the default two-buffer GEMM kernels.
-  const bool dd = c->dedup && cfg->dropout_ratio == 0.f && (gemm_variant() == 0 || (gemm_variant() >= 5 && gemm_variant() <= 8)) && !ablate_on();
+  // De-duplicate the batch rows.  Dropout sits BEHIND the projection (fc7 -> ReLU -> drop2, mednet_embedding_train.prototxt:190-230): the
+  // projection of equal rows is equal, only the mask differs per instance.  Where the segment-wise pair carries the masks (k_score_fwd +
+  // k_seg_bwd at D = 512: every instance masks its row as it reads it, the backward sums m_i-weighted terms per distinct row) dropout
+  // rides the de-duplicated path; on the other shapes it stays dense (the mask in the forward GEMM's epilogue).  The two executions
+  // evaluate the same mask function (vv_internal.h: DropSpec).  Needs the default two-buffer GEMM kernels.
+  const bool drop_on = cfg->dropout_ratio > 0.f;
+  const bool drop_dd = drop_on && c->drop_dedup && c->seg_bwd && score_fwd_dropout_supported(D, C, Nn);
+  const bool dd = c->dedup && (!drop_on || drop_dd) && (gemm_variant() == 0 || (gemm_variant() >= 5 && gemm_variant() <= 8)) && !ablate_on();
+  DropSpec dsp;
+  if (drop_on) {
+    dsp.mode = cfg->dropout_mask ? 2 : 1;
+    dsp.thr = (uint32_t)(cfg->dropout_ratio * 65536.f + 0.5f);
+    dsp.s32 = (uint32_t)(mix64(cfg->dropout_seed * 0x9E3779B97F4A7C15ull + c->iter, 0x5eedull) >> 32);
+    dsp.scale = 1.f / (1.f - cfg->dropout_ratio);
+    dsp.mask = cfg->dropout_mask ? c->mask : nullptr;
+    dsp.B = B; dsp.CN = CN; dsp.D = D;
+  }
+  c->last_drop = (dd && drop_on) ? dsp : DropSpec();
   c->last_dedup = dd;
   if (!dd) launch_map_rows(didx, c->rows, c->R, c->Rp, (int32_t)c->n_rows, (int32_t)row_limit, s);
   if (dd) {
@@ -869,8 +887,8 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   fa.R_hint = dd ? *(volatile int32_t*)c->U_host : 0;
   fa.seq_host = c->seq_host_dev; fa.seq = seq;
 
-  fa.drop_ratio = cfg->dropout_ratio;
-  fa.mask = (cfg->dropout_ratio > 0.f && cfg->dropout_mask) ? c->mask : nullptr;
+  fa.drop_ratio = (dd && drop_on) ? 0.f : cfg->dropout_ratio;      // (de-duplicated: H holds the shared pre-dropout rows, the instances mask them)
+  fa.mask = (!(dd && drop_on) && cfg->dropout_ratio > 0.f && cfg->dropout_mask) ? c->mask : nullptr;
   fa.drop_seed = cfg->dropout_seed * 0x9E3779B97F4A7C15ull + c->iter;
   fa.B = B; fa.CN = CN;
   if (c->upd_inflight) {
@@ -950,6 +968,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   sa.map = dd ? c->dd_map : nullptr; sa.seg_start = dd ? c->dd_seg : nullptr; sa.ord = dd ? c->dd_ord : nullptr;
   sa.item_w = cfg->item_weight ? c->item_w : nullptr;
   sa.gate_host = c->seq_host_dev + 1; sa.gate_seq = seq;
+  if (dd && drop_on) sa.drop = dsp;
 
   // de-duplicated batches of the supported shape: the backward stays factored per instance and is summed per distinct
   // row (k_score_fwd + k_seg_bwd); otherwise per-instance 16-bit gradient rows (+ k_segsum when de-duplicated)
@@ -975,6 +994,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
     if (gd.gg && proactive) { sa.bound_out = c->gg_bound; sa.bound_seq = seq; }
     ba.H = c->H; ba.V = c->segV; ba.rec = c->seg_rec; ba.seg_start = c->dd_seg; ba.info = c->dd_info; ba.dYu = c->dYu;
     ba.dbp = c->seg_dbp; ba.Rp = c->Rp; ba.D = D; ba.Dp = c->Dp; ba.inv_sg = 1.f / c->sg;
+    if (drop_on) ba.drop = dsp;
   } else if (dd) {
     ga.dYh = c->dYh; ga.seg_start = c->dd_seg; ga.info = c->dd_info; ga.dYu = c->dYu; ga.Rp = c->Rp; ga.Dp = c->Dp;
   }
@@ -1384,7 +1404,8 @@ int vv_blobs_get(vv_ctx* c, float* ip2, float* target_score, float* negative_sco
     if (c->last_dedup) {               // expand the per-slot rows back to one row per instance
       DevTmp<float> d;
       HIPCHK(d.alloc(n));
-      launch_gather_rows_f32(c->H, c->dd_map, c->R, D, d, c->stream);
+      if (c->last_drop.mode) launch_gather_rows_dropout(c->H, c->dd_map, c->R, D, c->last_drop, d, c->stream);    // the instance's own mask on the shared row
+      else launch_gather_rows_f32(c->H, c->dd_map, c->R, D, d, c->stream);
       HIPCHK(hipStreamSynchronize(c->stream));
       HIPCHK(hipMemcpy(tmp.data(), d, n * 4, hipMemcpyDeviceToHost));
     } else {
@@ -1409,12 +1430,34 @@ int vv_blobs_get(vv_ctx* c, float* ip2, float* target_score, float* negative_sco
       HIPCHK(hipMemcpy(&gh, c->gg, sizeof(gh), hipMemcpyDeviceToHost));
       sgf *= gh.mul;
     }
-    if (c->last_seg_bwd) {
+    DevTmp<float> yrows; DevTmp<uint16_t> dyrows;
+    bool expanded = false;
+    if (c->last_seg_bwd && c->last_drop.mode) {
+      // ... with dropout: the instances' masked rows are materialised (item-major) and the per-instance kernel runs on them as on a
+      // dense batch whose forward pass applied the mask -- its gradient rows come out per instance, nothing to ungroup
+      HIPCHK(yrows.alloc(n));
+      HIPCHK(dyrows.alloc((size_t)(c->Rp + BK) * c->Dp));
+      launch_gather_rows_dropout(c->H, c->dd_map, c->R, D, c->last_drop, yrows, c->stream);
+      ScoreArgs la = c->last_score;
+      la.H = yrows; la.dYh = dyrows; la.map = nullptr; la.seg_start = nullptr; la.ord = nullptr; la.V = nullptr; la.rec = nullptr;
+      la.drop = DropSpec(); la.bound_out = nullptr;
+      la.sg = sgf; la.guard = GuardArgs();
+      launch_score_loss(c->prec, la, c->stream);
+      expanded = true;
+    } else if (c->last_seg_bwd) {
       // the step kept its backward factored: produce the per-instance rows now (same forward values; the loss partials
       // it rewrites are the ones already there, its bias partials go to the buffer the step did not use)
       ScoreArgs la = c->last_score;
       la.sg = sgf; la.guard = GuardArgs();
       launch_score_loss(c->prec, la, c->stream);
+    }
+    if (expanded) {
+      launch_dyh_to_float(c->prec, dyrows, c->R, D, c->Dp, 1.f / sgf, d, c->stream);
+      HIPCHK(hipStreamSynchronize(c->stream));
+      std::vector<float> tmp(n);
+      HIPCHK(hipMemcpy(tmp.data(), d, n * 4, hipMemcpyDeviceToHost));
+      reorder(tmp, ip1_diff);
+      return VV_OK;
     }
     if (c->last_dedup) {
       HIPCHK(ungrouped.alloc((size_t)c->R * c->Dp));

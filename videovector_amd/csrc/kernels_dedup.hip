@@ -238,6 +238,22 @@ __global__ __launch_bounds__(256) void k_gather_rows_f32(const float* src, const
   const float* sp = src + (int64_t)map[r] * D;
   for (int d = threadIdx.x; d < D; d += 256) dst[(int64_t)r * D + d] = sp[d];
 }
+// ... with the instance's dropout mask applied (de-duplicated execution with dropout: src holds the shared pre-dropout rows); instance
+// r = b CN + ch, its mask is that of the reference's row ch B + b (DropSpec)
+__global__ __launch_bounds__(256) void k_gather_rows_dropout(const float* src, const int32_t* map, int R, int D, DropSpec dr, float* dst) {
+  const int r = blockIdx.x;
+  const int bb = r / dr.CN, ch = r - bb * dr.CN;
+  const int64_t rr = (int64_t)ch * dr.B + bb;
+  const uint32_t rc = drop_row_ctr(rr, D, dr.s32);
+  const float* sp = src + (int64_t)map[r] * D;
+  for (int d = threadIdx.x * 4; d < D; d += 1024) {
+    const uint32_t kp = drop_keep4(dr, rr, rc, d);
+    for (int j = 0; j < 4 && d + j < D; ++j) dst[(int64_t)r * D + d + j] = ((kp >> j) & 1u) ? sp[d + j] * dr.scale : 0.f;
+  }
+}
+void launch_gather_rows_dropout(const float* src, const int32_t* map, int R, int D, const DropSpec& dr, float* dst, hipStream_t s) {
+  if (R > 0) hipLaunchKernelGGL(k_gather_rows_dropout, dim3(R), dim3(256), 0, s, src, map, R, D, dr, dst);
+}
 void launch_gather_rows_f32(const float* src, const int32_t* map, int R, int D, float* dst, hipStream_t s) {
   if (R > 0) hipLaunchKernelGGL(k_gather_rows_f32, dim3(R), dim3(256), 0, s, src, map, R, D, dst);
 }

@@ -515,7 +515,9 @@ static bool launch_score_loss_reg(const ScoreArgs& a, hipStream_t s) {
 
 // ---- segment-wise backward, pass 1: k_score_loss_reg without the per-instance gradient rows.  Forward as there; the
 // backward stops at the factored form (vv_internal.h: SegRec): one record per instance, Ah_b and dA_b per item.
-template <int NW, int RPW, int DV>
+// DROP (ScoreArgs::drop): the rows of H are the shared PRE-dropout projections; every instance applies its own mask (and 1 / (1 - ratio))
+// as its row arrives, and everything behind that -- norms, scores, records -- is the reference's graph on the masked rows.
+template <int NW, int RPW, int DV, bool DROP = false>
 __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int THREADS = 64 * NW;
@@ -544,6 +546,16 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
 #pragma unroll
     for (int v = 0; v < DV; ++v)
       x[k][v] = qi <= Nn ? *(const float4*)(a.H + (int64_t)hr * D + lane * 4 + v * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (DROP && qi <= Nn) {
+      const int64_t rr = (int64_t)ch * a.B + b;                    // the instance's row in the reference's order
+      const uint32_t rc = drop_row_ctr(rr, D, a.drop.s32);
+#pragma unroll
+      for (int v = 0; v < DV; ++v) {
+        const uint32_t kp = drop_keep4(a.drop, rr, rc, lane * 4 + v * 256);
+        x[k][v].x = (kp & 1u) ? x[k][v].x * a.drop.scale : 0.f; x[k][v].y = (kp & 2u) ? x[k][v].y * a.drop.scale : 0.f;
+        x[k][v].z = (kp & 4u) ? x[k][v].z * a.drop.scale : 0.f; x[k][v].w = (kp & 8u) ? x[k][v].w * a.drop.scale : 0.f;
+      }
+    }
   }
   float cx[CXM][CV];
 #pragma unroll
@@ -552,6 +564,16 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
     const int hr = a.map[r];
 #pragma unroll
     for (int v = 0; v < CV; ++v) cx[j][v] = j + 1 < C ? a.H[(int64_t)hr * D + tid + v * THREADS] : 0.f;
+    if (DROP && j + 1 < C) {
+      const int64_t rr = (int64_t)(j + 1) * a.B + b;
+      const uint32_t rc = drop_row_ctr(rr, D, a.drop.s32);
+#pragma unroll
+      for (int v = 0; v < CV; ++v) {
+        const int col = tid + v * THREADS;
+        const uint32_t kp = drop_keep4(a.drop, rr, rc, col & ~3);
+        cx[j][v] = ((kp >> (col & 3)) & 1u) ? cx[j][v] * a.drop.scale : 0.f;
+      }
+    }
   }
   float cf[CXM];
 #pragma unroll
@@ -879,6 +901,8 @@ __global__ __launch_bounds__(64 * NW, DV == 4 ? 4 : 1) void k_score_stream(Score
 // the segment-wise pair: k_seg_bwd holds a row of D = 512 or 1024 columns; the forward is the register-resident
 // k_score_fwd where an item fits (D = 512, up to 56 target / negative rows, 6 context rows), else the streaming kernel
 bool score_fwd_supported(const ScoreArgs& a) { return a.D == 512 || a.D == 1024; }
+// ... with dropout (ScoreArgs::drop): the register-resident kernel and k_seg_bwd's D = 512 form carry the per-instance masks
+bool score_fwd_dropout_supported(int D, int C, int Nn) { return D == 512 && C - 1 <= 6 && 1 + Nn <= 56 && ko().score_stream != 1; }
 
 // (KernelOpts::score_stream = 1: the one-sweep streaming kernel for every shape, A/B against k_score_fwd)
 void launch_score_fwd(const ScoreArgs& a_in, hipStream_t s) {
@@ -899,8 +923,13 @@ void launch_score_fwd(const ScoreArgs& a_in, hipStream_t s) {
   const size_t lds = sizeof(float) * ((size_t)(2 + 8) * a.D + 4 * (a.C + a.Nn) + 3 * 8);
 #define VV_SF(RPW)                                                                                        \
   do {                                                                                                    \
-    (void)hipFuncSetAttribute((const void*)k_score_fwd<8, RPW, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    VV_LAUNCH((k_score_fwd<8, RPW, 2>), dim3(a.B), dim3(512), lds, s, a);                                  \
+    if (a.drop.mode) {                                                                                    \
+      (void)hipFuncSetAttribute((const void*)k_score_fwd<8, RPW, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      VV_LAUNCH((k_score_fwd<8, RPW, 2, true>), dim3(a.B), dim3(512), lds, s, a);                          \
+    } else {                                                                                              \
+      (void)hipFuncSetAttribute((const void*)k_score_fwd<8, RPW, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      VV_LAUNCH((k_score_fwd<8, RPW, 2>), dim3(a.B), dim3(512), lds, s, a);                                \
+    }                                                                                                     \
   } while (0)
   if (rows <= 16) VV_SF(2);
   else if (rows <= 32) VV_SF(4);
@@ -917,8 +946,12 @@ void launch_score_fwd(const ScoreArgs& a_in, hipStream_t s) {
 // more than 64 times in one batch -- are summed in an order-independent way instead: every product is rounded to a
 // multiple of 2^-36 in f64 ((p + M) - M, M = 1.5 * 2^16; exact for |p| < 2^15 in the gradient's scaled units), and
 // sums of such multiples are exact in f64 up to 2^17, whatever the order.
-template <typename T, int CH>
+// DROP (SegBwdArgs::drop, CH == 1): every instance carries its own dropout mask m_i over the shared row:
+//   dx_u = [x_u > 0] (sum_i m_i alpha_i V_i - x_u scale sum_i m_i beta_i)        (alpha, beta already carry one factor scale)
+// -- the mask regenerated per instance from its reference row (b = vec / 2, ch = pad - b CN), the beta sum per column.
+template <typename T, int CH, bool DROP = false>
 __global__ __launch_bounds__(256) void k_seg_bwd(SegBwdArgs a) {
+  static_assert(!DROP || CH == 1, "dropout rides the D = 512 form");
   __shared__ float cs[4][512 * CH];
   __shared__ SegRec strip[4][64];
   float sgm;                                          // a repeat (guard round 1) scales the sums by a further 2^-k
@@ -973,6 +1006,18 @@ __global__ __launch_bounds__(256) void k_seg_bwd(SegBwdArgs a) {
     if (u + u_step < U) { seg_b = a.seg_start[u + u_step]; seg_e = a.seg_start[u + u_step + 1]; }
     float acc[CH][8];
     float bs = 0.f;
+    float bsv[DROP ? 8 : 1];                          // DROP: sum_i m_i beta_i per column
+    if (DROP) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bsv[j & (DROP ? 7 : 0)] = 0.f;
+    }
+    // the instance's keep bits for this lane's eight columns
+    auto keep8 = [&](const SegRec& r) -> uint32_t {
+      const int bb = r.vec >> 1, ch = r.pad - bb * a.drop.CN;
+      const int64_t rr = (int64_t)ch * a.drop.B + bb;
+      const uint32_t rc = drop_row_ctr(rr, D, a.drop.s32);
+      return drop_keep4(a.drop, rr, rc, c0) | (drop_keep4(a.drop, rr, rc, c0 + 4) << 4);
+    };
     if (n <= 64) {
       const SegRec* rs = a.rec + b;
       if (n > 1) {                                    // instance order
@@ -1003,6 +1048,17 @@ __global__ __launch_bounds__(256) void k_seg_bwd(SegBwdArgs a) {
 #pragma unroll
         for (int k = 0; k < UN; ++k) {
           const float al = r[k].alpha;
+          if (DROP) {
+            const uint32_t kp = keep8(r[k]);
+            const float vv[8] = {v0[k][0].x, v0[k][0].y, v0[k][0].z, v0[k][0].w, v1[k][0].x, v1[k][0].y, v1[k][0].z, v1[k][0].w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const bool kj = (kp >> j) & 1u;
+              acc[0][j] += kj ? al * vv[j] : 0.f;
+              bsv[j & (DROP ? 7 : 0)] += kj ? r[k].beta : 0.f;
+            }
+            continue;
+          }
 #pragma unroll
           for (int c = 0; c < CH; ++c) {
             acc[c][0] += al * v0[k][c].x; acc[c][1] += al * v0[k][c].y; acc[c][2] += al * v0[k][c].z; acc[c][3] += al * v0[k][c].w;
@@ -1013,6 +1069,19 @@ __global__ __launch_bounds__(256) void k_seg_bwd(SegBwdArgs a) {
       }
       for (; i < n; ++i) {
         const SegRec r = rs[i];
+        if (DROP) {
+          const float* vp = a.V + (int64_t)r.vec * D + c0;
+          const float4 v0 = *(const float4*)vp, v1 = *(const float4*)(vp + 4);
+          const uint32_t kp = keep8(r);
+          const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const bool kj = (kp >> j) & 1u;
+            acc[0][j] += kj ? r.alpha * vv[j] : 0.f;
+            bsv[j & (DROP ? 7 : 0)] += kj ? r.beta : 0.f;
+          }
+          continue;
+        }
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
           const float* vp = a.V + (int64_t)r.vec * D + 512 * c + c0;
@@ -1025,28 +1094,43 @@ __global__ __launch_bounds__(256) void k_seg_bwd(SegBwdArgs a) {
     } else {                                          // order-independent sums
       const double M = 98304.0;
       double dacc[CH][8], dbs = 0.0;
+      double dbsv[DROP ? 8 : 1];
 #pragma unroll
       for (int c = 0; c < CH; ++c)
 #pragma unroll
         for (int j = 0; j < 8; ++j) dacc[c][j] = 0.0;
+      if (DROP) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dbsv[j & (DROP ? 7 : 0)] = 0.0;
+      }
       for (int i = b; i < e; ++i) {
         const SegRec r = a.rec[i];
         const double al = (double)r.alpha;
+        const uint32_t kp = DROP ? keep8(r) : 0xffu;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
           const float* vp = a.V + (int64_t)r.vec * D + 512 * c + c0;
           const float4 v0 = *(const float4*)vp, v1 = *(const float4*)(vp + 4);
           const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-          for (int j = 0; j < 8; ++j) dacc[c][j] += (al * (double)vv[j] + M) - M;
+          for (int j = 0; j < 8; ++j) dacc[c][j] += (!DROP || ((kp >> j) & 1u)) ? (al * (double)vv[j] + M) - M : 0.0;
         }
-        dbs += ((double)r.beta + M) - M;
+        const double rb = ((double)r.beta + M) - M;
+        dbs += rb;
+        if (DROP) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dbsv[j & (DROP ? 7 : 0)] += ((kp >> j) & 1u) ? rb : 0.0;
+        }
       }
 #pragma unroll
       for (int c = 0; c < CH; ++c)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[c][j] = (float)dacc[c][j];
       bs = (float)dbs;
+      if (DROP) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsv[j & (DROP ? 7 : 0)] = (float)dbsv[j & (DROP ? 7 : 0)];
+      }
     }
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
@@ -1059,7 +1143,7 @@ __global__ __launch_bounds__(256) void k_seg_bwd(SegBwdArgs a) {
       float g[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        g[j] = xv[j] > 0.f ? (acc[c][j] - bs * xv[j]) * sgm : 0.f;
+        g[j] = xv[j] > 0.f ? (acc[c][j] - (DROP ? bsv[j & (DROP ? 7 : 0)] * a.drop.scale : bs) * xv[j]) * sgm : 0.f;
         col[c][j] += g[j];
         gmx = fmaxf(gmx, fabsf(g[j]));
       }
@@ -1088,6 +1172,11 @@ void launch_seg_bwd(int prec, const SegBwdArgs& a, hipStream_t s) {
   const int ch = a.D / 512;
   // (a conditional repeat of the gradient-scale guard normally returns at once: a quarter of the grid starts faster)
   const int nb = a.guard.round == 0 ? SEGB_BLOCKS : SEGB_BLOCKS / 4;
+  if (a.drop.mode && ch == 1) {
+    if (prec == 0) VV_LAUNCH((k_seg_bwd<F16, 1, true>), dim3(nb), dim3(256), 0, s, a);
+    else VV_LAUNCH((k_seg_bwd<BF16, 1, true>), dim3(nb), dim3(256), 0, s, a);
+    return;
+  }
 #define VV_SB(T, CH) VV_LAUNCH((k_seg_bwd<T, CH>), dim3(nb), dim3(256), 0, s, a)
   if (prec == 0) { if (ch == 1) VV_SB(F16, 1); else VV_SB(F16, 2); }
   else { if (ch == 1) VV_SB(BF16, 1); else VV_SB(BF16, 2); }

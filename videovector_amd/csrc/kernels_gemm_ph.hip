@@ -68,11 +68,7 @@ __device__ __forceinline__ int ph_xcd_remap(int bid, int nblk) {
   return x * q + (x < rem ? x : rem) + (bid >> 3);
 }
 
-// 32-bit finaliser of the dropout mask's counter hash (two multiply-xorshift rounds: C. Wellons' "lowbias32" constants)
-__device__ __forceinline__ uint32_t drop_mix32(uint32_t x) {
-  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
-  return x;
-}
+// (drop_mix32, the dropout mask's counter hash: vv_internal.h, DropSpec)
 constexpr int PH_SLOT = 16384;                 // one half-tile: 128 rows x 64 halves
 constexpr int PH_LDS_BYTES = 8 * PH_SLOT;      // ring of 8 slots = 128 KiB
 #define PH_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -337,8 +333,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
         int bb = (int)((float)m * rcp_cn), ch = m - bb * a.CN;
         if (ch < 0) { --bb; ch += a.CN; } else if (ch >= a.CN) { ++bb; ch -= a.CN; }
         ref_row = (int64_t)ch * a.B + bb;
-        const uint64_t r2 = (uint64_t)ref_row * (uint64_t)(2 * ((a.D + 3) >> 2));
-        row_ctr = (uint32_t)r2 + (uint32_t)(r2 >> 32) * 0x9E3779B9u + drop_s32;
+        row_ctr = drop_row_ctr(ref_row, a.D, drop_s32);
       }
 #pragma unroll
       for (int nh = 0; nh < 2; ++nh)

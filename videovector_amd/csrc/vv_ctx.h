@@ -71,6 +71,8 @@ struct vv_ctx {
   float* item_w = nullptr;          // [B] loss-term weights of the current batch
   uint8_t* mask = nullptr; size_t mask_bytes = 0;
   float* slabs = nullptr; size_t slab_bytes = 0; int S = 1, kps = 0;
+  bool drop_dedup = true;                   // option "drop_dedup" (VV_DROP_DEDUP): dropout rides the de-duplicated path where the kernels carry the masks
+  vv::DropSpec last_drop;                   // the last step's dropout on the de-duplicated path (mode 0: none): the blob accessors re-apply it
   float* loss2 = nullptr;           // {loss, violations}
   float sg = 1.f; float last_loss_weight = 1.f;
   uint64_t iter = 0;

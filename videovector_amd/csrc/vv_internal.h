@@ -128,6 +128,37 @@ constexpr int W_GATE_STRIDE = 32;   // ints between two chunk flags: a 128-B lin
 // k_seg_bwd then produces, per distinct row u, dYu[u] = [x_u > 0] (sum_r alpha_r V[vec_r] - (sum_r beta_r) x_u) from
 // the records of its instances: the per-instance 16-bit gradient rows ((C+Nn) B D values written and read back) are
 // never materialised.
+// The dropout mask of the path as a function (drop2 sits behind fc7 + ReLU, mednet_embedding_train.prototxt:220-230): element (reference
+// row r = ch B + b, column n).  mode 1: counter hash -- quad n / 4 of row r owns counters row_ctr(r) + 2 (n / 4) + {0, 1}, each 32-bit hash
+// gives two 16-bit uniforms, keep <=> uniform >= thr; mode 2: the caller's explicit mask[r D + n].  The forward GEMM's epilogue (dense
+// execution) and the score / segment kernels (de-duplicated execution: the projection is shared, the mask is per instance) evaluate the SAME
+// function, so the two executions drop the same elements.
+struct DropSpec {
+  int mode = 0;                    // 0 none, 1 counter hash, 2 explicit mask
+  uint32_t thr = 0, s32 = 0;       // mode 1: threshold on the 16-bit uniform, the step's stream
+  float scale = 1.f;               // 1 / (1 - ratio)
+  const uint8_t* mask = nullptr;   // mode 2
+  int B = 0, CN = 0, D = 0;
+};
+__device__ __forceinline__ uint32_t drop_mix32(uint32_t x) {     // (two multiply-xorshift rounds: C. Wellons' "lowbias32" constants)
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t drop_row_ctr(int64_t ref_row, int D, uint32_t s32) {
+  const uint64_t r2 = (uint64_t)ref_row * (uint64_t)(2 * ((D + 3) >> 2));
+  return (uint32_t)r2 + (uint32_t)(r2 >> 32) * 0x9E3779B9u + s32;
+}
+// keep bits of columns n .. n + 3 (n a multiple of 4) of reference row ref_row; bit j = column n + j
+__device__ __forceinline__ uint32_t drop_keep4(const DropSpec& d, int64_t ref_row, uint32_t row_ctr, int n) {
+  if (d.mode == 2) {
+    const uint32_t m = *(const uint32_t*)(d.mask + (uint64_t)ref_row * d.D + n);       // (D a multiple of 4 on these paths)
+    return ((m & 0xffu) != 0) | (((m >> 8) & 0xffu) != 0) << 1 | (((m >> 16) & 0xffu) != 0) << 2 | ((m >> 24) != 0) << 3;
+  }
+  const uint32_t c0 = row_ctr + (uint32_t)(n >> 1);
+  const uint32_t h0 = drop_mix32(c0), h1 = drop_mix32(c0 + 1u);
+  return ((h0 & 0xffffu) >= d.thr) | ((h0 >> 16) >= d.thr) << 1 | ((h1 & 0xffffu) >= d.thr) << 2 | ((h1 >> 16) >= d.thr) << 3;
+}
+
 struct SegRec { float alpha, beta; int32_t vec; int32_t pad; };   // pad: the instance index b (C+Nn) + ch (sets the summation order)
 constexpr int SEGB_BLOCKS = 1024;     // persistent grid of k_seg_bwd = rows of its bias partials
 
@@ -160,6 +191,8 @@ struct ScoreArgs {
   SegRec* rec = nullptr;             // [R]
   unsigned long long* bound_out = nullptr;   // GuardArgs::bound: (seq << 32) | bits of the largest per-instance element bound
   int32_t bound_seq = 0;
+  DropSpec drop;                     // de-duplicated execution with dropout (k_score_fwd): H holds the SHARED pre-dropout rows, every
+                                     // instance applies its own mask as it reads its row
 };
 
 // Row de-duplication of one batch (kernels_dedup.hip).  The sampler draws the negatives of every item
@@ -197,6 +230,7 @@ struct SegBwdArgs {
   int Rp, D, Dp;
   float inv_sg;
   GuardArgs guard;
+  DropSpec drop;                 // as ScoreArgs::drop: dx_u = [x_u > 0] (sum_i m_i alpha_i V_i - x_u scale sum_i m_i beta_i), m_i the instance's mask
 };
 
 struct SegsumArgs {
@@ -345,9 +379,11 @@ void launch_dedup(const DedupArgs& a, hipStream_t s);
 void launch_dedup_groups(const DedupArgs& a, hipStream_t s);
 void launch_dedup_pos(const DedupArgs& a, hipStream_t s);   // pos[] for the debug accessors only
 void launch_segsum(int prec, const SegsumArgs& a, hipStream_t s);
+bool score_fwd_dropout_supported(int D, int C, int Nn);
 bool score_fwd_supported(const ScoreArgs& a);               // shapes the segment-wise pair is built for
 void launch_score_fwd(const ScoreArgs& a, hipStream_t s);   // forward + factored backward records (dedup mode)
 void launch_seg_bwd(int prec, const SegBwdArgs& a, hipStream_t s);
+void launch_gather_rows_dropout(const float* src, const int32_t* map, int R, int D, const DropSpec& dr, float* dst, hipStream_t s);
 void launch_gather_rows_f32(const float* src, const int32_t* map, int R, int D, float* dst, hipStream_t s);
 void launch_gather_rows_u16(const uint16_t* src, const int32_t* pos, int R, int Dp, uint16_t* dst, hipStream_t s);
 void launch_reduce(const ReduceArgs& a, hipStream_t s);
