@@ -119,3 +119,48 @@ def test_sibling_lead_forward_kernel_is_bit_identical(setup, monkeypatch):
     finally:
         monkeypatch.setenv("VV_FWD_LEAD", "1")
         vv.Engine(0, "f16")                           # back to the default kernel for the tests that follow
+
+
+def test_full_size_dropout_on_the_deduplicated_path(setup, oracle):
+    """The shipped dropout ratio 0.9 at the benchmark's size: the de-duplicated execution (the mask per instance on the shared projection) and
+    the dense one (the mask in the forward GEMM's epilogue) drop the same elements and agree; a shard of the batch against the oracle with
+    the same explicit mask."""
+    vv, ds, idx, W, b, _ = setup
+    out = {}
+    for dd in (1, 0):
+        eng = vv.Engine(0, "f16")
+        eng.set_option("drop_dedup", dd)
+        eng.table_synth(ds.seed, ds.n_rows, F); eng.params_set(W, b)
+        cfg = vv.StepConfig(B, C, Nn, dropout_ratio=0.9, dropout_seed=1701)
+        eng.forward_backward(cfg, idx)
+        dW, db = eng.grads()
+        out[dd] = (eng.dedup_stats(), eng.loss(), dW.copy(), db.copy())
+        eng.forward_backward(cfg, idx)                           # idempotence under the same seed and iteration count: not expected (the
+        del eng                                                  # stream advances with the iteration); only that a second step runs
+    (st1, l1, dW1, db1), (st0, l0, dW0, db0) = out[1], out[0]
+    assert st1[1] < st1[0] == B * (C + Nn) and st0[1] == st0[0]
+    assert abs(l1[0] - l0[0]) <= 2e-6 * l0[0] and l1[1] == l0[1]
+    e = float(np.linalg.norm(dW1 - dW0) / np.linalg.norm(dW0))
+    print("FULLSIZE dropout 0.9: %d rows, %d distinct; loss %.6f / %.6f; dW dedup vs dense %.2e" % (st1 + (l1[0], l0[0], e)))
+    assert e <= 2e-3 and np.linalg.norm(db1 - db0) <= 1e-4 * np.linalg.norm(db0)
+    # a shard against the oracle, explicit mask
+    sh = idx[200:232]
+    Bs = sh.shape[0]
+    uniq, inv = np.unique(sh.reshape(-1), return_inverse=True)
+    table = ds.table(F, uniq)
+    il = inv.reshape(sh.shape).astype(np.int32)
+    mask = (np.random.default_rng(9).random(((C + Nn) * Bs, D)) > 0.9).astype(np.uint8)
+    ref = oracle.forward_backward(table, il, W, b, C_=C, Nn=Nn, dropout_ratio=0.9, dropout_mask=mask, global_count=B * Nn,
+                                  want=("H", "s_true", "s_bogus", "dW"))
+    eng = vv.Engine(0, "f16")
+    eng.table_synth(ds.seed, ds.n_rows, F); eng.params_set(W, b)
+    cfg = vv.StepConfig(Bs, C, Nn, dropout_ratio=0.9, dropout_mask=mask, global_count=B * Nn)
+    eng.forward_backward(cfg, sh)
+    rows, nu = eng.dedup_stats()
+    assert nu == len(uniq) < rows
+    got = eng.blobs(cfg)
+    nz = np.linalg.norm(ref["H"], axis=1) > 0
+    e_emb = (np.linalg.norm(got["ip2"] - ref["H"], axis=1)[nz] / np.linalg.norm(ref["H"], axis=1)[nz]).max()
+    assert e_emb <= 1e-3 and abs(eng.loss()[0] - ref["loss"]) <= 1e-3 * ref["loss"]
+    assert np.abs(got["negative_scores"] - ref["s_bogus"]).max() <= 1e-3
+    assert np.linalg.norm(eng.grads()[0] - ref["dW"]) <= 5e-2 * np.linalg.norm(ref["dW"])
