@@ -515,6 +515,7 @@ static bool launch_score_loss_reg(const ScoreArgs& a, hipStream_t s) {
 
 // ---- segment-wise backward, pass 1: k_score_loss_reg without the per-instance gradient rows.  Forward as there; the
 // backward stops at the factored form (vv_internal.h: SegRec): one record per instance, Ah_b and dA_b per item.
+// (Sixteen waves per item, four rows per wave -- one item per CU at a time instead of two items of eight waves: 36 against 25 us, round 4.)
 // DROP (ScoreArgs::drop): the rows of H are the shared PRE-dropout projections; every instance applies its own mask (and 1 / (1 - ratio))
 // as its row arrives, and everything behind that -- norms, scores, records -- is the reference's graph on the masked rows.
 template <int NW, int RPW, int DV, bool DROP = false>
