@@ -238,6 +238,21 @@ def test_dropout_on_the_deduplicated_path_matches_oracle(vv, oracle, prec):
     assert rel_fro(eng2.grads()[0], got["dW"]) <= (4e-3 if prec == "bf16" else 2e-3)
 
 
+def test_dropout_on_the_deduplicated_path_l1_weighted_pairwise(vv, oracle):
+    """The same path under the options that change the backward's coefficients: L1 hinge, per-item loss weights (the weighted loss's third
+    bottom), two channels in front of the negatives (C = 2: one context row, as PAIRWISE batches have), 30 negatives (the four-rows-per-wave form)."""
+    B, C, Nn, F, D = 24, 2, 30, 256, 512
+    ds, table, idx, W, b = make_case(29, 30, B, C, Nn, F, D, wstd=0.01)
+    rng = np.random.default_rng(7)
+    idx = rng.integers(0, 90, size=(B, C + Nn)).astype(np.int32)
+    mask = (rng.random(((C + Nn) * B, D)) > 0.5).astype(np.uint8)
+    iw = (0.5 + rng.random(B)).astype(np.float32)
+    eng, _, got, ref = run_both(vv, oracle, "f16", table, idx, W, b, C, Nn, dropout_ratio=0.5, dropout_mask=mask, norm=1, item_weight=iw, margin=1.0)
+    rows, uniq = eng.dedup_stats()
+    assert uniq == len(np.unique(idx)) < rows
+    check(got, ref, TOL["f16"], "dropout-dedup-l1w/f16")
+
+
 def test_counter_based_dropout_dedup_equals_dense(vv):
     """Counter-hash masks (the product's own generator) at D = 512: the de-duplicated and the dense execution evaluate the same mask
     function, so they drop the same elements of every instance's row; loss equal to rounding, gradients to the reassociation of the sums."""
