@@ -583,7 +583,7 @@ def main():
         # rows the GEMMs really processed: distinct table rows per timed batch of this rank (host recount on the identical
         # stream of the second sampler; the ring's batches are the same batches)
         if DROPOUT > 0:
-            U = float(R)                      # dropout: every instance has its own mask, nothing is shared
+            U = float(R)                      # the shipped shape under dropout runs dense (D = 4096)
         elif args.dedup == "on" and batches is not None:
             U = float(np.mean([len(np.unique(batches[i])) for i in range(S + Wm, S + Wm + K)]))
         elif args.dedup == "on":
@@ -657,7 +657,7 @@ def main():
                                    % (1 if args.workload == "cfg2" else 4, D, B_PER_GPU, Bg, NN),
                        "global_batch": Bg, "triplets_per_step": Bg * NN,
                        "parallelism": "dp%d" % world, "items_per_s": value / NN,
-                       "dedup": args.dedup if DROPOUT == 0 else "off (dropout: every instance has its own mask; dense kernels)",
+                       "dedup": args.dedup if DROPOUT == 0 else "off (dropout at D = 4096: dense kernels -- the de-duplicated path carries the per-instance masks at D = 512 only, and 128-item batches hardly repeat a row)",
                        "cpu_binding_rank0": cpu_bind,
                        "sampler": ("one per rank: the reference's sampler at batch %d with srand(1 + rank) and its own starting record, "
                                    "%d stage thread(s), prefetch depth %d" % (B_PER_GPU, args.sampler_threads, args.prefetch_depth))
