@@ -48,11 +48,17 @@ def _rank_main(rank, world, id_path, overlap, transport, q, env=None):
     eng.table_synth(ds.seed, ds.n_rows, F)
     eng.params_set(W, b)
     eng.comm_init(world, rank, id_path, transport)
-    if overlap == "sharded": eng.comm_schedule("sharded")
+    mix = isinstance(overlap, str) and overlap.startswith("mix_")
+    if overlap in ("sharded", "mix_sharded_overlap", "mix_sharded_exposed"): eng.comm_schedule("sharded")
+    elif overlap == "mix_overlap_sync": eng.comm_overlap(True)
     else: eng.comm_overlap(overlap)
     cfg = vv.StepConfig(B, C, Nn, global_count=world * B * Nn, lr=0.05)
     losses = []
-    for g in _batches(ds, world):
+    for k, g in enumerate(_batches(ds, world)):
+        if mix and k == ITERS // 2:                # the schedule changes in mid-run: every rank makes the same call
+            if overlap == "mix_sharded_overlap": eng.comm_overlap(True)        # vv_comm_overlap(ctx, 1) leaves the sharded schedule
+            elif overlap == "mix_sharded_exposed": eng.grads_device()          # a holder of the gradient buffer: whole-matrix updates from here on
+            elif overlap == "mix_overlap_sync": eng.comm_overlap(False)        # the next update runs on the compute stream
         eng.forward_backward(cfg, g[rank * B:(rank + 1) * B])
         eng.apply_update(cfg)                      # all-reduces first
         losses.append(eng.loss()[0])
@@ -128,6 +134,20 @@ def test_sharded_update_is_the_synchronous_update_bit_for_bit(world, inline):
             assert np.array_equal(shard[r][k], sync[r][k]), "sharded differs from sync (rank %d, array %d)" % (r, k)
         assert shard[r][3] == sync[r][3]                       # the per-rank losses of all six iterations: the forward passes read the same bits
     assert np.isfinite(shard[0][0]).all() and np.abs(shard[0][2]).max() > 0
+
+
+@pytest.mark.parametrize("mode", ["mix_sharded_overlap", "mix_sharded_exposed", "mix_overlap_sync"])
+def test_schedule_changes_in_mid_run_keep_the_synchronous_trajectory(mode):
+    """(a) a step that leaves the SHARDED schedule without vv_comm_schedule -- vv_comm_overlap(ctx, 1), or the gradient buffer
+    handed out by vv_grads_device -- found the other ranks' rows of the fp32 master W and of the history stale and applied the whole-matrix
+    rule to them; (b) an update queued on the COMPUTE stream right after an overlapped step did not wait for the end of the previous update's
+    kernels on the communication stream.  Three steps in one schedule, three in the other, two ranks: bit for bit the all-synchronous run."""
+    ref = _run_world(2, False)
+    res = _run_world(2, mode)
+    for r in (0, 1):
+        for i, what in enumerate(("W", "b", "hW")):
+            assert np.array_equal(res[r][i], ref[r][i]), (mode, "rank %d %s differs from the synchronous run" % (r, what))
+        assert res[r][3] == ref[r][3], (mode, res[r][3], ref[r][3])
 
 
 @pytest.mark.parametrize("overlap", [False, True, "sharded"])

@@ -164,3 +164,69 @@ def test_full_size_dropout_on_the_deduplicated_path(setup, oracle):
     assert e_emb <= 1e-3 and abs(eng.loss()[0] - ref["loss"]) <= 1e-3 * ref["loss"]
     assert np.abs(got["negative_scores"] - ref["s_bogus"]).max() <= 1e-3
     assert np.linalg.norm(eng.grads()[0] - ref["dW"]) <= 5e-2 * np.linalg.norm(ref["dW"])
+
+
+def _local(ds, idx):
+    """The batch's distinct table rows as a compact fp32 table for the oracle + the batch re-indexed into it."""
+    uniq, inv = np.unique(idx.reshape(-1), return_inverse=True)
+    return ds.table(F, uniq), inv.reshape(idx.shape).astype(np.int32), len(uniq)
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.9])
+def test_the_whole_benchmark_batch_against_the_oracle(setup, oracle, dropout):
+    """not a shard -- ALL 56 320 rows of the BASELINE configs[1] batch, on the engine state bench.py times (de-duplication
+    on; the SECOND call of an engine, whose forward GEMM is planned from the previous step's distinct-row count: 192-row tiles, ~216
+    workgroups, sibling lead), against oracle.forward_backward on the same batch: every ip2 row, every score, the loss, the violations,
+    dW / db against the oracle on the same rounded operands, and W / history after one vv_apply_update against oracle.sgd_update.
+    dropout 0.9 (the shipped ratio) with an explicit mask: the mask per instance on the shared projection."""
+    vv, ds, idx, W, b, _ = setup
+    table, il, nu = _local(ds, idx)
+    mask = None
+    kw = {}
+    if dropout > 0:
+        mask = (np.random.default_rng(11).random(((C + Nn) * B, D)) > dropout).astype(np.uint8)
+        kw = dict(dropout_ratio=dropout, dropout_mask=mask)
+    lr = 0.01
+    eng = vv.Engine(0, "f16")
+    eng.table_synth(ds.seed, ds.n_rows, F); eng.params_set(W, b)
+    cfg = vv.StepConfig(B, C, Nn, lr=lr, **kw)
+    eng.forward_backward(cfg, idx)
+    eng.forward_backward(cfg, idx)                # the plan of a running job (the first call sized its tiles for 56 320 rows)
+    rows, u = eng.dedup_stats()
+    assert rows == B * (C + Nn) and u == nu < rows
+    got = eng.blobs(cfg)
+    loss, viol = eng.loss()
+    dW, db = eng.grads()
+    want = ("H", "s_true", "s_bogus", "dW", "db")
+    ref = oracle.forward_backward(table, il, W, b, C_=C, Nn=Nn, want=want, **kw)
+    # -- forward: every row, every score
+    nr = np.linalg.norm(ref["H"], axis=1)
+    nz = nr > 0
+    e_rows = np.linalg.norm(got["ip2"] - ref["H"], axis=1)[nz] / nr[nz]
+    assert nz.sum() >= 0.999 * len(nr) and np.all(got["ip2"][~nz] == 0)
+    e_s = max(np.abs(got["target_score"] - ref["s_true"]).max(), np.abs(got["negative_scores"] - ref["s_bogus"]).max())
+    print("FULLBATCH dropout %.1f: %d rows (%d distinct): ip2 rows max %.2e mean %.2e, scores %.2e, loss %.7f / %.7f, violations %d / %d"
+          % (dropout, rows, u, e_rows.max(), e_rows.mean(), e_s, loss, ref["loss"], viol, ref["violations"]))
+    assert e_rows.max() <= 1e-3
+    assert e_s <= 1e-3
+    assert abs(loss - ref["loss"]) <= 1e-3 * ref["loss"]
+    assert abs(viol - ref["violations"]) <= max(2e-3 * ref["violations"], 2)
+    # -- backward: the kernels' arithmetic against the oracle on the SAME rounded operands (module docstring of test_gpu_parity.py)
+    sw = 2.0 ** (12 - np.frexp(np.abs(W).max())[1])
+    Wq = (W * sw).astype(np.float16).astype(np.float32) / sw
+    refq = oracle.forward_backward(table, il, Wq, b, C_=C, Nn=Nn, want=("dW", "db"), **kw)
+    rel = lambda a, r: float(np.linalg.norm(a - r) / np.linalg.norm(r))
+    print("FULLBATCH dropout %.1f: dW %.2e db %.2e vs the oracle at f16(W); %.2e vs the fp32-operand oracle"
+          % (dropout, rel(dW, refq["dW"]), rel(db, refq["db"]), rel(dW, ref["dW"])))
+    assert rel(dW, refq["dW"]) <= 2e-3 and rel(db, refq["db"]) <= 2e-3
+    assert rel(dW, ref["dW"]) <= 5e-2
+    # -- the update (solver.cpp:485-576): the solver's rule on the oracle's own gradient, and -- the rule alone -- on the engine's
+    eng.apply_update(cfg)
+    Wn, bn, hW, hb = eng.params_get()
+    for g_w, g_b, tol in ((refq["dW"], refq["db"], 2e-3), (dW, db, 2e-6)):
+        Wo, bo, hWo, hbo = W.copy(), b.copy(), np.zeros_like(W), np.zeros_like(b)
+        oracle.sgd_update(Wo, g_w.copy(), hWo, lr, 1.0, 0.9, 5e-4, 1.0)
+        oracle.sgd_update(bo, g_b.copy(), hbo, lr, 2.0, 0.9, 5e-4, 0.0)
+        assert rel(hW, hWo) <= tol and rel(hb, hbo) <= tol, (tol, rel(hW, hWo), rel(hb, hbo))
+        assert rel(Wn - W, Wo - W) <= tol and rel(bn - b, bo - b) <= tol
+    assert np.linalg.norm(Wn - W) > 0

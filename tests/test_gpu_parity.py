@@ -76,8 +76,10 @@ def make_case(seed, n_videos, B, C, Nn, F, D, wstd=1e-3, real=False):
     return ds, table, idx, W, b
 
 
-def run_both(vv, oracle, prec, table, idx, W, b, C, Nn, **kw):
+def run_both(vv, oracle, prec, table, idx, W, b, C, Nn, dedup=None, **kw):
     eng = vv.Engine(0, prec)
+    if dedup is not None:
+        eng.set_dedup(dedup)
     eng.table_set(table)
     eng.params_set(W, b)
     B = idx.shape[0]
@@ -152,6 +154,20 @@ def test_multi_tile_shapes(vv, oracle, prec):
     ds, table, idx, W, b = make_case(4, 40, 64, 5, 11, 512, 512)
     _, _, got, ref = run_both(vv, oracle, prec, table, idx, W, b, 5, 11)
     check(got, ref, TOL[prec], "multitile/%s" % prec)
+
+
+@pytest.mark.parametrize("D", [2048, 1536, 3072])
+@pytest.mark.parametrize("dedup", [False, True])
+def test_wide_rows_small_batch_sixteen_wave_score_kernel(vv, oracle, dedup, D):
+    """Few items of wide rows (D >= 2048, B <= 512) run k_score_loss with sixteen waves per item.  At D = 2048 its column-parallel
+    backward phase has TWO row groups side by side, each with a [D] partial-sum area for dAh and one for db: ADVICE r4 found those areas
+    sized for four waves (1024 floats) -- group 1 of dAh ran into group 0 of db and group 1 of db over the kernel's small arrays and past the
+    allocation.  D = 1536 (four-wave form, two groups) and D = 3072 (one group) bracket the case."""
+    B, C, Nn, F = 24, 3, 6, 256
+    ds, table, idx, W, b = make_case(77 + D, 40, B, C, Nn, F, D)
+    _, _, got, ref = run_both(vv, oracle, "f16", table, idx, W, b, C, Nn, dedup=dedup)
+    check(got, ref, TOL["f16"], "wide-rows D=%d dedup=%s" % (D, dedup))
+    assert got["viol"] == ref["violations"]
 
 
 def test_ragged_shapes_and_empty_slots(vv, oracle):

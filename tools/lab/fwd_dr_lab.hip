@@ -34,6 +34,16 @@ __global__ void k_fill_w(uint16_t* w, uint16_t* wq, int D, int Fp, int nk, uint6
   }
 }
 
+// r05: the product forward kernel with time stamps (ABL bit 9, kernels_gemm_ph.hip): 192-row tiles, with / without the sibling lead
+template <int ABL, int LEAD>
+static void launch_ph_ts(const FwdArgs& a, hipStream_t s) {
+  constexpr int LDS = LEAD ? 10 * PH_SLOT : PH_LDS_BYTES;
+  static bool once = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<F16, 0, true, 3, ABL, false, 0, LEAD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS), true);
+  (void)once;
+  const dim3 grid(((a.R + 191) / 192) * 2), block(GEMM_THREADS);
+  hipLaunchKernelGGL((k_fwd_gemm_ph<F16, 0, true, 3, ABL, false, 0, LEAD>), grid, block, LDS, s, a);
+}
+
 template <int MT, int P, int ABL, int TD = 0, int OPT = 0>
 static void launch_dr(const FwdArgs& a, hipStream_t s) {
   constexpr int LDS = (P + 1) * 16 * MT * 128 + (TD ? 2048 : 0);
@@ -87,6 +97,8 @@ int main(int argc, char** argv) {
   base.table = table; base.Wh = Wh; base.bias = bias; base.scales = sc; base.R = U; base.D = D; base.Fp = Fp;
   base.zero_row = (int32_t)n_rows; base.relu = 1; base.drop_ratio = 0.f; base.mask = nullptr; base.B = 1; base.CN = 1;
   hipStream_t st; CHK(hipStreamCreate(&st));
+  const int ts_wg = ((U + 191) / 192) * 2;
+  uint32_t* ts_buf; CHK(hipMalloc(&ts_buf, (size_t)ts_wg * 8 * 12 * 4)); CHK(hipMemset(ts_buf, 0, (size_t)ts_wg * 8 * 12 * 4));
   struct Var { const char* name; int kind; };
   std::vector<Var> vars = {{"ph_lead", 0}, {"dr12p4", 1}, {"dr12p2", 2}, {"dr12p4_noA", 3}, {"dr12p4_noMM", 4}, {"dr12p4_noRD", 5},
                            {"dr12p4_hotA", 6}, {"dr12p4_noB", 7}, {"dr12p4_noAnoB", 8}, {"dr12p4_onlyMM", 9}, {"dr16p4", 10}, {"dr8p4", 11},
@@ -97,10 +109,26 @@ int main(int argc, char** argv) {
                            {"dr12_rot1", 30}, {"dr12_rot2", 31}, {"dr12_rot4", 32}, {"dr12_rot1_onlyA", 33}, {"dr12_rot2_onlyA", 34}, {"dr12_rot4_onlyA", 35},
                            {"dr12_run512_onlyA", 36}, {"dr12_run1k_onlyA", 37},
                            {"dr12_bl1_onlyA", 38}, {"dr12_bl2_onlyA", 39}, {"dr12_bl4_onlyA", 40}, {"dr12_bl2_onlyAB", 41}, {"dr12_bl2_noRD", 42},
-                           {"dr12_spread_onlyA", 43}, {"dr12_spread_full", 44}, {"dr12_spread_noRD", 45}, {"dr12_spread_run1k_onlyA", 46}};
+                           {"dr12_spread_onlyA", 43}, {"dr12_spread_full", 44}, {"dr12_spread_noRD", 45}, {"dr12_spread_run1k_onlyA", 46},
+                           {"dr12_even_onlyA", 47}, {"dr12_even_onlyAB", 48}, {"dr12_split_onlyA", 49}, {"dr12_split_onlyAB", 50},
+                           {"ph_ts_lead", 60}, {"ph_ts_plain", 61}, {"ph_ts_lead_hotA", 62}, {"ph_ts_lead_nostream", 63}, {"ph_ts_lead_nomm", 64},
+                           {"ph_ts_lead_nostore", 65}, {"ph_plain", 66}};
   auto run = [&](int kind, int set, float* Hout) {
     FwdArgs a = base; a.rows = rows + (size_t)set * Rp; a.H = Hout;
     if (kind == 0) { a.Wh = Wh; launch_fwd_gemm_ph(0, a, st); return; }
+    if (kind >= 60) {
+      a.Wh = Wh; a.mask = (const uint8_t*)ts_buf;
+      switch (kind) {
+        case 60: launch_ph_ts<512, 1>(a, st); break;
+        case 61: launch_ph_ts<512, 0>(a, st); break;
+        case 62: launch_ph_ts<512 + 8, 1>(a, st); break;
+        case 63: launch_ph_ts<512 + 1, 1>(a, st); break;
+        case 64: launch_ph_ts<512 + 2, 1>(a, st); break;
+        case 65: launch_ph_ts<512 + 64, 1>(a, st); break;
+        case 66: launch_ph_ts<0, 0>(a, st); break;
+      }
+      return;
+    }
     a.Wh = Wq;
     switch (kind) {
       case 1: launch_dr<12, 4, 0>(a, st); break;
@@ -149,6 +177,10 @@ int main(int argc, char** argv) {
       case 44: launch_dr<12, 4, 0, 0, 1 + 2048>(a, st); break;               // full kernel, K spread
       case 45: launch_dr<12, 4, 4, 0, 1 + 2048>(a, st); break;               // both streams, no fragment reads
       case 46: launch_dr<12, 4, 2 + 4 + 16, 0, 1 + 2048 + 16 + 256>(a, st); break;   // rows alone, K spread, 1-KiB runs
+      case 47: launch_dr<12, 4, 2 + 4 + 16, 0, 1 + 4096>(a, st); break;      // r05: rows alone, only the even column tile asks (no duplicates, 108 pullers)
+      case 48: launch_dr<12, 4, 2 + 4, 0, 1 + 4096>(a, st); break;           //      ... + W on every workgroup
+      case 49: launch_dr<12, 4, 2 + 4 + 16, 0, 1 + 8192>(a, st); break;      // r05: rows alone, every sibling only its half of the rows (no duplicates, 216 pullers)
+      case 50: launch_dr<12, 4, 2 + 4, 0, 1 + 8192>(a, st); break;           //      ... + W
     }
   };
   // correctness: the real variants against the LDS kernel, bit for bit, on every row set
@@ -176,6 +208,25 @@ int main(int argc, char** argv) {
       CHK(hipEventRecord(e1, st)); CHK(hipEventSynchronize(e1));
       float ms = 0; CHK(hipEventElapsedTime(&ms, e0, e1));
       printf("round %d  %-16s %8.2f us\n", r, v.name, ms * 1000.f / iters);
+      if (v.kind >= 60 && v.kind <= 65) {
+        // the stamps of the LAST launch: mean over the workgroups, waves 0-3 (the leading group) and 4-7 apart
+        std::vector<uint32_t> hb((size_t)ts_wg * 8 * 12);
+        CHK(hipMemcpy(hb.data(), ts_buf, hb.size() * 4, hipMemcpyDeviceToHost));
+        for (int grp = 0; grp < 2; ++grp) {
+          double sum[12] = {0}; double mx7 = 0, mn7 = 1e18;
+          for (int w = 0; w < ts_wg; ++w) for (int wv = grp * 4; wv < grp * 4 + 4; ++wv) {
+            const uint32_t* o = &hb[((size_t)w * 8 + wv) * 12];
+            for (int j = 0; j < 12; ++j) sum[j] += o[j];
+            mx7 = std::max(mx7, (double)o[7]); mn7 = std::min(mn7, (double)o[7]);
+          }
+          const double n = ts_wg * 4.0;
+          const double mhz = (sum[9] / n) / ((sum[8] / n) / 100.0);           // shader clocks per us of real time
+          printf("   stamps waves %d-%d: load %.0f  vmwait %.0f  bar_after_load %.0f  mfma %.0f  bar_after_mfma %.0f  | prologue %.0f  loop_end %.0f  end %.0f (min %.0f max %.0f) clocks;  %.0f MHz;"
+                 "  per phase (256): load %.0f vm %.0f bar1 %.0f mfma %.0f bar2 %.0f\n", grp * 4, grp * 4 + 3,
+                 sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n, sum[5] / n, sum[6] / n, sum[7] / n, mn7, mx7, mhz,
+                 sum[0] / n / 256, sum[1] / n / 256, sum[2] / n / 256, sum[3] / n / 256, sum[4] / n / 256);
+        }
+      }
       fflush(stdout);
     }
   return 0;

@@ -165,7 +165,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_dr(FwdArgs a) {
   // column parity 1 / 2 / 4 K-tiles early -- each sibling is the first toucher of half of the lines and finds the other half in L2
   const int blead = ((OPT >> 9) & 3) == 0 ? 0 : (1 << (((OPT >> 9) & 3) - 1));
   const int sibp = (L % tilesN) & 1;
+  // (lab, r05, STREAM TIMING ONLY -- the LDS image is incomplete and the counted waits see fewer operations):
+  //   OPT bit 12: only the EVEN column tile of a row tile asks for the gathered rows (108 pullers x 1.5 MB, no duplicate requests);
+  //   OPT bit 13: every sibling asks only for ITS half of the rows (216 pullers x 0.75 MB, no duplicate requests)
   auto a_issue = [&](int tt0, int slot, int i) {
+    if ((OPT & 4096) && sibp && tt0 >= P) return;
+    if ((OPT & 8192) && ((((i * 8 + wave) * 8 >= BMT / 2) ? 1 : 0) != sibp) && tt0 >= P) return;
     int tt = rotk(tt0);
     if (blead && (((i * 8 + wave) * 8 >= BMT / 2) ? 1 : 0) == sibp) { tt += blead; if (tt >= nk) tt -= nk; }
     if ((OPT & 16) && (!(ABL & 1) || tt0 < P)) { dr_glds16<(OPT >> 2) & 3>(aoff2[tt % RUNG][i], a.table + (int64_t)(tt - tt % RUNG) * BK, lds0 + slot * SLOTB + (i * 8 + wave) * 1024); return; }

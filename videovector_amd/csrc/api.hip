@@ -245,6 +245,7 @@ static void free_batch(vv_ctx* c) {
 int vv_destroy(vv_ctx* c) {
   if (!c) return VV_OK;
   (void)hipSetDevice(c->device);
+  if (vv::g_ko == &c->ko) vv::g_ko = nullptr;        // (this thread's launcher options pointed into the context)
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm) { vv::comm_destroy(c->comm); c->comm = nullptr; }    // drains the communication stream: before any buffer it uses goes
   vv_ops_release(c);
@@ -1187,9 +1188,17 @@ int vv_apply_update(vv_ctx* c, const vv_step_cfg* cfg) {
   // two updates in a row: the first one completes first.  (After a gated forward GEMM -- upd_unjoined -- nothing is due here: the
   // new update is queued on the communication stream behind the old one, and what this step's kernels on the compute stream read
   // of the old one -- the half copy, its scale, the bias, the per-block maxima -- was stored at agent scope before the gates opened.)
-  if (c->upd_inflight && (rc = comm_join(c))) return rc;
+  // That holds only while the new update goes to the communication stream too.  One that runs on the COMPUTE stream -- the schedule was
+  // switched to `sync`, the gradient buffer was handed out or bound after an overlapped step, the sharded update runs in-stream -- reads
+  // W and the history, which the previous update wrote with plain stores released only at its end: it joins first.
   const bool overlapped = c->comm && c->grads_pending && c->grads_chunked;
   const bool sharded = c->comm && c->grads_pending && c->grads_sharded;
+  const bool on_comm_stream = overlapped || (sharded && !c->comm_inline);
+  if ((c->upd_inflight || (c->upd_unjoined && !on_comm_stream)) && (rc = comm_join(c))) return rc;
+  // A sharded update left the other ranks' rows of the fp32 master W and of the history stale here; an update of the WHOLE matrix needs
+  // them (the step left the sharded path -- gradients exposed or bound, the schedule changed -- without a gather).  A
+  // collective, like the update itself: every rank takes this branch in the same iteration.
+  if (!sharded && c->params_partial && (rc = gather_params(c))) return rc;
   if (!overlapped && !sharded && c->grads_pending && (rc = vv_allreduce_grads(c))) return rc;     // data-parallel: the update consumes the SUM over the ranks
   SgdArgs a;
   float* const wmax_new = c->wmax_blocks + (1 - c->wmax_cur) * WMAX_SLOTS;     // the buffer the previous update did not write
@@ -1199,6 +1208,7 @@ int vv_apply_update(vv_ctx* c, const vv_step_cfg* cfg) {
   a.lr_mult_w = cfg->lr_mult[0]; a.lr_mult_b = cfg->lr_mult[1];
   a.decay_mult_w = cfg->decay_mult[0]; a.decay_mult_b = cfg->decay_mult[1];
   a.reg = cfg->reg; a.solver_type = cfg->solver_type; a.delta = cfg->delta;
+  a.skip_if = c->comm ? vv::comm_fail_flag(c->comm) : nullptr;
   if (c->red_lazy && !overlapped) {
     // the reduction is still due: reduce and update in one launch (k_reduce_sgd)
     FusedUpdArgs fa;
@@ -1605,6 +1615,7 @@ int vv_comm_init(vv_ctx* c, int32_t world, int32_t rank, const char* id_path, in
 
 int vv_comm_overlap(vv_ctx* c, int on) {
   if (!c) return fail(VV_ERR_ARG, "vv_comm_overlap: ctx is NULL");
+  if (on && c->comm_sharded && c->params_partial) { VV_ENTER(c); const int rcg = gather_params(c); if (rcg) return rcg; }   // (collective, as in vv_comm_schedule: leaving the sharded schedule)
   c->comm_overlap = on != 0;
   if (on) c->comm_sharded = false;
   return VV_OK;

@@ -124,7 +124,8 @@ struct Comm {
   uint32_t* status_host = nullptr; uint32_t* status_dev = nullptr; // != 0: a wait gave up (a rank is missing)
   uint32_t* xcd_count = nullptr;                 // device word: the meeting kernel's workgroups 1..7 count themselves in
   uint32_t seq = 0;                              // meeting points so far (every rank counts the same ones)
-  double peer_timeout_s = 30.0;
+  uint32_t* fail_dev = nullptr;     // device word: != 0 once a meeting gave up -- the exchange kernels queued behind it return at once, the update is skipped
+  double peer_timeout_s = 120.0;
   std::string err;
 };
 
@@ -143,6 +144,7 @@ static bool shm_barrier(Comm* c, double timeout_s) {
 }
 
 const char* comm_error(Comm* c) { return c ? c->err.c_str() : "no communicator"; }
+const uint32_t* comm_fail_flag(Comm* c) { return c ? c->fail_dev : nullptr; }
 bool comm_failed(Comm* c) {
   if (!c || !c->status_host || !*(volatile uint32_t*)c->status_host) return false;
   c->err = "a rank did not reach the exchange in time (direct peer transport)";
@@ -164,6 +166,7 @@ void comm_destroy(Comm* c) {
     c->regs.clear();
     if (c->flags_host) (void)hipHostUnregister(c->flags_host);
     if (c->status_host) (void)hipHostFree(c->status_host);
+    if (c->fail_dev) (void)hipFree(c->fail_dev);
     if (c->xcd_count) (void)hipFree(c->xcd_count);
   }
   if (c->shm) { munmap((void*)c->shm, c->shm_bytes); if (c->rank == 0) shm_unlink(c->shm_name.c_str()); }
@@ -330,7 +333,10 @@ Comm* comm_create(int world, int rank, const char* id_path, int transport, size_
       c->status_host[0] = 0;
       if (hipHostGetDevicePointer((void**)&c->status_dev, c->status_host, 0) != hipSuccess) return fail("hipHostGetDevicePointer failed");
       if (hipMalloc((void**)&c->xcd_count, 64) != hipSuccess || hipMemset(c->xcd_count, 0, 64) != hipSuccess) return fail("hipMalloc failed");
-      c->peer_timeout_s = getenv("VV_COMM_TIMEOUT") ? atof(getenv("VV_COMM_TIMEOUT")) : 30.0;
+      if (hipMalloc((void**)&c->fail_dev, 64) != hipSuccess || hipMemset(c->fail_dev, 0, 64) != hipSuccess) return fail("hipMalloc failed");
+      // (the same default as every other wait of the transports: a rank held up by a long host pause -- first-use kernel load, snapshot
+      // I/O -- must not make its peers give up first)
+      c->peer_timeout_s = getenv("VV_COMM_TIMEOUT") ? atof(getenv("VV_COMM_TIMEOUT")) : 120.0;
     }
     if (!shm_barrier(c, timeout_s)) return fail("ranks did not all arrive");
     if (rank == 0) shm_unlink(c->shm_name.c_str());     // every rank holds its mapping: the name has done its job (nothing is left behind, crash or not)
@@ -347,8 +353,11 @@ Comm* comm_create(int world, int rank, const char* id_path, int transport, size_
 // (where a peer's read over xGMI is served) without relying on the scope the runtime gives a kernel's end-of-kernel release; workgroup 0
 // waits for the other seven (a device counter), raises this rank's flag to seq (release, system scope), and lane r waits for rank r's
 // flag.  One wave polls: it occupies nothing a peer process on the same device needs in order to get there.  A wait that outlasts
-// `timeout_ticks` (100 MHz) gives up and sets *status; the host reports it at the next call.
-__global__ void __launch_bounds__(64) k_peer_meet(uint32_t* flags, uint32_t* xcd_count, int world, int rank, uint32_t seq, unsigned long long timeout_ticks, uint32_t* status) {
+// `timeout_ticks` (100 MHz) gives up and sets *status (host-visible: every later entry point fails) and *fail_dev (device memory: the
+// reduce / gather kernels and the update queued behind this meeting on the stream return at once instead of working on a peer's
+// incomplete data).  Neither word is ever cleared: a failed exchange is FATAL for the context -- the ranks' parameters can no longer be
+// assumed equal; the job restarts from a snapshot.
+__global__ void __launch_bounds__(64) k_peer_meet(uint32_t* flags, uint32_t* xcd_count, int world, int rank, uint32_t seq, unsigned long long timeout_ticks, uint32_t* status, uint32_t* fail_dev) {
   const int t = threadIdx.x;
   __atomic_thread_fence(__ATOMIC_RELEASE);                       // (system scope: buffer_wbl2 sc0 sc1)
   if (blockIdx.x != 0) {
@@ -361,7 +370,7 @@ __global__ void __launch_bounds__(64) k_peer_meet(uint32_t* flags, uint32_t* xcd
     unsigned spins = 0;
     while ((int32_t)(__hip_atomic_load(xcd_count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
       __builtin_amdgcn_s_sleep(2);
-      if ((++spins & 255u) == 0 && wall_clock64() - t0 > timeout_ticks) { __hip_atomic_store(status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+      if ((++spins & 255u) == 0 && wall_clock64() - t0 > timeout_ticks) { __hip_atomic_store(fail_dev, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
     }
     __hip_atomic_store(flags + (size_t)rank * kPeerFlagStride, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
@@ -369,7 +378,7 @@ __global__ void __launch_bounds__(64) k_peer_meet(uint32_t* flags, uint32_t* xcd
     unsigned spins = 0;
     while ((int32_t)(__hip_atomic_load(flags + (size_t)t * kPeerFlagStride, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
       __builtin_amdgcn_s_sleep(8);
-      if ((++spins & 255u) == 0 && wall_clock64() - t0 > timeout_ticks) { __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+      if ((++spins & 255u) == 0 && wall_clock64() - t0 > timeout_ticks) { __hip_atomic_store(fail_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
     }
   }
 }
@@ -387,7 +396,8 @@ __device__ __forceinline__ float ld_peer4(const float* p) {
 struct PeerSrc { const float* p[kPeerMax]; };
 // out[i] = ((src0[i] + src1[i]) + src2[i]) + ...   -- rank order, the order of the shared-memory transport's sums
 template <int WORLD>      // 0: any world (run-time loop)
-__global__ void __launch_bounds__(256) k_peer_reduce(PeerSrc src, float* __restrict__ out, size_t n, int world_rt, int vec) {
+__global__ void __launch_bounds__(256) k_peer_reduce(PeerSrc src, float* __restrict__ out, size_t n, int world_rt, int vec, const uint32_t* fail_dev) {
+  if (__hip_atomic_load(fail_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;      // the meeting in front gave up: a peer's data is not there
   const int world = WORLD ? WORLD : world_rt;
   const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nth = (size_t)gridDim.x * 256;
   const size_t n2 = vec ? n / 2 : 0;
@@ -416,12 +426,14 @@ __global__ void __launch_bounds__(256) k_peer_reduce(PeerSrc src, float* __restr
 constexpr int kGatherBufs = 4;
 struct GatherArgs {
   int n, world, rank, blocks_per_piece;
+  const uint32_t* fail_dev;
   unsigned char* dst[kGatherBufs];                       // this rank's buffers
   const unsigned char* src[kGatherBufs][kPeerMax];       // the same buffers in every rank (peer mappings)
   size_t stride[kGatherBufs], total[kGatherBufs];        // rank r owns bytes [r stride, min((r + 1) stride, total))
 };
 // piece (buffer i, peer r) = blockIdx.y: the peer's own bytes of buffer i pulled into this rank's copy
 __global__ void __launch_bounds__(256) k_peer_gather(GatherArgs g) {
+  if (__hip_atomic_load(g.fail_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;    // the meeting in front gave up
   const int i = blockIdx.y / g.world, r = blockIdx.y % g.world;
   if (r == g.rank) return;
   const size_t lo = (size_t)r * g.stride[i];
@@ -483,7 +495,7 @@ static int peer_meet(Comm* c) {
   if (c->status_host && *(volatile uint32_t*)c->status_host) { c->err = "a rank did not reach the exchange in time (direct peer transport)"; return -1; }
   if (c->world == 1) return 0;
   ++c->seq;
-  k_peer_meet<<<8, 64, 0, c->cur>>>(c->flags_dev, c->xcd_count, c->world, c->rank, c->seq, (unsigned long long)(c->peer_timeout_s * 1e8), c->status_dev);
+  k_peer_meet<<<8, 64, 0, c->cur>>>(c->flags_dev, c->xcd_count, c->world, c->rank, c->seq, (unsigned long long)(c->peer_timeout_s * 1e8), c->status_dev, c->fail_dev);
   return hipGetLastError() == hipSuccess ? 0 : (c->err = "launch of the meeting kernel failed", -1);
 }
 
@@ -499,10 +511,10 @@ static int peer_reduce_range(Comm* c, float* buf, size_t lo, size_t n) {
   const size_t work = vec ? (n + 1) / 2 : n;
   const int blocks = (int)std::min<size_t>(1024, std::max<size_t>(1, (work + 255) / 256));
   switch (c->world) {
-    case 2: k_peer_reduce<2><<<blocks, 256, 0, c->cur>>>(src, buf + lo, n, c->world, vec); break;
-    case 4: k_peer_reduce<4><<<blocks, 256, 0, c->cur>>>(src, buf + lo, n, c->world, vec); break;
-    case 8: k_peer_reduce<8><<<blocks, 256, 0, c->cur>>>(src, buf + lo, n, c->world, vec); break;
-    default: k_peer_reduce<0><<<blocks, 256, 0, c->cur>>>(src, buf + lo, n, c->world, vec); break;
+    case 2: k_peer_reduce<2><<<blocks, 256, 0, c->cur>>>(src, buf + lo, n, c->world, vec, c->fail_dev); break;
+    case 4: k_peer_reduce<4><<<blocks, 256, 0, c->cur>>>(src, buf + lo, n, c->world, vec, c->fail_dev); break;
+    case 8: k_peer_reduce<8><<<blocks, 256, 0, c->cur>>>(src, buf + lo, n, c->world, vec, c->fail_dev); break;
+    default: k_peer_reduce<0><<<blocks, 256, 0, c->cur>>>(src, buf + lo, n, c->world, vec, c->fail_dev); break;
   }
   return hipGetLastError() == hipSuccess ? 0 : (c->err = "launch of the reduce kernel failed", -1);
 }
@@ -512,7 +524,7 @@ static int peer_gather(Comm* c, void* const* bufs, const size_t* stride, const s
   if (n > kGatherBufs) { c->err = "too many buffers in one all-gather"; return -1; }
   GatherArgs g;
   memset(&g, 0, sizeof(g));
-  g.n = n; g.world = c->world; g.rank = c->rank;
+  g.n = n; g.world = c->world; g.rank = c->rank; g.fail_dev = c->fail_dev;
   size_t largest = 0;
   for (int i = 0; i < n; ++i) {
     PeerReg* reg = peer_reg(c, bufs[i]);

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(NT) void k_score_loss(ScoreArgs a) {
   const int D = a.D, C = a.C, Nn = a.Nn, CN = C + Nn;
   float* A = sm;               // [D] context mean
   float* Ah = A + D;           // [D] normalised context mean
-  const int PD = D > 1024 ? D : 1024;
+  const int PD = D > 4 * NT ? D : 4 * NT;   // (phase 4: G row groups of D columns, G D <= 4 NT when D / 4 < NT -- score_loss_lds() sizes the same)
   float* acc0 = Ah + D;        // [G][D] row-group partial dAh (G*D <= PD)
   float* acc1 = acc0 + PD;     // [G][D] row-group partial db
   float* n2 = acc1 + PD;       // [CN] squared norms
@@ -1189,9 +1189,11 @@ void launch_score_loss(int prec, const ScoreArgs& a_in, hipStream_t s) {
   ScoreArgs a = a_in;
   a.items_rr = 1;          // per-instance rows (dense execution): an item's rows are contiguous already; XCD ranges measured + 1 us (42.8 against 41.8)
   if (ko().score_reg && (prec == 0 ? launch_score_loss_reg<F16>(a, s) : launch_score_loss_reg<BF16>(a, s))) return;
-  const size_t lds = sizeof(float) * ((size_t)2 * a.D + 2 * (a.D > 1024 ? a.D : 1024) + 8 * (a.C + a.Nn) + 16);
   const bool vec = a.D % 4 == 0;
   const bool wide = vec && a.D >= 2048 && a.B <= 512;       // few items of wide rows: sixteen waves per item
+  // the two [G][D] partial-sum areas hold G D <= 4 NT floats (with the 1024-thread form and D = 2048 they ran over at a fixed 1024)
+  const int nt = wide ? 1024 : SL_THREADS;
+  const size_t lds = sizeof(float) * ((size_t)2 * a.D + 2 * (size_t)(a.D > 4 * nt ? a.D : 4 * nt) + 8 * (a.C + a.Nn) + 16);
   const dim3 grid(a.B), block(wide ? 1024 : SL_THREADS);
 #define VV_SL(T, V, NT)                                                                          \
   do {                                                                                           \
@@ -1396,6 +1398,7 @@ void launch_reduce(const ReduceArgs& a, hipStream_t s) {
 // max |w| for the f16 range guard.
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void k_sgd(SgdArgs a) {
+  if (a.skip_if && __hip_atomic_load(a.skip_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // (a failed exchange in front: SgdArgs::skip_if)
   const float sw = a.scales->sw_next;
   const int64_t nW = (int64_t)a.D * a.F;
   const float lr_w = a.rate * a.lr_mult_w, dc_w = a.weight_decay * a.decay_mult_w;

@@ -172,6 +172,20 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm(FwdArgs a) {
   const float descale = 1.0f / (a.scales->sx * a.scales->sw_cur);
   const float dscale = DROP ? 1.0f / (1.0f - a.drop_ratio) : 1.0f;
   const float lo = a.relu ? 0.f : -INFINITY;
+  // the lane's 16 bias values, loaded once and together (inside the store loop every quad waited for its own loads AND -- vmcnt counts
+  // stores -- for the previous quad's store: kernels_gemm_ph.hip, epilogue)
+  float bq[4][4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int n = n0 + wn * 64 + ni * 16 + fq * 4;
+    if (VEC) {
+      const float4 b4 = n < a.D ? *(const float4*)(a.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      bq[ni][0] = b4.x; bq[ni][1] = b4.y; bq[ni][2] = b4.z; bq[ni][3] = b4.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bq[ni][j] = n + j < a.D ? a.bias[n + j] : 0.f;
+    }
+  }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int m = m0 + wm * (MI * 16) + mi * 16 + frow;
@@ -188,8 +202,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm(FwdArgs a) {
       float v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float bj = (n + j < a.D) ? a.bias[n + j] : 0.f;
-        v[j] = fmaxf(acc[mi][ni][j] * descale + bj, lo);
+        v[j] = fmaxf(acc[mi][ni][j] * descale + bq[ni][j], lo);
         if (DROP) {
           const uint64_t e = (uint64_t)(ref_row * a.D + n + j);
           bool keep;

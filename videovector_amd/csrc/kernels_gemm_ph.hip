@@ -110,6 +110,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int HROWS = 32 * MQ;               // rows of the lower A half-tile (upper: HROWS - 16 DEAD)
   constexpr int BMT = 2 * HROWS - 16 * DEAD;   // rows of the output tile
+  if (ABL & 512) asm volatile("s_memtime s[84:85]\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b32 s101, s84" ::: "s84", "s85", "s101");   // (lab: time stamps, below)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -243,25 +244,59 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
 #define PH_MFMA(mh, nh, bfr)                                                                         \
   __builtin_amdgcn_s_barrier();                                                                      \
   __builtin_amdgcn_sched_barrier(0);                                                                 \
+  PH_TS("s[90:91]")                                                                                        \
   if (!abl_mm) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int mi = 0; mi < MQ; ++mi) \
     if (!(DEAD && (mh) == 1 && mi == MQ - 1 && dead_hi))                                             \
     _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                 \
       acc[mh][mi][nh][ni] = T::mfma(bfr[ni][kk], af[mi][kk], acc[mh][mi][nh][ni]);                   \
   __builtin_amdgcn_sched_barrier(0);                                                                 \
+  if (TS) {           /* the stamps consumed here were taken at least one MFMA segment ago */       \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"                                                          \
+                 "s_sub_u32 s100, s92, s94\n\ts_add_u32 s98, s98, s100\n\t"   /* mfma += d - previous c */ \
+                 "s_sub_u32 s100, s84, s92\n\ts_add_u32 s99, s99, s100\n\t"   /* bar2 += e - d */          \
+                 "s_sub_u32 s100, s86, s84\n\ts_add_u32 s95, s95, s100\n\t"   /* load += b0 - e */         \
+                 "s_sub_u32 s100, s88, s86\n\ts_add_u32 s96, s96, s100\n\t"   /* vmwait += b - b0 */       \
+                 "s_sub_u32 s100, s90, s88\n\ts_add_u32 s97, s97, s100\n\t"   /* bar1 += c - b */          \
+                 "s_mov_b32 s94, s90\n\ts_memtime s[92:93]" ::: PH_TS_CLOB);                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+  }                                                                                                  \
   __builtin_amdgcn_s_barrier();                                                                      \
-  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_sched_barrier(0);                                                                 \
+  PH_TS("s[84:85]")
   // stream step of phase (t, p): half-tile 4t + p + 6, then the counted wait for what the next phase reads
 #define PH_STREAM(tpar, t, p, wait)                                                                  \
   {                                                                                                  \
     const int h = 4 * (t) + (p) + 6;                                                                 \
     constexpr int q_ = ((p) + 2) & 3;                                                                \
     constexpr int slot_ = (LEAD && q_ == 0) ? PH_RING(J + 3) : 4 * (((tpar) + (((p) + 6) >> 2)) & 1) + q_;   /* A_lo's place (p = 2) carries K-tile t + 3 */ \
-    if ((!CHK || h < H) && !abl_st) { issue(h >> 2, q_, slot_); if (wait) PH_WAITQ(); }              \
-    else if (wait) PH_WAIT(0);                                                                       \
+    if ((!CHK || h < H) && !abl_st) { issue(h >> 2, q_, slot_); PH_TS("s[86:87]") if (wait) PH_WAITQ(); }  \
+    else { PH_TS("s[86:87]") if (wait) PH_WAIT(0); }                                                    \
+    PH_TS("s[88:89]")                                                                              \
   }
   // ABL: timing studies only (VV_ABLATE, results wrong): 1 no LDS-DMA stream in the loop, 2 no MFMA, 4 no fragment
   // reads, 8 every gathered row is the (L2-hot) zero row
   constexpr bool abl_st = ABL & 1, abl_mm = ABL & 2, abl_rd = ABL & 4;
+  // (lab, ABL 512: TIME STAMPS.  Every wave reads the shader clock (s_memtime) right after each of the two barriers of a phase, after its
+  // stream issue, after its counted wait and after its last MFMA issue, and keeps five sums -- load segment up to the wait / the counted
+  // vmcnt wait / barrier behind the load segment / MFMA segment / barrier behind it; lane 0 of every wave writes them, the kernel's cycles
+  // and its 100 MHz real time to FwdArgs::mask (as uint32[12] per wave) at the end.  tools/lab/fwd_dr_lab.hip prints them.
+  // Stamps and sums live in FIXED scalar registers s78..s101 that only these assembly blocks name (the kernel itself needs ~62 SGPRs and
+  // the allocator hands them out from s0 upwards; as compiler-visible values every stamp was spilled to a VGPR lane on the spot -- 700
+  // v_writelane / v_readlane in the loop -- and as `s_memtime` builtins each one was followed by s_waitcnt lgkmcnt(0), draining the wave's
+  // fragment reads).  A stamp is read only behind the explicit lgkmcnt(0) of the consuming block, which sits behind the phase's MFMAs --
+  // where the fragments have been waited for anyway.
+  //   s[84:85] e (after the barrier behind the MFMA segment = start of the load segment)   s[86:87] b0 (stream issued)
+  //   s[88:89] b (counted wait passed)   s[90:91] c (after the barrier behind the load segment)   s[92:93] d (last MFMA issued)
+  //   s94 previous c   s95..s99 sums: load, vmwait, bar1, mfma, bar2   s100 scratch   s101 kernel start   s83 loop start   s[78:79] real time)
+  constexpr bool TS = (ABL & 512) != 0;
+#define PH_TS_CLOB "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s100", "s101", "scc"
+#define PH_TS(pair) if (TS) { asm volatile("s_memtime " pair ::: PH_TS_CLOB); __builtin_amdgcn_sched_barrier(0); }
+  if (TS) {
+    asm volatile("s_memrealtime s[78:79]\n\ts_memtime s[84:85]\n\ts_waitcnt lgkmcnt(0)\n\t"
+                 "s_mov_b32 s83, s84\n\ts_mov_b32 s86, s84\n\ts_mov_b32 s88, s84\n\ts_mov_b32 s90, s84\n\ts_mov_b32 s92, s84\n\ts_mov_b32 s94, s84\n\t"
+                 "s_mov_b32 s95, 0\n\ts_mov_b32 s96, 0\n\ts_mov_b32 s97, 0\n\ts_mov_b32 s98, 0\n\ts_mov_b32 s99, 0" ::: PH_TS_CLOB);
+    __builtin_amdgcn_sched_barrier(0);
+  }
   if (abl_rd) {
 #pragma unroll
     for (int mi = 0; mi < MQ; ++mi) { af[mi][0] = i16x8{1, 2, 3, 4, 5, 6, 7, (short)mi}; af[mi][1] = af[mi][0]; }
@@ -301,6 +336,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
     ktile(t, I0{}, I0{}, std::true_type{}); ktile(t + 1, I1{}, I1{}, std::true_type{});
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();   // waves 0-3 catch the extra barrier of waves 4-7
+  if (TS) asm volatile("s_memtime s[80:81]\n\ts_waitcnt lgkmcnt(0)" ::: PH_TS_CLOB);      // s80: end of the K loop
 #undef PH_LOAD_A
 #undef PH_LOAD_B
 #undef PH_MFMA
@@ -319,6 +355,24 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
   const uint32_t drop_thr = DROP ? (uint32_t)(a.drop_ratio * 65536.f + 0.5f) : 0u;      // keep <=> 16-bit uniform >= thr
   const uint32_t drop_s32 = DROP ? (uint32_t)(mix64(a.drop_seed, 0x5eedull) >> 32) : 0u;  // the step's stream
   const float lo = a.relu ? 0.f : -INFINITY;
+  // The lane's 16 bias values (its four output quads), loaded ONCE and all together.  Round 5, from the kernel's own time stamps
+  // (profiles/r05_fwd_stamps.txt): with the loads inside the store loop hipcc put four scalar-dword loads and an s_waitcnt vmcnt(0)
+  // in front of EVERY one of the 24 stores -- vmcnt counts stores too, so each quad waited for its bias round trip AND for the previous
+  // quad's store to be acknowledged: 24 serial round trips, 23 000 clocks (11 us) from the last MFMA to the last store.
+  float bq[2][2][4];
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int n = n0 + nh * 128 + wn * 32 + ni * 16 + fq * 4;
+      if (VEC) {                               // (D % 4 == 0 and n % 4 == 0: the quad is inside [0, D) or outside as a whole)
+        const float4 b4 = n < a.D ? *(const float4*)(a.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bq[nh][ni][0] = b4.x * dscale; bq[nh][ni][1] = b4.y * dscale; bq[nh][ni][2] = b4.z * dscale; bq[nh][ni][3] = b4.w * dscale;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bq[nh][ni][j] = (n + j < a.D ? a.bias[n + j] : 0.f) * dscale;
+      }
+    }
 #pragma unroll
   for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -351,9 +405,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
           }
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float bj = (n + j < a.D) ? a.bias[n + j] : 0.f;
             // (dropout: the 1 / (1 - ratio) of the kept values rides in the descale and the bias -- ReLU commutes with a positive factor)
-            v[j] = fmaxf(acc[mh][mi][nh][ni][j] * descale_d + bj * dscale, lo);
+            v[j] = fmaxf(acc[mh][mi][nh][ni][j] * descale_d + bq[nh][ni][j], lo);
             if (DROP) {
               bool keep;
               if (DROP == 2) keep = (n + j < a.D) && a.mask[(uint64_t)(ref_row * a.D + n + j)] != 0;
@@ -368,6 +421,26 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
             for (int j = 0; j < 4; ++j) if (n + j < a.D) dst[j] = v[j];
         }
     }
+  if (TS) {
+    uint32_t o_[12];
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime s[84:85]\n\ts_memrealtime s[86:87]\n\ts_waitcnt lgkmcnt(0)\n\t"
+                 "s_mov_b32 %0, s95\n\ts_mov_b32 %1, s96\n\ts_mov_b32 %2, s97\n\ts_mov_b32 %3, s98\n\ts_mov_b32 %4, s99\n\t"
+                 "s_sub_u32 %5, s83, s101\n\t"        /* up to the loop's first phase (prologue: row ids, first six half-tiles, first wait) */
+                 "s_sub_u32 %6, s80, s101\n\t"        /* ... to the end of the K loop */
+                 "s_sub_u32 %7, s84, s101\n\t"        /* ... to the last store's completion */
+                 "s_sub_u32 %8, s86, s78\n\t"         /* 100 MHz ticks from the loop's start to the end */
+                 "s_sub_u32 %9, s84, s83"              /* shader clocks over the same span */
+                 : "=s"(o_[0]), "=s"(o_[1]), "=s"(o_[2]), "=s"(o_[3]), "=s"(o_[4]), "=s"(o_[5]), "=s"(o_[6]), "=s"(o_[7]), "=s"(o_[8]), "=s"(o_[9])
+                 :: PH_TS_CLOB, "memory");
+    if (lane == 0) {
+      uint32_t* o = (uint32_t*)a.mask + ((size_t)blockIdx.x * 8 + wave) * 12;
+#pragma unroll
+      for (int j = 0; j < 10; ++j) o[j] = o_[j];
+      o[10] = 0; o[11] = 0;
+    }
+  }
+#undef PH_TS
+#undef PH_TS_CLOB
 }
 
 #ifdef VV_LAB

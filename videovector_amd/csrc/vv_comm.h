@@ -29,6 +29,7 @@ void comm_use_stream(Comm* c, hipStream_t s);   // the collectives called from n
                                                 // events between the two); nullptr: back to the communication stream
 int comm_record_done(Comm* c);             // records comm_done_event behind everything queued on the communication stream
 const char* comm_error(Comm* c);
+const uint32_t* comm_fail_flag(Comm* c);   // device word, != 0 once an exchange gave up (direct peer transport; null otherwise): the update behind it is skipped
 bool comm_failed(Comm* c);                 // a wait inside the exchange gave up (direct peer transport: a rank is missing); comm_error says so
 int comm_world(Comm* c);
 int comm_rank(Comm* c);

@@ -314,6 +314,9 @@ struct SgdArgs {
   // the workgroup whose add is the last sets *pub_flag = pub_seq (and clears the counter for the next chunk).  The
   // consumer polls the flag and runs an agent-scope acquire (FwdArgs::gate).  No separate launch, no L2 write-back.
   int32_t* pub_flag = nullptr; int32_t* pub_count = nullptr; int32_t pub_seq = 0;
+  // data-parallel, direct peer transport: != 0 once an exchange in front of this launch gave up (a rank is missing) -- the gradient is
+  // not the sum over the ranks; the launch changes nothing (and publishes nothing: the failure is fatal for the context, comm.hip)
+  const uint32_t* skip_if = nullptr;
 };
 
 // Reduction and update in one launch (k_reduce_sgd; api.hip: the lazy reduction).  r: what k_reduce would have been given (its

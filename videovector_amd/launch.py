@@ -37,13 +37,22 @@ def rank_env(rank, world, port, run_id, base=None):
     return env
 
 
+# prctl is bound ONCE, at import time in the launcher: between fork and exec the child must not dlopen or allocate (the launcher may have
+# other threads holding the loader's or malloc's lock at the moment of the fork) -- it only calls the function already resolved
+try:
+    _PRCTL = ctypes.CDLL(None, use_errno=True).prctl
+    _PRCTL.argtypes = [ctypes.c_int, ctypes.c_ulong, ctypes.c_ulong, ctypes.c_ulong, ctypes.c_ulong]
+    _PRCTL.restype = ctypes.c_int
+except Exception:                                 # no libc prctl (not Linux): ranks are then stopped by the launcher's own handlers only
+    _PRCTL = None
+_PDEATHSIG_MSG = b"[vv launch] prctl(PR_SET_PDEATHSIG) failed in a rank: it will not be signalled should the launcher be killed\n"
+
+
 def _child_setup():
     """In the rank, between fork and exec: own session; SIGTERM when the launcher dies."""
     os.setsid()
-    try:
-        ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGTERM), 0, 0, 0)      # PR_SET_PDEATHSIG = 1
-    except Exception:
-        pass
+    if _PRCTL is not None and _PRCTL(1, int(signal.SIGTERM), 0, 0, 0) != 0:      # PR_SET_PDEATHSIG = 1
+        os.write(2, _PDEATHSIG_MSG)               # (the launcher's stderr: a raw write, nothing that allocates or locks)
 
 
 class _Stopped(SystemExit):
