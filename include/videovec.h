@@ -69,6 +69,8 @@ int vv_set_dedup(vv_ctx* ctx, int on);
  *   "comm_gate" (VV_COMM_GATE, 1)    the overlapped update gates the next forward GEMM chunk by chunk (0: the stream joins)
  *   "comm_inline" (VV_COMM_INLINE, 1)  the SHARDED update's three steps (reduce-scatter, the rule on this rank's rows, all-gather) are queued
  *                                    on the compute stream itself (0: on the communication stream, the next forward GEMM gated on one flag)
+ *   "comm_first_inline" (VV_COMM_FIRST_INLINE, 1)  the OVERLAPPED update's first F-chunk (exchange, rule, publish) is queued on the compute stream,
+ *                                    the others on the communication stream (0: all of them there, the next forward GEMM waits at its first gate for the hand-off)
  *   "comm_chunks" (VV_COMM_CHUNKS, 3)  F-chunks of the overlapped update, 1 .. 4
  *   "comm_test_delay_us" (VV_COMM_TEST_DELAY_US, 0)  TEST HOOK: holds the communication stream this long in front of every chunk
  * Ablated / experimental kernels (timing studies whose results may be wrong) are NOT reachable through this library: they and their

@@ -176,9 +176,11 @@ static int create_init(vv_ctx* c) {
   HIPCHK(hipHostMalloc((void**)&c->U_host, 2 * sizeof(int32_t), hipHostMallocMapped));   // {U, saturated f16 gradient sums}
   c->U_host[0] = c->U_host[1] = 0;
   HIPCHK(hipHostGetDevicePointer((void**)&c->U_host_dev, c->U_host, 0));
-  HIPCHK(hipMalloc(&c->w_gate, (W_CHUNKS_MAX + 1) * W_GATE_STRIDE * sizeof(int32_t)));
-  HIPCHK(hipMemset(c->w_gate, 0, (W_CHUNKS_MAX + 1) * W_GATE_STRIDE * sizeof(int32_t)));
+  HIPCHK(hipMalloc(&c->w_gate, (W_CHUNKS_MAX + 2) * W_GATE_STRIDE * sizeof(int32_t)));
+  HIPCHK(hipMemset(c->w_gate, 0, (W_CHUNKS_MAX + 2) * W_GATE_STRIDE * sizeof(int32_t)));
   c->pub_count = c->w_gate + W_CHUNKS_MAX * W_GATE_STRIDE;      // the arrival counter of the publishing kernels: a line of its own
+  c->pub_count0 = c->pub_count + W_GATE_STRIDE;                 // ... and the one of the FIRST chunk's kernel, which runs on the compute stream beside them
+  if (const char* v = opt_env("VV_COMM_FIRST_INLINE")) c->overlap_first_inline = atoi(v) != 0;
   { const char* nc = opt_env("VV_COMM_CHUNKS"); if (nc) c->n_chunks = std::max(1, std::min(W_CHUNKS_MAX, atoi(nc))); }
   HIPCHK(hipEventCreateWithFlags(&c->ev_chunk0, hipEventDisableTiming));
   HIPCHK(hipHostMalloc((void**)&c->gate_err, sizeof(int32_t), hipHostMallocMapped));
@@ -287,6 +289,7 @@ int vv_set_option(vv_ctx* c, const char* name, double value) {
   if (n == "score_stream") { c->ko.score_stream = iv; return VV_OK; }
   if (n == "comm_gate") { c->comm_gate = iv != 0; return VV_OK; }
   if (n == "comm_inline") { c->comm_inline = iv != 0; return VV_OK; }
+  if (n == "comm_first_inline") { c->overlap_first_inline = iv != 0; return VV_OK; }
   if (n == "comm_chunks") { c->n_chunks = std::max(1, std::min(W_CHUNKS_MAX, iv)); return VV_OK; }
   if (n == "comm_test_delay_us") { c->comm_test_delay_us = iv; return VV_OK; }
 #ifdef VV_LAB
@@ -311,6 +314,7 @@ int vv_get_option(vv_ctx* c, const char* name, double* value) {
   else if (n == "score_stream") *value = c->ko.score_stream;
   else if (n == "comm_gate") *value = c->comm_gate;
   else if (n == "comm_inline") *value = c->comm_inline;
+  else if (n == "comm_first_inline") *value = c->overlap_first_inline;
   else if (n == "comm_chunks") *value = c->n_chunks;
   else if (n == "comm_test_delay_us") *value = c->comm_test_delay_us;
   else return fail(VV_ERR_ARG, "vv_get_option: unknown option '%s'", name);
@@ -992,6 +996,14 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   SegsumArgs ga;
   if (seg) {
     sa.V = c->segV; sa.rec = c->seg_rec;
+#ifdef VV_LAB
+    if (lab_env("VV_LAB_SCORE_TS")) {
+      // (lab) k_score_fwd's phase stamps: one buffer, every step overwrites it; tools/lab/score_ts.py reads it through vv_lab_score_ts
+      static thread_local uint32_t* ts_buf = nullptr;
+      if (!ts_buf) { HIPCHK(hipMalloc(&ts_buf, (size_t)65536 * 16 * 4)); HIPCHK(hipMemset(ts_buf, 0, (size_t)65536 * 16 * 4)); }
+      sa.lab_ts = ts_buf; c->lab_score_ts = ts_buf;
+    }
+#endif
     if (gd.gg && proactive) { sa.bound_out = c->gg_bound; sa.bound_seq = seq; }
     ba.H = c->H; ba.V = c->segV; ba.rec = c->seg_rec; ba.seg_start = c->dd_seg; ba.info = c->dd_info; ba.dYu = c->dYu;
     ba.dbp = c->seg_dbp; ba.Rp = c->Rp; ba.D = D; ba.Dp = c->Dp; ba.inv_sg = 1.f / c->sg;
@@ -1290,23 +1302,37 @@ int vv_apply_update(vv_ctx* c, const vv_step_cfg* cfg) {
     const int32_t useq = ++c->upd_seq;
     const int nch = chunk_plan(c);               // (the layout k_reduce wrote: same Fp, same plan)
     a.pub_count = c->pub_count; a.pub_seq = useq;
+    // Round 5: the FIRST chunk stays on the compute stream (overlap_first_inline, default).  The next forward GEMM cannot pass its first
+    // gate before chunk 0 has arrived whatever stream brings it -- on the communication stream it arrived behind the hand-off chain
+    // [event -> that stream wakes -> the collective's launch -> k_sgd on the CUs the waiting GEMM leaves free -> publish], ~17 us during
+    // which the GEMM sat at the gate (profiles/r04_overlap_cost.txt: overlap = sync + 20 us on one rank).  In-stream, chunk 0's exchange and
+    // update are the synchronous schedule's (no hand-off, the whole chip for its k_sgd), the GEMM starts behind them with gate 0 open, and the
+    // chain of chunk 1 runs beside the GEMM's first K-tiles (chunk 0's columns: half of the loop) instead of in front of them.
+    const bool first_inl = c->overlap_first_inline && nch > 1;
+    struct StreamScope { vv::Comm* k; ~StreamScope() { vv::comm_use_stream(k, nullptr); } } scope{c->comm};
     for (int k = 0; k < nch; ++k) {
-      // chunk 0 may start as soon as ITS reduction is done (ev_chunk0, fb_impl); the others follow the whole backward pass
-      hipEvent_t after = k == 0 ? (c->chunk0_event ? c->ev_chunk0 : c->ev_chunk) : (k == 1 && c->chunk0_event ? c->ev_chunk : nullptr);
+      const bool inl = first_inl && k == 0;
+      hipStream_t ks = inl ? c->stream : cs;
+      // (second-stream form) chunk 0 may start as soon as ITS reduction is done (ev_chunk0, fb_impl); the others follow the whole backward pass
+      hipEvent_t after = inl ? nullptr : (first_inl ? (k == 1 ? c->ev_chunk : nullptr)
+                          : (k == 0 ? (c->chunk0_event ? c->ev_chunk0 : c->ev_chunk) : (k == 1 && c->chunk0_event ? c->ev_chunk : nullptr)));
       const int c0 = std::min(c->F, c->chunk_kt[k] * BK), c1 = std::min(c->F, c->chunk_kt[k + 1] * BK);
       const bool last = k == nch - 1;
       const size_t off = (size_t)c->D * c0, n = (size_t)c->D * (c1 - c0) + (last ? (size_t)c->D : 0);
       const int delay_us = c->comm_test_delay_us;
       if (after) HIPCHK(hipStreamWaitEvent(cs, after, 0));
-      if (delay_us > 0) launch_delay(delay_us, cs);      // test hook: a slow exchange, so that the next forward GEMM really waits at its gates
+      if (delay_us > 0) launch_delay(delay_us, ks);      // test hook: a slow exchange, so that the next forward GEMM really waits at its gates
       const bool skip_ar1 = c->comm_skip_ar1;   // (lab) diagnosis: no collective call at world 1
+      vv::comm_use_stream(c->comm, inl ? c->stream : nullptr);
       if (!(skip_ar1 && vv::comm_world(c->comm) == 1) && n > 0 && vv::comm_allreduce(c->comm, c->grads, off, n, nullptr))
         return fail(VV_ERR_HIP, "all-reduce: %s", vv::comm_error(c->comm));
       a.chunked = 1; a.f_begin = c0; a.f_count = c1 - c0; a.do_bias = last; a.set_scale = k == 0;
       a.blk_off = k * (SGD_BLOCKS / nch); a.n_blk = last ? SGD_BLOCKS - a.blk_off : SGD_BLOCKS / nch;      // together: every slot of wmax_blocks
       a.pub_flag = c->w_gate + k * W_GATE_STRIDE;          // the kernel's last workgroup publishes the chunk (SgdArgs::pub_flag)
-      if (k == 0) PROFILED(c, "sgd", launch_sgd(c->prec, a, cs)); else launch_sgd(c->prec, a, cs);     // (an empty chunk: its wmax slots become 0, the bias if it is the last)
+      a.pub_count = inl ? c->pub_count0 : c->pub_count;    // (a counter of its own: the chunk-1 kernel may run at the same time)
+      if (k == 0) PROFILED(c, "sgd", launch_sgd(c->prec, a, ks)); else launch_sgd(c->prec, a, ks);     // (an empty chunk: its wmax slots become 0, the bias if it is the last)
     }
+    vv::comm_use_stream(c->comm, nullptr);
     if (vv::comm_record_done(c->comm)) return fail(VV_ERR_HIP, "all-reduce: %s", vv::comm_error(c->comm));
     c->grads_pending = false; c->upd_inflight = true; c->upd_unjoined = false;    // (comm_done_event now marks the end of THIS update, behind the old one)
   } else
@@ -1694,3 +1720,13 @@ int vv_profile_get(vv_ctx* c, const char* kernel, double* avg_ms, int64_t* launc
 }
 
 }  // extern "C"
+
+#ifdef VV_LAB
+// (lab) copies the 16-word stamp records of the last k_score_fwd launch (VV_LAB_SCORE_TS=1) to `out` (n_items x 16 uint32)
+extern "C" int vv_lab_score_ts(vv_ctx* c, uint32_t* out, int n_items) {
+  if (!c || !c->lab_score_ts || !out) return VV_ERR_STATE;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(out, c->lab_score_ts, (size_t)n_items * 16 * 4, hipMemcpyDeviceToHost));
+  return VV_OK;
+}
+#endif

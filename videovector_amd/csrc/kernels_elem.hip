@@ -536,6 +536,16 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
   int* ooff = (int*)(red + 3 * NW);   // [CN] grouped position of channel ch's instance
   const int b = item_of_block(a.items_rr), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float eps = 1e-10f;
+#ifdef VV_LAB
+  // (lab: phase stamps of wave 0, written by thread 0 at the kernel's end -- ScoreArgs::lab_ts)
+  uint32_t ts_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long rt0_ = 0;
+#define SF_TS(i) if (a.lab_ts && wave == 0) ts_[i] = (uint32_t)__builtin_readcyclecounter();
+  if (a.lab_ts && wave == 0) rt0_ = __builtin_amdgcn_s_memrealtime();
+#else
+#define SF_TS(i)
+#endif
+  SF_TS(0)
 
   float4 x[RPW][DV];
 #pragma unroll
@@ -595,6 +605,7 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
     ssq += s * s;
   }
   const float sA = block_sum_w<NW>(ssq, red);
+  SF_TS(1)                                         // the context rows have arrived, first block-wide sum
   const float nA = sqrtf(sA) + eps;
   float* Vb = a.V + (int64_t)2 * b * D;
 #pragma unroll
@@ -623,6 +634,7 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
     if (lane == 63 && qi <= Nn) { const int ch = qi == 0 ? 0 : C + qi - 1; n2[ch] = s; tq[ch] = t; }
   }
   __syncthreads();
+  SF_TS(2)                                         // every wave's target / negative rows have arrived and are reduced
 
   // ---- scores, hinge, loss, coefficients
   const float sp = tq[0] / (sqrtf(n2[0]) + eps);
@@ -652,6 +664,7 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
     if (a.gate_host && b == 0) __hip_atomic_store(a.gate_host, a.gate_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __syncthreads();
+  SF_TS(3)
 
   // ---- dAh = sum_q k3_q x_q from registers; the record of every target / negative instance
   float bnd = 0.f;
@@ -682,6 +695,7 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
   }
   if (lane == 0) red[wave] = bnd;                   // (red is free here: block_sum3_w's readers are past the barrier above)
   __syncthreads();
+  SF_TS(4)
 
   // ---- backward of the context normalisation: dA_b
   float bnd_item = 0.f;
@@ -715,6 +729,19 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
     bnd_item = fmaxf(bnd_item, am * a.drop_scale * a.sg * 4.f * sA * gsum * inv_denA);
     atomicMax(a.bound_out + (b & (GG_BOUND_SLOTS - 1)) * GG_BOUND_STRIDE, ((unsigned long long)(unsigned)a.bound_seq << 32) | __float_as_uint(bnd_item));
   }
+#ifdef VV_LAB
+  SF_TS(5)
+  if (a.lab_ts && tid == 0) {
+    const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+    uint32_t* o = a.lab_ts + (size_t)blockIdx.x * 16;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) o[i] = ts_[i];
+    o[6] = (uint32_t)rt0_; o[7] = (uint32_t)rt1; o[8] = (uint32_t)b;
+    o[9] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 4);           // HW_ID (wave, simd, cu, sh, se ...)
+    o[10] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20);          // XCC_ID
+  }
+#endif
+#undef SF_TS
 }
 
 // ---- the same pass for items that do not fit in registers (D = 1024, hundreds of negatives: the per-GPU shape of BASELINE

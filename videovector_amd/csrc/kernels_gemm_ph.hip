@@ -659,7 +659,22 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
     const int64_t kg0 = (int64_t)(k_begin + c0) * BK;
     const int live = nk_c * BK;
     __syncthreads();                                          // the previous chunk's stream is drained (tail waits)
-    for (int i = tid; i < nk * BK; i += GEMM_THREADS) ids[i] = (i < live && !(ABL & 8)) ? a.rows[kg0 + i] : a.zero_row;
+    {
+      // all of a thread's ids requested together, then stored (round 5: as a plain loop hipcc waited vmcnt(0) for every id before the
+      // next load went out -- five to six serial L2 / HBM round trips in front of the first K-tile at the benchmark's split length)
+      constexpr int NID = PH_WG_IDS / GEMM_THREADS;
+      int32_t idv[NID];
+#pragma unroll
+      for (int j = 0; j < NID; ++j) {
+        const int i = tid + j * GEMM_THREADS;
+        idv[j] = (i < live && !(ABL & 8)) ? a.rows[kg0 + i] : a.zero_row;
+      }
+#pragma unroll
+      for (int j = 0; j < NID; ++j) {
+        const int i = tid + j * GEMM_THREADS;
+        if (i < nk * BK) ids[i] = idv[j];
+      }
+    }
     __syncthreads();
     const uint16_t* pa0 = a.dYh + (kg0 + srow0) * a.Dp + m0 + scol0;
     const uint16_t* pa1 = a.dYh + (kg0 + srow1) * a.Dp + m0 + scol1;

@@ -138,6 +138,7 @@ struct vv_ctx {
   vv::KernelOpts ko;                // which kernels the launchers pick (vv_internal.h)
   bool fuse_update = true;          // "fuse_update" / VV_FUSE_UPDATE=0: reduce at the end of every backward pass, update apart
   bool comm_gate = true;            // "comm_gate" / VV_COMM_GATE=0: the overlapped update never gates the forward GEMM (the stream joins)
+  uint32_t* lab_score_ts = nullptr;         // (lab builds) device buffer of k_score_fwd's phase stamps, api.hip
   bool comm_inline = true;                  // option "comm_inline" (VV_COMM_INLINE): the sharded update queued on the compute stream itself (no second stream, no gate)
   int comm_test_delay_us = 0;       // "comm_test_delay_us" / VV_COMM_TEST_DELAY_US: TEST HOOK -- the communication stream held this long per chunk
   // (lab) -- settable in a -DVV_LAB build only
@@ -162,6 +163,8 @@ struct vv_ctx {
   int n_chunks = 3;                 // F-chunks of the overlapped update (env VV_COMM_CHUNKS, 1 .. 4)
   int chunk_kt[5] = {0, 0, 0, 0, 0};    // first K-tile of each chunk for the current Fp (chunk_plan)
   int32_t* pub_count = nullptr;     // device: arrival counter of the publishing SGD kernels (behind the flags)
+  int32_t* pub_count0 = nullptr;    // ... of the first chunk's kernel when that one runs on the compute stream (overlap_first_inline)
+  bool overlap_first_inline = true; // VV_COMM_FIRST_INLINE: the overlapped update's first F-chunk (exchange + SGD) in the compute stream, the rest on the communication stream
   hipEvent_t ev_chunk0 = nullptr; bool chunk0_event = false;     // the first F-chunk's reduction is done (recorded by fb_impl)
   int32_t* gate_err = nullptr; int32_t* gate_err_dev = nullptr;     // pinned + mapped: a gated forward gave up waiting
   hipEvent_t ev_chunk = nullptr;

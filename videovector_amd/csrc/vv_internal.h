@@ -193,6 +193,8 @@ struct ScoreArgs {
   int32_t bound_seq = 0;
   DropSpec drop;                     // de-duplicated execution with dropout (k_score_fwd): H holds the SHARED pre-dropout rows, every
                                      // instance applies its own mask as it reads its row
+  uint32_t* lab_ts = nullptr;        // (lab builds, VV_LAB_SCORE_TS=1: 16 words per item -- shader-clock stamps of k_score_fwd's phases, 100 MHz
+                                     //  real time of its start and end, the compute unit it ran on; the product never sets or reads it)
 };
 
 // Row de-duplication of one batch (kernels_dedup.hip).  The sampler draws the negatives of every item
