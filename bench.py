@@ -9,8 +9,11 @@ Workload = BASELINE.json configs[1] per GPU: synthetic fc7 features 4096-d -> 51
 
 A step = one full training iteration on one batch: (row de-duplication,) gather-GEMM forward, fused score/loss
 forward+backward, (per-row gradient sums,) gather-GEMM^T weight gradient, fused SGD update; for N > 1 the exact exchange of
-[dW|db]: by default chunk by chunk on the library's communication stream while the next step's forward GEMM already runs and
-waits per chunk inside the kernel (--allreduce overlap), or the whole all-reduce between backward and update (sync).
+[dW|db]: by default the SHARDED update in the compute stream (reduce-scatter, the rule on D / N rows, all-gather of the 16-bit copy:
+--allreduce sharded); or chunk by chunk on the library's communication stream while the next step's forward GEMM already runs and
+waits per chunk inside the kernel (overlap); or the whole all-reduce between backward and update (sync).  An N > 1 line carries all
+three as `schedules` legs, the sharded schedule over the direct peer transport and the one-logical-sampler arrangement as legs run in
+fresh processes (`peer_transport_leg`, `node_sampler_leg`), each with its step time and final loss.
 What is timed, and reported as what:
 
   value            END TO END, sustainable: the triplet sampler (the reference's sequential libc-rand() sampler,
@@ -119,8 +122,83 @@ def cpu_baseline(ds, idx, W, b, items, iters, threads=0):
     return out
 
 
+def helper_main():
+    """`bench.py --helper`: a process that never touches the GPU.  Every rank of an N > 1 run starts one BEFORE its own first GPU call; later it
+    asks it -- one JSON line in, one out -- to run a further bench.py rank (a leg that may not come back: the direct peer transport on a
+    node it has never run on) as a FRESH process, under a time limit.  The asking rank is never replaced and never exec()s; a leg that
+    wedges is killed by process group (this helper is a session leader: the rank kills it and everything it started, by PID)."""
+    import signal
+    import subprocess
+    from videovector_amd import launch as _launch
+
+    def die_with_parent():                                      # (between fork and exec: the pre-bound prctl only, videovector_amd/launch.py)
+        if _launch._PRCTL is not None:
+            _launch._PRCTL(1, int(signal.SIGTERM), 0, 0, 0)     # PR_SET_PDEATHSIG
+    die_with_parent()                                           # this helper goes when its rank goes, and a leg goes when the helper goes
+    for line in sys.stdin:
+        try:
+            cmd = json.loads(line)
+        except ValueError:
+            break
+        reply = {"rc": None, "line": None, "err_tail": None}
+        try:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__)] + cmd["argv"], env=dict(os.environ, **cmd.get("env", {})),
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=cmd.get("timeout", 300), text=True,
+                               preexec_fn=die_with_parent)
+            reply["rc"] = p.returncode
+            js = [x for x in p.stdout.splitlines() if x.startswith("{")]
+            reply["line"] = js[-1] if js else None
+            reply["err_tail"] = p.stderr[-600:]
+        except subprocess.TimeoutExpired as e:
+            reply["err_tail"] = "timed out after %.0f s" % e.timeout
+        except Exception as e:                                  # noqa: BLE001 -- whatever it was, the asking rank gets a line back
+            reply["err_tail"] = "%s: %s" % (type(e).__name__, e)
+        sys.stdout.write(json.dumps(reply) + "\n")
+        sys.stdout.flush()
+
+
+class LegHelper:
+    """The asking side of helper_main()."""
+
+    def __init__(self):
+        import subprocess
+        self.p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--helper"], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                  text=True, start_new_session=True)
+
+    def run(self, argv, env, timeout_s):
+        import select
+        import signal
+        if self.p is None or self.p.poll() is not None:
+            return {"rc": None, "line": None, "err_tail": "the helper process is gone"}
+        try:
+            self.p.stdin.write(json.dumps({"argv": argv, "env": env, "timeout": timeout_s}) + "\n")
+            self.p.stdin.flush()
+            r, _, _ = select.select([self.p.stdout], [], [], timeout_s + 30.0)
+            if r:
+                return json.loads(self.p.stdout.readline())
+        except (OSError, ValueError) as e:
+            return {"rc": None, "line": None, "err_tail": "helper: %s" % e}
+        try:                                                    # no answer: the helper and whatever it started, by process group
+            os.killpg(self.p.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        self.p = None
+        return {"rc": None, "line": None, "err_tail": "no answer within %.0f s: killed" % (timeout_s + 30.0)}
+
+    def close(self):
+        if self.p is not None and self.p.poll() is None:
+            try:
+                self.p.stdin.close()
+                self.p.wait(timeout=10)
+            except Exception:                                   # noqa: BLE001
+                self.p.kill()
+        self.p = None
+
+
 def main():
     t_process_start = time.perf_counter()
+    if len(sys.argv) > 1 and sys.argv[1] == "--helper":
+        return helper_main()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -178,6 +256,12 @@ def main():
         # never exec()s -- becomes the launcher of N ranks of itself (videovector_amd/launch.py) and relays rank 0's line.
         from videovector_amd.launch import launch_ranks
         sys.exit(launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+
+    # N > 1, the full line: the helper for the legs that run as fresh processes -- started HERE, before this rank's first GPU call
+    leg_helper = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not args.no_extra_legs and args.workload == "cfg2" and os.environ.get("VV_BENCH_CHILD") != "1" \
+            and args.allreduce != "stale" and args.comm != "torch":
+        leg_helper = LegHelper()
 
     global B_PER_GPU, NN, D
     if args.workload == "cfg5":
@@ -350,9 +434,10 @@ def main():
     want_peer = args.comm == "peer"                 # the library's communicator, over its direct peer transport
     if want_peer:
         args.comm = "lib"
-    # auto: the library's communicator overlaps the exchange with the next forward GEMM (RCCL's rings: wire time worth hiding); over the
-    # direct peer transport the short exchange runs sharded in the compute stream; torch's collective is synchronous
-    mode = args.allreduce if args.allreduce != "auto" else ((("sharded" if want_peer else "overlap") if args.comm == "lib" else "sync") if world > 1 else "none")
+    # auto (round 5): the SHARDED update in the compute stream on either transport -- on one rank over real RCCL it costs what the synchronous
+    # schedule costs (0.2195 against 0.2197 ms) while `overlap` pays 20-26 us before it hides anything (profiles/r05_overlap_cost.txt), and it
+    # moves 3/4 of the all-reduce's bytes; the line's `schedules` legs time all three on the node it runs on.  torch's collective is synchronous.
+    mode = args.allreduce if args.allreduce != "auto" else (("sharded" if args.comm == "lib" else "sync") if world > 1 else "none")
     if world == 1 and mode in ("sync", "overlap", "sharded"):
         mode = "none"
     comm = args.comm if mode in ("sync", "overlap", "sharded") else "none"
@@ -360,11 +445,14 @@ def main():
         raise SystemExit("--allreduce %s needs --comm lib (the chunked all-reduce / the sharded update live in the library)" % mode)
     # the library's communicator: RCCL, or the shared-memory transport under the one-device test hook
     comm_transport = "peer" if want_peer else ("rccl" if os.environ.get("VV_DIST_BACKEND", "nccl") == "nccl" else "shm")
+    if want_peer and os.environ.get("VV_BENCH_TEST_PEER_AS"):        # test hook: the peer leg's communicator fails to come up (tests/test_gpu_dist.py)
+        comm_transport = os.environ["VV_BENCH_TEST_PEER_AS"]
     comm_id_path = "/tmp/vv_comm_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", str(os.getppid())))
 
     def lr_at(it):     # shipped solver: inv policy, base 1e-3, gamma 1e-3, power .75
         return 1e-3 * (1.0 + 1e-3 * it) ** -0.75
 
+    no_hint = os.environ.get("VV_BENCH_NO_HINT") == "1"      # (A/B: vv_update_hint off -- the update always as its own launch)
     KERNELS = ("dedup", "fwd_gemm", "score_loss", "segsum", "guard", "wgrad_gemm", "reduce", "sgd", "reduce_sgd")
     GEMMS = ("fwd_gemm",)      # timed INSIDE the timed region: the dominant kernel (the roofline's); the others on the same steps of the per-step leg
 
@@ -373,8 +461,13 @@ def main():
         n_comm = 0
         comm_kind = None                          # "torch" once a run had to fall back from the library's communicator
 
-        def __init__(self, prec, dedup):
+        def __init__(self, prec, dedup, sched=None, transport=None):
+            # sched / transport: a schedule leg (N > 1) -- another exact schedule, or the other transport, than the line's default
             self.prec = prec
+            self.mode = mode if sched is None else sched
+            self.comm = comm if sched is None else "lib"
+            self.transport = comm_transport if transport is None else transport
+            self.comm_error = None
             self.eng = vv.Engine(local_rank, prec)
             self.eng.set_stream(work_stream.cuda_stream)
             self.eng.table_synth(ds.seed, ds.n_rows, F)
@@ -385,35 +478,43 @@ def main():
                 self.cfg.set("dropout_ratio", DROPOUT); self.cfg.set("dropout_seed", 1701)
             self.grads = None
             self.trainer = None
-            if mode == "stale":
+            if self.mode == "stale":
                 from videovector_amd.dist import GpuBackend, PipelinedTrainer
                 be = GpuBackend(self.eng, self.cfg, stream=work_stream)
                 self.trainer = PipelinedTrainer(be, None, NN, dist=dist, rank=rank, world=world)
-            elif comm == "torch":
+            elif self.comm == "torch":
                 self.grads = torch.zeros(D * F + D, dtype=torch.float32, device=dev)
                 self.eng.grads_bind(self.grads.data_ptr())
-            elif comm == "lib":
+            elif self.comm == "lib":
                 Run.n_comm += 1                   # one communicator per engine: its own id file
                 if rank == 0 and os.path.exists(comm_id_path + "_%d" % Run.n_comm):
                     os.unlink(comm_id_path + "_%d" % Run.n_comm)
                 dist.barrier()
                 ok = 1
                 try:
-                    self.eng.comm_init(world, rank, comm_id_path + "_%d" % Run.n_comm, comm_transport)
-                    self.eng.comm_schedule(mode)
+                    self.eng.comm_init(world, rank, comm_id_path + "_%d" % Run.n_comm, self.transport)
+                    self.eng.comm_schedule(self.mode)
                 except vv.VVError as e:
                     ok = 0
+                    self.comm_error = str(e)
                     print("rank %d: library communicator failed (%s)" % (rank, e), file=sys.stderr)
                 flag = torch.tensor([ok], dtype=torch.int32, device=dev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 if int(flag.item()) == 0:
-                    # some rank could not bring the library's communicator up: every rank falls back to the collective
-                    # of torch.distributed (same RCCL, same exact synchronous schedule) and the line says so
                     if ok:
                         self.eng.comm_destroy()
-                    Run.comm_kind = "torch"
-                    self.grads = torch.zeros(D * F + D, dtype=torch.float32, device=dev)
-                    self.eng.grads_bind(self.grads.data_ptr())
+                    if sched is not None:
+                        # a schedule leg whose communicator did not come up on some rank: the leg is skipped (every rank alike), the line says why
+                        self.comm_error = self.comm_error or "the communicator did not come up on another rank"
+                        self.comm = "failed"
+                    elif os.environ.get("VV_BENCH_CHILD") == "1":
+                        raise SystemExit("bench.py (leg process): the %s communicator did not come up: %s" % (self.transport, self.comm_error or "another rank failed"))
+                    else:
+                        # some rank could not bring the library's communicator up: every rank falls back to the collective
+                        # of torch.distributed (same RCCL, same exact synchronous schedule) and the line says so
+                        Run.comm_kind = "torch"
+                        self.grads = torch.zeros(D * F + D, dtype=torch.float32, device=dev)
+                        self.eng.grads_bind(self.grads.data_ptr())
             self.it = 0
 
         def reset(self, dedup):
@@ -428,6 +529,8 @@ def main():
                 assert source == "resident", "--allreduce stale runs on resident indices"
                 self.trainer.step(lr_at(self.it), global_batch=Bg, idx_dev_ptr=idx_dev.data_ptr() + i * stride)
             else:
+                if self.comm == "none" and not no_hint:
+                    eng.update_hint(cfg)           # Solver::Step as one unit (include/videovec.h): with one split of K the update rides in the weight-gradient GEMM
                 if source == "q1":
                     idx_h, last_h, _ = sampler.next(want_last=True)
                     eng.forward_backward_q1(cfg, idx_h, last_h)
@@ -437,9 +540,9 @@ def main():
                     if diag: host_ms.append((time.perf_counter() - th0) * 1e3)
                 else:
                     eng.forward_backward(cfg, idx_dev_ptr=idx_dev.data_ptr() + i * stride, idx_ready=True)   # uploaded and synchronised at set-up
-                if comm == "torch" or Run.comm_kind == "torch":
+                if self.comm == "torch" or (self.grads is not None and Run.comm_kind == "torch"):
                     dist.all_reduce(self.grads)
-                elif comm == "lib":
+                elif self.comm == "lib":
                     eng.allreduce_grads()          # (vv_apply_update would call it too; explicit for the reader)
                 eng.apply_update(cfg)
             self.it += 1
@@ -523,6 +626,7 @@ def main():
         g_el, g_kern, _ = run.timed("resident", profile=False)
         extra["gpu_path_only"] = {"value": Bg * NN * K / g_el, "unit": "triplets/s", "ms_per_step": g_el / K * 1e3,
                                   "note": "index batches resident in HBM before the timed region: sampler, ring and H2D excluded"}
+        extra["gpu_path_only"]["final_loss"] = run.eng.loss()[0]
         run.reset(args.dedup == "on")
         _, s_kern, steps_ms = run.timed(main_source, per_step_events=True, profile="all")
         extra["step_ms_stats"] = dict(stats(steps_ms), note="end-to-end steps, one HIP event per step (a separate run of the same K "
@@ -559,6 +663,27 @@ def main():
                                                     "kernels_ms": {k: round(v[0], 4) for k, v in q_kern.items() if v[1] > 0}}
             run.cfg.set("dropout_ratio", 0.0)
         run.eng.close()
+        if world > 1 and comm == "lib" and mode in ("sync", "overlap", "sharded") and args.workload == "cfg2":
+            # the three exact schedules (and, below, the other transport) in ONE invocation -- the same K steps on the same
+            # resident batches, a fresh engine and communicator each.  `value` stays the default schedule's; every leg's final loss must be the
+            # default's, bit for bit (the schedules reduce the same numbers in the same order).
+            legs = {mode: {"ms_per_step": extra["gpu_path_only"]["ms_per_step"], "value": extra["gpu_path_only"]["value"],
+                           "final_loss": extra["gpu_path_only"]["final_loss"], "default": True, "source": "resident indices (= gpu_path_only)"}}
+            for sched in ("sync", "overlap", "sharded"):
+                if sched in legs:
+                    continue
+                r2 = Run(args.prec, args.dedup == "on", sched=sched)
+                if r2.comm == "failed":
+                    legs[sched] = {"error": r2.comm_error}
+                else:
+                    l_el, _, _ = r2.timed("resident", profile=False)
+                    legs[sched] = {"ms_per_step": l_el / K * 1e3, "value": Bg * NN * K / l_el, "final_loss": r2.eng.loss()[0], "source": "resident indices"}
+                r2.eng.close()
+            extra["schedules"] = {"transport": comm_transport, "legs": legs,
+                                  "note": "the exact schedules of DESIGN.md 8 on the same batches, K steps each behind the same settle + warm-up steps: "
+                                          "sync = whole-buffer all-reduce between backward and update; overlap = the update F-chunk by F-chunk, the first "
+                                          "chunk in the compute stream, the rest on the communication stream beside the next forward GEMM (gated per "
+                                          "chunk); sharded = reduce-scatter, the rule on D / N rows, all-gather of the 16-bit copy, in the compute stream"}
     # the other operand type, end to end (configs[4] is quoted for bf16 operands while the product defaults to f16: --workload cfg5 always
     # shows both; their parity bounds against the fp32 CPU path are tests/test_gpu_cfg5.py's -- f16 1e-3, bf16 4e-3 on the embeddings)
     if (not args.no_extra_legs or args.workload == "cfg5") and not shipped:
@@ -573,6 +698,27 @@ def main():
                 extra[other + "_execution"]["parity_vs_fp32_cpu_path"] = ("tests/test_gpu_cfg5.py::test_cfg5_shard_matches_oracle: embeddings <= 1e-3 and "
                                                                           "scores <= 1e-3 with f16 operands (the north star's bound), <= 4e-3 / 2e-3 with bf16")
             run2.eng.close()
+    # N > 1: the legs that run as FRESH processes (one per rank, started by the helper each rank launched before its first GPU call), under a
+    # time limit: the direct peer transport -- which on a node it has never run on may fail to map, or not come back -- and the ONE-logical-
+    # sampler arrangement (SURVEY 8e's batch) beside the per-rank samplers.  A leg that fails leaves its error string, not a dead job.
+    child = {}
+    if leg_helper is not None:
+        base_port = int(os.environ.get("MASTER_PORT", "29500"))
+        rid = os.environ.get("TORCHELASTIC_RUN_ID", str(os.getppid()))
+        common = ["--gpus", str(world), "--steps", str(K), "--warmup", str(Wm), "--no-extra-legs", "--no-cpu-baseline", "--prec", args.prec,
+                  "--dedup", args.dedup, "--settle-ms", str(args.settle_ms), "--sampler-threads", str(args.sampler_threads),
+                  "--prefetch-depth", str(args.prefetch_depth), "--cpu-bind", args.cpu_bind]
+        want = []
+        if comm == "lib" and not want_peer and mode in ("sync", "overlap", "sharded"):
+            want.append(("peer_transport_leg", common + ["--comm", "peer", "--allreduce", "sharded", "--sampler", smode], 101))
+        if smode == "rank" and mode in ("sync", "overlap", "sharded"):
+            want.append(("node_sampler_leg", common + ["--comm", "peer" if want_peer else args.comm, "--allreduce", mode, "--sampler", "node"], 202))
+        limit = float(os.environ.get("VV_BENCH_CHILD_TIMEOUT", "240"))
+        for name, argv, off in want:
+            if dist: dist.barrier()
+            child[name] = leg_helper.run(argv, {"MASTER_PORT": str(base_port + off), "TORCHELASTIC_RUN_ID": rid + "_" + name, "VV_BENCH_CHILD": "1",
+                                                "VV_COMM_TIMEOUT": os.environ.get("VV_COMM_TIMEOUT", "30")}, limit)
+        leg_helper.close()
     t_legs_done = time.perf_counter()
 
     if rank == 0:
@@ -674,7 +820,7 @@ def main():
                                                 "stream while the next step's forward GEMM runs and waits per chunk inside the kernel",
                                      "sharded": "exact SGD; reduce-scatter of the gradients, the solver's rule on this rank's D / N rows, all-gather of "
                                                 "the 16-bit copy of W + the bias (3/4 of the all-reduce's wire bytes, 1/N of the update's "
-                                                "traffic) on the communication stream; the next forward GEMM waits at one gate",
+                                                "traffic), queued in the compute stream (the default for N > 1)",
                                      "stale": "overlapped with the next iteration's forward/backward "
                                               "(one-update delayed gradients: NOT the reference's algorithm)"}[mode]},
             "roofline": roof,
@@ -698,6 +844,14 @@ def main():
             "final_loss": loss, "final_violations": viol,
         }
         out.update(extra)
+        for name, rep in child.items():
+            if rep.get("line"):
+                cj = json.loads(rep["line"])
+                out[name] = {"ms_per_step": cj["ms_per_step"], "value": cj["value"], "final_loss": cj["final_loss"],
+                             "allreduce": cj["config"]["allreduce"], "comm": cj["config"]["comm"], "sampler": cj["config"]["sampler"],
+                             "source": "a fresh process per rank (started by each rank's helper before the rank's first GPU call), end to end like `value`"}
+            else:
+                out[name] = {"error": (rep.get("err_tail") or "no line").strip()[-400:], "rc": rep.get("rc")}
         if one_logical is not None:
             out["one_logical_sampler"] = one_logical
         # where the wall-clock time of this process goes besides the K timed steps (for whoever times the whole command)

@@ -62,6 +62,10 @@ class Net {
   bool has_layer(const string& layer_name);
   const shared_ptr<Layer<Dtype> > layer_by_name(const string& layer_name);
   void set_debug_info(const bool value) { debug_info_ = value; }
+  // Solver::Step: the next ForwardBackward is followed by Update with the hyper-parameters already set (vv_update_hint, include/videovec.h:
+  // the library may apply the update where the gradient is produced).  Not with debug_info (its lines read the diffs) nor on the
+  // layer-by-layer executor.
+  void HintUpdate();
   // The reference's Solver::Solve uses ForwardBackward's return value only on display iterations
   // (solver.cpp:194-196).  Reading the loss back costs a device synchronisation, so the solver says when it
   // wants it; otherwise ForwardBackward returns the last value read and the GPU keeps running ahead.

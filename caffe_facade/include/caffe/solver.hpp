@@ -33,6 +33,10 @@ class Solver {
   // hooks of the concrete solver
   virtual void PreSolve() {}
   virtual void ComputeUpdateValue() = 0;
+  // The iteration's update hyper-parameters handed to the net BEFORE ForwardBackward, without the log line (ComputeUpdateValue prints it
+  // where the reference does, behind the loss lines): Solver::Step runs ForwardBackward, ComputeUpdateValue and Update back to back and
+  // reads no diff in between, so the net may announce the update to the library (Net::HintUpdate -> vv_update_hint)
+  virtual void PrepareUpdate() {}
   virtual void SnapshotSolverState(SolverState* out) = 0;
   virtual void RestoreSolverState(const SolverState& in) = 0;
 
@@ -63,6 +67,7 @@ class SGDSolver : public Solver<Dtype> {
   virtual int solver_type() const { return VV_SOLVER_SGD; }  // which rule k_sgd applies
   virtual void PreSolve();
   virtual void ComputeUpdateValue();                         // solver.cpp:485-531 (hyper-parameters only)
+  virtual void PrepareUpdate();
   virtual void SnapshotSolverState(SolverState* out);        // solver.cpp:578-586
   virtual void RestoreSolverState(const SolverState& in);    // solver.cpp:588-596
   vector<shared_ptr<Blob<Dtype> > > history_;

@@ -676,6 +676,11 @@ Dtype Net<Dtype>::ForwardTest() {
 }
 
 template <typename Dtype>
+void Net<Dtype>::HintUpdate() {
+  if (sequential_ || plan_.test || debug_info_ || !ctx_) return;
+  VV_CHECK(vv_update_hint(ctx_, &cfg_));
+}
+template <typename Dtype>
 void Net<Dtype>::Update() {
   VV_CHECK(vv_apply_update(ctx_, &cfg_));
   params_stale_ = true;

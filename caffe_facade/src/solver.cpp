@@ -149,6 +149,8 @@ void Solver<Dtype>::Step(bool display) {
   vector<Blob<Dtype>*> no_bottom;
   net_->set_debug_info(display && param_.get_bool("debug_info"));
   net_->set_loss_needed(display);                   // the loss is read back from the device only when it is shown
+  PrepareUpdate();                                  // this iteration's rate (a function of iter_) ...
+  net_->HintUpdate();                               // ... and: ForwardBackward is followed by Update, nothing reads a diff in between
   const Dtype loss = net_->ForwardBackward(no_bottom);
   if (display) {
     LOG(INFO) << "Iteration " << iter_ << ", loss = " << loss;                          // solver.cpp:196
@@ -279,6 +281,11 @@ void SGDSolver<Dtype>::ComputeUpdateValue() {
   if (this->param_.get_int("display") && this->iter_ % this->param_.get_int("display") == 0)
     LOG(INFO) << "Iteration " << this->iter_ << ", lr = " << rate;                    // solver.cpp:492-494
   this->net_->SetUpdateHyperParams(rate, (float)this->param_.get_num("momentum"), (float)this->param_.get_num("weight_decay"),
+                                   this->param_.get_str("regularization_type"), solver_type(), (float)this->param_.get_num("delta"));
+}
+template <typename Dtype>
+void SGDSolver<Dtype>::PrepareUpdate() {
+  this->net_->SetUpdateHyperParams(GetLearningRate(), (float)this->param_.get_num("momentum"), (float)this->param_.get_num("weight_decay"),
                                    this->param_.get_str("regularization_type"), solver_type(), (float)this->param_.get_num("delta"));
 }
 template <typename Dtype>

@@ -66,11 +66,13 @@ int vv_set_dedup(vv_ctx* ctx, int on);
  *   "fwd_lead" (VV_FWD_LEAD, 1)      the forward GEMM's sibling lead
  *   "wgrad_tr" (VV_WGRAD_TR, 1)      transposed LDS reads in the weight-gradient GEMM (0: the first-round kernel)
  *   "score_stream" (VV_SCORE_STREAM, 0)  1: the one-sweep score kernel for every shape
+ *   "score_pipe" (VV_SCORE_PIPE, 1)  the register-resident score kernel as persistent workgroups that request the next item's rows before the
+ *                                    current item's phases (batches of two or more items per CU; 0: one workgroup per item)
  *   "comm_gate" (VV_COMM_GATE, 1)    the overlapped update gates the next forward GEMM chunk by chunk (0: the stream joins)
  *   "comm_inline" (VV_COMM_INLINE, 1)  the SHARDED update's three steps (reduce-scatter, the rule on this rank's rows, all-gather) are queued
  *                                    on the compute stream itself (0: on the communication stream, the next forward GEMM gated on one flag)
- *   "comm_first_inline" (VV_COMM_FIRST_INLINE, 1)  the OVERLAPPED update's first F-chunk (exchange, rule, publish) is queued on the compute stream,
- *                                    the others on the communication stream (0: all of them there, the next forward GEMM waits at its first gate for the hand-off)
+ *   "comm_first_inline" (VV_COMM_FIRST_INLINE, 0)  1: the OVERLAPPED update's first F-chunk (exchange, rule, publish) is queued on the compute stream,
+ *                                    the others on the communication stream (measured slower on one rank: off by default)
  *   "comm_chunks" (VV_COMM_CHUNKS, 3)  F-chunks of the overlapped update, 1 .. 4
  *   "comm_test_delay_us" (VV_COMM_TEST_DELAY_US, 0)  TEST HOOK: holds the communication stream this long in front of every chunk
  * Ablated / experimental kernels (timing studies whose results may be wrong) are NOT reachable through this library: they and their
@@ -177,6 +179,17 @@ int vv_forward_backward_q1(vv_ctx* ctx, const vv_step_cfg* cfg, const int32_t* i
 int vv_apply_update(vv_ctx* ctx, const vv_step_cfg* cfg);
 /* Both of the above: one iteration of Solver::Solve's loop body (solver.cpp:194,219-220). */
 int vv_step(vv_ctx* ctx, const vv_step_cfg* cfg, const int32_t* idx, int idx_on_device);
+/* Solver::Step as ONE unit (solver.cpp:177-221: ForwardBackward, ComputeUpdateValue, Update back to back): announces that the NEXT
+ * vv_forward_backward* call will be followed by vv_apply_update with exactly these solver parameters (lr, momentum, weight_decay, lr_mult,
+ * decay_mult, reg, solver_type, delta) and that nothing reads the gradient in between.  The library may then apply the update where the
+ * gradient is produced: when the weight-gradient GEMM runs with one split of K (large D x F, small batches -- the shipped
+ * mednet_embedding_train.prototxt: 4096 x 4096, batch 128) its epilogue applies the solver's rule to the tile it holds, and the 4 D F bytes
+ * of dW are neither written nor read back; vv_apply_update then only finishes the step (bias, loss, scale bookkeeping).  Parameters, history
+ * and losses are bit for bit those of the un-hinted calls.  Between such a vv_forward_backward* and its vv_apply_update only vv_loss_get
+ * is allowed (vv_grads_*, vv_params_get, another forward pass: VV_ERR_STATE -- the gradient of such a step is not kept, the parameters are
+ * half-way).  Where the fusion does not apply (several splits of K, a communicator, a bound gradient buffer) the hint changes nothing.
+ * vv_step announces itself.  One hint covers one step. */
+int vv_update_hint(vv_ctx* ctx, const vv_step_cfg* cfg);
 
 /* Loss (already multiplied by loss_weight) and train_violations of the last forward; synchronises.
  * (the two tops of MAX_MARGIN_LOSS, max_margin_loss_layer.cpp:111-126.) */

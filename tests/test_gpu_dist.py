@@ -13,16 +13,33 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _run(cmd, timeout, env):
+    """subprocess.run(capture_output=True, text=True) whose time limit takes the WHOLE process tree down (the launcher's ranks are
+    grandchildren: killed by process group, by PID -- a rank left behind would keep the GPU busy under every later test)."""
+    import signal
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        out, err = p.communicate()
+        raise AssertionError("timed out after %d s: %s\n--- stderr tail ---\n%s" % (timeout, " ".join(cmd[-14:]), err[-3000:]))
+    return subprocess.CompletedProcess(cmd, p.returncode, out, err)
+
+
 @pytest.mark.parametrize("mode", ["sync", "overlap", "sharded", "torch-sync", "stale", "peer-sharded", "peer-overlap", "peer-auto"])
 def test_bench_two_ranks_on_one_device(mode):
     env = dict(os.environ, VV_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     port = "295%02d" % {"sync": 17, "overlap": 19, "torch-sync": 21, "stale": 23, "sharded": 25, "peer-sharded": 27, "peer-overlap": 29, "peer-auto": 37}[mode]
     extra = ["--comm", "torch"] if mode == "torch-sync" else (["--comm", "peer"] if mode.startswith("peer-") else [])   # peer: the one-shot direct exchange (hipIpc mappings)
     ar = "sync" if mode == "torch-sync" else mode.replace("peer-", "")          # (peer-auto: --allreduce auto = sharded over this transport)
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"),
                         "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
-                        "--allreduce", ar, "--sampler", "node", "--settle-ms", "2"] + extra + (["--no-extra-legs"] if mode != "stale" else []), capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+                        "--allreduce", ar, "--sampler", "node", "--settle-ms", "2"] + extra + (["--no-extra-legs"] if mode != "stale" else []), 600, env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                    # rank 0 only
@@ -47,10 +64,10 @@ def test_bench_fallbacks_keep_the_run_alive():
     losses = {}
     for tag, extra_env in (("ring", {}), ("private", {"VV_BENCH_PRIVATE_SAMPLERS": "1"})):
         env = dict(os.environ, VV_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
-        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+        r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                             "--master-addr", "127.0.0.1", "--master-port", "29531" if tag == "ring" else "29533",
                             os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
-                            "--no-extra-legs", "--sampler", "node", "--settle-ms", "2"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+                            "--no-extra-legs", "--sampler", "node", "--settle-ms", "2"], 600, env)
         assert r.returncode == 0, r.stderr[-3000:]
         d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
         assert ("fallback" in d["config"]["sampler"]) == (tag == "private")
@@ -62,10 +79,9 @@ def test_bench_per_rank_samplers_is_the_default_for_two_ranks():
     """N > 1 default: every rank runs the reference's sampler for its own batch (own draw stream and starting record);
     the line names the mode and carries the measured bound of the one-logical-sampler form beside it."""
     env = dict(os.environ, VV_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29535", os.path.join(ROOT, "bench.py"),
-                        "--gpus", "2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--settle-ms", "2"],
-                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+                        "--gpus", "2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--settle-ms", "2"], 600, env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -83,8 +99,8 @@ def test_bench_bare_command_launches_its_own_ranks():
     (videovector_amd/launch.py) and rank 0's ONE line comes out of its stdout -- the form the driver's 1-GPU command has."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
     env.update(VV_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
-                        "--no-cpu-baseline", "--settle-ms", "2"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    r = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+                        "--no-cpu-baseline", "--settle-ms", "2"], 900, env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -95,14 +111,41 @@ def test_bench_bare_command_launches_its_own_ranks():
     assert d["roofline"]["frac"] > 0 and d["roofline"]["kernel"]
     assert d["gpu_path_only"]["value"] > 0
     assert d["value"] > 0 and abs(d["value"] - 2048 * 50 * 6 / (d["ms_per_step"] * 6e-3)) <= 1e-6 * d["value"]
+    # ONE invocation answers DESIGN.md 9.1 -- the three exact schedules on the library's transport, the sharded schedule
+    # over the direct peer transport and the one-logical-sampler arrangement, each with its step time and final loss; the schedules (and the
+    # other transport) reduce the same numbers in the same order: the same loss, bit for bit, as the line's own
+    legs = d["schedules"]["legs"]
+    assert set(legs) == {"sync", "overlap", "sharded"} and sum(1 for v in legs.values() if v.get("default")) == 1
+    for name, leg in legs.items():
+        assert "error" not in leg, (name, leg)
+        assert leg["ms_per_step"] > 0 and leg["final_loss"] == d["final_loss"], (name, leg["final_loss"], d["final_loss"])
+    peer = d["peer_transport_leg"]
+    assert "error" not in peer, peer
+    assert peer["ms_per_step"] > 0 and peer["final_loss"] == d["final_loss"] and "direct peer exchange" in peer["comm"]
+    node = d["node_sampler_leg"]
+    assert "error" not in node, node
+    assert node["ms_per_step"] > 0 and 0 < node["final_loss"] < 16 and "one per node" in node["sampler"]
+
+
+def test_bench_leg_process_that_fails_leaves_an_error_string_not_a_dead_job():
+    """The direct peer transport's leg runs as fresh processes under a time limit: here its communicator is made to fail (an unknown transport
+    name reaches vv_comm_init through VV_BENCH_TEST_PEER_AS) -- the line still comes out, with the error in the leg's place."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(VV_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", VV_BENCH_TEST_PEER_AS="no-such-transport")
+    r = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--no-cpu-baseline", "--settle-ms", "2"], 900, env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert "error" in d["peer_transport_leg"] and d["peer_transport_leg"]["error"], d["peer_transport_leg"]
+    assert d["value"] > 0 and "error" not in d["node_sampler_leg"]
 
 
 def test_bench_bare_command_a_dead_rank_fails_the_job():
     """rank 1 dies right after the rendezvous while rank 0 waits for it: rc != 0 and a message, not a hang."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
     env.update(VV_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", VV_BENCH_TEST_FAIL_RANK="1", VV_LAUNCH_GRACE="5")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-                        "--no-cpu-baseline", "--no-extra-legs", "--settle-ms", "2"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    r = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-extra-legs", "--settle-ms", "2"], 300, env)
     assert r.returncode == 7, (r.returncode, r.stderr[-2000:])
     assert "rank 1 exited with code 7" in r.stderr
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -119,9 +162,9 @@ def test_bench_eight_ranks_overlap_node_sampler_matches_one_process_at_the_globa
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
     env.update(VV_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     K, Wm, settle_ms = 3, 1, 0.5                                   # settle steps = ceil(0.5 / 0.25) = 2 -> 6 iterations
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", str(K), "--warmup", str(Wm),
+    r = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", str(K), "--warmup", str(Wm),
                         "--no-cpu-baseline", "--no-extra-legs", "--allreduce", "overlap", "--sampler", "node",
-                        "--settle-ms", str(settle_ms), "--sampler-threads", "2"], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+                        "--settle-ms", str(settle_ms), "--sampler-threads", "2"], 1500, env)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 8192 and d["config"]["parallelism"] == "dp8"

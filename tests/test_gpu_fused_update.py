@@ -61,3 +61,68 @@ def test_fused_update_is_bit_identical(tmp_path, prec, solver, D):
     for k in a.files:
         assert np.array_equal(a[k], b[k]), k
     assert np.isfinite(a["W"]).all() and np.abs(a["hW"]).max() > 0
+
+
+CHILD_HINT = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import videovector_amd as vv
+from videovector_amd.synth import SyntheticVideos, init_weights
+B, C, Nn, F, D = 128, 5, 10, 4096, int(sys.argv[4])
+hint, drop = int(sys.argv[5]), float(sys.argv[6])
+ds = SyntheticVideos(seed=7, n_videos=512)
+smp = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, batch_size=B, context_size=C, num_negative_samples=Nn,
+                 max_buffer_size=5000, negative_swap_percentage=50)
+W, b = init_weights(7, D, F)
+eng = vv.Engine(0, sys.argv[1])
+eng.table_synth(ds.seed, ds.n_rows, F)
+eng.params_set(W, b)
+solver = int(sys.argv[2])
+out, losses, refused = {}, [], 0
+for it in range(10):
+    idx = smp.next()
+    idx = idx[0] if isinstance(idx, tuple) else idx
+    cfg = vv.StepConfig(B, C, Nn, lr=0.05 / (1 + it), momentum=0.0 if solver == 2 else 0.9, weight_decay=5e-4, dropout_ratio=drop, dropout_seed=5)
+    cfg.set("solver_type", solver)
+    if solver == 2: cfg.set("delta", 1e-8)
+    if hint and it != 6: eng.update_hint(cfg)                # (iteration 6: an un-hinted step between hinted ones)
+    eng.forward_backward(cfg, idx)
+    if it %% 3 == 1: losses.append(eng.loss())              # the loss may be asked for between the two calls
+    if hint and it == 4:
+        for f in (eng.grads, eng.params_get):               # ... nothing else may
+            try:
+                f()
+            except vv.VVError:
+                refused += 1
+    eng.apply_update(cfg)
+    if it %% 3 == 2: losses.append(eng.loss())
+    if hint and it == 5:
+        try:
+            eng.grads()                                      # the gradient of a hinted, fused step was never stored
+        except vv.VVError:
+            refused += 1
+    if it == 6: out["dW_6"] = eng.grads()[0]                 # (the un-hinted step's gradient is there as ever)
+Wn, bn, hW, hb = eng.params_get()
+out.update(W=Wn, b=bn, hW=hW, hb=hb, losses=np.array(losses, dtype=np.float64), refused=np.array([refused]))
+np.savez(sys.argv[3], **out)
+"""
+
+
+@pytest.mark.parametrize("prec,solver,D,drop", [("f16", 0, 4096, 0.9), ("f16", 1, 4096, 0.0), ("f16", 2, 4096, 0.0), ("bf16", 0, 4096, 0.0), ("f16", 0, 512, 0.0)])
+def test_update_in_the_weight_gradient_epilogue_is_bit_identical(tmp_path, prec, solver, D, drop):
+    """vv_update_hint: with one split of K -- the shipped 4096 x 4096 matrix at batch 128 -- the weight-gradient GEMM applies
+    the solver's rule to the tile in its accumulators and dW is never written.  Parameters, bias, both histories and every loss are bit for bit
+    those of the same calls without the hint; between the hinted backward pass and its update only the loss may be read; D = 512 at this batch
+    has several splits: the hint changes nothing there (and refuses nothing)."""
+    res = {}
+    for hint in (0, 1):
+        out = tmp_path / ("h_%s_%d_%d_%d.npz" % (prec, solver, D, hint))
+        r = subprocess.run([sys.executable, "-c", CHILD_HINT % ROOT, prec, str(solver), str(out), str(D), str(hint), str(drop)],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[hint] = np.load(out)
+    a, b = res[0], res[1]
+    for k in ("W", "b", "hW", "hb", "losses", "dW_6"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.isfinite(a["W"]).all() and np.abs(a["hW"]).max() > 0 and np.abs(a["W"] - b["W"]).max() == 0
+    assert int(b["refused"][0]) == (3 if D == 4096 else 0), int(b["refused"][0])

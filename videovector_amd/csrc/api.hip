@@ -30,6 +30,7 @@ static inline const char* lab_env(const char*) { return nullptr; }
 #endif
 using namespace vv;
 
+static int upd_pending_guard(vv_ctx* c, const char* who);      // (vv_update_hint, below)
 thread_local char vv_g_err[512] = "";
 int vv_fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -137,6 +138,7 @@ static int create_init(vv_ctx* c) {
   if (const char* v = opt_env("VV_WGRAD_TR")) c->ko.wgrad_tr = atoi(v) != 0;
   if (const char* v = opt_env("VV_FWD_LEAD")) c->ko.fwd_lead = atoi(v);
   if (const char* v = opt_env("VV_SCORE_STREAM")) c->ko.score_stream = atoi(v);
+  if (const char* v = opt_env("VV_SCORE_PIPE")) c->ko.score_pipe = atoi(v);
   if (const char* v = opt_env("VV_SEG_BWD")) c->seg_bwd = atoi(v) != 0;
   if (const char* v = opt_env("VV_DEDUP")) c->dedup = atoi(v) != 0;
   if (const char* v = opt_env("VV_FUSE_UPDATE")) c->fuse_update = atoi(v) != 0;
@@ -287,6 +289,7 @@ int vv_set_option(vv_ctx* c, const char* name, double value) {
   if (n == "fwd_lead") { c->ko.fwd_lead = iv; return VV_OK; }
   if (n == "wgrad_tr") { c->ko.wgrad_tr = iv != 0; return VV_OK; }
   if (n == "score_stream") { c->ko.score_stream = iv; return VV_OK; }
+  if (n == "score_pipe") { c->ko.score_pipe = iv; return VV_OK; }
   if (n == "comm_gate") { c->comm_gate = iv != 0; return VV_OK; }
   if (n == "comm_inline") { c->comm_inline = iv != 0; return VV_OK; }
   if (n == "comm_first_inline") { c->overlap_first_inline = iv != 0; return VV_OK; }
@@ -312,6 +315,7 @@ int vv_get_option(vv_ctx* c, const char* name, double* value) {
   else if (n == "fwd_lead") *value = c->ko.fwd_lead;
   else if (n == "wgrad_tr") *value = c->ko.wgrad_tr;
   else if (n == "score_stream") *value = c->ko.score_stream;
+  else if (n == "score_pipe") *value = c->ko.score_pipe;
   else if (n == "comm_gate") *value = c->comm_gate;
   else if (n == "comm_inline") *value = c->comm_inline;
   else if (n == "comm_first_inline") *value = c->overlap_first_inline;
@@ -528,6 +532,7 @@ static int gather_params(vv_ctx* c) {
 
 int vv_params_get(vv_ctx* c, float* W, float* b, float* hW, float* hb) {
   if (!c) return fail(VV_ERR_ARG, "vv_params_get: ctx is NULL");
+  { const int rcg = upd_pending_guard(c, "vv_params_get"); if (rcg) return rcg; }
   if (!c->W) return fail(VV_ERR_STATE, "vv_params_get: no parameters");
   VV_ENTER(c);
   { const int rcj = comm_join(c); if (rcj) return rcj; }
@@ -652,6 +657,15 @@ static void flush_scale_update(vv_ctx* c) {
 // The reduction vv_forward_backward left undone (vv_ctx::red_lazy): run it now, as the plain k_reduce -- somebody reads the
 // gradient or the loss before an update.
 static int reduce_now(vv_ctx* c) {
+  if (c->upd_in_wgrad) {
+    // (vv_loss_get between the backward pass and vv_apply_update of a step announced by vv_update_hint: the loss scalars now, from the
+    // partials; the bias update and the bookkeeping stay with vv_apply_update)
+    ReduceArgs ra = c->red_args;
+    ra.parts = 2; ra.scale_sc = nullptr; ra.gmax_host = nullptr;
+    launch_reduce(ra, c->stream);
+    HIPCHK(hipGetLastError());
+    return VV_OK;
+  }
   if (c->grads_stale) {
     // the fused update consumed the slabs without writing dW out; they are untouched since: reduce them now (dW only --
     // db, the loss and the guard's report were produced by the fused launch)
@@ -796,7 +810,30 @@ static int dd_issue(vv_ctx* c, const int32_t* didx, int idx_on_device, int64_t r
 
 // idx_on_device: 0 host indices; 1 device indices produced on the context's stream (ordered after everything queued
 // there); 2 device indices that are complete already (no ordering needed: the ring's staging slots, static batches)
+// vv_update_hint: the parameter matrix of this step was updated inside the weight-gradient GEMM; until vv_apply_update has finished the step
+// (bias, loss, the scale bookkeeping) the parameters are half-way -- only vv_apply_update and vv_loss_get may come next
+static int upd_pending_guard(vv_ctx* c, const char* who) {
+  if (c && c->grads_lost && !strncmp(who, "vv_grads", 8))
+    return fail(VV_ERR_STATE, "%s: the last step was announced by vv_update_hint and applied its update where the gradient was produced: "
+                              "that gradient was never stored (run the step without the hint to read it)", who);
+  if (c && c->upd_in_wgrad)
+    return fail(VV_ERR_STATE, "%s: the step announced by vv_update_hint has applied its update where the gradient was produced -- call vv_apply_update "
+                              "first (the gradient of such a step is not kept; without the hint every call is allowed as before)", who);
+  return VV_OK;
+}
+
+int vv_update_hint(vv_ctx* c, const vv_step_cfg* cfg) {
+  int rc = check_cfg(c, cfg);
+  if (rc) return rc;
+  c->upd_hint = true;
+  c->upd_cfg = *cfg;
+  return VV_OK;
+}
+
 static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int idx_on_device, int64_t row_limit, int32_t seq = 0) {
+  { const int rcg = upd_pending_guard(c, "vv_forward_backward"); if (rcg) return rcg; }
+  const bool upd_hint = c && c->upd_hint;       // (consumed by this call whatever path it takes)
+  if (c) c->upd_hint = false;
   int rc = check_cfg(c, cfg);
   if (rc) return rc;
   if (!idx) return fail(VV_ERR_ARG, "vv_forward_backward: idx is NULL");
@@ -1067,8 +1104,34 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
     ra.scale_sc = c->scales; ra.scale_wmax = c->wmax_blocks + c->wmax_cur * WMAX_SLOTS; ra.scale_n = c->wmax_n; ra.scale_prec = c->prec;
     c->scale_pending = false; c->wmax_seed_live = false;
   }
+  // vv_update_hint + one split of K: the tile in the weight-gradient GEMM's accumulators IS the gradient -- the solver's rule is applied
+  // there (WgradUpd) and the 4 D F bytes of dW are neither written nor read back (the shipped configuration: D = F = 4096, 134 MB of the
+  // update's 370).  vv_apply_update then runs only the bias / loss workgroups.
+  const bool fuse_w = upd_hint && lazy && c->S == 1 && wgrad_can_fuse_update() && !c->fuse_keep_grads &&
+                      (c->Dp / BM) * (c->Fp / BN) <= WMAX_SLOTS;
+  if (fuse_w) {
+    const vv_step_cfg& uc = c->upd_cfg;
+    WgradUpd& u = wa.upd;
+    wa.fuse_upd = 1;
+    u.W = c->W; u.hW = c->hW; u.Wh = c->Wh; u.scales = c->scales;
+    u.wmax_blocks = c->wmax_blocks + (1 - c->wmax_cur) * WMAX_SLOTS;
+    u.wmax_prev = c->wmax_blocks + c->wmax_cur * WMAX_SLOTS; u.wmax_prev_n = c->wmax_n;
+    u.recompute_scale = c->scale_pending ? 1 : 0; u.prec = c->prec;
+    u.D = c->D; u.F = c->F;
+    u.rate = uc.lr; u.momentum = uc.momentum; u.weight_decay = uc.weight_decay; u.lr_mult_w = uc.lr_mult[0]; u.decay_mult_w = uc.decay_mult[0];
+    u.delta = uc.delta; u.reg = uc.reg; u.solver_type = uc.solver_type;
+    u.sg = ra.sg; u.gg = ra.gg; u.ip_scale = ra.ip_scale;
+  }
   PROFILED(c, "wgrad_gemm", launch_wgrad_gemm(c->prec, wa, s));
   c->red_lazy = false; c->grads_stale = false;        // (the slabs now hold this step's gradient)
+  c->grads_lost = false;
+  if (fuse_w) {
+    if (wa.upd.recompute_scale && c->wmax_seed_live) {       // vv_params_set's seed has now been folded into a scale: clear it behind the launch
+      HIPCHK(hipMemsetAsync(&c->scales->wmax_bits, 0, sizeof(unsigned), s));
+      c->wmax_seed_live = false;
+    }
+    c->upd_in_wgrad = true; c->upd_wgrad_blocks = (c->Dp / BM) * (c->Fp / BN);
+  }
   if (lazy) {
     c->red_args = ra; c->red_lazy = true;
     c->grads_pending = false; c->grads_chunked = false; c->chunk0_event = false;
@@ -1221,6 +1284,25 @@ int vv_apply_update(vv_ctx* c, const vv_step_cfg* cfg) {
   a.decay_mult_w = cfg->decay_mult[0]; a.decay_mult_b = cfg->decay_mult[1];
   a.reg = cfg->reg; a.solver_type = cfg->solver_type; a.delta = cfg->delta;
   a.skip_if = c->comm ? vv::comm_fail_flag(c->comm) : nullptr;
+  if (c->upd_in_wgrad) {
+    // the parameter matrix was updated in the weight-gradient GEMM (vv_update_hint): bias, loss, the guard's report -- k_reduce_sgd's
+    // special workgroups alone -- and the bookkeeping of the scale
+    const vv_step_cfg& uc = c->upd_cfg;
+    if (cfg->lr != uc.lr || cfg->momentum != uc.momentum || cfg->weight_decay != uc.weight_decay || cfg->lr_mult[0] != uc.lr_mult[0] ||
+        cfg->decay_mult[0] != uc.decay_mult[0] || cfg->reg != uc.reg || cfg->solver_type != uc.solver_type || cfg->delta != uc.delta)
+      return fail(VV_ERR_ARG, "vv_apply_update: the solver parameters differ from those announced by vv_update_hint (the weights were updated with the announced ones)");
+    FusedUpdArgs fa;
+    fa.r = c->red_args; fa.g = a; fa.prec = c->prec; fa.no_params = 1; fa.recompute_scale = 0; fa.store_grads = 0;
+    c->red_lazy = false; c->grads_stale = false; c->upd_in_wgrad = false;
+    c->grads_lost = true;                       // (dW of this step never existed outside the GEMM's registers)
+    PROFILED(c, "reduce_sgd", (void)launch_reduce_sgd(fa, c->stream));
+    c->wmax_cur = 1 - c->wmax_cur; c->wmax_n = c->upd_wgrad_blocks;
+    c->scale_pending = true;
+    HIPCHK(hipGetLastError());
+    c->iter++;
+    c->prof_calls++;
+    return VV_OK;
+  }
   if (c->red_lazy && !overlapped) {
     // the reduction is still due: reduce and update in one launch (k_reduce_sgd)
     FusedUpdArgs fa;
@@ -1298,17 +1380,21 @@ int vv_apply_update(vv_ctx* c, const vv_step_cfg* cfg) {
     // the next forward GEMM (fb_impl) starts right away and waits for each chunk where its K loop reaches it.  db rides
     // with the last chunk; the bias is updated there.
     hipStream_t cs = vv::comm_stream(c->comm);
-    HIPCHK(hipEventRecord(c->ev_chunk, c->stream));
     const int32_t useq = ++c->upd_seq;
     const int nch = chunk_plan(c);               // (the layout k_reduce wrote: same Fp, same plan)
     a.pub_count = c->pub_count; a.pub_seq = useq;
-    // Round 5: the FIRST chunk stays on the compute stream (overlap_first_inline, default).  The next forward GEMM cannot pass its first
+    // Round 5, an option (overlap_first_inline; OFF by default: measured slower, vv_ctx.h): the FIRST chunk on the compute stream.  The next forward GEMM cannot pass its first
     // gate before chunk 0 has arrived whatever stream brings it -- on the communication stream it arrived behind the hand-off chain
     // [event -> that stream wakes -> the collective's launch -> k_sgd on the CUs the waiting GEMM leaves free -> publish], ~17 us during
     // which the GEMM sat at the gate (profiles/r04_overlap_cost.txt: overlap = sync + 20 us on one rank).  In-stream, chunk 0's exchange and
     // update are the synchronous schedule's (no hand-off, the whole chip for its k_sgd), the GEMM starts behind them with gate 0 open, and the
     // chain of chunk 1 runs beside the GEMM's first K-tiles (chunk 0's columns: half of the loop) instead of in front of them.
+    // The other chunks follow chunk 0 through ONE event, recorded behind its kernel: the collectives of a step then run in one order on every
+    // transport (the direct peer transport's meeting points are numbered in host order and must be reached in that order: with chunk 1 free to
+    // start beside chunk 0 its meeting overtook chunk 0's and the ranks waited for each other for good -- the first build of this, caught by
+    // tests/test_gpu_dist.py [peer-overlap]).  RCCL serialises a communicator's collectives anyway.
     const bool first_inl = c->overlap_first_inline && nch > 1;
+    if (!first_inl) HIPCHK(hipEventRecord(c->ev_chunk, c->stream));
     struct StreamScope { vv::Comm* k; ~StreamScope() { vv::comm_use_stream(k, nullptr); } } scope{c->comm};
     for (int k = 0; k < nch; ++k) {
       const bool inl = first_inl && k == 0;
@@ -1331,6 +1417,7 @@ int vv_apply_update(vv_ctx* c, const vv_step_cfg* cfg) {
       a.pub_flag = c->w_gate + k * W_GATE_STRIDE;          // the kernel's last workgroup publishes the chunk (SgdArgs::pub_flag)
       a.pub_count = inl ? c->pub_count0 : c->pub_count;    // (a counter of its own: the chunk-1 kernel may run at the same time)
       if (k == 0) PROFILED(c, "sgd", launch_sgd(c->prec, a, ks)); else launch_sgd(c->prec, a, ks);     // (an empty chunk: its wmax slots become 0, the bias if it is the last)
+      if (inl) HIPCHK(hipEventRecord(c->ev_chunk, c->stream));
     }
     vv::comm_use_stream(c->comm, nullptr);
     if (vv::comm_record_done(c->comm)) return fail(VV_ERR_HIP, "all-reduce: %s", vv::comm_error(c->comm));
@@ -1349,7 +1436,9 @@ int vv_apply_update(vv_ctx* c, const vv_step_cfg* cfg) {
 }
 
 int vv_step(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int idx_on_device) {
-  int rc = vv_forward_backward(c, cfg, idx, idx_on_device);
+  int rc = vv_update_hint(c, cfg);                  // (nothing reads the gradient between the two halves of this call)
+  if (rc) return rc;
+  rc = vv_forward_backward(c, cfg, idx, idx_on_device);
   if (rc) return rc;
   return vv_apply_update(c, cfg);
 }
@@ -1370,6 +1459,7 @@ int vv_loss_get(vv_ctx* c, float* loss, float* violations) {
 
 int vv_grads_device(vv_ctx* c, void** dev_ptr, int64_t* n_floats) {
   if (!c || !dev_ptr || !n_floats) return fail(VV_ERR_ARG, "vv_grads_device: NULL argument");
+  { const int rcg = upd_pending_guard(c, "vv_grads_device"); if (rcg) return rcg; }
   if (!c->grads) return fail(VV_ERR_STATE, "vv_grads_device: no parameters");
   { const int rcr = reduce_now(c); if (rcr) return rcr; }      // (whoever reads the buffer on the stream finds the gradient queued in front)
   c->grads_exposed = true;                                     // ... and every later one at the end of its vv_forward_backward
@@ -1379,6 +1469,7 @@ int vv_grads_device(vv_ctx* c, void** dev_ptr, int64_t* n_floats) {
 }
 
 int vv_grads_bind(vv_ctx* c, void* dev_ptr) {
+  { const int rcg = upd_pending_guard(c, "vv_grads_bind"); if (rcg) return rcg; }
   if (!c) return fail(VV_ERR_ARG, "vv_grads_bind: ctx is NULL");
   if (!c->grads_own) return fail(VV_ERR_STATE, "vv_grads_bind: no parameters");
   // no synchronisation: kernels already queued keep the pointer they were launched with; the next
@@ -1389,6 +1480,7 @@ int vv_grads_bind(vv_ctx* c, void* dev_ptr) {
 }
 
 int vv_grads_get(vv_ctx* c, float* dW, float* db) {
+  { const int rcg = upd_pending_guard(c, "vv_grads_get"); if (rcg) return rcg; }
   if (!c) return fail(VV_ERR_ARG, "vv_grads_get: ctx is NULL");
   if (!c->have_fwd) return fail(VV_ERR_STATE, "vv_grads_get: no backward pass yet");
   VV_ENTER(c);
@@ -1657,6 +1749,7 @@ int vv_comm_schedule(vv_ctx* c, int schedule) {
 }
 
 int vv_allreduce_grads(vv_ctx* c) {
+  { const int rcg = upd_pending_guard(c, "vv_allreduce_grads"); if (rcg) return rcg; }
   if (!c) return fail(VV_ERR_ARG, "vv_allreduce_grads: ctx is NULL");
   if (!c->comm) { c->grads_pending = false; return VV_OK; }
   if (!c->have_fwd) return fail(VV_ERR_STATE, "vv_allreduce_grads: no gradients (call vv_forward_backward)");

@@ -744,6 +744,247 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
 #undef SF_TS
 }
 
+// ---- k_score_fwd, PERSISTENT AND PIPELINED (round 5).  k_score_fwd's own phase stamps (profiles/r05_score_fwd_stamps.txt): a workgroup lives
+// 11.6 us of which 8.9 us are the wait for its rows (index load -> 110 KB of rows) and 2.8 us its five compute phases; the 1024 workgroups
+// run as two rounds of 512 that start together, so the chip alternates between everybody loading and everybody computing.  Here one
+// workgroup per CU (the second register set keeps a second one out) walks its items -- the same item -> XCD ranges as item_of_block --
+// with the NEXT item's rows (and the indices of the one after) requested before the current item's phases run.  What that takes:
+//   * every request of the prefetch is UNCONDITIONAL (indices clamped to a valid row instead of `if (...) load`): hipcc's counted waits
+//     (vmcnt is in order) can only leave requests in flight that are certain to have been issued -- behind a conditional one it waits for all;
+//   * no global load inside an item's phases (the coefficients and the item's weight come with the prefetch);
+//   * the phases' barriers are bare s_barrier behind s_waitcnt lgkmcnt(0): __syncthreads() is a workgroup-scope release, and behind a
+//     global store hipcc makes that s_waitcnt vmcnt(0) -- the prefetch would be drained at the first barrier (nothing a phase stores to
+//     global memory is read by another wave of the workgroup).
+// Per item the arithmetic, its order and every output are k_score_fwd's: bit-identical results (tests/test_gpu_segbwd.py,
+// test_gpu_fullsize.py, test_gpu_dedup.py run both).  No dropout form (k_score_fwd<.., true> stays one workgroup per item).
+#define SFP_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+template <int NW>
+__device__ __forceinline__ float sfp_block_sum(float v, float* red) {
+  v = wave_sum63(v);
+  SFP_BAR();
+  if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = v;
+  SFP_BAR();
+  float s = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) s += red[w];
+  return s;
+}
+template <int NW>
+__device__ __forceinline__ void sfp_block_sum3(float& x, float& y, float& z, float* red) {
+  x = wave_sum63(x); y = wave_sum63(y); z = wave_sum63(z);
+  SFP_BAR();
+  if ((threadIdx.x & 63) == 63) { const int w = threadIdx.x >> 6; red[w] = x; red[NW + w] = y; red[2 * NW + w] = z; }
+  SFP_BAR();
+  x = y = z = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) { x += red[w]; y += red[NW + w]; z += red[2 * NW + w]; }
+}
+template <int NW, int RPW, int DV>
+__global__ __launch_bounds__(64 * NW) void k_score_fwd_p(ScoreArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int THREADS = 64 * NW;
+  constexpr int CV = 256 * DV / THREADS;
+  static_assert(CV >= 1 && CV * THREADS == 256 * DV, "D must be a multiple of the thread count");
+  constexpr int CXM = 6;
+  const int D = a.D, C = a.C, Nn = a.Nn, CN = C + Nn;
+  float* A = sm;               // [D]
+  float* Ah = A + D;           // [D]
+  float* acc0 = Ah + D;        // [NW][D] per-wave partial dAh
+  float* n2 = acc0 + NW * D;   // [CN]
+  float* tq = n2 + CN;         // [CN]
+  float* cq = tq + CN;         // [CN]
+  float* red = cq + CN;        // [3 NW]
+  int* ooff = (int*)(red + 3 * NW);   // [CN] grouped position of channel ch's instance
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int G = (int)gridDim.x;
+  const float eps = 1e-10f;
+  // virtual block vb = blockIdx + j G (G a multiple of 8: the XCD of vb is this workgroup's) -> item, as item_of_block over B blocks
+  auto item_of = [&](int vb) { return (a.items_rr || (a.B & 7)) ? vb : (vb & 7) * (a.B >> 3) + (vb >> 3); };
+  struct Idx { int hr[RPW]; int hc[CXM]; int m, o; float wb; };
+  struct Rows { float4 x[RPW][DV]; float cx[CXM][CV]; int seg, o; float wb; };   // (o, wb: carried over from the item's Idx)
+  const int tch = tid < CN ? tid : CN - 1;                     // this thread's channel (the threads past CN repeat the last one: no branch)
+  auto load_idx = [&](int b, Idx& I) {
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+      const int qi = wave + NW * k;
+      const int q = qi <= Nn ? qi : Nn;                        // (a slot past the last negative repeats it: its row is loaded and ignored)
+      I.hr[k] = a.map[b * CN + (q == 0 ? 0 : C + q - 1)];
+    }
+#pragma unroll
+    for (int j = 0; j < CXM; ++j) I.hc[j] = a.map[b * CN + (j + 1 < C ? j + 1 : C - 1)];
+    I.m = a.map[b * CN + tch]; I.o = a.ord[b * CN + tch];
+    I.wb = *(a.item_w ? a.item_w + b : a.loss_part);           // (no weights: any readable float; the value is not used)
+  };
+  auto load_rows = [&](const Idx& I, Rows& R) {
+#pragma unroll
+    for (int k = 0; k < RPW; ++k)
+#pragma unroll
+      for (int v = 0; v < DV; ++v) R.x[k][v] = *(const float4*)(a.H + (int64_t)I.hr[k] * D + lane * 4 + v * 256);
+#pragma unroll
+    for (int j = 0; j < CXM; ++j)
+#pragma unroll
+      for (int v = 0; v < CV; ++v) R.cx[j][v] = a.H[(int64_t)I.hc[j] * D + tid + v * THREADS];
+    R.seg = a.seg_start[I.m];
+    R.o = I.o; R.wb = I.wb;
+  };
+  float cf[CXM];
+#pragma unroll
+  for (int j = 0; j < CXM; ++j) cf[j] = j + 1 < C ? a.coeff[j] : 0.f;
+  const float coeff_t = a.coeff[tid < C - 1 ? tid : 0];          // the context instance's coefficient of thread tid < C - 1
+
+  // one item's phases: k_score_fwd's, statement for statement
+  auto compute = [&](int b, const Rows& R) {
+    if (tid < CN) ooff[tid] = R.seg + R.o;
+    float ssq = 0.f;
+#pragma unroll
+    for (int v = 0; v < CV; ++v) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < CXM; ++j) s += cf[j] * R.cx[j][v];
+      A[tid + v * THREADS] = s;
+      ssq += s * s;
+    }
+    const float sA = sfp_block_sum<NW>(ssq, red);
+    const float nA = sqrtf(sA) + eps;
+    float* Vb = a.V + (int64_t)2 * b * D;
+#pragma unroll
+    for (int v = 0; v < CV; ++v) {
+      const float ah = A[tid + v * THREADS] / nA;
+      Ah[tid + v * THREADS] = ah;
+      Vb[tid + v * THREADS] = ah;
+    }
+    SFP_BAR();
+    float4 y[DV];
+#pragma unroll
+    for (int v = 0; v < DV; ++v) y[v] = *(const float4*)(Ah + lane * 4 + v * 256);
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+      const int qi = wave + NW * k;
+      float s = 0.f, t = 0.f;
+#pragma unroll
+      for (int v = 0; v < DV; ++v) {
+        const float4 xx = R.x[k][v];
+        s += xx.x * xx.x + xx.y * xx.y + xx.z * xx.z + xx.w * xx.w;
+        t += xx.x * y[v].x + xx.y * y[v].y + xx.z * y[v].z + xx.w * y[v].w;
+      }
+      s = wave_sum63(s); t = wave_sum63(t);
+      if (lane == 63 && qi <= Nn) { const int ch = qi == 0 ? 0 : C + qi - 1; n2[ch] = s; tq[ch] = t; }
+    }
+    SFP_BAR();
+    const float sp = tq[0] / (sqrtf(n2[0]) + eps);
+    const float wb = a.item_w ? R.wb : 1.f;
+    float lsum = 0.f, vsum = 0.f, gsum = 0.f;
+    for (int k = tid; k < Nn; k += THREADS) {
+      const int ch = C + k;
+      const float sn = tq[ch] / (sqrtf(n2[ch]) + eps);
+      const float d = sp - sn;
+      const float h = fmaxf(0.f, a.margin - d);
+      float g;
+      if (a.norm == 2) { lsum += wb * h * h; g = 2.f * wb * h * a.grad_scale; }
+      else { lsum += wb * fabsf(h); g = h > 0.f ? wb * a.grad_scale : 0.f; }
+      vsum += d < 0.f ? 1.f : 0.f;
+      gsum += g;
+      cq[ch] = g;
+      if (a.s_bogus) a.s_bogus[(int64_t)b * Nn + k] = sn;
+    }
+    sfp_block_sum3<NW>(lsum, vsum, gsum, red);
+    if (tid == 0) {
+      cq[0] = -gsum;
+      a.loss_part[b] = lsum;
+      a.viol_part[b] = vsum;
+      if (a.s_true) a.s_true[b] = sp;
+      if (a.gate_host && b == 0) __hip_atomic_store(a.gate_host, a.gate_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    SFP_BAR();
+    float bnd = 0.f;
+    float4 pa[DV];
+#pragma unroll
+    for (int v = 0; v < DV; ++v) pa[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+      const int qi = wave + NW * k;
+      if (qi > Nn) continue;                         // wave-uniform
+      const int ch = qi == 0 ? 0 : C + qi - 1;
+      const float c = cq[ch], s = n2[ch], t = tq[ch];
+      const float rs = sqrtf(s);
+      const float k3 = c * __builtin_amdgcn_rcpf(rs + eps);
+      const float cd = c * __builtin_amdgcn_rcpf(s * rs + eps) * a.drop_scale * a.sg;
+      bnd = fmaxf(bnd, fabsf(cd * s) + fabsf(cd * t) * rs);
+      if (lane == 0) { SegRec rc; rc.alpha = cd * s; rc.beta = cd * t; rc.vec = 2 * b; rc.pad = b * CN + ch; a.rec[ooff[ch]] = rc; }
+#pragma unroll
+      for (int v = 0; v < DV; ++v) {
+        pa[v].x += k3 * R.x[k][v].x; pa[v].y += k3 * R.x[k][v].y; pa[v].z += k3 * R.x[k][v].z; pa[v].w += k3 * R.x[k][v].w;
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < DV; ++v) *(float4*)(acc0 + wave * D + lane * 4 + v * 256) = pa[v];
+    if (tid < C - 1) {
+      SegRec rc; rc.alpha = coeff_t * a.drop_scale * a.sg; rc.beta = 0.f; rc.vec = 2 * b + 1; rc.pad = b * CN + tid + 1;
+      a.rec[ooff[tid + 1]] = rc;
+    }
+    if (lane == 0) red[wave] = bnd;
+    SFP_BAR();
+    float bnd_item = 0.f;
+    if (tid == 0) {
+#pragma unroll
+      for (int w = 0; w < NW; ++w) bnd_item = fmaxf(bnd_item, red[w]);
+    }
+    float dot = 0.f;
+    float u[CV];
+#pragma unroll
+    for (int v = 0; v < CV; ++v) {
+      const int d = tid + v * THREADS;
+      float us = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) us += acc0[w * D + d];
+      u[v] = us;
+      dot += A[d] * us;
+    }
+    dot = sfp_block_sum<NW>(dot, red);
+    const float inv_denA = 1.f / (sA * sqrtf(sA) + eps);
+#pragma unroll
+    for (int v = 0; v < CV; ++v) {
+      const int d = tid + v * THREADS;
+      Vb[D + d] = (sA * u[v] - A[d] * dot) * inv_denA;
+    }
+    if (tid == 0 && a.bound_out) {
+      float am = 0.f;
+#pragma unroll
+      for (int j = 0; j < CXM; ++j) am = fmaxf(am, fabsf(cf[j]));
+      bnd_item = fmaxf(bnd_item, am * a.drop_scale * a.sg * 4.f * sA * gsum * inv_denA);
+      atomicMax(a.bound_out + (b & (GG_BOUND_SLOTS - 1)) * GG_BOUND_STRIDE, ((unsigned long long)(unsigned)a.bound_seq << 32) | __float_as_uint(bnd_item));
+    }
+    SFP_BAR();                                       // the LDS areas are the next item's
+  };
+
+  const int me = (int)blockIdx.x;
+  const int n_it = ((int)a.B - me + G - 1) / G;      // items of this workgroup: virtual blocks me, me + G, ...
+  if (n_it <= 0) return;
+  auto item = [&](int j) { return item_of(me + (j < n_it ? j : n_it - 1) * G); };   // (past the end: the last item again -- requests stay unconditional)
+  Idx I;
+  Rows R0, R1;
+  load_idx(item(0), I);
+  load_rows(I, R0);
+  load_idx(item(1), I);
+  int j = 0;
+  for (; j + 2 < n_it; j += 2) {                     // two items per trip: the register sets swap roles by name, not by copy
+    load_rows(I, R1);                                // item j + 1's rows fly beside item j's phases
+    load_idx(item(j + 2), I);
+    compute(item(j), R0);
+    load_rows(I, R0);
+    load_idx(item(j + 3), I);
+    compute(item(j + 1), R1);
+  }
+  if (j + 1 < n_it) {                                // two items left
+    load_rows(I, R1);
+    compute(item(j), R0);
+    compute(item(j + 1), R1);
+  } else {
+    compute(item(j), R0);
+  }
+}
+#undef SFP_BAR
+
 // ---- the same pass for items that do not fit in registers (D = 1024, hundreds of negatives: the per-GPU shape of BASELINE
 // configs[4]): ONE sweep over the item's rows.  A wave takes negatives wave, wave + NW, ...; a row is in registers (DV float4
 // per lane) while its norm and its dot with Ah are reduced inside the wave, and because every wave has computed the TARGET's
@@ -949,6 +1190,20 @@ void launch_score_fwd(const ScoreArgs& a_in, hipStream_t s) {
     return;
   }
   const size_t lds = sizeof(float) * ((size_t)(2 + 8) * a.D + 4 * (a.C + a.Nn) + 3 * 8);
+  // the persistent, pipelined form: batches of at least two items per CU, no dropout (KernelOpts::score_pipe, VV_SCORE_PIPE=0: one workgroup per item)
+  static int n_cu = 0;
+  if (!n_cu) { int dev = 0; hipDeviceProp_t pr; (void)hipGetDevice(&dev); n_cu = hipGetDeviceProperties(&pr, dev) == hipSuccess ? pr.multiProcessorCount : 256; }
+  const int G = n_cu & ~7;
+  if (ko().score_pipe && !a.drop.mode && G >= 8 && a.B >= 2 * G) {
+#define VV_SFP(RPW)                                                                                       \
+    do {                                                                                                  \
+      (void)hipFuncSetAttribute((const void*)k_score_fwd_p<8, RPW, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      VV_LAUNCH((k_score_fwd_p<8, RPW, 2>), dim3(G), dim3(512), lds, s, a);                              \
+    } while (0)
+    if (rows <= 16) VV_SFP(2); else if (rows <= 32) VV_SFP(4); else VV_SFP(7);
+#undef VV_SFP
+    return;
+  }
 #define VV_SF(RPW)                                                                                        \
   do {                                                                                                    \
     if (a.drop.mode) {                                                                                    \
@@ -1661,7 +1916,7 @@ __global__ __launch_bounds__(256) void k_reduce_sgd(FusedUpdArgs fa) {
 }
 int launch_reduce_sgd(const FusedUpdArgs& a, hipStream_t s) {
   const int ndb = (a.r.D + 15) / 16;
-  const int nblk = (int)std::min<int64_t>(((int64_t)a.r.D * (a.r.F / 4) + 255) / 256, WMAX_SLOTS);
+  const int nblk = a.no_params ? 0 : (int)std::min<int64_t>(((int64_t)a.r.D * (a.r.F / 4) + 255) / 256, WMAX_SLOTS);
   const dim3 grid(nblk + ndb + 1);
   if (a.prec == 0) VV_LAUNCH((k_reduce_sgd<F16>), grid, dim3(256), 0, s, a);
   else VV_LAUNCH((k_reduce_sgd<BF16>), grid, dim3(256), 0, s, a);

@@ -468,6 +468,11 @@ static void launch_wgrad_t(const WgradArgs& a, hipStream_t s) {
 
 void launch_wgrad_gemm_ph(int prec, const WgradArgs& a, hipStream_t s);
 void launch_wgrad_gemm_w4(int prec, const WgradArgs& a, hipStream_t s);
+// the update in the epilogue (WgradArgs::fuse_upd) exists in the phase-staggered kernel only: api.hip asks before it fills WgradUpd
+bool wgrad_can_fuse_update() {
+  const int v = ko().gemm_variant;
+  return (v == 5 || v == 6) && ko().wgrad_tr != 0 && !ko().ablate && !ko().lab_wg_abl;
+}
 void launch_wgrad_gemm(int prec, const WgradArgs& a, hipStream_t s) {
   const int g_gemm_variant = ko().gemm_variant; const bool g_wgrad_tr = ko().wgrad_tr != 0;
 #ifdef VV_LAB

@@ -601,7 +601,8 @@ __device__ __forceinline__ i16x4 ph_tr(const unsigned char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(p));
 }
 
-template <typename T, int ABL = 0>
+// UPD: one split of K (S == 1) and the solver's update applied to the tile where it stands (WgradUpd, vv_internal.h) instead of the slab store
+template <typename T, int ABL = 0, bool UPD = false>
 __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int32_t* ids = (int32_t*)(smem + PH_LDS_BYTES);
@@ -752,6 +753,97 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
 #undef PW_TILE
   }
 
+  if constexpr (UPD) {
+    // ---- the update on the tile (k_reduce_sgd's parameter workgroups, element for element: the same products, the same rule, the same
+    // roundings -- parameters, history and half copy bit for bit those of the two-launch form, tests/test_gpu_fused_update.py)
+    const WgradUpd& u = a.upd;
+    __shared__ float red8[8];
+    float sw = u.scales->sw_next;
+    if (u.recompute_scale) {                              // the scale of the new half copy from the previous update's per-block maxima
+      float mm = 0.f;
+      for (int k = tid; k < u.wmax_prev_n; k += GEMM_THREADS) mm = fmaxf(mm, u.wmax_prev[k]);
+#pragma unroll
+      for (int o2 = 32; o2 > 0; o2 >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o2, 64));
+      if (lane == 0) red8[wave] = mm;
+      __syncthreads();
+      mm = red8[0];
+#pragma unroll
+      for (int w8 = 1; w8 < 8; ++w8) mm = fmaxf(mm, red8[w8]);
+      __syncthreads();
+      const float mx = fmaxf(mm, __uint_as_float(u.scales->wmax_bits));
+      sw = 1.f;
+      if (u.prec == 0 && mx > 0.f && isfinite(mx)) { int e; frexpf(mx, &e); sw = ldexpf(1.f, 12 - e); }
+    }
+    const float sgf = u.gg ? u.sg * u.gg->mul : u.sg;
+    const float inv = u.ip_scale / (sgf * u.scales->sx);
+    const float lr_w = u.rate * u.lr_mult_w, dc_w = u.weight_decay * u.decay_mult_w;
+    auto rule = [&](float w, float gr, float& h) {        // (k_sgd's)
+      if (dc_w != 0.f) gr += dc_w * (u.reg == 2 ? w : (float)((w > 0.f) - (w < 0.f)));
+      float up;
+      if (u.solver_type == 1) { const float h0 = h; h = lr_w * gr + u.momentum * h0; up = (1.f + u.momentum) * h - u.momentum * h0; }
+      else if (u.solver_type == 2) { h += gr * gr; up = lr_w * (gr / (sqrtf(h) + u.delta)); }
+      else { h = lr_w * gr + u.momentum * h; up = h; }
+      return w - up;
+    };
+    float wmax = 0.f;
+    // groups of four quads (one row m, one 128-column half: ni = 0..3), W and history of the NEXT group requested before this one is stored
+    f32x4 wv[2][4], hv[2][4];
+    auto gaddr = [&](int grp, int ni, int& m, int& n) {
+      const int mh = grp >> 2, mi = (grp >> 1) & 1, nh = grp & 1;
+      m = m0 + mh * 128 + wn * 32 + mi * 16 + li;
+      n = n0 + nh * 128 + wm * 64 + ni * 16 + g * 4;
+    };
+    auto gload = [&](int grp, int buf) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        int m, n; gaddr(grp, ni, m, n);
+        const bool in = m < u.D && n < u.F;
+        const int64_t o = (int64_t)m * u.F + n;
+        wv[buf][ni] = in ? __builtin_nontemporal_load((const f32x4*)(u.W + o)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        hv[buf][ni] = in ? __builtin_nontemporal_load((const f32x4*)(u.hW + o)) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    gload(0, 0);
+#pragma unroll
+    for (int grp = 0; grp < 8; ++grp) {
+      const int buf = grp & 1;
+      if (grp + 1 < 8) gload(grp + 1, buf ^ 1);
+      const int mh = grp >> 2, mi = (grp >> 1) & 1, nh = grp & 1;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        int m, n; gaddr(grp, ni, m, n);
+        if (m >= u.D || n >= u.F) continue;
+        const int64_t o = (int64_t)m * u.F + n;
+        const f32x4 v = acc[nh][ni][mh][mi];
+        f32x4 wq = wv[buf][ni], hq = hv[buf][ni];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float gr = __fmul_rn(v[j], inv);          // (a rounded product, as the slab path stores it: no contraction into the rule)
+          float hj = hq[j];
+          wq[j] = rule(wq[j], gr, hj);
+          hq[j] = hj;
+          wmax = fmaxf(wmax, fabsf(wq[j]));
+        }
+        __builtin_nontemporal_store(wq, (f32x4*)(u.W + o));
+        __builtin_nontemporal_store(hq, (f32x4*)(u.hW + o));
+        const uint32_t lo = T::from_float(wq[0] * sw) | ((uint32_t)T::from_float(wq[1] * sw) << 16);
+        const uint32_t hi = T::from_float(wq[2] * sw) | ((uint32_t)T::from_float(wq[3] * sw) << 16);
+        *(uint2*)(u.Wh + (int64_t)m * a.Fp + n) = make_uint2(lo, hi);
+      }
+    }
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o2, 64));
+    if (lane == 0) red8[wave] = wmax;
+    __syncthreads();
+    if (tid == 0) {
+      float wb = red8[0];
+#pragma unroll
+      for (int w8 = 1; w8 < 8; ++w8) wb = fmaxf(wb, red8[w8]);
+      u.wmax_blocks[blockIdx.x] = wb;
+      if (blockIdx.x == 0) { u.scales->sw_cur = sw; if (u.recompute_scale) u.scales->sw_next = sw; }
+    }
+    return;
+  }
   // D' = X_frag^T-major: the lane's column is m (dY column = output row d), its 4 registers 4 consecutive n
   float* slab = a.slabs + (int64_t)sp * a.Dp * a.Fp;
 #pragma unroll
@@ -1097,6 +1189,13 @@ static void launch_wgrad_ph_t(const WgradArgs& a, hipStream_t s) {
     }
   }
 #endif
+  if (a.fuse_upd) {                       // (one split of K: the update where the gradient is born -- api.hip decides, WgradUpd)
+    static bool once_u = ((void)hipFuncSetAttribute((const void*)k_wgrad_gemm_ph<T, 0, true>,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, PH_WG_LDS_BYTES), true);
+    (void)once_u;
+    VV_LAUNCH((k_wgrad_gemm_ph<T, 0, true>), grid, block, PH_WG_LDS_BYTES, s, a);
+    return;
+  }
   VV_LAUNCH((k_wgrad_gemm_ph<T>), grid, block, PH_WG_LDS_BYTES, s, a);
 }
 

@@ -138,6 +138,13 @@ struct vv_ctx {
   vv::KernelOpts ko;                // which kernels the launchers pick (vv_internal.h)
   bool fuse_update = true;          // "fuse_update" / VV_FUSE_UPDATE=0: reduce at the end of every backward pass, update apart
   bool comm_gate = true;            // "comm_gate" / VV_COMM_GATE=0: the overlapped update never gates the forward GEMM (the stream joins)
+  // vv_update_hint: the next vv_forward_backward* is followed by vv_apply_update with these solver parameters and nothing reads the gradient
+  // in between -- with one split of K the weight-gradient GEMM then applies the update itself (WgradUpd)
+  bool upd_hint = false;
+  vv_step_cfg upd_cfg;
+  bool upd_in_wgrad = false;                // this step's parameter matrix is already updated; vv_apply_update finishes the step
+  int upd_wgrad_blocks = 0;                 // per-block max |w| slots that launch wrote
+  bool grads_lost = false;                  // the last step's dW was consumed in registers (vv_grads_* refuse until the next backward pass)
   uint32_t* lab_score_ts = nullptr;         // (lab builds) device buffer of k_score_fwd's phase stamps, api.hip
   bool comm_inline = true;                  // option "comm_inline" (VV_COMM_INLINE): the sharded update queued on the compute stream itself (no second stream, no gate)
   int comm_test_delay_us = 0;       // "comm_test_delay_us" / VV_COMM_TEST_DELAY_US: TEST HOOK -- the communication stream held this long per chunk
@@ -164,7 +171,9 @@ struct vv_ctx {
   int chunk_kt[5] = {0, 0, 0, 0, 0};    // first K-tile of each chunk for the current Fp (chunk_plan)
   int32_t* pub_count = nullptr;     // device: arrival counter of the publishing SGD kernels (behind the flags)
   int32_t* pub_count0 = nullptr;    // ... of the first chunk's kernel when that one runs on the compute stream (overlap_first_inline)
-  bool overlap_first_inline = true; // VV_COMM_FIRST_INLINE: the overlapped update's first F-chunk (exchange + SGD) in the compute stream, the rest on the communication stream
+  bool overlap_first_inline = false; // VV_COMM_FIRST_INLINE=1: the overlapped update's first F-chunk (exchange + SGD) in the compute stream, the rest on the communication
+                                    // stream (round 5: built, measured, NOT the default -- one rank over real RCCL 0.2490-0.2501 ms against 0.2401-0.2430 with every
+                                    // chunk on the communication stream: chunk 0 loses its head start behind its own reduction launch, profiles/r05_overlap_cost.txt)
   hipEvent_t ev_chunk0 = nullptr; bool chunk0_event = false;     // the first F-chunk's reduction is done (recorded by fb_impl)
   int32_t* gate_err = nullptr; int32_t* gate_err_dev = nullptr;     // pinned + mapped: a gated forward gave up waiting
   hipEvent_t ev_chunk = nullptr;

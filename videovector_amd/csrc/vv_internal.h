@@ -244,6 +244,21 @@ struct SegsumArgs {
   GuardArgs guard;
 };
 
+// The solver's update applied in the weight-gradient GEMM's epilogue (one split of K: the tile in the accumulators IS the gradient;
+// api.hip: vv_update_hint).  What k_reduce_sgd does per 16 bytes of W -- unscale, the solver's rule (solver.cpp:502-531 / 599-655 / 714-781),
+// blob.cpp:112-136, the new 16-bit copy, max |w| for the next scale -- done on the 256 x 256 tile while it is in registers: the 4 D F
+// bytes of dW are neither written nor read back.  Bias, loss and the guard's report stay with k_reduce_sgd's special workgroups.
+struct WgradUpd {
+  float* W; float* hW; uint16_t* Wh;
+  Scales* scales;
+  float* wmax_blocks;                    // one slot per workgroup of the GEMM (this update's per-block max |w|)
+  const float* wmax_prev; int wmax_prev_n; int recompute_scale; int prec;      // as FusedUpdArgs
+  int D, F;                              // the matrix (tiles are padded to Dp x Fp)
+  float rate, momentum, weight_decay, lr_mult_w, decay_mult_w, delta;
+  int reg, solver_type;
+  float sg; const GradGuard* gg; float ip_scale;          // dW = acc * ip_scale / (sg * gg->mul * sx), as ReduceArgs
+};
+
 struct WgradArgs {
   const uint16_t* dYh;     // [Rp][Dp]
   const uint16_t* table;   // [n_rows+1][Fp]
@@ -257,6 +272,8 @@ struct WgradArgs {
   int tm_begin = 0, tm_count = 0;    // restrict the launch to M tiles [tm_begin, tm_begin + tm_count) (0 = all): the
                                      // data-parallel overlap all-reduces one row block of dW while the next is computed
   int abl = 0;                       // as FwdArgs::abl
+  int fuse_upd = 0;                  // 1: S == 1 and the epilogue applies `upd` instead of storing the tile to the slab
+  WgradUpd upd;
 };
 
 struct ReduceArgs {
@@ -327,6 +344,8 @@ struct SgdArgs {
 // recompute_scale is set, else takes Scales::sw_next as it stands; this update's maxima go to g.wmax_blocks (another buffer).
 struct FusedUpdArgs {
   ReduceArgs r; SgdArgs g;
+  int no_params = 0;         // 1: only the special workgroups (bias, loss, the guard's report): the parameter matrix was updated in the
+                             //    weight-gradient GEMM's epilogue (WgradUpd)
   const float* wmax_prev = nullptr; int wmax_prev_n = 0; int recompute_scale = 0; int prec = 0;
   int store_grads = 0;       // also write dW to the gradient buffer (0: it stays in the slabs, api.hip materialises it on request)
 };
@@ -342,6 +361,7 @@ struct KernelOpts {
   int fwd_lead = 1;        // "fwd_lead" / VV_FWD_LEAD: the forward GEMM's sibling lead (kernels_gemm_ph.hip)
   int wgrad_tr = 1;        // "wgrad_tr" / VV_WGRAD_TR: transposed LDS reads in the weight-gradient GEMM (0: the round-1 kernel)
   int score_stream = 0;    // "score_stream" / VV_SCORE_STREAM: the one-sweep score kernel for every shape
+  int score_pipe = 1;      // "score_pipe" / VV_SCORE_PIPE: the persistent, pipelined form of the register-resident score kernel (k_score_fwd_p; 0: one workgroup per item)
   int gemm_variant = 5;    // (lab) VV_GEMM_VARIANT: 5 = the phase-staggered kernels; 0 = the round-1 kernels; 6 / 7 / 8 mixtures
   int ablate = 0;          // (lab) VV_ABLATE: ablated instantiations of the dense-size GEMMs (results wrong)
   int lab_fwd_abl = 0;     // (lab) VV_LAB_FWD_ABL: ablations of the 192-row forward kernel at the de-duplicated size (results wrong)
@@ -379,6 +399,7 @@ void launch_fwd_gemm(int prec, const FwdArgs& a, hipStream_t s);
 bool fwd_gemm_can_gate(const FwdArgs& a);                     // the forward kernel has a gated form for these arguments (FwdArgs::gate)
 long fwd_gemm_plan(int R, int R_hint, int D, int* mq_out);   // workgroups of the default forward GEMM that get a tile
 void launch_wgrad_gemm(int prec, const WgradArgs& a, hipStream_t s);
+bool wgrad_can_fuse_update();
 void launch_score_loss(int prec, const ScoreArgs& a, hipStream_t s);
 void launch_dedup(const DedupArgs& a, hipStream_t s);
 void launch_dedup_groups(const DedupArgs& a, hipStream_t s);

@@ -73,6 +73,7 @@ def load_library():
         "vv_forward_backward": [vp, vp, vp, C.c_int], "vv_apply_update": [vp, vp],
         "vv_forward_backward_q1": [vp, vp, vp, vp],
         "vv_step": [vp, vp, vp, C.c_int],
+        "vv_update_hint": [vp, vp],
         "vv_forward_backward_ring": [vp, vp, vp, i32, i32, vp, C.c_double],
         "vv_dev_alloc": [vp, C.c_size_t, C.POINTER(vp)], "vv_dev_free": [vp, vp],
         "vv_dev_upload": [vp, vp, vp, C.c_size_t], "vv_dev_download": [vp, vp, vp, C.c_size_t],
@@ -273,8 +274,10 @@ class Engine:
 
     # ---- data parallel (vv_comm_*)
     def comm_init(self, world, rank, id_path, transport="rccl"):
-        self._chk(self.L.vv_comm_init(self.h, world, rank, None if id_path is None else id_path.encode(),
-                                      {"rccl": 0, "shm": 1, "peer": 2}[transport]))
+        kinds = {"rccl": 0, "shm": 1, "peer": 2}
+        if transport not in kinds:
+            raise VVError("comm_init: unknown transport %r (rccl, shm, peer)" % (transport,))
+        self._chk(self.L.vv_comm_init(self.h, world, rank, None if id_path is None else id_path.encode(), kinds[transport]))
 
     def comm_overlap(self, on=True):
         self._chk(self.L.vv_comm_overlap(self.h, int(bool(on))))
@@ -289,10 +292,15 @@ class Engine:
     def comm_destroy(self):
         self._chk(self.L.vv_comm_destroy(self.h))
 
+    def update_hint(self, cfg):
+        """The next forward_backward* is followed by apply_update(cfg) and nothing reads the gradient in between (vv_update_hint)."""
+        self._chk(self.L.vv_update_hint(self.h, C.byref(cfg.c)))
+
     def apply_update(self, cfg):
         self._chk(self.L.vv_apply_update(self.h, C.byref(cfg.c)))
 
     def step(self, cfg, idx=None, idx_dev_ptr=None):
+        self.update_hint(cfg)                      # (what vv_step does: nothing reads the gradient between the two calls)
         self.forward_backward(cfg, idx, idx_dev_ptr)
         self.apply_update(cfg)
 
