@@ -66,8 +66,30 @@ def cpu_baseline(ds, idx, W, b, items, iters, threads=0):
     links an external BLAS for its sgemm (Makefile.config:34): when the machine has one (MKL ships in the image) it is
     timed against the oracle's own blocked sgemm on one warm-up iteration each and the faster is used and named.  The
     GFLOP/s of the two fc7 GEMMs alone is reported next to the whole-iteration rate."""
+    # OpenMP placement of the oracle's own runtime (read when liboracle.so loads -- torch's bundled OpenMP is another library): threads on
+    # neighbouring cores of one socket.  profiles/r05_cpu_scaling.txt: 32 threads 0.273 s bound `close` against 0.358 s unbound.
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
+    # an external BLAS must not bring a second, spinning thread pool onto the same bound cores (MKL's own OpenMP runtime did: the iterations
+    # after its trial ran 20x slower): its GNU threading layer shares the oracle's runtime, and idle workers of any Intel runtime sleep at once
+    os.environ.setdefault("MKL_THREADING_LAYER", "GNU")
+    os.environ.setdefault("KMP_BLOCKTIME", "0")
     from oracle import oracle as orc
     orc.set_threads(threads)
+    # What this process may use of the host: the MI355X boxes' containers carry a CPU-time quota (cgroup cpu.max: 16 CPUs' worth on a 256-thread
+    # host) -- more runnable threads than ~2x the quota are throttled, not run (64 threads 0.47-0.63 s, 128 0.74-0.97 s, 256 4-20 s per iteration)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = os.cpu_count() or 1
+    allow = max(1, min(affinity, int(np.ceil(quota)) if quota else affinity))
     sh = idx[:items]
     uniq, inv = np.unique(sh.reshape(-1), return_inverse=True)
     table = ds.table(F, uniq)
@@ -88,33 +110,39 @@ def cpu_baseline(ds, idx, W, b, items, iters, threads=0):
     if threads == 0:
         all_t = orc.get_threads()
         one()                                    # first touch of the buffer pool
-        for t_ in sorted({all_t, max(1, all_t // 2), max(1, all_t // 4)}, reverse=True):
+        cand = {min(all_t, allow), min(all_t, 2 * allow), min(all_t, 3 * allow)} if quota else {all_t, max(1, all_t // 2), max(1, all_t // 4)}
+        for t_ in sorted(cand, reverse=True):
             orc.set_threads(t_)
             tried[t_] = one()
         orc.set_threads(min(tried, key=tried.get))
-    t_own = one()
-    t_ext = None
-    if blas and orc.set_blas(blas):
-        t_ext = one()
-    use_ext = t_ext is not None and t_ext < t_own
-    if not use_ext:
-        orc.set_blas(None)
+    # the oracle's own sgemm first, completely (timed iterations and its GEMM rates) -- then the external BLAS, if any, the same way: whatever a
+    # foreign library leaves behind (threads, bindings) cannot touch the first measurement; the faster of the two is reported
+    orc.set_blas(None)
+    one()
     ts = [one() for _ in range(iters)]
     t = float(np.mean(ts))
-    gemm = None
-    if hasattr(orc, "gemm_gflops"):
-        gemm = orc.gemm_gflops(items * (C + NN), D, F)
+    gemm = orc.gemm_gflops(items * (C + NN), D, F) if hasattr(orc, "gemm_gflops") else None
+    use_ext = False
+    if blas and orc.set_blas(blas):
+        one()
+        ts_e = [one() for _ in range(iters)]
+        if float(np.mean(ts_e)) < t:
+            use_ext, ts, t = True, ts_e, float(np.mean(ts_e))
+            gemm = orc.gemm_gflops(items * (C + NN), D, F) if hasattr(orc, "gemm_gflops") else None
     orc.set_blas(None)
     out = {"value": items * NN / t, "unit": "triplets/s", "cores": orc.get_threads(), "kind": "port",
            "blas": ("cblas_sgemm of " + os.path.basename(blas)) if use_ext else "the oracle's own blocked OpenMP sgemm",
            "sample": "%d of %d batch items (%d rows) of the same 4096->%d, C5, Nn%d step, "
                      "%d timed iterations after warm-up, %.2f s each" % (items, B_PER_GPU, items * (C + NN), D, NN, iters, t),
            "iteration_gflops": 4.0 * items * (C + NN) * F * D / t / 1e9,
-           "host_logical_cpus": os.cpu_count(),
-           "note": "thread count picked on one warm-up iteration each (all / half / a quarter of the host's threads): on the two-socket "
-                   "hosts of the MI355X boxes that is a fraction of the machine -- the oracle's sgemm is not NUMA-aware (it packs its "
-                   "panels on the calling thread's node), so this baseline is UNDERSTATED against what a NUMA-aware BLAS on every core "
-                   "would do; it is a stated baseline, never the target"}
+           "host_logical_cpus": os.cpu_count(), "cpu_quota_cpus": quota, "cpus_in_affinity_mask": affinity,
+           "omp_binding": "%s / %s" % (os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES")),
+           "note": ("this process may use %.0f CPUs' worth of time (cgroup cpu.max) of the host's %d logical CPUs: the thread count is picked among "
+                    "1x / 2x / 3x that allowance on one warm-up iteration each, threads bound to neighbouring cores (profiles/r05_cpu_scaling.txt: "
+                    "every count above ~2x the allowance runs slower -- throttling, not NUMA); `cores` = the threads used.  A stated baseline for "
+                    "THIS allowance, never the target" % (quota, os.cpu_count())) if quota else
+                   ("thread count picked on one warm-up iteration each (all / half / a quarter of the host's threads), threads bound to "
+                    "neighbouring cores; a stated baseline, never the target")}
     if tried:
         out["threads_tried_s_per_iteration"] = {str(k): round(v, 3) for k, v in tried.items()}
     if gemm is not None:
@@ -716,8 +744,12 @@ def main():
         limit = float(os.environ.get("VV_BENCH_CHILD_TIMEOUT", "240"))
         for name, argv, off in want:
             if dist: dist.barrier()
+            t_leg = time.perf_counter()
+            # (under torch.distributed.run the AGENT hosts the rendezvous store of the job; the leg's own job has no agent: its rank 0 hosts one)
             child[name] = leg_helper.run(argv, {"MASTER_PORT": str(base_port + off), "TORCHELASTIC_RUN_ID": rid + "_" + name, "VV_BENCH_CHILD": "1",
+                                                "TORCHELASTIC_USE_AGENT_STORE": "False",
                                                 "VV_COMM_TIMEOUT": os.environ.get("VV_COMM_TIMEOUT", "30")}, limit)
+            child[name]["wall_s"] = round(time.perf_counter() - t_leg, 2)
         leg_helper.close()
     t_legs_done = time.perf_counter()
 
@@ -849,9 +881,10 @@ def main():
                 cj = json.loads(rep["line"])
                 out[name] = {"ms_per_step": cj["ms_per_step"], "value": cj["value"], "final_loss": cj["final_loss"],
                              "allreduce": cj["config"]["allreduce"], "comm": cj["config"]["comm"], "sampler": cj["config"]["sampler"],
+                             "wall_s": rep.get("wall_s"),
                              "source": "a fresh process per rank (started by each rank's helper before the rank's first GPU call), end to end like `value`"}
             else:
-                out[name] = {"error": (rep.get("err_tail") or "no line").strip()[-400:], "rc": rep.get("rc")}
+                out[name] = {"error": (rep.get("err_tail") or "no line").strip()[-400:], "rc": rep.get("rc"), "wall_s": rep.get("wall_s")}
         if one_logical is not None:
             out["one_logical_sampler"] = one_logical
         # where the wall-clock time of this process goes besides the K timed steps (for whoever times the whole command)

@@ -66,8 +66,6 @@ int vv_set_dedup(vv_ctx* ctx, int on);
  *   "fwd_lead" (VV_FWD_LEAD, 1)      the forward GEMM's sibling lead
  *   "wgrad_tr" (VV_WGRAD_TR, 1)      transposed LDS reads in the weight-gradient GEMM (0: the first-round kernel)
  *   "score_stream" (VV_SCORE_STREAM, 0)  1: the one-sweep score kernel for every shape
- *   "score_pipe" (VV_SCORE_PIPE, 1)  the register-resident score kernel as persistent workgroups that request the next item's rows before the
- *                                    current item's phases (batches of two or more items per CU; 0: one workgroup per item)
  *   "comm_gate" (VV_COMM_GATE, 1)    the overlapped update gates the next forward GEMM chunk by chunk (0: the stream joins)
  *   "comm_inline" (VV_COMM_INLINE, 1)  the SHARDED update's three steps (reduce-scatter, the rule on this rank's rows, all-gather) are queued
  *                                    on the compute stream itself (0: on the communication stream, the next forward GEMM gated on one flag)

@@ -92,6 +92,14 @@ def test_bench_per_rank_samplers_is_the_default_for_two_ranks():
     assert d["value"] > 0 and 0 < d["final_loss"] < 16 and d["settle"]["steps"] == 8
     assert d["gpu_path_only"]["value"] > 0 and d["dense_execution"]["value"] > 0
     assert "logical CPUs" in d["config"]["cpu_binding_rank0"] or d["config"]["cpu_binding_rank0"].startswith("not bound")
+    # the driver's launch form (torch.distributed.run): the schedule legs and the fresh-process legs come back here too (their own rendezvous:
+    # the launcher's agent does not host a store for them)
+    assert "reduce-scatter" in d["config"]["allreduce"]                  # N > 1 default: the sharded update in the compute stream
+    assert set(d["schedules"]["legs"]) == {"sync", "overlap", "sharded"} and d["schedules"]["legs"]["sharded"].get("default")
+    for name, leg in d["schedules"]["legs"].items():
+        assert leg["final_loss"] == d["final_loss"], (name, leg)
+    assert "error" not in d["peer_transport_leg"] and d["peer_transport_leg"]["final_loss"] == d["final_loss"], d["peer_transport_leg"]
+    assert "error" not in d["node_sampler_leg"] and d["node_sampler_leg"]["wall_s"] < 200, d["node_sampler_leg"]
 
 
 def test_bench_bare_command_launches_its_own_ranks():

@@ -231,26 +231,3 @@ def test_the_whole_benchmark_batch_against_the_oracle(setup, oracle, dropout):
         assert rel(Wn - W, Wo - W) <= tol and rel(bn - b, bo - b) <= tol
     assert np.linalg.norm(Wn - W) > 0
 
-
-def test_pipelined_score_kernel_is_bit_identical(setup):
-    """The default score kernel of batches of two or more items per CU is persistent and pipelined (k_score_fwd_p: one workgroup per CU walks
-    its items with the next item's rows requested before the current item's phases; unconditional clamped requests, bare barriers) -- per item
-    the arithmetic and its order are k_score_fwd's.  score_pipe = 0 selects one workgroup per item: every output bit must agree."""
-    vv, ds, idx, W, b, _ = setup
-    cfg = vv.StepConfig(B, C, Nn, lr=0.01)
-    res = {}
-    for pipe in (1, 0):
-        e = vv.Engine(0, "f16")
-        e.set_option("score_pipe", pipe)
-        assert e.get_option("score_pipe") == pipe
-        e.table_synth(ds.seed, ds.n_rows, F); e.params_set(W, b)
-        e.forward_backward(cfg, idx)
-        e.forward_backward(cfg, idx)
-        blobs = e.blobs(cfg, ip1_diff=True)
-        dW, db = e.grads()
-        e.apply_update(cfg)
-        Wn = e.params_get()[0]
-        res[pipe] = (e.loss(), blobs["target_score"].copy(), blobs["negative_scores"].copy(), blobs["ip1_diff"].copy(), dW.copy(), db.copy(), Wn.copy())
-        del e
-    for x, y in zip(res[1], res[0]):
-        assert np.array_equal(np.asarray(x), np.asarray(y))

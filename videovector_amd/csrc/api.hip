@@ -138,7 +138,6 @@ static int create_init(vv_ctx* c) {
   if (const char* v = opt_env("VV_WGRAD_TR")) c->ko.wgrad_tr = atoi(v) != 0;
   if (const char* v = opt_env("VV_FWD_LEAD")) c->ko.fwd_lead = atoi(v);
   if (const char* v = opt_env("VV_SCORE_STREAM")) c->ko.score_stream = atoi(v);
-  if (const char* v = opt_env("VV_SCORE_PIPE")) c->ko.score_pipe = atoi(v);
   if (const char* v = opt_env("VV_SEG_BWD")) c->seg_bwd = atoi(v) != 0;
   if (const char* v = opt_env("VV_DEDUP")) c->dedup = atoi(v) != 0;
   if (const char* v = opt_env("VV_FUSE_UPDATE")) c->fuse_update = atoi(v) != 0;
@@ -156,6 +155,7 @@ static int create_init(vv_ctx* c) {
   if (const char* v = lab_env("VV_SCORE_REG")) c->ko.score_reg = atoi(v);
   if (const char* v = lab_env("VV_SCORE_WAVES")) c->ko.score_waves = atoi(v);
   if (const char* v = lab_env("VV_SCORE_RR")) c->ko.score_rr = atoi(v);
+  if (const char* v = lab_env("VV_LAB_SCORE_PIPE")) c->ko.lab_score_pipe = atoi(v);
   if (const char* v = lab_env("VV_GUARD_PROACTIVE")) c->guard_proactive = atoi(v) != 0;
   if (const char* v = lab_env("VV_FUSE_KEEP_GRADS")) c->fuse_keep_grads = atoi(v) != 0;
   if (const char* v = lab_env("VV_COMM_SKIP_AR1")) c->comm_skip_ar1 = atoi(v) != 0;
@@ -289,7 +289,6 @@ int vv_set_option(vv_ctx* c, const char* name, double value) {
   if (n == "fwd_lead") { c->ko.fwd_lead = iv; return VV_OK; }
   if (n == "wgrad_tr") { c->ko.wgrad_tr = iv != 0; return VV_OK; }
   if (n == "score_stream") { c->ko.score_stream = iv; return VV_OK; }
-  if (n == "score_pipe") { c->ko.score_pipe = iv; return VV_OK; }
   if (n == "comm_gate") { c->comm_gate = iv != 0; return VV_OK; }
   if (n == "comm_inline") { c->comm_inline = iv != 0; return VV_OK; }
   if (n == "comm_first_inline") { c->overlap_first_inline = iv != 0; return VV_OK; }
@@ -315,7 +314,6 @@ int vv_get_option(vv_ctx* c, const char* name, double* value) {
   else if (n == "fwd_lead") *value = c->ko.fwd_lead;
   else if (n == "wgrad_tr") *value = c->ko.wgrad_tr;
   else if (n == "score_stream") *value = c->ko.score_stream;
-  else if (n == "score_pipe") *value = c->ko.score_pipe;
   else if (n == "comm_gate") *value = c->comm_gate;
   else if (n == "comm_inline") *value = c->comm_inline;
   else if (n == "comm_first_inline") *value = c->overlap_first_inline;
@@ -1034,6 +1032,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   if (seg) {
     sa.V = c->segV; sa.rec = c->seg_rec;
 #ifdef VV_LAB
+    if (const char* v = lab_env("VV_LAB_SCORE_HACK")) sa.lab_hack = atoi(v);
     if (lab_env("VV_LAB_SCORE_TS")) {
       // (lab) k_score_fwd's phase stamps: one buffer, every step overwrites it; tools/lab/score_ts.py reads it through vv_lab_score_ts
       static thread_local uint32_t* ts_buf = nullptr;

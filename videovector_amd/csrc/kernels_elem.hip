@@ -554,6 +554,14 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
     const int ch = qi == 0 ? 0 : C + qi - 1;
     const int r = b * CN + (qi <= Nn ? ch : 0);
     const int hr = a.map[r];
+#ifdef VV_LAB
+    if (a.lab_hack) {                                // (lab: what the row loads' time depends on -- results wrong)
+      const int64_t rs = a.lab_hack == 1 ? D / 2 : D;
+#pragma unroll
+      for (int v = 0; v < DV; ++v)
+        x[k][v] = (qi <= Nn && !(a.lab_hack == 2 && v > 0)) ? *(const float4*)(a.H + (int64_t)hr * rs + lane * 4 + v * 256) : make_float4(1.f, 0.f, 0.f, 0.f);
+    } else
+#endif
 #pragma unroll
     for (int v = 0; v < DV; ++v)
       x[k][v] = qi <= Nn ? *(const float4*)(a.H + (int64_t)hr * D + lane * 4 + v * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -744,6 +752,8 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
 #undef SF_TS
 }
 
+#ifdef VV_LAB
+// (lab build only: tools/lab/score_fwd_pipelined.hip.txt -- not adopted)
 // ---- k_score_fwd, PERSISTENT AND PIPELINED (round 5).  k_score_fwd's own phase stamps (profiles/r05_score_fwd_stamps.txt): a workgroup lives
 // 11.6 us of which 8.9 us are the wait for its rows (index load -> 110 KB of rows) and 2.8 us its five compute phases; the 1024 workgroups
 // run as two rounds of 512 that start together, so the chip alternates between everybody loading and everybody computing.  Here one
@@ -985,6 +995,8 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd_p(ScoreArgs a) {
 }
 #undef SFP_BAR
 
+
+#endif  // VV_LAB
 // ---- the same pass for items that do not fit in registers (D = 1024, hundreds of negatives: the per-GPU shape of BASELINE
 // configs[4]): ONE sweep over the item's rows.  A wave takes negatives wave, wave + NW, ...; a row is in registers (DV float4
 // per lane) while its norm and its dot with Ah are reduced inside the wave, and because every wave has computed the TARGET's
@@ -1190,11 +1202,12 @@ void launch_score_fwd(const ScoreArgs& a_in, hipStream_t s) {
     return;
   }
   const size_t lds = sizeof(float) * ((size_t)(2 + 8) * a.D + 4 * (a.C + a.Nn) + 3 * 8);
+#ifdef VV_LAB
   // the persistent, pipelined form: batches of at least two items per CU, no dropout (KernelOpts::score_pipe, VV_SCORE_PIPE=0: one workgroup per item)
   static int n_cu = 0;
   if (!n_cu) { int dev = 0; hipDeviceProp_t pr; (void)hipGetDevice(&dev); n_cu = hipGetDeviceProperties(&pr, dev) == hipSuccess ? pr.multiProcessorCount : 256; }
   const int G = n_cu & ~7;
-  if (ko().score_pipe && !a.drop.mode && G >= 8 && a.B >= 2 * G) {
+  if (ko().lab_score_pipe && !a.drop.mode && G >= 8 && a.B >= 2 * G) {
 #define VV_SFP(RPW)                                                                                       \
     do {                                                                                                  \
       (void)hipFuncSetAttribute((const void*)k_score_fwd_p<8, RPW, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -1204,6 +1217,7 @@ void launch_score_fwd(const ScoreArgs& a_in, hipStream_t s) {
 #undef VV_SFP
     return;
   }
+#endif
 #define VV_SF(RPW)                                                                                        \
   do {                                                                                                    \
     if (a.drop.mode) {                                                                                    \

@@ -654,6 +654,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) ya[mi] = rd + (((wn * 4 + mi * 2 + (pp >> 1)) ^ hx) << 4);
 
+  // (lab, ABL bit 9: TIME STAMPS, as in k_fwd_gemm_ph -- fixed scalar registers s78..s101 that only these assembly blocks name;
+  // per phase: [load segment incl. its counted wait | barrier | MFMA segment (16 MFMAs = 256 clocks of matrix pipe) | barrier])
+  constexpr bool WTSON = (ABL & 512) != 0;
+#define WTS_CLOB "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s100", "s101", "scc"
+#define WTS(pair) if (WTSON) { asm volatile("s_memtime " pair ::: WTS_CLOB); __builtin_amdgcn_sched_barrier(0); }
+  if (WTSON) asm volatile("s_memtime s[84:85]\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b32 s101, s84\n\ts_mov_b32 s83, 0\n\t"
+                          "s_mov_b32 s95, 0\n\ts_mov_b32 s96, 0\n\ts_mov_b32 s97, 0\n\ts_mov_b32 s98, 0\n\ts_mov_b32 s99, 0" ::: WTS_CLOB);
   for (int c0 = 0; c0 < nk_all; c0 += PH_WG_IDS / BK) {      // super-chunks of at most 128 K-tiles
     const int nk_c = nk_all - c0 < PH_WG_IDS / BK ? nk_all - c0 : PH_WG_IDS / BK;
     const int nk = (nk_c + 1) & ~1;                           // even number of K-tiles; a padded one multiplies zeros
@@ -703,6 +710,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();                // waves 4-7 run one segment behind
     if (wm == 1) __builtin_amdgcn_s_setprio(1);
+    if (WTSON) asm volatile("s_memrealtime s[78:79]\n\ts_memtime s[84:85]\n\ts_waitcnt lgkmcnt(0)\n\t"
+                            "s_mov_b32 s83, s84\n\ts_mov_b32 s88, s84\n\ts_mov_b32 s90, s84\n\ts_mov_b32 s92, s84\n\ts_mov_b32 s94, s84" ::: WTS_CLOB);
 
     i16x8 xf[4][2], yf[2][2];
     constexpr bool abl_st = ABL & 1, abl_mm = ABL & 2, abl_rd = ABL & 4;
@@ -719,14 +728,26 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
       dst[x][kk] = i16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                      \
     }
 #define PW_MFMA(nh, mh)                                                                                \
+    WTS("s[88:89]")            /* b: this wave's load segment is done (reads issued, stream issued, wait passed) */ \
     __builtin_amdgcn_s_barrier();                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
+    WTS("s[90:91]")                                                                                    \
     if (!abl_mm) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)  \
       _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                 \
         acc[nh][ni][mh][mi] = T::mfma(xf[ni][kk], yf[mi][kk], acc[nh][ni][mh][mi]);                    \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
+    if (WTSON) {                                                                                       \
+      asm volatile("s_waitcnt lgkmcnt(0)\n\t"                                                          \
+                   "s_sub_u32 s100, s92, s94\n\ts_add_u32 s98, s98, s100\n\t"   /* mfma += d - previous c */ \
+                   "s_sub_u32 s100, s84, s92\n\ts_add_u32 s99, s99, s100\n\t"   /* bar2 += e - d */          \
+                   "s_sub_u32 s100, s88, s84\n\ts_add_u32 s95, s95, s100\n\t"   /* load (incl. its wait) += b - e */ \
+                   "s_sub_u32 s100, s90, s88\n\ts_add_u32 s97, s97, s100\n\t"   /* bar1 += c - b */          \
+                   "s_mov_b32 s94, s90\n\ts_memtime s[92:93]" ::: WTS_CLOB);                                  \
+      __builtin_amdgcn_sched_barrier(0);                                                               \
+    }                                                                                                  \
     __builtin_amdgcn_s_barrier();                                                                      \
-    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    WTS("s[84:85]")
     // one K-tile of parity par (slots 4*par ..), the stream working on K-tiles t+1 and t+2
 #define PW_TILE(par, t)                                                                                \
     PW_LOAD(xf, xa, 4, 4 * (par) + 0) PW_LOAD(yf, ya, 2, 4 * (par) + 1)                                \
@@ -748,6 +769,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();                // waves 0-3 catch the extra barrier of waves 4-7
     if (wm == 1) __builtin_amdgcn_s_setprio(0);
+    if (WTSON) asm volatile("s_memtime s[80:81]\n\ts_waitcnt lgkmcnt(0)" ::: WTS_CLOB);      // s80: end of the K loop
 #undef PW_LOAD
 #undef PW_MFMA
 #undef PW_TILE
@@ -757,7 +779,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
     // ---- the update on the tile (k_reduce_sgd's parameter workgroups, element for element: the same products, the same rule, the same
     // roundings -- parameters, history and half copy bit for bit those of the two-launch form, tests/test_gpu_fused_update.py)
     const WgradUpd& u = a.upd;
-    __shared__ float red8[8];
+    __syncthreads();                                      // (every wave is out of the K loop: the ring is free)
+    float* red8 = (float*)smem;                           // the kernel's dynamic LDS is all 160 KiB of the CU: no static word beside it
     float sw = u.scales->sw_next;
     if (u.recompute_scale) {                              // the scale of the new half copy from the previous update's per-block maxima
       float mm = 0.f;
@@ -786,43 +809,49 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
       return w - up;
     };
     float wmax = 0.f;
-    // groups of four quads (one row m, one 128-column half: ni = 0..3), W and history of the NEXT group requested before this one is stored
-    f32x4 wv[2][4], hv[2][4];
-    auto gaddr = [&](int grp, int ni, int& m, int& n) {
-      const int mh = grp >> 2, mi = (grp >> 1) & 1, nh = grp & 1;
-      m = m0 + mh * 128 + wn * 32 + mi * 16 + li;
-      n = n0 + nh * 128 + wm * 64 + ni * 16 + g * 4;
-    };
-    auto gload = [&](int grp, int buf) {
+    // The tile leaves the accumulators through LDS, 128 rows at a time (a 133 KB image, rows 1040 bytes apart: the sixteen rows a
+    // ds_write_b128 touches fall on disjoint banks), and is applied to W in ROW order: a wave's instruction covers 1 KiB of one row of W --
+    // whole lines, sixteen independent 16-byte loads of W and of the history in flight per lane.  (First build: the rule applied straight
+    // from the accumulators' layout -- 64-byte pieces of sixteen rows per instruction, eight dependent load/store groups per lane: the
+    // 300 MB of the update took 86 us inside the GEMM against 63 us for k_reduce_sgd's 370 MB; profiles/r05_shipped_update.txt.)
+    constexpr int TSTR = 260;                             // floats between two rows of the LDS image
+    float* tile = (float*)smem + 64;                      // (behind red8)
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        int m, n; gaddr(grp, ni, m, n);
+    for (int mh = 0; mh < 2; ++mh) {
+      __syncthreads();                                    // the image (and red8's readers) are done with
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+            *(f32x4*)(tile + (wn * 32 + mi * 16 + li) * TSTR + nh * 128 + wm * 64 + ni * 16 + g * 4) = acc[nh][ni][mh][mi];
+      __syncthreads();
+      f32x4 wv[16], hv[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int e = tid + GEMM_THREADS * j, r = e >> 6, c = (e & 63) * 4;
+        const int m = m0 + mh * 128 + r, n = n0 + c;
         const bool in = m < u.D && n < u.F;
         const int64_t o = (int64_t)m * u.F + n;
-        wv[buf][ni] = in ? __builtin_nontemporal_load((const f32x4*)(u.W + o)) : f32x4{0.f, 0.f, 0.f, 0.f};
-        hv[buf][ni] = in ? __builtin_nontemporal_load((const f32x4*)(u.hW + o)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        wv[j] = in ? __builtin_nontemporal_load((const f32x4*)(u.W + o)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        hv[j] = in ? __builtin_nontemporal_load((const f32x4*)(u.hW + o)) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
-    };
-    gload(0, 0);
 #pragma unroll
-    for (int grp = 0; grp < 8; ++grp) {
-      const int buf = grp & 1;
-      if (grp + 1 < 8) gload(grp + 1, buf ^ 1);
-      const int mh = grp >> 2, mi = (grp >> 1) & 1, nh = grp & 1;
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        int m, n; gaddr(grp, ni, m, n);
+      for (int j = 0; j < 16; ++j) {
+        const int e = tid + GEMM_THREADS * j, r = e >> 6, c = (e & 63) * 4;
+        const int m = m0 + mh * 128 + r, n = n0 + c;
         if (m >= u.D || n >= u.F) continue;
         const int64_t o = (int64_t)m * u.F + n;
-        const f32x4 v = acc[nh][ni][mh][mi];
-        f32x4 wq = wv[buf][ni], hq = hv[buf][ni];
+        const f32x4 v = *(const f32x4*)(tile + r * TSTR + c);
+        f32x4 wq = wv[j], hq = hv[j];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float gr = __fmul_rn(v[j], inv);          // (a rounded product, as the slab path stores it: no contraction into the rule)
-          float hj = hq[j];
-          wq[j] = rule(wq[j], gr, hj);
-          hq[j] = hj;
-          wmax = fmaxf(wmax, fabsf(wq[j]));
+        for (int q = 0; q < 4; ++q) {
+          const float gr = __fmul_rn(v[q], inv);          // (a rounded product, as the slab path stores it: no contraction into the rule)
+          float hj = hq[q];
+          wq[q] = rule(wq[q], gr, hj);
+          hq[q] = hj;
+          wmax = fmaxf(wmax, fabsf(wq[q]));
         }
         __builtin_nontemporal_store(wq, (f32x4*)(u.W + o));
         __builtin_nontemporal_store(hq, (f32x4*)(u.hW + o));
@@ -831,6 +860,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
         *(uint2*)(u.Wh + (int64_t)m * a.Fp + n) = make_uint2(lo, hi);
       }
     }
+    __syncthreads();
 #pragma unroll
     for (int o2 = 32; o2 > 0; o2 >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o2, 64));
     if (lane == 0) red8[wave] = wmax;
@@ -861,6 +891,22 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
           if (!(ABL & 64) || v[0] == 12345.f) *(float4*)(slab + (int64_t)m * a.Fp + n) = make_float4(v[0], v[1], v[2], v[3]);   // (lab, ABL 64: no stores)
         }
     }
+  if (WTSON) {
+    uint32_t o_[10];
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime s[84:85]\n\ts_memrealtime s[86:87]\n\ts_waitcnt lgkmcnt(0)\n\t"
+                 "s_mov_b32 %0, s95\n\ts_mov_b32 %1, s96\n\ts_mov_b32 %2, s97\n\ts_mov_b32 %3, s98\n\ts_mov_b32 %4, s99\n\t"
+                 "s_sub_u32 %5, s83, s101\n\ts_sub_u32 %6, s80, s101\n\ts_sub_u32 %7, s84, s101\n\ts_sub_u32 %8, s86, s78\n\ts_sub_u32 %9, s84, s83"
+                 : "=s"(o_[0]), "=s"(o_[1]), "=s"(o_[2]), "=s"(o_[3]), "=s"(o_[4]), "=s"(o_[5]), "=s"(o_[6]), "=s"(o_[7]), "=s"(o_[8]), "=s"(o_[9])
+                 :: WTS_CLOB, "memory");
+    if (lane == 0) {
+      uint32_t* o = (uint32_t*)(a.slabs + (int64_t)a.S * a.Dp * a.Fp) + ((size_t)blockIdx.x * 8 + wave) * 12;      // (lab: behind the last slab -- the harness allocates the room)
+#pragma unroll
+      for (int j = 0; j < 10; ++j) o[j] = o_[j];
+      o[10] = (uint32_t)nk_all; o[11] = 0;
+    }
+  }
+#undef WTS
+#undef WTS_CLOB
 }
 
 #ifdef VV_LAB

@@ -193,6 +193,7 @@ struct ScoreArgs {
   int32_t bound_seq = 0;
   DropSpec drop;                     // de-duplicated execution with dropout (k_score_fwd): H holds the SHARED pre-dropout rows, every
                                      // instance applies its own mask as it reads its row
+  int lab_hack = 0;                  // (lab builds, VV_LAB_SCORE_HACK: timing studies of k_score_fwd's row loads -- WRONG results) 1: rows 1 KiB apart (half the footprint, the same requests), 2: only the first half of every row is loaded (half the bytes and requests)
   uint32_t* lab_ts = nullptr;        // (lab builds, VV_LAB_SCORE_TS=1: 16 words per item -- shader-clock stamps of k_score_fwd's phases, 100 MHz
                                      //  real time of its start and end, the compute unit it ran on; the product never sets or reads it)
 };
@@ -361,7 +362,6 @@ struct KernelOpts {
   int fwd_lead = 1;        // "fwd_lead" / VV_FWD_LEAD: the forward GEMM's sibling lead (kernels_gemm_ph.hip)
   int wgrad_tr = 1;        // "wgrad_tr" / VV_WGRAD_TR: transposed LDS reads in the weight-gradient GEMM (0: the round-1 kernel)
   int score_stream = 0;    // "score_stream" / VV_SCORE_STREAM: the one-sweep score kernel for every shape
-  int score_pipe = 1;      // "score_pipe" / VV_SCORE_PIPE: the persistent, pipelined form of the register-resident score kernel (k_score_fwd_p; 0: one workgroup per item)
   int gemm_variant = 5;    // (lab) VV_GEMM_VARIANT: 5 = the phase-staggered kernels; 0 = the round-1 kernels; 6 / 7 / 8 mixtures
   int ablate = 0;          // (lab) VV_ABLATE: ablated instantiations of the dense-size GEMMs (results wrong)
   int lab_fwd_abl = 0;     // (lab) VV_LAB_FWD_ABL: ablations of the 192-row forward kernel at the de-duplicated size (results wrong)
@@ -370,6 +370,7 @@ struct KernelOpts {
   int ph_mq = 0;           // (lab) VV_PH_MQ: force the forward tile (2, 3, 4 = 128 / 192 / 256 rows, 31 = 176 rows)
   int score_reg = 1;       // (lab) VV_SCORE_REG=0: the LDS-resident score kernel
   int score_waves = 8;     // (lab) VV_SCORE_WAVES=4
+  int lab_score_pipe = 0;  // (lab) VV_LAB_SCORE_PIPE=1: the persistent, pipelined score kernel (tools/lab/score_fwd_pipelined.hip.txt)
   int score_rr = 0;        // (lab) VV_SCORE_RR=1: the item-major kernels deal their items round-robin over the XCDs again (kernels_elem.hip: item_of_block)
 };
 extern thread_local const KernelOpts* g_ko;
