@@ -112,7 +112,7 @@ int main(int argc, char** argv) {
                            {"dr12_spread_onlyA", 43}, {"dr12_spread_full", 44}, {"dr12_spread_noRD", 45}, {"dr12_spread_run1k_onlyA", 46},
                            {"dr12_even_onlyA", 47}, {"dr12_even_onlyAB", 48}, {"dr12_split_onlyA", 49}, {"dr12_split_onlyAB", 50},
                            {"ph_ts_lead", 60}, {"ph_ts_plain", 61}, {"ph_ts_lead_hotA", 62}, {"ph_ts_lead_nostream", 63}, {"ph_ts_lead_nomm", 64},
-                           {"ph_ts_lead_nostore", 65}, {"ph_plain", 66}};
+                           {"ph_ts_lead_nostore", 65}, {"ph_plain", 66}, {"ph_sf_plain", 67}, {"ph_sf_lead", 68}, {"ph_lead2", 69}};
   auto run = [&](int kind, int set, float* Hout) {
     FwdArgs a = base; a.rows = rows + (size_t)set * Rp; a.H = Hout;
     if (kind == 0) { a.Wh = Wh; launch_fwd_gemm_ph(0, a, st); return; }
@@ -126,6 +126,9 @@ int main(int argc, char** argv) {
         case 64: launch_ph_ts<512 + 2, 1>(a, st); break;
         case 65: launch_ph_ts<512 + 64, 1>(a, st); break;
         case 66: launch_ph_ts<0, 0>(a, st); break;
+        case 67: launch_ph_ts<1024, 0>(a, st); break;       // r05: the phase's LDS-DMA in front of its fragment reads
+        case 68: launch_ph_ts<1024, 1>(a, st); break;
+        case 69: launch_ph_ts<0, 1>(a, st); break;
       }
       return;
     }
@@ -185,7 +188,7 @@ int main(int argc, char** argv) {
   };
   // correctness: the real variants against the LDS kernel, bit for bit, on every row set
   std::vector<float> h0((size_t)U * D), h1((size_t)U * D);
-  for (int kind : {1, 17, 20, 22, 23, 24}) {
+  for (int kind : {1, 17, 67, 68, 69}) {
     long bad = 0; double maxd = 0;
     for (int set = 0; set < NSETS; ++set) {
       CHK(hipMemsetAsync(H0, 0xff, (int64_t)Rp * D * 4, st)); CHK(hipMemsetAsync(H1, 0xff, (int64_t)Rp * D * 4, st));
@@ -195,7 +198,8 @@ int main(int argc, char** argv) {
       for (size_t i = 0; i < h0.size(); ++i) if (memcmp(&h0[i], &h1[i], 4)) { ++bad; maxd = std::max(maxd, (double)fabsf(h0[i] - h1[i])); }
     }
     double s = 0; for (size_t i = 0; i < h0.size(); ++i) s += h0[i];
-    printf("check %-10s: %ld of %zu x %d values differ (max |d| %.3g), mean out %.4f\n", vars[kind].name, bad, h0.size(), NSETS, maxd, s / h0.size());
+    const char* nm = "?"; for (auto& v : vars) if (v.kind == kind) nm = v.name;
+    printf("check %-10s: %ld of %zu x %d values differ (max |d| %.3g), mean out %.4f\n", nm, bad, h0.size(), NSETS, maxd, s / h0.size());
   }
   hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
   int set = 0;

@@ -310,9 +310,17 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
     constexpr int PAR = decltype(par_c)::value, J = decltype(j_c)::value;
     constexpr bool CHK = decltype(chk)::value;
     (void)J;
+    if constexpr ((ABL & 1024) != 0) {               // (lab, ABL bit 10: the phase's LDS-DMA instructions in front of its fragment reads)
+#define PH_WAITSF(p) if ((!CHK || 4 * t + (p) + 6 < H) && !abl_st) { PH_WAITQ(); } else { PH_WAIT(0); }
+      PH_STREAM(PAR, t, 0, false) PH_LOAD_A(4 * PAR + 0) PH_LOAD_B(b0, 4 * PAR + 1) PH_WAITSF(0) PH_MFMA(0, 0, b0)
+      PH_STREAM(PAR, t, 1, false) PH_LOAD_B(b1, 4 * PAR + 2) PH_WAITSF(1) PH_MFMA(0, 1, b1)
+#undef PH_WAITSF
+      PH_STREAM(PAR, t, 2, false) PH_LOAD_A(4 * PAR + 3) PH_MFMA(1, 1, b1)
+    } else {
     PH_LOAD_A(4 * PAR + 0) PH_LOAD_B(b0, 4 * PAR + 1) PH_STREAM(PAR, t, 0, true) PH_MFMA(0, 0, b0)
     PH_LOAD_B(b1, 4 * PAR + 2) PH_STREAM(PAR, t, 1, true) PH_MFMA(0, 1, b1)
     PH_LOAD_A(4 * PAR + 3) PH_STREAM(PAR, t, 2, false) PH_MFMA(1, 1, b1)
+    }
     if (GATE && PAR == 0 && t + 2 == gate_at) {                          // B_lo(t + 2) opens a chunk
       gate_wait(g_next);
       if (++g_next >= a.gate_n) gated = false;
@@ -714,7 +722,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
                             "s_mov_b32 s83, s84\n\ts_mov_b32 s88, s84\n\ts_mov_b32 s90, s84\n\ts_mov_b32 s92, s84\n\ts_mov_b32 s94, s84" ::: WTS_CLOB);
 
     i16x8 xf[4][2], yf[2][2];
-    constexpr bool abl_st = ABL & 1, abl_mm = ABL & 2, abl_rd = ABL & 4;
+    constexpr bool abl_st = ABL & 1, abl_mm = ABL & 2, abl_rd = ABL & 4, SF = (ABL & 1024) != 0;
     if (abl_rd) {
 #pragma unroll
       for (int x = 0; x < 4; ++x) { xf[x][0] = xf[x][1] = i16x8{1, 2, 3, 4, 5, 6, 7, (short)x}; }
@@ -749,19 +757,25 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
     __builtin_amdgcn_sched_barrier(0);                                                                 \
     WTS("s[84:85]")
     // one K-tile of parity par (slots 4*par ..), the stream working on K-tiles t+1 and t+2
+    /* (lab, ABL bit 10: the phase's two LDS-DMA instructions IN FRONT of its fragment reads instead of behind them) */ \
 #define PW_TILE(par, t)                                                                                \
+    if (SF && (t) + 1 < nk && !abl_st) issue_x(idn0, idn1, true, 4 * (1 - (par)) + 3);                 \
     PW_LOAD(xf, xa, 4, 4 * (par) + 0) PW_LOAD(yf, ya, 2, 4 * (par) + 1)                                \
-    if ((t) + 1 < nk && !abl_st) issue_x(idn0, idn1, true, 4 * (1 - (par)) + 3);                       \
+    if (!SF && (t) + 1 < nk && !abl_st) issue_x(idn0, idn1, true, 4 * (1 - (par)) + 3);                \
     PW_MFMA(0, 0)                                                                                      \
+    if (SF && (t) + 1 < nk && !abl_st) issue_y((t) + 1, false, 4 * (1 - (par)) + 1);                   \
     PW_LOAD(yf, ya, 2, 4 * (par) + 2)                                                                  \
-    if ((t) + 1 < nk && !abl_st) issue_y((t) + 1, false, 4 * (1 - (par)) + 1);                         \
+    if (!SF && (t) + 1 < nk && !abl_st) issue_y((t) + 1, false, 4 * (1 - (par)) + 1);                  \
     if ((t) + 2 < nk) { idn0 = ids[((t) + 2) * BK + srow0]; idn1 = ids[((t) + 2) * BK + srow1]; }      \
     PW_MFMA(0, 1)                                                                                      \
+    if (SF && (t) + 2 < nk && !abl_st) issue_x(idn0, idn1, false, 4 * (par) + 0);                      \
     PW_LOAD(xf, xa, 4, 4 * (par) + 3)                                                                  \
-    if ((t) + 2 < nk && !abl_st) issue_x(idn0, idn1, false, 4 * (par) + 0);                            \
+    if (!SF && (t) + 2 < nk && !abl_st) issue_x(idn0, idn1, false, 4 * (par) + 0);                     \
     PW_MFMA(1, 1)                                                                                      \
+    if (SF && (t) + 2 < nk && !abl_st) issue_y((t) + 2, true, 4 * (par) + 2);                          \
     PW_LOAD(yf, ya, 2, 4 * (par) + 1)                                                                  \
-    if ((t) + 2 < nk && !abl_st) { issue_y((t) + 2, true, 4 * (par) + 2); PH_WAIT(4); } else PH_WAIT(0); \
+    if (!SF && (t) + 2 < nk && !abl_st) issue_y((t) + 2, true, 4 * (par) + 2);                         \
+    if ((t) + 2 < nk && !abl_st) { PH_WAIT(4); } else PH_WAIT(0);                                      \
     PW_MFMA(1, 0)
     for (int t = 0; t < nk; t += 2) {
       PW_TILE(0, t)
