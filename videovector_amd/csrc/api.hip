@@ -183,6 +183,7 @@ static int create_init(vv_ctx* c) {
   c->pub_count = c->w_gate + W_CHUNKS_MAX * W_GATE_STRIDE;      // the arrival counter of the publishing kernels: a line of its own
   c->pub_count0 = c->pub_count + W_GATE_STRIDE;                 // ... and the one of the FIRST chunk's kernel, which runs on the compute stream beside them
   if (const char* v = opt_env("VV_COMM_FIRST_INLINE")) c->overlap_first_inline = atoi(v) != 0;
+  if (const char* v = opt_env("VV_WGRAD_UPDATE")) c->wgrad_update = atoi(v) != 0;
   { const char* nc = opt_env("VV_COMM_CHUNKS"); if (nc) c->n_chunks = std::max(1, std::min(W_CHUNKS_MAX, atoi(nc))); }
   HIPCHK(hipEventCreateWithFlags(&c->ev_chunk0, hipEventDisableTiming));
   HIPCHK(hipHostMalloc((void**)&c->gate_err, sizeof(int32_t), hipHostMallocMapped));
@@ -292,6 +293,7 @@ int vv_set_option(vv_ctx* c, const char* name, double value) {
   if (n == "comm_gate") { c->comm_gate = iv != 0; return VV_OK; }
   if (n == "comm_inline") { c->comm_inline = iv != 0; return VV_OK; }
   if (n == "comm_first_inline") { c->overlap_first_inline = iv != 0; return VV_OK; }
+  if (n == "wgrad_update") { c->wgrad_update = iv != 0; return VV_OK; }
   if (n == "comm_chunks") { c->n_chunks = std::max(1, std::min(W_CHUNKS_MAX, iv)); return VV_OK; }
   if (n == "comm_test_delay_us") { c->comm_test_delay_us = iv; return VV_OK; }
 #ifdef VV_LAB
@@ -317,6 +319,7 @@ int vv_get_option(vv_ctx* c, const char* name, double* value) {
   else if (n == "comm_gate") *value = c->comm_gate;
   else if (n == "comm_inline") *value = c->comm_inline;
   else if (n == "comm_first_inline") *value = c->overlap_first_inline;
+  else if (n == "wgrad_update") *value = c->wgrad_update;
   else if (n == "comm_chunks") *value = c->n_chunks;
   else if (n == "comm_test_delay_us") *value = c->comm_test_delay_us;
   else return fail(VV_ERR_ARG, "vv_get_option: unknown option '%s'", name);
@@ -487,6 +490,7 @@ int vv_params_set(vv_ctx* c, int32_t D, const float* W, const float* b, const fl
     HIPCHK(hipMalloc(&c->grads_own, (nW + D) * 4));
     HIPCHK(hipMemset(c->grads_own, 0, (nW + D) * 4));
     c->grads = c->grads_own;
+    if (getenv("VV_DEBUG_PTRS")) fprintf(stderr, "[vv ptrs] W %p hW %p Wh %p grads %p (D %d F %d)\n", (void*)c->W, (void*)c->hW, (void*)c->Wh, (void*)c->grads_own, D, c->F);
     free_batch(c);
   }
   HIPCHK(hipMemcpy(c->W, W, nW * 4, hipMemcpyHostToDevice));
@@ -1106,7 +1110,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   // vv_update_hint + one split of K: the tile in the weight-gradient GEMM's accumulators IS the gradient -- the solver's rule is applied
   // there (WgradUpd) and the 4 D F bytes of dW are neither written nor read back (the shipped configuration: D = F = 4096, 134 MB of the
   // update's 370).  vv_apply_update then runs only the bias / loss workgroups.
-  const bool fuse_w = upd_hint && lazy && c->S == 1 && wgrad_can_fuse_update() && !c->fuse_keep_grads &&
+  const bool fuse_w = upd_hint && c->wgrad_update && lazy && c->S == 1 && wgrad_can_fuse_update() && !c->fuse_keep_grads &&
                       (c->Dp / BM) * (c->Fp / BN) <= WMAX_SLOTS;
   if (fuse_w) {
     const vv_step_cfg& uc = c->upd_cfg;
