@@ -200,6 +200,40 @@ def test_prefetch_general_path_and_restarts(oracle):
     a.close()
 
 
+@pytest.mark.parametrize("width", ["avx2", "avx512"])
+@pytest.mark.parametrize("case", ["long_videos_always_swap", "crowded_buffer", "odd_slot_count", "buffer_equals_slots", "benchmark_shape"])
+def test_both_vector_widths_of_the_walk_and_the_slot_draw_are_the_oracle_stream(oracle, monkeypatch, width, case):
+    """sampler.cc has two forms of the swap-in walk and of the negative-slot draw: 256-bit (any x86-64-v3 host) and 512-bit
+    (chosen at creation when the host has AVX-512 F/BW/DQ/VL/VBMI2; VV_SAMPLER_AVX512=0 forces the first).  Both must be the
+    oracle's stream, bit for bit, serial and pipelined -- on the shapes where they differ most: videos of more than 64 and more
+    than 128 shots with a 99 % swap-in (nearly every test taken: up to 64 taken tests per chunk, position words up to word 127 of
+    the chunk), a buffer that holds most of a small dataset, so that swap-ins keep evicting later shots of the video being walked (restarts), slot counts that are not
+    a multiple of the vector length, a buffer of exactly the slot count (the last divisor of the draw is 1)."""
+    monkeypatch.setenv("VV_SAMPLER_AVX512", "1" if width == "avx512" else "0")
+    cfg = {
+        "long_videos_always_swap": (dict(seed=3, n_videos=60, lo=50, span=120), dict(batch_size=24, context_size=5, num_negative_samples=20, max_buffer_size=3000, negative_swap_percentage=99)),
+        "crowded_buffer": (dict(seed=4, n_videos=40, lo=6, span=90), dict(batch_size=16, context_size=3, num_negative_samples=7, max_buffer_size=1500, negative_swap_percentage=90)),
+        "odd_slot_count": (dict(seed=5, n_videos=200, lo=5, span=70), dict(batch_size=32, context_size=5, num_negative_samples=37, max_buffer_size=900, negative_swap_percentage=35)),
+        "buffer_equals_slots": (dict(seed=6, n_videos=80, lo=8, span=40), dict(batch_size=8, context_size=5, num_negative_samples=33, max_buffer_size=33, negative_swap_percentage=50)),
+        "benchmark_shape": (dict(seed=1701, n_videos=512), dict(batch_size=128, context_size=5, num_negative_samples=50, max_buffer_size=5000, negative_swap_percentage=50)),
+    }[case]
+    ds = SyntheticVideos(**cfg[0])
+    a = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, **cfg[1])
+    if width == "avx512" and a.stat(7) != 1:
+        a.close()
+        pytest.skip("this host has no AVX-512 VBMI2")
+    assert a.stat(7) == (1 if width == "avx512" else 0)
+    o = oracle.Sampler(ds.video_id, ds.n_shots, ds.row_base, **cfg[1])
+    for _ in range(12):
+        assert np.array_equal(a.next(), o.next()[0])
+    a.prefetch_start(depth=3, threads=4)
+    for _ in range(24):
+        assert np.array_equal(a.next(), o.next()[0])
+    if case == "crowded_buffer":
+        assert a.stat(0) > 0, "the restart path was not exercised"
+    a.close()
+
+
 def _ring_consumer(name, consumer, world, n_batches, q):
     import videovector_amd as vv2
     r = vv2.BatchRing.attach(name, timeout_s=30.0)

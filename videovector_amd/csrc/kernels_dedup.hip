@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k_dd_claim(DedupArgs a) {
 
 // exclusive block scan of one int per thread (DD_BLOCK threads); returns the prefix, *total = block sum
 __device__ __forceinline__ int block_excl_scan(int v, int* total, int* sm /* >= 17 ints */) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int inc = v;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }

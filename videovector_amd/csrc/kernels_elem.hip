@@ -115,7 +115,7 @@ __global__ __launch_bounds__(NT) void k_score_loss(ScoreArgs a) {
   float* k1 = (float*)(ooff + CN);   // [CN] per-row constants of the backward pass (see phase 4)
   float* k2 = k1 + CN;
   float* k3 = k2 + CN;
-  const int b = item_of_block(a.items_rr), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = item_of_block(a.items_rr), tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const float eps = 1e-10f;
   __shared__ float ggs[16];
   float sgm;
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(64 * NW) void k_score_loss_reg(ScoreArgs a) {
   float* cq = tq + CN;         // [CN]
   float* red = cq + CN;        // [3 NW]
   int* ooff = (int*)(red + 3 * NW);   // [CN] row of dYh receiving channel ch's gradient
-  const int b = item_of_block(a.items_rr), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = item_of_block(a.items_rr), tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const float eps = 1e-10f;
   __shared__ float ggs[16];
   float sgm;
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
   float* cq = tq + CN;         // [CN]
   float* red = cq + CN;        // [3 NW]
   int* ooff = (int*)(red + 3 * NW);   // [CN] grouped position of channel ch's instance
-  const int b = item_of_block(a.items_rr), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = item_of_block(a.items_rr), tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const float eps = 1e-10f;
 #ifdef VV_LAB
   // (lab: phase stamps of wave 0, written by thread 0 at the kernel's end -- ScoreArgs::lab_ts)
@@ -547,6 +547,26 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
 #endif
   SF_TS(0)
 
+  // (round 5: the context rows are requested FIRST -- vmcnt completes in order, and the context mean, its block sum and the normalised vector
+  // are what the kernel computes first: behind the 14 target / negative rows they waited for all of them, profiles/r05_score_fwd_stamps.txt)
+  float cx[CXM][CV];
+#pragma unroll
+  for (int j = 0; j < CXM; ++j) {
+    const int r = b * CN + (j + 1 < C ? j + 1 : 0);
+    const int hr = a.map[r];
+#pragma unroll
+    for (int v = 0; v < CV; ++v) cx[j][v] = j + 1 < C ? a.H[(int64_t)hr * D + tid + v * THREADS] : 0.f;
+    if (DROP && j + 1 < C) {
+      const int64_t rr = (int64_t)(j + 1) * a.B + b;
+      const uint32_t rc = drop_row_ctr(rr, D, a.drop.s32);
+#pragma unroll
+      for (int v = 0; v < CV; ++v) {
+        const int col = tid + v * THREADS;
+        const uint32_t kp = drop_keep4(a.drop, rr, rc, col & ~3);
+        cx[j][v] = ((kp >> (col & 3)) & 1u) ? cx[j][v] * a.drop.scale : 0.f;
+      }
+    }
+  }
   float4 x[RPW][DV];
 #pragma unroll
   for (int k = 0; k < RPW; ++k) {
@@ -573,24 +593,6 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
         const uint32_t kp = drop_keep4(a.drop, rr, rc, lane * 4 + v * 256);
         x[k][v].x = (kp & 1u) ? x[k][v].x * a.drop.scale : 0.f; x[k][v].y = (kp & 2u) ? x[k][v].y * a.drop.scale : 0.f;
         x[k][v].z = (kp & 4u) ? x[k][v].z * a.drop.scale : 0.f; x[k][v].w = (kp & 8u) ? x[k][v].w * a.drop.scale : 0.f;
-      }
-    }
-  }
-  float cx[CXM][CV];
-#pragma unroll
-  for (int j = 0; j < CXM; ++j) {
-    const int r = b * CN + (j + 1 < C ? j + 1 : 0);
-    const int hr = a.map[r];
-#pragma unroll
-    for (int v = 0; v < CV; ++v) cx[j][v] = j + 1 < C ? a.H[(int64_t)hr * D + tid + v * THREADS] : 0.f;
-    if (DROP && j + 1 < C) {
-      const int64_t rr = (int64_t)(j + 1) * a.B + b;
-      const uint32_t rc = drop_row_ctr(rr, D, a.drop.s32);
-#pragma unroll
-      for (int v = 0; v < CV; ++v) {
-        const int col = tid + v * THREADS;
-        const uint32_t kp = drop_keep4(a.drop, rr, rc, col & ~3);
-        cx[j][v] = ((kp >> (col & 3)) & 1u) ? cx[j][v] * a.drop.scale : 0.f;
       }
     }
   }
@@ -805,7 +807,7 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd_p(ScoreArgs a) {
   float* cq = tq + CN;         // [CN]
   float* red = cq + CN;        // [3 NW]
   int* ooff = (int*)(red + 3 * NW);   // [CN] grouped position of channel ch's instance
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int G = (int)gridDim.x;
   const float eps = 1e-10f;
   // virtual block vb = blockIdx + j G (G a multiple of 8: the XCD of vb is this workgroup's) -> item, as item_of_block over B blocks
@@ -1017,7 +1019,7 @@ __global__ __launch_bounds__(64 * NW, DV == 4 ? 4 : 1) void k_score_stream(Score
   float* Ah = A + D;           // [D]
   float* acc0 = Ah + D;        // [NW][D] per-wave partial dAh
   float* red = acc0 + NW * D;  // [4 NW]: three groups for the loss sums, one for the waves' gradient bounds
-  const int b = item_of_block(a.items_rr), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = item_of_block(a.items_rr), tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const float eps = 1e-10f;
   const int32_t* map = a.map + (int64_t)b * CN;
   const int32_t* ord = a.ord + (int64_t)b * CN;
@@ -1267,7 +1269,7 @@ __global__ __launch_bounds__(256) void k_seg_bwd(SegBwdArgs a) {
   }
   const int U = a.info[0];
   const int Uk = min((U + BK - 1) / BK * BK, a.Rp);   // the wgrad K loop reads whole BK-row steps
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c0 = lane * 8, D = a.D;                   // D = 512 CH; chunk c covers columns 512 c + c0 .. + 7
   float col[CH][8];
 #pragma unroll
@@ -2118,7 +2120,7 @@ void launch_dyh_to_float(int prec, const uint16_t* dYh, int R, int D, int Dp, fl
 
 // NORMALIZATION forward on rows of x in place (normalization_layer.cu:10-45): y = x/(|x|+1e-10)
 __global__ __launch_bounds__(256) void k_row_normalize(float* x, int n, int D) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + wave;
   if (r >= n) return;
   float* p = x + (int64_t)r * D;

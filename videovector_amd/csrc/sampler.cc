@@ -51,7 +51,8 @@ namespace {
 // word >> 1; the first 310 outputs are discarded by srandom.  (glibc 2.35 stdlib/random_r.c)
 class LibcRand {
  public:
-  void init(int block, int swap_pct, uint32_t seed = 1) {
+  void init(int block, int swap_pct, uint32_t seed = 1, bool wide = false) {
+    wide_ = wide;
     uint32_t st[31];
     if (seed == 0) seed = 1;             // srandom_r: seed 0 is seed 1 (the never-seeded stream)
     int64_t w = seed;
@@ -131,13 +132,34 @@ class LibcRand {
 
  private:
   static constexpr int kHist = 40;               // words kept in front of the first unconsumed value (>= 37)
+  // Eight words per step from x[k] = x[k-9] + x[k-31] + x[k-34] + x[k-37].  Read back from memory, the operands would be loads that
+  // straddle the stores of the last few steps (no store forwarding: each step would wait for them to drain), so the scalar form --
+  // whose loads forward -- ran faster than a 256-bit one (1.6 against ~2 ticks per word); with AVX-512VL the last forty words stay in
+  // five registers and the four operand windows are cut out of them by VALIGND.
   void generate(uint32_t* __restrict h, int from) {       // h = the values' start, kHist words of history in front of it
+    if (wide_) { generate_valign(h, from); return; }
     const int n = n_;
     int i = from;
     for (; i + 8 <= n; i += 8) {                 // every operand of a block lies in front of the block
       uint32_t t[8];
       for (int j = 0; j < 8; ++j) t[j] = h[i + j - 9] + h[i + j - 31] + h[i + j - 34] + h[i + j - 37];
       for (int j = 0; j < 8; ++j) h[i + j] = t[j];
+    }
+    for (; i < n; ++i) h[i] = h[i - 31] + h[i - 3];
+  }
+  __attribute__((target("avx512f,avx512vl"))) void generate_valign(uint32_t* __restrict h, int from) {
+    const int n = n_;
+    int i = from;
+    if (i + 8 <= n) {
+      __m256i v1 = _mm256_loadu_si256((const __m256i*)(h + i - 8)), v2 = _mm256_loadu_si256((const __m256i*)(h + i - 16));
+      __m256i v3 = _mm256_loadu_si256((const __m256i*)(h + i - 24)), v4 = _mm256_loadu_si256((const __m256i*)(h + i - 32));
+      __m256i v5 = _mm256_loadu_si256((const __m256i*)(h + i - 40));
+      for (; i + 8 <= n; i += 8) {
+        const __m256i far = _mm256_add_epi32(_mm256_add_epi32(_mm256_alignr_epi32(v3, v4, 1), _mm256_alignr_epi32(v4, v5, 6)), _mm256_alignr_epi32(v4, v5, 3));
+        const __m256i nv = _mm256_add_epi32(far, _mm256_alignr_epi32(v1, v2, 7));      // (the operand that depends on the last step joins last)
+        _mm256_storeu_si256((__m256i*)(h + i), nv);
+        v5 = v4; v4 = v3; v3 = v2; v2 = v1; v1 = nv;
+      }
     }
     for (; i < n; ++i) h[i] = h[i - 31] + h[i - 3];
   }
@@ -175,6 +197,7 @@ class LibcRand {
   const uint32_t* base_ = nullptr;
   int n_ = 0, pos_ = 0, avail_ = 0;
   uint32_t swap_ = 0;
+  bool wide_ = false;
   // helper mode
   std::vector<uint32_t> blk_[2];
   std::thread helper_;
@@ -402,10 +425,17 @@ struct vv_sampler {
   int next_general(int32_t* idx, int32_t* last_src, int32_t* label);
   void select_item(uint32_t* rec);
   template <bool LOG> void swap_item(uint32_t* rec, int32_t* brow, Event* ev_ring, uint64_t ev_mask, uint64_t* ev_head);
+  template <bool LOG> void swap_item_512(uint32_t* rec, int32_t* brow, Event* ev_ring, uint64_t ev_mask, uint64_t* ev_head);
+  template <bool LOG> void swap(uint32_t* rec, int32_t* brow, Event* ev_ring, uint64_t evm, uint64_t* ev_head) {
+    if (wide) swap_item_512<LOG>(rec, brow, ev_ring, evm, ev_head); else swap_item<LOG>(rec, brow, ev_ring, evm, ev_head);
+  }
+  bool wide = false;                          // AVX-512 (F, BW, DQ, VL, VBMI2) forms of the walk and of the stream generation; VV_SAMPLER_AVX512=0 disables
+  double inv_mb = 0.0;                        // 1.0 / max_buffer_size
   int cur_v = 0, cur_n = 0, cur_a_total = 0;  // the item between select_item and swap_item
   int64_t stat_restarts = 0;
   int sample_batch(int32_t* idx, int32_t* last_src, int32_t* label);
   void negs_item(const uint32_t* rec, int32_t* out, const int32_t* brow);
+  void negs(const uint32_t* rec, int32_t* out, const int32_t* brow) { negs_item(rec, out, brow); }   // (a 512-bit form -- the Nn remainders in double precision first -- measured SLOWER than this loop: 114 against 86 ns per 50 slots)
   void frames_item(const uint32_t* rec, int32_t* out, int32_t* label);
   std::vector<uint32_t> rec1;                 // the serial path's one item record
 
@@ -434,6 +464,9 @@ struct vv_sampler {
 // 2 or fewer than C shots adds nothing and consumes no draw) and hand the frames / negs stages the raw stream words they
 // own.  swap: the swap-in loop (:888-906 with AddToBuffer :24-37), branch-free: a shot that is not swapped in writes
 // to a dummy slot / dummy row instead of branching on a coin flip.
+#ifdef VV_WALK_PROF
+uint64_t g_wp[8];
+#endif
 void vv_sampler::select_item(uint32_t* rec) {
   const int C = p.context_size, Nn = p.num_negative_samples, V = (int)video_id.size();
   int v, n;
@@ -444,12 +477,15 @@ void vv_sampler::select_item(uint32_t* rec) {
   }
   const bool shuffled = (p.context_type == VV_CONTEXT_WINDOW || p.context_type == VV_CONTEXT_PAST) && Nn > 0 && n > C;
   const int a_total = CA + (shuffled ? n - C - 1 : 0);     // :432/:517 random_unique, :482/:566 random_shuffle
+#ifdef VV_WALK_PROF
+  { const uint64_t t_ = __rdtsc(); rng.ensure(a_total + Nn + 2 * n + 16); g_wp[4] += __rdtsc() - t_; }
+#else
   rng.ensure(a_total + Nn + 2 * n + 16);      // the swap-in reads whole 8-word groups
+#endif
   rec[0] = (uint32_t)v;
   const uint32_t* hv = rng.peek();
-  for (int i = 0; i < CA; ++i) rec[4 + i] = hv[i];
-  hv += a_total;
-  for (int i = 0; i < Nn; ++i) rec[4 + CA + i] = hv[i];
+  memcpy(rec + 4, hv, (size_t)CA * 4);
+  memcpy(rec + 4 + CA, hv + a_total, (size_t)Nn * 4);
   cur_v = v; cur_n = n; cur_a_total = a_total;
 }
 
@@ -482,6 +518,12 @@ static inline int select128(u128 x, int k) {        // position of the k-th (1-b
 // The k-th shot that is not in the buffer owns the k-th test; the taken ones are pdep(pext(F, TEST), notin).  Only the
 // taken shots are then visited.  A swap-in that evicts a LATER shot of the same video changes that shot's membership:
 // the walk restarts behind the evicting shot (rare; counted in stat_restarts).
+#ifdef VV_WALK_PROF
+#define WP(i, expr) { const uint64_t t_ = __rdtsc(); expr; g_wp[i] += __rdtsc() - t_; }
+#define WPT(i) { const uint64_t t_ = __rdtsc(); g_wp[i] += t_ - wp_t; wp_t = t_; }
+#else
+#define WPT(i)
+#endif
 template <bool LOG>
 __attribute__((noinline)) void vv_sampler::swap_item(uint32_t* rec, int32_t* brow, Event* ev_ring, uint64_t evm, uint64_t* ev_head) {
   const int Nn = p.num_negative_samples, v = cur_v, n = cur_n, a_total = cur_a_total;
@@ -489,6 +531,9 @@ __attribute__((noinline)) void vv_sampler::swap_item(uint32_t* rec, int32_t* bro
   int q = 0;
   uint32_t nev = 0;
   const uint64_t ev0 = LOG ? *ev_head : 0;
+#ifdef VV_WALK_PROF
+  uint64_t wp_t = __rdtsc();
+#endif
   if (Nn > 0 && p.negative_swap_percentage > 0) {
     uint8_t* inb = row_in_buf.data() - row_min;              // indexed by table row
     const int mb = p.max_buffer_size;
@@ -528,6 +573,7 @@ __attribute__((noinline)) void vv_sampler::swap_item(uint32_t* rec, int32_t* bro
       uint64_t TS = _pdep_u64(comp, notin);                  // taken shots, in shot order (same count as TK)
       int q_end = q + pm + 1 + (int)((F >> pm) & 1);
       bool restarted = false;
+      WPT(1)
       while (TS) {
         const int j = j0 + (int)_tzcnt_u64(TS); TS &= TS - 1;
         const uint64_t k_lo = (uint64_t)TK;
@@ -545,6 +591,137 @@ __attribute__((noinline)) void vv_sampler::swap_item(uint32_t* rec, int32_t* bro
         }
       }
       if (!restarted) { q = q_end; j0 += cnt; }
+      WPT(2)
+    }
+  }
+  rng.skip(a_total + Nn + q);
+  rec[1] = nev; rec[2] = (uint32_t)ev0; rec[3] = (uint32_t)(ev0 >> 32);
+  if (LOG) *ev_head = ev0 + nev;
+}
+
+// ---- the same swap-in with 512-bit vectors (Zen 4/5, Sapphire Rapids ...): sixteen predicate bits per compare-into-mask, the
+// membership bits of 64 shots from one load, and -- the larger part -- the taken tests' buffer positions computed for the whole
+// chunk at once instead of inside the loop that applies them: the stream words behind the taken tests are packed by VPCOMPRESSD
+// (mask = the taken tests' bits moved up by one), the taken shots' numbers by VPCOMPRESSB, and rand() % max_buffer_size is taken in
+// double precision: for 0 <= a < 2^31 the rounded product a * (1/d) is within a/d * 2^-52 < 1/d of a/d, so its integer part is the
+// quotient except when a is a multiple of d and the product fell just below it (remainder d instead of 0: one compare).  The loop that
+// is left reads (position, shot) pairs and moves rows -- the part that has to stay sequential (two tests may name the same slot).
+#define VV_T512 __attribute__((target("avx512f,avx512bw,avx512dq,avx512vl,avx512vbmi2,bmi,bmi2,lzcnt,popcnt")))
+VV_T512 static inline uint32_t swap_flags16(const uint32_t* w, __m512i vsw) {
+  const __m512i t = _mm512_srli_epi32(_mm512_loadu_si512((const void*)w), 1);
+  const __m512i magic = _mm512_set1_epi32(0x51EB851F);
+  const __m512i pe = _mm512_srli_epi64(_mm512_mul_epu32(t, magic), 37);                           // even lanes: t / 100
+  const __m512i po = _mm512_srli_epi64(_mm512_mul_epu32(_mm512_srli_epi64(t, 32), magic), 37);   // odd lanes
+  const __m512i q = _mm512_or_si512(pe, _mm512_slli_epi64(po, 32));
+  const __m512i r = _mm512_sub_epi32(t, _mm512_mullo_epi32(q, _mm512_set1_epi32(100)));
+  return (uint32_t)_mm512_cmplt_epu32_mask(r, vsw);
+}
+// (a >> 1) % d of sixteen stream words, d < 2^31 (see above)
+VV_T512 static inline __m512i mod16(__m512i words, __m512d vinv, __m256i vd) {
+  const __m512i a = _mm512_srli_epi32(words, 1);
+  const __m256i a0 = _mm512_castsi512_si256(a), a1 = _mm512_extracti64x4_epi64(a, 1);
+  const __m256i q0 = _mm512_cvttpd_epi32(_mm512_mul_pd(_mm512_cvtepi32_pd(a0), vinv));
+  const __m256i q1 = _mm512_cvttpd_epi32(_mm512_mul_pd(_mm512_cvtepi32_pd(a1), vinv));
+  __m256i r0 = _mm256_sub_epi32(a0, _mm256_mullo_epi32(q0, vd)), r1 = _mm256_sub_epi32(a1, _mm256_mullo_epi32(q1, vd));
+  r0 = _mm256_mask_sub_epi32(r0, _mm256_cmpeq_epi32_mask(r0, vd), r0, vd);
+  r1 = _mm256_mask_sub_epi32(r1, _mm256_cmpeq_epi32_mask(r1, vd), r1, vd);
+  return _mm512_inserti64x4(_mm512_castsi256_si512(r0), r1, 1);
+}
+
+template <bool LOG>
+VV_T512 __attribute__((noinline)) void vv_sampler::swap_item_512(uint32_t* rec, int32_t* brow, Event* ev_ring, uint64_t evm, uint64_t* ev_head) {
+  const int Nn = p.num_negative_samples, v = cur_v, n = cur_n, a_total = cur_a_total;
+  const uint32_t* hv = rng.peek() + a_total + Nn;
+  int q = 0;
+  uint32_t nev = 0;
+  const uint64_t ev0 = LOG ? *ev_head : 0;
+#ifdef VV_WALK_PROF
+  uint64_t wp_t = __rdtsc();
+#endif
+  if (Nn > 0 && p.negative_swap_percentage > 0) {
+    uint8_t* inb = row_in_buf.data() - row_min;              // indexed by table row
+    const int mb = p.max_buffer_size;
+    const int64_t base = row_base[v];
+    const __m512i vsw = _mm512_set1_epi32(p.negative_swap_percentage);
+    const __m512d vinv = _mm512_set1_pd(inv_mb);
+    const __m256i vd = _mm256_set1_epi32(mb);
+    const __m512i iota = _mm512_set_epi8(63, 62, 61, 60, 59, 58, 57, 56, 55, 54, 53, 52, 51, 50, 49, 48, 47, 46, 45, 44, 43, 42, 41, 40, 39, 38, 37, 36, 35, 34, 33, 32,
+                                         31, 30, 29, 28, 27, 26, 25, 24, 23, 22, 21, 20, 19, 18, 17, 16, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0);
+    alignas(64) int32_t posv[64 + 16];
+    alignas(64) uint8_t jb[64];
+    int j0 = 0;
+    while (j0 < n) {
+      const int cnt = std::min(n - j0, 64);
+      // shots j0 .. j0+cnt-1 that are not in the buffer (the bitmap is padded: reading 64 bytes is always in bounds)
+      uint64_t notin = _mm512_cmpeq_epi8_mask(_mm512_loadu_si512((const void*)(inb + base + j0)), _mm512_setzero_si512());
+      if (cnt < 64) notin &= (1ull << cnt) - 1;
+      const int m = __builtin_popcountll(notin);
+      if (m == 0) { j0 += cnt; continue; }
+      // predicate bits of stream positions q .. q + 2m - 1
+      const uint32_t* w = hv + q;
+      uint64_t f0 = 0, f1 = 0;
+      const int groups = (2 * m + 15) >> 4;
+      for (int g = 0; g < groups && g < 4; ++g) f0 |= (uint64_t)swap_flags16(w + 16 * g, vsw) << (16 * g);
+      for (int g = 4; g < groups; ++g) f1 |= (uint64_t)swap_flags16(w + 16 * g, vsw) << (16 * (g - 4));
+      const u128 F = ((u128)f1 << 64) | f0;
+      const u128 EVEN = ((u128)0x5555555555555555ull << 64) | 0x5555555555555555ull;
+      const u128 S = F & ~(F << 1);
+      const u128 E = F & ~(F + (S & EVEN));
+      const u128 O = F & ~E;
+      const u128 TEST = ~(F << 1) | ((E << 1) & EVEN) | ((O << 1) & ~EVEN);
+      const int pm = select128(TEST, m);                     // position of the last test of this chunk
+      const u128 upto = pm == 127 ? ~(u128)0 : (((u128)1 << (pm + 1)) - 1);
+      const u128 TK = TEST & F & upto;                       // taken tests, in stream order
+      const uint64_t t_lo = (uint64_t)TEST, t_hi = (uint64_t)(TEST >> 64);
+      const int c0 = __builtin_popcountll(t_lo);
+      uint64_t comp = _pext_u64((uint64_t)F, t_lo);          // predicate of the k-th test at bit k
+      if (c0 < 64) comp |= _pext_u64((uint64_t)(F >> 64), t_hi) << c0;
+      const uint64_t TS = _pdep_u64(comp, notin);            // taken shots, in shot order (same count as TK)
+      const int q_end = q + pm + 1 + (int)((F >> pm) & 1);
+      // the chunk's (slot, shot) pairs: the word behind each taken test, reduced modulo the buffer size; the shots' numbers
+      const uint64_t k_lo = (uint64_t)TK, k_hi = (uint64_t)(TK >> 64);
+      int nt = 0;
+      WPT(1)
+      {
+        // (the m tests of a chunk end at position 2(m-1) <= 126 at the latest: the last position word is word 127)
+        uint64_t pw = k_lo << 1;                             // bit i: word i is a position word
+        for (int g = 0; g < 4; ++g, pw >>= 16) {
+          const __mmask16 mk = (__mmask16)pw;
+          if (!mk) continue;
+          const __m512i pk = _mm512_maskz_compress_epi32(mk, _mm512_loadu_si512((const void*)(w + 16 * g)));
+          _mm512_storeu_si512((void*)(posv + nt), mod16(pk, vinv, vd));
+          nt += __builtin_popcount(mk);
+        }
+        if ((k_lo >> 63) | k_hi) {
+          pw = (k_hi << 1) | (k_lo >> 63);
+          for (int g = 4; g < 8; ++g, pw >>= 16) {
+            const __mmask16 mk = (__mmask16)pw;
+            if (!mk) continue;
+            const __m512i pk = _mm512_maskz_compress_epi32(mk, _mm512_loadu_si512((const void*)(w + 16 * g)));
+            _mm512_storeu_si512((void*)(posv + nt), mod16(pk, vinv, vd));
+            nt += __builtin_popcount(mk);
+          }
+        }
+      }
+      _mm512_store_si512((void*)jb, _mm512_maskz_compress_epi8((__mmask64)TS, iota));
+      bool restarted = false;
+      WPT(5)
+      const int32_t hi_row = (int32_t)(base + j0 + cnt);
+      for (int k = 0; k < nt; ++k) {
+        const int32_t pos = posv[k];
+        const int32_t r = (int32_t)(base + j0 + jb[k]);
+        const int32_t old = brow[pos];
+        inb[old] = 0; inb[r] = 1; brow[pos] = r;
+        if (LOG) { ev_ring[(ev0 + nev) & evm] = Event{pos, r}; ++nev; }
+        if (old > r && old < hi_row) {
+          // a later shot of this video left the buffer: its membership bit above is stale
+          const int tp = select128(TK, k + 1);
+          j0 = j0 + jb[k] + 1; q = q + tp + 2; restarted = true; ++stat_restarts;
+          break;
+        }
+      }
+      if (!restarted) { q = q_end; j0 += cnt; }
+      WPT(2)
     }
   }
   rng.skip(a_total + Nn + q);
@@ -581,21 +758,24 @@ void vv_sampler::frames_item(const uint32_t* rec, int32_t* out, int32_t* label) 
     out[0] = (int32_t)(base + f0); out[1] = (int32_t)(base + f1);                    // :400-405, draw order, not sorted
     if (label && p.output_shot_distance) *label = pair_label(f0, f1);               // :407-415
   } else if (p.context_type == VV_CONTEXT_WINDOW || p.context_type == VV_CONTEXT_PAST) {
-    // random_unique(perm, C) on the identity permutation of 0..n-1, kept sparse: only the touched entries
-    int32_t oi[64], ov[64]; int no = 0;
-    int32_t fr[32];
-    std::vector<int32_t> big_i, big_v, big_f;
-    int32_t *pi = oi, *pv = ov, *pf = fr;
-    if (2 * C > 64) { big_i.resize(2 * C); big_v.resize(2 * C); big_f.resize(C); pi = big_i.data(); pv = big_v.data(); pf = big_f.data(); }
-    auto get = [&](int i) { for (int k = no - 1; k >= 0; --k) if (pi[k] == i) return pv[k]; return (int32_t)i; };
-    auto set = [&](int i, int32_t val) { for (int k = no - 1; k >= 0; --k) if (pi[k] == i) { pv[k] = val; return; } pi[no] = i; pv[no] = val; ++no; };
+    // random_unique(perm, C) on the identity permutation of 0..n-1, kept sparse.  Step `first` exchanges perm[first] and perm[j],
+    // j = first + rand() % left >= first: perm[first] is final from then on and is never read again, so only the entries that were
+    // some earlier step's j matter -- (J[k], W[k]) = "perm[J[k]] holds W[k]", the latest k wins.  The look-ups run over all earlier
+    // steps without branching on the comparison (at C = 5 ten compare-selects per item instead of data-dependent searches), and the
+    // sort (:437, :522) is an odd-even transposition network of min / max: the frame stage's time was mostly mispredicted branches.
+    int32_t Jb[32], Wb[32], fr[32];
+    std::vector<int32_t> big;
+    int32_t *J = Jb, *W = Wb, *pf = fr;
+    if (C > 32) { big.resize(3 * (size_t)C); J = big.data(); W = J + C; pf = W + C; }
     for (int first = 0, left = n; first < C; ++first, --left) {
       const int j = first + fm.mod((int32_t)(x[first] >> 1), left);
-      const int32_t vf = get(first), vj = get(j);
-      set(first, vj); set(j, vf);
+      int32_t vf = first, vj = j;
+      for (int k = 0; k < first; ++k) { vf = J[k] == first ? W[k] : vf; vj = J[k] == j ? W[k] : vj; }
+      vj = j == first ? vf : vj;
+      pf[first] = vj; J[first] = j; W[first] = vf;
     }
-    for (int i = 0; i < C; ++i) pf[i] = get(i);
-    std::sort(pf, pf + C);                                                           // :437, :522
+    for (int round = 0; round < C; ++round)
+      for (int i = round & 1; i + 1 < C; i += 2) { const int32_t a = pf[i], b = pf[i + 1]; pf[i] = a < b ? a : b; pf[i + 1] = a < b ? b : a; }
     if (p.context_type == VV_CONTEXT_WINDOW) {
       const int half = C / 2;
       for (int i = 0, ctx = 0; i < C; ++i) {                                         // :439-453: the middle one is the target
@@ -789,7 +969,7 @@ void vv_sampler::run_walk() {
     if (tw) wait_walk.store(wait_walk.load(std::memory_order_relaxed) + (__rdtsc() - tw), std::memory_order_relaxed);
     uint32_t* rec = recs.data() + (size_t)(it % ring_items) * rec_words;
     select_item(rec);
-    swap_item<true>(rec, buf_row.data(), events.data(), ev_mask, &ev_head);
+    swap<true>(rec, buf_row.data(), events.data(), ev_mask, &ev_head);
     ++it;
     if (it - published >= chunk || it % B == 0) { walked.store(it, std::memory_order_release); published = it; }
   }
@@ -819,7 +999,7 @@ void vv_sampler::run_negs(bool also_frames) {
     if (tw) wait_negs.store(wait_negs.load(std::memory_order_relaxed) + (__rdtsc() - tw), std::memory_order_relaxed);
     const uint32_t* rec = recs.data() + (size_t)(it % ring_items) * rec_words;
     int32_t* out = ring->idx_of(k) + (size_t)(it % B) * CN;
-    negs_item(rec, out + C, brow);
+    negs(rec, out + C, brow);
     if (also_frames) frames_item(rec, out, ring->label_of(k) + (it % B));
     const uint64_t e0 = (uint64_t)rec[2] | ((uint64_t)rec[3] << 32);
     const uint32_t nev = rec[1];
@@ -872,9 +1052,9 @@ int vv_sampler::sample_batch(int32_t* idx, int32_t* last_src, int32_t* label) {
   for (int it = 0; it < B; ++it) {
     int32_t* o = out + (size_t)it * CN;
     select_item(rec);
-    negs_item(rec, o + C, buf_row.data());       // the buffer as it stands BEFORE this item's swap-in (:855-875 precede :888-906)
+    negs(rec, o + C, buf_row.data());       // the buffer as it stands BEFORE this item's swap-in (:855-875 precede :888-906)
     frames_item(rec, o, label ? label + it : nullptr);
-    swap_item<false>(rec, buf_row.data(), nullptr, 0, nullptr);
+    swap<false>(rec, buf_row.data(), nullptr, 0, nullptr);
   }
   if (last_src) memcpy(last_src, out, (size_t)B * CN * 4);     // no same-video negatives on this path: last == row
   return VV_OK;
@@ -965,12 +1145,18 @@ int vv_sampler_create_neg(const vv_sampler_param* p_in, int32_t n_videos, const 
   s->CA = (p->context_type == VV_CONTEXT_WINDOW || p->context_type == VV_CONTEXT_PAST || p->context_type == VV_CONTEXT_PAIRWISE) ? C
           : (p->context_type == VV_CONTEXT_PAST_CONTINUOUS ? 2 : 0);
   s->rec_words = 4 + s->CA + Nn;
+  {
+    const char* e = getenv("VV_SAMPLER_AVX512");
+    s->wide = !(e && atoi(e) == 0) && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512dq") &&
+              __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512vbmi2") && __builtin_cpu_supports("bmi2");
+    s->inv_mb = p->max_buffer_size > 0 ? 1.0 / (double)p->max_buffer_size : 0.0;
+  }
   s->rec1.assign((size_t)s->rec_words, 0u);
   {
     const int64_t per_item = (int64_t)C + Nn + 3ll * max_n + 32;
     const int64_t block = std::max<int64_t>(16384, 4 * per_item);
     if (block > (1ll << 28)) { delete s; return VV_ERR_ARG; }
-    s->rng.init((int)block, Nn > 0 ? p->negative_swap_percentage : 0, (uint32_t)p->rand_seed);
+    s->rng.init((int)block, Nn > 0 ? p->negative_swap_percentage : 0, (uint32_t)p->rand_seed, s->wide);
   }
   if (!s->fast) s->slots.assign((size_t)p->batch_size * CN, Slot());
   const int mb = Nn > 0 ? p->max_buffer_size : 0;
@@ -1109,6 +1295,7 @@ int64_t vv_sampler_stat(vv_sampler* s, int32_t which) {
     case 4: return (int64_t)s->wait_walk.load(std::memory_order_relaxed);     // ... of which the walk stage spent waiting
     case 5: return (int64_t)s->wait_negs.load(std::memory_order_relaxed);     // ... the negative-slot stage
     case 6: return (int64_t)s->wait_frames.load(std::memory_order_relaxed);   // ... the frame stage
+    case 7: return s->wide ? 1 : 0;              // 512-bit forms in use
     default: return -1;
   }
 }
