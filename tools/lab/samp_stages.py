@@ -13,10 +13,10 @@ for B in (1024, 8192):
             s.prefetch_start(depth=8, threads=threads)
             n = max(8, 400 * 1024 // B)
             for _ in range(4): s.next()
-            t0 = time.perf_counter(); c0 = [s.stat(i) for i in (3, 4, 5, 6)]
+            t0 = time.perf_counter(); c0 = [s.stat(i) for i in (3, 4, 5, 6, 8)]
             for _ in range(n): s.next()
-            el = time.perf_counter() - t0; c1 = [s.stat(i) for i in (3, 4, 5, 6)]
+            el = time.perf_counter() - t0; c1 = [s.stat(i) for i in (3, 4, 5, 6, 8)]
             d = [b - a for a, b in zip(c0, c1)]
-            print("B %5d threads %d: %.3f ms/batch; waiting: walk %4.1f%%  negs %4.1f%%  frames %4.1f%%" % (
-                B, threads, el / n * 1e3, 100 * d[1] / d[0], 100 * d[2] / d[0], 100 * d[3] / d[0]), flush=True)
+            print("B %5d threads %d: %.3f ms/batch; waiting: walk %4.1f%% (+ %4.1f%% for the stream thread)  negs %4.1f%%  frames %4.1f%%" % (
+                B, threads, el / n * 1e3, 100 * d[1] / d[0], 100 * d[4] / d[0], 100 * d[2] / d[0], 100 * d[3] / d[0]), flush=True)
             s.close()

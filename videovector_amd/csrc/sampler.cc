@@ -44,15 +44,42 @@
 
 #include "../../include/videovec.h"
 
+#ifdef VV_WALK_PROF
+extern uint64_t g_wp[8];
+#endif
 namespace {
+
+#define VV_T512 __attribute__((target("avx512f,avx512bw,avx512dq,avx512vl,avx512vbmi2,bmi,bmi2,lzcnt,popcnt")))
+VV_T512 static inline uint32_t swap_flags16v(__m512i words, __m512i vsw) {      // ((word >> 1) % 100 < vsw) of sixteen stream words, as mask bits
+  const __m512i t = _mm512_srli_epi32(words, 1);
+  const __m512i magic = _mm512_set1_epi32(0x51EB851F);
+  const __m512i pe = _mm512_srli_epi64(_mm512_mul_epu32(t, magic), 37);                           // even lanes: t / 100
+  const __m512i po = _mm512_srli_epi64(_mm512_mul_epu32(_mm512_srli_epi64(t, 32), magic), 37);   // odd lanes
+  const __m512i q = _mm512_or_si512(pe, _mm512_slli_epi64(po, 32));
+  const __m512i r = _mm512_sub_epi32(t, _mm512_mullo_epi32(q, _mm512_set1_epi32(100)));
+  return (uint32_t)_mm512_cmplt_epu32_mask(r, vsw);
+}
+// (a >> 1) % d of sixteen stream words, d < 2^31 (see above)
+VV_T512 static inline __m512i mod16(__m512i words, __m512d vinv, __m256i vd) {
+  const __m512i a = _mm512_srli_epi32(words, 1);
+  const __m256i a0 = _mm512_castsi512_si256(a), a1 = _mm512_extracti64x4_epi64(a, 1);
+  const __m256i q0 = _mm512_cvttpd_epi32(_mm512_mul_pd(_mm512_cvtepi32_pd(a0), vinv));
+  const __m256i q1 = _mm512_cvttpd_epi32(_mm512_mul_pd(_mm512_cvtepi32_pd(a1), vinv));
+  __m256i r0 = _mm256_sub_epi32(a0, _mm256_mullo_epi32(q0, vd)), r1 = _mm256_sub_epi32(a1, _mm256_mullo_epi32(q1, vd));
+  r0 = _mm256_mask_sub_epi32(r0, _mm256_cmpeq_epi32_mask(r0, vd), r0, vd);
+  r1 = _mm256_mask_sub_epi32(r1, _mm256_cmpeq_epi32_mask(r1, vd), r1, vd);
+  return _mm512_inserti64x4(_mm512_castsi256_si512(r0), r1, 1);
+}
 
 // glibc rand() == random() with the default TYPE_3 state: 31 words seeded from seed 1 by the
 // 16807 Lehmer recurrence, then state[f] += state[f-3] walking f cyclically; output is the new
 // word >> 1; the first 310 outputs are discarded by srandom.  (glibc 2.35 stdlib/random_r.c)
 class LibcRand {
  public:
-  void init(int block, int swap_pct, uint32_t seed = 1, bool wide = false) {
+  void init(int block, int swap_pct, uint32_t seed = 1, bool wide = false, int mb = 0) {
     wide_ = wide;
+    if (const char* e = getenv("VV_SAMPLER_PREFETCH")) pf_ = atoi(e);
+    aux_ = wide && mb > 0 && swap_pct > 0; mb_ = mb; inv_mb_ = mb > 0 ? 1.0 / (double)mb : 0.0;
     uint32_t st[31];
     if (seed == 0) seed = 1;             // srandom_r: seed 0 is seed 1 (the never-seeded stream)
     int64_t w = seed;
@@ -72,11 +99,13 @@ class LibcRand {
     // closer than 9 positions, so eight values are produced per vector step instead of one per store-to-load round trip.
     n_ = block; swap_ = (uint32_t)swap_pct;
     h_.assign((size_t)kHist + n_ + 8, 0u);
+    if (aux_) { hf_.assign((size_t)kHist + n_ + 64, 0); hp_.assign((size_t)kHist + n_ + 16, 0); }
     uint32_t* h = h_.data();
     for (int i = 0; i < 31; ++i) h[kHist - 31 + i] = st[(f + i) % 31];
     for (int i = kHist - 32; i >= 0; --i) h[i] = h[i + 31] - h[i + 28];     // run the recurrence backwards for the extra history
-    generate(h_.data() + kHist, 0);
+    generate(h_.data() + kHist, aux_ ? hf_.data() + kHist : nullptr, aux_ ? hp_.data() + kHist : nullptr, 0);
     base_ = h_.data() + kHist; pos_ = 0; avail_ = n_;
+    if (aux_) { basef_ = hf_.data() + kHist; basep_ = hp_.data() + kHist; }
   }
   ~LibcRand() { if (helper_on_) { helper_stop_.store(1); if (helper_.joinable()) helper_.join(); } }
   int capacity() const { return n_; }
@@ -86,10 +115,33 @@ class LibcRand {
     if (helper_on_) { switch_block(); return; }
     const int m = n_ - pos_;                       // unconsumed values
     memmove(h_.data(), h_.data() + pos_, (size_t)(kHist + m) * sizeof(uint32_t));
-    generate(h_.data() + kHist, m);
+    if (aux_) { memmove(hf_.data(), hf_.data() + pos_, (size_t)(kHist + m)); memmove(hp_.data(), hp_.data() + pos_, (size_t)(kHist + m) * sizeof(int32_t)); }
+#ifdef VV_WALK_PROF
+    const uint64_t tg_ = __rdtsc();
+#endif
+    generate(h_.data() + kHist, aux_ ? hf_.data() + kHist : nullptr, aux_ ? hp_.data() + kHist : nullptr, m);
+#ifdef VV_WALK_PROF
+    g_wp[6] += __rdtsc() - tg_; g_wp[7] += (uint64_t)(n_ - m);
+#endif
     pos_ = 0;
   }
   const uint32_t* peek() const { return base_ + pos_; }     // raw words: rand() = word >> 1
+  // with the 512-bit forms, beside every word: its swap-in predicate as a byte (0xFF: (word >> 1) % 100 < negative_swap_percentage)
+  // and (word >> 1) % max_buffer_size -- computed where the words are generated (the helper thread, when there is one) instead of
+  // inside the walk's dependent chain
+  bool has_aux() const { return aux_; }
+  // With the stream thread on another core every line the walk reads comes out of that core's L2 (the helper wrote it there): ask for
+  // the lines `pf_` words ahead of the cursor, one item's worth per item (VV_SAMPLER_PREFETCH words; 0 = off).
+  void prefetch_ahead(int words) {
+    if (!helper_on_ || pf_ <= 0) return;
+    const int a = pos_ + pf_, b = std::min(a + words, avail_);
+    for (int i = a & ~15; i < b; i += 16) {
+      _mm_prefetch((const char*)(base_ + i), _MM_HINT_T0);
+      if (aux_) { _mm_prefetch((const char*)(basep_ + i), _MM_HINT_T0); if ((i & 63) == 0) _mm_prefetch((const char*)(basef_ + i), _MM_HINT_T0); }
+    }
+  }
+  const uint8_t* peek_flags() const { return basef_ + pos_; }
+  const int32_t* peek_posmod() const { return basep_ + pos_; }
   void skip(int k) { pos_ += k; }
   int32_t next() { ensure(1); return (int32_t)(base_[pos_++] >> 1); }
   void discard(int64_t k) {
@@ -104,10 +156,17 @@ class LibcRand {
   // helper.  Only the consumer's thread touches pos_ / base_ / avail_; the buffers change hands through fill_ / ready_.
   void start_helper() {
     if (helper_on_) return;
-    for (int b = 0; b < 2; ++b) blk_[b].assign((size_t)n_ + kHist + n_ + 8, 0u);
+    for (int b = 0; b < 2; ++b) {
+      blk_[b].assign((size_t)n_ + kHist + n_ + 8, 0u);
+      if (aux_) { blkf_[b].assign((size_t)n_ + kHist + n_ + 64, 0); blkp_[b].assign((size_t)n_ + kHist + n_ + 16, 0); }
+    }
     // the single buffer's state becomes block 0's: history + values at the same offsets, the cursor where it was
     memcpy(blk_[0].data() + n_, h_.data(), (size_t)(kHist + n_) * sizeof(uint32_t));
     cur_ = 0; base_ = blk_[0].data() + n_ + kHist; avail_ = n_;        // (pos_ unchanged)
+    if (aux_) {
+      memcpy(blkf_[0].data() + n_, hf_.data(), (size_t)(kHist + n_)); memcpy(blkp_[0].data() + n_, hp_.data(), (size_t)(kHist + n_) * sizeof(int32_t));
+      basef_ = blkf_[0].data() + n_ + kHist; basep_ = blkp_[0].data() + n_ + kHist;
+    }
     ready_[0].store(1); ready_[1].store(0);
     helper_stop_.store(0);
     fill_.store(1, std::memory_order_release);                        // fill block 1 as the continuation of block 0
@@ -123,21 +182,23 @@ class LibcRand {
     const int m = avail_ - pos_;
     const int keep = std::min(m, n_);
     memcpy(h_.data(), base_ + pos_ - kHist, (size_t)(kHist + keep) * sizeof(uint32_t));
-    generate(h_.data() + kHist, keep);
+    if (aux_) { memcpy(hf_.data(), basef_ + pos_ - kHist, (size_t)(kHist + keep)); memcpy(hp_.data(), basep_ + pos_ - kHist, (size_t)(kHist + keep) * sizeof(int32_t)); }
+    generate(h_.data() + kHist, aux_ ? hf_.data() + kHist : nullptr, aux_ ? hp_.data() + kHist : nullptr, keep);
     base_ = h_.data() + kHist; pos_ = 0; avail_ = n_;
+    if (aux_) { basef_ = hf_.data() + kHist; basep_ = hp_.data() + kHist; }
     // (m > n_ cannot happen: a switch leaves at most n_ - 1 + n_ values and the next ensure() only runs it down)
-    blk_[0].clear(); blk_[0].shrink_to_fit(); blk_[1].clear(); blk_[1].shrink_to_fit();
+    for (int b = 0; b < 2; ++b) { blk_[b].clear(); blk_[b].shrink_to_fit(); blkf_[b].clear(); blkf_[b].shrink_to_fit(); blkp_[b].clear(); blkp_[b].shrink_to_fit(); }
   }
+  uint64_t wait_ticks() const { return wait_ticks_; }         // time-stamp-counter ticks the consumer waited for the helper's next block
   void pin_helper_like_caller(const cpu_set_t* set) { helper_set_ = set ? *set : cpu_set_t(); helper_pin_ = set != nullptr; }
 
  private:
-  static constexpr int kHist = 40;               // words kept in front of the first unconsumed value (>= 37)
-  // Eight words per step from x[k] = x[k-9] + x[k-31] + x[k-34] + x[k-37].  Read back from memory, the operands would be loads that
-  // straddle the stores of the last few steps (no store forwarding: each step would wait for them to drain), so the scalar form --
-  // whose loads forward -- ran faster than a 256-bit one (1.6 against ~2 ticks per word); with AVX-512VL the last forty words stay in
-  // five registers and the four operand windows are cut out of them by VALIGND.
-  void generate(uint32_t* __restrict h, int from) {       // h = the values' start, kHist words of history in front of it
-    if (wide_) { generate_valign(h, from); return; }
+  static constexpr int kHist = 48;               // words kept in front of the first unconsumed value (>= 46: the 512-bit generator's farthest operand; three whole vectors)
+  // Eight words per step from x[k] = x[k-9] + x[k-31] + x[k-34] + x[k-37].  (Scalar on purpose: 256-bit loads of the operands would
+  // straddle the stores of the last few steps -- no store forwarding, each step waits for them to drain -- and measured slower, ~2 against
+  // 1.6 ticks per word.)
+  void generate(uint32_t* __restrict h, uint8_t* f, int32_t* pm, int from) {       // h = the values' start, kHist words of history in front of it
+    if (wide_) { generate_wide(h, f, pm, from); return; }
     const int n = n_;
     int i = from;
     for (; i + 8 <= n; i += 8) {                 // every operand of a block lies in front of the block
@@ -147,21 +208,39 @@ class LibcRand {
     }
     for (; i < n; ++i) h[i] = h[i - 31] + h[i - 3];
   }
-  __attribute__((target("avx512f,avx512vl"))) void generate_valign(uint32_t* __restrict h, int from) {
+  // 512-bit form: sixteen words per step need every operand at least sixteen positions back.  Substituting the recurrence into its
+  // nearest term four more times gives x[k] = x[k-18] + x[k-31] + x[k-34] + x[k-37] + x[k-40] + x[k-43] + x[k-46]; the last 48 words stay
+  // in three registers and the seven operand windows are cut out of them by VALIGND (read back from memory they would be loads that
+  // straddle the stores of the last steps -- no store forwarding).  In the same pass, while the new words are in a register: their
+  // swap-in predicate bytes and slot remainders (see peek_flags).
+  template <bool AUX>
+  VV_T512 int generate_wide_loop(uint32_t* __restrict h, uint8_t* __restrict f, int32_t* __restrict pm, int i) {
     const int n = n_;
-    int i = from;
-    if (i + 8 <= n) {
-      __m256i v1 = _mm256_loadu_si256((const __m256i*)(h + i - 8)), v2 = _mm256_loadu_si256((const __m256i*)(h + i - 16));
-      __m256i v3 = _mm256_loadu_si256((const __m256i*)(h + i - 24)), v4 = _mm256_loadu_si256((const __m256i*)(h + i - 32));
-      __m256i v5 = _mm256_loadu_si256((const __m256i*)(h + i - 40));
-      for (; i + 8 <= n; i += 8) {
-        const __m256i far = _mm256_add_epi32(_mm256_add_epi32(_mm256_alignr_epi32(v3, v4, 1), _mm256_alignr_epi32(v4, v5, 6)), _mm256_alignr_epi32(v4, v5, 3));
-        const __m256i nv = _mm256_add_epi32(far, _mm256_alignr_epi32(v1, v2, 7));      // (the operand that depends on the last step joins last)
-        _mm256_storeu_si256((__m256i*)(h + i), nv);
-        v5 = v4; v4 = v3; v3 = v2; v2 = v1; v1 = nv;
+    if (i + 16 > n) return i;
+    const __m512i vsw = _mm512_set1_epi32((int)swap_);
+    const __m512d vinv = _mm512_set1_pd(inv_mb_);
+    const __m256i vd = _mm256_set1_epi32(mb_ > 0 ? mb_ : 1);
+    __m512i v1 = _mm512_loadu_si512((const void*)(h + i - 16)), v2 = _mm512_loadu_si512((const void*)(h + i - 32)), v3 = _mm512_loadu_si512((const void*)(h + i - 48));
+    for (; i + 16 <= n; i += 16) {
+      const __m512i far = _mm512_add_epi32(_mm512_add_epi32(_mm512_add_epi32(_mm512_alignr_epi32(v2, v3, 14), _mm512_alignr_epi32(v2, v3, 11)),
+                                                            _mm512_add_epi32(_mm512_alignr_epi32(v2, v3, 8), _mm512_alignr_epi32(v2, v3, 5))),
+                                           _mm512_alignr_epi32(v2, v3, 2));
+      const __m512i nv = _mm512_add_epi32(far, _mm512_add_epi32(_mm512_alignr_epi32(v1, v2, 14), _mm512_alignr_epi32(v1, v2, 1)));   // (the operands that depend on the last step join last)
+      _mm512_storeu_si512((void*)(h + i), nv);
+      if (AUX) {
+        _mm_storeu_si128((__m128i*)(f + i), _mm_movm_epi8((__mmask16)swap_flags16v(nv, vsw)));
+        _mm512_storeu_si512((void*)(pm + i), mod16(nv, vinv, vd));
       }
+      v3 = v2; v2 = v1; v1 = nv;
     }
-    for (; i < n; ++i) h[i] = h[i - 31] + h[i - 3];
+    return i;
+  }
+  void generate_wide(uint32_t* h, uint8_t* f, int32_t* pm, int from) {
+    int i = f ? generate_wide_loop<true>(h, f, pm, from) : generate_wide_loop<false>(h, nullptr, nullptr, from);
+    for (; i < n_; ++i) {
+      h[i] = h[i - 31] + h[i - 3];
+      if (f) { const uint32_t t = h[i] >> 1; f[i] = t % 100u < swap_ ? 0xFF : 0; pm[i] = (int32_t)(t % (uint32_t)mb_); }
+    }
   }
   void helper_loop() {
     if (helper_pin_) (void)sched_setaffinity(0, sizeof(helper_set_), &helper_set_);
@@ -176,7 +255,7 @@ class LibcRand {
       uint32_t* dst = blk_[b].data() + n_ + kHist;                     // values of block b
       const uint32_t* src = blk_[1 - b].data() + n_ + kHist + n_ - kHist;   // the other block's last kHist values
       memcpy(dst - kHist, src, (size_t)kHist * sizeof(uint32_t));
-      generate(dst, 0);
+      generate(dst, aux_ ? blkf_[b].data() + n_ + kHist : nullptr, aux_ ? blkp_[b].data() + n_ + kHist : nullptr, 0);
       fill_.store(-1, std::memory_order_relaxed);
       ready_[b].store(1, std::memory_order_release);
     }
@@ -184,10 +263,19 @@ class LibcRand {
   void switch_block() {
     const int nb = 1 - cur_;
     unsigned spins = 0;
-    while (!ready_[nb].load(std::memory_order_acquire)) { if (++spins < 100000) __builtin_ia32_pause(); else sched_yield(); }
+    if (!ready_[nb].load(std::memory_order_acquire)) {               // the helper has not finished the next block: the consumer outruns it
+      const uint64_t t0 = __rdtsc();
+      while (!ready_[nb].load(std::memory_order_acquire)) { if (++spins < 100000) __builtin_ia32_pause(); else sched_yield(); }
+      wait_ticks_ += __rdtsc() - t0;
+    }
     const int m = avail_ - pos_;                                       // unconsumed values of the current run
     uint32_t* nv = blk_[nb].data() + n_ + kHist;
     memcpy(nv - m - kHist, base_ + pos_ - kHist, (size_t)(kHist + m) * sizeof(uint32_t));   // (the copy's end rewrites the block's own history with the same words)
+    if (aux_) {
+      uint8_t* nf = blkf_[nb].data() + n_ + kHist; int32_t* np = blkp_[nb].data() + n_ + kHist;
+      memcpy(nf - m, basef_ + pos_, (size_t)m); memcpy(np - m, basep_ + pos_, (size_t)m * sizeof(int32_t));
+      basef_ = nf - m; basep_ = np - m;
+    }
     base_ = nv - m; pos_ = 0; avail_ = m + n_;
     ready_[cur_].store(0, std::memory_order_relaxed);
     fill_.store(cur_, std::memory_order_release);                      // the exhausted block: continuation of block nb
@@ -197,9 +285,15 @@ class LibcRand {
   const uint32_t* base_ = nullptr;
   int n_ = 0, pos_ = 0, avail_ = 0;
   uint32_t swap_ = 0;
-  bool wide_ = false;
+  bool wide_ = false, aux_ = false;
+  uint64_t wait_ticks_ = 0;
+  int pf_ = 0;
+  int mb_ = 0; double inv_mb_ = 0.0;
+  std::vector<uint8_t> hf_; std::vector<int32_t> hp_;
+  const uint8_t* basef_ = nullptr; const int32_t* basep_ = nullptr;
   // helper mode
   std::vector<uint32_t> blk_[2];
+  std::vector<uint8_t> blkf_[2]; std::vector<int32_t> blkp_[2];
   std::thread helper_;
   bool helper_on_ = false; int cur_ = 0;
   std::atomic<int> fill_{-1}, helper_stop_{0};
@@ -236,8 +330,9 @@ class FastMod {
 // aligned group of 8 CPUs (one CCD = one L3 on those hosts) plus the SMT siblings the kernel reports for them -- a set,
 // not one CPU each, so that a runtime helper thread landing on one of them cannot hold a stage up for a time slice.
 // VV_SAMPLER_CPUS="a,b,c,..." overrides the set, VV_SAMPLER_PIN=0 disables.
-bool stage_cpu_set(cpu_set_t* out) {
+bool stage_cpu_set(cpu_set_t* out, cpu_set_t* per_stage = nullptr, int* n_per_stage = nullptr) {
   CPU_ZERO(out);
+  if (n_per_stage) *n_per_stage = 0;
   const char* off = getenv("VV_SAMPLER_PIN");
   if (off && atoi(off) == 0) return false;
   if (const char* e = getenv("VV_SAMPLER_CPUS")) {
@@ -254,6 +349,10 @@ bool stage_cpu_set(cpu_set_t* out) {
   for (int c = g0; c < g0 + 8 && c < CPU_SETSIZE; ++c) {
     if (!CPU_ISSET(c, &allowed)) continue;
     CPU_SET(c, out); ++n;
+    // a core of its own for each stage thread (the CPU and its SMT siblings), not the caller's: see the note at the function's end
+    cpu_set_t* mine = (per_stage && n_per_stage && c != cur && *n_per_stage < 4) ? &per_stage[*n_per_stage] : nullptr;
+    if (mine) { CPU_ZERO(mine); CPU_SET(c, mine); }
+    bool with_caller = false;
     char path[128];                                    // SMT siblings of c
     snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
     if (FILE* f = fopen(path, "r")) {
@@ -263,12 +362,20 @@ bool stage_cpu_set(cpu_set_t* out) {
           const int a = atoi(q); int b = a;
           while (*q && *q != ',' && *q != '-' && *q != '\n') ++q;
           if (*q == '-') { ++q; b = atoi(q); while (*q && *q != ',' && *q != '\n') ++q; }
-          for (int k = a; k <= b && k < CPU_SETSIZE; ++k) if (k >= 0 && CPU_ISSET(k, &allowed)) CPU_SET(k, out);
+          for (int k = a; k <= b && k < CPU_SETSIZE; ++k) {
+            if (k >= 0 && CPU_ISSET(k, &allowed)) { CPU_SET(k, out); if (mine) CPU_SET(k, mine); }
+            if (k == cur) with_caller = true;
+          }
           if (*q == ',') ++q;
         }
       fclose(f);
     }
+    if (mine && !with_caller) ++*n_per_stage;
   }
+  // Round 5: inside the common set the scheduler kept moving the stage threads (and now and then put two on the siblings of one
+  // core): ten samplers of the 8192-item batch spread over 0.83 .. 1.34 ms; with the four threads on four cores of their own
+  // 0.759 .. 0.768 (profiles/r05_sampler_place.txt; siblings sharing a core were slower in every pairing tried).  So when the
+  // group has four cores beside the caller's, each stage thread gets one (per_stage); otherwise the common set as before.
   return n >= 4;                                       // too few neighbours: leave placement to the scheduler
 }
 void pin_self(const cpu_set_t* set) {
@@ -427,7 +534,7 @@ struct vv_sampler {
   template <bool LOG> void swap_item(uint32_t* rec, int32_t* brow, Event* ev_ring, uint64_t ev_mask, uint64_t* ev_head);
   template <bool LOG> void swap_item_512(uint32_t* rec, int32_t* brow, Event* ev_ring, uint64_t ev_mask, uint64_t* ev_head);
   template <bool LOG> void swap(uint32_t* rec, int32_t* brow, Event* ev_ring, uint64_t evm, uint64_t* ev_head) {
-    if (wide) swap_item_512<LOG>(rec, brow, ev_ring, evm, ev_head); else swap_item<LOG>(rec, brow, ev_ring, evm, ev_head);
+    if (wide && rng.has_aux()) swap_item_512<LOG>(rec, brow, ev_ring, evm, ev_head); else swap_item<LOG>(rec, brow, ev_ring, evm, ev_head);
   }
   bool wide = false;                          // AVX-512 (F, BW, DQ, VL, VBMI2) forms of the walk and of the stream generation; VV_SAMPLER_AVX512=0 disables
   double inv_mb = 0.0;                        // 1.0 / max_buffer_size
@@ -467,6 +574,9 @@ struct vv_sampler {
 #ifdef VV_WALK_PROF
 uint64_t g_wp[8];
 #endif
+#ifdef VV_WALK_LAB
+int g_lab = 0;
+#endif
 void vv_sampler::select_item(uint32_t* rec) {
   const int C = p.context_size, Nn = p.num_negative_samples, V = (int)video_id.size();
   int v, n;
@@ -478,11 +588,12 @@ void vv_sampler::select_item(uint32_t* rec) {
   const bool shuffled = (p.context_type == VV_CONTEXT_WINDOW || p.context_type == VV_CONTEXT_PAST) && Nn > 0 && n > C;
   const int a_total = CA + (shuffled ? n - C - 1 : 0);     // :432/:517 random_unique, :482/:566 random_shuffle
 #ifdef VV_WALK_PROF
-  { const uint64_t t_ = __rdtsc(); rng.ensure(a_total + Nn + 2 * n + 16); g_wp[4] += __rdtsc() - t_; }
+  { const uint64_t t_ = __rdtsc(); rng.ensure(a_total + Nn + 2 * n + 160); g_wp[4] += __rdtsc() - t_; }
 #else
-  rng.ensure(a_total + Nn + 2 * n + 16);      // the swap-in reads whole 8-word groups
+  rng.ensure(a_total + Nn + 2 * n + 160);     // the swap-in reads whole groups of 8 / 16 words, the 512-bit form 128 predicate bytes from its position
 #endif
   rec[0] = (uint32_t)v;
+  rng.prefetch_ahead(a_total + Nn + 2 * n);
   const uint32_t* hv = rng.peek();
   memcpy(rec + 4, hv, (size_t)CA * 4);
   memcpy(rec + 4 + CA, hv + a_total, (size_t)Nn * 4);
@@ -505,8 +616,10 @@ typedef unsigned __int128 u128;
 static inline int select128(u128 x, int k) {        // position of the k-th (1-based) set bit; k <= popcount(x)
   const uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
   const int c0 = __builtin_popcountll(lo);
-  if (k <= c0) return (int)_tzcnt_u64(_pdep_u64(1ull << (k - 1), lo));
-  return 64 + (int)_tzcnt_u64(_pdep_u64(1ull << (k - 1 - c0), hi));
+  // both halves, then a select: which half holds the k-th bit depends on the video's length -- as a branch it is mispredicted often
+  const int in_lo = (int)_tzcnt_u64(_pdep_u64(1ull << ((k - 1) & 63), lo));
+  const int in_hi = 64 + (int)_tzcnt_u64(_pdep_u64(1ull << ((k - 1 - c0) & 63), hi));
+  return k <= c0 ? in_lo : in_hi;
 }
 
 // The swap-in of one video (:888-906 with AddToBuffer :24-37).  The reference walks the video's shots in order; a shot
@@ -584,7 +697,9 @@ __attribute__((noinline)) void vv_sampler::swap_item(uint32_t* rec, int32_t* bro
         const int32_t old = brow[pos];
         inb[old] = 0; inb[r] = 1; brow[pos] = r;
         if (LOG) { ev_ring[(ev0 + nev) & evm] = Event{pos, r}; ++nev; }
-        if (old > r && old < (int32_t)(base + j0 + cnt)) {
+        // (ONE unsigned compare for r < old < end of chunk: written as two, the first -- is the evicted row behind this one in the
+        // table? -- is a coin flip the branch predictor loses half the time: it was 10 of the loop's 12 cycles per swap-in)
+        if ((uint32_t)(old - r - 1) < (uint32_t)((int32_t)(base + j0 + cnt) - r - 1)) {
           // a later shot of this video left the buffer: its membership bit above is stale
           j0 = j + 1; q = q + tp + 2; restarted = true; ++stat_restarts;
           break;
@@ -606,32 +721,11 @@ __attribute__((noinline)) void vv_sampler::swap_item(uint32_t* rec, int32_t* bro
 // double precision: for 0 <= a < 2^31 the rounded product a * (1/d) is within a/d * 2^-52 < 1/d of a/d, so its integer part is the
 // quotient except when a is a multiple of d and the product fell just below it (remainder d instead of 0: one compare).  The loop that
 // is left reads (position, shot) pairs and moves rows -- the part that has to stay sequential (two tests may name the same slot).
-#define VV_T512 __attribute__((target("avx512f,avx512bw,avx512dq,avx512vl,avx512vbmi2,bmi,bmi2,lzcnt,popcnt")))
-VV_T512 static inline uint32_t swap_flags16(const uint32_t* w, __m512i vsw) {
-  const __m512i t = _mm512_srli_epi32(_mm512_loadu_si512((const void*)w), 1);
-  const __m512i magic = _mm512_set1_epi32(0x51EB851F);
-  const __m512i pe = _mm512_srli_epi64(_mm512_mul_epu32(t, magic), 37);                           // even lanes: t / 100
-  const __m512i po = _mm512_srli_epi64(_mm512_mul_epu32(_mm512_srli_epi64(t, 32), magic), 37);   // odd lanes
-  const __m512i q = _mm512_or_si512(pe, _mm512_slli_epi64(po, 32));
-  const __m512i r = _mm512_sub_epi32(t, _mm512_mullo_epi32(q, _mm512_set1_epi32(100)));
-  return (uint32_t)_mm512_cmplt_epu32_mask(r, vsw);
-}
-// (a >> 1) % d of sixteen stream words, d < 2^31 (see above)
-VV_T512 static inline __m512i mod16(__m512i words, __m512d vinv, __m256i vd) {
-  const __m512i a = _mm512_srli_epi32(words, 1);
-  const __m256i a0 = _mm512_castsi512_si256(a), a1 = _mm512_extracti64x4_epi64(a, 1);
-  const __m256i q0 = _mm512_cvttpd_epi32(_mm512_mul_pd(_mm512_cvtepi32_pd(a0), vinv));
-  const __m256i q1 = _mm512_cvttpd_epi32(_mm512_mul_pd(_mm512_cvtepi32_pd(a1), vinv));
-  __m256i r0 = _mm256_sub_epi32(a0, _mm256_mullo_epi32(q0, vd)), r1 = _mm256_sub_epi32(a1, _mm256_mullo_epi32(q1, vd));
-  r0 = _mm256_mask_sub_epi32(r0, _mm256_cmpeq_epi32_mask(r0, vd), r0, vd);
-  r1 = _mm256_mask_sub_epi32(r1, _mm256_cmpeq_epi32_mask(r1, vd), r1, vd);
-  return _mm512_inserti64x4(_mm512_castsi256_si512(r0), r1, 1);
-}
-
 template <bool LOG>
 VV_T512 __attribute__((noinline)) void vv_sampler::swap_item_512(uint32_t* rec, int32_t* brow, Event* ev_ring, uint64_t evm, uint64_t* ev_head) {
   const int Nn = p.num_negative_samples, v = cur_v, n = cur_n, a_total = cur_a_total;
-  const uint32_t* hv = rng.peek() + a_total + Nn;
+  const uint8_t* hf = rng.peek_flags() + a_total + Nn;       // the stream's predicate bytes and slot remainders from this item's first swap-in word on
+  const int32_t* hp = rng.peek_posmod() + a_total + Nn;
   int q = 0;
   uint32_t nev = 0;
   const uint64_t ev0 = LOG ? *ev_head : 0;
@@ -640,11 +734,7 @@ VV_T512 __attribute__((noinline)) void vv_sampler::swap_item_512(uint32_t* rec, 
 #endif
   if (Nn > 0 && p.negative_swap_percentage > 0) {
     uint8_t* inb = row_in_buf.data() - row_min;              // indexed by table row
-    const int mb = p.max_buffer_size;
     const int64_t base = row_base[v];
-    const __m512i vsw = _mm512_set1_epi32(p.negative_swap_percentage);
-    const __m512d vinv = _mm512_set1_pd(inv_mb);
-    const __m256i vd = _mm256_set1_epi32(mb);
     const __m512i iota = _mm512_set_epi8(63, 62, 61, 60, 59, 58, 57, 56, 55, 54, 53, 52, 51, 50, 49, 48, 47, 46, 45, 44, 43, 42, 41, 40, 39, 38, 37, 36, 35, 34, 33, 32,
                                          31, 30, 29, 28, 27, 26, 25, 24, 23, 22, 21, 20, 19, 18, 17, 16, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0);
     alignas(64) int32_t posv[64 + 16];
@@ -657,12 +747,10 @@ VV_T512 __attribute__((noinline)) void vv_sampler::swap_item_512(uint32_t* rec, 
       if (cnt < 64) notin &= (1ull << cnt) - 1;
       const int m = __builtin_popcountll(notin);
       if (m == 0) { j0 += cnt; continue; }
-      // predicate bits of stream positions q .. q + 2m - 1
-      const uint32_t* w = hv + q;
-      uint64_t f0 = 0, f1 = 0;
-      const int groups = (2 * m + 15) >> 4;
-      for (int g = 0; g < groups && g < 4; ++g) f0 |= (uint64_t)swap_flags16(w + 16 * g, vsw) << (16 * g);
-      for (int g = 4; g < groups; ++g) f1 |= (uint64_t)swap_flags16(w + 16 * g, vsw) << (16 * (g - 4));
+      // predicate bits of stream positions q .. q + 127 (the stream carries them as bytes: LibcRand::generate_wide)
+      const __m512i fb0 = _mm512_loadu_si512((const void*)(hf + q)), fb1 = _mm512_loadu_si512((const void*)(hf + q + 64));
+      const uint64_t f0 = _mm512_test_epi8_mask(fb0, fb0), f1 = _mm512_test_epi8_mask(fb1, fb1);
+      const int32_t* w = hp + q;
       const u128 F = ((u128)f1 << 64) | f0;
       const u128 EVEN = ((u128)0x5555555555555555ull << 64) | 0x5555555555555555ull;
       const u128 S = F & ~(F << 1);
@@ -678,27 +766,24 @@ VV_T512 __attribute__((noinline)) void vv_sampler::swap_item_512(uint32_t* rec, 
       if (c0 < 64) comp |= _pext_u64((uint64_t)(F >> 64), t_hi) << c0;
       const uint64_t TS = _pdep_u64(comp, notin);            // taken shots, in shot order (same count as TK)
       const int q_end = q + pm + 1 + (int)((F >> pm) & 1);
-      // the chunk's (slot, shot) pairs: the word behind each taken test, reduced modulo the buffer size; the shots' numbers
+      // the chunk's (slot, shot) pairs: the slot remainder of the word behind each taken test; the shots' numbers
       const uint64_t k_lo = (uint64_t)TK, k_hi = (uint64_t)(TK >> 64);
       int nt = 0;
       WPT(1)
       {
-        // (the m tests of a chunk end at position 2(m-1) <= 126 at the latest: the last position word is word 127)
+        // (the m tests of a chunk end at position 2(m-1) <= 126 at the latest: the last position word is word 127.)  Four groups of
+        // sixteen without looking at their masks -- an empty group packs nothing -- then the upper four if any taken test lies there
         uint64_t pw = k_lo << 1;                             // bit i: word i is a position word
         for (int g = 0; g < 4; ++g, pw >>= 16) {
           const __mmask16 mk = (__mmask16)pw;
-          if (!mk) continue;
-          const __m512i pk = _mm512_maskz_compress_epi32(mk, _mm512_loadu_si512((const void*)(w + 16 * g)));
-          _mm512_storeu_si512((void*)(posv + nt), mod16(pk, vinv, vd));
+          _mm512_storeu_si512((void*)(posv + nt), _mm512_maskz_compress_epi32(mk, _mm512_loadu_si512((const void*)(w + 16 * g))));
           nt += __builtin_popcount(mk);
         }
         if ((k_lo >> 63) | k_hi) {
           pw = (k_hi << 1) | (k_lo >> 63);
           for (int g = 4; g < 8; ++g, pw >>= 16) {
             const __mmask16 mk = (__mmask16)pw;
-            if (!mk) continue;
-            const __m512i pk = _mm512_maskz_compress_epi32(mk, _mm512_loadu_si512((const void*)(w + 16 * g)));
-            _mm512_storeu_si512((void*)(posv + nt), mod16(pk, vinv, vd));
+            _mm512_storeu_si512((void*)(posv + nt), _mm512_maskz_compress_epi32(mk, _mm512_loadu_si512((const void*)(w + 16 * g))));
             nt += __builtin_popcount(mk);
           }
         }
@@ -707,13 +792,36 @@ VV_T512 __attribute__((noinline)) void vv_sampler::swap_item_512(uint32_t* rec, 
       bool restarted = false;
       WPT(5)
       const int32_t hi_row = (int32_t)(base + j0 + cnt);
+#ifdef VV_WALK_LAB
+      if (g_lab & 1) nt = 0;                                 // (lab: no buffer updates at all)
+      static int32_t posv2[80]; static uint8_t jb2[64];
+      if (g_lab & 16) {                                      // (lab: slots / shots of the PREVIOUS chunk -- no store-to-load forwarding from the vector stores)
+        for (int k = 0; k < nt; ++k) {
+          const int32_t pos = posv2[k];
+          const int32_t r = (int32_t)(base + j0 + (jb2[k] % cnt));
+          const int32_t old = brow[pos];
+          inb[old] = 0; inb[r] = 1; brow[pos] = r;
+        }
+        memcpy(posv2, posv, sizeof(posv2)); memcpy(jb2, jb, 64);
+        nt = 0;
+      }
+#endif
       for (int k = 0; k < nt; ++k) {
         const int32_t pos = posv[k];
         const int32_t r = (int32_t)(base + j0 + jb[k]);
+#ifdef VV_WALK_LAB
+        if (g_lab & 2) { const int32_t old = brow[pos]; brow[pos] = r; if ((uint32_t)(old - r - 1) < (uint32_t)(hi_row - r - 1)) ++stat_restarts; continue; }   // no membership stores
+        if (g_lab & 32) { const int32_t old = brow[pos]; if ((uint32_t)(old - r - 1) < (uint32_t)(hi_row - r - 1)) ++stat_restarts; continue; }   // loads only
+        if (g_lab & 64) { brow[pos] = r; continue; }                                                // slot stores only
+        if (g_lab & 128) { const int32_t old = brow[pos]; inb[old] = 0; if ((uint32_t)(old - r - 1) < (uint32_t)(hi_row - r - 1)) ++stat_restarts; continue; }   // load + evicted row's byte
+        if (g_lab & 256) { inb[(uint32_t)(pos * 16) % 80000u] = 0; continue; }                       // a random byte store alone
+        if (g_lab & 4) { inb[r] = 1; continue; }                                                   // no slot exchange
+        if (g_lab & 8) { const int32_t old = brow[pos]; inb[old & 0xfff] = 0; inb[r] = 1; brow[pos] = r; continue; }   // evicted row's byte in a 4-KiB window
+#endif
         const int32_t old = brow[pos];
         inb[old] = 0; inb[r] = 1; brow[pos] = r;
         if (LOG) { ev_ring[(ev0 + nev) & evm] = Event{pos, r}; ++nev; }
-        if (old > r && old < hi_row) {
+        if ((uint32_t)(old - r - 1) < (uint32_t)(hi_row - r - 1)) {      // r < old < hi_row in one compare (see swap_item)
           // a later shot of this video left the buffer: its membership bit above is stale
           const int tp = select128(TK, k + 1);
           j0 = j0 + jb[k] + 1; q = q + tp + 2; restarted = true; ++stat_restarts;
@@ -950,7 +1058,8 @@ void vv_sampler::run_batches() {
 void vv_sampler::run_walk() {
   const int B = p.batch_size;
   uint64_t ev_head = 0;
-  int64_t it = 0, published = 0;
+  int64_t it = 0, published = 0, done_seen = 0;
+  uint64_t tail_seen = 0;
   const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(32, B));
   const uint64_t ev_cap = ev_mask + 1;
   while (!stop.load(std::memory_order_relaxed)) {
@@ -958,9 +1067,13 @@ void vv_sampler::run_walk() {
     // the record slot must have been consumed by both later stages, its batch buffer released by every consumer,
     // and the event ring must have room for one more video
     uint64_t tw = 0;
+    // (the later stages' counters as last read: they only grow, so a stale value errs on the safe side -- they are read again only
+    // when it says "no room".  Read for every item, each was a line the other core had just written: a miss on the walk's path per item.)
     for (;;) {
-      const int64_t done = std::min(ring->hdr->done_negs.load(std::memory_order_acquire), ring->hdr->done_frames.load(std::memory_order_acquire));
-      if (it - done < ring_items && ev_head + (uint64_t)max_n <= ev_tail.load(std::memory_order_acquire) + ev_cap) break;
+      if (it - done_seen < ring_items && ev_head + (uint64_t)max_n <= tail_seen + ev_cap) break;
+      done_seen = std::min(ring->hdr->done_negs.load(std::memory_order_acquire), ring->hdr->done_frames.load(std::memory_order_acquire));
+      tail_seen = ev_tail.load(std::memory_order_acquire);
+      if (it - done_seen < ring_items && ev_head + (uint64_t)max_n <= tail_seen + ev_cap) break;
       if (published < it) { walked.store(it, std::memory_order_release); published = it; }
       if (stop.load(std::memory_order_relaxed)) return;
       if (!tw) tw = __rdtsc();
@@ -979,6 +1092,7 @@ void vv_sampler::run_negs(bool also_frames) {
   const int B = p.batch_size, C = p.context_size, CN = C + p.num_negative_samples;
   RingHdr* h = ring->hdr;
   int64_t it = 0, published = 0, avail = 0;
+  uint64_t ev_done = 0;
   int32_t* brow = buf_row_negs.data();
   while (!stop.load(std::memory_order_relaxed)) {
     unsigned spins = 0;
@@ -986,7 +1100,7 @@ void vv_sampler::run_negs(bool also_frames) {
     while (it >= avail) {
       avail = walked.load(std::memory_order_acquire);
       if (it < avail) break;
-      if (published < it) { ring->hdr->done_negs.store(it, std::memory_order_release); if (also_frames) ring->hdr->done_frames.store(it, std::memory_order_release); published = it; }
+      if (published < it) { ev_tail.store(ev_done, std::memory_order_release); ring->hdr->done_negs.store(it, std::memory_order_release); if (also_frames) ring->hdr->done_frames.store(it, std::memory_order_release); published = it; }
       if (stop.load(std::memory_order_relaxed)) return;
       if (!tw) tw = __rdtsc();
       backoff(spins);
@@ -1004,9 +1118,10 @@ void vv_sampler::run_negs(bool also_frames) {
     const uint64_t e0 = (uint64_t)rec[2] | ((uint64_t)rec[3] << 32);
     const uint32_t nev = rec[1];
     for (uint32_t e = 0; e < nev; ++e) { const Event ev = events[(e0 + e) & ev_mask]; brow[ev.pos] = ev.row; }
-    if (nev) ev_tail.store(e0 + nev, std::memory_order_release);
+    if (nev) ev_done = e0 + nev;
     ++it;
     if (it - published >= 32 || it % B == 0) {
+      ev_tail.store(ev_done, std::memory_order_release);        // (with the item counter, not per item: the walk reads this line)
       ring->hdr->done_negs.store(it, std::memory_order_release);
       if (also_frames) ring->hdr->done_frames.store(it, std::memory_order_release);
       published = it;
@@ -1153,10 +1268,12 @@ int vv_sampler_create_neg(const vv_sampler_param* p_in, int32_t n_videos, const 
   }
   s->rec1.assign((size_t)s->rec_words, 0u);
   {
-    const int64_t per_item = (int64_t)C + Nn + 3ll * max_n + 32;
-    const int64_t block = std::max<int64_t>(16384, 4 * per_item);
+    const int64_t per_item = (int64_t)C + Nn + 3ll * max_n + 32 + 160;
+    int64_t want = 16384;
+    if (const char* e = getenv("VV_SAMPLER_BLOCK")) want = std::max<int64_t>(1024, atoll(e));      // (tuning: words per generated block)
+    const int64_t block = (std::max<int64_t>(want, 4 * per_item) + 15) / 16 * 16;
     if (block > (1ll << 28)) { delete s; return VV_ERR_ARG; }
-    s->rng.init((int)block, Nn > 0 ? p->negative_swap_percentage : 0, (uint32_t)p->rand_seed, s->wide);
+    s->rng.init((int)block, Nn > 0 ? p->negative_swap_percentage : 0, (uint32_t)p->rand_seed, s->wide, Nn > 0 ? p->max_buffer_size : 0);
   }
   if (!s->fast) s->slots.assign((size_t)p->batch_size * CN, Slot());
   const int mb = Nn > 0 ? p->max_buffer_size : 0;
@@ -1247,6 +1364,7 @@ int vv_sampler_prefetch_start(vv_sampler* s, int32_t depth, int32_t threads, con
   // staged pipeline
   s->ring_items = (int64_t)B * std::min<int64_t>(depth, 4);
   if (s->ring_items < 256) s->ring_items = 256;
+  if (const char* e = getenv("VV_SAMPLER_RING_ITEMS")) s->ring_items = std::max<int64_t>(64, atoll(e));      // (tuning: item records between the walk and the later stages)
   s->recs.assign((size_t)s->ring_items * s->rec_words, 0u);
   uint64_t cap = 1; while (cap < (uint64_t)s->ring_items * 32 + 4ull * s->max_n) cap <<= 1;
   s->events.assign(cap, vv_sampler::Event{0, 0}); s->ev_mask = cap - 1;
@@ -1255,14 +1373,31 @@ int vv_sampler_prefetch_start(vv_sampler* s, int32_t depth, int32_t threads, con
   s->wait_walk.store(0); s->wait_negs.store(0); s->wait_frames.store(0); s->tsc_start = __rdtsc();
   const bool three = threads >= 3;
   s->n_stage_threads = threads >= 4 ? 4 : (three ? 3 : 2);
-  cpu_set_t set; const bool pin = stage_cpu_set(&set);
+  cpu_set_t set, own[4]; int n_own = 0;
+  const bool pin = stage_cpu_set(&set, own, &n_own);
+  // VV_SAMPLER_PLACE="walk,stream,negs,frames": one CPU number per stage thread (-1 / missing: the common set) -- which stages share
+  // a core (SMT siblings share its L1 / L2: the walk reads what the stream thread writes) is a property of the host, measured, not guessed
+  cpu_set_t one[4]; bool has[4] = {false, false, false, false};
+  if (const char* e = getenv("VV_SAMPLER_PLACE")) {
+    int k = 0;
+    for (const char* q = e; *q && k < 4; ++k) {
+      const int c = atoi(q);
+      if (c >= 0 && c < CPU_SETSIZE) { CPU_ZERO(&one[k]); CPU_SET(c, &one[k]); has[k] = true; }
+      while (*q && *q != ',') ++q;
+      if (*q) ++q;
+    }
+  }
+  const bool spread = pin && n_own >= 4 && !(getenv("VV_SAMPLER_SPREAD") && atoi(getenv("VV_SAMPLER_SPREAD")) == 0);
+  const cpu_set_t sw = has[0] ? one[0] : (spread ? own[0] : set), ss = has[1] ? one[1] : (spread ? own[1] : set);
+  const cpu_set_t sn = has[2] ? one[2] : (spread ? own[2] : set), sf = has[3] ? one[3] : (spread ? own[3] : set);
+  const bool pw = pin || has[0], ps = pin || has[1], pn = pin || has[2], pf = pin || has[3];
   if (threads >= 4) {            // the fourth thread generates the rand() stream a block ahead of the walk (LibcRand::start_helper)
-    s->rng.pin_helper_like_caller(pin ? &set : nullptr);
+    s->rng.pin_helper_like_caller(ps ? &ss : nullptr);
     s->rng.start_helper();
   }
-  s->threads.emplace_back([s, set, pin]() { pin_self(pin ? &set : nullptr); s->run_walk(); });
-  s->threads.emplace_back([s, three, set, pin]() { pin_self(pin ? &set : nullptr); s->run_negs(!three); });
-  if (three) s->threads.emplace_back([s, set, pin]() { pin_self(pin ? &set : nullptr); s->run_frames(); });
+  s->threads.emplace_back([s, sw, pw]() { pin_self(pw ? &sw : nullptr); s->run_walk(); });
+  s->threads.emplace_back([s, three, sn, pn]() { pin_self(pn ? &sn : nullptr); s->run_negs(!three); });
+  if (three) s->threads.emplace_back([s, sf, pf]() { pin_self(pf ? &sf : nullptr); s->run_frames(); });
   return VV_OK;
 }
 
@@ -1296,6 +1431,7 @@ int64_t vv_sampler_stat(vv_sampler* s, int32_t which) {
     case 5: return (int64_t)s->wait_negs.load(std::memory_order_relaxed);     // ... the negative-slot stage
     case 6: return (int64_t)s->wait_frames.load(std::memory_order_relaxed);   // ... the frame stage
     case 7: return s->wide ? 1 : 0;              // 512-bit forms in use
+    case 8: return (int64_t)s->rng.wait_ticks(); // ticks the walk stage waited for the stream-generating thread's next block (read when the pipeline is quiet or approximately)
     default: return -1;
   }
 }
