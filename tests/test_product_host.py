@@ -234,6 +234,34 @@ def test_both_vector_widths_of_the_walk_and_the_slot_draw_are_the_oracle_stream(
     a.close()
 
 
+@pytest.mark.parametrize("width", ["avx2", "avx512"])
+def test_stream_blocks_of_a_dozen_items_and_a_stalling_consumer(oracle, monkeypatch, width):
+    """Four stage threads, the stream generated by its own thread in blocks that change hands with the walk: blocks of a dozen
+    items (VV_SAMPLER_BLOCK; far fewer than the 32 items after which the walk publishes its progress), a consumer that pauses so
+    that every stage runs into a full ring, a stop while everything is blocked -- the stream stays the oracle's."""
+    import time
+    monkeypatch.setenv("VV_SAMPLER_AVX512", "1" if width == "avx512" else "0")
+    monkeypatch.setenv("VV_SAMPLER_BLOCK", "1024")
+    ds = SyntheticVideos(seed=21, n_videos=150, lo=4, span=60)
+    kw = dict(batch_size=40, context_size=5, num_negative_samples=16, max_buffer_size=600, negative_swap_percentage=60)
+    a = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, **kw)
+    o = oracle.Sampler(ds.video_id, ds.n_shots, ds.row_base, **kw)
+    a.prefetch_start(depth=2, threads=4)
+    for k in range(50):
+        if k % 10 == 3:
+            time.sleep(0.05)
+        assert np.array_equal(a.next(), o.next()[0])
+    time.sleep(0.05)                     # ring full, every stage waiting: the stop must still get through
+    a.prefetch_stop()
+    a.close()
+    a = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, **kw)
+    o = oracle.Sampler(ds.video_id, ds.n_shots, ds.row_base, **kw)
+    a.prefetch_start(depth=4, threads=4)
+    for _ in range(30):
+        assert np.array_equal(a.next(), o.next()[0])
+    a.close()
+
+
 def _ring_consumer(name, consumer, world, n_batches, q):
     import videovector_amd as vv2
     r = vv2.BatchRing.attach(name, timeout_s=30.0)
