@@ -390,7 +390,8 @@ int vv_sampler_prefetch_stop(vv_sampler* s);
  * ticks since the pipeline started, 4 / 5 / 6 = ticks of them the walk / negative-slot / frame stage spent waiting,
  * 7 = the 512-bit forms of the walk and the slot draw are in use (0/1: the host has AVX-512 F/BW/DQ/VL/VBMI2 and
  * VV_SAMPLER_AVX512 is not 0; same indices either way), 8 = ticks the walk stage waited for the stream-generating
- * thread (four-thread pipeline).  -1 = unknown. */
+ * thread (four-thread pipeline), 9 = cores held for the stage threads (4: one each, claimed against other samplers
+ * of the host through /dev/shm/vv_sampler_cpu_<n> locks; 0: the threads share the caller's group of CPUs).  -1 = unknown. */
 int64_t vv_sampler_stat(vv_sampler* s, int32_t which);
 
 /* A reader's view of a sampler's batch ring.  vv_sampler_ring: the producer process's own handle (owned by the

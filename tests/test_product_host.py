@@ -262,6 +262,28 @@ def test_stream_blocks_of_a_dozen_items_and_a_stalling_consumer(oracle, monkeypa
     a.close()
 
 
+def test_two_samplers_never_pin_their_stage_threads_to_the_same_cores(oracle):
+    """Each stage thread of a pipeline gets a core of its own when the caller's group of eight has four to spare -- claimed through
+    a lock per CPU, so that a second sampler (another rank of an unbound job, a second data layer) takes OTHER cores or, when there
+    are none left, shares the group as before; the claim ends with the pipeline.  Streams unaffected."""
+    ds = SyntheticVideos(seed=31, n_videos=100, lo=6, span=30)
+    kw = dict(batch_size=32, context_size=5, num_negative_samples=8, max_buffer_size=300, negative_swap_percentage=50)
+    a = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, **kw)
+    b = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, **kw)
+    oa = oracle.Sampler(ds.video_id, ds.n_shots, ds.row_base, **kw)
+    ob = oracle.Sampler(ds.video_id, ds.n_shots, ds.row_base, **kw)
+    a.prefetch_start(depth=2, threads=4)
+    b.prefetch_start(depth=2, threads=4)
+    held = sorted(os.readlink("/proc/self/fd/" + f) for f in os.listdir("/proc/self/fd")
+                  if os.path.exists("/proc/self/fd/" + f) and "vv_sampler_cpu_" in os.readlink("/proc/self/fd/" + f))
+    assert a.stat(9) in (0, 4) and b.stat(9) in (0, 4)
+    assert len(held) == a.stat(9) + b.stat(9) and len(set(held)) == len(held)       # distinct CPUs
+    for _ in range(6):
+        assert np.array_equal(a.next(), oa.next()[0]) and np.array_equal(b.next(), ob.next()[0])
+    a.close(); b.close()
+    assert not [f for f in os.listdir("/proc/self/fd") if os.path.exists("/proc/self/fd/" + f) and "vv_sampler_cpu_" in os.readlink("/proc/self/fd/" + f)]
+
+
 def _ring_consumer(name, consumer, world, n_batches, q):
     import videovector_amd as vv2
     r = vv2.BatchRing.attach(name, timeout_s=30.0)

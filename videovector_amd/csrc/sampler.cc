@@ -38,6 +38,7 @@
 #include <fcntl.h>
 #include <immintrin.h>
 #include <sched.h>
+#include <sys/file.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -330,7 +331,7 @@ class FastMod {
 // aligned group of 8 CPUs (one CCD = one L3 on those hosts) plus the SMT siblings the kernel reports for them -- a set,
 // not one CPU each, so that a runtime helper thread landing on one of them cannot hold a stage up for a time slice.
 // VV_SAMPLER_CPUS="a,b,c,..." overrides the set, VV_SAMPLER_PIN=0 disables.
-bool stage_cpu_set(cpu_set_t* out, cpu_set_t* per_stage = nullptr, int* n_per_stage = nullptr) {
+bool stage_cpu_set(cpu_set_t* out, cpu_set_t* per_stage = nullptr, int* n_per_stage = nullptr, int* first_cpu = nullptr) {
   CPU_ZERO(out);
   if (n_per_stage) *n_per_stage = 0;
   const char* off = getenv("VV_SAMPLER_PIN");
@@ -350,8 +351,8 @@ bool stage_cpu_set(cpu_set_t* out, cpu_set_t* per_stage = nullptr, int* n_per_st
     if (!CPU_ISSET(c, &allowed)) continue;
     CPU_SET(c, out); ++n;
     // a core of its own for each stage thread (the CPU and its SMT siblings), not the caller's: see the note at the function's end
-    cpu_set_t* mine = (per_stage && n_per_stage && c != cur && *n_per_stage < 4) ? &per_stage[*n_per_stage] : nullptr;
-    if (mine) { CPU_ZERO(mine); CPU_SET(c, mine); }
+    cpu_set_t* mine = (per_stage && n_per_stage && c != cur && *n_per_stage < 8) ? &per_stage[*n_per_stage] : nullptr;
+    if (mine) { CPU_ZERO(mine); CPU_SET(c, mine); if (first_cpu) first_cpu[*n_per_stage] = c; }
     bool with_caller = false;
     char path[128];                                    // SMT siblings of c
     snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
@@ -375,8 +376,28 @@ bool stage_cpu_set(cpu_set_t* out, cpu_set_t* per_stage = nullptr, int* n_per_st
   // Round 5: inside the common set the scheduler kept moving the stage threads (and now and then put two on the siblings of one
   // core): ten samplers of the 8192-item batch spread over 0.83 .. 1.34 ms; with the four threads on four cores of their own
   // 0.759 .. 0.768 (profiles/r05_sampler_place.txt; siblings sharing a core were slower in every pairing tried).  So when the
-  // group has four cores beside the caller's, each stage thread gets one (per_stage); otherwise the common set as before.
+  // group has four cores beside the caller's THAT NO OTHER SAMPLER HOLDS, each stage thread gets one (per_stage; claimed by the caller
+  // through claim_cores below); otherwise the common set as before.
   return n >= 4;                                       // too few neighbours: leave placement to the scheduler
+}
+// Two samplers whose callers sit in the same group of eight (two ranks of an unbound job, two samplers of one process) must not pin their
+// stage threads to the same cores -- a spinning stage thread per core is the whole point.  A core is claimed by holding an exclusive
+// flock on /dev/shm/vv_sampler_cpu_<n> for as long as the pipeline runs (the lock dies with the descriptor, i.e. with the process).
+// -> number of cores claimed (their sets moved to the front of per_stage), descriptors in fds.
+int claim_cores(cpu_set_t* per_stage, const int* first_cpu, int n, int want, int* fds) {
+  int got = 0;
+  for (int i = 0; i < n && got < want; ++i) {
+    char path[64];
+    snprintf(path, sizeof(path), "/dev/shm/vv_sampler_cpu_%d", first_cpu[i]);
+    const int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+    if (fd < 0) continue;
+    if (flock(fd, LOCK_EX | LOCK_NB) != 0) { close(fd); continue; }
+    fds[got] = fd;
+    per_stage[got] = per_stage[i];
+    ++got;
+  }
+  if (got < want) { for (int i = 0; i < got; ++i) close(fds[i]); return 0; }
+  return got;
 }
 void pin_self(const cpu_set_t* set) {
   if (set) (void)sched_setaffinity(0, sizeof(*set), set);
@@ -549,6 +570,7 @@ struct vv_sampler {
   // ---- prefetch pipeline
   vv_batch_ring* ring = nullptr;
   std::vector<std::thread> threads;
+  int core_fds[4] = {-1, -1, -1, -1}, n_core_fds = 0;     // the stage threads' cores, held while the pipeline runs (claim_cores)
   std::atomic<int> stop{0};
   int n_stage_threads = 0;
   std::vector<uint32_t> recs; int64_t ring_items = 0;
@@ -1373,8 +1395,12 @@ int vv_sampler_prefetch_start(vv_sampler* s, int32_t depth, int32_t threads, con
   s->wait_walk.store(0); s->wait_negs.store(0); s->wait_frames.store(0); s->tsc_start = __rdtsc();
   const bool three = threads >= 3;
   s->n_stage_threads = threads >= 4 ? 4 : (three ? 3 : 2);
-  cpu_set_t set, own[4]; int n_own = 0;
-  const bool pin = stage_cpu_set(&set, own, &n_own);
+  cpu_set_t set, own[8]; int n_own = 0, first_cpu[8];
+  const bool pin = stage_cpu_set(&set, own, &n_own, first_cpu);
+  if (pin && n_own >= 4 && !(getenv("VV_SAMPLER_SPREAD") && atoi(getenv("VV_SAMPLER_SPREAD")) == 0)) {
+    n_own = claim_cores(own, first_cpu, n_own, 4, s->core_fds);
+    s->n_core_fds = n_own;
+  } else n_own = 0;
   // VV_SAMPLER_PLACE="walk,stream,negs,frames": one CPU number per stage thread (-1 / missing: the common set) -- which stages share
   // a core (SMT siblings share its L1 / L2: the walk reads what the stream thread writes) is a property of the host, measured, not guessed
   cpu_set_t one[4]; bool has[4] = {false, false, false, false};
@@ -1387,7 +1413,7 @@ int vv_sampler_prefetch_start(vv_sampler* s, int32_t depth, int32_t threads, con
       if (*q) ++q;
     }
   }
-  const bool spread = pin && n_own >= 4 && !(getenv("VV_SAMPLER_SPREAD") && atoi(getenv("VV_SAMPLER_SPREAD")) == 0);
+  const bool spread = n_own >= 4;
   const cpu_set_t sw = has[0] ? one[0] : (spread ? own[0] : set), ss = has[1] ? one[1] : (spread ? own[1] : set);
   const cpu_set_t sn = has[2] ? one[2] : (spread ? own[2] : set), sf = has[3] ? one[3] : (spread ? own[3] : set);
   const bool pw = pin || has[0], ps = pin || has[1], pn = pin || has[2], pf = pin || has[3];
@@ -1408,6 +1434,8 @@ int vv_sampler_prefetch_stop(vv_sampler* s) {
   for (auto& t : s->threads) if (t.joinable()) t.join();
   s->threads.clear();
   s->rng.stop_helper();
+  for (int i = 0; i < s->n_core_fds; ++i) close(s->core_fds[i]);
+  s->n_core_fds = 0;
   ring_free(s->ring);
   s->ring = nullptr;
   s->n_stage_threads = 0;
@@ -1431,6 +1459,7 @@ int64_t vv_sampler_stat(vv_sampler* s, int32_t which) {
     case 5: return (int64_t)s->wait_negs.load(std::memory_order_relaxed);     // ... the negative-slot stage
     case 6: return (int64_t)s->wait_frames.load(std::memory_order_relaxed);   // ... the frame stage
     case 7: return s->wide ? 1 : 0;              // 512-bit forms in use
+    case 9: return s->n_core_fds;                // cores claimed for the stage threads (4 = one each; 0 = the common set)
     case 8: return (int64_t)s->rng.wait_ticks(); // ticks the walk stage waited for the stream-generating thread's next block (read when the pipeline is quiet or approximately)
     default: return -1;
   }
