@@ -490,7 +490,9 @@ int vv_params_set(vv_ctx* c, int32_t D, const float* W, const float* b, const fl
     HIPCHK(hipMalloc(&c->grads_own, (nW + D) * 4));
     HIPCHK(hipMemset(c->grads_own, 0, (nW + D) * 4));
     c->grads = c->grads_own;
+#ifdef VV_LAB
     if (getenv("VV_DEBUG_PTRS")) fprintf(stderr, "[vv ptrs] W %p hW %p Wh %p grads %p (D %d F %d)\n", (void*)c->W, (void*)c->hW, (void*)c->Wh, (void*)c->grads_own, D, c->F);
+#endif
     free_batch(c);
   }
   HIPCHK(hipMemcpy(c->W, W, nW * 4, hipMemcpyHostToDevice));
