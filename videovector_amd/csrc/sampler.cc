@@ -599,6 +599,9 @@ uint64_t g_wp[8];
 #ifdef VV_WALK_LAB
 int g_lab = 0;
 #endif
+#ifdef VV_SAMPLER_LAB
+static int g_plab = 0;       // (lab build only: parts of the pipeline's hand-over switched off, results wrong by design)
+#endif
 void vv_sampler::select_item(uint32_t* rec) {
   const int C = p.context_size, Nn = p.num_negative_samples, V = (int)video_id.size();
   int v, n;
@@ -617,8 +620,13 @@ void vv_sampler::select_item(uint32_t* rec) {
   rec[0] = (uint32_t)v;
   rng.prefetch_ahead(a_total + Nn + 2 * n);
   const uint32_t* hv = rng.peek();
+#ifdef VV_SAMPLER_LAB
+  if (!(g_plab & 8))
+#endif
+  {
   memcpy(rec + 4, hv, (size_t)CA * 4);
   memcpy(rec + 4 + CA, hv + a_total, (size_t)Nn * 4);
+  }
   cur_v = v; cur_n = n; cur_a_total = a_total;
 }
 
@@ -1104,6 +1112,9 @@ void vv_sampler::run_walk() {
     if (tw) wait_walk.store(wait_walk.load(std::memory_order_relaxed) + (__rdtsc() - tw), std::memory_order_relaxed);
     uint32_t* rec = recs.data() + (size_t)(it % ring_items) * rec_words;
     select_item(rec);
+#ifdef VV_SAMPLER_LAB
+    if (g_plab & 16) swap<false>(rec, buf_row.data(), nullptr, 0, nullptr); else
+#endif
     swap<true>(rec, buf_row.data(), events.data(), ev_mask, &ev_head);
     ++it;
     if (it - published >= chunk || it % B == 0) { walked.store(it, std::memory_order_release); published = it; }
@@ -1135,10 +1146,20 @@ void vv_sampler::run_negs(bool also_frames) {
     if (tw) wait_negs.store(wait_negs.load(std::memory_order_relaxed) + (__rdtsc() - tw), std::memory_order_relaxed);
     const uint32_t* rec = recs.data() + (size_t)(it % ring_items) * rec_words;
     int32_t* out = ring->idx_of(k) + (size_t)(it % B) * CN;
+#ifdef VV_SAMPLER_LAB
+    static uint32_t fake[512];
+    negs((g_plab & 2) ? fake : rec, out + C, brow);
+#else
     negs(rec, out + C, brow);
+#endif
     if (also_frames) frames_item(rec, out, ring->label_of(k) + (it % B));
     const uint64_t e0 = (uint64_t)rec[2] | ((uint64_t)rec[3] << 32);
+#ifdef VV_SAMPLER_LAB
+    const uint32_t nev = (g_plab & 1) ? 0 : rec[1];
+    if (g_plab & 1) ev_done = e0 + rec[1];
+#else
     const uint32_t nev = rec[1];
+#endif
     for (uint32_t e = 0; e < nev; ++e) { const Event ev = events[(e0 + e) & ev_mask]; brow[ev.pos] = ev.row; }
     if (nev) ev_done = e0 + nev;
     ++it;
@@ -1173,6 +1194,9 @@ void vv_sampler::run_frames() {
     }
     if (tw) wait_frames.store(wait_frames.load(std::memory_order_relaxed) + (__rdtsc() - tw), std::memory_order_relaxed);
     const uint32_t* rec = recs.data() + (size_t)(it % ring_items) * rec_words;
+#ifdef VV_SAMPLER_LAB
+    if (!(g_plab & 4))
+#endif
     frames_item(rec, ring->idx_of(k) + (size_t)(it % B) * CN, ring->label_of(k) + (it % B));
     ++it;
     if (it - published >= 32 || it % B == 0) { ring->hdr->done_frames.store(it, std::memory_order_release); published = it; }
@@ -1377,6 +1401,9 @@ int vv_sampler_prefetch_start(vv_sampler* s, int32_t depth, int32_t threads, con
   s->ring = ring_create(shm_name, depth, B, CN, consumers, !s->fast);
   if (!s->ring) return VV_ERR_STATE;
   s->stop.store(0);
+#ifdef VV_SAMPLER_LAB
+  g_plab = getenv("VV_SAMPLER_LAB") ? atoi(getenv("VV_SAMPLER_LAB")) : 0;
+#endif
   if (!s->fast || threads == 1) {
     s->n_stage_threads = 1;
     cpu_set_t set; const bool pin = stage_cpu_set(&set);
