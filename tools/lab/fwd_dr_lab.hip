@@ -35,13 +35,13 @@ __global__ void k_fill_w(uint16_t* w, uint16_t* wq, int D, int Fp, int nk, uint6
 }
 
 // r05: the product forward kernel with time stamps (ABL bit 9, kernels_gemm_ph.hip): 192-row tiles, with / without the sibling lead
-template <int ABL, int LEAD>
+template <int ABL, int LEAD, int MRG = 0>
 static void launch_ph_ts(const FwdArgs& a, hipStream_t s) {
   constexpr int LDS = LEAD ? 10 * PH_SLOT : PH_LDS_BYTES;
-  static bool once = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<F16, 0, true, 3, ABL, false, 0, LEAD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS), true);
+  static bool once = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<F16, 0, true, 3, ABL, false, 0, LEAD, MRG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS), true);
   (void)once;
   const dim3 grid(((a.R + 191) / 192) * 2), block(GEMM_THREADS);
-  hipLaunchKernelGGL((k_fwd_gemm_ph<F16, 0, true, 3, ABL, false, 0, LEAD>), grid, block, LDS, s, a);
+  hipLaunchKernelGGL((k_fwd_gemm_ph<F16, 0, true, 3, ABL, false, 0, LEAD, MRG>), grid, block, LDS, s, a);
 }
 
 template <int MT, int P, int ABL, int TD = 0, int OPT = 0>
@@ -112,7 +112,9 @@ int main(int argc, char** argv) {
                            {"dr12_spread_onlyA", 43}, {"dr12_spread_full", 44}, {"dr12_spread_noRD", 45}, {"dr12_spread_run1k_onlyA", 46},
                            {"dr12_even_onlyA", 47}, {"dr12_even_onlyAB", 48}, {"dr12_split_onlyA", 49}, {"dr12_split_onlyAB", 50},
                            {"ph_ts_lead", 60}, {"ph_ts_plain", 61}, {"ph_ts_lead_hotA", 62}, {"ph_ts_lead_nostream", 63}, {"ph_ts_lead_nomm", 64},
-                           {"ph_ts_lead_nostore", 65}, {"ph_plain", 66}, {"ph_sf_plain", 67}, {"ph_sf_lead", 68}, {"ph_lead2", 69}};
+                           {"ph_ts_lead_nostore", 65}, {"ph_plain", 66}, {"ph_sf_plain", 67}, {"ph_sf_lead", 68}, {"ph_lead2", 69},
+                           {"marks_lead_4ph", 70}, {"marks_lead_merged", 71}, {"marks_plain_4ph", 72}, {"marks_plain_merged", 73},
+                           {"marks_lead_4ph_hotA", 74}, {"marks_lead_merged_hotA", 75}, {"marks_lead_4ph_nostream", 76}, {"marks_lead_merged_nostream", 77}};
   auto run = [&](int kind, int set, float* Hout) {
     FwdArgs a = base; a.rows = rows + (size_t)set * Rp; a.H = Hout;
     if (kind == 0) { a.Wh = Wh; launch_fwd_gemm_ph(0, a, st); return; }
@@ -129,6 +131,14 @@ int main(int argc, char** argv) {
         case 67: launch_ph_ts<1024, 0>(a, st); break;       // r05: the phase's LDS-DMA in front of its fragment reads
         case 68: launch_ph_ts<1024, 1>(a, st); break;
         case 69: launch_ph_ts<0, 1>(a, st); break;
+        case 70: launch_ph_ts<2048, 1, 0>(a, st); break;     // r05: the kernel's four marks only; four phases per K-tile ...
+        case 71: launch_ph_ts<2048, 1, 1>(a, st); break;     // ... and two merged ones
+        case 72: launch_ph_ts<2048, 0, 0>(a, st); break;
+        case 73: launch_ph_ts<2048, 0, 1>(a, st); break;
+        case 74: launch_ph_ts<2048 + 8, 1, 0>(a, st); break; // rows = the L2-hot zero row
+        case 75: launch_ph_ts<2048 + 8, 1, 1>(a, st); break;
+        case 76: launch_ph_ts<2048 + 1, 1, 0>(a, st); break; // no LDS-DMA stream in the loop
+        case 77: launch_ph_ts<2048 + 1, 1, 1>(a, st); break;
       }
       return;
     }
@@ -212,7 +222,7 @@ int main(int argc, char** argv) {
       CHK(hipEventRecord(e1, st)); CHK(hipEventSynchronize(e1));
       float ms = 0; CHK(hipEventElapsedTime(&ms, e0, e1));
       printf("round %d  %-16s %8.2f us\n", r, v.name, ms * 1000.f / iters);
-      if (v.kind >= 60 && v.kind <= 65) {
+      if ((v.kind >= 60 && v.kind <= 65) || (v.kind >= 70 && v.kind <= 77)) {
         // the stamps of the LAST launch: mean over the workgroups, waves 0-3 (the leading group) and 4-7 apart
         std::vector<uint32_t> hb((size_t)ts_wg * 8 * 12);
         CHK(hipMemcpy(hb.data(), ts_buf, hb.size() * 4, hipMemcpyDeviceToHost));

@@ -137,6 +137,7 @@ static int create_init(vv_ctx* c) {
   // product options: initial values from the environment, per context (vv_set_option changes them afterwards)
   if (const char* v = opt_env("VV_WGRAD_TR")) c->ko.wgrad_tr = atoi(v) != 0;
   if (const char* v = opt_env("VV_FWD_LEAD")) c->ko.fwd_lead = atoi(v);
+  if (const char* v = opt_env("VV_FWD_MERGE")) c->ko.fwd_merge = atoi(v);
   if (const char* v = opt_env("VV_SCORE_STREAM")) c->ko.score_stream = atoi(v);
   if (const char* v = opt_env("VV_SEG_BWD")) c->seg_bwd = atoi(v) != 0;
   if (const char* v = opt_env("VV_DEDUP")) c->dedup = atoi(v) != 0;
@@ -288,6 +289,7 @@ int vv_set_option(vv_ctx* c, const char* name, double value) {
   if (n == "drop_dedup") { c->drop_dedup = iv != 0; return VV_OK; }
   if (n == "fuse_update") { c->fuse_update = iv != 0; return VV_OK; }
   if (n == "fwd_lead") { c->ko.fwd_lead = iv; return VV_OK; }
+  if (n == "fwd_merge") { c->ko.fwd_merge = iv; return VV_OK; }
   if (n == "wgrad_tr") { c->ko.wgrad_tr = iv != 0; return VV_OK; }
   if (n == "score_stream") { c->ko.score_stream = iv; return VV_OK; }
   if (n == "comm_gate") { c->comm_gate = iv != 0; return VV_OK; }
@@ -314,6 +316,7 @@ int vv_get_option(vv_ctx* c, const char* name, double* value) {
   else if (n == "drop_dedup") *value = c->drop_dedup;
   else if (n == "fuse_update") *value = c->fuse_update;
   else if (n == "fwd_lead") *value = c->ko.fwd_lead;
+  else if (n == "fwd_merge") *value = c->ko.fwd_merge;
   else if (n == "wgrad_tr") *value = c->ko.wgrad_tr;
   else if (n == "score_stream") *value = c->ko.score_stream;
   else if (n == "comm_gate") *value = c->comm_gate;

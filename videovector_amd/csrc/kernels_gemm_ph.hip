@@ -105,12 +105,20 @@ constexpr int PH_LDS_BYTES = 8 * PH_SLOT;      // ring of 8 slots = 128 KiB
 // 160 KiB of LDS), and the loop is unrolled by four K-tiles so that every ring position is a constant.
 // DROP: 0 no dropout, 1 the counter-based mask, 2 an explicit mask (FwdArgs::mask) -- separate instantiations: with the choice made per
 // element at run time the epilogue was 700 branches and 50 KB of code, and the dense-size kernel took 17 us longer for it
-template <typename T, int DROP, bool VEC, int MQ, int ABL = 0, bool GATE = false, int DEAD = 0, int LEAD = 0>
+// MRG (0 / 1; round 5): TWO phases per barrier pair.  The stamps (profiles/r05_fwd_stamps.txt) put a phase at 192 clocks of matrix pipe
+// plus ~45 of barrier release plus what the partner's load segment overhangs: 512 intervals of ~250.  The fragments of a K-tile already
+// live in registers together (A half 24 + B_lo 16 + B_hi 16 VGPRs), so the four phases pair up without a register more:
+//   M0: read A_lo, B_lo, B_hi | stream steps 0, 1 | barrier | A_lo x B_lo, A_lo x B_hi (24 MFMAs) | barrier
+//   M1: read A_hi             | stream steps 2, 3 | barrier | A_hi x B_hi, A_hi x B_lo (24 MFMAs) | barrier
+// 256 intervals of ~430.  The stream keeps its order and its six half-tiles of distance; the counted waits move: before M1 everything
+// but the four youngest half-tiles (A_hi(t) is the fifth youngest), before M0 everything but the THREE youngest (B_hi(t + 1), issued in
+// M0(t), is the fourth youngest: the one half-tile whose flight is half a K-tile instead of a whole one -- it is a W tile, an L2 hit).
+template <typename T, int DROP, bool VEC, int MQ, int ABL = 0, bool GATE = false, int DEAD = 0, int LEAD = 0, int MRG = 0>
 __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int HROWS = 32 * MQ;               // rows of the lower A half-tile (upper: HROWS - 16 DEAD)
   constexpr int BMT = 2 * HROWS - 16 * DEAD;   // rows of the output tile
-  if (ABL & 512) asm volatile("s_memtime s[84:85]\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b32 s101, s84" ::: "s84", "s85", "s101");   // (lab: time stamps, below)
+  if (ABL & (512 | 2048)) asm volatile("s_memtime s[84:85]\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b32 s101, s84" ::: "s84", "s85", "s101");   // (lab: time stamps, below)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -218,7 +226,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
   } else {
     issue(0, 0, 0); issue(0, 1, 1); issue(0, 2, 2); issue(0, 3, 3); issue(1, 0, 4); issue(1, 1, 5);
   }
-  PH_WAITQ();                                  // half-tiles 0, 1 (A_lo, B_lo of K-tile 0) have landed
+  if (MRG) PH_WAIT(6);                         // MRG: A_lo, B_lo AND B_hi of K-tile 0 (all but the three youngest half-tiles)
+  else PH_WAITQ();                             // half-tiles 0, 1 (A_lo, B_lo of K-tile 0) have landed
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one segment behind
   if (wm == 1) __builtin_amdgcn_s_setprio(1);  // the younger half loses VALU arbitration otherwise
@@ -273,6 +282,32 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
     else { PH_TS("s[86:87]") if (wait) PH_WAIT(0); }                                                    \
     PH_TS("s[88:89]")                                                                              \
   }
+  // MRG: the two MFMA blocks of a merged phase between ONE pair of barriers
+#define PH_MFMA2(mhA, nhA, bfrA, mhB, nhB, bfrB)                                                     \
+  __builtin_amdgcn_s_barrier();                                                                      \
+  __builtin_amdgcn_sched_barrier(0);                                                                 \
+  if (!abl_mm) {                                                                                     \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int mi = 0; mi < MQ; ++mi) \
+      if (!(DEAD && (mhA) == 1 && mi == MQ - 1 && dead_hi))                                          \
+      _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                               \
+        acc[mhA][mi][nhA][ni] = T::mfma(bfrA[ni][kk], af[mi][kk], acc[mhA][mi][nhA][ni]);            \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int mi = 0; mi < MQ; ++mi) \
+      if (!(DEAD && (mhB) == 1 && mi == MQ - 1 && dead_hi))                                          \
+      _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                               \
+        acc[mhB][mi][nhB][ni] = T::mfma(bfrB[ni][kk], af[mi][kk], acc[mhB][mi][nhB][ni]);            \
+  }                                                                                                  \
+  __builtin_amdgcn_sched_barrier(0);                                                                 \
+  __builtin_amdgcn_s_barrier();                                                                      \
+  __builtin_amdgcn_sched_barrier(0);
+  // stream step with the merged schedule's wait in front of M0 (all but the three youngest half-tiles)
+#define PH_STREAM6(tpar, t, p)                                                                       \
+  {                                                                                                  \
+    const int h = 4 * (t) + (p) + 6;                                                                 \
+    constexpr int q_ = ((p) + 2) & 3;                                                                \
+    constexpr int slot_ = (LEAD && q_ == 0) ? PH_RING(J + 3) : 4 * (((tpar) + (((p) + 6) >> 2)) & 1) + q_; \
+    if ((!CHK || h < H) && !abl_st) { issue(h >> 2, q_, slot_); PH_WAIT(6); }                        \
+    else { PH_WAIT(0); }                                                                             \
+  }
   // ABL: timing studies only (VV_ABLATE, results wrong): 1 no LDS-DMA stream in the loop, 2 no MFMA, 4 no fragment
   // reads, 8 every gathered row is the (L2-hot) zero row
   constexpr bool abl_st = ABL & 1, abl_mm = ABL & 2, abl_rd = ABL & 4;
@@ -289,9 +324,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
   //   s[88:89] b (counted wait passed)   s[90:91] c (after the barrier behind the load segment)   s[92:93] d (last MFMA issued)
   //   s94 previous c   s95..s99 sums: load, vmwait, bar1, mfma, bar2   s100 scratch   s101 kernel start   s83 loop start   s[78:79] real time)
   constexpr bool TS = (ABL & 512) != 0;
+  constexpr bool TSL = (ABL & 2048) != 0;      // (lab: only the kernel's four marks -- start, loop start, loop end, last store -- and the real time: no per-phase stamps)
 #define PH_TS_CLOB "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s100", "s101", "scc"
 #define PH_TS(pair) if (TS) { asm volatile("s_memtime " pair ::: PH_TS_CLOB); __builtin_amdgcn_sched_barrier(0); }
-  if (TS) {
+  if (TS || TSL) {
     asm volatile("s_memrealtime s[78:79]\n\ts_memtime s[84:85]\n\ts_waitcnt lgkmcnt(0)\n\t"
                  "s_mov_b32 s83, s84\n\ts_mov_b32 s86, s84\n\ts_mov_b32 s88, s84\n\ts_mov_b32 s90, s84\n\ts_mov_b32 s92, s84\n\ts_mov_b32 s94, s84\n\t"
                  "s_mov_b32 s95, 0\n\ts_mov_b32 s96, 0\n\ts_mov_b32 s97, 0\n\ts_mov_b32 s98, 0\n\ts_mov_b32 s99, 0" ::: PH_TS_CLOB);
@@ -316,6 +352,19 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
       PH_STREAM(PAR, t, 1, false) PH_LOAD_B(b1, 4 * PAR + 2) PH_WAITSF(1) PH_MFMA(0, 1, b1)
 #undef PH_WAITSF
       PH_STREAM(PAR, t, 2, false) PH_LOAD_A(4 * PAR + 3) PH_MFMA(1, 1, b1)
+    } else if constexpr (MRG != 0) {
+      PH_LOAD_A(4 * PAR + 0) PH_LOAD_B(b0, 4 * PAR + 1) PH_LOAD_B(b1, 4 * PAR + 2)
+      PH_STREAM(PAR, t, 0, false) PH_STREAM(PAR, t, 1, true)
+      PH_MFMA2(0, 0, b0, 0, 1, b1)
+      PH_LOAD_A(4 * PAR + 3) PH_STREAM(PAR, t, 2, false)
+      if (GATE && PAR == 0 && t + 2 == gate_at) {                        // B_lo(t + 2) opens a chunk
+        gate_wait(g_next);
+        if (++g_next >= a.gate_n) gated = false;
+        gate_at = gated ? a.gate_kt[g_next] : -1;
+      }
+      PH_STREAM6(PAR, t, 3)
+      PH_MFMA2(1, 1, b1, 1, 0, b0)
+      return;
     } else {
     PH_LOAD_A(4 * PAR + 0) PH_LOAD_B(b0, 4 * PAR + 1) PH_STREAM(PAR, t, 0, true) PH_MFMA(0, 0, b0)
     PH_LOAD_B(b1, 4 * PAR + 2) PH_STREAM(PAR, t, 1, true) PH_MFMA(0, 1, b1)
@@ -344,11 +393,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
     ktile(t, I0{}, I0{}, std::true_type{}); ktile(t + 1, I1{}, I1{}, std::true_type{});
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();   // waves 0-3 catch the extra barrier of waves 4-7
-  if (TS) asm volatile("s_memtime s[80:81]\n\ts_waitcnt lgkmcnt(0)" ::: PH_TS_CLOB);      // s80: end of the K loop
+  if (TS || TSL) asm volatile("s_memtime s[80:81]\n\ts_waitcnt lgkmcnt(0)" ::: PH_TS_CLOB);      // s80: end of the K loop
 #undef PH_LOAD_A
 #undef PH_LOAD_B
 #undef PH_MFMA
+#undef PH_MFMA2
 #undef PH_STREAM
+#undef PH_STREAM6
 #undef PH_WAITQ
 #undef PH_RING
 
@@ -429,7 +480,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
             for (int j = 0; j < 4; ++j) if (n + j < a.D) dst[j] = v[j];
         }
     }
-  if (TS) {
+  if (TS || TSL) {
     uint32_t o_[12];
     asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime s[84:85]\n\ts_memrealtime s[86:87]\n\ts_waitcnt lgkmcnt(0)\n\t"
                  "s_mov_b32 %0, s95\n\ts_mov_b32 %1, s96\n\ts_mov_b32 %2, s97\n\ts_mov_b32 %3, s98\n\ts_mov_b32 %4, s99\n\t"
@@ -1103,8 +1154,15 @@ static void launch_fwd_ph_q(const FwdArgs& a, hipStream_t s, long tiles_est) {
     // the sibling lead: 78.6-79.7 against 81.7-82.9 us at the benchmark's de-duplicated size (192-row tiles, one round), 215
     // against 218 us for 192-row tiles in three rounds.  Not for 256-row tiles: that instantiation has no registers left for
     // it (256 + 48 bytes of scratch: dense 229 against 183 us, cfg 5 560 against 470 us)
-    if (ko().fwd_lead && Dp / BN > 1 && !a.gate) {        // (the gated kernel keeps its static LDS word: no room beside ten slots)        // (the gated kernel keeps its static LDS word: no room beside ten slots)
+    if (ko().fwd_lead && Dp / BN > 1 && !a.gate) {        // (the gated kernel keeps its static LDS word: no room beside ten slots)
       constexpr int LDS10 = 10 * PH_SLOT;
+      if (ko().fwd_merge) {
+        static bool once_m = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, false, DEAD, 1, 1>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS10), true);
+        (void)once_m;
+        VV_LAUNCH((k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, false, DEAD, 1, 1>), grid, block, LDS10, s, a);
+        return;
+      }
       static bool once_l = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, false, DEAD, 1>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS10), true);
       (void)once_l;
@@ -1118,6 +1176,15 @@ static void launch_fwd_ph_q(const FwdArgs& a, hipStream_t s, long tiles_est) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, PH_LDS_BYTES), true);
       (void)once_g;
       VV_LAUNCH((k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, true, DEAD>), grid, block, PH_LDS_BYTES, s, a);
+      return;
+    }
+  }
+  if constexpr (!DROP && VEC && DEAD == 0) {
+    if (ko().fwd_merge) {
+      static bool once_m0 = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, false, DEAD, 0, 1>,
+                             hipFuncAttributeMaxDynamicSharedMemorySize, PH_LDS_BYTES), true);
+      (void)once_m0;
+      VV_LAUNCH((k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, false, DEAD, 0, 1>), grid, block, PH_LDS_BYTES, s, a);
       return;
     }
   }

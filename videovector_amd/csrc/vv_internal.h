@@ -360,6 +360,7 @@ constexpr int WMAX_SLOTS = 2048;      // slots of one per-block-maxima buffer (k
 // instantiations are compiled only there.
 struct KernelOpts {
   int fwd_lead = 1;        // "fwd_lead" / VV_FWD_LEAD: the forward GEMM's sibling lead (kernels_gemm_ph.hip)
+  int fwd_merge = 0;       // "fwd_merge" / VV_FWD_MERGE: the forward GEMM with two phases per barrier pair (k_fwd_gemm_ph, MRG)
   int wgrad_tr = 1;        // "wgrad_tr" / VV_WGRAD_TR: transposed LDS reads in the weight-gradient GEMM (0: the round-1 kernel)
   int score_stream = 0;    // "score_stream" / VV_SCORE_STREAM: the one-sweep score kernel for every shape
   int gemm_variant = 5;    // (lab) VV_GEMM_VARIANT: 5 = the phase-staggered kernels; 0 = the round-1 kernels; 6 / 7 / 8 mixtures
