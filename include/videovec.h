@@ -64,6 +64,7 @@ int vv_set_dedup(vv_ctx* ctx, int on);
  *   "drop_dedup" (VV_DROP_DEDUP, 1)  dropout on the de-duplicated path where the kernels carry per-instance masks (D = 512); 0: dense
  *   "fuse_update" (VV_FUSE_UPDATE, 1) reduction of the split-K partials and the solver update in one launch (0: two launches)
  *   "fwd_lead" (VV_FWD_LEAD, 1)      the forward GEMM's sibling lead
+ *   "fwd_merge" (VV_FWD_MERGE, 0)    the forward GEMM with two phases per barrier pair (bit-identical results; measured not faster)
  *   "wgrad_tr" (VV_WGRAD_TR, 1)      transposed LDS reads in the weight-gradient GEMM (0: the first-round kernel)
  *   "score_stream" (VV_SCORE_STREAM, 0)  1: the one-sweep score kernel for every shape
  *   "comm_gate" (VV_COMM_GATE, 1)    the overlapped update gates the next forward GEMM chunk by chunk (0: the stream joins)
