@@ -121,6 +121,29 @@ def test_sibling_lead_forward_kernel_is_bit_identical(setup, monkeypatch):
         vv.Engine(0, "f16")                           # back to the default kernel for the tests that follow
 
 
+@pytest.mark.parametrize("dedup", [1, 0])
+def test_forward_kernel_with_merged_phases_is_bit_identical(setup, dedup):
+    """Option fwd_merge: the forward GEMM with two phases per barrier pair (k_fwd_gemm_ph, MRG) -- other barriers, other counted waits,
+    the same half-tiles in the same LDS slots and the same MFMA order per accumulator: every output bit must agree with the four-phase
+    kernel, with the sibling lead at the de-duplicated size (192-row tiles) and without it at the dense size (256-row tiles)."""
+    vv, ds, idx, W, b, _ = setup
+    cfg = vv.StepConfig(B, C, Nn)
+    out = []
+    for merge in (0, 1):
+        e = vv.Engine(0, "f16")
+        e.set_option("dedup", dedup)
+        e.set_option("fwd_merge", merge)
+        e.table_synth(ds.seed, ds.n_rows, F)
+        e.params_set(W, b)
+        e.forward_backward(cfg, idx)
+        e.forward_backward(cfg, idx)                  # (the second call: the tile plan follows the previous step's distinct-row count)
+        dW, db = e.grads()
+        out.append((e.blobs(cfg)["ip2"].copy(), dW.copy(), db.copy(), e.loss()))
+        del e
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    assert out[0][3] == out[1][3]
+
+
 def test_full_size_dropout_on_the_deduplicated_path(setup, oracle):
     """The shipped dropout ratio 0.9 at the benchmark's size: the de-duplicated execution (the mask per instance on the shared projection) and
     the dense one (the mask in the forward GEMM's epilogue) drop the same elements and agree; a shard of the batch against the oracle with
