@@ -847,6 +847,8 @@ def main():
                        "global_batch": Bg, "triplets_per_step": Bg * NN,
                        "parallelism": "dp%d" % world, "items_per_s": value / NN,
                        "dedup": args.dedup if DROPOUT == 0 else "off (dropout at D = 4096: dense kernels -- the de-duplicated path carries the per-instance masks at D = 512 only, and 128-item batches hardly repeat a row)",
+                       "sampler_host": ({"avx512_forms": bool(sampler.stat(7) == 1), "cores_held_for_stage_threads": int(sampler.stat(9))}
+                                        if sampler is not None else None),
                        "cpu_binding_rank0": cpu_bind,
                        "sampler": ("one per rank: the reference's sampler at batch %d with srand(1 + rank) and its own starting record, "
                                    "%d stage thread(s), prefetch depth %d" % (B_PER_GPU, args.sampler_threads, args.prefetch_depth))
