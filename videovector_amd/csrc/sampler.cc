@@ -365,6 +365,7 @@ bool stage_cpu_set(cpu_set_t* out, cpu_set_t* per_stage = nullptr, int* n_per_st
           if (*q == '-') { ++q; b = atoi(q); while (*q && *q != ',' && *q != '\n') ++q; }
           for (int k = a; k <= b && k < CPU_SETSIZE; ++k) {
             if (k >= 0 && CPU_ISSET(k, &allowed)) { CPU_SET(k, out); if (mine) CPU_SET(k, mine); }
+            if (mine && first_cpu && k >= 0 && k < first_cpu[*n_per_stage]) first_cpu[*n_per_stage] = k;   // the core's name for claim_cores: its lowest CPU, whichever sibling the group holds
             if (k == cur) with_caller = true;
           }
           if (*q == ',') ++q;
