@@ -272,7 +272,7 @@ def main():
     ap.add_argument("--sampler-threads", type=int, default=int(os.environ.get("VV_SAMPLER_THREADS", "4")))
     ap.add_argument("--prefetch-depth", type=int, default=128,
                     help="batches the sampler keeps ahead of the consumer (the reference: 1).  128 (29 MB of index batches) covers the stretches of up to several hundred steps in "
-                         "which the sampler -- 0.09 ms per batch at the median against a 0.21 ms step since round 5 (0.13 before), with the host's occasional slow stretches -- falls behind (profiles/r02_long_run.txt, r05_sampler_rates_closing.txt)")
+                         "which the sampler -- 0.09 ms per batch at the median against a 0.21 ms step since round 5 (0.13 before), with the host's occasional slow stretches -- falls behind (profiles/r02_long_run.txt, r05_sampler_rates.txt)")
     ap.add_argument("--settle-ms", type=float, default=50.0,
                     help="untimed steps of the same workload, this many ms of them, in front of the W warm-up steps of every "
                          "leg: the device needs ~25 ms of continuous work after an idle spell (set-up, a host-side leg) before "
