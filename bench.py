@@ -752,15 +752,15 @@ def main():
             child[name]["wall_s"] = round(time.perf_counter() - t_leg, 2)
         leg_helper.close()
     if shipped and not no_hint:
-        # vv_update_hint with the option "wgrad_update": the solver's rule applied in the weight-gradient GEMM's epilogue (one split of K at this
-        # shape) -- bit-identical parameters; off by default because a few runs are much slower (profiles/r05_shipped_update.txt): timed beside the line
+        # vv_update_hint + option "wgrad_update" (default): the solver's rule applied in the weight-gradient GEMM's epilogue (one split of K at this
+        # shape) -- bit-identical parameters.  Timed beside the line: the update as its own launch (option 0), the form of rounds 3-4.
         run3 = Run(args.prec, args.dedup == "on")
-        run3.eng.set_option("wgrad_update", 1)
+        run3.eng.set_option("wgrad_update", 0)
         w_el, w_kern, _ = run3.timed("q1")
-        extra["update_in_wgrad_execution"] = {"value": Bg * NN * K / w_el, "unit": "triplets/s", "ms_per_step": w_el / K * 1e3,
-                                              "kernels_ms": {k: round(v[0], 4) for k, v in w_kern.items() if v[1] > 0},
-                                              "final_loss": run3.eng.loss()[0],
-                                              "note": "option wgrad_update = 1 (VV_WGRAD_UPDATE): the update in k_wgrad_gemm_ph's epilogue, bias / loss in a 5 us launch"}
+        extra["update_as_own_launch_execution"] = {"value": Bg * NN * K / w_el, "unit": "triplets/s", "ms_per_step": w_el / K * 1e3,
+                                                   "kernels_ms": {k: round(v[0], 4) for k, v in w_kern.items() if v[1] > 0},
+                                                   "final_loss": run3.eng.loss()[0],
+                                                   "note": "option wgrad_update = 0 (VV_WGRAD_UPDATE=0): weight-gradient GEMM stores dW, k_reduce_sgd applies the rule (the line itself: the update in the GEMM's epilogue)"}
         run3.eng.close()
     t_legs_done = time.perf_counter()
 

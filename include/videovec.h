@@ -72,8 +72,8 @@ int vv_set_dedup(vv_ctx* ctx, int on);
  *                                    on the compute stream itself (0: on the communication stream, the next forward GEMM gated on one flag)
  *   "comm_first_inline" (VV_COMM_FIRST_INLINE, 0)  1: the OVERLAPPED update's first F-chunk (exchange, rule, publish) is queued on the compute stream,
  *                                    the others on the communication stream (measured slower on one rank: off by default)
- *   "wgrad_update" (VV_WGRAD_UPDATE, 0)  1: a step announced by vv_update_hint whose weight-gradient GEMM has one split of K applies the solver's
- *                                    rule in that GEMM's epilogue (bit-identical parameters; faster in most runs, much slower in a few: off by default)
+ *   "wgrad_update" (VV_WGRAD_UPDATE, 1)  a step announced by vv_update_hint whose weight-gradient GEMM has one split of K applies the solver's
+ *                                    rule in that GEMM's epilogue (bit-identical parameters; 0: the update as its own launch)
  *   "comm_chunks" (VV_COMM_CHUNKS, 3)  F-chunks of the overlapped update, 1 .. 4
  *   "comm_test_delay_us" (VV_COMM_TEST_DELAY_US, 0)  TEST HOOK: holds the communication stream this long in front of every chunk
  * Ablated / experimental kernels (timing studies whose results may be wrong) are NOT reachable through this library: they and their
@@ -183,7 +183,7 @@ int vv_step(vv_ctx* ctx, const vv_step_cfg* cfg, const int32_t* idx, int idx_on_
 /* Solver::Step as ONE unit (solver.cpp:177-221: ForwardBackward, ComputeUpdateValue, Update back to back): announces that the NEXT
  * vv_forward_backward* call will be followed by vv_apply_update with exactly these solver parameters (lr, momentum, weight_decay, lr_mult,
  * decay_mult, reg, solver_type, delta) and that nothing reads the gradient in between.  The library may then apply the update where the
- * gradient is produced (option "wgrad_update", off by default): when the weight-gradient GEMM runs with one split of K (large D x F, small batches -- the shipped
+ * gradient is produced (option "wgrad_update", on by default): when the weight-gradient GEMM runs with one split of K (large D x F, small batches -- the shipped
  * mednet_embedding_train.prototxt: 4096 x 4096, batch 128) its epilogue applies the solver's rule to the tile it holds, and the 4 D F bytes
  * of dW are neither written nor read back; vv_apply_update then only finishes the step (bias, loss, scale bookkeeping).  Parameters, history
  * and losses are bit for bit those of the un-hinted calls.  Between such a vv_forward_backward* and its vv_apply_update only vv_loss_get

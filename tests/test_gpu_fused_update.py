@@ -75,7 +75,7 @@ smp = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, batch_size=B, context_siz
                  max_buffer_size=5000, negative_swap_percentage=50)
 W, b = init_weights(7, D, F)
 eng = vv.Engine(0, sys.argv[1])
-eng.set_option("wgrad_update", 1)                        # (off by default: include/videovec.h)
+eng.set_option("wgrad_update", 1)                        # (the default since the rotated epilogue; set explicitly)
 eng.table_synth(ds.seed, ds.n_rows, F)
 eng.params_set(W, b)
 solver = int(sys.argv[2])

@@ -486,9 +486,25 @@ int vv_params_set(vv_ctx* c, int32_t D, const float* W, const float* b, const fl
     dfree(c->W); dfree(c->b); dfree(c->hW); dfree(c->hb); dfree(c->Wh); dfree(c->grads_own);
     c->W = c->b = c->hW = c->hb = nullptr; c->Wh = nullptr; c->grads = c->grads_own = nullptr;
     c->D = D; c->Dp = (int)round_up(D, D_ALIGN);
+#ifdef VV_LAB
+    // (lab: VV_LAB_PARAM_ARENA="skew_hW,skew_Wh" bytes -- W, its history and the 16-bit copy in ONE allocation, the second and third a
+    // 2-MiB multiple + the given skew behind the first: does the update-in-the-epilogue kernel's speed depend on their relative placement?
+    // The arena is never freed: lab processes exit.)
+    if (const char* e = getenv("VV_LAB_PARAM_ARENA")) {
+      const size_t S = round_up(nW * 4, (size_t)2 << 20);
+      const size_t sk1 = (size_t)atoll(e), sk2 = strchr(e, ',') ? (size_t)atoll(strchr(e, ',') + 1) : 0;
+      char* arena = nullptr;
+      HIPCHK(hipMalloc(&arena, 3 * S + ((size_t)16 << 20)));
+      c->W = (float*)arena; c->hW = (float*)(arena + S + sk1); c->Wh = (uint16_t*)(arena + 2 * S + ((size_t)4 << 20) + sk2);
+      HIPCHK(hipMalloc(&c->b, D * 4)); HIPCHK(hipMalloc(&c->hb, D * 4));
+      fprintf(stderr, "[vv lab] parameter arena: W %p hW %p Wh %p\n", (void*)c->W, (void*)c->hW, (void*)c->Wh);
+    } else
+#endif
+    {
     HIPCHK(hipMalloc(&c->W, nW * 4)); HIPCHK(hipMalloc(&c->hW, nW * 4));
     HIPCHK(hipMalloc(&c->b, D * 4)); HIPCHK(hipMalloc(&c->hb, D * 4));
     HIPCHK(hipMalloc(&c->Wh, (size_t)c->Dp * c->Fp * 2));
+    }
     HIPCHK(hipMemset(c->Wh, 0, (size_t)c->Dp * c->Fp * 2));
     HIPCHK(hipMalloc(&c->grads_own, (nW + D) * 4));
     HIPCHK(hipMemset(c->grads_own, 0, (nW + D) * 4));

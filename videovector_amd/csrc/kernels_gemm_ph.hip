@@ -892,10 +892,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
           for (int ni = 0; ni < 4; ++ni)
             *(f32x4*)(tile + (wn * 32 + mi * 16 + li) * TSTR + nh * 128 + wm * 64 + ni * 16 + g * 4) = acc[nh][ni][mh][mi];
       __syncthreads();
+      // (the sixteen row groups in an order that depends on the tile: with every workgroup of the chip walking rows 0-7, 8-15, ... of its
+      // tile at the same moment the requests of a moment differ in few address bits above the row pitch, and where they fall in the memory
+      // system's interleave is decided by the buffers' PHYSICAL placement: two processes in sixteen ran this epilogue at half speed,
+      // profiles/r05_shipped_update.txt)
+      const int rot = (tn * 5 + tm * 3 + mh * 8) & 15;
       f32x4 wv[16], hv[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const int e = tid + GEMM_THREADS * j, r = e >> 6, c = (e & 63) * 4;
+        const int e = tid + GEMM_THREADS * ((j + rot) & 15), r = e >> 6, c = (e & 63) * 4;
         const int m = m0 + mh * 128 + r, n = n0 + c;
         const bool in = m < u.D && n < u.F;
         const int64_t o = (int64_t)m * u.F + n;
@@ -904,7 +909,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
       }
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const int e = tid + GEMM_THREADS * j, r = e >> 6, c = (e & 63) * 4;
+        const int e = tid + GEMM_THREADS * ((j + rot) & 15), r = e >> 6, c = (e & 63) * 4;
         const int m = m0 + mh * 128 + r, n = n0 + c;
         if (m >= u.D || n >= u.F) continue;
         const int64_t o = (int64_t)m * u.F + n;

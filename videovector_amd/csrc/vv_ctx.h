@@ -141,10 +141,11 @@ struct vv_ctx {
   // vv_update_hint: the next vv_forward_backward* is followed by vv_apply_update with these solver parameters and nothing reads the gradient
   // in between -- with one split of K the weight-gradient GEMM then applies the update itself (WgradUpd)
   bool upd_hint = false;
-  bool wgrad_update = false;                // option "wgrad_update" (VV_WGRAD_UPDATE): a hinted step with one split of K applies its update in the weight-gradient
-                                            // GEMM's epilogue.  OFF by default: 0.2177-0.2265 ms against 0.2293-0.2323 ms at the shipped shape in 15 of 17 runs --
-                                            // and 0.302 ms in the other two (the fused kernel 182-188 us instead of 101-113: not reproduced on demand, not explained;
-                                            // profiles/r05_shipped_update.txt).  The hint itself is always accepted.
+  bool wgrad_update = true;                 // option "wgrad_update" (VV_WGRAD_UPDATE): a hinted step with one split of K applies its update in the weight-gradient
+                                            // GEMM's epilogue.  ON since the epilogue walks its row groups in an order that depends on the tile (k_wgrad_gemm_ph, UPD):
+                                            // before that, two processes in sixteen ran it at half speed (182-196 us instead of 100-125), decided by where the buffers
+                                            // happened to lie in physical memory; with it forty processes in forty at 95-107 us: 0.211-0.224 ms per iteration at the
+                                            // shipped shape against 0.229-0.236 with the update as its own launch (profiles/r05_shipped_update.txt).
   vv_step_cfg upd_cfg;
   bool upd_in_wgrad = false;                // this step's parameter matrix is already updated; vv_apply_update finishes the step
   int upd_wgrad_blocks = 0;                 // per-block max |w| slots that launch wrote
