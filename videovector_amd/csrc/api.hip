@@ -600,7 +600,7 @@ static int ensure_batch(vv_ctx* c, int B, int C, int Nn) {
   if (S > total_steps) S = total_steps;
   if (S < 1) S = 1;
   c->S = S; c->kps = (total_steps + S - 1) / S;
-  c->slab_bytes = (size_t)S * c->Dp * c->Fp * 4;
+  c->slab_bytes = (size_t)S * (size_t)slab_pitch(c->Dp, c->Fp) * 4;
   HIPCHK(hipMalloc(&c->slabs, c->slab_bytes));
   // de-duplication work arrays
   c->dd_agg_stride = c->R / 1024 + 2;

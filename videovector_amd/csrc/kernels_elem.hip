@@ -1630,7 +1630,7 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
   if (!(a.parts & 1)) return;
   const float sgf = a.sg_dev ? *a.sg_dev : (a.gg ? a.sg * a.gg->mul : a.sg);   // the scale the 16-bit gradients really carry
   const float inv = a.ip_scale / (sgf * a.scales->sx);
-  const int64_t slab_sz = (int64_t)a.Dp * a.Fp;
+  const int64_t slab_sz = slab_pitch(a.Dp, a.Fp);
   const int d0 = a.d_begin, dn = a.d_count > 0 ? a.d_count : a.D;
   if (VEC) {
     const int fb = a.f_count > 0 ? a.f_begin : 0, fn = a.f_count > 0 ? a.f_count : a.F;
@@ -1863,7 +1863,7 @@ __global__ __launch_bounds__(256) void k_reduce_sgd(FusedUpdArgs fa) {
   const int nblk = G - n_special;
   const int f4 = a.F / 4;
   const int64_t n4 = (int64_t)a.D * f4;
-  const int64_t slab_sz = (int64_t)a.Dp * a.Fp;
+  const int64_t slab_sz = slab_pitch(a.Dp, a.Fp);
   int64_t i = (int64_t)bid * 256 + threadIdx.x;
   // the first element's loads fly while the scale is worked out
   float4 t[8], w = make_float4(0.f, 0.f, 0.f, 0.f), h = w;

@@ -387,7 +387,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm(WgradArgs a) {
 
   // swapped operands (D' = X_tile^T dY_tile): lane column = m (output row d), registers = 4
   // consecutive n (feature columns) -> 16-B stores into the split's fp32 slab.
-  float* slab = a.slabs + (int64_t)sp * a.Dp * a.Fp;
+  float* slab = a.slabs + (int64_t)sp * slab_pitch(a.Dp, a.Fp);
 #pragma unroll
   for (int mi = 0; mi < 8; ++mi) {
     const int m = m0 + wm * 128 + mi * 16 + li;

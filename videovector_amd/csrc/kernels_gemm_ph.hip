@@ -945,7 +945,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
     return;
   }
   // D' = X_frag^T-major: the lane's column is m (dY column = output row d), its 4 registers 4 consecutive n
-  float* slab = a.slabs + (int64_t)sp * a.Dp * a.Fp;
+  float* slab = a.slabs + (int64_t)sp * slab_pitch(a.Dp, a.Fp);
 #pragma unroll
   for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -969,7 +969,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
                  : "=s"(o_[0]), "=s"(o_[1]), "=s"(o_[2]), "=s"(o_[3]), "=s"(o_[4]), "=s"(o_[5]), "=s"(o_[6]), "=s"(o_[7]), "=s"(o_[8]), "=s"(o_[9])
                  :: WTS_CLOB, "memory");
     if (lane == 0) {
-      uint32_t* o = (uint32_t*)(a.slabs + (int64_t)a.S * a.Dp * a.Fp) + ((size_t)blockIdx.x * 8 + wave) * 12;      // (lab: behind the last slab -- the harness allocates the room)
+      uint32_t* o = (uint32_t*)(a.slabs + (int64_t)a.S * slab_pitch(a.Dp, a.Fp)) + ((size_t)blockIdx.x * 8 + wave) * 12;      // (lab: behind the last slab -- the harness allocates the room)
 #pragma unroll
       for (int j = 0; j < 10; ++j) o[j] = o_[j];
       o[10] = (uint32_t)nk_all; o[11] = 0;
@@ -1117,7 +1117,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef W4_STAGE
   }
 
-  float* slab = a.slabs + (int64_t)sp * a.Dp * a.Fp;
+  float* slab = a.slabs + (int64_t)sp * slab_pitch(a.Dp, a.Fp);
 #pragma unroll
   for (int mi = 0; mi < 8; ++mi) {
     const int m = m0 + wy * 128 + mi * 16 + li;

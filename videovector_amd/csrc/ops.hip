@@ -403,7 +403,7 @@ int vv_op_inner_product_bwd(vv_ctx* c, const float* dY, int64_t R, float ip_regu
   const int tiles = (Dp / BM) * (c->Fp / BN);
   const int total_steps = (int)(Rp / BK);
   int S = std::max(1, std::min((256 + tiles - 1) / tiles, total_steps));
-  const size_t need = (size_t)S * Dp * c->Fp * 4;
+  const size_t need = (size_t)S * (size_t)slab_pitch(Dp, c->Fp) * 4;
   if (need > s.slab_bytes) {
     HIPCHK(hipStreamSynchronize(c->stream));
     if (s.slabs) (void)hipFree(s.slabs);

@@ -7,6 +7,16 @@
 
 namespace vv {
 
+// Floats between two split-K slabs of the weight gradient.  Exactly D_p x F_p (8 MiB at 512 x 4096) puts the eight streams that k_reduce /
+// k_reduce_sgd read side by side a power of two apart, and a reader of the slabs alone gains 11 % from 4 KiB of skew (3.93 -> 4.38 TB/s,
+// tools/lab/slab_pitch_lab.hip) -- but in the step k_reduce_sgd's 0.9 us are given back by the weight-gradient GEMM's stores (+0.7 us),
+// alternating builds on one box (profiles/r05_slab_pitch.txt): the pad stays 0; -DVV_SLAB_PAD=<floats> builds the other form.
+#ifndef VV_SLAB_PAD
+#define VV_SLAB_PAD 0
+#endif
+__host__ __device__ inline int64_t slab_pitch(int Dp, int Fp) { return (int64_t)Dp * Fp + VV_SLAB_PAD; }
+
+
 // ---------------------------------------------------------------------------------------------
 // GEMM tiling shared by the forward (gather-GEMM) and weight-gradient (gather-GEMM^T) kernels.
 // One workgroup = 512 threads = 8 waves (2 along M x 4 along N), one 256x256 output tile,
