@@ -150,6 +150,27 @@ def cpu_baseline(ds, idx, W, b, items, iters, threads=0):
     return out
 
 
+BOX_REF_GEMM_TFLOPS = 1200.0   # the reference rate `ms_per_step_at_ref` is quoted at (a round number near the pool's median box)
+
+
+def box_record(box, ms_per_step):
+    """The line's `box` object: the two probes of vv_box_probe before and after the timed leg, their means, and the step time scaled to a
+    reference box (ms x gemm_tflops / 1200): two runs of the same code on boxes whose clocks differ should agree in that figure."""
+    if not box:
+        return None
+    b, a = box["before"], box.get("after") or box["before"]
+    mean = lambda k: 0.5 * (b[k] + a[k])
+    return {"gemm_tflops": mean("gemm_tflops"), "copy_tbs": mean("copy_tbs"), "gemm_clock_mhz": mean("gemm_clock_mhz"),
+            "before_timed_leg": {k: b[k] for k in ("gemm_tflops", "gemm_ms", "gemm_clock_mhz", "copy_tbs", "copy_ms")},
+            "after_timed_leg": {k: a[k] for k in ("gemm_tflops", "gemm_ms", "gemm_clock_mhz", "copy_tbs", "copy_ms")},
+            "ref_gemm_tflops": BOX_REF_GEMM_TFLOPS, "ms_per_step_at_ref": ms_per_step * mean("gemm_tflops") / BOX_REF_GEMM_TFLOPS,
+            "probes": "vv_box_probe (include/videovec.h): gemm = the benchmark's forward instantiation (k_fwd_gemm_ph, f16, 192-row tiles, 216 "
+                      "workgroups) on contiguous rows of a random table, %d x %d x %d, operands uniform in [-1, 1), 24 launches behind 8 warm-up "
+                      "launches, clock = s_memtime / s_memrealtime inside the kernel (median over workgroups); copy = 1 GiB device-to-device, "
+                      "read + written bytes per second, 6 copies behind 2" % tuple(b["gemm_shape"]),
+            "note": "a calibration of the box, not of the code: ms_per_step_at_ref = ms_per_step x gemm_tflops / ref_gemm_tflops"}
+
+
 def helper_main():
     """`bench.py --helper`: a process that never touches the GPU.  Every rank of an N > 1 run starts one BEFORE its own first GPU call; later it
     asks it -- one JSON line in, one out -- to run a further bench.py rank (a leg that may not come back: the direct peer transport on a
@@ -641,7 +662,14 @@ def main():
     main_prof = "gemm" if (not args.no_extra_legs and args.workload == "cfg2") else "all"
     if shipped:
         S = max(1, int(args.settle_ms / 0.5))
+    # Box calibration: two fixed probes of the library -- the benchmark's forward GEMM instantiation on contiguous random
+    # rows, a 1 GiB streaming copy -- right before the settle steps of the timed leg and right after it: what THIS device delivers now.
+    box = None
+    if rank == 0 and os.environ.get("VV_BENCH_NO_BOX") != "1":
+        box = {"before": run.eng.box_probe()}
     elapsed, kern, diag_ms = run.timed(main_source, per_step_events=diag, profile=main_prof)
+    if box is not None:
+        box["after"] = run.eng.box_probe()
     main_cold_ms = run.cold_ms
     if diag and rank == 0:
         print("main-leg step ms: " + " ".join("%.3f" % x for x in diag_ms), file=sys.stderr)
@@ -869,6 +897,7 @@ def main():
                                      "stale": "overlapped with the next iteration's forward/backward "
                                               "(one-update delayed gradients: NOT the reference's algorithm)"}[mode]},
             "roofline": roof,
+            "box": box_record(box, ms),
             "kernels_ms": {k: round(v, 4) for k, v in live.items()},
             "kernel_timing": ("HIP events on the kernels' dispatch packets, every %d-th of the %d timed steps (%d samples per kernel)"
                               % (max(5, K // 8), K, max([v[1] for v in kern.values()] or [0])))

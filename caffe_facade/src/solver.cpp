@@ -150,7 +150,11 @@ void Solver<Dtype>::Step(bool display) {
   net_->set_debug_info(display && param_.get_bool("debug_info"));
   net_->set_loss_needed(display);                   // the loss is read back from the device only when it is shown
   PrepareUpdate();                                  // this iteration's rate (a function of iter_) ...
-  net_->HintUpdate();                               // ... and: ForwardBackward is followed by Update, nothing reads a diff in between
+  // ... and: ForwardBackward is followed by Update and nothing reads a diff in between -- unless this solver's snapshots carry the diffs
+  // (snapshot_diff, caffe.proto SolverParameter field 16; Net::ToProto, net.cpp:784-800, then reads them back): such a job keeps its
+  // gradient, i.e. the update stays its own launch (with the hint the shipped 4096 x 4096 shape applies the rule in the
+  // weight-gradient GEMM's epilogue and the gradient never exists outside its registers)
+  if (!param_.get_bool("snapshot_diff")) net_->HintUpdate();
   const Dtype loss = net_->ForwardBackward(no_bottom);
   if (display) {
     LOG(INFO) << "Iteration " << iter_ << ", loss = " << loss;                          // solver.cpp:196

@@ -426,6 +426,22 @@ int vv_profile_enable(vv_ctx* ctx, int on);
 int vv_profile_select(vv_ctx* ctx, const char* kernels);
 int vv_profile_get(vv_ctx* ctx, const char* kernel, double* avg_ms, int64_t* launches);
 
+/* Box calibration for the benchmark: what THIS device delivers at the moment of the call, so that step times measured on different boxes of
+ * a pool can be compared (the step's GEMMs run at whatever clock the chip holds under them).  No reference counterpart: `caffe device_query`
+ * (tools/caffe.cpp:108-121, Caffe::DeviceQuery, src/caffe/common.cpp:147-180) prints static properties only.  Two fixed probes on buffers of
+ * their own (2.2 GB, released before the call returns), queued on the context's stream, ~10 ms of device time:
+ *   gemm  the benchmark's forward instantiation (f16 operands, 192-row tiles, 216 workgroups) on CONTIGUOUS rows of a random table,
+ *         20 736 x 4096 x 512, operands uniform in [-1, 1): TFLOP/s over 24 back-to-back launches behind 8 warm-up launches, and the shader
+ *         clock held inside the kernel (s_memtime over s_memrealtime, median over its workgroups)
+ *   copy  a 1 GiB device-to-device streaming copy: bytes read + written per second over 6 copies behind 2 */
+typedef struct {
+  double gemm_tflops, gemm_ms, gemm_clock_mhz;
+  double copy_tbs, copy_ms;
+  int32_t gemm_rows, gemm_k, gemm_n, gemm_launches;
+  int64_t copy_bytes;
+} vv_box_probe_result;
+int vv_box_probe(vv_ctx* ctx, vv_box_probe_result* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -567,3 +567,28 @@ def test_caffe_train_data_parallel_per_rank_samplers(tool, pb, oracle, tmp_path)
         lr = oracle.learning_rate("inv", 0.01, 1e-3, 0.75, 0, it)
         oracle.sgd_update(Wq, 0.5 * (res[0]["dW"] + res[1]["dW"]), hW, lr, 1.0, 0.9, 5e-4, 1.0)
         oracle.sgd_update(bq, 0.5 * (res[0]["db"] + res[1]["db"]), hb, lr, 2.0, 0.9, 5e-4, 0.0)
+
+
+def test_caffe_train_snapshot_diff_at_the_shape_whose_update_rides_in_the_gemm(tool, pb, tmp_path):
+    """ADVICE r5 (medium): with `snapshot_diff: true` (caffe.proto SolverParameter field 16; Net::ToProto writes the diffs, net.cpp:784-800)
+    Solver::Snapshot reads the parameter gradient back -- which a hinted step at the shipped 4096 x 4096 shape (one split of K: the solver's
+    rule applied in the weight-gradient GEMM's epilogue) never stores.  Such a solver now keeps the update as its own launch: the job runs,
+    the snapshot carries a diff of the blob's size, and the weights are bit for bit those of the same job without diffs (hinted)."""
+    B, C, Nn, F, D, V = 128, 5, 10, 4096, 4096, 300
+    net_p = tmp_path / "net.prototxt"
+    net_p.write_text(train_net("synthetic://videos=%d;seed=1701;features=%d" % (V, F), B, C, Nn, D, max_buffer=2000, w_std=0.01))
+    out = {}
+    for tag, diff in (("plain", False), ("diff", True)):
+        sol_p = tmp_path / ("solver_%s.prototxt" % tag)
+        sol_p.write_text(solver(str(net_p), base_lr=0.01, max_iter=3, display=1, snapshot=2, random_seed=7,
+                                snapshot_prefix=str(tmp_path / ("snap_" + tag)), snapshot_diff=diff))
+        log = run_caffe(["train", "--solver=%s" % sol_p], str(tmp_path / (tag + ".log")))
+        assert "Optimization Done." in log
+        net = pb["NetParameter"]()
+        net.ParseFromString(open(tmp_path / ("snap_%s_iter_2.caffemodel" % tag), "rb").read())
+        fc = [l for l in net.layers if l.name == "fc7"][0]
+        out[tag] = (np.array(fc.blobs[0].data, np.float32), np.array(fc.blobs[0].diff, np.float32), np.array(fc.blobs[1].diff, np.float32))
+    assert np.array_equal(out["plain"][0], out["diff"][0])
+    assert out["plain"][1].size == 0                                  # snapshot_diff false: no diff fields
+    dW, db = out["diff"][1], out["diff"][2]
+    assert dW.size == D * F and db.size == D and np.isfinite(dW).all() and np.abs(dW).max() > 0 and np.abs(db).max() > 0

@@ -1335,6 +1335,27 @@ void launch_wgrad_gemm_ph(int prec, const WgradArgs& a, hipStream_t s) {
   if (prec == 0) launch_wgrad_ph_t<F16>(a, s); else launch_wgrad_ph_t<BF16>(a, s);
 }
 
+// Box calibration (probe.hip: vv_box_probe).  The benchmark's own forward instantiation -- f16 operands, 192-row tiles, sibling lead, no
+// dropout -- on the rows the caller hands it (contiguous rows of a random table: FwdArgs::n_dev null, the grid covers R).  marks: the same
+// kernel with its four time marks (ABL bit 11: kernel start, loop start, loop end, last store + the 100 MHz real-time counter; every wave
+// leaves uint32[12] at FwdArgs::mask): shader clocks over the K loop / real time over the K loop = the clock the chip held under the GEMM.
+void launch_fwd_probe(const FwdArgs& a, hipStream_t s, bool marks) {
+  constexpr int LDS10 = 10 * PH_SLOT;
+  const int Dp = (int)round_up(a.D, D_ALIGN);
+  const dim3 grid(((a.R + 191) / 192) * (Dp / BN)), block(GEMM_THREADS);
+  if (marks) {
+    static bool once_m = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<F16, 0, true, 3, 2048, false, 0, 1>,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS10), true);
+    (void)once_m;
+    hipLaunchKernelGGL((k_fwd_gemm_ph<F16, 0, true, 3, 2048, false, 0, 1>), grid, block, LDS10, s, a);
+  } else {
+    static bool once_p = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<F16, 0, true, 3, 0, false, 0, 1>,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS10), true);
+    (void)once_p;
+    hipLaunchKernelGGL((k_fwd_gemm_ph<F16, 0, true, 3, 0, false, 0, 1>), grid, block, LDS10, s, a);
+  }
+}
+
 void launch_fwd_gemm_ph(int prec, const FwdArgs& a, hipStream_t s) {
   if (prec == 0) launch_fwd_ph_p<F16>(a, s); else launch_fwd_ph_p<BF16>(a, s);
 }

@@ -37,6 +37,13 @@ class _StepCfg(C.Structure):
 _lib = None
 
 
+class _BoxProbe(C.Structure):
+    _fields_ = [("gemm_tflops", C.c_double), ("gemm_ms", C.c_double), ("gemm_clock_mhz", C.c_double),
+                ("copy_tbs", C.c_double), ("copy_ms", C.c_double),
+                ("gemm_rows", C.c_int32), ("gemm_k", C.c_int32), ("gemm_n", C.c_int32), ("gemm_launches", C.c_int32),
+                ("copy_bytes", C.c_int64)]
+
+
 def load_library():
     """Load libvideovec.so; raises (never falls back) when the HIP library is not built."""
     global _lib
@@ -100,6 +107,7 @@ def load_library():
         "vv_profile_enable": [vp, C.c_int],
         "vv_profile_select": [vp, C.c_char_p],
         "vv_profile_get": [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)],
+        "vv_box_probe": [vp, C.POINTER(_BoxProbe)],
     }
     for name, args in sigs.items():
         fn = getattr(L, name)
@@ -374,6 +382,15 @@ class Engine:
         ms, n = C.c_double(), C.c_int64()
         self._chk(self.L.vv_profile_get(self.h, kernel.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def box_probe(self):
+        """vv_box_probe: what this device delivers right now on two fixed probes (the benchmark's forward GEMM instantiation on contiguous
+        random rows; a 1 GiB streaming copy) -- the calibration record of a bench line."""
+        r = _BoxProbe()
+        self._chk(self.L.vv_box_probe(self.h, C.byref(r)))
+        return {"gemm_tflops": r.gemm_tflops, "gemm_ms": r.gemm_ms, "gemm_clock_mhz": r.gemm_clock_mhz,
+                "copy_tbs": r.copy_tbs, "copy_ms": r.copy_ms,
+                "gemm_shape": [r.gemm_rows, r.gemm_k, r.gemm_n], "gemm_launches": r.gemm_launches, "copy_bytes": r.copy_bytes}
 
 
 class DevBuf:

@@ -140,7 +140,8 @@ def extraction_net(source, batch, D, *, normalize=False, w_std=0.001):
 
 def solver(net_path, *, base_lr=0.001, momentum=0.9, weight_decay=0.0005, lr_policy="inv", gamma=0.001,
            power=0.75, stepsize=0, display=10, max_iter=100, snapshot=0, snapshot_prefix="videovec",
-           random_seed=-1, snapshot_after_train=True, test_iter=0, test_interval=0, solver_type=None, delta=None):
+           random_seed=-1, snapshot_after_train=True, test_iter=0, test_interval=0, solver_type=None, delta=None,
+           snapshot_diff=False):
     """Same fields as projects/videovec_embedding/mednet_embedding_train_solver.prototxt (+ solver_type / delta)."""
     s = ['net: "%s"' % net_path, "base_lr: %g" % base_lr, "momentum: %g" % momentum,
          "weight_decay: %g" % weight_decay, 'lr_policy: "%s"' % lr_policy, "gamma: %g" % gamma,
@@ -158,4 +159,6 @@ def solver(net_path, *, base_lr=0.001, momentum=0.9, weight_decay=0.0005, lr_pol
         s.append("solver_type: %s" % solver_type)
     if delta is not None:
         s.append("delta: %g" % delta)
+    if snapshot_diff:
+        s.append("snapshot_diff: true")
     return "\n".join(s) + "\n"
