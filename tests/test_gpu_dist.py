@@ -94,10 +94,21 @@ def test_bench_per_rank_samplers_is_the_default_for_two_ranks():
     assert "logical CPUs" in d["config"]["cpu_binding_rank0"] or d["config"]["cpu_binding_rank0"].startswith("not bound")
     # the driver's launch form (torch.distributed.run): the schedule legs and the fresh-process legs come back here too (their own rendezvous:
     # the launcher's agent does not host a store for them)
-    assert "reduce-scatter" in d["config"]["allreduce"]                  # N > 1 default: the sharded update in the compute stream
-    assert set(d["schedules"]["legs"]) == {"sync", "overlap", "sharded"} and d["schedules"]["legs"]["sharded"].get("default")
-    for name, leg in d["schedules"]["legs"].items():
+    # N > 1 default: --allreduce auto = the fastest of the three exact schedules AS MEASURED BY THIS INVOCATION, before
+    # the timed run; the two conformant forms ride beside `value` as first-class numbers and the deviation is stated in one line
+    legs = d["schedules"]["legs"]
+    assert set(legs) == {"sync", "overlap", "sharded"}
+    auto = d["schedules"]["auto"]
+    fastest = min(legs, key=lambda k: legs[k]["ms_per_step"])
+    assert auto["picked"] == fastest and legs[fastest].get("default") and sum(1 for v in legs.values() if v.get("default")) == 1
+    key = {"sync": "synchronous", "overlap": "F-chunk by F-chunk", "sharded": "reduce-scatter"}[fastest]
+    assert key in d["config"]["allreduce"]
+    for name, leg in legs.items():
         assert leg["final_loss"] == d["final_loss"], (name, leg)
+    assert d["value_overlap_schedule"]["value"] == legs["overlap"]["value"] or fastest == "overlap"
+    assert d["value_reference_batch"]["value"] == d["node_sampler_leg"]["value"] and d["value_reference_batch"]["value"] > 0
+    assert "per-rank samplers" in d["config"]["deviation"]
+    assert ("schedule " + fastest in d["config"]["deviation"]) == (fastest != "overlap")
     assert "error" not in d["peer_transport_leg"] and d["peer_transport_leg"]["final_loss"] == d["final_loss"], d["peer_transport_leg"]
     assert "error" not in d["node_sampler_leg"] and d["node_sampler_leg"]["wall_s"] < 200, d["node_sampler_leg"]
 

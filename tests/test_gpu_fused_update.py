@@ -127,3 +127,60 @@ def test_update_in_the_weight_gradient_epilogue_is_bit_identical(tmp_path, prec,
         assert np.array_equal(a[k], b[k]), k
     assert np.isfinite(a["W"]).all() and np.abs(a["hW"]).max() > 0 and np.abs(a["W"] - b["W"]).max() == 0
     assert int(b["refused"][0]) == (3 if D == 4096 else 0), int(b["refused"][0])
+
+
+CHILD_HINT_EDGES = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import videovector_amd as vv
+from videovector_amd.synth import SyntheticVideos, init_weights
+B, C, Nn, F, D = 128, 5, 10, 4096, 4096
+ds = SyntheticVideos(seed=7, n_videos=512)
+smp = vv.Sampler(ds.video_id, ds.n_shots, ds.row_base, batch_size=B, context_size=C, num_negative_samples=Nn,
+                 max_buffer_size=5000, negative_swap_percentage=50)
+W, b = init_weights(7, D, F)
+eng = vv.Engine(0, "f16")
+eng.table_synth(ds.seed, ds.n_rows, F)
+eng.params_set(W, b)
+cfg = vv.StepConfig(B, C, Nn, lr=0.05, momentum=0.9, weight_decay=5e-4)
+idx = smp.next()
+idx = idx[0] if isinstance(idx, tuple) else idx
+res = {}
+# 1. a hint whose backward call returns early (an index out of range) is consumed: the next, un-hinted step keeps its gradient and
+#    leaves the parameters alone until vv_apply_update
+bad = idx.copy(); bad[0, 0] = ds.n_rows + 5
+eng.update_hint(cfg)
+try:
+    eng.forward_backward(cfg, bad); res["bad_refused"] = 0
+except vv.VVError:
+    res["bad_refused"] = 1
+eng.forward_backward(cfg, idx)
+dW = eng.grads()[0]
+res["grad_nonzero"] = int(np.abs(dW).max() > 0)
+res["params_untouched"] = int(np.array_equal(eng.params_get()[0], W))
+eng.apply_update(cfg)
+# 2. between a hinted, fused backward pass and its update: no embedding (new half copy, old bias); vv_params_set un-sticks the context
+eng.update_hint(cfg)
+eng.forward_backward(cfg, idx)
+try:
+    eng.embed(np.arange(4, dtype=np.int32)); res["embed_refused"] = 0
+except vv.VVError:
+    res["embed_refused"] = 1
+eng.params_set(W, b)
+eng.forward_backward(cfg, idx)                    # (was refused for ever: 'call vv_apply_update first')
+eng.apply_update(cfg)
+res["after_reset_finite"] = int(np.isfinite(eng.params_get()[0]).all())
+res["embed_ok"] = int(np.isfinite(eng.embed(np.arange(4, dtype=np.int32))).all())
+np.savez(sys.argv[1], **{k: np.array([v]) for k, v in res.items()})
+"""
+
+
+def test_update_hint_edge_cases(tmp_path):
+    """a hint is consumed by the backward call that follows it even when that call returns early; vv_params_set clears a hinted
+    step that was waiting for its update; vv_embed is refused (VV_ERR_STATE) while the parameters are half-way."""
+    out = tmp_path / "edges.npz"
+    r = subprocess.run([sys.executable, "-c", CHILD_HINT_EDGES % ROOT, str(out)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    z = np.load(out)
+    for k in ("bad_refused", "grad_nonzero", "params_untouched", "embed_refused", "after_reset_finite", "embed_ok"):
+        assert int(z[k][0]) == 1, k

@@ -521,6 +521,9 @@ int vv_params_set(vv_ctx* c, int32_t D, const float* W, const float* b, const fl
   // scale for the half copy from max|W|, then convert (a scale update still pending from an earlier SGD step is void)
   c->scale_pending = false;
   c->red_lazy = false; c->grads_stale = false;   // (a gradient nobody asked for goes with the parameters it belonged to)
+  // ... and so does a hinted step that was waiting for its vv_apply_update (its half-applied update is overwritten here) and a hint not yet
+  // consumed (the context was stuck -- every later vv_forward_backward refused, vv_apply_update failing on !have_fwd)
+  c->upd_in_wgrad = false; c->upd_hint = false; c->grads_lost = false;
   HIPCHK(hipMemsetAsync(&c->scales->wmax_bits, 0, sizeof(unsigned), c->stream));
   launch_absmax(c->W, (int64_t)nW, &c->scales->wmax_bits, c->stream);
   launch_scale_update(c->prec, c->scales, nullptr, 0, c->stream);
@@ -844,6 +847,15 @@ static int upd_pending_guard(vv_ctx* c, const char* who) {
                               "first (the gradient of such a step is not kept; without the hint every call is allowed as before)", who);
   return VV_OK;
 }
+
+// "One hint covers one step": the vv_forward_backward* entry point that follows vv_update_hint consumes it even when it returns early (bad
+// arguments, no batch in the ring, a failed allocation) -- a hint left standing would apply an update, with a stale rate, in some later,
+// unrelated backward pass.  fb_impl takes the hint first; this drops what is left when the wrapper never got there.
+struct HintScope {
+  vv_ctx* c;
+  explicit HintScope(vv_ctx* c_) : c(c_) {}
+  ~HintScope() { if (c) c->upd_hint = false; }
+};
 
 int vv_update_hint(vv_ctx* c, const vv_step_cfg* cfg) {
   int rc = check_cfg(c, cfg);
@@ -1188,6 +1200,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
 }
 
 int vv_forward_backward(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int idx_on_device) {
+  HintScope hint_scope(c);
   if (idx_on_device < 0 || idx_on_device > 2) return fail(VV_ERR_ARG, "vv_forward_backward: idx_on_device must be 0, 1 or 2");
   return fb_impl(c, cfg, idx, idx_on_device, c ? c->n_rows : 0);
 }
@@ -1201,6 +1214,7 @@ int vv_forward_backward(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, i
 // step that read it has stamped its sequence number into host-visible memory.
 int vv_forward_backward_ring(vv_ctx* c, const vv_step_cfg* cfg, vv_batch_ring* ring, int32_t consumer, int32_t item_begin,
                              int32_t* label_out, double timeout_s) {
+  HintScope hint_scope(c);
   int rc = check_cfg(c, cfg);
   if (rc) return rc;
   if (!ring) return fail(VV_ERR_ARG, "vv_forward_backward_ring: ring is NULL");
@@ -1248,6 +1262,7 @@ static int ensure_scratch_rows(vv_ctx* c, int64_t need) {
 }
 
 int vv_forward_backward_q1(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, const int32_t* last_src) {
+  HintScope hint_scope(c);
   int rc = check_cfg(c, cfg);
   if (rc) return rc;
   if (!idx || !last_src) return fail(VV_ERR_ARG, "vv_forward_backward_q1: NULL index array");
@@ -1633,6 +1648,7 @@ int vv_embed(vv_ctx* c, const int32_t* rows, int64_t n, int relu, int l2norm, fl
   if (!c || !out || n <= 0) return fail(VV_ERR_ARG, "vv_embed: bad argument");
   if (!c->table || !c->W) return fail(VV_ERR_STATE, "vv_embed: table and parameters must be set first");
   if (n > (1ll << 30)) return fail(VV_ERR_ARG, "vv_embed: n too large");
+  { const int rcg = upd_pending_guard(c, "vv_embed"); if (rcg) return rcg; }     // (a hinted step half-way: new half copy, old bias)
   VV_ENTER(c);
   { const int rcj = comm_join(c); if (rcj) return rcj; }
   const int D = c->D;
@@ -1664,6 +1680,7 @@ int vv_embed_mean(vv_ctx* c, const int32_t* rows, int64_t n, int32_t k, const fl
   if (!c || !rows || !out || n <= 0 || k <= 0) return fail(VV_ERR_ARG, "vv_embed_mean: bad argument");
   if (!c->table || !c->W) return fail(VV_ERR_STATE, "vv_embed_mean: table and parameters must be set first");
   if (n > (1ll << 24)) return fail(VV_ERR_ARG, "vv_embed_mean: n too large");
+  { const int rcg = upd_pending_guard(c, "vv_embed_mean"); if (rcg) return rcg; }     // (a hinted step half-way: new half copy, old bias)
   VV_ENTER(c);
   { const int rcj = comm_join(c); if (rcj) return rcj; }
   for (int64_t i = 0; i < n * k; ++i)
@@ -1747,6 +1764,7 @@ int vv_comm_init(vv_ctx* c, int32_t world, int32_t rank, const char* id_path, in
   if (transport != VV_COMM_RCCL && transport != VV_COMM_SHM && transport != VV_COMM_PEER) return fail(VV_ERR_ARG, "vv_comm_init: unknown transport %d", transport);
   if (!c->W) return fail(VV_ERR_STATE, "vv_comm_init: set the parameters first (they size the gradient buffer)");
   if (c->comm) return fail(VV_ERR_STATE, "vv_comm_init: a communicator already exists");
+  { const int rcg = upd_pending_guard(c, "vv_comm_init"); if (rcg) return rcg; }
   VV_ENTER(c);
   std::string err;
   c->comm = vv::comm_create(world, rank, id_path ? id_path : "", transport, (size_t)c->D * c->F + c->D, &err);
@@ -1766,6 +1784,7 @@ int vv_comm_overlap(vv_ctx* c, int on) {
 int vv_comm_schedule(vv_ctx* c, int schedule) {
   if (!c) return fail(VV_ERR_ARG, "vv_comm_schedule: ctx is NULL");
   if (schedule < 0 || schedule > 2) return fail(VV_ERR_ARG, "vv_comm_schedule: 0 sync, 1 overlap, 2 sharded");
+  { const int rcg = upd_pending_guard(c, "vv_comm_schedule"); if (rcg) return rcg; }
   if (schedule != 2 && c->params_partial) { VV_ENTER(c); const int rcg = gather_params(c); if (rcg) return rcg; }     // (collective: the other schedules update the whole matrix)
   c->comm_overlap = schedule == 1;
   c->comm_sharded = schedule == 2;

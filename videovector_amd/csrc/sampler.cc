@@ -384,13 +384,21 @@ bool stage_cpu_set(cpu_set_t* out, cpu_set_t* per_stage = nullptr, int* n_per_st
 // Two samplers whose callers sit in the same group of eight (two ranks of an unbound job, two samplers of one process) must not pin their
 // stage threads to the same cores -- a spinning stage thread per core is the whole point.  A core is claimed by holding an exclusive
 // flock on /dev/shm/vv_sampler_cpu_<n> for as long as the pipeline runs (the lock dies with the descriptor, i.e. with the process).
+// The lock files: empty, one per core ever claimed on this host, never unlinked (unlinking a file another process is about to lock would
+// give two holders of "the same" core); opened READ-ONLY -- flock works on any descriptor -- and made world-readable whatever the umask,
+// so that samplers of different users on a shared host see each other's claims (as O_RDWR a second user's open failed, every
+// claim with it, and the sampler fell back to the common set without a trace but vv_sampler_stat 9 == 0).
 // -> number of cores claimed (their sets moved to the front of per_stage), descriptors in fds.
 int claim_cores(cpu_set_t* per_stage, const int* first_cpu, int n, int want, int* fds) {
   int got = 0;
   for (int i = 0; i < n && got < want; ++i) {
     char path[64];
     snprintf(path, sizeof(path), "/dev/shm/vv_sampler_cpu_%d", first_cpu[i]);
-    const int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+    int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) {
+      fd = open(path, O_CREAT | O_RDONLY | O_CLOEXEC, 0444);
+      if (fd >= 0) (void)fchmod(fd, 0444);               // (the creator's umask may have taken the others' read bit)
+    }
     if (fd < 0) continue;
     if (flock(fd, LOCK_EX | LOCK_NB) != 0) { close(fd); continue; }
     fds[got] = fd;
