@@ -52,8 +52,8 @@ def test_cfg5_dedup_equals_dense_at_full_size(setup):
 BL = 512          # configs[4] is 8 GPUs x 512 items; one rank's batch, normalised by the global count
 
 
-@pytest.mark.parametrize("prec,dropout", [("f16", 0.0), ("f16", 0.9), ("bf16", 0.0), ("bf16", 0.9)])
-def test_cfg5_whole_per_gpu_batch_against_the_oracle(setup, oracle, prec, dropout):
+@pytest.mark.parametrize("prec,dropout,h16", [("f16", 0.0, 0), ("f16", 0.9, 0), ("bf16", 0.0, 0), ("bf16", 0.9, 0), ("f16", 0.0, 1), ("bf16", 0.0, 1)])
+def test_cfg5_whole_per_gpu_batch_against_the_oracle(setup, oracle, prec, dropout, h16):
     """not a shard -- ALL 104 960 rows of one rank's batch of configs[4] (B = 512 of the global 4096, Nn = 200, 4096 -> 1024,
     loss normalised by the global count) on the engine state `bench.py --workload cfg5` times (the SECOND call of an engine: de-duplication on,
     the tile plan from the previous step's distinct-row count, four N tiles, the one-sweep score kernel; under dropout -- no per-instance masks at
@@ -73,6 +73,7 @@ def test_cfg5_whole_per_gpu_batch_against_the_oracle(setup, oracle, prec, dropou
         kw = dict(dropout_ratio=dropout, dropout_mask=(np.random.default_rng(13).random(((C + Nn) * BL, D)) > dropout).astype(np.uint8))
     lr = 0.01
     eng = vv.Engine(0, prec)
+    eng.set_option("h16", h16)                                     # (round 6: ip2 as f16 for the one-sweep score kernel and k_seg_bwd)
     eng.table_synth(ds.seed, ds.n_rows, F); eng.params_set(W, b)
     cfg = vv.StepConfig(BL, C, Nn, lr=lr, global_count=gcount, **kw)
     eng.forward_backward(cfg, sh)
@@ -87,8 +88,8 @@ def test_cfg5_whole_per_gpu_batch_against_the_oracle(setup, oracle, prec, dropou
     nz = nr > 0
     e_rows = np.linalg.norm(got["ip2"] - ref["H"], axis=1)[nz] / nr[nz]
     e_s = max(np.abs(got["target_score"] - ref["s_true"]).max(), np.abs(got["negative_scores"] - ref["s_bogus"]).max())
-    print("CFG5 whole rank batch %s dropout %.1f: %d rows (%d distinct): ip2 rows max %.2e mean %.2e, scores %.2e, loss %.7f / %.7f, violations %d / %d"
-          % (prec, dropout, rows, u, e_rows.max(), e_rows.mean(), e_s, loss, ref["loss"], viol, ref["violations"]))
+    print("CFG5 whole rank batch %s dropout %.1f h16 %d: %d rows (%d distinct): ip2 rows max %.2e mean %.2e, scores %.2e, loss %.7f / %.7f, violations %d / %d"
+          % (prec, dropout, h16, rows, u, e_rows.max(), e_rows.mean(), e_s, loss, ref["loss"], viol, ref["violations"]))
     assert nz.sum() >= 0.999 * len(nr) and np.all(got["ip2"][~nz] == 0)
     assert e_rows.max() <= tol["emb"] and e_s <= tol["score"]
     assert abs(loss - ref["loss"]) <= 1e-3 * ref["loss"]
@@ -96,8 +97,8 @@ def test_cfg5_whole_per_gpu_batch_against_the_oracle(setup, oracle, prec, dropou
     # the kernels' arithmetic against the oracle on the SAME rounded operands (tests/test_gpu_parity.py, module docstring)
     refq = oracle.forward_backward(round_table(table, prec), il, round_operand(W, prec), b, C_=C, Nn=Nn, global_count=gcount, want=("dW", "db"), **kw)
     rel = lambda a, r: float(np.linalg.norm(a - r) / np.linalg.norm(r))
-    print("CFG5 whole rank batch %s dropout %.1f: dW %.2e db %.2e vs the oracle on rounded operands; %.2e vs the fp32-operand oracle"
-          % (prec, dropout, rel(dW, refq["dW"]), rel(db, refq["db"]), rel(dW, ref["dW"])))
+    print("CFG5 whole rank batch %s dropout %.1f h16 %d: dW %.2e db %.2e vs the oracle on rounded operands; %.2e vs the fp32-operand oracle"
+          % (prec, dropout, h16, rel(dW, refq["dW"]), rel(db, refq["db"]), rel(dW, ref["dW"])))
     assert rel(dW, refq["dW"]) <= tol["grad_q"] and rel(db, refq["db"]) <= tol["grad_q"]
     assert rel(dW, ref["dW"]) <= tol["grad"]
     # the update: the solver's rule on the engine's own gradient (solver.cpp:485-576)

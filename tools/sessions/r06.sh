@@ -54,21 +54,74 @@ for task in "$@"; do
       echo "arms: ${AB_ENVS}"; summ $O/r06_${TAG}_ab*.json ;;
     gputests)   # the GPU parity suite (TESTS = a -k expression or file list; default: everything marked gpu)
       timeout 3000 python -m pytest ${TESTS:-tests} -x -q -m gpu > $O/r06_${TAG}_gputests.txt 2>&1; tail -15 $O/r06_${TAG}_gputests.txt ;;
+    tests_s)    # selected GPU tests with their printed figures: TESTS = files, KEXPR = a -k expression
+      timeout 3000 python -m pytest $TESTS -x -q -s -m gpu -k "${KEXPR:-test}" > $O/r06_${TAG}_tests_s.txt 2>&1; grep -v '^$' $O/r06_${TAG}_tests_s.txt | grep -i 'FULLBATCH\|CFG5\|passed\|failed\|error' | tail -40 ;;
+    ab5)        # the same A/B on the per-GPU work of BASELINE configs[4] (batch 4096, 200 negatives, 4096 -> 1024)
+      IFS='|' read -ra ARMS <<< "${AB_ENVS:-|}"
+      for i in 1 2; do
+        n=0
+        for arm in "${ARMS[@]}"; do
+          env $arm timeout 900 python bench.py --workload cfg5 --no-extra-legs --no-cpu-baseline --steps 30 --warmup 5 > $O/r06_${TAG}_ab5_${n}_$i.json 2>> $O/r06_${TAG}_bench.err
+          n=$((n + 1))
+        done
+      done
+      echo "arms: ${AB_ENVS}"; summ $O/r06_${TAG}_ab5_*.json ;;
     smoke)
       timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/r06_${TAG}_smoke.txt 2>&1; tail -5 $O/r06_${TAG}_smoke.txt ;;
     cfg5)
       timeout 900 python bench.py --workload cfg5 --steps 30 --warmup 5 --no-cpu-baseline > $O/r06_${TAG}_bench_cfg5.json 2>> $O/r06_${TAG}_bench.err; summ $O/r06_${TAG}_bench_cfg5.json ;;
     shipped)
       timeout 900 python bench.py --workload shipped --steps 200 --warmup 20 --no-cpu-baseline > $O/r06_${TAG}_bench_shipped.json 2>> $O/r06_${TAG}_bench.err; summ $O/r06_${TAG}_bench_shipped.json ;;
-    prof)       # rocprofv3 kernel trace + stats of the default step (cd /tmp first: the profiler writes beside the cwd)
-      R=$PWD; ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $R/$O/r06_${TAG}_prof -o trace -- python3 $R/bench.py --no-extra-legs --no-cpu-baseline --steps 600 > $R/$O/r06_${TAG}_prof_bench.json 2> $R/$O/r06_${TAG}_prof.err )
-      find $O/r06_${TAG}_prof -name '*kernel_stats.csv' | head -1 | xargs -r head -12 ;;
-    pmc)        # HBM traffic per kernel: separate passes (FETCH_SIZE / WRITE_SIZE do not fit one)
-      R=$PWD
-      for ctr in FETCH_SIZE WRITE_SIZE; do
-        ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $ctr -d $R/$O/r06_${TAG}_pmc_$ctr -o pmc -- python3 $R/bench.py --no-extra-legs --no-cpu-baseline --steps 60 --warmup 5 --settle-ms 0 > /dev/null 2> $R/$O/r06_${TAG}_pmc_$ctr.err )
+    final)      # the closing session: bench legs, rocprofv3 kernel trace + HBM PMC passes (dedup on / off), SQ counters, sampler rates, facade rate
+      P0=$O/r06_${TAG}
+      timeout 900 python bench.py > ${P0}_bench.json 2> ${P0}_bench.err; echo "bench exit $?" >> ${P0}_bench.err
+      timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > ${P0}_bench_driver_args.json 2>> ${P0}_bench.err
+      timeout 600 python bench.py --dedup off --no-cpu-baseline --no-extra-legs > ${P0}_bench_dense.json 2>> ${P0}_bench.err
+      timeout 600 python bench.py --prec bf16 --no-cpu-baseline --no-extra-legs > ${P0}_bench_bf16.json 2>> ${P0}_bench.err
+      timeout 600 python bench.py --workload cfg5 --no-cpu-baseline --no-extra-legs --steps 40 --warmup 5 > ${P0}_bench_cfg5.json 2>> ${P0}_bench.err
+      timeout 600 python bench.py --workload shipped --steps 200 --warmup 20 --no-cpu-baseline > ${P0}_bench_shipped.json 2>> ${P0}_bench.err
+      rm -rf $O/prof_r06_${TAG} && mkdir -p $O/prof_r06_${TAG}
+      for mode in on off; do
+        P=$O/prof_r06_${TAG}/dedup_${mode}
+        timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -o kt -- python3 bench.py --steps 400 --warmup 5 --no-cpu-baseline --no-extra-legs --dedup $mode > ${P0}_prof_trace_${mode}.log 2>&1
+        timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $P/pmc_fetch -o pf -- python3 bench.py --steps 6 --warmup 2 --settle-ms 0 --no-cpu-baseline --no-extra-legs --dedup $mode > ${P0}_prof_fetch_${mode}.log 2>&1
+        timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $P/pmc_write -o pw -- python3 bench.py --steps 6 --warmup 2 --settle-ms 0 --no-cpu-baseline --no-extra-legs --dedup $mode > ${P0}_prof_write_${mode}.log 2>&1
+        python3 tools/summarize_prof.py $P > ${P0}_kernel_trace_and_pmc_summary_dedup_${mode}.txt 2>&1
+        cp $(find $P/trace -name "*kernel_stats.csv" | head -1) ${P0}_kernel_stats_dedup_${mode}.csv
       done
-      python3 tools/make_pmc_json.py $O/r06_${TAG}_pmc_FETCH_SIZE $O/r06_${TAG}_pmc_WRITE_SIZE > $O/r06_${TAG}_pmc.json 2> $O/r06_${TAG}_pmc_json.err; head -c 1500 $O/r06_${TAG}_pmc.json ;;
+      python3 tools/make_pmc_json.py $O/prof_r06_${TAG} > ${P0}_pmc.json 2> ${P0}_pmc.err
+      i=0
+      for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
+                 "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" \
+                 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS"; do
+        i=$((i+1))
+        timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/prof_r06_${TAG}/sq_on_$i -o sq -- python3 bench.py --steps 6 --warmup 2 --settle-ms 0 --no-cpu-baseline --no-extra-legs > ${P0}_sq_on_$i.log 2>&1
+      done
+      PROFDIR=$O/prof_r06_${TAG} python3 - > ${P0}_sq_counters_summary.txt <<'PY'
+import csv, glob, collections, os
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(os.environ["PROFDIR"] + "/sq_on_*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        n = r["Kernel_Name"].split("(")[0]
+        for k in ("k_fwd_gemm", "k_wgrad_gemm", "k_score_fwd", "k_seg_bwd", "k_reduce_sgd"):
+            if k in n:
+                acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+print("== dedup on (the default step)")
+for k, cs in acc.items():
+    print(k, " ".join("%s=%.4g" % (c, sum(v) / len(v)) for c, v in sorted(cs.items())))
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in cs and "SQ_BUSY_CYCLES" in cs:
+        mf = sum(cs["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(cs["SQ_VALU_MFMA_BUSY_CYCLES"])
+        bz = sum(cs["SQ_BUSY_CYCLES"]) / len(cs["SQ_BUSY_CYCLES"])
+        print("   kernel cycles %.0f, matrix pipe busy per SIMD = %.3f" % (bz / 32, mf / (bz / 32 * 1024)))
+PY
+      python3 tools/samp_rates.py 10 ${P0}_sampler_rates.json > ${P0}_sampler_rates.txt 2>&1
+      bash tools/facade_rate.sh > ${P0}_facade_rate.txt 2>&1
+      (lscpu | head -25; nproc; echo "cgroup cpu.max: $(cat /sys/fs/cgroup/cpu.max 2>/dev/null)"; uptime) > ${P0}_host_cpu.txt 2>&1
+      find $O/prof_r06_${TAG} -name "*kernel_trace.csv" -size +1M -delete
+      find $O/prof_r06_${TAG} -name "*counter_collection.csv" -size +1M -delete
+      summ ${P0}_bench.json ${P0}_bench_driver_args.json ${P0}_bench_dense.json ${P0}_bench_bf16.json ${P0}_bench_cfg5.json ${P0}_bench_shipped.json
+      grep -E "k_fwd|k_wgrad|k_score|k_reduce|k_sgd|k_seg|k_dd" ${P0}_kernel_trace_and_pmc_summary_dedup_on.txt | head -24
+      cut -c1-300 ${P0}_sq_counters_summary.txt ;;
     *) echo "unknown task $task" ;;
   esac
 done

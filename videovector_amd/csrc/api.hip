@@ -140,6 +140,7 @@ static int create_init(vv_ctx* c) {
   if (const char* v = opt_env("VV_FWD_MERGE")) c->ko.fwd_merge = atoi(v);
   if (const char* v = opt_env("VV_SCORE_STREAM")) c->ko.score_stream = atoi(v);
   if (const char* v = opt_env("VV_SEG_BWD")) c->seg_bwd = atoi(v) != 0;
+  if (const char* v = opt_env("VV_H16")) c->h16 = atoi(v) != 0;
   if (const char* v = opt_env("VV_DEDUP")) c->dedup = atoi(v) != 0;
   if (const char* v = opt_env("VV_FUSE_UPDATE")) c->fuse_update = atoi(v) != 0;
   if (const char* v = opt_env("VV_DROP_DEDUP")) c->drop_dedup = atoi(v) != 0;
@@ -287,6 +288,7 @@ int vv_set_option(vv_ctx* c, const char* name, double value) {
   if (n == "dedup") return vv_set_dedup(c, iv);
   if (n == "seg_bwd") { c->seg_bwd = iv != 0; return VV_OK; }
   if (n == "drop_dedup") { c->drop_dedup = iv != 0; return VV_OK; }
+  if (n == "h16") { c->h16 = iv != 0; return VV_OK; }
   if (n == "fuse_update") { c->fuse_update = iv != 0; return VV_OK; }
   if (n == "fwd_lead") { c->ko.fwd_lead = iv; return VV_OK; }
   if (n == "fwd_merge") { c->ko.fwd_merge = iv; return VV_OK; }
@@ -314,6 +316,7 @@ int vv_get_option(vv_ctx* c, const char* name, double* value) {
   if (n == "dedup") *value = c->dedup;
   else if (n == "seg_bwd") *value = c->seg_bwd;
   else if (n == "drop_dedup") *value = c->drop_dedup;
+  else if (n == "h16") *value = c->h16;
   else if (n == "fuse_update") *value = c->fuse_update;
   else if (n == "fwd_lead") *value = c->ko.fwd_lead;
   else if (n == "fwd_merge") *value = c->ko.fwd_merge;
@@ -964,6 +967,12 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   fa.R_hint = dd ? *(volatile int32_t*)c->U_host : 0;
   fa.seq_host = c->seq_host_dev; fa.seq = seq;
 
+  // ip2 as f16 (option "h16"): only where the segment-wise pair reads it -- de-duplicated batches of D = 512 / 1024 (k_score_fwd / k_score_stream /
+  // k_seg_bwd carry the f16 row loads; the dense and the generic kernels keep fp32 rows), D % 8 == 0, the phase-staggered forward kernel
+  const bool seg_path = dd && c->seg_bwd && (D == 512 || D == 1024);
+  const bool h16 = c->h16 && seg_path && gemm_variant() == 5 && !ablate_on();
+  fa.h16 = h16 ? 1 : 0;
+  c->last_h16 = h16;
   fa.drop_ratio = (dd && drop_on) ? 0.f : cfg->dropout_ratio;      // (de-duplicated: H holds the shared pre-dropout rows, the instances mask them)
   fa.mask = (!(dd && drop_on) && cfg->dropout_ratio > 0.f && cfg->dropout_mask) ? c->mask : nullptr;
   fa.drop_seed = cfg->dropout_seed * 0x9E3779B97F4A7C15ull + c->iter;
@@ -1050,6 +1059,8 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   // de-duplicated batches of the supported shape: the backward stays factored per instance and is summed per distinct
   // row (k_score_fwd + k_seg_bwd); otherwise per-instance 16-bit gradient rows (+ k_segsum when de-duplicated)
   const bool seg = dd && c->seg_bwd && score_fwd_supported(sa);
+  if (seg != seg_path) return fail(VV_ERR_STATE, "internal error: the forward pass was planned for %s rows of ip2, the score kernels expect the other form", h16 ? "f16" : "fp32");
+  sa.h16 = h16 ? 1 : 0;
   c->last_seg_bwd = seg; c->last_score = sa;
   // f16 gradient-scale guard (vv_internal.h: GradGuard): the kernels that round gradients to 16 bits are launched once as
   // usual (round 0) and once more per guard round as conditional repeats -- near-empty launches unless the round before
@@ -1079,7 +1090,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
 #endif
     if (gd.gg && proactive) { sa.bound_out = c->gg_bound; sa.bound_seq = seq; }
     ba.H = c->H; ba.V = c->segV; ba.rec = c->seg_rec; ba.seg_start = c->dd_seg; ba.info = c->dd_info; ba.dYu = c->dYu;
-    ba.dbp = c->seg_dbp; ba.Rp = c->Rp; ba.D = D; ba.Dp = c->Dp; ba.inv_sg = 1.f / c->sg;
+    ba.dbp = c->seg_dbp; ba.Rp = c->Rp; ba.D = D; ba.Dp = c->Dp; ba.inv_sg = 1.f / c->sg; ba.h16 = h16 ? 1 : 0;
     if (drop_on) ba.drop = dsp;
   } else if (dd) {
     ga.dYh = c->dYh; ga.seg_start = c->dd_seg; ga.info = c->dd_info; ga.dYu = c->dYu; ga.Rp = c->Rp; ga.Dp = c->Dp;
@@ -1571,8 +1582,8 @@ int vv_blobs_get(vv_ctx* c, float* ip2, float* target_score, float* negative_sco
     if (c->last_dedup) {               // expand the per-slot rows back to one row per instance
       DevTmp<float> d;
       HIPCHK(d.alloc(n));
-      if (c->last_drop.mode) launch_gather_rows_dropout(c->H, c->dd_map, c->R, D, c->last_drop, d, c->stream);    // the instance's own mask on the shared row
-      else launch_gather_rows_f32(c->H, c->dd_map, c->R, D, d, c->stream);
+      if (c->last_drop.mode) launch_gather_rows_dropout(c->H, c->dd_map, c->R, D, c->last_drop, d, c->stream, c->last_h16);    // the instance's own mask on the shared row
+      else launch_gather_rows_f32(c->H, c->dd_map, c->R, D, d, c->stream, c->last_h16);
       HIPCHK(hipStreamSynchronize(c->stream));
       HIPCHK(hipMemcpy(tmp.data(), d, n * 4, hipMemcpyDeviceToHost));
     } else {
@@ -1599,15 +1610,17 @@ int vv_blobs_get(vv_ctx* c, float* ip2, float* target_score, float* negative_sco
     }
     DevTmp<float> yrows; DevTmp<uint16_t> dyrows;
     bool expanded = false;
-    if (c->last_seg_bwd && c->last_drop.mode) {
+    if (c->last_seg_bwd && (c->last_drop.mode || c->last_h16)) {
       // ... with dropout: the instances' masked rows are materialised (item-major) and the per-instance kernel runs on them as on a
       // dense batch whose forward pass applied the mask -- its gradient rows come out per instance, nothing to ungroup
+      // (... and with ip2 stored as f16: the per-instance kernel reads fp32 rows -- the instances' rows are materialised as such)
       HIPCHK(yrows.alloc(n));
       HIPCHK(dyrows.alloc((size_t)(c->Rp + BK) * c->Dp));
-      launch_gather_rows_dropout(c->H, c->dd_map, c->R, D, c->last_drop, yrows, c->stream);
+      if (c->last_drop.mode) launch_gather_rows_dropout(c->H, c->dd_map, c->R, D, c->last_drop, yrows, c->stream, c->last_h16);
+      else launch_gather_rows_f32(c->H, c->dd_map, c->R, D, yrows, c->stream, c->last_h16);
       ScoreArgs la = c->last_score;
       la.H = yrows; la.dYh = dyrows; la.map = nullptr; la.seg_start = nullptr; la.ord = nullptr; la.V = nullptr; la.rec = nullptr;
-      la.drop = DropSpec(); la.bound_out = nullptr;
+      la.drop = DropSpec(); la.bound_out = nullptr; la.h16 = 0;
       la.sg = sgf; la.guard = GuardArgs();
       launch_score_loss(c->prec, la, c->stream);
       expanded = true;

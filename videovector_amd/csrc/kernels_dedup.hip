@@ -232,30 +232,39 @@ void launch_segsum(int prec, const SegsumArgs& a, hipStream_t s) {
   else VV_LAUNCH(k_segsum<BF16>, grid, block, 0, s, a);
 }
 
-// debug / parity accessors: expand per-slot rows back to per-instance rows
+// debug / parity accessors: expand per-slot rows back to per-instance rows (H16: the source rows are f16, FwdArgs::h16)
+template <bool H16>
 __global__ __launch_bounds__(256) void k_gather_rows_f32(const float* src, const int32_t* map, int R, int D, float* dst) {
   const int r = blockIdx.x;
-  const float* sp = src + (int64_t)map[r] * D;
-  for (int d = threadIdx.x; d < D; d += 256) dst[(int64_t)r * D + d] = sp[d];
+  const int64_t so = (int64_t)(map ? map[r] : r) * D;
+  for (int d = threadIdx.x; d < D; d += 256) dst[(int64_t)r * D + d] = H16 ? (float)((const _Float16*)src)[so + d] : src[so + d];
 }
 // ... with the instance's dropout mask applied (de-duplicated execution with dropout: src holds the shared pre-dropout rows); instance
 // r = b CN + ch, its mask is that of the reference's row ch B + b (DropSpec)
+template <bool H16>
 __global__ __launch_bounds__(256) void k_gather_rows_dropout(const float* src, const int32_t* map, int R, int D, DropSpec dr, float* dst) {
   const int r = blockIdx.x;
   const int bb = r / dr.CN, ch = r - bb * dr.CN;
   const int64_t rr = (int64_t)ch * dr.B + bb;
   const uint32_t rc = drop_row_ctr(rr, D, dr.s32);
-  const float* sp = src + (int64_t)map[r] * D;
+  const int64_t so = (int64_t)(map ? map[r] : r) * D;
   for (int d = threadIdx.x * 4; d < D; d += 1024) {
     const uint32_t kp = drop_keep4(dr, rr, rc, d);
-    for (int j = 0; j < 4 && d + j < D; ++j) dst[(int64_t)r * D + d + j] = ((kp >> j) & 1u) ? sp[d + j] * dr.scale : 0.f;
+    for (int j = 0; j < 4 && d + j < D; ++j) {
+      const float x = H16 ? (float)((const _Float16*)src)[so + d + j] : src[so + d + j];
+      dst[(int64_t)r * D + d + j] = ((kp >> j) & 1u) ? x * dr.scale : 0.f;
+    }
   }
 }
-void launch_gather_rows_dropout(const float* src, const int32_t* map, int R, int D, const DropSpec& dr, float* dst, hipStream_t s) {
-  if (R > 0) hipLaunchKernelGGL(k_gather_rows_dropout, dim3(R), dim3(256), 0, s, src, map, R, D, dr, dst);
+void launch_gather_rows_dropout(const float* src, const int32_t* map, int R, int D, const DropSpec& dr, float* dst, hipStream_t s, int h16) {
+  if (R <= 0) return;
+  if (h16) hipLaunchKernelGGL(k_gather_rows_dropout<true>, dim3(R), dim3(256), 0, s, src, map, R, D, dr, dst);
+  else hipLaunchKernelGGL(k_gather_rows_dropout<false>, dim3(R), dim3(256), 0, s, src, map, R, D, dr, dst);
 }
-void launch_gather_rows_f32(const float* src, const int32_t* map, int R, int D, float* dst, hipStream_t s) {
-  if (R > 0) hipLaunchKernelGGL(k_gather_rows_f32, dim3(R), dim3(256), 0, s, src, map, R, D, dst);
+void launch_gather_rows_f32(const float* src, const int32_t* map, int R, int D, float* dst, hipStream_t s, int h16) {
+  if (R <= 0) return;
+  if (h16) hipLaunchKernelGGL(k_gather_rows_f32<true>, dim3(R), dim3(256), 0, s, src, map, R, D, dst);
+  else hipLaunchKernelGGL(k_gather_rows_f32<false>, dim3(R), dim3(256), 0, s, src, map, R, D, dst);
 }
 __global__ __launch_bounds__(256) void k_gather_rows_u16(const uint16_t* src, const int32_t* pos, int R, int Dp, uint16_t* dst) {
   const int r = blockIdx.x;

@@ -513,12 +513,35 @@ static bool launch_score_loss_reg(const ScoreArgs& a, hipStream_t s) {
   return true;
 }
 
+// ---- rows of H as fp32 or as f16 (round 6, FwdArgs::h16 / ScoreArgs::h16).  The kernels below hold a row as float4 pieces per lane; which
+// columns a piece covers depends on the storage: fp32 rows are read 16 bytes = 4 columns per lane and piece (piece v: columns lane 4 + 256 v),
+// f16 rows 16 bytes = 8 columns per lane (pieces 2 w, 2 w + 1: columns 512 w + lane 8 .. + 3 and + 4 .. + 7) -- 8-byte row loads run at ~0.6 of the
+// 16-byte rate per byte (profiles/r04_h16_intermediate.txt).  h_col: first column of piece v; h_row: the DV pieces of one row.
+template <bool H16> __device__ __forceinline__ int h_col(int lane, int v) { return H16 ? (v >> 1) * 512 + lane * 8 + (v & 1) * 4 : lane * 4 + v * 256; }
+template <bool H16> __device__ __forceinline__ float h_at(const float* H, int64_t i) { return H16 ? (float)((const _Float16*)H)[i] : H[i]; }
+template <bool H16, int DV> __device__ __forceinline__ void h_row(const float* H, int64_t row, int D, int lane, float4* x) {
+  if constexpr (H16) {
+    static_assert(DV % 2 == 0, "f16 rows are read 8 columns at a time");
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const _Float16* hp = (const _Float16*)H + row * D + lane * 8;
+#pragma unroll
+    for (int w = 0; w < DV / 2; ++w) {
+      const h8 q = *(const h8*)(hp + 512 * w);
+      x[2 * w] = make_float4((float)q[0], (float)q[1], (float)q[2], (float)q[3]);
+      x[2 * w + 1] = make_float4((float)q[4], (float)q[5], (float)q[6], (float)q[7]);
+    }
+  } else {
+#pragma unroll
+    for (int v = 0; v < DV; ++v) x[v] = *(const float4*)(H + row * D + lane * 4 + v * 256);
+  }
+}
+
 // ---- segment-wise backward, pass 1: k_score_loss_reg without the per-instance gradient rows.  Forward as there; the
 // backward stops at the factored form (vv_internal.h: SegRec): one record per instance, Ah_b and dA_b per item.
 // (Sixteen waves per item, four rows per wave -- one item per CU at a time instead of two items of eight waves: 36 against 25 us, round 4.)
 // DROP (ScoreArgs::drop): the rows of H are the shared PRE-dropout projections; every instance applies its own mask (and 1 / (1 - ratio))
 // as its row arrives, and everything behind that -- norms, scores, records -- is the reference's graph on the masked rows.
-template <int NW, int RPW, int DV, bool DROP = false>
+template <int NW, int RPW, int DV, bool DROP = false, bool H16 = false>
 __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int THREADS = 64 * NW;
@@ -555,7 +578,7 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
     const int r = b * CN + (j + 1 < C ? j + 1 : 0);
     const int hr = a.map[r];
 #pragma unroll
-    for (int v = 0; v < CV; ++v) cx[j][v] = j + 1 < C ? a.H[(int64_t)hr * D + tid + v * THREADS] : 0.f;
+    for (int v = 0; v < CV; ++v) cx[j][v] = j + 1 < C ? h_at<H16>(a.H, (int64_t)hr * D + tid + v * THREADS) : 0.f;
     if (DROP && j + 1 < C) {
       const int64_t rr = (int64_t)(j + 1) * a.B + b;
       const uint32_t rc = drop_row_ctr(rr, D, a.drop.s32);
@@ -582,15 +605,17 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
         x[k][v] = (qi <= Nn && !(a.lab_hack == 2 && v > 0)) ? *(const float4*)(a.H + (int64_t)hr * rs + lane * 4 + v * 256) : make_float4(1.f, 0.f, 0.f, 0.f);
     } else
 #endif
+    {
+      h_row<H16, DV>(a.H, hr, D, lane, x[k]);          // (always a valid row: channel 0 stands in past the item's last negative)
 #pragma unroll
-    for (int v = 0; v < DV; ++v)
-      x[k][v] = qi <= Nn ? *(const float4*)(a.H + (int64_t)hr * D + lane * 4 + v * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int v = 0; v < DV; ++v) x[k][v] = qi <= Nn ? x[k][v] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if (DROP && qi <= Nn) {
       const int64_t rr = (int64_t)ch * a.B + b;                    // the instance's row in the reference's order
       const uint32_t rc = drop_row_ctr(rr, D, a.drop.s32);
 #pragma unroll
       for (int v = 0; v < DV; ++v) {
-        const uint32_t kp = drop_keep4(a.drop, rr, rc, lane * 4 + v * 256);
+        const uint32_t kp = drop_keep4(a.drop, rr, rc, h_col<H16>(lane, v));
         x[k][v].x = (kp & 1u) ? x[k][v].x * a.drop.scale : 0.f; x[k][v].y = (kp & 2u) ? x[k][v].y * a.drop.scale : 0.f;
         x[k][v].z = (kp & 4u) ? x[k][v].z * a.drop.scale : 0.f; x[k][v].w = (kp & 8u) ? x[k][v].w * a.drop.scale : 0.f;
       }
@@ -629,7 +654,7 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
   // ---- norms and dots from registers
   float4 y[DV];
 #pragma unroll
-  for (int v = 0; v < DV; ++v) y[v] = *(const float4*)(Ah + lane * 4 + v * 256);
+  for (int v = 0; v < DV; ++v) y[v] = *(const float4*)(Ah + h_col<H16>(lane, v));
 #pragma unroll
   for (int k = 0; k < RPW; ++k) {
     const int qi = wave + NW * k;
@@ -698,7 +723,7 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
     }
   }
 #pragma unroll
-  for (int v = 0; v < DV; ++v) *(float4*)(acc0 + wave * D + lane * 4 + v * 256) = pa[v];
+  for (int v = 0; v < DV; ++v) *(float4*)(acc0 + wave * D + h_col<H16>(lane, v)) = pa[v];
   if (tid < C - 1) {
     SegRec rc; rc.alpha = a.coeff[tid] * a.drop_scale * a.sg; rc.beta = 0.f; rc.vec = 2 * b + 1; rc.pad = b * CN + tid + 1;
     a.rec[ooff[tid + 1]] = rc;
@@ -755,7 +780,7 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
 }
 
 #ifdef VV_LAB
-// (lab build only: tools/lab/score_fwd_pipelined.hip.txt -- not adopted)
+// (lab build only: profiles/attic/score_fwd_pipelined.hip.txt -- not adopted)
 // ---- k_score_fwd, PERSISTENT AND PIPELINED (round 5).  k_score_fwd's own phase stamps (profiles/r05_score_fwd_stamps.txt): a workgroup lives
 // 11.6 us of which 8.9 us are the wait for its rows (index load -> 110 KB of rows) and 2.8 us its five compute phases; the 1024 workgroups
 // run as two rounds of 512 that start together, so the chip alternates between everybody loading and everybody computing.  Here one
@@ -1008,7 +1033,7 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd_p(ScoreArgs a) {
 // 2.26 ms cfg-5 step; this kernel 0.47 ms.)  Sums in a fixed order: a wave's rows in sequence, then the waves in sequence.
 // (DV = 4 sits at the edge of 128 VGPRs: two workgroups per CU need 4 waves per SIMD -- the gradient bound's two registers
 // pushed it to 131 and one workgroup per CU, 0.47 -> 0.70 ms at cfg 5; the second launch bound holds it at 128)
-template <int NW, int DV>
+template <int NW, int DV, bool H16 = false>
 __global__ __launch_bounds__(64 * NW, DV == 4 ? 4 : 1) void k_score_stream(ScoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int THREADS = 64 * NW;
@@ -1030,7 +1055,7 @@ __global__ __launch_bounds__(64 * NW, DV == 4 ? 4 : 1) void k_score_stream(Score
   for (int v = 0; v < CV; ++v) {
     const int d = tid + v * THREADS;
     float sx = 0.f;
-    for (int j = 1; j < C; ++j) sx += a.coeff[j - 1] * a.H[(int64_t)map[j] * D + d];
+    for (int j = 1; j < C; ++j) sx += a.coeff[j - 1] * h_at<H16>(a.H, (int64_t)map[j] * D + d);
     A[d] = sx;
     ssq += sx * sx;
   }
@@ -1047,13 +1072,9 @@ __global__ __launch_bounds__(64 * NW, DV == 4 ? 4 : 1) void k_score_stream(Score
   __syncthreads();
   float4 y[DV];
 #pragma unroll
-  for (int v = 0; v < DV; ++v) y[v] = *(const float4*)(Ah + lane * 4 + v * 256);
+  for (int v = 0; v < DV; ++v) y[v] = *(const float4*)(Ah + h_col<H16>(lane, v));
 
-  auto load_row = [&](int ch, float4* x) {
-    const float* h = a.H + (int64_t)map[ch] * D + lane * 4;
-#pragma unroll
-    for (int v = 0; v < DV; ++v) x[v] = *(const float4*)(h + v * 256);
-  };
+  auto load_row = [&](int ch, float4* x) { h_row<H16, DV>(a.H, map[ch], D, lane, x); };
   // norm^2 and dot with Ah of a row held in registers; both totals in every lane
   auto norm_dot = [&](const float4* x, float& s, float& t) {
     float ps = 0.f, pt = 0.f;
@@ -1141,7 +1162,7 @@ __global__ __launch_bounds__(64 * NW, DV == 4 ? 4 : 1) void k_score_stream(Score
     }
   }
 #pragma unroll
-  for (int v = 0; v < DV; ++v) *(float4*)(acc0 + wave * D + lane * 4 + v * 256) = pa[v];
+  for (int v = 0; v < DV; ++v) *(float4*)(acc0 + wave * D + h_col<H16>(lane, v)) = pa[v];
   for (int j = 1 + tid; j < C; j += THREADS) {
     SegRec rc; rc.alpha = a.coeff[j - 1] * a.drop_scale * a.sg; rc.beta = 0.f; rc.vec = 2 * b + 1; rc.pad = b * CN + j;
     a.rec[a.seg_start[map[j]] + ord[j]] = rc;
@@ -1194,13 +1215,14 @@ void launch_score_fwd(const ScoreArgs& a_in, hipStream_t s) {
   const int rows = 1 + a.Nn;
   if (!(a.D == 512 && a.C - 1 <= 6 && rows <= 56) || ko().score_stream == 1) {
     const size_t lds = sizeof(float) * ((size_t)(2 + 8) * a.D + 4 * 8);
-    if (a.D == 512) {
-      (void)hipFuncSetAttribute((const void*)k_score_stream<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      VV_LAUNCH((k_score_stream<8, 2>), dim3(a.B), dim3(512), lds, s, a);
-    } else {
-      (void)hipFuncSetAttribute((const void*)k_score_stream<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      VV_LAUNCH((k_score_stream<8, 4>), dim3(a.B), dim3(512), lds, s, a);
-    }
+#define VV_SS(DV, H16)                                                                                     \
+    do {                                                                                                  \
+      (void)hipFuncSetAttribute((const void*)k_score_stream<8, DV, H16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      VV_LAUNCH((k_score_stream<8, DV, H16>), dim3(a.B), dim3(512), lds, s, a);                            \
+    } while (0)
+    if (a.D == 512) { if (a.h16) VV_SS(2, true); else VV_SS(2, false); }
+    else { if (a.h16) VV_SS(4, true); else VV_SS(4, false); }
+#undef VV_SS
     return;
   }
   const size_t lds = sizeof(float) * ((size_t)(2 + 8) * a.D + 4 * (a.C + a.Nn) + 3 * 8);
@@ -1220,22 +1242,34 @@ void launch_score_fwd(const ScoreArgs& a_in, hipStream_t s) {
     return;
   }
 #endif
+#define VV_SF1(RPW, DROP, H16)                                                                            \
+  do {                                                                                                    \
+    (void)hipFuncSetAttribute((const void*)k_score_fwd<8, RPW, 2, DROP, H16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    VV_LAUNCH((k_score_fwd<8, RPW, 2, DROP, H16>), dim3(a.B), dim3(512), lds, s, a);                       \
+  } while (0)
 #define VV_SF(RPW)                                                                                        \
   do {                                                                                                    \
-    if (a.drop.mode) {                                                                                    \
-      (void)hipFuncSetAttribute((const void*)k_score_fwd<8, RPW, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      VV_LAUNCH((k_score_fwd<8, RPW, 2, true>), dim3(a.B), dim3(512), lds, s, a);                          \
-    } else {                                                                                              \
-      (void)hipFuncSetAttribute((const void*)k_score_fwd<8, RPW, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      VV_LAUNCH((k_score_fwd<8, RPW, 2>), dim3(a.B), dim3(512), lds, s, a);                                \
-    }                                                                                                     \
+    if (a.drop.mode) { if (a.h16) VV_SF1(RPW, true, true); else VV_SF1(RPW, true, false); }               \
+    else { if (a.h16) VV_SF1(RPW, false, true); else VV_SF1(RPW, false, false); }                         \
   } while (0)
   if (rows <= 16) VV_SF(2);
   else if (rows <= 32) VV_SF(4);
   else VV_SF(7);
 #undef VV_SF
+#undef VV_SF1
 }
 
+// eight consecutive columns of a row of H (fp32: two 16-byte loads; f16, SegBwdArgs::h16: one)
+template <bool H16> __device__ __forceinline__ void seg_row8(const float* H, int64_t i, float4& lo, float4& hi) {
+  if constexpr (H16) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const h8 q = *(const h8*)((const _Float16*)H + i);
+    lo = make_float4((float)q[0], (float)q[1], (float)q[2], (float)q[3]);
+    hi = make_float4((float)q[4], (float)q[5], (float)q[6], (float)q[7]);
+  } else {
+    lo = *(const float4*)(H + i); hi = *(const float4*)(H + i + 4);
+  }
+}
 // ---- segment-wise backward, pass 2: one wave per distinct row, a lane owns 8 consecutive columns (D = 512).
 // Persistent grid: wave w of block g takes rows 4 g + w, + 4 SEGB_BLOCKS, ...; the column sums of the rows it produced
 // (the bias gradient) leave as one partial row per block.
@@ -1248,7 +1282,7 @@ void launch_score_fwd(const ScoreArgs& a_in, hipStream_t s) {
 // DROP (SegBwdArgs::drop, CH == 1): every instance carries its own dropout mask m_i over the shared row:
 //   dx_u = [x_u > 0] (sum_i m_i alpha_i V_i - x_u scale sum_i m_i beta_i)        (alpha, beta already carry one factor scale)
 // -- the mask regenerated per instance from its reference row (b = vec / 2, ch = pad - b CN), the beta sum per column.
-template <typename T, int CH, bool DROP = false>
+template <typename T, int CH, bool DROP = false, bool H16 = false>
 __global__ __launch_bounds__(256) void k_seg_bwd(SegBwdArgs a) {
   static_assert(!DROP || CH == 1, "dropout rides the D = 512 form");
   __shared__ float cs[4][512 * CH];
@@ -1297,10 +1331,7 @@ __global__ __launch_bounds__(256) void k_seg_bwd(SegBwdArgs a) {
     float4 xr0[CH], xr1[CH];
     if (CH == 1) {                                    // (D = 1024 with its long segments: the early row costs more in registers than it hides -- 0.437 -> 0.473 ms at cfg 5)
 #pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        const float* xp = a.H + (int64_t)u * D + 512 * c + c0;
-        xr0[c] = *(const float4*)xp; xr1[c] = *(const float4*)(xp + 4);      // (as non-temporal loads: no gain, profiles/r03_step_ablations.txt 5d)
-      }
+      for (int c = 0; c < CH; ++c) seg_row8<H16>(a.H, (int64_t)u * D + 512 * c + c0, xr0[c], xr1[c]);      // (as non-temporal loads: no gain, profiles/r03_step_ablations.txt 5d)
     }
     if (u + u_step < U) { seg_b = a.seg_start[u + u_step]; seg_e = a.seg_start[u + u_step + 1]; }
     float acc[CH][8];
@@ -1433,10 +1464,7 @@ __global__ __launch_bounds__(256) void k_seg_bwd(SegBwdArgs a) {
     }
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      if (CH != 1) {
-        const float* xp = a.H + (int64_t)u * D + 512 * c + c0;
-        xr0[c] = *(const float4*)xp; xr1[c] = *(const float4*)(xp + 4);
-      }
+      if (CH != 1) seg_row8<H16>(a.H, (int64_t)u * D + 512 * c + c0, xr0[c], xr1[c]);
       const float4 x0 = xr0[c], x1 = xr1[c];
       const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
       float g[8];
@@ -1471,14 +1499,14 @@ void launch_seg_bwd(int prec, const SegBwdArgs& a, hipStream_t s) {
   const int ch = a.D / 512;
   // (a conditional repeat of the gradient-scale guard normally returns at once: a quarter of the grid starts faster)
   const int nb = a.guard.round == 0 ? SEGB_BLOCKS : SEGB_BLOCKS / 4;
+#define VV_SB(T, CH, DROP) do { if (a.h16) VV_LAUNCH((k_seg_bwd<T, CH, DROP, true>), dim3(nb), dim3(256), 0, s, a); \
+                                 else VV_LAUNCH((k_seg_bwd<T, CH, DROP, false>), dim3(nb), dim3(256), 0, s, a); } while (0)
   if (a.drop.mode && ch == 1) {
-    if (prec == 0) VV_LAUNCH((k_seg_bwd<F16, 1, true>), dim3(nb), dim3(256), 0, s, a);
-    else VV_LAUNCH((k_seg_bwd<BF16, 1, true>), dim3(nb), dim3(256), 0, s, a);
+    if (prec == 0) VV_SB(F16, 1, true); else VV_SB(BF16, 1, true);
     return;
   }
-#define VV_SB(T, CH) VV_LAUNCH((k_seg_bwd<T, CH>), dim3(nb), dim3(256), 0, s, a)
-  if (prec == 0) { if (ch == 1) VV_SB(F16, 1); else VV_SB(F16, 2); }
-  else { if (ch == 1) VV_SB(BF16, 1); else VV_SB(BF16, 2); }
+  if (prec == 0) { if (ch == 1) VV_SB(F16, 1, false); else VV_SB(F16, 2, false); }
+  else { if (ch == 1) VV_SB(BF16, 1, false); else VV_SB(BF16, 2, false); }
 #undef VV_SB
 }
 

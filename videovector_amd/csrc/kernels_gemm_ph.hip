@@ -113,8 +113,13 @@ constexpr int PH_LDS_BYTES = 8 * PH_SLOT;      // ring of 8 slots = 128 KiB
 // 256 intervals of ~430.  The stream keeps its order and its six half-tiles of distance; the counted waits move: before M1 everything
 // but the four youngest half-tiles (A_hi(t) is the fifth youngest), before M0 everything but the THREE youngest (B_hi(t + 1), issued in
 // M0(t), is the fourth youngest: the one half-tile whose flight is half a K-tile instead of a whole one -- it is a W tile, an L2 hit).
-template <typename T, int DROP, bool VEC, int MQ, int ABL = 0, bool GATE = false, int DEAD = 0, int LEAD = 0, int MRG = 0>
+// O16 (round 6; FwdArgs::h16): ip2 leaves as f16 -- half the bytes of the kernel's store-bound epilogue (42 -> 21 MB at the benchmark's size)
+// and of every later read of it.  A lane's two quads of a 32-column group (ni = 0, 1: columns fq 4 .. + 3 and 16 + fq 4 .. + 3, four halves
+// = two registers each) are regrouped by two v_permlane16_swap into EIGHT consecutive columns per lane -- one 16-byte store where the fp32
+// form issues two: half the store instructions as well (the tail of this epilogue is store-ISSUE-bound, cdna_hip_programming.md T21).
+template <typename T, int DROP, bool VEC, int MQ, int ABL = 0, bool GATE = false, int DEAD = 0, int LEAD = 0, int MRG = 0, bool O16 = false>
 __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
+  static_assert(!O16 || (VEC && DROP == 0), "the f16 output form exists for the plain forward (D % 8 == 0, no dropout in the epilogue)");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int HROWS = 32 * MQ;               // rows of the lower A half-tile (upper: HROWS - 16 DEAD)
   constexpr int BMT = 2 * HROWS - 16 * DEAD;   // rows of the output tile
@@ -432,6 +437,37 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
         for (int j = 0; j < 4; ++j) bq[nh][ni][j] = (n + j < a.D ? a.bias[n + j] : 0.f) * dscale;
       }
     }
+  if constexpr (O16) {
+    uint16_t* H16 = (uint16_t*)a.H;
+    const float lo16 = fmaxf(lo, -65504.f);
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+      for (int mi = 0; mi < MQ; ++mi) {
+        if (DEAD && mh == 1 && mi == MQ - 1 && dead_hi) continue;        // (wave-uniform)
+        const int m = m0 + (mh ^ hswap) * HROWS + wm * 16 * MQ + mi * 16 + frow;
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+          uint32_t p[2][2];
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            _Float16 h[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              h[j] = (_Float16)fminf(fmaxf(acc[mh][mi][nh][ni][j] * descale_d + bq[nh][ni][j], lo16), 65504.f);   // (saturated: an inf here would be a NaN loss)
+            p[ni][0] = (uint32_t)__builtin_bit_cast(uint16_t, h[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, h[1]) << 16);
+            p[ni][1] = (uint32_t)__builtin_bit_cast(uint16_t, h[2]) | ((uint32_t)__builtin_bit_cast(uint16_t, h[3]) << 16);
+          }
+          // rows of 16 lanes: (first, second)' = ([f0 s0 f2 s2], [f1 s1 f3 s3]) -- the lane of row r then holds the eight columns
+          // (r & 1) 16 + (r >> 1) 8 .. + 7 of the group: first' its lower four, second' its upper four
+          const auto s0 = __builtin_amdgcn_permlane16_swap(p[0][0], p[1][0], false, false);
+          const auto s1 = __builtin_amdgcn_permlane16_swap(p[0][1], p[1][1], false, false);
+          const int n = n0 + nh * 128 + wn * 32 + (fq & 1) * 16 + (fq >> 1) * 8;
+          if ((ABL & 64) && s0[0] != 12345u) continue;                    // (lab, ABL 64: no stores)
+          if (m < R && n < a.D) *(uint4*)(H16 + (int64_t)m * a.D + n) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        }
+      }
+  } else
 #pragma unroll
   for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -1155,6 +1191,32 @@ static void launch_fwd_ph_q(const FwdArgs& a, hipStream_t s, long tiles_est) {
   constexpr int BMT = 64 * MQ - 16 * DEAD;
   const dim3 grid(((a.R + BMT - 1) / BMT) * (Dp / BN)), block(GEMM_THREADS);
   (void)tiles_est;
+  if constexpr (!DROP && VEC && DEAD == 0) {
+    if (a.h16) {                          // ip2 as f16 (FwdArgs::h16): the same three forms -- sibling lead, gated, plain -- with the narrow epilogue
+      constexpr int LDS10 = 10 * PH_SLOT;
+      if constexpr (MQ <= 3) {
+        if (ko().fwd_lead && Dp / BN > 1 && !a.gate) {
+          static bool once_l16 = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, false, DEAD, 1, 0, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS10), true);
+          (void)once_l16;
+          VV_LAUNCH((k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, false, DEAD, 1, 0, true>), grid, block, LDS10, s, a);
+          return;
+        }
+      }
+      if (a.gate) {
+        static bool once_g16 = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, true, DEAD, 0, 0, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, PH_LDS_BYTES), true);
+        (void)once_g16;
+        VV_LAUNCH((k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, true, DEAD, 0, 0, true>), grid, block, PH_LDS_BYTES, s, a);
+        return;
+      }
+      static bool once_p16 = ((void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, false, DEAD, 0, 0, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, PH_LDS_BYTES), true);
+      (void)once_p16;
+      VV_LAUNCH((k_fwd_gemm_ph<T, DROP, VEC, MQ, 0, false, DEAD, 0, 0, true>), grid, block, PH_LDS_BYTES, s, a);
+      return;
+    }
+  }
   if constexpr (!DROP && VEC && DEAD == 0 && MQ <= 3) {
     // the sibling lead: 78.6-79.7 against 81.7-82.9 us at the benchmark's de-duplicated size (192-row tiles, one round), 215
     // against 218 us for 192-row tiles in three rounds.  Not for 256-row tiles: that instantiation has no registers left for

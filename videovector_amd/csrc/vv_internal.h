@@ -127,6 +127,10 @@ struct FwdArgs {
   int gate_n = 0;              // chunks (1 .. W_CHUNKS_MAX)
   int gate_kt[5] = {0, 0, 0, 0, 0};   // first K-tile of each chunk (even; gate_kt[0] = 0, gate_kt[gate_n] = all K-tiles)
   int32_t* gate_err = nullptr; // host-mapped: set when a wait gave up (bounded: a lost update must not hang the device)
+  // H as 16-bit floats (round 6, option "h16"): the forward GEMM stores ip2 as f16 -- [R][D] halves in the same buffer, scale 1, values past
+  // f16's range saturated at +-65504 -- for the kernels that then read it as such (k_score_fwd / k_score_stream / k_seg_bwd: ScoreArgs::h16).
+  // Only the segment-wise path sets it (api.hip); everything else keeps fp32 rows.
+  int h16 = 0;
 };
 constexpr int W_CHUNKS_MAX = 4; // F-chunks of the overlapped update at most (chunk-major gradient buffer, api.hip: chunk_plan)
 constexpr int W_GATE_STRIDE = 32;   // ints between two chunk flags: a 128-B line each (the waiting workgroups poll them)
@@ -203,6 +207,7 @@ struct ScoreArgs {
   int32_t bound_seq = 0;
   DropSpec drop;                     // de-duplicated execution with dropout (k_score_fwd): H holds the SHARED pre-dropout rows, every
                                      // instance applies its own mask as it reads its row
+  int h16 = 0;                       // H holds f16 rows (FwdArgs::h16): launch_score_fwd's kernels only
   int lab_hack = 0;                  // (lab builds, VV_LAB_SCORE_HACK: timing studies of k_score_fwd's row loads -- WRONG results) 1: rows 1 KiB apart (half the footprint, the same requests), 2: only the first half of every row is loaded (half the bytes and requests)
   uint32_t* lab_ts = nullptr;        // (lab builds, VV_LAB_SCORE_TS=1: 16 words per item -- shader-clock stamps of k_score_fwd's phases, 100 MHz
                                      //  real time of its start and end, the compute unit it ran on; the product never sets or reads it)
@@ -244,6 +249,7 @@ struct SegBwdArgs {
   float inv_sg;
   GuardArgs guard;
   DropSpec drop;                 // as ScoreArgs::drop: dx_u = [x_u > 0] (sum_i m_i alpha_i V_i - x_u scale sum_i m_i beta_i), m_i the instance's mask
+  int h16 = 0;                   // H holds f16 rows (FwdArgs::h16)
 };
 
 struct SegsumArgs {
@@ -381,7 +387,7 @@ struct KernelOpts {
   int ph_mq = 0;           // (lab) VV_PH_MQ: force the forward tile (2, 3, 4 = 128 / 192 / 256 rows, 31 = 176 rows)
   int score_reg = 1;       // (lab) VV_SCORE_REG=0: the LDS-resident score kernel
   int score_waves = 8;     // (lab) VV_SCORE_WAVES=4
-  int lab_score_pipe = 0;  // (lab) VV_LAB_SCORE_PIPE=1: the persistent, pipelined score kernel (tools/lab/score_fwd_pipelined.hip.txt)
+  int lab_score_pipe = 0;  // (lab) VV_LAB_SCORE_PIPE=1: the persistent, pipelined score kernel (profiles/attic/score_fwd_pipelined.hip.txt)
   int score_rr = 0;        // (lab) VV_SCORE_RR=1: the item-major kernels deal their items round-robin over the XCDs again (kernels_elem.hip: item_of_block)
 };
 extern thread_local const KernelOpts* g_ko;
@@ -421,8 +427,9 @@ bool score_fwd_dropout_supported(int D, int C, int Nn);
 bool score_fwd_supported(const ScoreArgs& a);               // shapes the segment-wise pair is built for
 void launch_score_fwd(const ScoreArgs& a, hipStream_t s);   // forward + factored backward records (dedup mode)
 void launch_seg_bwd(int prec, const SegBwdArgs& a, hipStream_t s);
-void launch_gather_rows_dropout(const float* src, const int32_t* map, int R, int D, const DropSpec& dr, float* dst, hipStream_t s);
-void launch_gather_rows_f32(const float* src, const int32_t* map, int R, int D, float* dst, hipStream_t s);
+// (h16: src holds f16 rows -- FwdArgs::h16; map == nullptr: row r is its own source)
+void launch_gather_rows_dropout(const float* src, const int32_t* map, int R, int D, const DropSpec& dr, float* dst, hipStream_t s, int h16 = 0);
+void launch_gather_rows_f32(const float* src, const int32_t* map, int R, int D, float* dst, hipStream_t s, int h16 = 0);
 void launch_gather_rows_u16(const uint16_t* src, const int32_t* pos, int R, int Dp, uint16_t* dst, hipStream_t s);
 void launch_reduce(const ReduceArgs& a, hipStream_t s);
 void launch_sgd(int prec, const SgdArgs& a, hipStream_t s);
