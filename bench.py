@@ -153,22 +153,25 @@ def cpu_baseline(ds, idx, W, b, items, iters, threads=0):
 BOX_REF_GEMM_TFLOPS = 1200.0   # the reference rate `ms_per_step_at_ref` is quoted at (a round number near the pool's median box)
 
 
-def box_record(box, ms_per_step):
-    """The line's `box` object: the two probes of vv_box_probe before and after the timed leg, their means, and the step time scaled to a
-    reference box (ms x gemm_tflops / 1200): two runs of the same code on boxes whose clocks differ should agree in that figure."""
+def box_record(box, ms_per_step, gemm_ms_in_step):
+    """The line's `box` object: vv_box_probe right before the settle steps of the timed leg (a cold device: noisy) and right after the timed
+    leg (steady state: repeatable to ~1 % on one box) -- the second is the calibration.  ms_per_step_at_ref scales the step's GEMM share
+    (the two GEMM kernels' own durations) to a reference box and leaves the rest as measured: ms - gemm_ms x (1 - gemm_tflops / ref)."""
     if not box:
         return None
     b, a = box["before"], box.get("after") or box["before"]
-    mean = lambda k: 0.5 * (b[k] + a[k])
-    return {"gemm_tflops": mean("gemm_tflops"), "copy_tbs": mean("copy_tbs"), "gemm_clock_mhz": mean("gemm_clock_mhz"),
-            "before_timed_leg": {k: b[k] for k in ("gemm_tflops", "gemm_ms", "gemm_clock_mhz", "copy_tbs", "copy_ms")},
-            "after_timed_leg": {k: a[k] for k in ("gemm_tflops", "gemm_ms", "gemm_clock_mhz", "copy_tbs", "copy_ms")},
-            "ref_gemm_tflops": BOX_REF_GEMM_TFLOPS, "ms_per_step_at_ref": ms_per_step * mean("gemm_tflops") / BOX_REF_GEMM_TFLOPS,
+    keys = ("gemm_tflops", "gemm_ms", "gemm_clock_mhz", "copy_tbs", "copy_ms")
+    return {"gemm_tflops": a["gemm_tflops"], "copy_tbs": a["copy_tbs"], "gemm_clock_mhz": a["gemm_clock_mhz"],
+            "after_timed_leg": {k: a[k] for k in keys}, "before_settle_steps_cold": {k: b[k] for k in keys},
+            "ref_gemm_tflops": BOX_REF_GEMM_TFLOPS, "gemm_ms_in_step": gemm_ms_in_step,
+            "ms_per_step_at_ref": ms_per_step - gemm_ms_in_step * (1.0 - a["gemm_tflops"] / BOX_REF_GEMM_TFLOPS),
             "probes": "vv_box_probe (include/videovec.h): gemm = the benchmark's forward instantiation (k_fwd_gemm_ph, f16, 192-row tiles, 216 "
                       "workgroups) on contiguous rows of a random table, %d x %d x %d, operands uniform in [-1, 1), 24 launches behind 8 warm-up "
                       "launches, clock = s_memtime / s_memrealtime inside the kernel (median over workgroups); copy = 1 GiB device-to-device, "
                       "read + written bytes per second, 6 copies behind 2" % tuple(b["gemm_shape"]),
-            "note": "a calibration of the box, not of the code: ms_per_step_at_ref = ms_per_step x gemm_tflops / ref_gemm_tflops"}
+            "note": "a calibration of the box, not of the code: the top-level figures are the probe right AFTER the timed leg (steady state); "
+                    "ms_per_step_at_ref = ms_per_step - gemm_ms_in_step x (1 - gemm_tflops / ref_gemm_tflops), gemm_ms_in_step = the two GEMM "
+                    "kernels' durations"}
 
 
 def helper_main():
@@ -711,6 +714,16 @@ def main():
             for k, v in s_kern.items():
                 if k not in GEMMS:
                     kern[k] = v
+        if args.dedup == "on" and run.eng.get_option("h16"):
+            # round 6: ip2 travels as f16 between the forward GEMM and the segment-wise pair (option "h16", one more f16 rounding of the
+            # embeddings: DESIGN.md 3.6 / 5); the same steps with fp32 rows -- the rounds 1-5 form -- beside it
+            run.reset(True)
+            run.eng.set_option("h16", 0)
+            f_el, f_kern, _ = run.timed("resident")
+            run.eng.set_option("h16", 1)
+            extra["fp32_ip2_execution"] = {"value": Bg * NN * K / f_el, "unit": "triplets/s", "ms_per_step": f_el / K * 1e3,
+                                           "source": "resident indices; option h16 = 0 (VV_H16=0): ip2 rows as fp32",
+                                           "kernels_ms": {k: round(v[0], 4) for k, v in f_kern.items() if v[1] > 0}}
         if args.dedup == "on":
             run.reset(False)
             d_el, d_kern, _ = run.timed("resident")
@@ -901,6 +914,9 @@ def main():
                                    % (1 if args.workload == "cfg2" else 4, D, B_PER_GPU, Bg, NN),
                        "global_batch": Bg, "triplets_per_step": Bg * NN,
                        "parallelism": "dp%d" % world, "items_per_s": value / NN,
+                       "ip2_rows": ("f16 between the forward GEMM and the score / segment kernels (option h16; fp32 accumulate, one f16 rounding of the "
+                                    "stored embedding: rows 3.5e-4, scores 5e-5 off the fp32 CPU path on whole batches, tests/test_gpu_fullsize.py)"
+                                    if (args.dedup == "on" and DROPOUT == 0 and os.environ.get("VV_H16", "1") != "0" and D in (512, 1024)) else "fp32"),
                        "dedup": args.dedup if DROPOUT == 0 else "off (dropout at D = 4096: dense kernels -- the de-duplicated path carries the per-instance masks at D = 512 only, and 128-item batches hardly repeat a row)",
                        "sampler_host": ({"avx512_forms": bool(sampler.stat(7) == 1), "cores_held_for_stage_threads": int(sampler.stat(9))}
                                         if sampler is not None else None),
@@ -924,7 +940,7 @@ def main():
                                      "stale": "overlapped with the next iteration's forward/backward "
                                               "(one-update delayed gradients: NOT the reference's algorithm)"}[mode]},
             "roofline": roof,
-            "box": box_record(box, ms),
+            "box": box_record(box, ms, live.get("fwd_gemm", 0.0) + live.get("wgrad_gemm", 0.0)),
             "kernels_ms": {k: round(v, 4) for k, v in live.items()},
             "kernel_timing": ("HIP events on the kernels' dispatch packets, every %d-th of the %d timed steps (%d samples per kernel)"
                               % (max(5, K // 8), K, max([v[1] for v in kern.values()] or [0])))

@@ -62,9 +62,15 @@ int vv_set_dedup(vv_ctx* ctx, int on);
  *   "dedup" (VV_DEDUP, 1)            row de-duplication, as vv_set_dedup
  *   "seg_bwd" (VV_SEG_BWD, 1)        segment-wise backward of de-duplicated batches (0: per-instance gradient rows + their sums)
  *   "drop_dedup" (VV_DROP_DEDUP, 1)  dropout on the de-duplicated path where the kernels carry per-instance masks (D = 512); 0: dense
- *   "h16" (VV_H16, 0)                ip2 stored as f16 between the forward GEMM and the segment-wise score / backward kernels (de-duplicated batches
+ *   "h16" (VV_H16, 1)                ip2 stored as f16 between the forward GEMM and the segment-wise score / backward kernels (de-duplicated batches
  *                                    of D = 512 / 1024): half the bytes of the GEMM's epilogue and of every later read of a row; adds one f16 rounding
- *                                    (2^-12 relative per element; values past 65504 saturate) to the embeddings the loss is computed from
+ *                                    (2^-12 relative per element; values past 65504 saturate) to the embeddings the loss is computed from --
+ *                                    measured against the fp32 oracle on whole batches: rows 2.7e-4 -> 3.5e-4, scores 3.8e-5 -> 5.3e-5, loss
+ *                                    unchanged to 1e-6 (inside the 1e-3 the path is held to); 0: fp32 rows (the rounds 1-5 form)
+ *   "slab16" (VV_SLAB16, 1)          the weight gradient's split-K partial products as f16 x one power of two per (split, 256 x 256 tile) instead of
+ *                                    fp32 (half of the 134 MB they cost per step at the benchmark's shape; a second rounding, 2^-12 relative per
+ *                                    partial product, in the gradient path -- every split still accumulates in fp32 and the sum over the splits is
+ *                                    taken in fp32: dW against the oracle on the same operands 3.5e-4 -> 4.6e-4 on whole batches); 0: fp32 slabs
  *   "fuse_update" (VV_FUSE_UPDATE, 1) reduction of the split-K partials and the solver update in one launch (0: two launches)
  *   "fwd_lead" (VV_FWD_LEAD, 1)      the forward GEMM's sibling lead
  *   "fwd_merge" (VV_FWD_MERGE, 0)    the forward GEMM with two phases per barrier pair (bit-identical results; measured not faster)

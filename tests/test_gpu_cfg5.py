@@ -42,8 +42,10 @@ def test_cfg5_dedup_equals_dense_at_full_size(setup):
     print("CFG5 rows %d distinct %d (factor %.1f) loss %.6f violations %.0f" % (st1 + (st1[0] / st1[1],) + l1))
     # same forward; the segment-wise backward's score kernel may differ in the last bit of the loss, and db is summed
     # per distinct row instead of per item
-    assert abs(l0[0] - l1[0]) <= 1e-6 * l0[0] and l0[1] == l1[1]
-    assert np.linalg.norm(db1 - db0) <= 1e-5 * np.linalg.norm(db0)
+    # (round 6: the de-duplicated path reads ip2 as f16 -- option h16 --, the dense one as fp32: a score difference within 2^-12 of zero may
+    # fall on the other side: a handful of the 819 200 violation flags)
+    assert abs(l0[0] - l1[0]) <= 2e-6 * l0[0] and abs(l0[1] - l1[1]) <= 8
+    assert np.linalg.norm(db1 - db0) <= 1e-3 * np.linalg.norm(db0)      # (1e-5 while both executions read fp32 rows of ip2; the f16 rows' 2^-12: 3e-4)
     rel = np.linalg.norm(dW1 - dW0) / np.linalg.norm(dW0)
     assert rel <= 4e-3, rel                                       # bf16 rounding of the per-row gradient sums
     assert np.isfinite(l1[0]) and 0 < l1[0] < 16 and 0 <= l1[1] <= B * Nn

@@ -47,8 +47,10 @@ def test_caffe_train_matches_oracle_trajectory(tool, pb, oracle, tmp_path, dedup
     # the gradient sums are reassociated, and this small case is chaotic (tests/test_gpu_parity.py:
     # test_sgd_steps_match_oracle), so the weights after 12 free-running iterations get a loose bound while
     # every per-iteration loss keeps the 1e-3 bound.
+    # (round 6: "0" also keeps the split-K partial products of dW as fp32 -- VV_SLAB16=0, the tight bounds are bounds on fixed arithmetic,
+    # tests/conftest.py: fp32_slabs --; "1" is the library as it ships: de-duplication, f16 rows of ip2, f16 partial products)
     import videovector_amd as vv
-    env = {"VV_DEDUP": dedup}
+    env = {"VV_DEDUP": dedup, "VV_SLAB16": dedup}
     loose = dedup == "1"
     B, C, Nn, F, D, V = 32, 5, 2, 128, 32, 50
     net_p, sol_p = tmp_path / "net.prototxt", tmp_path / "solver.prototxt"

@@ -144,7 +144,7 @@ def test_forward_kernel_with_merged_phases_is_bit_identical(setup, dedup):
     assert out[0][3] == out[1][3]
 
 
-def test_full_size_dropout_on_the_deduplicated_path(setup, oracle):
+def test_full_size_dropout_on_the_deduplicated_path(setup, oracle, fp32_ip2):
     """The shipped dropout ratio 0.9 at the benchmark's size: the de-duplicated execution (the mask per instance on the shared projection) and
     the dense one (the mask in the forward GEMM's epilogue) drop the same elements and agree; a shard of the batch against the oracle with
     the same explicit mask."""
@@ -195,8 +195,8 @@ def _local(ds, idx):
     return ds.table(F, uniq), inv.reshape(idx.shape).astype(np.int32), len(uniq)
 
 
-@pytest.mark.parametrize("dropout,h16", [(0.0, 0), (0.9, 0), (0.0, 1), (0.9, 1)])
-def test_the_whole_benchmark_batch_against_the_oracle(setup, oracle, dropout, h16):
+@pytest.mark.parametrize("dropout,h16,slab16", [(0.0, 0, 0), (0.9, 0, 0), (0.0, 1, 0), (0.9, 1, 0), (0.0, 1, 1), (0.9, 1, 1)])
+def test_the_whole_benchmark_batch_against_the_oracle(setup, oracle, dropout, h16, slab16):
     """not a shard -- ALL 56 320 rows of the BASELINE configs[1] batch, on the engine state bench.py times (de-duplication
     on; the SECOND call of an engine, whose forward GEMM is planned from the previous step's distinct-row count: 192-row tiles, ~216
     workgroups, sibling lead), against oracle.forward_backward on the same batch: every ip2 row, every score, the loss, the violations,
@@ -212,6 +212,7 @@ def test_the_whole_benchmark_batch_against_the_oracle(setup, oracle, dropout, h1
     lr = 0.01
     eng = vv.Engine(0, "f16")
     eng.set_option("h16", h16)                    # (round 6: ip2 as f16 between the forward GEMM and the segment-wise pair -- the same bounds)
+    eng.set_option("slab16", slab16)              # (round 6: the split-K partial products of dW as f16 x a power of two per tile)
     eng.table_synth(ds.seed, ds.n_rows, F); eng.params_set(W, b)
     cfg = vv.StepConfig(B, C, Nn, lr=lr, **kw)
     eng.forward_backward(cfg, idx)
@@ -229,8 +230,8 @@ def test_the_whole_benchmark_batch_against_the_oracle(setup, oracle, dropout, h1
     e_rows = np.linalg.norm(got["ip2"] - ref["H"], axis=1)[nz] / nr[nz]
     assert nz.sum() >= 0.999 * len(nr) and np.all(got["ip2"][~nz] == 0)
     e_s = max(np.abs(got["target_score"] - ref["s_true"]).max(), np.abs(got["negative_scores"] - ref["s_bogus"]).max())
-    print("FULLBATCH dropout %.1f h16 %d: %d rows (%d distinct): ip2 rows max %.2e mean %.2e, scores %.2e, loss %.7f / %.7f, violations %d / %d"
-          % (dropout, h16, rows, u, e_rows.max(), e_rows.mean(), e_s, loss, ref["loss"], viol, ref["violations"]))
+    print("FULLBATCH dropout %.1f h16 %d slab16 %d: %d rows (%d distinct): ip2 rows max %.2e mean %.2e, scores %.2e, loss %.7f / %.7f, violations %d / %d"
+          % (dropout, h16, slab16, rows, u, e_rows.max(), e_rows.mean(), e_s, loss, ref["loss"], viol, ref["violations"]))
     assert e_rows.max() <= 1e-3
     assert e_s <= 1e-3
     assert abs(loss - ref["loss"]) <= 1e-3 * ref["loss"]
@@ -240,8 +241,8 @@ def test_the_whole_benchmark_batch_against_the_oracle(setup, oracle, dropout, h1
     Wq = (W * sw).astype(np.float16).astype(np.float32) / sw
     refq = oracle.forward_backward(table, il, Wq, b, C_=C, Nn=Nn, want=("dW", "db"), **kw)
     rel = lambda a, r: float(np.linalg.norm(a - r) / np.linalg.norm(r))
-    print("FULLBATCH dropout %.1f h16 %d: dW %.2e db %.2e vs the oracle at f16(W); %.2e vs the fp32-operand oracle"
-          % (dropout, h16, rel(dW, refq["dW"]), rel(db, refq["db"]), rel(dW, ref["dW"])))
+    print("FULLBATCH dropout %.1f h16 %d slab16 %d: dW %.2e db %.2e vs the oracle at f16(W); %.2e vs the fp32-operand oracle"
+          % (dropout, h16, slab16, rel(dW, refq["dW"]), rel(db, refq["db"]), rel(dW, ref["dW"])))
     assert rel(dW, refq["dW"]) <= 2e-3 and rel(db, refq["db"]) <= 2e-3
     assert rel(dW, ref["dW"]) <= 5e-2
     # -- the update (solver.cpp:485-576): the solver's rule on the oracle's own gradient, and -- the rule alone -- on the engine's

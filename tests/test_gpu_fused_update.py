@@ -45,18 +45,20 @@ np.savez(sys.argv[3], **out)
 """
 
 
-def _run(tmp_path, prec, solver, fuse, D=512):
-    out = tmp_path / ("o_%s_%d_%d_%d.npz" % (prec, solver, fuse, D))
-    env = dict(os.environ, VV_FUSE_UPDATE=str(fuse))
+def _run(tmp_path, prec, solver, fuse, D=512, slab16=0):
+    out = tmp_path / ("o_%s_%d_%d_%d_%d.npz" % (prec, solver, fuse, D, slab16))
+    env = dict(os.environ, VV_FUSE_UPDATE=str(fuse), VV_SLAB16=str(slab16))
     r = subprocess.run([sys.executable, "-c", CHILD % ROOT, prec, str(solver), str(out), str(D)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     return np.load(out)
 
 
-@pytest.mark.parametrize("prec,solver,D", [("f16", 0, 512), ("f16", 1, 512), ("f16", 2, 512), ("bf16", 0, 512), ("f16", 0, 1024)])
-def test_fused_update_is_bit_identical(tmp_path, prec, solver, D):
-    """(D = 1024: more 16-byte elements than the fused launch has threads -- its loop)"""
-    a, b = _run(tmp_path, prec, solver, 0, D), _run(tmp_path, prec, solver, 1, D)
+@pytest.mark.parametrize("prec,solver,D,slab16", [("f16", 0, 512, 0), ("f16", 1, 512, 0), ("f16", 2, 512, 0), ("bf16", 0, 512, 0), ("f16", 0, 1024, 0),
+                                                  ("f16", 0, 512, 1), ("bf16", 1, 1024, 1)])
+def test_fused_update_is_bit_identical(tmp_path, prec, solver, D, slab16):
+    """(D = 1024: more 16-byte elements than the fused launch has threads -- its loop.  slab16 = 1, round 6: the split-K partial products as f16 x
+    a power of two per tile -- both forms read the same halves and the same factors in the same order)"""
+    a, b = _run(tmp_path, prec, solver, 0, D, slab16), _run(tmp_path, prec, solver, 1, D, slab16)
     assert set(a.files) == set(b.files)
     for k in a.files:
         assert np.array_equal(a[k], b[k]), k

@@ -27,7 +27,7 @@ def random_case(rng):
 
 
 @pytest.mark.parametrize("seed", range(24))
-def test_random_shapes_dedup_dense_oracle(vv, oracle, seed):
+def test_random_shapes_dedup_dense_oracle(vv, oracle, seed, fp32_ip2):
     rng = np.random.default_rng(1000 + seed)
     B, C, Nn, F, D, table, idx, W, b = random_case(rng)
     kw = dict(norm="L1" if seed % 5 == 0 else "L2", margin=float(rng.choice([0.5, 2.0])))
@@ -67,7 +67,7 @@ def test_random_shapes_dedup_dense_oracle(vv, oracle, seed):
 
 
 @pytest.mark.parametrize("seed", range(12))
-def test_random_shapes_dropout_on_the_deduplicated_path(vv, oracle, seed):
+def test_random_shapes_dropout_on_the_deduplicated_path(vv, oracle, seed, fp32_ip2):
     """Dropout at D = 512 on random shapes (ragged batches, empty slots, heavy repetition, 1..60 negatives, 2..7 channels in front of them):
     the de-duplicated execution (mask per instance on the shared projection) against the dense one (mask in the GEMM's epilogue) with the
     product's counter-hash masks, and -- every third seed -- against the oracle with an explicit mask.  Shapes the register-resident score

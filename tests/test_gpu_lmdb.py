@@ -18,7 +18,7 @@ from videovector_amd.synth import init_weights
 pytestmark = pytest.mark.gpu
 
 
-def test_caffe_train_from_lmdb_matches_oracle(tool, pb, lmdb_pb, oracle, tmp_path):
+def test_caffe_train_from_lmdb_matches_oracle(tool, pb, lmdb_pb, oracle, tmp_path, fp32_slabs):
     B, C, Nn, F, D = 16, 5, 3, 96, 32
     vids = make_shots_db(lmdb_pb, str(tmp_path / "train_db"), n_videos=31, F=F, seed=9)
     net_p, sol_p = tmp_path / "net.prototxt", tmp_path / "solver.prototxt"

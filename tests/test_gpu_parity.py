@@ -226,7 +226,7 @@ def test_dropout_with_explicit_mask_and_options(vv, oracle, prec):
 
 
 @pytest.mark.parametrize("prec", ["f16", "bf16"])
-def test_dropout_on_the_deduplicated_path_matches_oracle(vv, oracle, prec):
+def test_dropout_on_the_deduplicated_path_matches_oracle(vv, oracle, prec, fp32_ip2):
     """drop2 sits behind fc7 + ReLU (mednet_embedding_train.prototxt:190-230), so equal table rows share their projection and only the mask
     is per instance: at D = 512 dropout rides the de-duplicated path (k_score_fwd masks every instance's row, k_seg_bwd sums the
     mask-weighted terms per distinct row).  Explicit mask, rows that repeat inside and across items, every blob against the oracle."""
@@ -269,7 +269,7 @@ def test_dropout_on_the_deduplicated_path_l1_weighted_pairwise(vv, oracle):
     check(got, ref, TOL["f16"], "dropout-dedup-l1w/f16")
 
 
-def test_counter_based_dropout_dedup_equals_dense(vv):
+def test_counter_based_dropout_dedup_equals_dense(vv, fp32_ip2):
     """Counter-hash masks (the product's own generator) at D = 512: the de-duplicated and the dense execution evaluate the same mask
     function, so they drop the same elements of every instance's row; loss equal to rounding, gradients to the reassociation of the sums."""
     B, C, Nn, F, D = 64, 5, 20, 512, 512
@@ -313,7 +313,7 @@ def test_counter_based_dropout_statistics(vv):
 
 
 @pytest.mark.parametrize("prec", ["f16", "bf16"])
-def test_sgd_steps_match_oracle(vv, oracle, prec):
+def test_sgd_steps_match_oracle(vv, oracle, prec, fp32_slabs):
     # Four solver iterations (inv lr policy, momentum, L2 decay, lr_mult 1/2, decay_mult 1/0).
     # The oracle trajectory "q" takes each gradient at the operands the MFMA reads (rounded copy of
     # its own current W): weights, history and bias must then agree tightly.  The pure-fp32
@@ -467,7 +467,7 @@ def test_q1_same_video_negatives(vv, oracle):
     assert abs(eng.loss()[0] - got["loss"]) > 0
 
 
-def test_pipelined_trainer_single_gpu_matches_delayed_gradient_oracle(vv, oracle):
+def test_pipelined_trainer_single_gpu_matches_delayed_gradient_oracle(vv, oracle, fp32_slabs):
     # the schedule bench.py uses for N > 1 (videovector_amd/dist.py PipelinedTrainer), run with world 1:
     # gradients of iteration t+1 are taken before the update with g_t is applied
     from videovector_amd.dist import GpuBackend, PipelinedTrainer

@@ -37,7 +37,7 @@ def run_d(vv, prec, table, idx, W, b, C, Nn, seg, dedup=True, **kw):
 
 @pytest.mark.parametrize("prec", ["f16", "bf16"])
 @pytest.mark.parametrize("C,Nn", [(5, 10), (5, 20), (5, 50), (2, 3), (7, 55)])
-def test_segment_wise_backward_matches_the_row_writing_path(vv, oracle, prec, C, Nn):
+def test_segment_wise_backward_matches_the_row_writing_path(vv, oracle, prec, C, Nn, fp32_ip2):
     B, F = 64, 256
     ds, table, idx, W, b = make_case(21, 8, B, C, Nn, F, D, wstd=0.02)      # ~300 table rows: heavy repeats
     idx[3, 1] = -1; idx[17, C + 1] = -1
@@ -74,7 +74,7 @@ def test_segment_wise_backward_against_the_oracle(vv, oracle, prec):
         eng.close()
 
 
-def test_segment_wise_backward_degenerate_batches(vv):
+def test_segment_wise_backward_degenerate_batches(vv, fp32_ip2):
     B, C, Nn, F = 40, 3, 6, 256
     ds, table, idx, W, b = make_case(5, 30, B, C, Nn, F, D, wstd=0.05)
     # (a) one segment holding every instance (360 records on one wave); (b) no repeats; (c) a batch of one item
@@ -123,7 +123,7 @@ def test_segment_wise_backward_sgd_trajectory(vv):
     assert rel_fro(res[1][1] - W0, res[0][1] - W0) <= 1e-2      # free-running: the two roundings of dYu drift apart slowly
 
 
-def test_segment_wise_backward_is_bit_reproducible(vv):
+def test_segment_wise_backward_is_bit_reproducible(vv, fp32_ip2):
     """The records of a distinct row arrive in a different order in every run (an atomic counter hands out the
     positions); the sums must not depend on it: segments up to 64 instances are summed in instance order, longer ones
     with order-independent (exact) sums."""
@@ -141,7 +141,7 @@ def test_segment_wise_backward_is_bit_reproducible(vv):
 
 @pytest.mark.parametrize("prec", ["f16", "bf16"])
 @pytest.mark.parametrize("Dx,C,Nn", [(1024, 5, 20), (1024, 4, 200), (512, 5, 70), (512, 9, 10)])
-def test_segment_wise_backward_streaming_forward_shapes(vv, oracle, prec, Dx, C, Nn):
+def test_segment_wise_backward_streaming_forward_shapes(vv, oracle, prec, Dx, C, Nn, fp32_ip2):
     """Shapes the register-resident forward does not hold (D = 1024; more than 56 target / negative rows; more than 6
     context rows) take the streaming kernel's segment-wise form and the two-chunk k_seg_bwd: the per-GPU shape of
     BASELINE configs[4] is one of them."""

@@ -53,7 +53,7 @@ for task in "$@"; do
       done
       echo "arms: ${AB_ENVS}"; summ $O/r06_${TAG}_ab*.json ;;
     gputests)   # the GPU parity suite (TESTS = a -k expression or file list; default: everything marked gpu)
-      timeout 3000 python -m pytest ${TESTS:-tests} -x -q -m gpu > $O/r06_${TAG}_gputests.txt 2>&1; tail -15 $O/r06_${TAG}_gputests.txt ;;
+      timeout 3000 python -m pytest ${TESTS:-tests} ${NOX:--x} -q -m gpu > $O/r06_${TAG}_gputests.txt 2>&1; grep -E "^(FAILED|ERROR)|passed|failed" $O/r06_${TAG}_gputests.txt | tail -40 ;;
     tests_s)    # selected GPU tests with their printed figures: TESTS = files, KEXPR = a -k expression
       timeout 3000 python -m pytest $TESTS -x -q -s -m gpu -k "${KEXPR:-test}" > $O/r06_${TAG}_tests_s.txt 2>&1; grep -v '^$' $O/r06_${TAG}_tests_s.txt | grep -i 'FULLBATCH\|CFG5\|passed\|failed\|error' | tail -40 ;;
     ab5)        # the same A/B on the per-GPU work of BASELINE configs[4] (batch 4096, 200 negatives, 4096 -> 1024)

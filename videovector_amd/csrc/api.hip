@@ -141,6 +141,7 @@ static int create_init(vv_ctx* c) {
   if (const char* v = opt_env("VV_SCORE_STREAM")) c->ko.score_stream = atoi(v);
   if (const char* v = opt_env("VV_SEG_BWD")) c->seg_bwd = atoi(v) != 0;
   if (const char* v = opt_env("VV_H16")) c->h16 = atoi(v) != 0;
+  if (const char* v = opt_env("VV_SLAB16")) c->slab16 = atoi(v) != 0;
   if (const char* v = opt_env("VV_DEDUP")) c->dedup = atoi(v) != 0;
   if (const char* v = opt_env("VV_FUSE_UPDATE")) c->fuse_update = atoi(v) != 0;
   if (const char* v = opt_env("VV_DROP_DEDUP")) c->drop_dedup = atoi(v) != 0;
@@ -226,7 +227,7 @@ int vv_device_query(int device, char* buf, size_t n) {
 }
 
 static void free_batch(vv_ctx* c) {
-  dfree(c->idx_dev); dfree(c->rows); dfree(c->H); dfree(c->dYh); dfree(c->dbp);
+  dfree(c->idx_dev); dfree(c->rows); dfree(c->H); dfree(c->dYh); dfree(c->dbp); dfree(c->slab_sc); c->slab_sc = nullptr;
   dfree(c->loss_part); dfree(c->viol_part); dfree(c->s_true); dfree(c->s_bogus);
   dfree(c->coeff); dfree(c->slabs); dfree(c->item_w); c->item_w = nullptr;
   if (c->dd_stream) (void)hipStreamSynchronize(c->dd_stream);
@@ -289,6 +290,7 @@ int vv_set_option(vv_ctx* c, const char* name, double value) {
   if (n == "seg_bwd") { c->seg_bwd = iv != 0; return VV_OK; }
   if (n == "drop_dedup") { c->drop_dedup = iv != 0; return VV_OK; }
   if (n == "h16") { c->h16 = iv != 0; return VV_OK; }
+  if (n == "slab16") { c->slab16 = iv != 0; return VV_OK; }
   if (n == "fuse_update") { c->fuse_update = iv != 0; return VV_OK; }
   if (n == "fwd_lead") { c->ko.fwd_lead = iv; return VV_OK; }
   if (n == "fwd_merge") { c->ko.fwd_merge = iv; return VV_OK; }
@@ -317,6 +319,7 @@ int vv_get_option(vv_ctx* c, const char* name, double* value) {
   else if (n == "seg_bwd") *value = c->seg_bwd;
   else if (n == "drop_dedup") *value = c->drop_dedup;
   else if (n == "h16") *value = c->h16;
+  else if (n == "slab16") *value = c->slab16;
   else if (n == "fuse_update") *value = c->fuse_update;
   else if (n == "fwd_lead") *value = c->ko.fwd_lead;
   else if (n == "fwd_merge") *value = c->ko.fwd_merge;
@@ -608,6 +611,8 @@ static int ensure_batch(vv_ctx* c, int B, int C, int Nn) {
   c->S = S; c->kps = (total_steps + S - 1) / S;
   c->slab_bytes = (size_t)S * (size_t)slab_pitch(c->Dp, c->Fp) * 4;
   HIPCHK(hipMalloc(&c->slabs, c->slab_bytes));
+  HIPCHK(hipMalloc(&c->slab_sc, (size_t)8 * tiles * sizeof(float)));
+  HIPCHK(hipMemset(c->slab_sc, 0, (size_t)8 * tiles * sizeof(float)));
   // de-duplication work arrays
   c->dd_agg_stride = c->R / 1024 + 2;
   HIPCHK(hipMalloc(&c->dd_agg, (size_t)2 * c->dd_agg_stride * sizeof(unsigned long long)));
@@ -1168,6 +1173,12 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
     u.rate = uc.lr; u.momentum = uc.momentum; u.weight_decay = uc.weight_decay; u.lr_mult_w = uc.lr_mult[0]; u.decay_mult_w = uc.decay_mult[0];
     u.delta = uc.delta; u.reg = uc.reg; u.solver_type = uc.solver_type;
     u.sg = ra.sg; u.gg = ra.gg; u.ip_scale = ra.ip_scale;
+  }
+  // f16 split-K partial products (option "slab16"): the phase-staggered kernel with several splits only (one split: the update rides in the
+  // epilogue or the slab is the gradient); whoever reduces the slabs -- k_reduce, k_reduce_sgd, now or lazily -- reads the same flag
+  if (c->slab16 && !fuse_w && c->S > 1 && c->S <= 8 && c->F % 8 == 0 && wgrad_can_fuse_update()) {
+    wa.slab16 = 1; wa.slab_sc = c->slab_sc;
+    ra.slab16 = 1; ra.slab_sc = c->slab_sc;
   }
   PROFILED(c, "wgrad_gemm", launch_wgrad_gemm(c->prec, wa, s));
   c->red_lazy = false; c->grads_stale = false;        // (the slabs now hold this step's gradient)

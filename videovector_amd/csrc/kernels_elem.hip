@@ -26,6 +26,20 @@ __device__ __forceinline__ float4 nt_load4(const float* p) {
 __device__ __forceinline__ void nt_store4(float* p, const float4& v) {
   __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, (f32x4*)p);
 }
+// Four consecutive split-K partial products at element offset `off` of the slab buffer: fp32, or (S16, WgradArgs::slab16) f16 times the inverse
+// factor of their (split, tile).  slab_tile: the tile of element (d, f) in the factor array's order (k_wgrad_gemm_ph: tm * tilesN + tn).
+template <bool S16> __device__ __forceinline__ float4 slab_ld4(const float* slabs, int64_t off, float inv) {
+  if constexpr (S16) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    const u32x2 q = __builtin_nontemporal_load((const u32x2*)((const uint16_t*)slabs + off));
+    const h4 h = __builtin_bit_cast(h4, q);
+    return make_float4((float)h[0] * inv, (float)h[1] * inv, (float)h[2] * inv, (float)h[3] * inv);
+  } else {
+    return nt_load4(slabs + off);
+  }
+}
+__device__ __forceinline__ int slab_tile(int d, int f, int Fp) { return (d >> 8) * (Fp >> 8) + (f >> 8); }
 
 constexpr int SL_THREADS = 256;
 
@@ -541,6 +555,9 @@ template <bool H16, int DV> __device__ __forceinline__ void h_row(const float* H
 // (Sixteen waves per item, four rows per wave -- one item per CU at a time instead of two items of eight waves: 36 against 25 us, round 4.)
 // DROP (ScoreArgs::drop): the rows of H are the shared PRE-dropout projections; every instance applies its own mask (and 1 / (1 - ratio))
 // as its row arrives, and everything behind that -- norms, scores, records -- is the reference's graph on the masked rows.
+// (Round 6, with f16 rows -- 86 VGPRs instead of 112-127 -- two more residencies were measured and not kept: capped at 80 VGPRs = three
+// workgroups per CU instead of two, 7 registers spilled: 22.9 -> 23.7 us; FOUR waves per item with 14 rows per wave, three or four 256-thread
+// workgroups per CU = all 1024 items resident at once: 23.0 -> 26.2-27.1 us.  tools/sessions/r06_log.md s5, s8.)
 template <int NW, int RPW, int DV, bool DROP = false, bool H16 = false>
 __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -1639,7 +1656,7 @@ __device__ __forceinline__ void scale_update_body(Scales* sc, const float* wmax_
   sc->wmax_bits = 0u;
 }
 
-template <bool VEC>
+template <bool VEC, bool S16 = false>
 __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
   // The few workgroups with serial work (bias columns: a loop over the per-block partials; loss; scale) are numbered last
   // but DISPATCHED first: the 2048 dW workgroups fill every CU's block slots, and a workgroup that only starts when the
@@ -1668,6 +1685,27 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
          i += (int64_t)nblk * 256) {
       const int d = d0 + (int)(i / f4), f = fb + (int)(i % f4) * 4;
       const float* p = a.slabs + (int64_t)d * a.Fp + f;
+      if constexpr (S16) {             // f16 partial products: every split's four values times the inverse factor of its tile, summed in slab order
+        const int64_t po = (int64_t)d * a.Fp + f;
+        const int tiles = (a.Dp >> 8) * (a.Fp >> 8), tl = slab_tile(d, f, a.Fp);
+        float4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = u < a.S ? slab_ld4<true>(a.slabs, u * slab_sz + po, a.slab_sc[u * tiles + tl]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 s = t[0];
+#pragma unroll
+        for (int u = 1; u < 8; ++u)
+          if (u < a.S) { s.x += t[u].x; s.y += t[u].y; s.z += t[u].z; s.w += t[u].w; }
+        int64_t o = (int64_t)d * a.F + f;
+        if (a.n_chunks > 0) {
+          int cc = 0;
+          while (cc + 1 < a.n_chunks && f >= a.chunk_c0[cc + 1]) ++cc;
+          const int c0 = a.chunk_c0[cc], c1 = a.chunk_c0[cc + 1];
+          o = (int64_t)a.D * c0 + (int64_t)d * (c1 - c0) + (f - c0);
+        }
+        if (a.shard_rows > 0) o += (int64_t)(d / a.shard_rows) * a.shard_rows;
+        *(float4*)(a.grads + o) = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+        continue;
+      }
       float4 s = nt_load4(p);
       int k = 1;
       if (a.S == 8) {                  // the usual split: all eight loads in flight at once, summed in slab order
@@ -1714,7 +1752,8 @@ void launch_reduce(const ReduceArgs& a, hipStream_t s) {
   // dW blocks (fewer for a launch that reduces a column range only), db blocks, the loss block, the scale block
   const int dwb = !(a.parts & 1) ? 0 : (a.f_count > 0 && a.F % 4 == 0 ? std::max(64, (int)((int64_t)RED_DW_BLOCKS * a.f_count / a.F)) : RED_DW_BLOCKS);
   const dim3 grid(dwb + ((a.parts & 2) ? (a.D + 15) / 16 + 1 : 0) + (a.scale_sc ? 1 : 0));
-  if (a.F % 4 == 0) VV_LAUNCH(k_reduce<true>, grid, dim3(256), 0, s, a);
+  if (a.F % 4 == 0 && a.slab16) VV_LAUNCH((k_reduce<true, true>), grid, dim3(256), 0, s, a);     // (slab16 needs F % 8 == 0 and S <= 8: api.hip)
+  else if (a.F % 4 == 0) VV_LAUNCH(k_reduce<true>, grid, dim3(256), 0, s, a);
   else VV_LAUNCH(k_reduce<false>, grid, dim3(256), 0, s, a);
 }
 
@@ -1838,7 +1877,7 @@ void launch_scale_update(int prec, Scales* sc, const float* wmax_blocks, int n_b
 // (Round 4, residency: 76 registers = six workgroups per CU resident, the eight of a CU in two uneven rounds.  A one-element form at 57
 // registers with all eight resident is SLOWER (23.7 against 21.8 us), so is every cap below six (LDS-limited 5 / 4 / 3 per CU: 23.8-25 /
 // 24.7 / 29.5 us); half or a quarter of the workgroups with two / four elements per thread: the same 21.3-22.6 us.)
-template <typename T>
+template <typename T, bool S16 = false>
 __global__ __launch_bounds__(256) void k_reduce_sgd(FusedUpdArgs fa) {
   const ReduceArgs& a = fa.r;
   const SgdArgs& g = fa.g;
@@ -1897,13 +1936,42 @@ __global__ __launch_bounds__(256) void k_reduce_sgd(FusedUpdArgs fa) {
   float4 t[8], w = make_float4(0.f, 0.f, 0.f, 0.f), h = w;
   auto load = [&](int64_t ii) {
     const int d = (int)(ii / f4), f = (int)(ii % f4) * 4;
-    const float* p = a.slabs + (int64_t)d * a.Fp + f;
+    const int64_t po = (int64_t)d * a.Fp + f;
+    if constexpr (S16) {
+      const int tiles = (a.Dp >> 8) * (a.Fp >> 8), tl = slab_tile(d, f, a.Fp);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) t[u] = u < a.S ? nt_load4(p + u * slab_sz) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int u = 0; u < 8; ++u) t[u] = u < a.S ? slab_ld4<true>(a.slabs, u * slab_sz + po, a.slab_sc[u * tiles + tl]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = u < a.S ? nt_load4(a.slabs + po + u * slab_sz) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     const int64_t o = (int64_t)d * a.F + f;
     w = nt_load4(g.W + o); h = nt_load4(g.hW + o);
   };
-  if (i < n4) load(i);
+  // S16 (f16 partial products): EIGHT elements per thread -- 16-byte loads of the eight slabs (8-byte accesses run at ~0.6 of the 16-byte rate
+  // per byte), two 16-byte accesses each for W and the history, one 16-byte store of the half copy; the same per-element arithmetic in the same
+  // order as the four-element form and as k_reduce + k_sgd (bit-identical parameters, tests/test_gpu_fused_update.py)
+  typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+  typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+  const int f8 = a.F / 8;
+  const int64_t n8 = (int64_t)a.D * f8;
+  h8v t8[8]; float sc8[8]; float4 w1 = w, h1 = w;
+  auto load8 = [&](int64_t ii) {
+    const int d = (int)(ii / f8), f = (int)(ii % f8) * 8;
+    const int64_t po = (int64_t)d * a.Fp + f;
+    const int tiles = (a.Dp >> 8) * (a.Fp >> 8), tl = slab_tile(d, f, a.Fp);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (u < a.S) {
+        t8[u] = __builtin_bit_cast(h8v, __builtin_nontemporal_load((const u32x4v*)((const uint16_t*)a.slabs + u * slab_sz + po)));
+        sc8[u] = a.slab_sc[u * tiles + tl];
+      } else { t8[u] = h8v{0, 0, 0, 0, 0, 0, 0, 0}; sc8[u] = 0.f; }
+    }
+    const int64_t o = (int64_t)d * a.F + f;
+    w = nt_load4(g.W + o); w1 = nt_load4(g.W + o + 4); h = nt_load4(g.hW + o); h1 = nt_load4(g.hW + o + 4);
+  };
+  if constexpr (S16) { if (i < n8) load8(i); }
+  else { if (i < n4) load(i); }
   // the scale of the new half copy
   float sw = g.scales->sw_next;
   if (fa.recompute_scale) {
@@ -1927,6 +1995,34 @@ __global__ __launch_bounds__(256) void k_reduce_sgd(FusedUpdArgs fa) {
   const float inv = a.ip_scale / (sgf * a.scales->sx);
   const float lr_w = g.rate * g.lr_mult_w, dc_w = g.weight_decay * g.decay_mult_w;
   float wmax = 0.f;
+  if constexpr (S16) {
+    for (; i < n8; ) {
+      const int d = (int)(i / f8), f = (int)(i % f8) * 8;
+      const int64_t o = (int64_t)d * a.F + f;
+      float gr[8], wn[8], hn[8];
+      const float w8[8] = {w.x, w.y, w.z, w.w, w1.x, w1.y, w1.z, w1.w}, hh8[8] = {h.x, h.y, h.z, h.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float sj = (float)t8[0][j] * sc8[0];
+#pragma unroll
+        for (int u = 1; u < 8; ++u)
+          if (u < a.S) sj += (float)t8[u][j] * sc8[u];
+        gr[j] = __fmul_rn(sj, inv);
+        hn[j] = hh8[j];
+        wn[j] = rule(w8[j], gr[j], hn[j], lr_w, dc_w);
+        wmax = fmaxf(wmax, fabsf(wn[j]));
+      }
+      if (fa.store_grads) { nt_store4(a.grads + o, make_float4(gr[0], gr[1], gr[2], gr[3])); nt_store4(a.grads + o + 4, make_float4(gr[4], gr[5], gr[6], gr[7])); }
+      i += (int64_t)nblk * 256;
+      if (i < n8) load8(i);                      // the next element's loads before this one's stores
+      nt_store4(g.W + o, make_float4(wn[0], wn[1], wn[2], wn[3])); nt_store4(g.W + o + 4, make_float4(wn[4], wn[5], wn[6], wn[7]));
+      nt_store4(g.hW + o, make_float4(hn[0], hn[1], hn[2], hn[3])); nt_store4(g.hW + o + 4, make_float4(hn[4], hn[5], hn[6], hn[7]));
+      uint32_t q[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q[j] = T::from_float(wn[2 * j] * sw) | ((uint32_t)T::from_float(wn[2 * j + 1] * sw) << 16);
+      *(uint4*)(g.Wh + (int64_t)d * g.Fp + f) = make_uint4(q[0], q[1], q[2], q[3]);
+    }
+  } else
   for (; i < n4; ) {
     const int d = (int)(i / f4), f = (int)(i % f4) * 4;
     const int64_t o = (int64_t)d * a.F + f;
@@ -1960,8 +2056,14 @@ __global__ __launch_bounds__(256) void k_reduce_sgd(FusedUpdArgs fa) {
 }
 int launch_reduce_sgd(const FusedUpdArgs& a, hipStream_t s) {
   const int ndb = (a.r.D + 15) / 16;
-  const int nblk = a.no_params ? 0 : (int)std::min<int64_t>(((int64_t)a.r.D * (a.r.F / 4) + 255) / 256, WMAX_SLOTS);
+  const int ept = a.r.slab16 ? 8 : 4;                                       // elements per thread (k_reduce_sgd's S16 form: eight)
+  const int nblk = a.no_params ? 0 : (int)std::min<int64_t>(((int64_t)a.r.D * (a.r.F / ept) + 255) / 256, WMAX_SLOTS);
   const dim3 grid(nblk + ndb + 1);
+  if (a.r.slab16) {
+    if (a.prec == 0) VV_LAUNCH((k_reduce_sgd<F16, true>), grid, dim3(256), 0, s, a);
+    else VV_LAUNCH((k_reduce_sgd<BF16, true>), grid, dim3(256), 0, s, a);
+    return nblk;
+  }
   if (a.prec == 0) VV_LAUNCH((k_reduce_sgd<F16>), grid, dim3(256), 0, s, a);
   else VV_LAUNCH((k_reduce_sgd<BF16>), grid, dim3(256), 0, s, a);
   return nblk;

@@ -697,7 +697,8 @@ __device__ __forceinline__ i16x4 ph_tr(const unsigned char* p) {
 }
 
 // UPD: one split of K (S == 1) and the solver's update applied to the tile where it stands (WgradUpd, vv_internal.h) instead of the slab store
-template <typename T, int ABL = 0, bool UPD = false>
+// S16 (WgradArgs::slab16): the tile leaves as f16 x one power of two per (split, tile); stores widened as in the forward kernel's O16 form
+template <typename T, int ABL = 0, bool UPD = false, bool S16 = false>
 __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int32_t* ids = (int32_t*)(smem + PH_LDS_BYTES);
@@ -978,6 +979,58 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
       u.wmax_blocks[blockIdx.x] = wb;
       if (blockIdx.x == 0) { u.scales->sw_cur = sw; if (u.recompute_scale) u.scales->sw_next = sw; }
     }
+    return;
+  }
+  if constexpr (S16) {
+    // ---- f16 slabs: the tile's largest magnitude -> a power of two that puts it in [2^14, 2^15) -> halves, eight consecutive columns per lane
+    float mx = 0.f;
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mx = fmaxf(mx, fabsf(acc[nh][ni][mh][mi][j]));
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o2, 64));
+    __syncthreads();                                      // (every wave is out of the K loop: the ring is free)
+    float* red8 = (float*)smem;
+    if (lane == 0) red8[wave] = mx;
+    __syncthreads();
+    mx = red8[0];
+#pragma unroll
+    for (int w8 = 1; w8 < 8; ++w8) mx = fmaxf(mx, red8[w8]);
+    float sc = 1.f;
+    if (mx > 0.f && mx < 3.0e38f) { int e; (void)frexpf(mx, &e); sc = ldexpf(1.f, 15 - e); }      // mx sc in [2^14, 2^15); inf / nan: passed through at scale 1
+    if (tid == 0) a.slab_sc[(int64_t)sp * (tilesM * tilesN) + tm * tilesN + tn] = 1.f / sc;        // (a power of two: exact)
+    uint16_t* slab = (uint16_t*)a.slabs + (int64_t)sp * slab_pitch(a.Dp, a.Fp);
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int m = m0 + mh * 128 + wn * 32 + mi * 16 + li;
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            uint32_t p[2][2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const f32x4 v = acc[nh][2 * pr + q][mh][mi];
+              const _Float16 h0 = (_Float16)(v[0] * sc), h1 = (_Float16)(v[1] * sc), h2 = (_Float16)(v[2] * sc), h3 = (_Float16)(v[3] * sc);
+              p[q][0] = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
+              p[q][1] = (uint32_t)__builtin_bit_cast(uint16_t, h2) | ((uint32_t)__builtin_bit_cast(uint16_t, h3) << 16);
+            }
+            // (rows of 16 lanes, as k_fwd_gemm_ph's O16 epilogue: the lane of row g then holds columns (g & 1) 16 + (g >> 1) 8 .. + 7 of the 32-column pair)
+            const auto s0 = __builtin_amdgcn_permlane16_swap(p[0][0], p[1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(p[0][1], p[1][1], false, false);
+            const int n = n0 + nh * 128 + wm * 64 + pr * 32 + (g & 1) * 16 + (g >> 1) * 8;
+            *(uint4*)(slab + (int64_t)m * a.Fp + n) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+          }
+      }
     return;
   }
   // D' = X_frag^T-major: the lane's column is m (dY column = output row d), its 4 registers 4 consecutive n
@@ -1383,6 +1436,13 @@ static void launch_wgrad_ph_t(const WgradArgs& a, hipStream_t s) {
     }
   }
 #endif
+  if (a.slab16 && !a.fuse_upd) {
+    static bool once_s = ((void)hipFuncSetAttribute((const void*)k_wgrad_gemm_ph<T, 0, false, true>,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, PH_WG_LDS_BYTES), true);
+    (void)once_s;
+    VV_LAUNCH((k_wgrad_gemm_ph<T, 0, false, true>), grid, block, PH_WG_LDS_BYTES, s, a);
+    return;
+  }
   if (a.fuse_upd) {                       // (one split of K: the update where the gradient is born -- api.hip decides, WgradUpd)
     static bool once_u = ((void)hipFuncSetAttribute((const void*)k_wgrad_gemm_ph<T, 0, true>,
                           hipFuncAttributeMaxDynamicSharedMemorySize, PH_WG_LDS_BYTES), true);

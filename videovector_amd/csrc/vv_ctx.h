@@ -98,7 +98,9 @@ struct vv_ctx {
   float* segV = nullptr; vv::SegRec* seg_rec = nullptr; float* seg_dbp = nullptr;
   bool seg_bwd = true;             // env VV_SEG_BWD=0: the per-instance gradient rows + k_segsum instead
   bool last_seg_bwd = false;
-  bool h16 = false;                // option "h16" (VV_H16): ip2 as f16 between the forward GEMM and the segment-wise pair (FwdArgs::h16)
+  bool slab16 = true;              // option "slab16" (VV_SLAB16=0: fp32): the weight gradient's split-K partial products as f16 x a power of two per (split, tile)
+  float* slab_sc = nullptr;        // ... their inverse factors, [8][tiles]
+  bool h16 = true;                 // option "h16" (VV_H16=0: fp32 rows): ip2 as f16 between the forward GEMM and the segment-wise pair (FwdArgs::h16)
   bool last_h16 = false;           // ... and whether the last forward pass stored it that way (the accessors read H accordingly)
   vv::ScoreArgs last_score;            // to rebuild the per-instance gradient rows for vv_blobs_get(ip1_diff)
   int32_t* U_host = nullptr;        // pinned + mapped: k_dd_leaders stores U here every step, the launcher reads it late

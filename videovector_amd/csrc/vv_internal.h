@@ -291,10 +291,16 @@ struct WgradArgs {
   int abl = 0;                       // as FwdArgs::abl
   int fuse_upd = 0;                  // 1: S == 1 and the epilogue applies `upd` instead of storing the tile to the slab
   WgradUpd upd;
+  // Split-K partial products as f16 (round 6, option "slab16"; k_wgrad_gemm_ph only): the slab buffer holds [S][Dp][Fp] HALVES, every
+  // (split, 256 x 256 tile) carries one power-of-two factor -- the tile's largest magnitude placed in [2^14, 2^15): no overflow whatever the
+  // gradient scale, 11 significant bits per partial product -- whose inverse goes to slab_sc[split * tiles + tm * tilesN + tn]
+  int slab16 = 0;
+  float* slab_sc = nullptr;
 };
 
 struct ReduceArgs {
   const float* slabs; int S, Dp, Fp;
+  int slab16 = 0; const float* slab_sc = nullptr;   // WgradArgs::slab16: f16 partial products and their per-(split, tile) factors
   const float* dbp; int B;
   int db_rows = 0;         // rows of dbp (0 = B, one per item; the segment-wise backward writes SEGB_BLOCKS partials)
   const Scales* scales;
