@@ -884,6 +884,23 @@ def main():
             except Exception:
                 pmc = None
         roof["traffic"] = pmc
+        # the whole step's HBM bytes by the same PMC passes beside what the de-duplicated algorithm needs
+        if os.path.exists(pmc_path) and args.workload == "cfg2" and args.dedup == "on" and DROPOUT == 0:
+            try:
+                pk = json.load(open(pmc_path)).get("dedup_on", {})
+                step_k = ("fwd_gemm", "score_loss", "segsum", "wgrad_gemm", "reduce_sgd")
+                pmc_step = sum(pk[k]["hbm_bytes_per_launch"] for k in step_k if k in pk)
+                h_b = 2.0 if (os.environ.get("VV_H16", "1") != "0") else 4.0
+                s_b = 2.0 if (os.environ.get("VV_SLAB16", "1") != "0") else 4.0
+                alg = (2.0 * U * F * 2 + 3.0 * U * D * h_b + 2.0 * U * D * 2 + 2.0 * 8 * D * F * s_b + 4.0 * D * F * 4 + 2.0 * D * F * 2)
+                roof["step_traffic"] = {"pmc_bytes_per_step": pmc_step, "algorithmic_bytes_per_step": alg, "ratio": pmc_step / alg if alg else None,
+                                        "kernels": list(step_k),
+                                        "algorithmic": "2 U F 2 (rows gathered by both GEMMs) + 3 U D h (ip2 written once, read by the score and the segment "
+                                                       "kernel; h = 2 B as f16) + 2 U D 2 (dYu) + 2 S D F s (split-K partial products, s = 2 B as f16) + "
+                                                       "4 D F 4 (W and history, read and written) + 2 D F 2 (the 16-bit copy of W)",
+                                        "note": "pmc: the committed passes of profiles/pmc_latest.json (sum over the step's five kernels), not measured by this run"}
+            except Exception:
+                pass
         roof["traffic_note"] = ("HBM bytes per launch from rocprofv3 PMC passes recorded in %s -- a committed profile of this "
                                 "kernel, NOT measured by this run" % pmc_src) if pmc is not None else None
         out = {

@@ -66,6 +66,8 @@ for task in "$@"; do
         done
       done
       echo "arms: ${AB_ENVS}"; summ $O/r06_${TAG}_ab5_*.json ;;
+    diag)       # the driver's 20-step region, step by step (VV_BENCH_DIAG: one HIP event per step + the host time of every call)
+      VV_BENCH_DIAG=1 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs > $O/r06_${TAG}_diag.json 2> $O/r06_${TAG}_diag.err; grep -E "main-leg|host ms" $O/r06_${TAG}_diag.err | cut -c1-600; summ $O/r06_${TAG}_diag.json ;;
     smoke)
       timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/r06_${TAG}_smoke.txt 2>&1; tail -5 $O/r06_${TAG}_smoke.txt ;;
     cfg5)
