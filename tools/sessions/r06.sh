@@ -83,6 +83,7 @@ for task in "$@"; do
       timeout 600 python bench.py --workload cfg5 --no-cpu-baseline --no-extra-legs --steps 40 --warmup 5 > ${P0}_bench_cfg5.json 2>> ${P0}_bench.err
       timeout 600 python bench.py --workload shipped --steps 200 --warmup 20 --no-cpu-baseline > ${P0}_bench_shipped.json 2>> ${P0}_bench.err
       rm -rf $O/prof_r06_${TAG} && mkdir -p $O/prof_r06_${TAG}
+      export VV_BENCH_NO_BOX=1       # (the profiled runs: without the box probe, whose GEMM launches carry the product kernel's name)
       for mode in on off; do
         P=$O/prof_r06_${TAG}/dedup_${mode}
         timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -o kt -- python3 bench.py --steps 400 --warmup 5 --no-cpu-baseline --no-extra-legs --dedup $mode > ${P0}_prof_trace_${mode}.log 2>&1
@@ -116,6 +117,7 @@ for k, cs in acc.items():
         bz = sum(cs["SQ_BUSY_CYCLES"]) / len(cs["SQ_BUSY_CYCLES"])
         print("   kernel cycles %.0f, matrix pipe busy per SIMD = %.3f" % (bz / 32, mf / (bz / 32 * 1024)))
 PY
+      unset VV_BENCH_NO_BOX
       python3 tools/samp_rates.py 10 ${P0}_sampler_rates.json > ${P0}_sampler_rates.txt 2>&1
       bash tools/facade_rate.sh > ${P0}_facade_rate.txt 2>&1
       (lscpu | head -25; nproc; echo "cgroup cpu.max: $(cat /sys/fs/cgroup/cpu.max 2>/dev/null)"; uptime) > ${P0}_host_cpu.txt 2>&1
