@@ -139,6 +139,7 @@ static int create_init(vv_ctx* c) {
   if (const char* v = opt_env("VV_FWD_LEAD")) c->ko.fwd_lead = atoi(v);
   if (const char* v = opt_env("VV_FWD_MERGE")) c->ko.fwd_merge = atoi(v);
   if (const char* v = opt_env("VV_SCORE_STREAM")) c->ko.score_stream = atoi(v);
+  if (const char* v = opt_env("VV_SCORE_PF")) c->ko.score_pf = atoi(v);
   if (const char* v = opt_env("VV_SEG_BWD")) c->seg_bwd = atoi(v) != 0;
   if (const char* v = opt_env("VV_H16")) c->h16 = atoi(v) != 0;
   if (const char* v = opt_env("VV_SLAB16")) c->slab16 = atoi(v) != 0;
@@ -296,6 +297,7 @@ int vv_set_option(vv_ctx* c, const char* name, double value) {
   if (n == "fwd_merge") { c->ko.fwd_merge = iv; return VV_OK; }
   if (n == "wgrad_tr") { c->ko.wgrad_tr = iv != 0; return VV_OK; }
   if (n == "score_stream") { c->ko.score_stream = iv; return VV_OK; }
+  if (n == "score_pf") { c->ko.score_pf = iv; return VV_OK; }
   if (n == "comm_gate") { c->comm_gate = iv != 0; return VV_OK; }
   if (n == "comm_inline") { c->comm_inline = iv != 0; return VV_OK; }
   if (n == "comm_first_inline") { c->overlap_first_inline = iv != 0; return VV_OK; }
@@ -325,6 +327,7 @@ int vv_get_option(vv_ctx* c, const char* name, double* value) {
   else if (n == "fwd_merge") *value = c->ko.fwd_merge;
   else if (n == "wgrad_tr") *value = c->ko.wgrad_tr;
   else if (n == "score_stream") *value = c->ko.score_stream;
+  else if (n == "score_pf") *value = c->ko.score_pf;
   else if (n == "comm_gate") *value = c->comm_gate;
   else if (n == "comm_inline") *value = c->comm_inline;
   else if (n == "comm_first_inline") *value = c->overlap_first_inline;

@@ -607,6 +607,15 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
       }
     }
   }
+  // (round 6, ScoreArgs::prefetch, f16 rows: this workgroup is in the kernel's FIRST round -- blocks 0 .. n/2 - 1 are resident together, two per
+  // CU --; block bid + n/2 of the second round runs on the same XCD.  While this item's compute phases run the memory system is idle (every
+  // workgroup of a round loads, then computes, in step): one line of the second-round item's rows per thread is requested then, into the XCD's
+  // L2, where the second round finds it.  The row index is requested here, with this item's own indices, so that nothing waits for it later.)
+  int pf_row = -1;
+  if (H16 && a.prefetch && !a.items_rr && !((int)gridDim.x & 7) && THREADS == 512) {
+    const int bid2 = (int)blockIdx.x + ((int)gridDim.x >> 1), r2 = tid >> 3;
+    if (bid2 < (int)gridDim.x && r2 < CN) pf_row = a.map[((bid2 & 7) * ((int)gridDim.x >> 3) + (bid2 >> 3)) * CN + r2];
+  }
   float4 x[RPW][DV];
 #pragma unroll
   for (int k = 0; k < RPW; ++k) {
@@ -687,6 +696,13 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd(ScoreArgs a) {
   }
   __syncthreads();
   SF_TS(2)                                         // every wave's target / negative rows have arrived and are reduced
+  if (H16 && a.prefetch) {
+    // the second round's rows: one 128-byte line per thread, requested as an LDS-DMA into 256 dead bytes behind the kernel's LDS arrays (a
+    // load into a register would land, whenever it lands, in a register the compiler has long handed to something else); never waited for
+    const char* pf = (const char*)a.H + (int64_t)(pf_row >= 0 ? pf_row : 0) * D * 2 + (tid & 7) * 128;
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)((__attribute__((address_space(3))) void*)(ooff + CN + 4)));
+    if (pf_row >= 0) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, off" :: "s"(m0v & ~3u), "v"(pf) : "m0", "memory");
+  }
 
   // ---- scores, hinge, loss, coefficients
   const float sp = tq[0] / (sqrtf(n2[0]) + eps);
@@ -1229,6 +1245,7 @@ bool score_fwd_dropout_supported(int D, int C, int Nn) { return D == 512 && C - 
 void launch_score_fwd(const ScoreArgs& a_in, hipStream_t s) {
   ScoreArgs a = a_in;
   a.items_rr = ko().score_rr;
+  a.prefetch = ko().score_pf;
   const int rows = 1 + a.Nn;
   if (!(a.D == 512 && a.C - 1 <= 6 && rows <= 56) || ko().score_stream == 1) {
     const size_t lds = sizeof(float) * ((size_t)(2 + 8) * a.D + 4 * 8);
@@ -1242,7 +1259,7 @@ void launch_score_fwd(const ScoreArgs& a_in, hipStream_t s) {
 #undef VV_SS
     return;
   }
-  const size_t lds = sizeof(float) * ((size_t)(2 + 8) * a.D + 4 * (a.C + a.Nn) + 3 * 8);
+  const size_t lds = sizeof(float) * ((size_t)(2 + 8) * a.D + 4 * (a.C + a.Nn) + 3 * 8) + 288;      // (+ 288: the prefetch's dead LDS-DMA target, ScoreArgs::prefetch)
 #ifdef VV_LAB
   // the persistent, pipelined form: batches of at least two items per CU, no dropout (KernelOpts::score_pipe, VV_SCORE_PIPE=0: one workgroup per item)
   static int n_cu = 0;

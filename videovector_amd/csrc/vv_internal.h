@@ -208,6 +208,7 @@ struct ScoreArgs {
   DropSpec drop;                     // de-duplicated execution with dropout (k_score_fwd): H holds the SHARED pre-dropout rows, every
                                      // instance applies its own mask as it reads its row
   int h16 = 0;                       // H holds f16 rows (FwdArgs::h16): launch_score_fwd's kernels only
+  int prefetch = 0;                  // k_score_fwd, f16 rows: first-round workgroups touch the second round's rows into the XCD's L2 (KernelOpts::score_pf)
   int lab_hack = 0;                  // (lab builds, VV_LAB_SCORE_HACK: timing studies of k_score_fwd's row loads -- WRONG results) 1: rows 1 KiB apart (half the footprint, the same requests), 2: only the first half of every row is loaded (half the bytes and requests)
   uint32_t* lab_ts = nullptr;        // (lab builds, VV_LAB_SCORE_TS=1: 16 words per item -- shader-clock stamps of k_score_fwd's phases, 100 MHz
                                      //  real time of its start and end, the compute unit it ran on; the product never sets or reads it)
@@ -385,6 +386,7 @@ struct KernelOpts {
   int fwd_merge = 0;       // "fwd_merge" / VV_FWD_MERGE: the forward GEMM with two phases per barrier pair (k_fwd_gemm_ph, MRG)
   int wgrad_tr = 1;        // "wgrad_tr" / VV_WGRAD_TR: transposed LDS reads in the weight-gradient GEMM (0: the round-1 kernel)
   int score_stream = 0;    // "score_stream" / VV_SCORE_STREAM: the one-sweep score kernel for every shape
+  int score_pf = 0;        // "score_pf" / VV_SCORE_PF: k_score_fwd's first-round workgroups prefetch the second round's rows into L2 (ScoreArgs::prefetch)
   int gemm_variant = 5;    // (lab) VV_GEMM_VARIANT: 5 = the phase-staggered kernels; 0 = the round-1 kernels; 6 / 7 / 8 mixtures
   int ablate = 0;          // (lab) VV_ABLATE: ablated instantiations of the dense-size GEMMs (results wrong)
   int lab_fwd_abl = 0;     // (lab) VV_LAB_FWD_ABL: ablations of the 192-row forward kernel at the de-duplicated size (results wrong)
