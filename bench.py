@@ -714,16 +714,18 @@ def main():
             for k, v in s_kern.items():
                 if k not in GEMMS:
                     kern[k] = v
-        if args.dedup == "on" and run.eng.get_option("h16"):
-            # round 6: ip2 travels as f16 between the forward GEMM and the segment-wise pair (option "h16", one more f16 rounding of the
-            # embeddings: DESIGN.md 3.6 / 5); the same steps with fp32 rows -- the rounds 1-5 form -- beside it
+        if args.dedup == "on" and (run.eng.get_option("h16") or run.eng.get_option("slab16")):
+            # round 6: two 16-bit intermediates (options "h16": ip2 between the forward GEMM and the segment-wise pair as f16; "slab16": the
+            # weight gradient's split-K partial products as f16 x a power of two per tile) -- the same steps with both as
+            # fp32, the rounds 1-5 arithmetic, beside the line
+            h16_was, s16_was = run.eng.get_option("h16"), run.eng.get_option("slab16")
             run.reset(True)
-            run.eng.set_option("h16", 0)
+            run.eng.set_option("h16", 0); run.eng.set_option("slab16", 0)
             f_el, f_kern, _ = run.timed("resident")
-            run.eng.set_option("h16", 1)
-            extra["fp32_ip2_execution"] = {"value": Bg * NN * K / f_el, "unit": "triplets/s", "ms_per_step": f_el / K * 1e3,
-                                           "source": "resident indices; option h16 = 0 (VV_H16=0): ip2 rows as fp32",
-                                           "kernels_ms": {k: round(v[0], 4) for k, v in f_kern.items() if v[1] > 0}}
+            run.eng.set_option("h16", h16_was); run.eng.set_option("slab16", s16_was)
+            extra["fp32_intermediates_execution"] = {"value": Bg * NN * K / f_el, "unit": "triplets/s", "ms_per_step": f_el / K * 1e3,
+                                                    "source": "resident indices; options h16 = 0 and slab16 = 0 (VV_H16=0 VV_SLAB16=0): ip2 rows and split-K partial products as fp32",
+                                                    "kernels_ms": {k: round(v[0], 4) for k, v in f_kern.items() if v[1] > 0}}
         if args.dedup == "on":
             run.reset(False)
             d_el, d_kern, _ = run.timed("resident")
@@ -934,6 +936,8 @@ def main():
                        "ip2_rows": ("f16 between the forward GEMM and the score / segment kernels (option h16; fp32 accumulate, one f16 rounding of the "
                                     "stored embedding: rows 3.5e-4, scores 5e-5 off the fp32 CPU path on whole batches, tests/test_gpu_fullsize.py)"
                                     if (args.dedup == "on" and DROPOUT == 0 and os.environ.get("VV_H16", "1") != "0" and D in (512, 1024)) else "fp32"),
+                       "split_k_partials": ("f16 x one power of two per (split, 256 x 256 tile), summed in fp32 (option slab16; dW 3.5e-4 -> 4.6e-4 off the "
+                                            "oracle on the same operands)" if (os.environ.get("VV_SLAB16", "1") != "0" and not shipped) else "fp32"),
                        "dedup": args.dedup if DROPOUT == 0 else "off (dropout at D = 4096: dense kernels -- the de-duplicated path carries the per-instance masks at D = 512 only, and 128-item batches hardly repeat a row)",
                        "sampler_host": ({"avx512_forms": bool(sampler.stat(7) == 1), "cores_held_for_stage_threads": int(sampler.stat(9))}
                                         if sampler is not None else None),

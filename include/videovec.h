@@ -71,6 +71,8 @@ int vv_set_dedup(vv_ctx* ctx, int on);
  *                                    fp32 (half of the 134 MB they cost per step at the benchmark's shape; a second rounding, 2^-12 relative per
  *                                    partial product, in the gradient path -- every split still accumulates in fp32 and the sum over the splits is
  *                                    taken in fp32: dW against the oracle on the same operands 3.5e-4 -> 4.6e-4 on whole batches); 0: fp32 slabs
+ *   "score_pf" (VV_SCORE_PF, 1)      the register-resident score kernel's first-round workgroups request the second round's rows into the XCD's L2
+ *                                    while they compute (bit-identical results)
  *   "fuse_update" (VV_FUSE_UPDATE, 1) reduction of the split-K partials and the solver update in one launch (0: two launches)
  *   "fwd_lead" (VV_FWD_LEAD, 1)      the forward GEMM's sibling lead
  *   "fwd_merge" (VV_FWD_MERGE, 0)    the forward GEMM with two phases per barrier pair (bit-identical results; measured not faster)

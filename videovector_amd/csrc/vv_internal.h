@@ -386,7 +386,7 @@ struct KernelOpts {
   int fwd_merge = 0;       // "fwd_merge" / VV_FWD_MERGE: the forward GEMM with two phases per barrier pair (k_fwd_gemm_ph, MRG)
   int wgrad_tr = 1;        // "wgrad_tr" / VV_WGRAD_TR: transposed LDS reads in the weight-gradient GEMM (0: the round-1 kernel)
   int score_stream = 0;    // "score_stream" / VV_SCORE_STREAM: the one-sweep score kernel for every shape
-  int score_pf = 0;        // "score_pf" / VV_SCORE_PF: k_score_fwd's first-round workgroups prefetch the second round's rows into L2 (ScoreArgs::prefetch)
+  int score_pf = 1;        // "score_pf" / VV_SCORE_PF=0: k_score_fwd's first-round workgroups prefetch the second round's rows into L2 (ScoreArgs::prefetch; 23.4 -> 22.8 us)
   int gemm_variant = 5;    // (lab) VV_GEMM_VARIANT: 5 = the phase-staggered kernels; 0 = the round-1 kernels; 6 / 7 / 8 mixtures
   int ablate = 0;          // (lab) VV_ABLATE: ablated instantiations of the dense-size GEMMs (results wrong)
   int lab_fwd_abl = 0;     // (lab) VV_LAB_FWD_ABL: ablations of the 192-row forward kernel at the de-duplicated size (results wrong)
