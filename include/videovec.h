@@ -71,6 +71,8 @@ int vv_set_dedup(vv_ctx* ctx, int on);
  *                                    fp32 (half of the 134 MB they cost per step at the benchmark's shape; a second rounding, 2^-12 relative per
  *                                    partial product, in the gradient path -- every split still accumulates in fp32 and the sum over the splits is
  *                                    taken in fp32: dW against the oracle on the same operands 3.5e-4 -> 4.6e-4 on whole batches); 0: fp32 slabs
+ *   "v16" (VV_V16, 1)                with h16, D = 1024 (the one-sweep score kernel: hundreds of negatives per item): the two per-item vectors the
+ *                                    segment-wise backward gathers once per instance stored as f16 (one more 2^-12 in the gradient)
  *   "score_pf" (VV_SCORE_PF, 1)      the register-resident score kernel's first-round workgroups request the second round's rows into the XCD's L2
  *                                    while they compute (bit-identical results)
  *   "fuse_update" (VV_FUSE_UPDATE, 1) reduction of the split-K partials and the solver update in one launch (0: two launches)

@@ -64,3 +64,21 @@ def test_split_k_partials_as_f16(vv, prec, D, B, C, Nn):
     assert np.isfinite(s["dW"]).all() and np.all(np.abs(s["dW"] - a["dW"]) <= 16 * 2.0 ** -11 * 8 * slack + 1e-12)
     s2 = run(vv, prec, table, idx, W, b, C, Nn, h16=1, slab16=1)
     assert np.array_equal(s2["dW"], s["dW"])
+
+
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+def test_per_item_vectors_as_f16_on_the_one_sweep_path(vv, prec):
+    """Option v16 (D = 1024, the one-sweep score kernel: the per-GPU shape of BASELINE configs[4]): Ah_b and dA_b leave as f16 -- dA_b times a
+    power of two whose inverse rides in the context instances' alpha -- and k_seg_bwd gathers half the bytes.  The forward pass is untouched;
+    the gradient moves by one more 2^-12."""
+    D, B, C, Nn = 1024, 64, 5, 200
+    ds, table, idx, W, b = make_case(31, 64, B, C, Nn, 1024, D, wstd=0.02)
+    idx[:, C:] = idx[:, C:] % 900
+    a = run(vv, prec, table, idx, W, b, C, Nn, h16=1, slab16=0, v16=0)
+    v = run(vv, prec, table, idx, W, b, C, Nn, h16=1, slab16=0, v16=1)
+    assert np.array_equal(v["ip2"], a["ip2"]) and v["loss"] == a["loss"]
+    print("V16 %s: dW %.2e db %.2e" % (prec, rel_fro(v["dW"], a["dW"]), rel_fro(v["db"], a["db"])))
+    tol = 1e-3 if prec == "f16" else 4e-3          # (bf16: dYu is rounded to 8 bits behind the sum -- a 2^-12 change of an input flips roundings of 2^-9)
+    assert rel_fro(v["dW"], a["dW"]) <= tol and rel_fro(v["db"], a["db"]) <= 1e-3
+    v2 = run(vv, prec, table, idx, W, b, C, Nn, h16=1, slab16=0, v16=1)
+    assert np.array_equal(v2["dW"], v["dW"]) and np.array_equal(v2["db"], v["db"])

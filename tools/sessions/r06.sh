@@ -42,6 +42,16 @@ for task in "$@"; do
         done
       done
       summ $O/r06_${TAG}_mq*.json ;;
+    ablab)      # the same A/B on the LAB library (ablated / timing-only instantiations: VV_LAB_* switches)
+      IFS='|' read -ra ARMS <<< "${AB_ENVS:-|}"
+      for i in 1 2 3; do
+        n=0
+        for arm in "${ARMS[@]}"; do
+          env VV_LIB=$LAB $arm timeout 600 python bench.py --no-extra-legs --no-cpu-baseline --steps 400 $AB_ARGS > $O/r06_${TAG}_ablab${n}_$i.json 2>> $O/r06_${TAG}_bench.err
+          n=$((n + 1))
+        done
+      done
+      echo "arms (lab library): ${AB_ENVS}"; summ $O/r06_${TAG}_ablab*.json ;;
     ab)         # A/B of environment settings, alternating: AB_ENVS="A=1 B=2|A=2" (| separates the arms), AB_ARGS extra bench.py arguments
       IFS='|' read -ra ARMS <<< "${AB_ENVS:-|}"
       for i in 1 2 3; do

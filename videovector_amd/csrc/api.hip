@@ -143,6 +143,7 @@ static int create_init(vv_ctx* c) {
   if (const char* v = opt_env("VV_SEG_BWD")) c->seg_bwd = atoi(v) != 0;
   if (const char* v = opt_env("VV_H16")) c->h16 = atoi(v) != 0;
   if (const char* v = opt_env("VV_SLAB16")) c->slab16 = atoi(v) != 0;
+  if (const char* v = opt_env("VV_V16")) c->v16 = atoi(v) != 0;
   if (const char* v = opt_env("VV_DEDUP")) c->dedup = atoi(v) != 0;
   if (const char* v = opt_env("VV_FUSE_UPDATE")) c->fuse_update = atoi(v) != 0;
   if (const char* v = opt_env("VV_DROP_DEDUP")) c->drop_dedup = atoi(v) != 0;
@@ -292,6 +293,7 @@ int vv_set_option(vv_ctx* c, const char* name, double value) {
   if (n == "drop_dedup") { c->drop_dedup = iv != 0; return VV_OK; }
   if (n == "h16") { c->h16 = iv != 0; return VV_OK; }
   if (n == "slab16") { c->slab16 = iv != 0; return VV_OK; }
+  if (n == "v16") { c->v16 = iv != 0; return VV_OK; }
   if (n == "fuse_update") { c->fuse_update = iv != 0; return VV_OK; }
   if (n == "fwd_lead") { c->ko.fwd_lead = iv; return VV_OK; }
   if (n == "fwd_merge") { c->ko.fwd_merge = iv; return VV_OK; }
@@ -322,6 +324,7 @@ int vv_get_option(vv_ctx* c, const char* name, double* value) {
   else if (n == "drop_dedup") *value = c->drop_dedup;
   else if (n == "h16") *value = c->h16;
   else if (n == "slab16") *value = c->slab16;
+  else if (n == "v16") *value = c->v16;
   else if (n == "fuse_update") *value = c->fuse_update;
   else if (n == "fwd_lead") *value = c->ko.fwd_lead;
   else if (n == "fwd_merge") *value = c->ko.fwd_merge;
@@ -1069,6 +1072,10 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   const bool seg = dd && c->seg_bwd && score_fwd_supported(sa);
   if (seg != seg_path) return fail(VV_ERR_STATE, "internal error: the forward pass was planned for %s rows of ip2, the score kernels expect the other form", h16 ? "f16" : "fp32");
   sa.h16 = h16 ? 1 : 0;
+  // the per-item vectors as f16: the one-sweep kernel's D = 1024 form only (840 k gathers of a 4 KB row per step at configs[4]'s per-GPU shape;
+  // at D = 512 the 2 MB matrix lives in L2 and 16-bit vectors measured net zero, profiles/r04_h16_intermediate.txt)
+  const bool v16 = h16 && c->v16 && D == 1024 && !drop_on;
+  sa.v16 = v16 ? 1 : 0;
   c->last_seg_bwd = seg; c->last_score = sa;
   // f16 gradient-scale guard (vv_internal.h: GradGuard): the kernels that round gradients to 16 bits are launched once as
   // usual (round 0) and once more per guard round as conditional repeats -- near-empty launches unless the round before
@@ -1098,7 +1105,7 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
 #endif
     if (gd.gg && proactive) { sa.bound_out = c->gg_bound; sa.bound_seq = seq; }
     ba.H = c->H; ba.V = c->segV; ba.rec = c->seg_rec; ba.seg_start = c->dd_seg; ba.info = c->dd_info; ba.dYu = c->dYu;
-    ba.dbp = c->seg_dbp; ba.Rp = c->Rp; ba.D = D; ba.Dp = c->Dp; ba.inv_sg = 1.f / c->sg; ba.h16 = h16 ? 1 : 0;
+    ba.dbp = c->seg_dbp; ba.Rp = c->Rp; ba.D = D; ba.Dp = c->Dp; ba.inv_sg = 1.f / c->sg; ba.h16 = h16 ? 1 : 0; ba.v16 = v16 ? 1 : 0;
     if (drop_on) ba.drop = dsp;
   } else if (dd) {
     ga.dYh = c->dYh; ga.seg_start = c->dd_seg; ga.info = c->dd_info; ga.dYu = c->dYu; ga.Rp = c->Rp; ga.Dp = c->Dp;

@@ -1066,7 +1066,10 @@ __global__ __launch_bounds__(64 * NW) void k_score_fwd_p(ScoreArgs a) {
 // 2.26 ms cfg-5 step; this kernel 0.47 ms.)  Sums in a fixed order: a wave's rows in sequence, then the waves in sequence.
 // (DV = 4 sits at the edge of 128 VGPRs: two workgroups per CU need 4 waves per SIMD -- the gradient bound's two registers
 // pushed it to 131 and one workgroup per CU, 0.47 -> 0.70 ms at cfg 5; the second launch bound holds it at 128)
-template <int NW, int DV, bool H16 = false>
+// V16 (round 6, ScoreArgs::v16): the two per-item vectors k_seg_bwd gathers once per instance -- Ah_b and dA_b -- leave as f16 (840 k gathers
+// of a 4 KB row at the per-GPU shape of configs[4]: half the bytes).  Ah_b as it is (|values| <= 1); dA_b times a power of two that puts its
+// largest magnitude in [2^13, 2^14), whose inverse rides in the context instances' alpha (exact) -- so their records are written behind dA_b.
+template <int NW, int DV, bool H16 = false, bool V16 = false>
 __global__ __launch_bounds__(64 * NW, DV == 4 ? 4 : 1) void k_score_stream(ScoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int THREADS = 64 * NW;
@@ -1095,12 +1098,13 @@ __global__ __launch_bounds__(64 * NW, DV == 4 ? 4 : 1) void k_score_stream(Score
   const float sA = block_sum_w<NW>(ssq, red);
   const float nA = sqrtf(sA) + eps;
   float* Vb = a.V + (int64_t)2 * b * D;
+  _Float16* Vh = (_Float16*)a.V + (int64_t)2 * b * D;
 #pragma unroll
   for (int v = 0; v < CV; ++v) {
     const int d = tid + v * THREADS;
     const float ah = A[d] / nA;
     Ah[d] = ah;
-    Vb[d] = ah;
+    if (V16) Vh[d] = (_Float16)ah; else Vb[d] = ah;
   }
   __syncthreads();
   float4 y[DV];
@@ -1196,10 +1200,11 @@ __global__ __launch_bounds__(64 * NW, DV == 4 ? 4 : 1) void k_score_stream(Score
   }
 #pragma unroll
   for (int v = 0; v < DV; ++v) *(float4*)(acc0 + wave * D + h_col<H16>(lane, v)) = pa[v];
-  for (int j = 1 + tid; j < C; j += THREADS) {
-    SegRec rc; rc.alpha = a.coeff[j - 1] * a.drop_scale * a.sg; rc.beta = 0.f; rc.vec = 2 * b + 1; rc.pad = b * CN + j;
-    a.rec[a.seg_start[map[j]] + ord[j]] = rc;
-  }
+  if (!V16)
+    for (int j = 1 + tid; j < C; j += THREADS) {
+      SegRec rc; rc.alpha = a.coeff[j - 1] * a.drop_scale * a.sg; rc.beta = 0.f; rc.vec = 2 * b + 1; rc.pad = b * CN + j;
+      a.rec[a.seg_start[map[j]] + ord[j]] = rc;
+    }
   if (lane == 0) red[3 * NW + wave] = bnd;          // (a fourth group of NW words behind the three of the loss sums)
   __syncthreads();
 
@@ -1222,10 +1227,33 @@ __global__ __launch_bounds__(64 * NW, DV == 4 ? 4 : 1) void k_score_stream(Score
   }
   dot = block_sum_w<NW>(dot, red);
   const float inv_denA = 1.f / (sA * sqrtf(sA) + eps);
+  if (V16) {
+    float da[CV], m = 0.f;
 #pragma unroll
-  for (int v = 0; v < CV; ++v) {
-    const int d = tid + v * THREADS;
-    Vb[D + d] = (sA * u[v] - A[d] * dot) * inv_denA;
+    for (int v = 0; v < CV; ++v) { da[v] = (sA * u[v] - A[tid + v * THREADS] * dot) * inv_denA; m = fmaxf(m, fabsf(da[v])); }
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) m = fmaxf(m, __shfl_xor(m, o2, 64));
+    __syncthreads();                                // (block_sum_w's readers of red[0 .. NW) are done)
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w]);
+    float sc = 1.f;
+    if (m > 0.f && m < 3.0e38f) { int e; (void)frexpf(m, &e); sc = ldexpf(1.f, 14 - e); }      // m sc in [2^13, 2^14)
+#pragma unroll
+    for (int v = 0; v < CV; ++v) Vh[D + tid + v * THREADS] = (_Float16)(da[v] * sc);
+    const float isc = 1.f / sc;                     // (a power of two: alpha_j / sc times the stored row is alpha_j dA_b)
+    for (int j = 1 + tid; j < C; j += THREADS) {
+      SegRec rc; rc.alpha = a.coeff[j - 1] * a.drop_scale * a.sg * isc; rc.beta = 0.f; rc.vec = 2 * b + 1; rc.pad = b * CN + j;
+      a.rec[a.seg_start[map[j]] + ord[j]] = rc;
+    }
+  } else {
+#pragma unroll
+    for (int v = 0; v < CV; ++v) {
+      const int d = tid + v * THREADS;
+      Vb[D + d] = (sA * u[v] - A[d] * dot) * inv_denA;
+    }
   }
   if (tid == 0 && a.bound_out) {                    // as k_score_fwd
     float coeff_max = 0.f;       // max |coeff_j|: the context instances' gradient bound
@@ -1255,6 +1283,10 @@ void launch_score_fwd(const ScoreArgs& a_in, hipStream_t s) {
       VV_LAUNCH((k_score_stream<8, DV, H16>), dim3(a.B), dim3(512), lds, s, a);                            \
     } while (0)
     if (a.D == 512) { if (a.h16) VV_SS(2, true); else VV_SS(2, false); }
+    else if (a.h16 && a.v16) {
+      (void)hipFuncSetAttribute((const void*)k_score_stream<8, 4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      VV_LAUNCH((k_score_stream<8, 4, true, true>), dim3(a.B), dim3(512), lds, s, a);
+    }
     else { if (a.h16) VV_SS(4, true); else VV_SS(4, false); }
 #undef VV_SS
     return;
@@ -1316,7 +1348,7 @@ template <bool H16> __device__ __forceinline__ void seg_row8(const float* H, int
 // DROP (SegBwdArgs::drop, CH == 1): every instance carries its own dropout mask m_i over the shared row:
 //   dx_u = [x_u > 0] (sum_i m_i alpha_i V_i - x_u scale sum_i m_i beta_i)        (alpha, beta already carry one factor scale)
 // -- the mask regenerated per instance from its reference row (b = vec / 2, ch = pad - b CN), the beta sum per column.
-template <typename T, int CH, bool DROP = false, bool H16 = false>
+template <typename T, int CH, bool DROP = false, bool H16 = false, bool V16 = false>
 __global__ __launch_bounds__(256) void k_seg_bwd(SegBwdArgs a) {
   static_assert(!DROP || CH == 1, "dropout rides the D = 512 form");
   __shared__ float cs[4][512 * CH];
@@ -1405,10 +1437,7 @@ __global__ __launch_bounds__(256) void k_seg_bwd(SegBwdArgs a) {
 #pragma unroll
         for (int k = 0; k < UN; ++k)
 #pragma unroll
-          for (int c = 0; c < CH; ++c) {
-            const float* vp = a.V + (int64_t)r[k].vec * D + 512 * c + c0;
-            v0[k][c] = *(const float4*)vp; v1[k][c] = *(const float4*)(vp + 4);
-          }
+          for (int c = 0; c < CH; ++c) seg_row8<V16>(a.V, (int64_t)r[k].vec * D + 512 * c + c0, v0[k][c], v1[k][c]);
 #pragma unroll
         for (int k = 0; k < UN; ++k) {
           const float al = r[k].alpha;
@@ -1448,8 +1477,8 @@ __global__ __launch_bounds__(256) void k_seg_bwd(SegBwdArgs a) {
         }
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-          const float* vp = a.V + (int64_t)r.vec * D + 512 * c + c0;
-          const float4 v0 = *(const float4*)vp, v1 = *(const float4*)(vp + 4);
+          float4 v0, v1;
+          seg_row8<V16>(a.V, (int64_t)r.vec * D + 512 * c + c0, v0, v1);
           acc[c][0] += r.alpha * v0.x; acc[c][1] += r.alpha * v0.y; acc[c][2] += r.alpha * v0.z; acc[c][3] += r.alpha * v0.w;
           acc[c][4] += r.alpha * v1.x; acc[c][5] += r.alpha * v1.y; acc[c][6] += r.alpha * v1.z; acc[c][7] += r.alpha * v1.w;
         }
@@ -1473,8 +1502,8 @@ __global__ __launch_bounds__(256) void k_seg_bwd(SegBwdArgs a) {
         const uint32_t kp = DROP ? keep8(r) : 0xffu;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-          const float* vp = a.V + (int64_t)r.vec * D + 512 * c + c0;
-          const float4 v0 = *(const float4*)vp, v1 = *(const float4*)(vp + 4);
+          float4 v0, v1;
+          seg_row8<V16>(a.V, (int64_t)r.vec * D + 512 * c + c0, v0, v1);
           const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
           for (int j = 0; j < 8; ++j) dacc[c][j] += (!DROP || ((kp >> j) & 1u)) ? (al * (double)vv[j] + M) - M : 0.0;
@@ -1537,6 +1566,11 @@ void launch_seg_bwd(int prec, const SegBwdArgs& a, hipStream_t s) {
                                  else VV_LAUNCH((k_seg_bwd<T, CH, DROP, false>), dim3(nb), dim3(256), 0, s, a); } while (0)
   if (a.drop.mode && ch == 1) {
     if (prec == 0) VV_SB(F16, 1, true); else VV_SB(BF16, 1, true);
+    return;
+  }
+  if (ch == 2 && a.h16 && a.v16) {               // (the one-sweep score kernel's f16 vectors: SegBwdArgs::v16)
+    if (prec == 0) VV_LAUNCH((k_seg_bwd<F16, 2, false, true, true>), dim3(nb), dim3(256), 0, s, a);
+    else VV_LAUNCH((k_seg_bwd<BF16, 2, false, true, true>), dim3(nb), dim3(256), 0, s, a);
     return;
   }
   if (prec == 0) { if (ch == 1) VV_SB(F16, 1, false); else VV_SB(F16, 2, false); }

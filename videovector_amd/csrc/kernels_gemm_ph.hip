@@ -729,6 +729,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
       for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) acc[nh][ni][mh][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // (lab, ABL bit 12: the same 128 accumulator registers as eight 32 x 32 tiles -- a timing study of the other MFMA shape, results wrong)
+  constexpr bool M32T = (ABL & 4096) != 0;
+  typedef float f32x16_t __attribute__((ext_vector_type(16)));
+  f32x16_t acc32[2][2][2];
+  if (M32T) {
+#pragma unroll
+    for (int x = 0; x < 8; ++x)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc32[x >> 2][(x >> 1) & 1][x & 1][j] = 0.f;
+  }
 
   // staging: instruction i (0, 1) of this wave fills k-rows (i*8 + wave)*4 .. +3 of a half-tile; lane -> (row, chunk).
   // dY rows advance by a constant stride, so its two source pointers are simply incremented; the upper column half of
@@ -828,6 +838,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
     __builtin_amdgcn_s_barrier();                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
     WTS("s[90:91]")                                                                                    \
+    if (M32T) {                /* (lab, ABL bit 12: TIMING ONLY -- the phase's 256 clocks of matrix pipe as 8 x 32x32x16 instead of 16 x 16x16x32, */ \
+      _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)  /* the same fragment registers read; results wrong) */ \
+        acc32[nh][ni >> 1][mh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, xf[ni][kk]), __builtin_bit_cast(f16x8, yf[ni & 1][kk]), acc32[nh][ni >> 1][mh], 0, 0, 0); \
+    } else                                                                                             \
     if (!abl_mm) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)  \
       _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                 \
         acc[nh][ni][mh][mi] = T::mfma(xf[ni][kk], yf[mi][kk], acc[nh][ni][mh][mi]);                    \
@@ -980,6 +994,19 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
       if (blockIdx.x == 0) { u.scales->sw_cur = sw; if (u.recompute_scale) u.scales->sw_next = sw; }
     }
     return;
+  }
+  if constexpr (M32T) {
+    const float z = (float)(a.abl & 1);            // (0 at run time: the timing study stores zeros -- the trajectory stays that of a decaying W)
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[nh][ni][mh][mi][j] = acc32[nh][ni >> 1][mh][((ni & 1) * 2 + mi) * 4 + j] * z;
   }
   if constexpr (S16) {
     // ---- f16 slabs: the tile's largest magnitude -> a power of two that puts it in [2^14, 2^15) -> halves, eight consecutive columns per lane
@@ -1431,7 +1458,7 @@ static void launch_wgrad_ph_t(const WgradArgs& a, hipStream_t s) {
         VV_LAUNCH((k_wgrad_gemm_ph<T, N>), grid, block, PH_WG_LDS_BYTES, s, a);                         \
         return;                                                                                        \
       }
-      VV_ABL_WGP(1) VV_ABL_WGP(2) VV_ABL_WGP(3) VV_ABL_WGP(4) VV_ABL_WGP(6) VV_ABL_WGP(7) VV_ABL_WGP(8) VV_ABL_WGP(9) VV_ABL_WGP(64) VV_ABL_WGP(71)
+      VV_ABL_WGP(1) VV_ABL_WGP(2) VV_ABL_WGP(3) VV_ABL_WGP(4) VV_ABL_WGP(6) VV_ABL_WGP(7) VV_ABL_WGP(8) VV_ABL_WGP(9) VV_ABL_WGP(64) VV_ABL_WGP(71) VV_ABL_WGP(4096)
 #undef VV_ABL_WGP
     }
   }

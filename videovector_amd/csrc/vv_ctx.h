@@ -100,6 +100,7 @@ struct vv_ctx {
   bool last_seg_bwd = false;
   bool slab16 = true;              // option "slab16" (VV_SLAB16=0: fp32): the weight gradient's split-K partial products as f16 x a power of two per (split, tile)
   float* slab_sc = nullptr;        // ... their inverse factors, [8][tiles]
+  bool v16 = true;                 // option "v16" (VV_V16=0: fp32): the per-item vectors of the one-sweep score kernel (D = 1024) as f16, with h16
   bool h16 = true;                 // option "h16" (VV_H16=0: fp32 rows): ip2 as f16 between the forward GEMM and the segment-wise pair (FwdArgs::h16)
   bool last_h16 = false;           // ... and whether the last forward pass stored it that way (the accessors read H accordingly)
   vv::ScoreArgs last_score;            // to rebuild the per-instance gradient rows for vv_blobs_get(ip1_diff)

@@ -208,6 +208,7 @@ struct ScoreArgs {
   DropSpec drop;                     // de-duplicated execution with dropout (k_score_fwd): H holds the SHARED pre-dropout rows, every
                                      // instance applies its own mask as it reads its row
   int h16 = 0;                       // H holds f16 rows (FwdArgs::h16): launch_score_fwd's kernels only
+  int v16 = 0;                       // V leaves as f16 (k_score_stream's V16 form; needs h16): SegBwdArgs::v16
   int prefetch = 0;                  // k_score_fwd, f16 rows: first-round workgroups touch the second round's rows into the XCD's L2 (KernelOpts::score_pf)
   int lab_hack = 0;                  // (lab builds, VV_LAB_SCORE_HACK: timing studies of k_score_fwd's row loads -- WRONG results) 1: rows 1 KiB apart (half the footprint, the same requests), 2: only the first half of every row is loaded (half the bytes and requests)
   uint32_t* lab_ts = nullptr;        // (lab builds, VV_LAB_SCORE_TS=1: 16 words per item -- shader-clock stamps of k_score_fwd's phases, 100 MHz
@@ -251,6 +252,7 @@ struct SegBwdArgs {
   GuardArgs guard;
   DropSpec drop;                 // as ScoreArgs::drop: dx_u = [x_u > 0] (sum_i m_i alpha_i V_i - x_u scale sum_i m_i beta_i), m_i the instance's mask
   int h16 = 0;                   // H holds f16 rows (FwdArgs::h16)
+  int v16 = 0;                   // V holds f16 rows (ScoreArgs::v16: the one-sweep score kernel wrote them so)
 };
 
 struct SegsumArgs {
