@@ -769,7 +769,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
                           "s_mov_b32 s95, 0\n\ts_mov_b32 s96, 0\n\ts_mov_b32 s97, 0\n\ts_mov_b32 s98, 0\n\ts_mov_b32 s99, 0" ::: WTS_CLOB);
   for (int c0 = 0; c0 < nk_all; c0 += PH_WG_IDS / BK) {      // super-chunks of at most 128 K-tiles
     const int nk_c = nk_all - c0 < PH_WG_IDS / BK ? nk_all - c0 : PH_WG_IDS / BK;
-    const int nk = (nk_c + 1) & ~1;                           // even number of K-tiles; a padded one multiplies zeros
+    // (round 6: an odd count runs its last K-tile alone -- the padded, all-zero partner tile of rounds 2-5 cost one of the benchmark's 42
+    // iterations per split; the row ids are still filled for an even count: the prologue stages K-tile 1 unconditionally)
+    const int nk = nk_c;
+    const int nk_ids = (nk_c + 1) & ~1;
     const int64_t kg0 = (int64_t)(k_begin + c0) * BK;
     const int live = nk_c * BK;
     __syncthreads();                                          // the previous chunk's stream is drained (tail waits)
@@ -786,7 +789,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
 #pragma unroll
       for (int j = 0; j < NID; ++j) {
         const int i = tid + j * GEMM_THREADS;
-        if (i < nk * BK) ids[i] = idv[j];
+        if (i < nk_ids * BK) ids[i] = idv[j];
       }
     }
     __syncthreads();
@@ -879,10 +882,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
     if (!SF && (t) + 2 < nk && !abl_st) issue_y((t) + 2, true, 4 * (par) + 2);                         \
     if ((t) + 2 < nk && !abl_st) { PH_WAIT(4); } else PH_WAIT(0);                                      \
     PW_MFMA(1, 0)
-    for (int t = 0; t < nk; t += 2) {
+    int t = 0;
+    for (; t + 1 < nk; t += 2) {
       PW_TILE(0, t)
       PW_TILE(1, t + 1)
     }
+    if (t < nk) { PW_TILE(0, t) }                             // (an odd count's last K-tile: t is even, its parity is 0)
     if (wm == 0) __builtin_amdgcn_s_barrier();                // waves 0-3 catch the extra barrier of waves 4-7
     if (wm == 1) __builtin_amdgcn_s_setprio(0);
     if (WTSON) asm volatile("s_memtime s[80:81]\n\ts_waitcnt lgkmcnt(0)" ::: WTS_CLOB);      // s80: end of the K loop
