@@ -132,10 +132,17 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
   const int R = a.n_dev ? *a.n_dev : a.R;
   const int nact = a.n_dev ? ((R + BMT - 1) / BMT) * tilesN : (int)gridDim.x;
   if (a.seq_host && blockIdx.x == 0 && tid == 0) __hip_atomic_store(a.seq_host, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  if ((int)blockIdx.x >= nact) return;
-  const int L = ph_xcd_remap(blockIdx.x, nact);
+  // (lab, ABL bit 13: the CEILING of a K-cut, timing only.  Every tile's workgroup runs 7/8 of its K-tiles (56 of 64: 13 824 K-tile units
+  // over 256 CUs are 54 each) and 40 further workgroups -- the ones a K-cut would put on the CUs this launch leaves idle -- run the same 56
+  // K-tiles on some tile and store nothing: no partial accumulators, no fix-up, no seam.  What the step gains with it is what a K-cut could
+  // gain at most; the grouping kernels of the next step lose their 40 CUs as they would.)
+  constexpr bool KCUT = (ABL & 8192) != 0;
+  const bool kc_helper = KCUT && (int)blockIdx.x >= nact && (int)blockIdx.x < nact + 40;
+  if ((int)blockIdx.x >= nact && !kc_helper) return;
+  const int L = kc_helper ? (((int)blockIdx.x - nact) * 5) % nact : ph_xcd_remap(blockIdx.x, nact);
   const int m0 = (L / tilesN) * BMT, n0 = (L % tilesN) * BN;
   const int Fp = a.Fp;
+  const int Rst = kc_helper ? 0 : R;            // rows this workgroup stores
 
   // staging sources: LDS-DMA instruction i (0, 1) of this wave fills rows (i*8 + wave)*8 .. +7 of a half-tile
   // (LEAD: odd column tiles hold the tile's UPPER rows in their "lower" half, the one that leads)
@@ -163,7 +170,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) acc[mh][mi][nh][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = Fp / BK;                      // K-tiles (Fp is a multiple of 256: nk % 4 == 0)
+  const int nk = KCUT ? (Fp / BK) / 8 * 7 : Fp / BK;   // K-tiles (Fp is a multiple of 256: nk % 4 == 0)
   const int H = 4 * nk;                        // half-tiles of this workgroup's stream
   // half-tile h = 4*kt + q, q: 0 A_lo, 1 B_lo, 2 B_hi, 3 A_hi; slot = h & 7
   const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(smem)) + wave * 1024;   // this wave's first piece of slot 0
@@ -464,7 +471,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
           const auto s1 = __builtin_amdgcn_permlane16_swap(p[0][1], p[1][1], false, false);
           const int n = n0 + nh * 128 + wn * 32 + (fq & 1) * 16 + (fq >> 1) * 8;
           if ((ABL & 64) && s0[0] != 12345u) continue;                    // (lab, ABL 64: no stores)
-          if (m < R && n < a.D) *(uint4*)(H16 + (int64_t)m * a.D + n) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+          if (m < Rst && n < a.D) *(uint4*)(H16 + (int64_t)m * a.D + n) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
         }
       }
   } else
@@ -474,7 +481,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_fwd_gemm_ph(FwdArgs a) {
     for (int mi = 0; mi < MQ; ++mi) {
       if (DEAD && mh == 1 && mi == MQ - 1 && dead_hi) continue;
       const int m = m0 + (mh ^ hswap) * HROWS + wm * 16 * MQ + mi * 16 + frow;
-      if (m >= R) continue;
+      if (m >= Rst) continue;
       int64_t ref_row = 0;
       uint32_t row_ctr = 0;                    // counter of the row's first quad of outputs (two counters per quad)
       if (DROP) {
@@ -1414,6 +1421,19 @@ static void launch_fwd_ph_t(const FwdArgs& a, hipStream_t s) {
       }
       VV_LAB_FWP(1) VV_LAB_FWP(2) VV_LAB_FWP(3) VV_LAB_FWP(6) VV_LAB_FWP(8) VV_LAB_FWP(14) VV_LAB_FWP(64) VV_LAB_FWP(67) VV_LAB_FWP(128) VV_LAB_FWP(256)
 #undef VV_LAB_FWP
+      if (lab_abl == 8192 && ko().fwd_lead) {   // the K-cut ceiling (k_fwd_gemm_ph, ABL bit 13), in the output form the step runs
+        long tiles_k = 0;
+        (void)fwd_pick_tile(a.R, a.n_dev ? a.R_hint : 0, a.D, &tiles_k);
+        const dim3 grid(tiles_k + 40);          // the product launch's grid + the 40 helpers
+        if (a.h16) {
+          (void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, 3, 8192, false, 0, 1, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * PH_SLOT);
+          VV_LAUNCH((k_fwd_gemm_ph<T, DROP, VEC, 3, 8192, false, 0, 1, 0, true>), grid, block, 10 * PH_SLOT, s, a);
+        } else {
+          (void)hipFuncSetAttribute((const void*)k_fwd_gemm_ph<T, DROP, VEC, 3, 8192, false, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * PH_SLOT);
+          VV_LAUNCH((k_fwd_gemm_ph<T, DROP, VEC, 3, 8192, false, 0, 1>), grid, block, 10 * PH_SLOT, s, a);
+        }
+        return;
+      }
     }
   }
   if constexpr (!DROP && VEC) {
