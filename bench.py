@@ -38,6 +38,9 @@ What is timed, and reported as what:
 Kernel durations (kernels_ms, roofline): HIP events on the kernels' own dispatch packets, on every max(5, K/8)-th step; inside the
 timed region only the forward GEMM (the dominant kernel, the roofline's) carries them -- a timed dispatch cannot be pipelined behind
 its predecessor, ~5 us each --, the other kernels are timed on the same steps of the step_ms_stats leg.
+roofline.traffic / roofline.step_traffic (HBM bytes per launch / per step): the full one-GPU line measures them ITSELF -- two child processes
+of this script under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, 8 steps each) before this process touches the GPU
+(live_traffic(); VV_BENCH_LIVE_TRAFFIC=0, --no-extra-legs or N > 1: the committed passes of profiles/pmc_latest.json instead, labelled as such).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -172,6 +175,51 @@ def box_record(box, ms_per_step, gemm_ms_in_step):
             "note": "a calibration of the box, not of the code: the top-level figures are the probe right AFTER the timed leg (steady state); "
                     "ms_per_step_at_ref = ms_per_step - gemm_ms_in_step x (1 - gemm_tflops / ref_gemm_tflops), gemm_ms_in_step = the two GEMM "
                     "kernels' durations"}
+
+
+def live_traffic(cfg_argv, first_timeout_s=300.0, timeout_s=150.0):
+    """HBM bytes per kernel launch MEASURED BY THIS INVOCATION (roofline.traffic, roofline.step_traffic): two child processes of this script,
+    each under `rocprofv3 --pmc <counter> --kernel-trace` (FETCH_SIZE and WRITE_SIZE in SEPARATE passes, as /opt/skills/guides/MI355X_MICROARCH.md
+    prescribes; no other trace domain), 8 steps of the same workload each (no box probe: its launches carry the product kernel's name; no extra
+    legs, no CPU baseline), started BEFORE this process touches the GPU and killed by process group on a time limit.  Returns (per-kernel dict
+    as tools/make_pmc_json.fold gives it, note) or (None, why not) -- the caller then falls back to the committed profile."""
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="vv_bench_pmc_", dir="/tmp")
+    t0 = time.perf_counter()
+    try:
+        for i, ctr in enumerate(("FETCH_SIZE", "WRITE_SIZE")):
+            cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, ctr), "-o", "p", "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--settle-ms", "0", "--no-cpu-baseline",
+                   "--no-extra-legs"] + cfg_argv
+            env = dict(os.environ, VV_BENCH_NO_BOX="1", VV_BENCH_CHILD="1", TMPDIR="/tmp")
+            p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = p.wait(timeout=first_timeout_s if i == 0 else timeout_s)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)            # the child is a session leader: it and everything it started, by PID
+                except OSError:
+                    pass
+                p.wait()
+                return None, "the %s pass did not finish within its time limit: killed" % ctr
+            if rc != 0:
+                return None, "the %s pass exited with %d" % (ctr, rc)
+        from tools.make_pmc_json import SOURCE, fold
+        d = fold(tmp)
+        if not d:
+            return None, "the passes left no counter rows"
+        return d, "measured by this invocation (%.0f s): %s; 8 steps per pass (2 warm-up + 6), the average over all launches of a kernel" % (
+            time.perf_counter() - t0, SOURCE)
+    except Exception as e:                                      # noqa: BLE001 -- the line falls back to the committed profile
+        return None, "%s: %s" % (type(e).__name__, e)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def helper_main():
@@ -315,6 +363,13 @@ def main():
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not args.no_extra_legs and args.workload == "cfg2" and os.environ.get("VV_BENCH_CHILD") != "1" \
             and args.allreduce != "stale" and args.comm != "torch":
         leg_helper = LegHelper()
+
+    # roofline.traffic measured by this invocation (one GPU, the full line only): the two PMC passes run as child processes HERE, before this
+    # process imports torch or touches HIP (VV_BENCH_LIVE_TRAFFIC=0: the committed profile instead)
+    live_pmc, live_pmc_note = None, "not attempted"
+    if args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_extra_legs and os.environ.get("VV_BENCH_CHILD") != "1" \
+            and os.environ.get("VV_BENCH_LIVE_TRAFFIC", "1") != "0":
+        live_pmc, live_pmc_note = live_traffic(["--workload", args.workload, "--dedup", args.dedup, "--prec", args.prec])
 
     global B_PER_GPU, NN, D
     if args.workload == "cfg5":
@@ -876,35 +931,48 @@ def main():
                     "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes}
         roof["avg_launch_ms"] = dom_ms
         roof["dedup_factor"] = R / U
-        pmc, pmc_src = None, None
+        pmc, pmc_src, pk, pmc_live = None, None, {}, False
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        committed = {}
         if os.path.exists(pmc_path) and args.workload == "cfg2":      # (the committed PMC passes are of the cfg-2 kernels)
             try:
                 pj = json.load(open(pmc_path))
-                pmc = pj.get("dedup_" + args.dedup, {}).get(dom, {}).get("hbm_bytes_per_launch")
+                committed = pj.get("dedup_" + args.dedup, {})
                 pmc_src = "profiles/pmc_latest.json (" + pj.get("_source", pj.get("source", "rocprofv3 PMC passes")) + ")"
             except Exception:
-                pmc = None
+                committed = {}
+        if live_pmc and dom in live_pmc:
+            pk, pmc_live = live_pmc, True
+        else:
+            pk = committed
+        pmc = pk.get(dom, {}).get("hbm_bytes_per_launch")
         roof["traffic"] = pmc
         # the whole step's HBM bytes by the same PMC passes beside what the de-duplicated algorithm needs
-        if os.path.exists(pmc_path) and args.workload == "cfg2" and args.dedup == "on" and DROPOUT == 0:
+        if pk and args.workload == "cfg2" and args.dedup == "on" and DROPOUT == 0:
             try:
-                pk = json.load(open(pmc_path)).get("dedup_on", {})
                 step_k = ("fwd_gemm", "score_loss", "segsum", "wgrad_gemm", "reduce_sgd")
-                pmc_step = sum(pk[k]["hbm_bytes_per_launch"] for k in step_k if k in pk)
+                pmc_step = sum(pk[k]["hbm_bytes_per_launch"] for k in step_k)
                 h_b = 2.0 if (os.environ.get("VV_H16", "1") != "0") else 4.0
                 s_b = 2.0 if (os.environ.get("VV_SLAB16", "1") != "0") else 4.0
                 alg = (2.0 * U * F * 2 + 3.0 * U * D * h_b + 2.0 * U * D * 2 + 2.0 * 8 * D * F * s_b + 4.0 * D * F * 4 + 2.0 * D * F * 2)
                 roof["step_traffic"] = {"pmc_bytes_per_step": pmc_step, "algorithmic_bytes_per_step": alg, "ratio": pmc_step / alg if alg else None,
-                                        "kernels": list(step_k),
+                                        "kernels": {k: pk[k]["hbm_bytes_per_launch"] for k in step_k},
                                         "algorithmic": "2 U F 2 (rows gathered by both GEMMs) + 3 U D h (ip2 written once, read by the score and the segment "
                                                        "kernel; h = 2 B as f16) + 2 U D 2 (dYu) + 2 S D F s (split-K partial products, s = 2 B as f16) + "
                                                        "4 D F 4 (W and history, read and written) + 2 D F 2 (the 16-bit copy of W)",
-                                        "note": "pmc: the committed passes of profiles/pmc_latest.json (sum over the step's five kernels), not measured by this run"}
+                                        "note": "pmc: the sum over the step's five kernels, " + ("measured by this invocation's own PMC passes" if pmc_live else
+                                                "the committed passes of profiles/pmc_latest.json, not measured by this run")}
             except Exception:
                 pass
-        roof["traffic_note"] = ("HBM bytes per launch from rocprofv3 PMC passes recorded in %s -- a committed profile of this "
-                                "kernel, NOT measured by this run" % pmc_src) if pmc is not None else None
+        if pmc is None:
+            roof["traffic_note"] = None
+        elif pmc_live:
+            roof["traffic_note"] = "HBM bytes per launch of this kernel, " + live_pmc_note
+            if committed.get(dom):
+                roof["traffic_committed_profile"] = committed[dom].get("hbm_bytes_per_launch")
+        else:
+            roof["traffic_note"] = ("HBM bytes per launch from rocprofv3 PMC passes recorded in %s -- a committed profile of this kernel, NOT measured "
+                                    "by this run (live passes: %s)" % (pmc_src, live_pmc_note))
         out = {
             "metric": "triplets/sec (whole node), 4096->%d-d embed, batch %d/GPU, C5, Nn%d" % (D, B_PER_GPU, NN),
             "value": value, "unit": "triplets/s", "n_gpus": world, "steps": K, "warmup": Wm,

@@ -86,7 +86,7 @@ for task in "$@"; do
       timeout 900 python bench.py --workload shipped --steps 200 --warmup 20 --no-cpu-baseline > $O/r06_${TAG}_bench_shipped.json 2>> $O/r06_${TAG}_bench.err; summ $O/r06_${TAG}_bench_shipped.json ;;
     final)      # the closing session: bench legs, rocprofv3 kernel trace + HBM PMC passes (dedup on / off), SQ counters, sampler rates, facade rate
       P0=$O/r06_${TAG}
-      timeout 900 python bench.py > ${P0}_bench.json 2> ${P0}_bench.err; echo "bench exit $?" >> ${P0}_bench.err
+      timeout 1200 python bench.py > ${P0}_bench.json 2> ${P0}_bench.err; echo "bench exit $?" >> ${P0}_bench.err
       timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > ${P0}_bench_driver_args.json 2>> ${P0}_bench.err
       timeout 600 python bench.py --dedup off --no-cpu-baseline --no-extra-legs > ${P0}_bench_dense.json 2>> ${P0}_bench.err
       timeout 600 python bench.py --prec bf16 --no-cpu-baseline --no-extra-legs > ${P0}_bench_bf16.json 2>> ${P0}_bench.err
