@@ -79,6 +79,8 @@ int vv_set_dedup(vv_ctx* ctx, int on);
  *   "fwd_lead" (VV_FWD_LEAD, 1)      the forward GEMM's sibling lead
  *   "fwd_merge" (VV_FWD_MERGE, 0)    the forward GEMM with two phases per barrier pair (bit-identical results; measured not faster)
  *   "wgrad_tr" (VV_WGRAD_TR, 1)      transposed LDS reads in the weight-gradient GEMM (0: the first-round kernel)
+ *   "wgrad_lean" (VV_WGRAD_LEAN, 1)  the weight-gradient GEMM's lean instantiations (tables below 4 GiB: gathered rows addressed as base + 32-bit
+ *                                    offset, fewer instructions in the loop's LOAD segments; bit-identical results); 0: 64-bit addresses
  *   "score_stream" (VV_SCORE_STREAM, 0)  1: the one-sweep score kernel for every shape
  *   "comm_gate" (VV_COMM_GATE, 1)    the overlapped update gates the next forward GEMM chunk by chunk (0: the stream joins)
  *   "comm_inline" (VV_COMM_INLINE, 1)  the SHARDED update's three steps (reduce-scatter, the rule on this rank's rows, all-gather) are queued

@@ -140,6 +140,7 @@ static int create_init(vv_ctx* c) {
   if (const char* v = opt_env("VV_FWD_MERGE")) c->ko.fwd_merge = atoi(v);
   if (const char* v = opt_env("VV_SCORE_STREAM")) c->ko.score_stream = atoi(v);
   if (const char* v = opt_env("VV_SCORE_PF")) c->ko.score_pf = atoi(v);
+  if (const char* v = opt_env("VV_WGRAD_LEAN")) c->ko.wgrad_lean = atoi(v);
   if (const char* v = opt_env("VV_SEG_BWD")) c->seg_bwd = atoi(v) != 0;
   if (const char* v = opt_env("VV_H16")) c->h16 = atoi(v) != 0;
   if (const char* v = opt_env("VV_SLAB16")) c->slab16 = atoi(v) != 0;
@@ -300,6 +301,7 @@ int vv_set_option(vv_ctx* c, const char* name, double value) {
   if (n == "wgrad_tr") { c->ko.wgrad_tr = iv != 0; return VV_OK; }
   if (n == "score_stream") { c->ko.score_stream = iv; return VV_OK; }
   if (n == "score_pf") { c->ko.score_pf = iv; return VV_OK; }
+  if (n == "wgrad_lean") { c->ko.wgrad_lean = iv; return VV_OK; }
   if (n == "comm_gate") { c->comm_gate = iv != 0; return VV_OK; }
   if (n == "comm_inline") { c->comm_inline = iv != 0; return VV_OK; }
   if (n == "comm_first_inline") { c->overlap_first_inline = iv != 0; return VV_OK; }
@@ -331,6 +333,7 @@ int vv_get_option(vv_ctx* c, const char* name, double* value) {
   else if (n == "wgrad_tr") *value = c->ko.wgrad_tr;
   else if (n == "score_stream") *value = c->ko.score_stream;
   else if (n == "score_pf") *value = c->ko.score_pf;
+  else if (n == "wgrad_lean") *value = c->ko.wgrad_lean;
   else if (n == "comm_gate") *value = c->comm_gate;
   else if (n == "comm_inline") *value = c->comm_inline;
   else if (n == "comm_first_inline") *value = c->overlap_first_inline;
@@ -1134,6 +1137,10 @@ static int fb_impl(vv_ctx* c, const vv_step_cfg* cfg, const int32_t* idx, int id
   wa.dYh = dd ? c->dYu : c->dYh; wa.table = c->table; wa.rows = dd ? c->dd_uniq : c->rows; wa.slabs = c->slabs;
   wa.Rp = c->Rp; wa.Dp = c->Dp; wa.Fp = c->Fp; wa.S = c->S; wa.ksteps_per_split = c->kps;
   wa.n_dev = dd ? c->dd_info : nullptr; wa.zero_row = (int32_t)c->n_rows;
+  {
+    const int64_t t_rows = c->n_rows + 1 + c->patch_cap;      // every row a K-tile can name: the table, its zero row, the scratch rows behind it
+    wa.lean = c->ko.wgrad_lean && t_rows < (1ll << 24) && (int64_t)c->Fp * 2 < (1ll << 24) && t_rows * c->Fp * 2 + 8192 < (1ll << 32);
+  }
   ReduceArgs ra;
   ra.slabs = c->slabs; ra.S = c->S; ra.Dp = c->Dp; ra.Fp = c->Fp; ra.dbp = seg ? c->seg_dbp : c->dbp; ra.B = B;
   ra.db_rows = seg ? SEGB_BLOCKS : 0;

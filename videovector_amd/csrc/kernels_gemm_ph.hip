@@ -63,6 +63,13 @@ __device__ __forceinline__ void ph_glds16_hi(const void* gsrc, unsigned char* ld
   const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(lds_wave_base - 256));
   asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off offset:256" :: "s"(m0v), "v"(gsrc) : "m0", "memory");
 }
+// The LEAN form (round 6, k_wgrad_gemm_ph): the source as a wave-uniform base in scalar registers + a 32-bit byte offset per lane, the LDS
+// address as (the wave's LDS base in a scalar register) + an immediate, added straight into M0: two instructions per issue, no address
+// arithmetic on the vector unit beyond the offset itself.  ldsimm and goff are literals; with goff the hardware moves the LDS address too
+// (see ph_glds16_hi): the caller takes it off ldsimm.
+#define PH_GLDS_S(lds_w, voff, sbase, ldsimm, goff)                                                    \
+  asm volatile("s_add_u32 m0, %0, %3\n\tglobal_load_lds_dwordx4 %1, %2 offset:" #goff                 \
+               :: "s"(lds_w), "v"(voff), "s"(sbase), "n"(ldsimm) : "m0", "scc", "memory")
 __device__ __forceinline__ int ph_xcd_remap(int bid, int nblk) {
   const int x = bid & 7, q = nblk >> 3, rem = nblk & 7;
   return x * q + (x < rem ? x : rem) + (bid >> 3);
@@ -705,7 +712,14 @@ __device__ __forceinline__ i16x4 ph_tr(const unsigned char* p) {
 
 // UPD: one split of K (S == 1) and the solver's update applied to the tile where it stands (WgradUpd, vv_internal.h) instead of the slab store
 // S16 (WgradArgs::slab16): the tile leaves as f16 x one power of two per (split, tile); stores widened as in the forward kernel's O16 form
-template <typename T, int ABL = 0, bool UPD = false, bool S16 = false>
+// LEAN (round 6; WgradArgs::lean): the LOAD segment of a phase is bound by the NUMBER of instructions the loading wave gets through the
+// issue port beside its partner's MFMA stream (tools/lab/lds_issue_lab.hip: ~15 clocks per LDS read whatever its width; by the ISA the
+// loop held 126 instructions per K-tile in its four LOAD segments, 362 clocks each, against 256 of MFMA).  The lean form issues the same
+// reads and the same stream with fewer instructions around them: sources as scalar base + 32-bit lane offset (one v_mad_u32_u24 per
+// gathered row instead of a 64-bit multiply and a 64-bit add; nothing per dY row), LDS addresses as scalar base + immediate into M0 (one
+// instruction instead of a null-checked address-space cast), and a K loop whose body carries no end-of-stream tests (the last K-tiles
+// run a checked copy).  Needs a table below 4 GiB and row ids below 2^24 (the host decides); bit-identical results.
+template <typename T, int ABL = 0, bool UPD = false, bool S16 = false, bool LEAN = false>
 __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int32_t* ids = (int32_t*)(smem + PH_LDS_BYTES);
@@ -757,6 +771,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
   const int g = lane >> 4, li = lane & 15, q4 = li >> 2, pp = li & 3;
   const uint16_t* tb0 = a.table + n0 + scol0;
   const uint16_t* tb1 = a.table + n0 + scol1;
+  // (LEAN) wave-uniform bases and per-lane byte offsets
+  const unsigned lds_w = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(smem)) + wave * 1024;
+  const uint16_t* xs = a.table + n0;
+  const unsigned Fp2 = (unsigned)a.Fp * 2u, xl0 = (unsigned)scol0 * 2u, xl1 = (unsigned)scol1 * 2u;
+  const unsigned yl0 = (unsigned)(srow0 * a.Dp + scol0) * 2u, yl1 = (unsigned)(srow1 * a.Dp + scol1) * 2u;
   // fragment reads: h(row1) does not depend on kk (bits 0, 1, 3 of the row), so kk, the +4-row partner and the slot are
   // immediate offsets of one address per fragment tile
   const int hx = ph_h(8 * g + q4) << 1;
@@ -814,14 +833,31 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
       if (!hi) { ph_glds16(tb0 + r0, dst); ph_glds16(tb1 + r1, dst + 8192); }
       else { ph_glds16_hi(tb0 + r0, dst); ph_glds16_hi(tb1 + r1, dst + 8192); }
     };
+    const uint16_t* ys = a.dYh + kg0 * a.Dp + m0;             // (LEAN) dY rows of K-tile kt: ys + kt a_step, wave-uniform
+    // hi, slot: literals (hi issues go to slots 2, 3, 6, 7: the LDS immediate stays positive)
+#define PW_ISSUE_X(i0, i1, hi, slot)                                                                   \
+    { if constexpr (LEAN) {                                                                            \
+      const unsigned o0_ = __umul24((unsigned)(i0), Fp2) + xl0, o1_ = __umul24((unsigned)(i1), Fp2) + xl1; \
+      if (!(hi)) { PH_GLDS_S(lds_w, o0_, xs, (slot) * PH_SLOT, 0); PH_GLDS_S(lds_w, o1_, xs, (slot) * PH_SLOT + 8192, 0); } \
+      else { PH_GLDS_S(lds_w, o0_, xs, (slot) * PH_SLOT - 256, 256); PH_GLDS_S(lds_w, o1_, xs, (slot) * PH_SLOT + 8192 - 256, 256); } \
+    } else issue_x(i0, i1, hi, slot); }
+#define PW_ISSUE_Y(kt, hi, slot)                                                                       \
+    { if constexpr (LEAN) {                                                                            \
+      const uint16_t* yk_ = ys + (int64_t)(kt) * a_step;                                               \
+      if (!(hi)) { PH_GLDS_S(lds_w, yl0, yk_, (slot) * PH_SLOT, 0); PH_GLDS_S(lds_w, yl1, yk_, (slot) * PH_SLOT + 8192, 0); } \
+      else { PH_GLDS_S(lds_w, yl0, yk_, (slot) * PH_SLOT - 256, 256); PH_GLDS_S(lds_w, yl1, yk_, (slot) * PH_SLOT + 8192 - 256, 256); } \
+    } else issue_y(kt, hi, slot); }
     // prologue, in stream order: X_lo(0), Y_hi(0), X_hi(0), Y_lo(0), X_lo(1), Y_hi(1)
-    issue_x(ids[srow0], ids[srow1], false, 0);
-    issue_y(0, true, 2);
-    issue_x(ids[srow0], ids[srow1], true, 3);
-    issue_y(0, false, 1);
-    issue_x(ids[BK + srow0], ids[BK + srow1], false, 4);
-    issue_y(1, true, 6);
+    {
+      const int i00 = ids[srow0], i01 = ids[srow1];
+      PW_ISSUE_X(i00, i01, false, 0)
+      PW_ISSUE_Y(0, true, 2)
+      PW_ISSUE_X(i00, i01, true, 3)
+      PW_ISSUE_Y(0, false, 1)
+    }
     int idn0 = ids[BK + srow0], idn1 = ids[BK + srow1];      // ids of the next X issue: X_hi(1) in phase (0, 0)
+    PW_ISSUE_X(idn0, idn1, false, 4)
+    PW_ISSUE_Y(1, true, 6)
     PH_WAIT(4);
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();                // waves 4-7 run one segment behind
@@ -870,37 +906,46 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
     WTS("s[84:85]")
     // one K-tile of parity par (slots 4*par ..), the stream working on K-tiles t+1 and t+2
     /* (lab, ABL bit 10: the phase's two LDS-DMA instructions IN FRONT of its fragment reads instead of behind them) */ \
-#define PW_TILE(par, t)                                                                                \
-    if (SF && (t) + 1 < nk && !abl_st) issue_x(idn0, idn1, true, 4 * (1 - (par)) + 3);                 \
+#define PW_TILE(par, t, CHK)                                                                           \
+    if (SF && (!(CHK) || (t) + 1 < nk) && !abl_st) PW_ISSUE_X(idn0, idn1, true, 4 * (1 - (par)) + 3)   \
     PW_LOAD(xf, xa, 4, 4 * (par) + 0) PW_LOAD(yf, ya, 2, 4 * (par) + 1)                                \
-    if (!SF && (t) + 1 < nk && !abl_st) issue_x(idn0, idn1, true, 4 * (1 - (par)) + 3);                \
+    if (!SF && (!(CHK) || (t) + 1 < nk) && !abl_st) PW_ISSUE_X(idn0, idn1, true, 4 * (1 - (par)) + 3)  \
     PW_MFMA(0, 0)                                                                                      \
-    if (SF && (t) + 1 < nk && !abl_st) issue_y((t) + 1, false, 4 * (1 - (par)) + 1);                   \
+    if (SF && (!(CHK) || (t) + 1 < nk) && !abl_st) PW_ISSUE_Y((t) + 1, false, 4 * (1 - (par)) + 1)     \
     PW_LOAD(yf, ya, 2, 4 * (par) + 2)                                                                  \
-    if (!SF && (t) + 1 < nk && !abl_st) issue_y((t) + 1, false, 4 * (1 - (par)) + 1);                  \
-    if ((t) + 2 < nk) { idn0 = ids[((t) + 2) * BK + srow0]; idn1 = ids[((t) + 2) * BK + srow1]; }      \
+    if (!SF && (!(CHK) || (t) + 1 < nk) && !abl_st) PW_ISSUE_Y((t) + 1, false, 4 * (1 - (par)) + 1)    \
+    if (!(CHK) || (t) + 2 < nk) { idn0 = ids[((t) + 2) * BK + srow0]; idn1 = ids[((t) + 2) * BK + srow1]; } \
     PW_MFMA(0, 1)                                                                                      \
-    if (SF && (t) + 2 < nk && !abl_st) issue_x(idn0, idn1, false, 4 * (par) + 0);                      \
+    if (SF && (!(CHK) || (t) + 2 < nk) && !abl_st) PW_ISSUE_X(idn0, idn1, false, 4 * (par) + 0)        \
     PW_LOAD(xf, xa, 4, 4 * (par) + 3)                                                                  \
-    if (!SF && (t) + 2 < nk && !abl_st) issue_x(idn0, idn1, false, 4 * (par) + 0);                     \
+    if (!SF && (!(CHK) || (t) + 2 < nk) && !abl_st) PW_ISSUE_X(idn0, idn1, false, 4 * (par) + 0)       \
     PW_MFMA(1, 1)                                                                                      \
-    if (SF && (t) + 2 < nk && !abl_st) issue_y((t) + 2, true, 4 * (par) + 2);                          \
+    if (SF && (!(CHK) || (t) + 2 < nk) && !abl_st) PW_ISSUE_Y((t) + 2, true, 4 * (par) + 2)            \
     PW_LOAD(yf, ya, 2, 4 * (par) + 1)                                                                  \
-    if (!SF && (t) + 2 < nk && !abl_st) issue_y((t) + 2, true, 4 * (par) + 2);                         \
-    if ((t) + 2 < nk && !abl_st) { PH_WAIT(4); } else PH_WAIT(0);                                      \
+    if (!SF && (!(CHK) || (t) + 2 < nk) && !abl_st) PW_ISSUE_Y((t) + 2, true, 4 * (par) + 2)           \
+    if ((!(CHK) || (t) + 2 < nk) && !abl_st) { PH_WAIT(4); } else PH_WAIT(0);                          \
     PW_MFMA(1, 0)
     int t = 0;
-    for (; t + 1 < nk; t += 2) {
-      PW_TILE(0, t)
-      PW_TILE(1, t + 1)
+    if constexpr (LEAN) {
+      // the body of the loop carries no end-of-stream tests: both of its K-tiles have two more behind them
+      for (; t + 3 < nk; t += 2) {
+        PW_TILE(0, t, 0)
+        PW_TILE(1, t + 1, 0)
+      }
     }
-    if (t < nk) { PW_TILE(0, t) }                             // (an odd count's last K-tile: t is even, its parity is 0)
+    for (; t + 1 < nk; t += 2) {
+      PW_TILE(0, t, 1)
+      PW_TILE(1, t + 1, 1)
+    }
+    if (t < nk) { PW_TILE(0, t, 1) }                          // (an odd count's last K-tile: t is even, its parity is 0)
     if (wm == 0) __builtin_amdgcn_s_barrier();                // waves 0-3 catch the extra barrier of waves 4-7
     if (wm == 1) __builtin_amdgcn_s_setprio(0);
     if (WTSON) asm volatile("s_memtime s[80:81]\n\ts_waitcnt lgkmcnt(0)" ::: WTS_CLOB);      // s80: end of the K loop
 #undef PW_LOAD
 #undef PW_MFMA
 #undef PW_TILE
+#undef PW_ISSUE_X
+#undef PW_ISSUE_Y
   }
 
   if constexpr (UPD) {
@@ -1488,21 +1533,21 @@ static void launch_wgrad_ph_t(const WgradArgs& a, hipStream_t s) {
     }
   }
 #endif
-  if (a.slab16 && !a.fuse_upd) {
-    static bool once_s = ((void)hipFuncSetAttribute((const void*)k_wgrad_gemm_ph<T, 0, false, true>,
-                          hipFuncAttributeMaxDynamicSharedMemorySize, PH_WG_LDS_BYTES), true);
-    (void)once_s;
-    VV_LAUNCH((k_wgrad_gemm_ph<T, 0, false, true>), grid, block, PH_WG_LDS_BYTES, s, a);
-    return;
+#define VV_WG_LAUNCH(...)                                                                              \
+  {                                                                                                    \
+    static bool once_ = ((void)hipFuncSetAttribute((const void*)k_wgrad_gemm_ph<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, PH_WG_LDS_BYTES), true); \
+    (void)once_;                                                                                       \
+    VV_LAUNCH((k_wgrad_gemm_ph<__VA_ARGS__>), grid, block, PH_WG_LDS_BYTES, s, a);                     \
+    return;                                                                                            \
   }
+  // (WgradArgs::lean: the table lies below 4 GiB and its row ids below 2^24 -- api.hip decides: the lean instantiations)
+  if (a.slab16 && !a.fuse_upd) { if (a.lean) VV_WG_LAUNCH(T, 0, false, true, true) else VV_WG_LAUNCH(T, 0, false, true) }
   if (a.fuse_upd) {                       // (one split of K: the update where the gradient is born -- api.hip decides, WgradUpd)
-    static bool once_u = ((void)hipFuncSetAttribute((const void*)k_wgrad_gemm_ph<T, 0, true>,
-                          hipFuncAttributeMaxDynamicSharedMemorySize, PH_WG_LDS_BYTES), true);
-    (void)once_u;
-    VV_LAUNCH((k_wgrad_gemm_ph<T, 0, true>), grid, block, PH_WG_LDS_BYTES, s, a);
-    return;
+    if (a.lean) VV_WG_LAUNCH(T, 0, true, false, true) else VV_WG_LAUNCH(T, 0, true)
   }
+  if (a.lean) VV_WG_LAUNCH(T, 0, false, false, true)
   VV_LAUNCH((k_wgrad_gemm_ph<T>), grid, block, PH_WG_LDS_BYTES, s, a);
+#undef VV_WG_LAUNCH
 }
 
 void launch_wgrad_gemm_ph(int prec, const WgradArgs& a, hipStream_t s) {

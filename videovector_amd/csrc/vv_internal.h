@@ -299,6 +299,9 @@ struct WgradArgs {
   // gradient scale, 11 significant bits per partial product -- whose inverse goes to slab_sc[split * tiles + tm * tilesN + tn]
   int slab16 = 0;
   float* slab_sc = nullptr;
+  // the LEAN instantiations of k_wgrad_gemm_ph (round 6, option "wgrad_lean"): gathered rows addressed as table + 32-bit byte offset --
+  // set by api.hip when every row of the table (scratch rows included) lies below 4 GiB and its index below 2^24
+  int lean = 0;
 };
 
 struct ReduceArgs {
@@ -389,6 +392,7 @@ struct KernelOpts {
   int wgrad_tr = 1;        // "wgrad_tr" / VV_WGRAD_TR: transposed LDS reads in the weight-gradient GEMM (0: the round-1 kernel)
   int score_stream = 0;    // "score_stream" / VV_SCORE_STREAM: the one-sweep score kernel for every shape
   int score_pf = 1;        // "score_pf" / VV_SCORE_PF=0: k_score_fwd's first-round workgroups prefetch the second round's rows into L2 (ScoreArgs::prefetch; 23.4 -> 22.8 us)
+  int wgrad_lean = 1;      // "wgrad_lean" / VV_WGRAD_LEAN=0: k_wgrad_gemm_ph's lean instantiations (fewer instructions in the LOAD segments: scalar bases + 32-bit lane offsets, LDS addresses as immediates, a K loop without end-of-stream tests); only for tables below 4 GiB
   int gemm_variant = 5;    // (lab) VV_GEMM_VARIANT: 5 = the phase-staggered kernels; 0 = the round-1 kernels; 6 / 7 / 8 mixtures
   int ablate = 0;          // (lab) VV_ABLATE: ablated instantiations of the dense-size GEMMs (results wrong)
   int lab_fwd_abl = 0;     // (lab) VV_LAB_FWD_ABL: ablations of the 192-row forward kernel at the de-duplicated size (results wrong)
