@@ -710,6 +710,11 @@ __device__ __forceinline__ i16x4 ph_tr(const unsigned char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(p));
 }
 
+// (the same read at an LDS address held as a number: nothing for the compiler to add per use but the instruction's own offset field)
+__device__ __forceinline__ i16x4 ph_tr_at(unsigned lds_addr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(uintptr_t)lds_addr);
+}
+
 // UPD: one split of K (S == 1) and the solver's update applied to the tile where it stands (WgradUpd, vv_internal.h) instead of the slab store
 // S16 (WgradArgs::slab16): the tile leaves as f16 x one power of two per (split, tile); stores widened as in the forward kernel's O16 form
 // LEAN (round 6; WgradArgs::lean): the LOAD segment of a phase is bound by the NUMBER of instructions the loading wave gets through the
@@ -858,7 +863,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
     int idn0 = ids[BK + srow0], idn1 = ids[BK + srow1];      // ids of the next X issue: X_hi(1) in phase (0, 0)
     PW_ISSUE_X(idn0, idn1, false, 4)
     PW_ISSUE_Y(1, true, 6)
-    PH_WAIT(4);
+    if constexpr (LEAN) { PW_ISSUE_X(idn0, idn1, true, 7) }   // (the lean schedule: X_hi travels with the Y_hi in front of it, below)
+    if constexpr (LEAN) { PH_WAIT(6); } else { PH_WAIT(4); }
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();                // waves 4-7 run one segment behind
     if (wm == 1) __builtin_amdgcn_s_setprio(1);
@@ -925,25 +931,65 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
     if (!SF && (!(CHK) || (t) + 2 < nk) && !abl_st) PW_ISSUE_Y((t) + 2, true, 4 * (par) + 2)           \
     if ((!(CHK) || (t) + 2 < nk) && !abl_st) { PH_WAIT(4); } else PH_WAIT(0);                          \
     PW_MFMA(1, 0)
+    // The LEAN schedule.  The four LOAD segments of a K-tile are not equal: the first reads X_lo AND Y_lo (24 fragment reads), the second and
+    // the fourth one Y half (8).  A segment costs what its instruction count costs (~11 clocks each beside the partner's MFMAs), the MFMA
+    // segment beside it 256 clocks: the first segment is the long one.  So its stream step -- X_hi of the next K-tile -- moves into the
+    // fourth segment of the K-tile before, right behind Y_hi (the stream's order is unchanged; the slot, this parity's X_hi, was last read
+    // in the third segment; six half-tile instructions in flight across the counted wait instead of four), and the fragment addresses
+    // of the upper half of the ring (LDS offsets past the 16-bit immediate) are values of their own instead of copies made per iteration.
+#define PW_LOADL(dst, alo, ahi, cnt, slot)                                                             \
+    _Pragma("unroll") for (int x = 0; x < cnt; ++x) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) { \
+      const unsigned p_ = ((slot) < 4 ? alo[x] : ahi[x]) + ((slot) & 3) * PH_SLOT + kk * 8192;         \
+      const i16x4 lo = ph_tr_at(p_), hi = ph_tr_at(p_ + 1024);                                         \
+      dst[x][kk] = i16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                      \
+    }
+#define PW_TILEL(par, t, CHK)                                                                          \
+    PW_LOADL(xf, xa0, xa4, 4, 4 * (par) + 0) PW_LOADL(yf, ya0, ya4, 2, 4 * (par) + 1)                  \
+    PW_MFMA(0, 0)                                                                                      \
+    PW_LOADL(yf, ya0, ya4, 2, 4 * (par) + 2)                                                           \
+    if (!(CHK) || (t) + 1 < nk) PW_ISSUE_Y((t) + 1, false, 4 * (1 - (par)) + 1)                        \
+    if (!(CHK) || (t) + 2 < nk) { idn0 = ids[((t) + 2) * BK + srow0]; idn1 = ids[((t) + 2) * BK + srow1]; } \
+    PW_MFMA(0, 1)                                                                                      \
+    PW_LOADL(xf, xa0, xa4, 4, 4 * (par) + 3)                                                           \
+    if (!(CHK) || (t) + 2 < nk) PW_ISSUE_X(idn0, idn1, false, 4 * (par) + 0)                           \
+    PW_MFMA(1, 1)                                                                                      \
+    PW_LOADL(yf, ya0, ya4, 2, 4 * (par) + 1)                                                           \
+    if (!(CHK) || (t) + 2 < nk) { PW_ISSUE_Y((t) + 2, true, 4 * (par) + 2) PW_ISSUE_X(idn0, idn1, true, 4 * (par) + 3) PH_WAIT(6); } \
+    else PH_WAIT(0);                                                                                   \
+    PW_MFMA(1, 0)
     int t = 0;
     if constexpr (LEAN) {
+      const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(smem);
+      unsigned xa0[4], ya0[2], xa4[4], ya4[2];                // LDS addresses of the fragments in slots 0-3 / 4-7 (as numbers)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) { xa0[ni] = lds0 + xa[ni]; xa4[ni] = xa0[ni] + 4 * PH_SLOT; asm volatile("" : "+v"(xa0[ni]), "+v"(xa4[ni])); }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) { ya0[mi] = lds0 + ya[mi]; ya4[mi] = ya0[mi] + 4 * PH_SLOT; asm volatile("" : "+v"(ya0[mi]), "+v"(ya4[mi])); }
       // the body of the loop carries no end-of-stream tests: both of its K-tiles have two more behind them
       for (; t + 3 < nk; t += 2) {
-        PW_TILE(0, t, 0)
-        PW_TILE(1, t + 1, 0)
+        PW_TILEL(0, t, 0)
+        PW_TILEL(1, t + 1, 0)
       }
+      for (; t + 1 < nk; t += 2) {
+        PW_TILEL(0, t, 1)
+        PW_TILEL(1, t + 1, 1)
+      }
+      if (t < nk) { PW_TILEL(0, t, 1) }
+    } else {
+      for (; t + 1 < nk; t += 2) {
+        PW_TILE(0, t, 1)
+        PW_TILE(1, t + 1, 1)
+      }
+      if (t < nk) { PW_TILE(0, t, 1) }                        // (an odd count's last K-tile: t is even, its parity is 0)
     }
-    for (; t + 1 < nk; t += 2) {
-      PW_TILE(0, t, 1)
-      PW_TILE(1, t + 1, 1)
-    }
-    if (t < nk) { PW_TILE(0, t, 1) }                          // (an odd count's last K-tile: t is even, its parity is 0)
     if (wm == 0) __builtin_amdgcn_s_barrier();                // waves 0-3 catch the extra barrier of waves 4-7
     if (wm == 1) __builtin_amdgcn_s_setprio(0);
     if (WTSON) asm volatile("s_memtime s[80:81]\n\ts_waitcnt lgkmcnt(0)" ::: WTS_CLOB);      // s80: end of the K loop
 #undef PW_LOAD
 #undef PW_MFMA
 #undef PW_TILE
+#undef PW_TILEL
+#undef PW_LOADL
 #undef PW_ISSUE_X
 #undef PW_ISSUE_Y
   }
