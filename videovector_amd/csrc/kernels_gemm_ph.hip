@@ -812,14 +812,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
       // next load went out -- five to six serial L2 / HBM round trips in front of the first K-tile at the benchmark's split length)
       constexpr int NID = PH_WG_IDS / GEMM_THREADS;
       int32_t idv[NID];
+      int tid_c = tid;                                        // (opaque: hipcc otherwise computes the sixteen LDS addresses of this fill in front of
+      asm volatile("" : "+v"(tid_c));                         //  the chunk loop and carries -- or spills -- them through the K loop)
 #pragma unroll
       for (int j = 0; j < NID; ++j) {
-        const int i = tid + j * GEMM_THREADS;
+        const int i = tid_c + j * GEMM_THREADS;
         idv[j] = (i < live && !(ABL & 8)) ? a.rows[kg0 + i] : a.zero_row;
       }
 #pragma unroll
       for (int j = 0; j < NID; ++j) {
-        const int i = tid + j * GEMM_THREADS;
+        const int i = tid_c + j * GEMM_THREADS;
         if (i < nk_ids * BK) ids[i] = idv[j];
       }
     }
@@ -853,18 +855,31 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
       else { PH_GLDS_S(lds_w, yl0, yk_, (slot) * PH_SLOT - 256, 256); PH_GLDS_S(lds_w, yl1, yk_, (slot) * PH_SLOT + 8192 - 256, 256); } \
     } else issue_y(kt, hi, slot); }
     // prologue, in stream order: X_lo(0), Y_hi(0), X_hi(0), Y_lo(0), X_lo(1), Y_hi(1)
-    {
+    // (LEAN, whose stream runs Y_lo, X_lo, Y_hi, X_hi per K-tile: all eight half-tiles of K-tiles 0 and 1)
+    int idn0, idn1;
+    if constexpr (LEAN) {
+      const int i00 = ids[srow0], i01 = ids[srow1];
+      PW_ISSUE_Y(0, false, 1)
+      PW_ISSUE_X(i00, i01, false, 0)
+      PW_ISSUE_Y(0, true, 2)
+      PW_ISSUE_X(i00, i01, true, 3)
+      idn0 = ids[BK + srow0]; idn1 = ids[BK + srow1];
+      PW_ISSUE_Y(1, false, 5)
+      PW_ISSUE_X(idn0, idn1, false, 4)
+      PW_ISSUE_Y(1, true, 6)
+      PW_ISSUE_X(idn0, idn1, true, 7)
+      PH_WAIT(8);                                             // K-tile 0 has landed (the fourth-phase wait of a K-tile "-1")
+    } else {
       const int i00 = ids[srow0], i01 = ids[srow1];
       PW_ISSUE_X(i00, i01, false, 0)
       PW_ISSUE_Y(0, true, 2)
       PW_ISSUE_X(i00, i01, true, 3)
       PW_ISSUE_Y(0, false, 1)
+      idn0 = ids[BK + srow0]; idn1 = ids[BK + srow1];        // ids of the next X issue: X_hi(1) in phase (0, 0)
+      PW_ISSUE_X(idn0, idn1, false, 4)
+      PW_ISSUE_Y(1, true, 6)
+      PH_WAIT(4);
     }
-    int idn0 = ids[BK + srow0], idn1 = ids[BK + srow1];      // ids of the next X issue: X_hi(1) in phase (0, 0)
-    PW_ISSUE_X(idn0, idn1, false, 4)
-    PW_ISSUE_Y(1, true, 6)
-    if constexpr (LEAN) { PW_ISSUE_X(idn0, idn1, true, 7) }   // (the lean schedule: X_hi travels with the Y_hi in front of it, below)
-    if constexpr (LEAN) { PH_WAIT(6); } else { PH_WAIT(4); }
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();                // waves 4-7 run one segment behind
     if (wm == 1) __builtin_amdgcn_s_setprio(1);
@@ -885,18 +900,19 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
       const i16x4 lo = ph_tr(p_), hi = ph_tr(p_ + 1024);                                               \
       dst[x][kk] = i16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                      \
     }
-#define PW_MFMA(nh, mh)                                                                                \
+#define PW_MFMA(nh, mh) PW_MFMAY(nh, mh, yf)
+#define PW_MFMAY(nh, mh, YB)                                                                           \
     WTS("s[88:89]")            /* b: this wave's load segment is done (reads issued, stream issued, wait passed) */ \
     __builtin_amdgcn_s_barrier();                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
     WTS("s[90:91]")                                                                                    \
     if (M32T) {                /* (lab, ABL bit 12: TIMING ONLY -- the phase's 256 clocks of matrix pipe as 8 x 32x32x16 instead of 16 x 16x16x32, */ \
       _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)  /* the same fragment registers read; results wrong) */ \
-        acc32[nh][ni >> 1][mh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, xf[ni][kk]), __builtin_bit_cast(f16x8, yf[ni & 1][kk]), acc32[nh][ni >> 1][mh], 0, 0, 0); \
+        acc32[nh][ni >> 1][mh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, xf[ni][kk]), __builtin_bit_cast(f16x8, YB[ni & 1][kk]), acc32[nh][ni >> 1][mh], 0, 0, 0); \
     } else                                                                                             \
     if (!abl_mm) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)  \
       _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                 \
-        acc[nh][ni][mh][mi] = T::mfma(xf[ni][kk], yf[mi][kk], acc[nh][ni][mh][mi]);                    \
+        acc[nh][ni][mh][mi] = T::mfma(xf[ni][kk], YB[mi][kk], acc[nh][ni][mh][mi]);                    \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
     if (WTSON) {                                                                                       \
       asm volatile("s_waitcnt lgkmcnt(0)\n\t"                                                          \
@@ -931,32 +947,37 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
     if (!SF && (!(CHK) || (t) + 2 < nk) && !abl_st) PW_ISSUE_Y((t) + 2, true, 4 * (par) + 2)           \
     if ((!(CHK) || (t) + 2 < nk) && !abl_st) { PH_WAIT(4); } else PH_WAIT(0);                          \
     PW_MFMA(1, 0)
-    // The LEAN schedule.  The four LOAD segments of a K-tile are not equal: the first reads X_lo AND Y_lo (24 fragment reads), the second and
-    // the fourth one Y half (8).  A segment costs what its instruction count costs (~11 clocks each beside the partner's MFMAs), the MFMA
-    // segment beside it 256 clocks: the first segment is the long one.  So its stream step -- X_hi of the next K-tile -- moves into the
-    // fourth segment of the K-tile before, right behind Y_hi (the stream's order is unchanged; the slot, this parity's X_hi, was last read
-    // in the third segment; six half-tile instructions in flight across the counted wait instead of four), and the fragment addresses
-    // of the upper half of the ring (LDS offsets past the 16-bit immediate) are values of their own instead of copies made per iteration.
+    // The LEAN schedule.  A segment costs what its instruction count costs (~11 clocks each beside the partner's MFMAs), the MFMA segment
+    // beside it 256 clocks; the four LOAD segments of a K-tile were not equal: the first read X_lo AND Y_lo (24 fragment reads), the fourth
+    // read Y_lo a second time.  Now: (1) TWO Y fragment buffers whose roles alternate per K-tile -- Y_lo(t) stays in its registers from the
+    // first to the fourth phase (no second read), Y_hi(t) goes to the other buffer, and the fourth LOAD segment reads Y_lo(t + 1) into that
+    // one once Y_hi is spent: 16 / 8 / 16 / 8 reads, 48 per K-tile instead of 56; (2) the stream runs Y_lo, X_lo, Y_hi, X_hi per K-tile,
+    // every half-tile issued at least five phases before its first read (Y_lo(t + 2) in the second phase into the slot Y_lo(t) left in
+    // the phase before this K-tile began; X_hi with the Y_hi in front of it in the fourth); two counted waits per K-tile: behind the third
+    // LOAD segment all but the five youngest half-tiles (Y_lo(t + 1) has landed), behind the fourth all but the four youngest (X_lo, Y_hi,
+    // X_hi of K-tile t + 1); (3) the fragment addresses of the upper half of the ring (LDS offsets past the 16-bit immediate) are values
+    // of their own instead of copies made per iteration.
 #define PW_LOADL(dst, alo, ahi, cnt, slot)                                                             \
     _Pragma("unroll") for (int x = 0; x < cnt; ++x) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) { \
       const unsigned p_ = ((slot) < 4 ? alo[x] : ahi[x]) + ((slot) & 3) * PH_SLOT + kk * 8192;         \
       const i16x4 lo = ph_tr_at(p_), hi = ph_tr_at(p_ + 1024);                                         \
       dst[x][kk] = i16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                      \
     }
-#define PW_TILEL(par, t, CHK)                                                                          \
-    PW_LOADL(xf, xa0, xa4, 4, 4 * (par) + 0) PW_LOADL(yf, ya0, ya4, 2, 4 * (par) + 1)                  \
-    PW_MFMA(0, 0)                                                                                      \
-    PW_LOADL(yf, ya0, ya4, 2, 4 * (par) + 2)                                                           \
-    if (!(CHK) || (t) + 1 < nk) PW_ISSUE_Y((t) + 1, false, 4 * (1 - (par)) + 1)                        \
-    if (!(CHK) || (t) + 2 < nk) { idn0 = ids[((t) + 2) * BK + srow0]; idn1 = ids[((t) + 2) * BK + srow1]; } \
-    PW_MFMA(0, 1)                                                                                      \
+    /* YL: the buffer that holds Y_lo(t) (read by the K-tile before, or in front of the loop); YH: the other one */ \
+#define PW_TILEL(par, t, CHK, YL, YH)                                                                  \
+    PW_LOADL(xf, xa0, xa4, 4, 4 * (par) + 0)                                                           \
+    PW_MFMAY(0, 0, YL)                                                                                 \
+    PW_LOADL(YH, ya0, ya4, 2, 4 * (par) + 2)                                                           \
+    if (!(CHK) || (t) + 2 < nk) { PW_ISSUE_Y((t) + 2, false, 4 * (par) + 1)                            \
+      idn0 = ids[((t) + 2) * BK + srow0]; idn1 = ids[((t) + 2) * BK + srow1]; }                        \
+    PW_MFMAY(0, 1, YH)                                                                                 \
     PW_LOADL(xf, xa0, xa4, 4, 4 * (par) + 3)                                                           \
-    if (!(CHK) || (t) + 2 < nk) PW_ISSUE_X(idn0, idn1, false, 4 * (par) + 0)                           \
-    PW_MFMA(1, 1)                                                                                      \
-    PW_LOADL(yf, ya0, ya4, 2, 4 * (par) + 1)                                                           \
-    if (!(CHK) || (t) + 2 < nk) { PW_ISSUE_Y((t) + 2, true, 4 * (par) + 2) PW_ISSUE_X(idn0, idn1, true, 4 * (par) + 3) PH_WAIT(6); } \
+    if (!(CHK) || (t) + 2 < nk) { PW_ISSUE_X(idn0, idn1, false, 4 * (par) + 0) PH_WAIT(10); } else PH_WAIT(0); \
+    PW_MFMAY(1, 1, YH)                                                                                 \
+    if (!(CHK) || (t) + 1 < nk) { PW_LOADL(YH, ya0, ya4, 2, 4 * (1 - (par)) + 1) }                     \
+    if (!(CHK) || (t) + 2 < nk) { PW_ISSUE_Y((t) + 2, true, 4 * (par) + 2) PW_ISSUE_X(idn0, idn1, true, 4 * (par) + 3) PH_WAIT(8); } \
     else PH_WAIT(0);                                                                                   \
-    PW_MFMA(1, 0)
+    PW_MFMAY(1, 0, YL)
     int t = 0;
     if constexpr (LEAN) {
       const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(smem);
@@ -966,15 +987,17 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) { ya0[mi] = lds0 + ya[mi]; ya4[mi] = ya0[mi] + 4 * PH_SLOT; asm volatile("" : "+v"(ya0[mi]), "+v"(ya4[mi])); }
       // the body of the loop carries no end-of-stream tests: both of its K-tiles have two more behind them
+      i16x8 yg[2][2];                                         // the second Y buffer
+      PW_LOADL(yf, ya0, ya4, 2, 1)                            // Y_lo(0) (every wave: in front of the loop)
       for (; t + 3 < nk; t += 2) {
-        PW_TILEL(0, t, 0)
-        PW_TILEL(1, t + 1, 0)
+        PW_TILEL(0, t, 0, yf, yg)
+        PW_TILEL(1, t + 1, 0, yg, yf)
       }
       for (; t + 1 < nk; t += 2) {
-        PW_TILEL(0, t, 1)
-        PW_TILEL(1, t + 1, 1)
+        PW_TILEL(0, t, 1, yf, yg)
+        PW_TILEL(1, t + 1, 1, yg, yf)
       }
-      if (t < nk) { PW_TILEL(0, t, 1) }
+      if (t < nk) { PW_TILEL(0, t, 1, yf, yg) }
     } else {
       for (; t + 1 < nk; t += 2) {
         PW_TILE(0, t, 1)
@@ -987,6 +1010,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
     if (WTSON) asm volatile("s_memtime s[80:81]\n\ts_waitcnt lgkmcnt(0)" ::: WTS_CLOB);      // s80: end of the K loop
 #undef PW_LOAD
 #undef PW_MFMA
+#undef PW_MFMAY
 #undef PW_TILE
 #undef PW_TILEL
 #undef PW_LOADL
@@ -994,6 +1018,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
 #undef PW_ISSUE_Y
   }
 
+  // The epilogues' store addresses are functions of the lane (li, g) and of kernel constants: left to itself hipcc computes the sixteen
+  // of them IN FRONT of the K loop and carries them through it (32 registers; with the lean loop's second Y buffer: 19-26 spilled dwords
+  // per lane, 13 MB of scratch written before the loop and read after it -- the kernel ran 5 us LONGER).  li_e / g_e are the same two
+  // numbers behind an opaque barrier: what depends on them is computed here, behind the loop.
+  int li_e = li, g_e = g;
+  asm volatile("" : "+v"(li_e), "+v"(g_e));
   if constexpr (UPD) {
     // ---- the update on the tile (k_reduce_sgd's parameter workgroups, element for element: the same products, the same rule, the same
     // roundings -- parameters, history and half copy bit for bit those of the two-launch form, tests/test_gpu_fused_update.py)
@@ -1044,7 +1074,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
         for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni)
-            *(f32x4*)(tile + (wn * 32 + mi * 16 + li) * TSTR + nh * 128 + wm * 64 + ni * 16 + g * 4) = acc[nh][ni][mh][mi];
+            *(f32x4*)(tile + (wn * 32 + mi * 16 + li_e) * TSTR + nh * 128 + wm * 64 + ni * 16 + g_e * 4) = acc[nh][ni][mh][mi];
       __syncthreads();
       // (the sixteen row groups in an order that depends on the tile: with every workgroup of the chip walking rows 0-7, 8-15, ... of its
       // tile at the same moment the requests of a moment differ in few address bits above the row pitch, and where they fall in the memory
@@ -1141,7 +1171,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
     for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
-        const int m = m0 + mh * 128 + wn * 32 + mi * 16 + li;
+        const int m = m0 + mh * 128 + wn * 32 + mi * 16 + li_e;
 #pragma unroll
         for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
@@ -1157,7 +1187,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
             // (rows of 16 lanes, as k_fwd_gemm_ph's O16 epilogue: the lane of row g then holds columns (g & 1) 16 + (g >> 1) 8 .. + 7 of the 32-column pair)
             const auto s0 = __builtin_amdgcn_permlane16_swap(p[0][0], p[1][0], false, false);
             const auto s1 = __builtin_amdgcn_permlane16_swap(p[0][1], p[1][1], false, false);
-            const int n = n0 + nh * 128 + wm * 64 + pr * 32 + (g & 1) * 16 + (g >> 1) * 8;
+            const int n = n0 + nh * 128 + wm * 64 + pr * 32 + (g_e & 1) * 16 + (g_e >> 1) * 8;
             *(uint4*)(slab + (int64_t)m * a.Fp + n) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
           }
       }
@@ -1169,12 +1199,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
   for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-      const int m = m0 + mh * 128 + wn * 32 + mi * 16 + li;
+      const int m = m0 + mh * 128 + wn * 32 + mi * 16 + li_e;
 #pragma unroll
       for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
-          const int n = n0 + nh * 128 + wm * 64 + ni * 16 + g * 4;
+          const int n = n0 + nh * 128 + wm * 64 + ni * 16 + g_e * 4;
           const f32x4 v = acc[nh][ni][mh][mi];
           // (plain stores: as non-temporal ones the 67 MB go straight to HBM and the kernel takes 8 us longer, profiles/r03_step_ablations.txt 5d)
           if (!(ABL & 64) || v[0] == 12345.f) *(float4*)(slab + (int64_t)m * a.Fp + n) = make_float4(v[0], v[1], v[2], v[3]);   // (lab, ABL 64: no stores)
