@@ -58,3 +58,28 @@ def test_lean_update_in_the_epilogue_is_bit_identical(vv, prec):
     for k in ("W", "b", "hW", "hb"):
         assert np.array_equal(a[k], l[k]), k
     assert a["loss"] == l["loss"]
+
+
+def test_lean_offsets_above_2_gib_and_the_fallback_past_4_gib(vv):
+    """The lean form's lane offsets are UNSIGNED 32-bit byte offsets from the table's base: rows between 2 and 4 GiB into a 3.85 GB table
+    must come out as with 64-bit addresses; a table past 4 GiB takes the 64-bit instantiations by itself (the option stays on)."""
+    B, C, Nn, F, D = 64, 5, 20, 4096, 512
+    rng = np.random.default_rng(3)
+    from videovector_amd.synth import init_weights
+    W, b = init_weights(3, D, F, std=0.02)
+    res = {}
+    for n_rows, lo in ((470000, 300000), (560000, 300000)):      # 3.85 GB: lean; 4.59 GB: not lean
+        idx = rng.integers(lo, n_rows, size=(B, C + Nn)).astype(np.int32)
+        idx[:, 0] = n_rows - 1 - np.arange(B)                     # the very last rows of the table
+        for lean in (0, 1):
+            eng = vv.Engine(0, "f16")
+            eng.set_option("wgrad_lean", lean)
+            eng.table_synth(11, n_rows, F)
+            eng.params_set(W, b)
+            cfg = vv.StepConfig(B, C, Nn)
+            eng.forward_backward(cfg, idx)
+            res[(n_rows, lean)] = eng.grads() + (eng.loss(),)
+            eng.close()
+        a, l = res[(n_rows, 0)], res[(n_rows, 1)]
+        assert np.array_equal(a[0], l[0]) and np.array_equal(a[1], l[1]) and a[2] == l[2], n_rows
+        assert np.abs(a[0]).max() > 0 and np.isfinite(a[0]).all()
