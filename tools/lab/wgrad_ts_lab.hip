@@ -29,6 +29,14 @@ static void launch(const WgradArgs& a, hipStream_t s) {
   const dim3 grid((a.Dp / BM) * (a.Fp / BN) * a.S), block(GEMM_THREADS);
   hipLaunchKernelGGL((k_wgrad_gemm_ph<F16, ABL>), grid, block, PH_WG_LDS_BYTES, s, a);
 }
+// (round 6) the LEAN instantiations (fp32 slabs): k_wgrad_gemm_ph<F16, ABL, false, false, true>
+template <int ABL>
+static void launch_lean(const WgradArgs& a, hipStream_t s) {
+  static bool once = ((void)hipFuncSetAttribute((const void*)k_wgrad_gemm_ph<F16, ABL, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PH_WG_LDS_BYTES), true);
+  (void)once;
+  const dim3 grid((a.Dp / BM) * (a.Fp / BN) * a.S), block(GEMM_THREADS);
+  hipLaunchKernelGGL((k_wgrad_gemm_ph<F16, ABL, false, false, true>), grid, block, PH_WG_LDS_BYTES, s, a);
+}
 int main(int argc, char** argv) {
   const int U = argc > 1 ? atoi(argv[1]) : 20650;
   const int iters = argc > 2 ? atoi(argv[2]) : 40;
@@ -64,7 +72,17 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
   const int nwg = (Dp / BM) * (Fp / BN) * S;
   struct Var { const char* name; int kind; };
-  const Var vars[] = {{"wgrad", 0}, {"wgrad_ts", 1}, {"wgrad_ts_nostream", 2}, {"wgrad_ts_nomm", 3}, {"wgrad_ts_nostore", 4}, {"wgrad_ts_hot", 5}, {"wgrad_sf", 6}, {"wgrad_ts_sf", 7}};
+  const Var vars[] = {{"wgrad", 0}, {"wgrad_ts", 1}, {"wgrad_ts_nostream", 2}, {"wgrad_ts_nomm", 3}, {"wgrad_ts_nostore", 4}, {"wgrad_ts_hot", 5}, {"wgrad_sf", 6}, {"wgrad_ts_sf", 7},
+                      {"wgrad_lean", 8}, {"wgrad_lean_ts", 9}, {"wgrad_lean_ts_hot", 10}};
+  {   // the lean build against the 64-bit-address build, bit for bit
+    std::vector<float> s0((size_t)S * Dp * Fp), s1(s0.size());
+    WgradArgs a = base; a.rows = rows;
+    launch<0>(a, st); CHK(hipStreamSynchronize(st)); CHK(hipMemcpy(s0.data(), slabs, s0.size() * 4, hipMemcpyDeviceToHost));
+    CHK(hipMemsetAsync(slabs, 0xff, s0.size() * 4, st));
+    launch_lean<0>(a, st); CHK(hipStreamSynchronize(st)); CHK(hipMemcpy(s1.data(), slabs, s1.size() * 4, hipMemcpyDeviceToHost));
+    long bad = 0; for (size_t i = 0; i < s0.size(); ++i) bad += memcmp(&s0[i], &s1[i], 4) != 0;
+    printf("check wgrad_lean: %ld of %zu slab values differ\n", bad, s0.size());
+  }
   {   // the stream-first build against the product build, bit for bit (slab 0 .. S-1)
     std::vector<float> s0((size_t)S * Dp * Fp), s1(s0.size());
     WgradArgs a = base; a.rows = rows;
@@ -88,6 +106,9 @@ int main(int argc, char** argv) {
           case 5: launch<512 + 8>(a, st); break;
           case 6: launch<1024>(a, st); break;                 // r05: the phase's LDS-DMA in front of its fragment reads
           case 7: launch<1024 + 512>(a, st); break;
+          case 8: launch_lean<0>(a, st); break;               // r06: the lean instantiation
+          case 9: launch_lean<512>(a, st); break;
+          case 10: launch_lean<512 + 8>(a, st); break;
         }
       };
       for (int i = 0; i < 5; ++i) run();
@@ -96,7 +117,7 @@ int main(int argc, char** argv) {
       CHK(hipEventRecord(e1, st)); CHK(hipEventSynchronize(e1));
       float ms = 0; CHK(hipEventElapsedTime(&ms, e0, e1));
       printf("round %d  %-18s %8.2f us\n", r, v.name, ms * 1000.f / iters);
-      if (v.kind >= 1 && v.kind != 6) {
+      if (v.kind >= 1 && v.kind != 6 && v.kind != 8) {
         std::vector<uint32_t> hb((size_t)nwg * 8 * 12);
         CHK(hipMemcpy(hb.data(), slabs + (int64_t)S * Dp * Fp, hb.size() * 4, hipMemcpyDeviceToHost));
         for (int grp = 0; grp < 2; ++grp) {
