@@ -723,7 +723,9 @@ __device__ __forceinline__ i16x4 ph_tr_at(unsigned lds_addr) {
 // reads and the same stream with fewer instructions around them: sources as scalar base + 32-bit lane offset (one v_mad_u32_u24 per
 // gathered row instead of a 64-bit multiply and a 64-bit add; nothing per dY row), LDS addresses as scalar base + immediate into M0 (one
 // instruction instead of a null-checked address-space cast), and a K loop whose body carries no end-of-stream tests (the last K-tiles
-// run a checked copy).  Needs a table below 4 GiB and row ids below 2^24 (the host decides); bit-identical results.
+// run a checked copy) -- and FEWER reads: two Y fragment buffers of alternating roles, Y_lo read once per K-tile (the schedule: below, at
+// PW_TILEL).  80 instructions per K-tile; stamps (profiles/r06_wgrad_stamps.txt): LOAD 352 -> 247 clocks per phase, below the MFMA
+// segment's 290.  Needs a table below 4 GiB and row ids below 2^24 (the host decides); bit-identical results.
 template <typename T, int ABL = 0, bool UPD = false, bool S16 = false, bool LEAN = false>
 __global__ __launch_bounds__(GEMM_THREADS) void k_wgrad_gemm_ph(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
