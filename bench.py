@@ -190,6 +190,8 @@ def live_traffic(cfg_argv, first_timeout_s=300.0, timeout_s=150.0):
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
         return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process runs under a profiler itself: no nested passes"
     tmp = tempfile.mkdtemp(prefix="vv_bench_pmc_", dir="/tmp")
     t0 = time.perf_counter()
     try:
